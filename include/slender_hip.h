@@ -1,0 +1,149 @@
+/*
+ * slender_hip.h — C ABI of libslender_hip.so, the MI355X (gfx950) kernels of the SlenderObjDet training hot path.
+ *
+ * Conventions (every entry point):
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless a parameter says "host";
+ *   - the caller owns every buffer (outputs, workspaces); nothing is allocated inside;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the call returns without synchronising;
+ *   - return value: 0 = ok, SOD_EARG (-1) bad argument / unsupported shape, SOD_ESIZE (-2) tensor exceeds the
+ *     32-bit buffer addressing range (2 GiB per operand), >0 = hipError_t of a failed launch;
+ *   - no global mutable state besides one-time kernel attribute set-up; re-entrant per stream.
+ *
+ * Each declaration cites the reference interface it replaces (paths under wanzysky/SlenderObjDet; "d2" =
+ * detectron2 @ 8bc84a2ff8a0b5787ec and "fvcore" are the un-vendored third-party packages the reference calls,
+ * see SURVEY.md §0 / §2.3).
+ */
+#ifndef SLENDER_HIP_H_
+#define SLENDER_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOD_MAX_LEVELS 8
+
+/* conv flags */
+#define SOD_CONV_RELU 1     /* y = max(y, 0) after bias/residual */
+#define SOD_CONV_RES_UP2 2  /* residual is half resolution and nearest-2x upsampled (FPN top-down path) */
+
+/* iou_loss types — slender_det/layers/iou_loss.py:25-32 */
+#define SOD_IOU_LOSS_IOU 0
+#define SOD_IOU_LOSS_LINEAR 1
+#define SOD_IOU_LOSS_GIOU 2
+
+const char* sod_version(void);
+/* bytes of the scratch buffer `ws` the reduction-type entry points need */
+long long sod_reduce_workspace_bytes(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Convolution, NHWC bf16, weights [K][R][S][C] bf16, fp32 accumulation on MFMA.
+ * Replaces ATen conv2d forward/backward under d2 ResNet/FPN (slender_det/modeling/backbone/fpn.py:94-115)
+ * and FCOSHead (slender_det/modeling/meta_arch/fcos/fcosv2.py:277-381).
+ *   y[n,ho,wo,k] = act( sum_{r,s,c} x[n,ho*stride-pad+r*dil, wo*stride-pad+s*dil, c] * w[k,r,s,c] + bias[k] + res )
+ * C must be a multiple of 8. *_img_stride = elements between consecutive images (<=0: dense), which lets the
+ * per-level head outputs land directly in the concatenated (N, sum(Hi*Wi), K) buffer the losses read
+ * (replaces permute_and_concat, slender_det/modeling/meta_arch/fcos/utils.py:32-52).
+ * out_f32: write fp32 instead of bf16.
+ * --------------------------------------------------------------------------------------------------------- */
+int sod_conv2d_fwd(const void* x, const void* w, const float* bias, const void* res, void* y,
+                   int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                   long long x_img_stride, long long y_img_stride, long long res_img_stride,
+                   int flags, int out_f32, void* stream);
+/* dx[n,h,w,c] = sum dy * w  (+ accum) masked by relu_mask>0.  wt is the transposed copy [C][R][S][K] bf16.
+ * K (channels of dy) must be a multiple of 8 (pad the gradient rows). */
+int sod_conv2d_dgrad(const void* dy, const void* wt, const void* accum, const void* relu_mask, void* dx,
+                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                     long long dy_img_stride, long long dx_img_stride, void* stream);
+/* dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,hi,wi,c]   (fp32, atomically accumulated: zero it once per step) */
+int sod_conv2d_wgrad(const void* dy, const void* x, float* dw,
+                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                     long long dy_img_stride, long long x_img_stride, int splits, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * GroupNorm (+ fused ReLU), NHWC bf16 — nn.GroupNorm(32, C) + nn.ReLU in FCOSHead (fcosv2.py:315-336).
+ * mean_rstd: [N][G][2] fp32 (saved for backward). C/G must be a multiple of 8.
+ * --------------------------------------------------------------------------------------------------------- */
+int sod_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd,
+                      int N, int HW, int C, int G, long long img_stride, float eps, int relu, void* stream);
+int sod_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean_rstd,
+                      void* dx, float* dgamma, float* dbeta, float* red_ws /* 2*N*G floats */,
+                      int N, int HW, int C, int G, long long img_stride, int relu, void* stream);
+
+/* elementwise helpers on bf16 tensors of n elements (n % 8 == 0) */
+int sod_relu_fwd(const void* x, void* y, long long n, void* stream);
+int sod_relu_bwd(const void* dy, const void* y, void* dx, long long n, void* stream);
+int sod_add_bf16(const void* a, const void* b, void* out, long long n, void* stream);
+/* dbias[c] += sum over (n, pixel) of dy — bias gradient of nn.Conv2d(bias=True) */
+int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C, long long img_stride, void* stream);
+/* d2 BasicStem: F.max_pool2d(x, kernel_size=3, stride=2, padding=1) */
+int sod_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, void* stream);
+/* backward of F.interpolate(scale_factor=2, mode="nearest") in d2 FPN */
+int sod_upsample2x_bwd(const void* g, void* dprev, int N, int Hc, int Wc, int C, void* stream);
+
+/* fp32 master weights [K][RS][C] -> bf16 [K][RS][Cpad] (times scale[k]: folded d2 FrozenBatchNorm2d) and the
+ * transposed bf16 [C][RS][K] copy for dgrad */
+int sod_weight_prep(const float* w, const float* scale, void* w_krsc, void* w_crsk, int K, int RS, int C, int Cpad, void* stream);
+int sod_scale_rows(float* g, const float* scale, int K, long long row, void* stream);
+
+/* torch.optim.SGD(momentum, nesterov, weight_decay) over the flat arena (slender_det/solver/build.py:21-25).
+ * segments_dev: device array of {long long begin, end; float lr_mult, wd}. */
+int sod_sgd_step(float* params, const float* grads, float* momentum_buf, const void* segments_dev, int nseg,
+                 const float* lr_dev, float lr, float momentum, int nesterov, int first_step, float grad_scale, void* stream);
+
+/* FCOSV2.preprocess_image (fcosv2.py:268-275) + ImageList.from_tensors: (x-mean)/std, zero pad, CHW -> NHWC(8) bf16.
+ * mean3/std3 are HOST pointers. */
+int sod_preprocess_image(const void* img, int is_uint8, int C, int H, int W, void* out, int Hp, int Wp, int Cpad,
+                         const float* mean3, const float* std3, void* stream);
+int sod_nchw_f32_to_nhwc_bf16(const float* x, void* y, int N, int C, int HW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Losses and targets (fp32)
+ * --------------------------------------------------------------------------------------------------------- */
+/* fvcore.nn.sigmoid_focal_loss_jit(inputs, targets, alpha, gamma, reduction) — call site fcosv2.py:124.
+ * Targets are either class indices `labels[M]` (value k in [0,K) marks column k; anything else = background) or a
+ * dense one-hot/soft `dense_targets[M,K]`. logits rows have pitch `ld`. elem_out (optional) [M,K] = reduction "none". */
+int sod_sigmoid_focal_loss_fwd(const float* logits, const int* labels, const float* dense_targets,
+                               long long M, int K, int ld, float alpha, float gamma, float* elem_out,
+                               float* sum_out, float* ws, void* stream);
+/* dlogits = dloss/dlogits * scale_num[0] / max(scale_den[0]*den_mul, den_min); rows of pitch ld_out, columns >= K zeroed */
+int sod_sigmoid_focal_loss_bwd(const float* logits, const int* labels, const float* dense_targets,
+                               long long M, int K, int ld, float alpha, float gamma,
+                               const float* scale_num, const float* scale_den, float den_mul, float den_min,
+                               void* dlogits, int ld_out, int out_bf16, void* stream);
+/* slender_det.layers.iou_loss(pred, target, weight, loss_type) — layers/iou_loss.py:4-37. pred/target [P,4] LTRB.
+ * mask (optional): rows with mask<0 or mask==mask_bg contribute 0. */
+int sod_iou_loss_fwd(const float* pred, const float* target, const float* weight, const int* mask, int mask_bg,
+                     long long P, int loss_type, float* elem_out, float* sum_out, float* ws, void* stream);
+int sod_iou_loss_bwd(const float* pred, const float* target, const float* weight, const int* mask, int mask_bg,
+                     long long P, int loss_type, const float* grad_scale, float* dpred, void* stream);
+/* compute_targets_for_locations + get_sample_region + compute_centerness_targets
+ * (slender_det/modeling/meta_arch/fcos/utils.py:108-212, 295-300) for a whole batch in one launch.
+ * boxes [sumG,4] XYXY, classes [sumG], box_offsets [N+1] (device); level tables are HOST arrays.
+ * Outputs: labels [N,L] (background = num_classes), reg_targets [N,L,4], ctr_targets [N,L] (0 on background),
+ * stats[2] = {number of positives, sum of centerness targets} over the batch. */
+int sod_fcos_assign(const float* boxes, const int* classes, const int* box_offsets, int N,
+                    int nlevels, const int* lvl_h, const int* lvl_w, const int* lvl_stride,
+                    const float* lvl_lo, const float* lvl_hi, float radius, int num_classes,
+                    int* labels, float* reg_targets, float* ctr_targets, float* stats, float* ws, void* stream);
+/* FCOSV2.losses, regression + centerness part (fcosv2.py:128-145) fused with Scale/exp of FCOSHead.forward
+ * (fcosv2.py:372-378): sums[0] = sum_pos iou_loss(pred, tgt)*ctr, sums[1] = sum_pos BCEWithLogits(ctr_logit, ctr). */
+int sod_fcos_regctr_loss_fwd(const float* box_raw, int ld_box, const float* ctr_logit, int ld_ctr,
+                             const int* labels, const float* reg_targets, const float* ctr_targets,
+                             const float* scales, int N, int nlevels, const int* lvl_h, const int* lvl_w,
+                             const int* lvl_stride, int num_classes, int loss_type, int norm_reg_targets,
+                             float* sums, float* ws, void* stream);
+int sod_fcos_regctr_loss_bwd(const float* box_raw, int ld_box, const float* ctr_logit, int ld_ctr,
+                             const int* labels, const float* reg_targets, const float* ctr_targets,
+                             const float* scales, int N, int nlevels, const int* lvl_h, const int* lvl_w,
+                             const int* lvl_stride, int num_classes, int loss_type, int norm_reg_targets,
+                             const float* grad_reg, const float* grad_ctr, const float* norm, float inv_world,
+                             void* dbox, int ld_out, int ctr_col, void* dctr, int ld_dctr, int dctr_col,
+                             float* dscales, float* ws, void* stream);
+/* out3 = {cls_loss, reg_loss, centerness_loss} with the all-reduced normalisers (fcosv2.py:115-145) */
+int sod_fcos_finalize_losses(const float* focal_sum, const float* regctr_sums, const float* stats,
+                             float inv_world, float* out3, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLENDER_HIP_H_ */

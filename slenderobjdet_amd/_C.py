@@ -1,0 +1,106 @@
+"""ctypes binding of ``libslender_hip.so`` (the C-ABI HIP library declared in ``include/slender_hip.h``).
+
+Plays the role ``slender_det._C`` (pybind module built by the reference's ``setup.py:41-86`` from
+``slender_det/layers/csrc/vision.cpp:64-80``) plays in the reference: the single native entry point of the
+Python host.  There is deliberately NO fallback: if the library is missing or a call fails, we raise.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslender_hip.so")
+
+_lib = None
+
+_P = c_void_p
+_I = c_int
+_L = c_longlong
+_F = c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/slender_hip.h
+_SIGS = {
+    "sod_conv2d_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _I, _P],
+    "sod_conv2d_dgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _P],
+    "sod_conv2d_wgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _P],
+    "sod_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _F, _I, _P],
+    "sod_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
+    "sod_relu_fwd": [_P, _P, _L, _P],
+    "sod_relu_bwd": [_P, _P, _P, _L, _P],
+    "sod_add_bf16": [_P, _P, _P, _L, _P],
+    "sod_bias_grad": [_P, _P, _I, _I, _I, _L, _P],
+    "sod_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
+    "sod_upsample2x_bwd": [_P, _P, _I, _I, _I, _I, _P],
+    "sod_weight_prep": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sod_scale_rows": [_P, _P, _I, _L, _P],
+    "sod_sgd_step": [_P, _P, _P, _P, _I, _P, _F, _F, _I, _I, _F, _P],
+    "sod_preprocess_image": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P],
+    "sod_nchw_f32_to_nhwc_bf16": [_P, _P, _I, _I, _I, _P],
+    "sod_sigmoid_focal_loss_fwd": [_P, _P, _P, _L, _I, _I, _F, _F, _P, _P, _P, _P],
+    "sod_sigmoid_focal_loss_bwd": [_P, _P, _P, _L, _I, _I, _F, _F, _P, _P, _F, _F, _P, _I, _I, _P],
+    "sod_iou_loss_fwd": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P],
+    "sod_iou_loss_bwd": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P],
+    "sod_fcos_assign": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P],
+    "sod_fcos_regctr_loss_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "sod_fcos_regctr_loss_bwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F,
+                                 _P, _I, _I, _P, _I, _I, _P, _P, _P],
+    "sod_fcos_finalize_losses": [_P, _P, _P, _F, _P, _P],
+    "sod_reduce_workspace_bytes": [],
+    "sod_version": [],
+}
+_RESTYPES = {"sod_reduce_workspace_bytes": c_longlong, "sod_version": c_char_p}
+
+
+class SlenderHipError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names include/slender_hip.h declares (used by the CPU-side symbol test)."""
+    return sorted(_SIGS)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlenderHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C slenderobjdet_amd/csrc). There is no CPU fallback for the HIP ops."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+_ERRS = {-1: "SOD_EARG (bad argument / unsupported shape)", -2: "SOD_ESIZE (operand exceeds 2 GiB)", -3: "SOD_EALIGN"}
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status (mirrors AT_ASSERTM/THCudaCheck ->
+    RuntimeError in the reference's extension, BorderAlign_cuda.cu:155-165,202)."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise SlenderHipError(f"{name} failed: {_ERRS.get(rc, 'hipError_t %d' % rc)}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def reduce_workspace_floats():
+    return int(load().sod_reduce_workspace_bytes()) // 4

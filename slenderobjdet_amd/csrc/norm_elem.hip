@@ -1,0 +1,520 @@
+// HBM-bound NHWC bf16 kernels around the convolutions: GroupNorm(+ReLU) fwd/bwd, ReLU backward mask,
+// bias gradient, max-pool, nearest-2x upsample backward, weight preparation (FrozenBN folding + transposed copy),
+// fused SGD over the flat parameter arena, image normalisation / batching.
+//
+// Reference call sites: nn.GroupNorm(32,C)+ReLU in FCOSHead (fcosv2.py:315-336), detectron2 FrozenBatchNorm2d /
+// BasicStem max_pool2d / FPN top-down path, torch.optim.SGD built by
+// slender_det/solver/build.py:8-33, preprocess_image (fcosv2.py:268-275).
+#include "common.h"
+#include "../../include/slender_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------ GroupNorm
+// x: (N, HW, C) bf16; thread owns one 8-channel vector column (c8) and strides over pixels.
+struct GnArgs {
+  const __bf16* x; const __bf16* dy; const float* gamma; const float* beta;
+  __bf16* y; __bf16* dx; float* stats;      // stats[N][G][2] : (sum,sumsq) then (mean,rstd)
+  float* red;                               // bwd: red[N][G][2] = (sum dy*g, sum dy*g*xhat)
+  float* dgamma; float* dbeta;
+  int N, HW, C, G, cpg, relu;
+  long long img_stride;                     // elements between images
+  float eps;
+  int pix_per_block;
+};
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
+  extern __shared__ float lsum[];   // [G][2]
+  const int n = blockIdx.y;
+  const int c8n = a.C >> 3;                 // vectors per pixel
+  for (int i = threadIdx.x; i < a.G * 2; i += 256) lsum[i] = 0.f;
+  __syncthreads();
+  const int rows_per_iter = 256 / c8n;      // host guarantees c8n divides 256
+  const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
+  const int p0 = blockIdx.x * a.pix_per_block;
+  int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
+  float s = 0.f, ss = 0.f;
+  const __bf16* base = a.x + (long long)n * a.img_stride + c8 * 8;
+  for (int p = p0 + prow; p < p1; p += rows_per_iter) {
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(base + (long long)p * a.C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s += f; ss += f * f; }
+  }
+  const int g = (c8 * 8) / a.cpg;
+  atomicAdd(&lsum[g * 2], s);
+  atomicAdd(&lsum[g * 2 + 1], ss);
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.G * 2; i += 256) atomicAdd(a.stats + (long long)n * a.G * 2 + i, lsum[i]);
+}
+
+__global__ void gn_finalize_stats_kernel(float* stats, int NG, float inv_m, float eps) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < NG) {
+    const float mean = stats[i * 2] * inv_m;
+    float var = stats[i * 2 + 1] * inv_m - mean * mean;
+    var = fmaxf(var, 0.f);
+    stats[i * 2] = mean;
+    stats[i * 2 + 1] = rsqrtf(var + eps);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
+  const int n = blockIdx.y;
+  const int c8n = a.C >> 3;
+  const int rows_per_iter = 256 / c8n;
+  const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
+  const int g = (c8 * 8) / a.cpg;
+  const float mean = a.stats[((long long)n * a.G + g) * 2], rstd = a.stats[((long long)n * a.G + g) * 2 + 1];
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float gm = a.gamma[c8 * 8 + e], bt = a.beta[c8 * 8 + e];
+    sc[e] = rstd * gm; sh[e] = bt - mean * rstd * gm;
+  }
+  const int p0 = blockIdx.x * a.pix_per_block;
+  int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
+  const long long base = (long long)n * a.img_stride + c8 * 8;
+  for (int p = p0 + prow; p < p1; p += rows_per_iter) {
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)p * a.C);
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = (float)v[e] * sc[e] + sh[e];
+      if (a.relu) f = fmaxf(f, 0.f);
+      o[e] = (__bf16)f;
+    }
+    *reinterpret_cast<bf16x8_t*>(a.y + base + (long long)p * a.C) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnArgs a) {
+  extern __shared__ float lsum[];   // [G][2]
+  const int n = blockIdx.y;
+  const int c8n = a.C >> 3;
+  for (int i = threadIdx.x; i < a.G * 2; i += 256) lsum[i] = 0.f;
+  __syncthreads();
+  const int rows_per_iter = 256 / c8n;
+  const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
+  const int g = (c8 * 8) / a.cpg;
+  const float mean = a.stats[((long long)n * a.G + g) * 2], rstd = a.stats[((long long)n * a.G + g) * 2 + 1];
+  float gm[8], bt[8], dg[8], db[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { gm[e] = a.gamma[c8 * 8 + e]; bt[e] = a.beta[c8 * 8 + e]; dg[e] = 0.f; db[e] = 0.f; }
+  float s1 = 0.f, s2 = 0.f;
+  const int p0 = blockIdx.x * a.pix_per_block;
+  int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
+  const long long base = (long long)n * a.img_stride + c8 * 8;
+  for (int p = p0 + prow; p < p1; p += rows_per_iter) {
+    const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)p * a.C);
+    const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)p * a.C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = ((float)xv[e] - mean) * rstd;
+      float d = (float)gv[e];
+      if (a.relu && !(xh * gm[e] + bt[e] > 0.f)) d = 0.f;
+      dg[e] += d * xh; db[e] += d;
+      s1 += d * gm[e]; s2 += d * gm[e] * xh;
+    }
+  }
+  atomicAdd(&lsum[g * 2], s1);
+  atomicAdd(&lsum[g * 2 + 1], s2);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {   // per-channel parameter gradients (fp32 accumulation in the grad arena)
+    atomicAdd(a.dgamma + c8 * 8 + e, dg[e]);
+    atomicAdd(a.dbeta + c8 * 8 + e, db[e]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.G * 2; i += 256) atomicAdd(a.red + (long long)n * a.G * 2 + i, lsum[i]);
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a, float inv_m) {
+  const int n = blockIdx.y;
+  const int c8n = a.C >> 3;
+  const int rows_per_iter = 256 / c8n;
+  const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
+  const int g = (c8 * 8) / a.cpg;
+  const float mean = a.stats[((long long)n * a.G + g) * 2], rstd = a.stats[((long long)n * a.G + g) * 2 + 1];
+  const float m1 = a.red[((long long)n * a.G + g) * 2] * inv_m, m2 = a.red[((long long)n * a.G + g) * 2 + 1] * inv_m;
+  float gm[8], bt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { gm[e] = a.gamma[c8 * 8 + e]; bt[e] = a.beta[c8 * 8 + e]; }
+  const int p0 = blockIdx.x * a.pix_per_block;
+  int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
+  const long long base = (long long)n * a.img_stride + c8 * 8;
+  for (int p = p0 + prow; p < p1; p += rows_per_iter) {
+    const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)p * a.C);
+    const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)p * a.C);
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = ((float)xv[e] - mean) * rstd;
+      float d = (float)gv[e];
+      if (a.relu && !(xh * gm[e] + bt[e] > 0.f)) d = 0.f;
+      o[e] = (__bf16)(rstd * (d * gm[e] - m1 - xh * m2));
+    }
+    *reinterpret_cast<bf16x8_t*>(a.dx + base + (long long)p * a.C) = o;
+  }
+}
+
+// ------------------------------------------------------------------ elementwise (8 x bf16 per lane)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ y,
+                                                       __bf16* __restrict__ dx, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const bf16x8_t g = reinterpret_cast<const bf16x8_t*>(dy)[i];
+    const bf16x8_t v = reinterpret_cast<const bf16x8_t*>(y)[i];
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ((float)v[e] > 0.f) ? g[e] : (__bf16)0.f;
+    reinterpret_cast<bf16x8_t*>(dx)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void relu_fwd_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const bf16x8_t v = reinterpret_cast<const bf16x8_t*>(x)[i];
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = ((float)v[e] > 0.f) ? v[e] : (__bf16)0.f;
+    reinterpret_cast<bf16x8_t*>(y)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b,
+                                                  __bf16* __restrict__ o, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const bf16x8_t x = reinterpret_cast<const bf16x8_t*>(a)[i];
+    const bf16x8_t y = reinterpret_cast<const bf16x8_t*>(b)[i];
+    bf16x8_t r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (__bf16)((float)x[e] + (float)y[e]);
+    reinterpret_cast<bf16x8_t*>(o)[i] = r;
+  }
+}
+
+// bias gradient: db[c] += sum over rows of dy[row][c]; dy rows may be strided per image
+__global__ __launch_bounds__(256) void channel_sum_kernel(const __bf16* __restrict__ dy, float* __restrict__ db,
+                                                          int HW, int C, long long img_stride, int pix_per_block) {
+  extern __shared__ float lsum[];   // [C]
+  const int n = blockIdx.y;
+  const int c8n = C >> 3;
+  for (int i = threadIdx.x; i < C; i += 256) lsum[i] = 0.f;
+  __syncthreads();
+  const int rows_per_iter = 256 / c8n;
+  const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int p0 = blockIdx.x * pix_per_block;
+  int p1 = p0 + pix_per_block; if (p1 > HW) p1 = HW;
+  if (threadIdx.x < rows_per_iter * c8n) {
+    const long long base = (long long)n * img_stride + c8 * 8;
+    for (int p = p0 + prow; p < p1; p += rows_per_iter) {
+      const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(dy + base + (long long)p * C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&lsum[c8 * 8 + e], s[e]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) atomicAdd(db + i, lsum[i]);
+}
+
+// 3x3 stride-2 pad-1 max pool, NHWC bf16 (detectron2 BasicStem)
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y,
+                                                           int N, int H, int W, int C, int Ho, int Wo) {
+  const int c8n = C >> 3;
+  const long long total = (long long)N * Ho * Wo * c8n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c8 = (int)(i % c8n);
+    long long r = i / c8n;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
+    for (int dh = 0; dh < 3; ++dh) {
+      const int h = ho * 2 - 1 + dh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int w = wo * 2 - 1 + dw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(x + (((long long)n * H + h) * W + w) * C + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+      }
+    }
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)m[e];
+    *reinterpret_cast<bf16x8_t*>(y + i * 8) = o;
+  }
+}
+
+// backward of nearest-2x upsample: dprev[n,h,w,:] = sum of the 2x2 block of g
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const __bf16* __restrict__ g, __bf16* __restrict__ d,
+                                                             int N, int Hc, int Wc, int C) {
+  const int c8n = C >> 3;
+  const long long total = (long long)N * Hc * Wc * c8n;
+  const int Wf = Wc * 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c8 = (int)(i % c8n);
+    long long r = i / c8n;
+    const int w = (int)(r % Wc); r /= Wc;
+    const int h = (int)(r % Hc);
+    const int n = (int)(r / Hc);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw) {
+        const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(g + (((long long)n * Hc * 2 + h * 2 + dh) * Wf + w * 2 + dw) * C + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+      }
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)s[e];
+    *reinterpret_cast<bf16x8_t*>(d + i * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------ weights
+// master fp32 KRSC -> bf16 KRSC (scaled per output channel) and bf16 CRSK (for dgrad)
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                          __bf16* __restrict__ w_krsc, __bf16* __restrict__ w_crsk,
+                                                          int K, int RS, int C, int Cpad /* fwd row pitch in channels */) {
+  const long long total = (long long)K * RS * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long long r = i / C;
+    const int t = (int)(r % RS);
+    const int k = (int)(r / RS);
+    float v = w[i];
+    if (scale) v *= scale[k];
+    const __bf16 b = (__bf16)v;
+    if (w_krsc) w_krsc[((long long)k * RS + t) * Cpad + c] = b;
+    if (w_crsk) w_crsk[((long long)c * RS + t) * K + k] = b;
+  }
+}
+
+// per-output-channel scaling of a weight gradient (chain rule through the folded FrozenBN scale)
+__global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ g, const float* __restrict__ scale, int K, long long row) {
+  const long long total = (long long)K * row;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) g[i] *= scale[i / row];
+}
+
+// ------------------------------------------------------------------ fused SGD over the flat arena
+// torch.optim.SGD semantics: d = g + wd*p ; buf = mom*buf + d (buf = d on the first step) ; p -= lr*d'
+struct SgdSeg { long long begin, end; float lr_mult, wd; };
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  const SgdSeg* __restrict__ segs, int nseg, const float* __restrict__ lr_dev,
+                                                  float lr_host, float momentum, int nesterov, int first_step, float grad_scale) {
+  const float base_lr = lr_dev ? lr_dev[0] : lr_host;
+  const SgdSeg sg = segs[blockIdx.y];
+  for (long long i = sg.begin + (long long)blockIdx.x * 256 + threadIdx.x; i < sg.end; i += (long long)gridDim.x * 256) {
+    float d = g[i] * grad_scale + sg.wd * p[i];
+    if (momentum != 0.f) {
+      const float b = first_step ? d : momentum * m[i] + d;
+      m[i] = b;
+      d = nesterov ? d + momentum * b : b;
+    }
+    p[i] -= base_lr * sg.lr_mult * d;
+  }
+}
+
+// ------------------------------------------------------------------ image batching
+// uint8/float CHW image -> (x - mean)/std -> NHWC bf16 with Cpad channels, zero padded to (Hp, Wp)
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_kernel(const T* __restrict__ img, int C, int H, int W,
+                                                         __bf16* __restrict__ out, int Hp, int Wp, int Cpad,
+                                                         float m0, float m1, float m2, float s0, float s1, float s2) {
+  const long long total = (long long)Hp * Wp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int w = (int)(i % Wp), h = (int)(i / Wp);
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)0.f;
+    if (h < H && w < W) {
+      const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+      for (int c = 0; c < C && c < 3; ++c) o[c] = (__bf16)(((float)img[((long long)c * H + h) * W + w] - mean[c]) / stdv[c]);
+    }
+    *reinterpret_cast<bf16x8_t*>(out + i * Cpad) = o;   // Cpad == 8
+  }
+}
+
+// NHWC bf16 <-> NCHW f32 layout conversion (API boundary only)
+__global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y,
+                                                                    int N, int C, int HW) {
+  const long long total = (long long)N * C * HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long long r = i / C;
+    const int p = (int)(r % HW);
+    const int n = (int)(r / HW);
+    y[i] = (__bf16)x[((long long)n * C + c) * HW + p];
+  }
+}
+
+inline int blocks_for(long long n, int cap = 4096) {
+  long long g = (n + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int gn_check(int N, int HW, int C, int G) {
+  if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G) return SOD_EARG;
+  const int cpg = C / G;
+  if (cpg % 8) return SOD_EARG;
+  const int c8n = C / 8;
+  if (c8n > 256 || 256 % c8n) return SOD_EARG;
+  return SOD_OK;
+}
+
+int gn_grid(int HW, int N, int& ppb) {
+  // ~2048 blocks in total
+  int gx = 2048 / (N > 0 ? N : 1);
+  if (gx < 1) gx = 1;
+  ppb = (HW + gx - 1) / gx;
+  if (ppb < 64) ppb = 64;
+  return (HW + ppb - 1) / ppb;
+}
+
+}  // namespace
+
+extern "C" int sod_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd,
+                                 int N, int HW, int C, int G, long long img_stride, float eps, int relu, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean_rstd) return SOD_EARG;
+  int rc = gn_check(N, HW, C, G);
+  if (rc) return rc;
+  if (img_stride <= 0) img_stride = (long long)HW * C;
+  hipStream_t st = (hipStream_t)stream;
+  GnArgs a{};
+  a.x = (const __bf16*)x; a.gamma = gamma; a.beta = beta; a.y = (__bf16*)y; a.stats = mean_rstd;
+  a.N = N; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.relu = relu; a.img_stride = img_stride; a.eps = eps;
+  const int gx = gn_grid(HW, N, a.pix_per_block);
+  hipError_t e = hipMemsetAsync(mean_rstd, 0, sizeof(float) * 2 * N * G, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * G, st, a);
+  hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3((N * G + 255) / 256), dim3(256), 0, st, mean_rstd, N * G,
+                     1.f / ((float)HW * (float)a.cpg), eps);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, N), dim3(256), 0, st, a);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean_rstd,
+                                 void* dx, float* dgamma, float* dbeta, float* red_ws /* 2*N*G floats */,
+                                 int N, int HW, int C, int G, long long img_stride, int relu, void* stream) {
+  if (!dy || !x || !gamma || !beta || !mean_rstd || !dx || !dgamma || !dbeta || !red_ws) return SOD_EARG;
+  int rc = gn_check(N, HW, C, G);
+  if (rc) return rc;
+  if (img_stride <= 0) img_stride = (long long)HW * C;
+  hipStream_t st = (hipStream_t)stream;
+  GnArgs a{};
+  a.x = (const __bf16*)x; a.dy = (const __bf16*)dy; a.gamma = gamma; a.beta = beta; a.dx = (__bf16*)dx;
+  a.stats = const_cast<float*>(mean_rstd); a.red = red_ws; a.dgamma = dgamma; a.dbeta = dbeta;
+  a.N = N; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.relu = relu; a.img_stride = img_stride;
+  const int gx = gn_grid(HW, N, a.pix_per_block);
+  hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * N * G, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * G, st, a);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), 0, st, a, 1.f / ((float)HW * (float)a.cpg));
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_relu_bwd(const void* dy, const void* y, void* dx, long long n, void* stream) {
+  if (!dy || !y || !dx || n < 0 || (n & 7)) return SOD_EARG;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, (const __bf16*)y, (__bf16*)dx, n / 8);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_relu_fwd(const void* x, void* y, long long n, void* stream) {
+  if (!x || !y || n < 0 || (n & 7)) return SOD_EARG;
+  hipLaunchKernelGGL(relu_fwd_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, n / 8);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_add_bf16(const void* a, const void* b, void* out, long long n, void* stream) {
+  if (!a || !b || !out || n < 0 || (n & 7)) return SOD_EARG;
+  hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, (const __bf16*)b, (__bf16*)out, n / 8);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C, long long img_stride, void* stream) {
+  if (!dy || !dbias || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || C > 2048) return SOD_EARG;
+  if (img_stride <= 0) img_stride = (long long)HW * C;
+  const int c8n = C / 8;
+  if (c8n > 256) return SOD_EARG;
+  int ppb;
+  const int gx = gn_grid(HW, N, ppb);
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(gx, N), dim3(256), sizeof(float) * C, (hipStream_t)stream, (const __bf16*)dy, dbias, HW, C, img_stride, ppb);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, void* stream) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return SOD_EARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks_for((long long)N * Ho * Wo * (C / 8), 16384)), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)x, (__bf16*)y, N, H, W, C, Ho, Wo);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_upsample2x_bwd(const void* g, void* dprev, int N, int Hc, int Wc, int C, void* stream) {
+  if (!g || !dprev || N <= 0 || Hc <= 0 || Wc <= 0 || C <= 0 || (C & 7)) return SOD_EARG;
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(blocks_for((long long)N * Hc * Wc * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const __bf16*)g, (__bf16*)dprev, N, Hc, Wc, C);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_weight_prep(const float* w, const float* scale, void* w_krsc, void* w_crsk, int K, int RS, int C, int Cpad, void* stream) {
+  if (!w || (!w_krsc && !w_crsk) || K <= 0 || RS <= 0 || C <= 0 || Cpad < C) return SOD_EARG;
+  hipLaunchKernelGGL(weight_prep_kernel, dim3(blocks_for((long long)K * RS * C)), dim3(256), 0, (hipStream_t)stream, w, scale,
+                     (__bf16*)w_krsc, (__bf16*)w_crsk, K, RS, C, Cpad);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_scale_rows(float* g, const float* scale, int K, long long row, void* stream) {
+  if (!g || !scale || K <= 0 || row <= 0) return SOD_EARG;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks_for((long long)K * row)), dim3(256), 0, (hipStream_t)stream, g, scale, K, row);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_sgd_step(float* params, const float* grads, float* momentum_buf, const void* segments_dev, int nseg,
+                            const float* lr_dev, float lr, float momentum, int nesterov, int first_step, float grad_scale, void* stream) {
+  if (!params || !grads || !segments_dev || nseg <= 0 || (momentum != 0.f && !momentum_buf)) return SOD_EARG;
+  hipLaunchKernelGGL(sgd_kernel, dim3(512, nseg), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf,
+                     (const SgdSeg*)segments_dev, nseg, lr_dev, lr, momentum, nesterov, first_step, grad_scale);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_preprocess_image(const void* img, int is_uint8, int C, int H, int W, void* out, int Hp, int Wp, int Cpad,
+                                    const float* mean3, const float* std3, void* stream) {
+  if (!img || !out || C <= 0 || C > 3 || H <= 0 || W <= 0 || Hp < H || Wp < W || Cpad != 8 || !mean3 || !std3) return SOD_EARG;
+  const int g = blocks_for((long long)Hp * Wp);
+  if (is_uint8)
+    hipLaunchKernelGGL(preprocess_kernel<uint8_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)img, C, H, W, (__bf16*)out, Hp, Wp, Cpad,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  else
+    hipLaunchKernelGGL(preprocess_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)img, C, H, W, (__bf16*)out, Hp, Wp, Cpad,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_nchw_f32_to_nhwc_bf16(const float* x, void* y, int N, int C, int HW, void* stream) {
+  if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return SOD_EARG;
+  hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3(blocks_for((long long)N * C * HW)), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y, N, C, HW);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}

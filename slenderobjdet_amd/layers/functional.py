@@ -1,0 +1,288 @@
+"""Raw (non-autograd) wrappers of the C-ABI HIP ops: allocate outputs with torch, pass pointers + shapes.
+
+Tensor conventions: activations are NHWC ``torch.bfloat16`` CUDA tensors, conv weights are ``[K, R, S, C]``
+bf16 ("KRSC"), losses/targets are fp32/int32.  Every function launches on ``torch.cuda.current_stream()``.
+"""
+import ctypes
+
+import torch
+
+from .. import _C
+from .._C import call, ptr, stream_ptr
+
+IOU_TYPES = {"iou": 0, "linear_iou": 1, "giou": 2}
+CONV_RELU = 1
+CONV_RES_UP2 = 2
+
+
+def _chk(t, dtype=None, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _C.SlenderHipError(f"{name} must be a CUDA/HIP tensor (the HIP ops have no CPU fallback)")
+    if not t.is_contiguous():
+        raise _C.SlenderHipError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise _C.SlenderHipError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+_ws_cache = {}
+
+
+def reduce_ws(device):
+    """Per-(device, stream) scratch for the two-stage reductions."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = torch.empty(_C.reduce_workspace_floats(), dtype=torch.float32, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def conv_out_size(H, W, R, S, stride, pad, dil):
+    Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+    return Ho, Wo
+
+
+def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, res_up2=False, out_f32=False,
+               out=None, y_img_stride=0, x_img_stride=0, x_shape=None):
+    """x (N,H,W,C) bf16, w (K,R,S,C) bf16 -> y (N,Ho,Wo,K). ``out``/``y_img_stride`` let the result land inside a
+    larger (N, L, K) buffer; ``x_shape`` overrides (N,H,W,C) when x is such a view."""
+    _chk(x, torch.bfloat16, "x"); _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias"); _chk(res, torch.bfloat16, "res")
+    N, H, W, C = x_shape if x_shape is not None else x.shape
+    K, R, S, Cw = w.shape
+    if Cw != C:
+        raise _C.SlenderHipError(f"weight channels {Cw} != input channels {C}")
+    Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
+    if out is None:
+        out = torch.empty((N, Ho, Wo, K), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    flags = (CONV_RELU if relu else 0) | (CONV_RES_UP2 if res_up2 else 0)
+    call("sod_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
+         x_img_stride, y_img_stride, 0, flags, 1 if out_f32 else 0, stream_ptr())
+    return out
+
+
+def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=None, dy_img_stride=0, dy_shape=None, out=None):
+    """dy (N,Ho,Wo,K) bf16, wt (C,R,S,K) bf16 (transposed weights) -> dx (N,H,W,C) bf16."""
+    _chk(dy, torch.bfloat16, "dy"); _chk(wt, torch.bfloat16, "wt"); _chk(accum, torch.bfloat16, "accum"); _chk(relu_mask, torch.bfloat16, "relu_mask")
+    N = dy_shape[0] if dy_shape is not None else dy.shape[0]
+    C, R, S, K = wt.shape
+    H, W = x_hw
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=dy.device)
+    call("sod_conv2d_dgrad", ptr(dy), ptr(wt), ptr(accum), ptr(relu_mask), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
+         dy_img_stride, 0, stream_ptr())
+    return out
+
+
+def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img_stride=0, K=None, x_shape=None, splits=0):
+    """Accumulates into dw (K,R,S,C) fp32."""
+    _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(dw, torch.float32, "dw")
+    N, H, W, C = x_shape if x_shape is not None else x.shape
+    if K is None:
+        K = dy.shape[-1]
+    call("sod_conv2d_wgrad", ptr(dy), ptr(x), ptr(dw), N, H, W, C, K, R, S, stride, pad, dil, dy_img_stride, x_img_stride,
+         splits, stream_ptr())
+    return dw
+
+
+def weight_prep(w_master, scale=None, want_krsc=True, want_crsk=True, cpad=None):
+    """fp32 (K,R,S,C) -> bf16 (K,R,S,Cpad) [* scale[k]] and bf16 (C,R,S,K)."""
+    _chk(w_master, torch.float32, "w"); _chk(scale, torch.float32, "scale")
+    K, R, S, C = w_master.shape
+    cpad = C if cpad is None else cpad
+    wk = (torch.zeros if cpad != C else torch.empty)((K, R, S, cpad), dtype=torch.bfloat16, device=w_master.device) if want_krsc else None
+    wc = torch.empty((C, R, S, K), dtype=torch.bfloat16, device=w_master.device) if want_crsk else None
+    call("sod_weight_prep", ptr(w_master), ptr(scale), ptr(wk), ptr(wc), K, R * S, C, cpad, stream_ptr())
+    return wk, wc
+
+
+def groupnorm_fwd(x, gamma, beta, G, eps=1e-5, relu=False):
+    _chk(x, torch.bfloat16, "x"); _chk(gamma, torch.float32, "gamma"); _chk(beta, torch.float32, "beta")
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    y = torch.empty_like(x)
+    stats = torch.empty((N, G, 2), dtype=torch.float32, device=x.device)
+    call("sod_groupnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stats), N, HW, C, G, 0, eps, 1 if relu else 0, stream_ptr())
+    return y, stats
+
+
+def groupnorm_bwd(dy, x, gamma, beta, stats, G, dgamma, dbeta, relu=False):
+    """Returns dx; accumulates dgamma/dbeta (fp32) in place."""
+    _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(dgamma, torch.float32, "dgamma"); _chk(dbeta, torch.float32, "dbeta")
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    dx = torch.empty_like(x)
+    red = torch.empty((N, G, 2), dtype=torch.float32, device=x.device)
+    call("sod_groupnorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(stats), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(red),
+         N, HW, C, G, 0, 1 if relu else 0, stream_ptr())
+    return dx
+
+
+def relu_fwd(x):
+    _chk(x, torch.bfloat16, "x")
+    y = torch.empty_like(x)
+    call("sod_relu_fwd", ptr(x), ptr(y), x.numel(), stream_ptr())
+    return y
+
+
+def relu_bwd(dy, y):
+    _chk(dy, torch.bfloat16, "dy"); _chk(y, torch.bfloat16, "y")
+    dx = torch.empty_like(dy)
+    call("sod_relu_bwd", ptr(dy), ptr(y), ptr(dx), dy.numel(), stream_ptr())
+    return dx
+
+
+def add_bf16(a, b):
+    _chk(a, torch.bfloat16, "a"); _chk(b, torch.bfloat16, "b")
+    o = torch.empty_like(a)
+    call("sod_add_bf16", ptr(a), ptr(b), ptr(o), a.numel(), stream_ptr())
+    return o
+
+
+def bias_grad(dy, dbias, N, HW, C, img_stride=0):
+    _chk(dy, torch.bfloat16, "dy"); _chk(dbias, torch.float32, "dbias")
+    call("sod_bias_grad", ptr(dy), ptr(dbias), N, HW, C, img_stride, stream_ptr())
+    return dbias
+
+
+def maxpool3x3s2(x):
+    _chk(x, torch.bfloat16, "x")
+    N, H, W, C = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty((N, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+    call("sod_maxpool3x3s2", ptr(x), ptr(y), N, H, W, C, stream_ptr())
+    return y
+
+
+def upsample2x_bwd(g):
+    _chk(g, torch.bfloat16, "g")
+    N, H, W, C = g.shape
+    d = torch.empty((N, H // 2, W // 2, C), dtype=torch.bfloat16, device=g.device)
+    call("sod_upsample2x_bwd", ptr(g), ptr(d), N, H // 2, W // 2, C, stream_ptr())
+    return d
+
+
+def preprocess_image(img, out, mean, std):
+    """img (C,H,W) uint8/float32 CUDA -> out (Hp,Wp,8) bf16 view of the batch buffer."""
+    if img.dtype not in (torch.uint8, torch.float32):
+        raise _C.SlenderHipError("image must be uint8 or float32")
+    _chk(img, None, "image"); _chk(out, torch.bfloat16, "out")
+    C, H, W = img.shape
+    Hp, Wp, Cp = out.shape
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    call("sod_preprocess_image", ptr(img), 1 if img.dtype == torch.uint8 else 0, C, H, W, ptr(out), Hp, Wp, Cp,
+         ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p), stream_ptr())
+    return out
+
+
+def nchw_f32_to_nhwc_bf16(x):
+    _chk(x, torch.float32, "x")
+    N, C, H, W = x.shape
+    y = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device)
+    call("sod_nchw_f32_to_nhwc_bf16", ptr(x), ptr(y), N, C, H * W, stream_ptr())
+    return y
+
+
+# ----------------------------------------------------------------------------------------------- losses
+def focal_loss_fwd(logits, labels=None, dense=None, alpha=0.25, gamma=2.0, K=None, want_elem=False):
+    _chk(logits, torch.float32, "logits"); _chk(labels, torch.int32, "labels"); _chk(dense, torch.float32, "targets")
+    ld = logits.shape[-1]
+    K = ld if K is None else K
+    M = logits.numel() // ld
+    elem = torch.empty((M, K), dtype=torch.float32, device=logits.device) if want_elem else None
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    call("sod_sigmoid_focal_loss_fwd", ptr(logits), ptr(labels), ptr(dense), M, K, ld, alpha, gamma, ptr(elem), ptr(out),
+         ptr(reduce_ws(logits.device)), stream_ptr())
+    return out, elem
+
+
+def focal_loss_bwd(logits, labels=None, dense=None, alpha=0.25, gamma=2.0, K=None, scale_num=None, scale_den=None,
+                   den_mul=1.0, den_min=1.0, ld_out=None, out_bf16=False, out=None):
+    _chk(logits, torch.float32, "logits")
+    ld = logits.shape[-1]
+    K = ld if K is None else K
+    M = logits.numel() // ld
+    ld_out = K if ld_out is None else ld_out
+    if out is None:
+        out = torch.empty((M, ld_out), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=logits.device)
+    call("sod_sigmoid_focal_loss_bwd", ptr(logits), ptr(labels), ptr(dense), M, K, ld, alpha, gamma, ptr(scale_num), ptr(scale_den),
+         den_mul, den_min, ptr(out), ld_out, 1 if out_bf16 else 0, stream_ptr())
+    return out
+
+
+def iou_loss_fwd(pred, target, weight=None, loss_type="iou", mask=None, mask_bg=-1, want_elem=False):
+    _chk(pred, torch.float32, "pred"); _chk(target, torch.float32, "target"); _chk(weight, torch.float32, "weight"); _chk(mask, torch.int32, "mask")
+    P = pred.shape[0]
+    elem = torch.empty(P, dtype=torch.float32, device=pred.device) if want_elem else None
+    out = torch.empty(1, dtype=torch.float32, device=pred.device)
+    call("sod_iou_loss_fwd", ptr(pred), ptr(target), ptr(weight), ptr(mask), mask_bg, P, IOU_TYPES[loss_type], ptr(elem), ptr(out),
+         ptr(reduce_ws(pred.device)), stream_ptr())
+    return out, elem
+
+
+def iou_loss_bwd(pred, target, weight=None, loss_type="iou", mask=None, mask_bg=-1, grad_scale=None):
+    P = pred.shape[0]
+    dpred = torch.empty_like(pred)
+    call("sod_iou_loss_bwd", ptr(pred), ptr(target), ptr(weight), ptr(mask), mask_bg, P, IOU_TYPES[loss_type], ptr(grad_scale), ptr(dpred), stream_ptr())
+    return dpred
+
+
+def _int_arr(v):
+    return (ctypes.c_int * len(v))(*[int(i) for i in v])
+
+
+def _float_arr(v):
+    return (ctypes.c_float * len(v))(*[float(i) for i in v])
+
+
+def fcos_assign(boxes, classes, box_offsets, N, lvl_hw, strides, sizes_of_interest, radius, num_classes):
+    """boxes (sumG,4) f32, classes (sumG,) i32, box_offsets (N+1,) i32 (all CUDA). Returns labels (N,L) i32,
+    reg_targets (N,L,4), ctr_targets (N,L), stats (2,) = [num_pos, sum_ctr]."""
+    dev = box_offsets.device
+    _chk(boxes, torch.float32, "boxes"); _chk(classes, torch.int32, "classes"); _chk(box_offsets, torch.int32, "box_offsets")
+    L = sum(h * w for h, w in lvl_hw)
+    labels = torch.empty((N, L), dtype=torch.int32, device=dev)
+    reg = torch.empty((N, L, 4), dtype=torch.float32, device=dev)
+    ctr = torch.empty((N, L), dtype=torch.float32, device=dev)
+    stats = torch.empty(2, dtype=torch.float32, device=dev)
+    nl = len(lvl_hw)
+    call("sod_fcos_assign", ptr(boxes), ptr(classes), ptr(box_offsets), N, nl,
+         ctypes.cast(_int_arr([h for h, _ in lvl_hw]), ctypes.c_void_p), ctypes.cast(_int_arr([w for _, w in lvl_hw]), ctypes.c_void_p),
+         ctypes.cast(_int_arr(strides), ctypes.c_void_p),
+         ctypes.cast(_float_arr([s[0] for s in sizes_of_interest]), ctypes.c_void_p),
+         ctypes.cast(_float_arr([s[1] for s in sizes_of_interest]), ctypes.c_void_p),
+         float(radius), num_classes, ptr(labels), ptr(reg), ptr(ctr), ptr(stats), ptr(reduce_ws(dev)), stream_ptr())
+    return labels, reg, ctr, stats
+
+
+def fcos_regctr_loss_fwd(box_raw, ld_box, ctr_logit, ld_ctr, labels, reg_t, ctr_t, scales, N, lvl_hw, strides, num_classes,
+                         loss_type, norm_reg):
+    dev = labels.device
+    sums = torch.empty(2, dtype=torch.float32, device=dev)
+    nl = len(lvl_hw)
+    call("sod_fcos_regctr_loss_fwd", ptr(box_raw), ld_box, ptr(ctr_logit), ld_ctr, ptr(labels), ptr(reg_t), ptr(ctr_t), ptr(scales), N, nl,
+         ctypes.cast(_int_arr([h for h, _ in lvl_hw]), ctypes.c_void_p), ctypes.cast(_int_arr([w for _, w in lvl_hw]), ctypes.c_void_p),
+         ctypes.cast(_int_arr(strides), ctypes.c_void_p), num_classes, IOU_TYPES[loss_type], 1 if norm_reg else 0,
+         ptr(sums), ptr(reduce_ws(dev)), stream_ptr())
+    return sums
+
+
+def fcos_regctr_loss_bwd(box_raw, ld_box, ctr_logit, ld_ctr, labels, reg_t, ctr_t, scales, N, lvl_hw, strides, num_classes,
+                         loss_type, norm_reg, grad_reg, grad_ctr, stats, inv_world, dbox, ld_out, ctr_col, dctr, ld_dctr, dctr_col,
+                         dscales):
+    dev = labels.device
+    nl = len(lvl_hw)
+    call("sod_fcos_regctr_loss_bwd", ptr(box_raw), ld_box, ptr(ctr_logit), ld_ctr, ptr(labels), ptr(reg_t), ptr(ctr_t), ptr(scales), N, nl,
+         ctypes.cast(_int_arr([h for h, _ in lvl_hw]), ctypes.c_void_p), ctypes.cast(_int_arr([w for _, w in lvl_hw]), ctypes.c_void_p),
+         ctypes.cast(_int_arr(strides), ctypes.c_void_p), num_classes, IOU_TYPES[loss_type], 1 if norm_reg else 0,
+         ptr(grad_reg), ptr(grad_ctr), ptr(stats), float(inv_world), ptr(dbox), ld_out, ctr_col, ptr(dctr), ld_dctr, dctr_col,
+         ptr(dscales), ptr(reduce_ws(dev)), stream_ptr())
+
+
+def fcos_finalize_losses(focal_sum, regctr_sums, stats, inv_world):
+    out = torch.empty(3, dtype=torch.float32, device=stats.device)
+    call("sod_fcos_finalize_losses", ptr(focal_sum), ptr(regctr_sums), ptr(stats), float(inv_world), ptr(out), stream_ptr())
+    return out

@@ -1,0 +1,190 @@
+"""GPU parity: HIP implicit-GEMM convolution (through the C ABI) vs the CPU oracle (F.conv2d / autograd, fp32).
+
+Operands are rounded to bf16 before BOTH paths, so the only differences are fp32 accumulation order and (for bf16
+outputs) the final rounding.  Tolerances: fp32 output 2e-4 * max|ref| ; bf16 output 2^-7 * max|ref|
+(one bf16 ulp at the top of the range is 2^-8 relative).
+"""
+import pytest
+import torch
+
+from oracle import nn as onn
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return onn.rb(torch.randn(shape, generator=g) * scale)
+
+
+def _close(got, ref, rel, what):
+    got = got.float().cpu()
+    tol = rel * max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert err <= tol, f"{what}: max abs err {err:.4g} > tol {tol:.4g} (ref max {ref.abs().max().item():.4g})"
+
+
+# (N, H, W, C, K, R, stride, pad, dil)
+FWD_CASES = [
+    (2, 13, 21, 64, 128, 3, 1, 1, 1),
+    (1, 9, 11, 256, 64, 1, 1, 0, 1),
+    (2, 14, 18, 64, 64, 3, 2, 1, 1),
+    (2, 16, 12, 128, 256, 1, 2, 0, 1),
+    (2, 32, 40, 8, 64, 7, 2, 3, 1),      # stem geometry (C padded 3 -> 8): generic contraction path
+    (1, 12, 10, 80, 256, 3, 1, 1, 1),    # C % 64 != 0
+    (2, 11, 13, 256, 80, 3, 1, 1, 1),    # cls_logits
+    (2, 11, 13, 256, 8, 3, 1, 1, 1),     # bbox_pred+centerness (padded to 8)
+    (1, 7, 9, 64, 5, 3, 1, 1, 1),        # Nout % 4 != 0: scalar epilogue
+    (1, 10, 10, 64, 64, 3, 1, 2, 2),     # dilation
+    (3, 25, 42, 256, 256, 3, 1, 1, 1),   # P5-sized level, 2 q-tiles x many p-tiles
+]
+
+
+@pytest.mark.parametrize("case", FWD_CASES)
+@pytest.mark.parametrize("out_f32", [True, False])
+def test_conv_fwd(cuda, case, out_f32):
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K, R, st, pad, dil = case
+    x = _rand((N, H, W, C), 1)
+    w = _rand((K, R, R, C), 2, 0.05)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(3))
+    ref = onn.conv2d(x, w, b, st, pad, dil)
+    y = HF.conv2d_fwd(x.to(cuda).bfloat16(), w.to(cuda).bfloat16(), b.to(cuda), stride=st, pad=pad, dil=dil, out_f32=out_f32)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == tuple(ref.shape)
+    _close(y, ref, 2e-4 if out_f32 else 2 ** -7, f"conv fwd {case}")
+
+
+def test_conv_fwd_epilogue(cuda):
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K = 2, 12, 20, 64, 128
+    x, w = _rand((N, H, W, C), 4), _rand((K, 3, 3, C), 5, 0.05)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(6))
+    res = _rand((N, H, W, K), 7)
+    ref = onn.conv2d(x, w, b, 1, 1, 1, res=res, relu=True)
+    y = HF.conv2d_fwd(x.to(cuda).bfloat16(), w.to(cuda).bfloat16(), b.to(cuda), res=res.to(cuda).bfloat16(), stride=1, pad=1, relu=True)
+    _close(y, ref, 2 ** -7, "bias+res+relu")
+    assert (y.float() >= 0).all()
+    # FPN top-down: lateral 1x1 + nearest-2x upsampled coarser map
+    w1 = _rand((K, 1, 1, C), 8, 0.1)
+    prev = _rand((N, H // 2, W // 2, K), 9)
+    ref = onn.conv2d(x, w1, b, 1, 0, 1, res=prev, res_up2=True)
+    y = HF.conv2d_fwd(x.to(cuda).bfloat16(), w1.to(cuda).bfloat16(), b.to(cuda), res=prev.to(cuda).bfloat16(), res_up2=True, out_f32=True)
+    _close(y, ref, 2e-4, "lateral + upsample2x residual")
+
+
+def test_conv_fwd_into_concat_buffer(cuda):
+    """Per-level head outputs land directly in the (N, sum HW, K) buffer (replaces permute_and_concat)."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, C, K = 2, 64, 80
+    hw = [(8, 12), (4, 6), (2, 3)]
+    L = sum(h * w for h, w in hw)
+    w = _rand((K, 3, 3, C), 10, 0.05)
+    buf = torch.full((N, L, K), 7.0, dtype=torch.float32, device=cuda)
+    refs, off = [], 0
+    for i, (h, ww) in enumerate(hw):
+        x = _rand((N, h, ww, C), 20 + i)
+        refs.append(onn.conv2d(x, w, None, 1, 1, 1).reshape(N, h * ww, K))
+
+        view = buf.view(-1)[off * K:]
+        HF.conv2d_fwd(x.to(cuda).bfloat16(), w.to(cuda).bfloat16(), None, stride=1, pad=1, out_f32=True, out=view, y_img_stride=L * K)
+        off += h * ww
+    _close(buf, torch.cat(refs, dim=1), 2e-4, "concat buffer")
+
+
+DGRAD_CASES = [
+    (2, 13, 21, 64, 128, 3, 1, 1, 1),
+    (1, 9, 11, 256, 64, 1, 1, 0, 1),
+    (2, 14, 18, 64, 64, 3, 2, 1, 1),
+    (2, 16, 12, 128, 256, 1, 2, 0, 1),
+    (2, 15, 13, 64, 128, 3, 2, 1, 1),    # odd input with stride 2
+    (2, 11, 13, 256, 80, 3, 1, 1, 1),    # dy has 80 channels: generic contraction
+    (2, 11, 13, 256, 8, 3, 1, 1, 1),
+    (1, 10, 10, 64, 64, 3, 1, 2, 2),
+    (3, 25, 42, 256, 256, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_conv_dgrad(cuda, case):
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K, R, st, pad, dil = case
+    x = _rand((N, H, W, C), 1)
+    w = _rand((K, R, R, C), 2, 0.05)
+    Ho, Wo = HF.conv_out_size(H, W, R, R, st, pad, dil)
+    dy = _rand((N, Ho, Wo, K), 3)
+    dx_ref, _ = onn.conv2d_backward(x, w, dy, st, pad, dil)
+    _, wt = HF.weight_prep(w.to(cuda), want_krsc=False)
+    dx = HF.conv2d_dgrad(dy.to(cuda).bfloat16(), wt, (H, W), st, pad, dil)
+    _close(dx, dx_ref, 2 ** -7, f"dgrad {case}")
+
+
+def test_conv_dgrad_accum_mask(cuda):
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K = 2, 10, 14, 64, 64
+    x, w, dy = _rand((N, H, W, C), 1), _rand((K, 3, 3, C), 2, 0.05), _rand((N, H, W, K), 3)
+    acc, act = _rand((N, H, W, C), 4), _rand((N, H, W, C), 5)
+    dx_ref, _ = onn.conv2d_backward(x, w, dy, 1, 1, 1)
+    ref = (dx_ref + acc) * (act > 0)
+    _, wt = HF.weight_prep(w.to(cuda), want_krsc=False)
+    dx = HF.conv2d_dgrad(dy.to(cuda).bfloat16(), wt, (H, W), 1, 1, 1, accum=acc.to(cuda).bfloat16(), relu_mask=act.to(cuda).bfloat16())
+    _close(dx, ref, 2 ** -7, "dgrad accum+mask")
+
+
+WGRAD_CASES = [
+    (2, 13, 21, 64, 128, 3, 1, 1, 1, 0),
+    (2, 13, 21, 64, 128, 3, 1, 1, 1, 1),
+    (1, 9, 11, 256, 64, 1, 1, 0, 1, 0),
+    (2, 14, 18, 64, 64, 3, 2, 1, 1, 3),
+    (2, 16, 12, 128, 256, 1, 2, 0, 1, 0),
+    (2, 11, 13, 256, 80, 3, 1, 1, 1, 0),
+    (2, 11, 13, 256, 8, 3, 1, 1, 1, 2),
+    (1, 10, 10, 64, 64, 3, 1, 2, 2, 0),
+    (3, 25, 42, 256, 256, 3, 1, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad(cuda, case):
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K, R, st, pad, dil, splits = case
+    x = _rand((N, H, W, C), 1)
+    w = _rand((K, R, R, C), 2, 0.05)
+    Ho, Wo = HF.conv_out_size(H, W, R, R, st, pad, dil)
+    dy = _rand((N, Ho, Wo, K), 3)
+    _, dw_ref = onn.conv2d_backward(x, w, dy, st, pad, dil)
+    dw = torch.zeros((K, R, R, C), dtype=torch.float32, device=cuda)
+    HF.conv2d_wgrad(dy.to(cuda).bfloat16(), x.to(cuda).bfloat16(), dw, R, R, st, pad, dil, splits=splits)
+    _close(dw, dw_ref, 2e-4, f"wgrad {case}")
+    # accumulation semantics: a second call doubles the buffer
+    HF.conv2d_wgrad(dy.to(cuda).bfloat16(), x.to(cuda).bfloat16(), dw, R, R, st, pad, dil, splits=splits)
+    _close(dw, 2 * dw_ref, 2e-4, f"wgrad accumulate {case}")
+
+
+def test_weight_prep(cuda):
+    from slenderobjdet_amd.layers import functional as HF
+
+    w = torch.randn(16, 3, 3, 24, generator=torch.Generator().manual_seed(0))
+    sc = torch.rand(16, generator=torch.Generator().manual_seed(1)) + 0.5
+    wk, wc = HF.weight_prep(w.to(cuda), sc.to(cuda))
+    ref = onn.rb(w * sc.view(-1, 1, 1, 1))
+    assert torch.equal(wk.float().cpu(), ref)
+    assert torch.equal(wc.float().cpu(), ref.permute(3, 1, 2, 0).contiguous())
+
+
+def test_conv_rejects_bad_args(cuda):
+    from slenderobjdet_amd import _C
+    from slenderobjdet_amd.layers import functional as HF
+
+    x = torch.zeros((1, 4, 4, 12), dtype=torch.bfloat16, device=cuda)   # C % 8 != 0
+    w = torch.zeros((8, 3, 3, 12), dtype=torch.bfloat16, device=cuda)
+    with pytest.raises(_C.SlenderHipError):
+        HF.conv2d_fwd(x, w, None, stride=1, pad=1)
+    with pytest.raises(_C.SlenderHipError):
+        HF.conv2d_fwd(x.cpu(), w.cpu(), None, stride=1, pad=1)
