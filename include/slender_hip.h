@@ -54,8 +54,9 @@ int sod_conv2d_fwd(const void* x, const void* w, const float* bias, const void* 
 int sod_conv2d_dgrad(const void* dy, const void* wt, const void* accum, const void* relu_mask, void* dx,
                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                      long long dy_img_stride, long long dx_img_stride, void* stream);
-/* dw[k,r,s,c] += sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,hi,wi,c]   (fp32, atomically accumulated: zero it once per step) */
-int sod_conv2d_wgrad(const void* dy, const void* x, float* dw,
+/* dw[k,r,s,c] += qscale[k] * sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,hi,wi,c]   (fp32, atomically accumulated: zero it once
+ * per step; qscale optional = the folded FrozenBatchNorm2d scale, chain rule through w_eff = w * scale) */
+int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const float* qscale,
                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                      long long dy_img_stride, long long x_img_stride, int splits, void* stream);
 

@@ -254,6 +254,7 @@ struct WgradArgs {
   const void* dy;      // (N,Ho,Wo,K) bf16 rows at dy_img_stride
   const void* x;       // (N,Hx,Wx,C) bf16
   float* dw;           // [K][R][S][C] fp32, accumulated atomically
+  const float* qscale; // optional per-output-channel factor (folded FrozenBN scale)
   uint32_t dy_bytes, x_bytes;
   int N, Hx, Wx, C, Ho, Wo, K;
   int R, S, stride, pad, dil;
@@ -371,10 +372,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     for (int e = 0; e < 4; ++e) {
       const int q = q0 + (wq * 4 + i) * 16 + fg * 4 + e;
       if (q >= a.K) continue;
+      const float qs = a.qscale ? a.qscale[q] : 1.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = c0 + (wc * 4 + j) * 16 + fr;
-        if (c < a.C) atomicAdd(a.dw + ((size_t)q * RS + tap) * a.C + c, acc[i][j][e]);
+        if (c < a.C) atomicAdd(a.dw + ((size_t)q * RS + tap) * a.C + c, acc[i][j][e] * qs);
       }
     }
   }
@@ -489,7 +491,7 @@ extern "C" int sod_conv2d_dgrad(const void* dy, const void* wt, const void* accu
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 
-extern "C" int sod_conv2d_wgrad(const void* dy, const void* x, float* dw,
+extern "C" int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const float* qscale,
                                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                 long long dy_img_stride, long long x_img_stride, int splits, void* stream) {
   if (!dy || !x || !dw) return SOD_EARG;
@@ -502,7 +504,7 @@ extern "C" int sod_conv2d_wgrad(const void* dy, const void* x, float* dw,
   const unsigned long long yb = (unsigned long long)N * dy_img_stride * 2ull, xb = (unsigned long long)N * x_img_stride * 2ull;
   if (yb >= 0x80000000ull || xb >= 0x80000000ull) return SOD_ESIZE;
   WgradArgs a{};
-  a.dy = dy; a.x = x; a.dw = dw; a.dy_bytes = (uint32_t)yb; a.x_bytes = (uint32_t)xb;
+  a.dy = dy; a.x = x; a.dw = dw; a.qscale = qscale; a.dy_bytes = (uint32_t)yb; a.x_bytes = (uint32_t)xb;
   a.N = N; a.Hx = H; a.Wx = W; a.C = C; a.Ho = Ho; a.Wo = Wo; a.K = K;
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   a.dy_img_stride = (int)dy_img_stride; a.x_img_stride = (int)x_img_stride;

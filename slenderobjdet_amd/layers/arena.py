@@ -1,0 +1,166 @@
+"""Flat parameter / gradient arena for MI355X.
+
+All trainable parameters of a model live in ONE contiguous fp32 buffer (``params``), their gradients in a second
+(``grads``) and the SGD momentum in a third.  ``nn.Parameter.data`` / ``.grad`` are views into them, so the
+reference-style code (``model.parameters()``, ``state_dict``) keeps working, while
+  * the optimizer is a single fused kernel launch over the arena (slender_det/solver/build.py:21-25 builds a
+    per-tensor torch.optim.SGD),
+  * ``zero_grad`` is one memset,
+  * the data-parallel gradient exchange (detectron2's DistributedDataParallel) is an RCCL
+    all-reduce over large contiguous buckets of ``grads`` launched as soon as the backward pass has finished
+    writing them (parameters are laid out in reverse registration order = roughly backward completion order).
+Weight gradients are accumulated into ``grads`` directly by the HIP wgrad kernels (no autograd-side copies).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+_ALIGN = 64  # elements; keeps every tensor 256-B aligned
+
+
+class ParamArena:
+    def __init__(self, model, bucket_mb=32.0):
+        seen, plist = set(), []
+        for name, p in model.named_parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                plist.append((name, p))
+        plist.reverse()
+        if not plist:
+            raise ValueError("model has no trainable parameters")
+        dev = plist[0][1].device
+        self.device = dev
+        offs, total = [], 0
+        for _, p in plist:
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = total
+        self.params = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.momentum = None
+        self.index = {}
+        self.names = []
+        for (name, p), off in zip(plist, offs):
+            n = p.numel()
+            view = self.params[off:off + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grads[off:off + n].view(p.shape)
+            self.index[id(p)] = (off, n)
+            self.names.append((name, off, n))
+        self._plist = [p for _, p in plist]
+        self.generation = 0          # bumped whenever params change behind torch's back (fused optimizer step)
+        # ---- gradient buckets for the data-parallel all-reduce ----
+        self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
+        self.buckets = []            # (begin, end)
+        b0 = 0
+        for (name, off, n), nxt in zip(self.names, offs[1:] + [total]):
+            if nxt - b0 >= self.bucket_elems:
+                self.buckets.append((b0, nxt))
+                b0 = nxt
+        if b0 < total:
+            self.buckets.append((b0, total))
+        self._bucket_of = {}
+        for (name, off, n), p in zip(self.names, self._plist):
+            for bi, (b, e) in enumerate(self.buckets):
+                if b <= off < e:
+                    self._bucket_of[id(p)] = bi
+        self._pending = None
+        self._uses = {}
+        self._comm_stream = None
+        self._handles = []
+
+    # ------------------------------------------------------------------ bookkeeping
+    def grad_view(self, p):
+        off, n = self.index[id(p)]
+        g = self.grads[off:off + n].view(p.shape)
+        if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+            p.grad = g
+        return g
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def bump(self):
+        self.generation += 1
+
+    # ------------------------------------------------------------------ data parallel
+    def note_use(self, p):
+        """Called in forward for every use of a trainable parameter (shared head weights are used once per level)."""
+        self._uses[id(p)] = self._uses.get(id(p), 0) + 1
+
+    def begin_backward(self):
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._world = world
+        if world <= 1:
+            self._uses.clear()
+            self._pending = None
+            return
+        counts = [0] * len(self.buckets)
+        for pid, c in self._uses.items():
+            counts[self._bucket_of[pid]] += c
+        self._pending = counts
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        if self._comm_stream is None and self.device.type == "cuda":
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+
+    def mark_ready(self, p):
+        """Called in backward after the last kernel that adds to ``p.grad`` for this use has been enqueued."""
+        if self._pending is None:
+            return
+        bi = self._bucket_of[id(p)]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0 and not self._launched[bi]:
+            self._launch_bucket(bi)
+
+    def _launch_bucket(self, bi):
+        b, e = self.buckets[bi]
+        view = self.grads[b:e]
+        self._launched[bi] = True
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ev)
+                h = dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            h = dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)
+        self._handles.append(h)
+
+    def finish_backward(self):
+        """Launch the buckets that did not complete during backward (parameters unused this step), then wait for
+        every all-reduce.  Gradients hold the SUM over ranks afterwards; the optimizer applies 1/world."""
+        if self._pending is None:
+            return
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:
+                self._launch_bucket(bi)
+        for h in self._handles:
+            h.wait()
+        if self.device.type == "cuda":
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._pending = None
+        self._uses.clear()
+
+    # ------------------------------------------------------------------ optimizer support
+    def build_segments(self, param_groups, base_lr):
+        """Merge per-parameter (lr, weight_decay) into contiguous arena segments for the fused SGD kernel."""
+        info = {}
+        for g in param_groups:
+            for p in g["params"]:
+                info[id(p)] = (g["lr"] / base_lr if base_lr else 1.0, g.get("weight_decay", 0.0))
+        segs = []
+        for p in self._plist:
+            off, n = self.index[id(p)]
+            lr_mult, wd = info.get(id(p), (0.0, 0.0))
+            end = off + (n + _ALIGN - 1) // _ALIGN * _ALIGN
+            if segs and segs[-1][1] == off and segs[-1][2] == lr_mult and segs[-1][3] == wd:
+                segs[-1][1] = end
+            else:
+                segs.append([off, end, lr_mult, wd])
+        arr = np.zeros(len(segs), dtype=np.dtype([("b", "<i8"), ("e", "<i8"), ("lr", "<f4"), ("wd", "<f4")]))
+        for i, (b, e, lr, wd) in enumerate(segs):
+            arr[i] = (b, e, lr, wd)
+        dev_arr = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+        return dev_arr, len(segs)

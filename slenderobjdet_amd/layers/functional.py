@@ -76,13 +76,13 @@ def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=Non
     return out
 
 
-def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img_stride=0, K=None, x_shape=None, splits=0):
+def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img_stride=0, K=None, x_shape=None, splits=0, qscale=None):
     """Accumulates into dw (K,R,S,C) fp32."""
     _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(dw, torch.float32, "dw")
     N, H, W, C = x_shape if x_shape is not None else x.shape
     if K is None:
         K = dy.shape[-1]
-    call("sod_conv2d_wgrad", ptr(dy), ptr(x), ptr(dw), N, H, W, C, K, R, S, stride, pad, dil, dy_img_stride, x_img_stride,
+    call("sod_conv2d_wgrad", ptr(dy), ptr(x), ptr(dw), ptr(qscale), N, H, W, C, K, R, S, stride, pad, dil, dy_img_stride, x_img_stride,
          splits, stream_ptr())
     return dw
 

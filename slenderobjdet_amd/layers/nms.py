@@ -1,0 +1,19 @@
+"""batched_nms with the torchvision / detectron2 contract: class-offset trick, greedy suppression
+of IoU > threshold in stable descending-score order, kept indices returned in score order."""
+import torch
+
+
+def nms(boxes, scores, iou_threshold):
+    from . import functional as HF
+
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    return HF.nms(boxes.float().contiguous(), scores.float().contiguous(), float(iou_threshold))
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + 1)
+    return nms(boxes + offsets[:, None], scores, iou_threshold)

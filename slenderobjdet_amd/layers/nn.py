@@ -1,0 +1,237 @@
+"""nn.Module / autograd layer over the HIP ops (NHWC bf16 activations, fp32 master weights in KRSC layout).
+
+Mirrors the building blocks the reference gets from detectron2.layers / torch.nn for this path:
+``Conv2d`` (+ FrozenBatchNorm2d, + ReLU, + residual add), ``nn.GroupNorm(32, C)`` + ReLU (fcosv2.py:315-336),
+``Scale`` (slender_det/layers/scale.py:5-11, fused into the loss kernel here).  Every forward/backward is a
+sequence of C-ABI calls; weight gradients are accumulated by the wgrad kernel straight into the flat gradient
+arena (:mod:`slenderobjdet_amd.layers.arena`).
+"""
+import math
+
+import torch
+from torch import nn
+from torch.autograd.function import once_differentiable
+
+from . import functional as HF
+
+
+def _arena_of(mod):
+    return getattr(mod, "_arena", None)
+
+
+class HipConv2d(nn.Module):
+    """Conv2d with optional folded FrozenBatchNorm2d, fused bias / residual / ReLU epilogue.
+
+    weight: (K, R, S, C) fp32 master copy ("KRSC"; ``weight_kcrs()`` gives the torch layout).
+    ``cin_pad``: pad input channels of the bf16 compute copy (stem: 3 -> 8).
+    ``mask_input``: the input is a post-ReLU tensor consumed only by this conv, so dgrad applies its ReLU mask
+    (the producer is then constructed with ``grad_premasked=True`` and skips its own mask pass).
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True,
+                 frozen_bn=False, relu=False, cin_pad=None, mask_input=False, grad_premasked=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = kernel_size, stride, padding, dilation
+        self.relu, self.mask_input, self.grad_premasked = relu, mask_input, grad_premasked
+        self.cin_pad = cin_pad
+        self.weight = nn.Parameter(torch.empty(out_channels, kernel_size, kernel_size, in_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.frozen_bn = frozen_bn
+        if frozen_bn:   # detectron2 FrozenBatchNorm2d buffers, eps 1e-5
+            self.register_buffer("bn_weight", torch.ones(out_channels))
+            self.register_buffer("bn_bias", torch.zeros(out_channels))
+            self.register_buffer("bn_running_mean", torch.zeros(out_channels))
+            self.register_buffer("bn_running_var", torch.ones(out_channels) - 1e-5)
+        self._prep_key = None
+        self.w_bf16 = self.wt_bf16 = self.bias_eff = self.bn_scale = None
+
+    # initialisers used by the model builders
+    def init_msra(self):       # c2_msra_fill: kaiming_normal_(fan_out, relu)
+        fan_out = self.out_channels * self.kernel_size * self.kernel_size
+        nn.init.normal_(self.weight, 0.0, math.sqrt(2.0 / fan_out))
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def init_xavier(self):     # c2_xavier_fill: kaiming_uniform_(a=1)
+        fan_in = self.in_channels * self.kernel_size * self.kernel_size
+        bound = math.sqrt(6.0 / (2.0 * fan_in))
+        nn.init.uniform_(self.weight, -bound, bound)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def init_normal(self, std=0.01, bias_value=0.0):
+        nn.init.normal_(self.weight, 0.0, std)
+        if self.bias is not None:
+            nn.init.constant_(self.bias, bias_value)
+
+    def weight_kcrs(self):
+        return self.weight.detach().permute(0, 3, 1, 2).contiguous()
+
+    def prepare(self, force=False):
+        """(Re)build the bf16 compute copies when the master weights changed."""
+        arena = _arena_of(self)
+        key = (self.weight._version, self.bias._version if self.bias is not None else 0,
+               arena.generation if (arena is not None and self.weight.requires_grad) else -1, self.weight.data_ptr())
+        if not force and key == self._prep_key:
+            return
+        w = self.weight.detach()
+        if self.frozen_bn:
+            scale = self.bn_weight * torch.rsqrt(self.bn_running_var + 1e-5)
+            shift = self.bn_bias - self.bn_running_mean * scale
+            self.bn_scale = scale.contiguous()
+            self.bias_eff = (shift + (self.bias.detach() * scale if self.bias is not None else 0)).contiguous()
+        else:
+            self.bn_scale = None
+            self.bias_eff = self.bias.detach() if self.bias is not None else None
+        need_t = self.weight.requires_grad or True
+        self.w_bf16, self.wt_bf16 = HF.weight_prep(w.contiguous(), self.bn_scale, True, need_t, self.cin_pad)
+        self._prep_key = key
+
+    def forward(self, x, res=None, res_up2=False):
+        self.prepare()
+        # the master weight rides along as a differentiable input so autograd builds the node; its gradient is
+        # accumulated by the wgrad kernel directly into the arena (backward returns None for it)
+        return _ConvFn.apply(x, res, self.weight, self, res_up2)
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, weight, mod, res_up2):
+        y = HF.conv2d_fwd(x, mod.w_bf16, mod.bias_eff, res, mod.stride, mod.padding, mod.dilation, relu=mod.relu, res_up2=res_up2)
+        ctx.mod, ctx.res_up2, ctx.has_res = mod, res_up2, res is not None
+        train_w = mod.weight.requires_grad
+        if train_w or x.requires_grad or (res is not None and res.requires_grad):
+            ctx.save_for_backward(x, y if mod.relu else None)
+            if train_w and _arena_of(mod) is not None:
+                _arena_of(mod).note_use(mod.weight)
+                if mod.bias is not None:
+                    _arena_of(mod).note_use(mod.bias)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        mod = ctx.mod
+        x, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = HF.relu_bwd(dy, y) if (mod.relu and not mod.grad_premasked) else dy
+        arena = _arena_of(mod)
+        N, H, W, C = x.shape
+        if mod.weight.requires_grad:
+            dw = arena.grad_view(mod.weight)
+            HF.conv2d_wgrad(g, x, dw, mod.kernel_size, mod.kernel_size, mod.stride, mod.padding, mod.dilation, qscale=mod.bn_scale)
+            arena.mark_ready(mod.weight)
+            if mod.bias is not None:
+                HF.bias_grad(g, arena.grad_view(mod.bias), N, g.shape[1] * g.shape[2], mod.out_channels)
+                arena.mark_ready(mod.bias)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = HF.conv2d_dgrad(g, mod.wt_bf16, (H, W), mod.stride, mod.padding, mod.dilation,
+                                 relu_mask=x if mod.mask_input else None)
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[1]:
+            dres = HF.upsample2x_bwd(g) if ctx.res_up2 else g
+        return dx, dres, None, None, None
+
+
+class HipGroupNorm(nn.Module):
+    """Parameters of nn.GroupNorm(num_groups, C); applied fused with the preceding conv by ConvGnRelu."""
+
+    def __init__(self, num_groups, num_channels, eps=1e-5):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+
+
+class ConvGnRelu(nn.Module):
+    """[Conv3x3(bias) -> GroupNorm(32) -> ReLU] unit of the FCOS towers (fcosv2.py:300-336)."""
+
+    def __init__(self, channels, num_groups=32):
+        super().__init__()
+        self.conv = HipConv2d(channels, channels, 3, 1, 1, bias=True)
+        self.gn = HipGroupNorm(num_groups, channels)
+
+    def forward(self, x):
+        self.conv.prepare()
+        return _ConvGnReluFn.apply(x, self.conv.weight, self)
+
+
+class _ConvGnReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, unit):
+        conv, gn = unit.conv, unit.gn
+        y1 = HF.conv2d_fwd(x, conv.w_bf16, conv.bias_eff, None, 1, 1, 1)
+        y2, stats = HF.groupnorm_fwd(y1, gn.weight.detach(), gn.bias.detach(), gn.num_groups, gn.eps, relu=True)
+        ctx.unit = unit
+        ctx.save_for_backward(x, y1, stats)
+        arena = _arena_of(conv)
+        if arena is not None and conv.weight.requires_grad:
+            for p in (conv.weight, conv.bias, gn.weight, gn.bias):
+                arena.note_use(p)
+        return y2
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy2):
+        conv, gn = ctx.unit.conv, ctx.unit.gn
+        x, y1, stats = ctx.saved_tensors
+        arena = _arena_of(conv)
+        dy1 = HF.groupnorm_bwd(dy2.contiguous(), y1, gn.weight.detach(), gn.bias.detach(), stats, gn.num_groups,
+                               arena.grad_view(gn.weight), arena.grad_view(gn.bias), relu=True)
+        arena.mark_ready(gn.weight)
+        arena.mark_ready(gn.bias)
+        N, H, W, C = x.shape
+        HF.conv2d_wgrad(dy1, x, arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
+        arena.mark_ready(conv.weight)
+        HF.bias_grad(dy1, arena.grad_view(conv.bias), N, H * W, C)
+        arena.mark_ready(conv.bias)
+        dx = HF.conv2d_dgrad(dy1, conv.wt_bf16, (H, W), 1, 1, 1) if ctx.needs_input_grad[0] else None
+        return dx, None, None
+
+
+class _ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = HF.relu_fwd(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return HF.relu_bwd(dy.contiguous(), y)
+
+
+def relu(x):
+    return _ReluFn.apply(x)
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        if x.requires_grad:
+            raise NotImplementedError("max-pool backward is not built: the stem is frozen (MODEL.BACKBONE.FREEZE_AT >= 1)")
+        return HF.maxpool3x3s2(x)
+
+
+def max_pool_3x3_s2(x):
+    return _MaxPoolFn.apply(x)
+
+
+class Scale(nn.Module):
+    """slender_det/layers/scale.py:5-11. Kept for API parity; FCOSHead fuses the multiply into the loss kernel."""
+
+    def __init__(self, init_value=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.FloatTensor([init_value]))
+
+    def forward(self, input):
+        return input * self.scale
+
+
+def attach_arena(model, arena):
+    for m in model.modules():
+        m._arena = arena

@@ -1,0 +1,144 @@
+"""ResNet (18/34/50/101/152) bottom-up backbone on the HIP conv kernels, NHWC bf16.
+
+Restates detectron2's ``build_resnet_backbone`` semantics (source absent) that
+slender_det/modeling/backbone/fpn.py:103 calls: BasicStem (7x7 s2 + FrozenBN + ReLU + max-pool 3x3 s2),
+Bottleneck / Basic blocks with the stride on the first 1x1 (``STRIDE_IN_1X1``), FrozenBatchNorm2d folded into the
+convolution weights, ``FREEZE_AT`` stages without gradients, MSRA initialisation.
+"""
+import torch
+from torch import nn
+
+from ...layers.nn import HipConv2d, max_pool_3x3_s2
+from ..shape_spec import ShapeSpec
+from .build import BACKBONE_REGISTRY, Backbone
+
+
+class BasicStem(nn.Module):
+    def __init__(self, in_channels=3, out_channels=64):
+        super().__init__()
+        self.conv1 = HipConv2d(in_channels, out_channels, 7, 2, 3, bias=False, frozen_bn=True, relu=True, cin_pad=8)
+        self.conv1.init_msra()
+        self.out_channels, self.stride = out_channels, 4
+
+    def forward(self, x):
+        return max_pool_3x3_s2(self.conv1(x))
+
+
+class BottleneckBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, bottleneck_channels, stride=1, stride_in_1x1=True, dilation=1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        self.shortcut = None
+        if in_channels != out_channels:
+            self.shortcut = HipConv2d(in_channels, out_channels, 1, stride, 0, bias=False, frozen_bn=True)
+        # conv1's / conv2's ReLU outputs have a single consumer, so the consumer's dgrad applies their masks
+        self.conv1 = HipConv2d(in_channels, bottleneck_channels, 1, s1, 0, bias=False, frozen_bn=True, relu=True, grad_premasked=True)
+        self.conv2 = HipConv2d(bottleneck_channels, bottleneck_channels, 3, s3, dilation, dilation, bias=False, frozen_bn=True,
+                               relu=True, mask_input=True, grad_premasked=True)
+        self.conv3 = HipConv2d(bottleneck_channels, out_channels, 1, 1, 0, bias=False, frozen_bn=True, relu=True, mask_input=True)
+        for m in (self.conv1, self.conv2, self.conv3, self.shortcut):
+            if m is not None:
+                m.init_msra()
+
+    def forward(self, x):
+        sc = self.shortcut(x) if self.shortcut is not None else x
+        out = self.conv2(self.conv1(x))
+        return self.conv3(out, res=sc)     # relu(conv3 + shortcut) fused in the conv epilogue
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, stride=1):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        self.shortcut = None
+        if in_channels != out_channels:
+            self.shortcut = HipConv2d(in_channels, out_channels, 1, stride, 0, bias=False, frozen_bn=True)
+        self.conv1 = HipConv2d(in_channels, out_channels, 3, stride, 1, bias=False, frozen_bn=True, relu=True, grad_premasked=True)
+        self.conv2 = HipConv2d(out_channels, out_channels, 3, 1, 1, bias=False, frozen_bn=True, relu=True, mask_input=True)
+        for m in (self.conv1, self.conv2, self.shortcut):
+            if m is not None:
+                m.init_msra()
+
+    def forward(self, x):
+        sc = self.shortcut(x) if self.shortcut is not None else x
+        return self.conv2(self.conv1(x), res=sc)
+
+
+class ResNet(Backbone):
+    def __init__(self, stem, stages, out_features):
+        super().__init__()
+        self.stem = stem
+        self._out_feature_strides = {"stem": stem.stride}
+        self._out_feature_channels = {"stem": stem.out_channels}
+        self.stages_and_names = []
+        cur_stride = stem.stride
+        for i, blocks in enumerate(stages):
+            name = "res" + str(i + 2)
+            stage = nn.Sequential(*blocks)
+            self.add_module(name, stage)
+            self.stages_and_names.append((stage, name))
+            cur_stride = int(cur_stride * blocks[0].stride)
+            self._out_feature_strides[name] = cur_stride
+            self._out_feature_channels[name] = blocks[-1].out_channels
+        self._out_features = out_features
+
+    def forward(self, x):
+        outputs = {}
+        x = self.stem(x)
+        if "stem" in self._out_features:
+            outputs["stem"] = x
+        for stage, name in self.stages_and_names:
+            x = stage(x)
+            if name in self._out_features:
+                outputs[name] = x
+        return outputs
+
+    def freeze(self, freeze_at=0):
+        """FREEZE_AT: 1 = stem, 2 = stem + res2, ..."""
+        if freeze_at >= 1:
+            for p in self.stem.parameters():
+                p.requires_grad = False
+        for idx, (stage, _) in enumerate(self.stages_and_names, start=2):
+            if freeze_at >= idx:
+                for p in stage.parameters():
+                    p.requires_grad = False
+        return self
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_backbone(cfg, input_shape):
+    depth = cfg.MODEL.RESNETS.DEPTH
+    out_features = cfg.MODEL.RESNETS.OUT_FEATURES
+    norm = cfg.MODEL.RESNETS.NORM
+    if norm != "FrozenBN":
+        raise NotImplementedError(f"MODEL.RESNETS.NORM={norm}: only FrozenBN (the default the FCOS/RetinaNet configs use) is built")
+    if cfg.MODEL.RESNETS.NUM_GROUPS != 1:
+        raise NotImplementedError("grouped (ResNeXt) convolutions are not built")
+    if any(cfg.MODEL.RESNETS.DEFORM_ON_PER_STAGE):
+        raise NotImplementedError("DEFORM_ON_PER_STAGE backbones are not wired yet")
+    stem = BasicStem(input_shape.channels, cfg.MODEL.RESNETS.STEM_OUT_CHANNELS)
+    blocks_per_stage = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}[depth]
+    in_ch = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
+    out_ch = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS
+    bott = cfg.MODEL.RESNETS.NUM_GROUPS * cfg.MODEL.RESNETS.WIDTH_PER_GROUP
+    if depth in (18, 34):
+        assert out_ch == 64, "Must set MODEL.RESNETS.RES2_OUT_CHANNELS = 64 for R18/R34"
+    stage_names = ["res2", "res3", "res4", "res5"]
+    max_stage = max(stage_names.index(f) + 2 for f in out_features if f in stage_names)
+    stages = []
+    for idx, stage_idx in enumerate(range(2, max_stage + 1)):
+        dilation = cfg.MODEL.RESNETS.RES5_DILATION if stage_idx == 5 else 1
+        first_stride = 1 if idx == 0 or (stage_idx == 5 and dilation == 2) else 2
+        blocks = []
+        for b in range(blocks_per_stage[idx]):
+            stride = first_stride if b == 0 else 1
+            if depth in (18, 34):
+                blocks.append(BasicBlock(in_ch, out_ch, stride))
+            else:
+                blocks.append(BottleneckBlock(in_ch, out_ch, bott, stride, cfg.MODEL.RESNETS.STRIDE_IN_1X1, dilation))
+            in_ch = out_ch
+        out_ch *= 2
+        bott *= 2
+        stages.append(blocks)
+    return ResNet(stem, stages, out_features).freeze(cfg.MODEL.BACKBONE.FREEZE_AT)

@@ -1,0 +1,2 @@
+from .build import META_ARCH_REGISTRY, build_model
+from .fcos import FCOS, FCOSV2, FCOSHead

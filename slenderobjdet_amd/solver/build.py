@@ -1,0 +1,126 @@
+"""``slender_det.solver`` surface (reference: slender_det/solver/build.py:8-104) + the WarmupMultiStepLR schedule the
+configs name (detectron2).
+
+``build_optimizer`` keeps the reference's per-parameter grouping (norm weight decay, bias lr/decay) but, for
+``SOLVER.OPTIM == "SGD"`` on a model that owns a flat arena, returns :class:`FusedSGD`: ONE kernel launch updates
+every parameter (vs ~160 small per-tensor kernels) and the arena generation counter tells the convolutions to
+refresh their bf16 compute copies.
+"""
+import bisect
+from typing import Any, Dict, List, Optional, Set
+
+import torch
+import torch.nn as nn
+
+from .. import _C
+from .._C import call, ptr, stream_ptr
+from ..layers.nn import HipGroupNorm
+
+_NORM_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm, nn.GroupNorm, nn.InstanceNorm1d,
+               nn.InstanceNorm2d, nn.InstanceNorm3d, nn.LayerNorm, nn.LocalResponseNorm, HipGroupNorm)
+
+
+def get_default_optimizer_params(model, base_lr, weight_decay, weight_decay_norm, bias_lr_factor=1.0,
+                                 weight_decay_bias=None, overrides: Optional[Dict[str, Dict[str, float]]] = None):
+    """solver/build.py:36-104: one group per parameter; norm layers use WEIGHT_DECAY_NORM, biases BIAS_LR_FACTOR /
+    WEIGHT_DECAY_BIAS."""
+    if weight_decay_bias is None:
+        weight_decay_bias = weight_decay
+    params: List[Dict[str, Any]] = []
+    memo: Set[int] = set()
+    for module in model.modules():
+        for pname, value in module.named_parameters(recurse=False):
+            if not value.requires_grad or id(value) in memo:
+                continue
+            memo.add(id(value))
+            hp = {"lr": base_lr, "weight_decay": weight_decay}
+            if isinstance(module, _NORM_TYPES):
+                hp["weight_decay"] = weight_decay_norm
+            elif pname == "bias":
+                hp["lr"] = base_lr * bias_lr_factor
+                hp["weight_decay"] = weight_decay_bias
+            if overrides is not None and pname in overrides:
+                hp.update(overrides[pname])
+            params.append({"params": [value], "lr": hp["lr"], "weight_decay": hp["weight_decay"]})
+    return params
+
+
+class FusedSGD(torch.optim.Optimizer):
+    """torch.optim.SGD semantics (momentum, dampening 0, optional nesterov, L2 weight decay) over the flat arena."""
+
+    def __init__(self, params, lr, momentum=0.0, nesterov=False, arena=None):
+        if arena is None:
+            raise ValueError("FusedSGD needs the model's ParamArena")
+        super().__init__(params, dict(lr=lr, momentum=momentum, nesterov=nesterov, weight_decay=0.0))
+        self.arena = arena
+        self._base_lr0 = lr
+        self._segs, self._nseg = arena.build_segments(self.param_groups, lr)
+        self._steps = 0
+        self.grad_scale = 1.0
+        if momentum != 0:
+            arena.momentum = torch.zeros_like(arena.params)
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        # every group carries lr = base_lr(t) * its multiplier; read the schedule from the first group
+        g0 = self.param_groups[0]
+        mult0 = getattr(self, "_mult0", None)
+        if mult0 is None:
+            mult0 = self._mult0 = (g0["initial_lr"] if "initial_lr" in g0 else g0["lr"]) / self._base_lr0
+        lr_now = g0["lr"] / mult0 if mult0 else 0.0
+        a = self.arena
+        call("sod_sgd_step", ptr(a.params), ptr(a.grads), ptr(a.momentum), ptr(self._segs), self._nseg, None, float(lr_now),
+             float(g0["momentum"]), 1 if g0["nesterov"] else 0, 1 if self._steps == 0 else 0, float(self.grad_scale), stream_ptr())
+        self._steps += 1
+        a.bump()
+
+
+def build_optimizer(cfg, model):
+    params = get_default_optimizer_params(model, base_lr=cfg.SOLVER.BASE_LR, weight_decay=cfg.SOLVER.WEIGHT_DECAY,
+                                          weight_decay_norm=cfg.SOLVER.WEIGHT_DECAY_NORM, bias_lr_factor=cfg.SOLVER.BIAS_LR_FACTOR,
+                                          weight_decay_bias=cfg.SOLVER.WEIGHT_DECAY_BIAS)
+    optim = cfg.SOLVER.OPTIM
+    arena = getattr(model, "arena", None)
+    if optim == "SGD":
+        if arena is not None:
+            return FusedSGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, nesterov=cfg.SOLVER.NESTEROV, arena=arena)
+        return torch.optim.SGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, nesterov=cfg.SOLVER.NESTEROV)
+    if optim == "ADAM":
+        return torch.optim.Adam(params, cfg.SOLVER.BASE_LR)
+    if optim == "ADAMW":
+        return torch.optim.AdamW(params, cfg.SOLVER.BASE_LR)
+    if optim == "ADAGRAD":   # the reference passes an undefined name here (solver/build.py:31); use the config value
+        return torch.optim.Adagrad(params, cfg.SOLVER.BASE_LR, weight_decay=cfg.SOLVER.WEIGHT_DECAY)
+    raise ValueError(optim)
+
+
+class WarmupMultiStepLR(torch.optim.lr_scheduler._LRScheduler):
+    def __init__(self, optimizer, milestones, gamma=0.1, warmup_factor=0.001, warmup_iters=1000, warmup_method="linear", last_epoch=-1):
+        if not list(milestones) == sorted(milestones):
+            raise ValueError("Milestones should be a list of increasing integers. Got {}".format(milestones))
+        self.milestones, self.gamma = list(milestones), gamma
+        self.warmup_factor, self.warmup_iters, self.warmup_method = warmup_factor, warmup_iters, warmup_method
+        super().__init__(optimizer, last_epoch)
+
+    def _warm(self, it):
+        if it >= self.warmup_iters:
+            return 1.0
+        if self.warmup_method == "constant":
+            return self.warmup_factor
+        alpha = it / self.warmup_iters
+        return self.warmup_factor * (1 - alpha) + alpha
+
+    def get_lr(self):
+        w = self._warm(self.last_epoch)
+        return [b * w * self.gamma ** bisect.bisect_right(self.milestones, self.last_epoch) for b in self.base_lrs]
+
+
+def build_lr_scheduler(cfg, optimizer):
+    name = cfg.SOLVER.LR_SCHEDULER_NAME
+    if name != "WarmupMultiStepLR":
+        raise ValueError(f"Unknown LR scheduler: {name}")
+    return WarmupMultiStepLR(optimizer, cfg.SOLVER.STEPS, cfg.SOLVER.GAMMA, warmup_factor=cfg.SOLVER.WARMUP_FACTOR,
+                             warmup_iters=cfg.SOLVER.WARMUP_ITERS, warmup_method=cfg.SOLVER.WARMUP_METHOD)

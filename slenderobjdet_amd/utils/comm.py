@@ -1,0 +1,74 @@
+"""``detectron2.utils.comm`` surface used by the reference (train_net.py:23, engine/defaults.py:7, fcos/utils.py:10-19):
+rank / world size helpers, barrier, dict reduction.  One process per GPU; backend "nccl" is RCCL on ROCm."""
+import functools
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size() -> int:
+    return dist.get_world_size() if is_dist() else 1
+
+
+def get_rank() -> int:
+    return dist.get_rank() if is_dist() else 0
+
+
+def get_local_rank() -> int:
+    return int(os.environ.get("LOCAL_RANK", 0)) if is_dist() else 0
+
+
+def is_main_process() -> bool:
+    return get_rank() == 0
+
+
+def synchronize():
+    if get_world_size() > 1:
+        dist.barrier()
+
+
+def get_num_gpus():
+    """slender_det/modeling/meta_arch/fcos/utils.py:10-11 reads WORLD_SIZE from the environment."""
+    return int(os.environ["WORLD_SIZE"]) if "WORLD_SIZE" in os.environ else 1
+
+
+def reduce_sum(tensor):
+    """fcos/utils.py:14-19 (all_reduce SUM of a clone when world > 1)."""
+    if get_world_size() <= 1:
+        return tensor
+    tensor = tensor.clone()
+    dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+    return tensor
+
+
+def reduce_dict(input_dict, average=True):
+    """Reduce scalar tensors of a dict to rank 0 (d2 SimpleTrainer._write_metrics)."""
+    world = get_world_size()
+    if world < 2:
+        return input_dict
+    with torch.no_grad():
+        names = sorted(input_dict.keys())
+        values = torch.stack([input_dict[k].detach().float().reshape(()) for k in names], dim=0)
+        dist.reduce(values, dst=0)
+        if dist.get_rank() == 0 and average:
+            values /= world
+        return {k: v for k, v in zip(names, values)}
+
+
+@functools.lru_cache()
+def _gloo_group():
+    return dist.new_group(backend="gloo") if dist.get_backend() == "nccl" else dist.group.WORLD
+
+
+def gather(data, dst=0):
+    """Gather picklable objects on ``dst`` (evaluation only; slender_det/evaluation/coco_evaluation.py:83)."""
+    if get_world_size() == 1:
+        return [data]
+    out = [None] * get_world_size() if get_rank() == dst else None
+    dist.gather_object(data, out, dst=dst, group=_gloo_group())
+    return out if get_rank() == dst else []
