@@ -1,0 +1,209 @@
+"""Oracle FCOS detector (CPU, fp32, NCHW, plain torch): ResNet-FPN -> FCOSHead -> targets -> losses -> SGD.
+
+Restates the training step of slender_det/modeling/meta_arch/fcos/fcosv2.py:63-148 on top of the detectron2
+ResNet/FPN semantics of SURVEY.md Appendix C.9/C.10 (third-party source absent: "parity unpinned" for those parts;
+FCOSHead / targets / losses are pinned by tests/golden).  Also the ``cpu_baseline`` of bench.py.
+
+``emulate_bf16=True`` rounds weights and every stored activation to bf16 at the same points where the HIP path stores
+bf16, so that end-to-end comparisons isolate kernel errors from the precision the product path computes in.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import fcos_targets as ot
+from . import losses as ol
+
+
+def _rb(t, on):
+    return t.to(torch.bfloat16).to(torch.float32) if on else t
+
+
+class _RoundSTE(torch.autograd.Function):
+    """bf16 rounding with a rounded straight-through gradient (activation gradients are stored as bf16 too)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+class OracleFCOS:
+    """Functional model over a dict of fp32 tensors in torch layouts (conv weights KCRS)."""
+
+    def __init__(self, params, buffers, cfg_like, emulate_bf16=False):
+        self.p = params          # name -> tensor (requires_grad for trainable)
+        self.b = buffers         # frozen BN scale/shift per conv name
+        self.c = cfg_like        # dict of hyper-parameters
+        self.emu = emulate_bf16
+
+    # ------------------------------------------------------------------ construction from the HIP model
+    @classmethod
+    def from_hip_model(cls, model, emulate_bf16=False):
+        """Copy weights out of a slenderobjdet_amd FCOSV2 (any device) into torch-layout CPU tensors."""
+        from slenderobjdet_amd.layers.nn import HipConv2d, HipGroupNorm
+
+        params, buffers = {}, {}
+        for name, m in model.named_modules():
+            if isinstance(m, HipConv2d):
+                w = m.weight.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
+                params[name + ".weight"] = w.requires_grad_(m.weight.requires_grad)
+                if m.bias is not None:
+                    params[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(m.bias.requires_grad)
+                if m.frozen_bn:
+                    scale = m.bn_weight.float().cpu() * torch.rsqrt(m.bn_running_var.float().cpu() + 1e-5)
+                    shift = m.bn_bias.float().cpu() - m.bn_running_mean.float().cpu() * scale
+                    buffers[name + ".scale"], buffers[name + ".shift"] = scale, shift
+            elif isinstance(m, HipGroupNorm):
+                params[name + ".weight"] = m.weight.detach().float().cpu().clone().requires_grad_(True)
+                params[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(True)
+        params["head.scales"] = model.head.scales.detach().float().cpu().clone().requires_grad_(True)
+        res_names = [name for _, name in model.backbone.bottom_up.stages_and_names]
+        blocks = {n: len(getattr(model.backbone.bottom_up, n)) for n in res_names}
+        bottleneck = any(k.endswith("conv3.weight") for k in params)
+        cfg_like = dict(
+            blocks=blocks, bottleneck=bottleneck, num_classes=model.num_classes, strides=list(model.fpn_strides),
+            radius=model.center_sampling_radius, alpha=model.focal_loss_alpha, gamma=model.focal_loss_gamma,
+            iou_type=model.iou_loss_type, norm_reg=model.head.norm_reg_targets, ctr_on_reg=model.head.centerness_on_reg,
+            kc=model.head.kc, mean=[float(v) for v in model.pixel_mean.flatten()], std=[float(v) for v in model.pixel_std.flatten()],
+            num_convs=len(model.head.cls_tower), size_div=model.backbone.size_divisibility,
+            stride_in_1x1={n: [blk.conv1.stride for blk in getattr(model.backbone.bottom_up, n)] for n in res_names},
+            block_stride={n: [blk.stride for blk in getattr(model.backbone.bottom_up, n)] for n in res_names},
+        )
+        return cls(params, buffers, cfg_like, emulate_bf16)
+
+    # ------------------------------------------------------------------ layers
+    def _act(self, x):
+        return _RoundSTE.apply(x) if self.emu else x
+
+    def _conv(self, name, x, stride=1, pad=0, relu=False, res=None):
+        w = self.p[name + ".weight"]
+        bias = self.p.get(name + ".bias")
+        if name + ".scale" in self.b:      # FrozenBN folded the way the product path folds it
+            w = w * self.b[name + ".scale"].view(-1, 1, 1, 1)
+            bias = self.b[name + ".shift"] + (bias * self.b[name + ".scale"] if bias is not None else 0)
+        if self.emu:
+            w = _RoundSTE.apply(w)
+        y = F.conv2d(x, w, bias, stride=stride, padding=pad)
+        if res is not None:
+            y = y + res
+        if relu:
+            y = torch.relu(y)
+        return self._act(y)
+
+    def _bottom_up(self, x):
+        c = self.c
+        x = self._conv("backbone.bottom_up.stem.conv1", x, 2, 3, relu=True)
+        x = F.max_pool2d(x, 3, 2, 1)
+        outs = {}
+        for stage, nblk in c["blocks"].items():
+            for b in range(nblk):
+                pre = f"backbone.bottom_up.{stage}.{b}"
+                bs = c["block_stride"][stage][b]
+                sc = self._conv(pre + ".shortcut", x, bs, 0) if (pre + ".shortcut.weight") in self.p else x
+                if c["bottleneck"]:
+                    s1 = c["stride_in_1x1"][stage][b]
+                    y = self._conv(pre + ".conv1", x, s1, 0, relu=True)
+                    y = self._conv(pre + ".conv2", y, bs // s1, 1, relu=True)
+                    x = self._conv(pre + ".conv3", y, 1, 0, relu=True, res=sc)
+                else:
+                    y = self._conv(pre + ".conv1", x, bs, 1, relu=True)
+                    x = self._conv(pre + ".conv2", y, 1, 1, relu=True, res=sc)
+            outs[stage] = x
+        return outs
+
+    def _fpn(self, feats):
+        names = ["res5", "res4", "res3"]
+        stage_id = {"res3": 3, "res4": 4, "res5": 5}
+        prev, outs = None, {}
+        for n in names:
+            s = stage_id[n]
+            up = F.interpolate(prev, scale_factor=2, mode="nearest") if prev is not None else None
+            prev = self._conv(f"backbone.fpn_lateral{s}", feats[n], 1, 0, res=up)
+            outs[f"p{s}"] = self._conv(f"backbone.fpn_output{s}", prev, 1, 1)
+        p6 = self._conv("backbone.top_block.p6", outs["p5"], 2, 1)
+        p7 = self._conv("backbone.top_block.p7", self._act(torch.relu(p6)), 2, 1)
+        outs["p6"], outs["p7"] = p6, p7
+        return [outs[k] for k in ("p3", "p4", "p5", "p6", "p7")]
+
+    def _tower(self, prefix, x):
+        for i in range(self.c["num_convs"]):
+            y = self._conv(f"{prefix}.{i}.conv", x, 1, 1)
+            y = F.group_norm(y, 32, self.p[f"{prefix}.{i}.gn.weight"], self.p[f"{prefix}.{i}.gn.bias"], 1e-5)
+            x = self._act(torch.relu(y))
+        return x
+
+    def _head(self, feats):
+        """Returns flattened (N*L, K) logits, (N*L, 4) box predictions, (N*L,) centerness logits (fcosv2.py:358-380 +
+        permute_and_concat)."""
+        c = self.c
+        K, kc = c["num_classes"], c["kc"]
+        cls_all, box_all, ctr_all = [], [], []
+        for lvl, f in enumerate(feats):
+            ct, bt = self._tower("head.cls_tower", f), self._tower("head.bbox_tower", f)
+            wc, bc = self.p["head.cls_pred.weight"], self.p["head.cls_pred.bias"]
+            wb, bb = self.p["head.box_pred.weight"], self.p["head.box_pred.bias"]
+            if self.emu:
+                wc, wb = _RoundSTE.apply(wc), _RoundSTE.apply(wb)
+            co = F.conv2d(ct, wc[:kc], bc[:kc], padding=1)
+            bo = F.conv2d(bt, wb[:5 if c["ctr_on_reg"] else 4], bb[:5 if c["ctr_on_reg"] else 4], padding=1)
+            logits = co[:, :K]
+            ctr = bo[:, 4:5] if c["ctr_on_reg"] else co[:, K:K + 1]
+            z = bo[:, :4] * self.p["head.scales"][lvl]
+            box = torch.relu(z) * c["strides"][lvl] if c["norm_reg"] else torch.exp(z)
+            N = f.shape[0]
+            cls_all.append(logits.permute(0, 2, 3, 1).reshape(N, -1, K))
+            box_all.append(box.permute(0, 2, 3, 1).reshape(N, -1, 4))
+            ctr_all.append(ctr.permute(0, 2, 3, 1).reshape(N, -1))
+        return torch.cat(cls_all, 1).reshape(-1, K), torch.cat(box_all, 1).reshape(-1, 4), torch.cat(ctr_all, 1).reshape(-1)
+
+    # ------------------------------------------------------------------ step
+    def preprocess(self, batched_inputs):
+        c = self.c
+        imgs = [(x["image"].float().cpu() - torch.tensor(c["mean"]).view(-1, 1, 1)) / torch.tensor(c["std"]).view(-1, 1, 1) for x in batched_inputs]
+        mh, mw = max(i.shape[1] for i in imgs), max(i.shape[2] for i in imgs)
+        d = c["size_div"]
+        mh, mw = (mh + d - 1) // d * d, (mw + d - 1) // d * d
+        batch = torch.zeros(len(imgs), 3, mh, mw)
+        for i, im in enumerate(imgs):
+            batch[i, :, : im.shape[1], : im.shape[2]] = im
+        return _rb(batch, self.emu)
+
+    def losses(self, batched_inputs, world=1):
+        c = self.c
+        x = self.preprocess(batched_inputs)
+        feats = self._fpn(self._bottom_up(x))
+        level_hw = [tuple(f.shape[2:]) for f in feats]
+        boxes = [b["instances"].gt_boxes.tensor.float().cpu() for b in batched_inputs]
+        classes = [b["instances"].gt_classes.cpu() for b in batched_inputs]
+        labels, reg_t = ot.targets_for_batch(level_hw, c["strides"], boxes, classes, c["radius"], c["num_classes"])
+        cls, box, ctr = self._head(feats)
+        return ol.fcos_losses(labels.reshape(-1), reg_t.reshape(-1, 4), cls, box, ctr, c["num_classes"], c["alpha"], c["gamma"],
+                              c["iou_type"], world)
+
+    def trainable(self):
+        return {k: v for k, v in self.p.items() if v.requires_grad}
+
+    def sgd_step(self, grads, state, lr, momentum=0.9, wd=1e-4, wd_norm=0.0):
+        """torch.optim.SGD with the reference's per-parameter weight decay (solver/build.py:36-104)."""
+        with torch.no_grad():
+            for k, p in self.trainable().items():
+                g = grads[k]
+                decay = wd_norm if ".gn." in k else wd
+                d = g + decay * p
+                if momentum:
+                    buf = state.get(k)
+                    buf = d.clone() if buf is None else momentum * buf + d
+                    state[k] = buf
+                    d = buf
+                p -= lr * d
+
+
+def random_batch_cpu(n, h, w, seed):
+    from slenderobjdet_amd.data import synthetic_batch
+
+    return synthetic_batch(n, h, w, seed, device="cpu")

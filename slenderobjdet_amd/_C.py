@@ -69,6 +69,10 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C slenderobjdet_amd/csrc). There is no CPU fallback for the HIP ops."
         )
+    # torch ships its own libamdhip64; it must be in the process BEFORE our library is dlopen'ed so that both bind to
+    # the same HIP runtime (otherwise our launches see "no device": two runtimes, two contexts)
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it

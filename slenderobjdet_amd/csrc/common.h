@@ -69,3 +69,6 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
 }
 
 #define SOD_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// Launch + error attribution: clear any stale (sticky-less) error left by other HIP users in this thread first.
+#define SOD_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)

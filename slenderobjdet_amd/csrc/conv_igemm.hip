@@ -396,7 +396,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.nq_tiles * a.np_tiles), dim3(256), lds, st, a);
+  SOD_LAUNCH(kern, dim3(a.nq_tiles * a.np_tiles), dim3(256), lds, st, a);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -532,7 +532,7 @@ extern "C" int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const 
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(a.nz * tiles), dim3(256), lds, (hipStream_t)stream, a);
+  SOD_LAUNCH(conv_wgrad_kernel, dim3(a.nz * tiles), dim3(256), lds, (hipStream_t)stream, a);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

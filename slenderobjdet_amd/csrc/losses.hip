@@ -407,8 +407,8 @@ extern "C" int sod_sigmoid_focal_loss_fwd(const float* logits, const int* labels
   if (!logits || (!labels && !dense_targets) || !sum_out || !ws || M < 0 || K <= 0 || ld < K) return SOD_EARG;
   hipStream_t st = (hipStream_t)stream;
   const int g = grid_for(M * K);
-  hipLaunchKernelGGL(focal_fwd_kernel, dim3(g), dim3(256), 0, st, logits, labels, dense_targets, M, K, ld, alpha, gamma, elem_out, ws);
-  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, g, 1, sum_out, 0);
+  SOD_LAUNCH(focal_fwd_kernel, dim3(g), dim3(256), 0, st, logits, labels, dense_targets, M, K, ld, alpha, gamma, elem_out, ws);
+  SOD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, g, 1, sum_out, 0);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -421,9 +421,9 @@ extern "C" int sod_sigmoid_focal_loss_bwd(const float* logits, const int* labels
   hipStream_t st = (hipStream_t)stream;
   const int g = grid_for(M * ld_out) * 2;
   if (out_bf16)
-    hipLaunchKernelGGL(focal_bwd_kernel<true>, dim3(g), dim3(256), 0, st, logits, labels, dense_targets, M, K, ld, alpha, gamma, scale_num, scale_den, den_mul, den_min, dlogits, ld_out);
+    SOD_LAUNCH(focal_bwd_kernel<true>, dim3(g), dim3(256), 0, st, logits, labels, dense_targets, M, K, ld, alpha, gamma, scale_num, scale_den, den_mul, den_min, dlogits, ld_out);
   else
-    hipLaunchKernelGGL(focal_bwd_kernel<false>, dim3(g), dim3(256), 0, st, logits, labels, dense_targets, M, K, ld, alpha, gamma, scale_num, scale_den, den_mul, den_min, dlogits, ld_out);
+    SOD_LAUNCH(focal_bwd_kernel<false>, dim3(g), dim3(256), 0, st, logits, labels, dense_targets, M, K, ld, alpha, gamma, scale_num, scale_den, den_mul, den_min, dlogits, ld_out);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -433,8 +433,8 @@ extern "C" int sod_iou_loss_fwd(const float* pred, const float* target, const fl
   if (!pred || !target || !sum_out || !ws || P < 0 || loss_type < 0 || loss_type > 2) return SOD_EARG;
   hipStream_t st = (hipStream_t)stream;
   const int g = grid_for(P);
-  hipLaunchKernelGGL(iou_fwd_kernel, dim3(g), dim3(256), 0, st, pred, target, weight, mask, mask_bg, P, loss_type, elem_out, ws);
-  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, g, 1, sum_out, 0);
+  SOD_LAUNCH(iou_fwd_kernel, dim3(g), dim3(256), 0, st, pred, target, weight, mask, mask_bg, P, loss_type, elem_out, ws);
+  SOD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, g, 1, sum_out, 0);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -442,7 +442,7 @@ extern "C" int sod_iou_loss_fwd(const float* pred, const float* target, const fl
 extern "C" int sod_iou_loss_bwd(const float* pred, const float* target, const float* weight, const int* mask, int mask_bg,
                                 long long P, int loss_type, const float* grad_scale, float* dpred, void* stream) {
   if (!pred || !target || !dpred || P < 0 || loss_type < 0 || loss_type > 2) return SOD_EARG;
-  hipLaunchKernelGGL(iou_bwd_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, pred, target, weight, mask, mask_bg, P, loss_type, grad_scale, dpred);
+  SOD_LAUNCH(iou_bwd_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, pred, target, weight, mask, mask_bg, P, loss_type, grad_scale, dpred);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -469,8 +469,8 @@ extern "C" int sod_fcos_assign(const float* boxes, const int* classes, const int
   if (gx * N > RED_BLOCKS) gx = RED_BLOCKS / N;
   if (gx < 1) return SOD_EARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(fcos_assign_kernel, dim3(gx, N), dim3(256), 0, st, a, ws);
-  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, gx * N, 2, stats, 0);
+  SOD_LAUNCH(fcos_assign_kernel, dim3(gx, N), dim3(256), 0, st, a, ws);
+  SOD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, gx * N, 2, stats, 0);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -498,8 +498,8 @@ extern "C" int sod_fcos_regctr_loss_fwd(const float* box_raw, int ld_box, const 
   a.type = loss_type; a.norm_reg = norm_reg_targets;
   hipStream_t st = (hipStream_t)stream;
   const int g = grid_for(a.M);
-  hipLaunchKernelGGL(regctr_fwd_kernel, dim3(g), dim3(256), 0, st, a, ws);
-  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, g, 2, sums, 0);
+  SOD_LAUNCH(regctr_fwd_kernel, dim3(g), dim3(256), 0, st, a, ws);
+  SOD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, g, 2, sums, 0);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -522,9 +522,9 @@ extern "C" int sod_fcos_regctr_loss_bwd(const float* box_raw, int ld_box, const 
   a.type = loss_type; a.norm_reg = norm_reg_targets;
   hipStream_t st = (hipStream_t)stream;
   const int g = grid_for(a.M);
-  hipLaunchKernelGGL(regctr_bwd_kernel, dim3(g), dim3(256), 0, st, a, grad_reg, grad_ctr, norm, inv_world, (__bf16*)dbox, ld_out, ctr_col,
+  SOD_LAUNCH(regctr_bwd_kernel, dim3(g), dim3(256), 0, st, a, grad_reg, grad_ctr, norm, inv_world, (__bf16*)dbox, ld_out, ctr_col,
                      (__bf16*)dctr, ld_dctr, dctr_col, ws);
-  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, g, nlevels, dscales, 1);
+  SOD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, g, nlevels, dscales, 1);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -532,7 +532,7 @@ extern "C" int sod_fcos_regctr_loss_bwd(const float* box_raw, int ld_box, const 
 extern "C" int sod_fcos_finalize_losses(const float* focal_sum, const float* regctr_sums, const float* stats,
                                         float inv_world, float* out3, void* stream) {
   if (!focal_sum || !regctr_sums || !stats || !out3) return SOD_EARG;
-  hipLaunchKernelGGL(fcos_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, focal_sum, regctr_sums, stats, inv_world, out3);
+  SOD_LAUNCH(fcos_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, focal_sum, regctr_sums, stats, inv_world, out3);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

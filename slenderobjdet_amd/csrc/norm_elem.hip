@@ -88,10 +88,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnArgs a) {
-  extern __shared__ float lsum[];   // [G][2]
+  extern __shared__ float lsum[];   // [G][2] group sums, then [C][2] per-channel (dgamma, dbeta) partials
   const int n = blockIdx.y;
   const int c8n = a.C >> 3;
-  for (int i = threadIdx.x; i < a.G * 2; i += 256) lsum[i] = 0.f;
+  float* lgrp = lsum;
+  float* lch = lsum + a.G * 2;
+  for (int i = threadIdx.x; i < a.G * 2 + a.C * 2; i += 256) lsum[i] = 0.f;
   __syncthreads();
   const int rows_per_iter = 256 / c8n;
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
@@ -116,15 +118,19 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnArgs a) {
       s1 += d * gm[e]; s2 += d * gm[e] * xh;
     }
   }
-  atomicAdd(&lsum[g * 2], s1);
-  atomicAdd(&lsum[g * 2 + 1], s2);
+  atomicAdd(&lgrp[g * 2], s1);
+  atomicAdd(&lgrp[g * 2 + 1], s2);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {   // per-channel parameter gradients (fp32 accumulation in the grad arena)
-    atomicAdd(a.dgamma + c8 * 8 + e, dg[e]);
-    atomicAdd(a.dbeta + c8 * 8 + e, db[e]);
+  for (int e = 0; e < 8; ++e) {   // block-level reduction in LDS first: one global atomic per channel per block
+    atomicAdd(&lch[(c8 * 8 + e) * 2], dg[e]);
+    atomicAdd(&lch[(c8 * 8 + e) * 2 + 1], db[e]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < a.G * 2; i += 256) atomicAdd(a.red + (long long)n * a.G * 2 + i, lsum[i]);
+  for (int i = threadIdx.x; i < a.G * 2; i += 256) atomicAdd(a.red + (long long)n * a.G * 2 + i, lgrp[i]);
+  for (int i = threadIdx.x; i < a.C; i += 256) {   // fp32 accumulation into the grad arena
+    atomicAdd(a.dgamma + i, lch[i * 2]);
+    atomicAdd(a.dbeta + i, lch[i * 2 + 1]);
+  }
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a, float inv_m) {
@@ -373,7 +379,7 @@ int gn_check(int N, int HW, int C, int G) {
 
 int gn_grid(int HW, int N, int& ppb) {
   // ~2048 blocks in total
-  int gx = 2048 / (N > 0 ? N : 1);
+  int gx = 1024 / (N > 0 ? N : 1);
   if (gx < 1) gx = 1;
   ppb = (HW + gx - 1) / gx;
   if (ppb < 64) ppb = 64;
@@ -395,10 +401,10 @@ extern "C" int sod_groupnorm_fwd(const void* x, const float* gamma, const float*
   const int gx = gn_grid(HW, N, a.pix_per_block);
   hipError_t e = hipMemsetAsync(mean_rstd, 0, sizeof(float) * 2 * N * G, st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * G, st, a);
-  hipLaunchKernelGGL(gn_finalize_stats_kernel, dim3((N * G + 255) / 256), dim3(256), 0, st, mean_rstd, N * G,
+  SOD_LAUNCH(gn_stats_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * G, st, a);
+  SOD_LAUNCH(gn_finalize_stats_kernel, dim3((N * G + 255) / 256), dim3(256), 0, st, mean_rstd, N * G,
                      1.f / ((float)HW * (float)a.cpg), eps);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(gx, N), dim3(256), 0, st, a);
+  SOD_LAUNCH(gn_apply_kernel, dim3(gx, N), dim3(256), 0, st, a);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -418,29 +424,29 @@ extern "C" int sod_groupnorm_bwd(const void* dy, const void* x, const float* gam
   const int gx = gn_grid(HW, N, a.pix_per_block);
   hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * N * G, st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * G, st, a);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), 0, st, a, 1.f / ((float)HW * (float)a.cpg));
+  SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * (G + C), st, a);
+  SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), 0, st, a, 1.f / ((float)HW * (float)a.cpg));
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
 
 extern "C" int sod_relu_bwd(const void* dy, const void* y, void* dx, long long n, void* stream) {
   if (!dy || !y || !dx || n < 0 || (n & 7)) return SOD_EARG;
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, (const __bf16*)y, (__bf16*)dx, n / 8);
+  SOD_LAUNCH(relu_bwd_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, (const __bf16*)y, (__bf16*)dx, n / 8);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
 
 extern "C" int sod_relu_fwd(const void* x, void* y, long long n, void* stream) {
   if (!x || !y || n < 0 || (n & 7)) return SOD_EARG;
-  hipLaunchKernelGGL(relu_fwd_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, n / 8);
+  SOD_LAUNCH(relu_fwd_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, n / 8);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
 
 extern "C" int sod_add_bf16(const void* a, const void* b, void* out, long long n, void* stream) {
   if (!a || !b || !out || n < 0 || (n & 7)) return SOD_EARG;
-  hipLaunchKernelGGL(add_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, (const __bf16*)b, (__bf16*)out, n / 8);
+  SOD_LAUNCH(add_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, (const __bf16*)b, (__bf16*)out, n / 8);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -452,7 +458,7 @@ extern "C" int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C,
   if (c8n > 256) return SOD_EARG;
   int ppb;
   const int gx = gn_grid(HW, N, ppb);
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(gx, N), dim3(256), sizeof(float) * C, (hipStream_t)stream, (const __bf16*)dy, dbias, HW, C, img_stride, ppb);
+  SOD_LAUNCH(channel_sum_kernel, dim3(gx, N), dim3(256), sizeof(float) * C, (hipStream_t)stream, (const __bf16*)dy, dbias, HW, C, img_stride, ppb);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -460,7 +466,7 @@ extern "C" int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C,
 extern "C" int sod_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, void* stream) {
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return SOD_EARG;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks_for((long long)N * Ho * Wo * (C / 8), 16384)), dim3(256), 0, (hipStream_t)stream,
+  SOD_LAUNCH(maxpool3x3s2_kernel, dim3(blocks_for((long long)N * Ho * Wo * (C / 8), 16384)), dim3(256), 0, (hipStream_t)stream,
                      (const __bf16*)x, (__bf16*)y, N, H, W, C, Ho, Wo);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
@@ -468,7 +474,7 @@ extern "C" int sod_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int
 
 extern "C" int sod_upsample2x_bwd(const void* g, void* dprev, int N, int Hc, int Wc, int C, void* stream) {
   if (!g || !dprev || N <= 0 || Hc <= 0 || Wc <= 0 || C <= 0 || (C & 7)) return SOD_EARG;
-  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(blocks_for((long long)N * Hc * Wc * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+  SOD_LAUNCH(upsample2x_bwd_kernel, dim3(blocks_for((long long)N * Hc * Wc * (C / 8))), dim3(256), 0, (hipStream_t)stream,
                      (const __bf16*)g, (__bf16*)dprev, N, Hc, Wc, C);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
@@ -476,7 +482,7 @@ extern "C" int sod_upsample2x_bwd(const void* g, void* dprev, int N, int Hc, int
 
 extern "C" int sod_weight_prep(const float* w, const float* scale, void* w_krsc, void* w_crsk, int K, int RS, int C, int Cpad, void* stream) {
   if (!w || (!w_krsc && !w_crsk) || K <= 0 || RS <= 0 || C <= 0 || Cpad < C) return SOD_EARG;
-  hipLaunchKernelGGL(weight_prep_kernel, dim3(blocks_for((long long)K * RS * C)), dim3(256), 0, (hipStream_t)stream, w, scale,
+  SOD_LAUNCH(weight_prep_kernel, dim3(blocks_for((long long)K * RS * C)), dim3(256), 0, (hipStream_t)stream, w, scale,
                      (__bf16*)w_krsc, (__bf16*)w_crsk, K, RS, C, Cpad);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
@@ -484,7 +490,7 @@ extern "C" int sod_weight_prep(const float* w, const float* scale, void* w_krsc,
 
 extern "C" int sod_scale_rows(float* g, const float* scale, int K, long long row, void* stream) {
   if (!g || !scale || K <= 0 || row <= 0) return SOD_EARG;
-  hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks_for((long long)K * row)), dim3(256), 0, (hipStream_t)stream, g, scale, K, row);
+  SOD_LAUNCH(scale_rows_kernel, dim3(blocks_for((long long)K * row)), dim3(256), 0, (hipStream_t)stream, g, scale, K, row);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -492,7 +498,7 @@ extern "C" int sod_scale_rows(float* g, const float* scale, int K, long long row
 extern "C" int sod_sgd_step(float* params, const float* grads, float* momentum_buf, const void* segments_dev, int nseg,
                             const float* lr_dev, float lr, float momentum, int nesterov, int first_step, float grad_scale, void* stream) {
   if (!params || !grads || !segments_dev || nseg <= 0 || (momentum != 0.f && !momentum_buf)) return SOD_EARG;
-  hipLaunchKernelGGL(sgd_kernel, dim3(512, nseg), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf,
+  SOD_LAUNCH(sgd_kernel, dim3(512, nseg), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf,
                      (const SgdSeg*)segments_dev, nseg, lr_dev, lr, momentum, nesterov, first_step, grad_scale);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
@@ -503,10 +509,10 @@ extern "C" int sod_preprocess_image(const void* img, int is_uint8, int C, int H,
   if (!img || !out || C <= 0 || C > 3 || H <= 0 || W <= 0 || Hp < H || Wp < W || Cpad != 8 || !mean3 || !std3) return SOD_EARG;
   const int g = blocks_for((long long)Hp * Wp);
   if (is_uint8)
-    hipLaunchKernelGGL(preprocess_kernel<uint8_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)img, C, H, W, (__bf16*)out, Hp, Wp, Cpad,
+    SOD_LAUNCH(preprocess_kernel<uint8_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)img, C, H, W, (__bf16*)out, Hp, Wp, Cpad,
                        mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
   else
-    hipLaunchKernelGGL(preprocess_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)img, C, H, W, (__bf16*)out, Hp, Wp, Cpad,
+    SOD_LAUNCH(preprocess_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)img, C, H, W, (__bf16*)out, Hp, Wp, Cpad,
                        mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
@@ -514,7 +520,7 @@ extern "C" int sod_preprocess_image(const void* img, int is_uint8, int C, int H,
 
 extern "C" int sod_nchw_f32_to_nhwc_bf16(const float* x, void* y, int N, int C, int HW, void* stream) {
   if (!x || !y || N <= 0 || C <= 0 || HW <= 0) return SOD_EARG;
-  hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3(blocks_for((long long)N * C * HW)), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y, N, C, HW);
+  SOD_LAUNCH(nchw_f32_to_nhwc_bf16_kernel, dim3(blocks_for((long long)N * C * HW)), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y, N, C, HW);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -11,6 +11,26 @@ from .. import _C
 from .._C import call, ptr, stream_ptr
 
 IOU_TYPES = {"iou": 0, "linear_iou": 1, "giou": 2}
+
+# Optional per-launch timing of the convolution kernels (bench.py roofline): a list that receives
+# (kind, algorithmic_flops, start_event, end_event); events are recorded on the stream the kernel is launched on.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(kind, flops, e0):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.append((kind, flops, e0, e1))
 CONV_RELU = 1
 CONV_RES_UP2 = 2
 
@@ -58,8 +78,10 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
     if out is None:
         out = torch.empty((N, Ho, Wo, K), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     flags = (CONV_RELU if relu else 0) | (CONV_RES_UP2 if res_up2 else 0)
+    e0 = _prof_begin()
     call("sod_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
          x_img_stride, y_img_stride, 0, flags, 1 if out_f32 else 0, stream_ptr())
+    _prof_end("conv_fwd", 2.0 * N * Ho * Wo * K * R * S * C, e0)
     return out
 
 
@@ -71,8 +93,11 @@ def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=Non
     H, W = x_hw
     if out is None:
         out = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=dy.device)
+    e0 = _prof_begin()
     call("sod_conv2d_dgrad", ptr(dy), ptr(wt), ptr(accum), ptr(relu_mask), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
          dy_img_stride, 0, stream_ptr())
+    Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
+    _prof_end("conv_dgrad", 2.0 * N * Ho * Wo * K * R * S * C, e0)
     return out
 
 
@@ -82,8 +107,11 @@ def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img
     N, H, W, C = x_shape if x_shape is not None else x.shape
     if K is None:
         K = dy.shape[-1]
+    e0 = _prof_begin()
     call("sod_conv2d_wgrad", ptr(dy), ptr(x), ptr(dw), ptr(qscale), N, H, W, C, K, R, S, stride, pad, dil, dy_img_stride, x_img_stride,
          splits, stream_ptr())
+    Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
+    _prof_end("conv_wgrad", 2.0 * N * Ho * Wo * K * R * S * C, e0)
     return dw
 
 
