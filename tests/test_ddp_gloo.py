@@ -1,0 +1,82 @@
+"""world_size-2 data-parallel gradient exchange on CPU (gloo): the arena's bucketed all-reduce, launched from the
+backward-side ``mark_ready`` notifications, must leave the SUM of the per-rank gradients on every rank; and the folded
+(num_pos, sum_ctr) normaliser all-reduce must match the reference's two reduce_sum calls (fcos/utils.py:14-19)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from slenderobjdet_amd.layers.arena import ParamArena
+        from slenderobjdet_amd.utils import comm
+
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(300, 200), torch.nn.Linear(200, 100), torch.nn.Linear(100, 50), torch.nn.Linear(50, 10))
+        arena = ParamArena(model, bucket_mb=0.01)   # several buckets
+        assert len(arena.buckets) >= 3
+        params = [p for p in model.parameters()]
+        # forward "uses": last layer used twice (like the head weights shared by FPN levels)
+        for p in params:
+            arena.note_use(p)
+        for p in params[-2:]:
+            arena.note_use(p)
+        arena.zero_grad()
+        arena.begin_backward()
+        g = torch.Generator().manual_seed(100 + rank)
+        expect = {}
+        for use in range(2):
+            for p in reversed(params):
+                if use == 1 and not any(p is q for q in params[-2:]):
+                    continue
+                contrib = torch.randn(p.shape, generator=g)
+                arena.grad_view(p).add_(contrib)
+                expect[id(p)] = expect.get(id(p), 0) + contrib
+                arena.mark_ready(p)
+        arena.finish_backward()
+        # every rank now holds the sum over ranks; rebuild the expectation with an explicit all_reduce
+        ok = True
+        for p in params:
+            e = expect[id(p)].clone()
+            dist.all_reduce(e)
+            ok = ok and torch.allclose(arena.grad_view(p), e, atol=1e-6)
+        # normaliser exchange: one 2-element all-reduce == two scalar reduce_sum calls
+        stats = torch.tensor([3.0 + rank, 1.5 * (rank + 1)])
+        folded = stats.clone()
+        dist.all_reduce(folded)
+        a = comm.reduce_sum(stats[0:1].clone())
+        b = comm.reduce_sum(stats[1:2].clone())
+        ok = ok and torch.allclose(folded, torch.cat([a, b])) and comm.get_world_size() == 2 and comm.get_num_gpus() == 2
+        out.put((rank, bool(ok)))
+    except Exception as e:   # surface the failure instead of letting the parent time out
+        out.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_arena_bucketed_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(0, True), (1, True)]

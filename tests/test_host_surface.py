@@ -1,0 +1,134 @@
+"""Host-side mirrors of the reference interfaces: config loading, registries, structures, optimizer grouping, synthetic data.
+CPU only."""
+import os
+
+import pytest
+import torch
+
+from slenderobjdet_amd.config import CfgNode, fresh_cfg, get_cfg
+
+CFG_DIR = os.path.join(os.path.dirname(__file__), "golden", "configs")
+
+
+def _write(tmp_path, name, text):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+def test_cfg_base_inheritance_and_overrides(tmp_path):
+    _write(tmp_path, "Base.yaml", 'MODEL:\n  META_ARCHITECTURE: "FCOS"\n  RESNETS:\n    OUT_FEATURES: ["res3", "res4", "res5"]\nSOLVER:\n  STEPS: (60000, 80000)\nDATASETS:\n  TRAIN: ("coco_2017_train",)\n')
+    leaf = _write(tmp_path, "leaf.yaml", '_BASE_: "Base.yaml"\nMODEL:\n  META_ARCHITECTURE: "FCOSV2"\n  FCOS:\n    CENTER_SAMPLING_RADIUS: 1.5\n    IOU_LOSS_TYPE: "giou"\n')
+    cfg = fresh_cfg()
+    cfg.merge_from_file(leaf)
+    assert cfg.MODEL.META_ARCHITECTURE == "FCOSV2" and cfg.MODEL.FCOS.CENTER_SAMPLING_RADIUS == 1.5
+    assert cfg.SOLVER.STEPS == (60000, 80000) and cfg.DATASETS.TRAIN == ("coco_2017_train",)
+    cfg.merge_from_list(["MODEL.RESNETS.DEPTH", "18", "SOLVER.BASE_LR", "0.02", "MODEL.DEVICE", "cpu"])
+    assert cfg.MODEL.RESNETS.DEPTH == 18 and cfg.SOLVER.BASE_LR == 0.02 and cfg.MODEL.DEVICE == "cpu"
+    with pytest.raises(KeyError):
+        cfg.merge_from_list(["MODEL.NOPE", 1])
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.SEED = 3
+    c2 = cfg.clone()
+    c2.defrost()
+    c2.SEED = 3
+    assert cfg.SEED == -1
+    assert "FCOSV2" in cfg.dump()
+
+
+def test_cfg_eval_tag_and_global_aliasing(tmp_path):
+    p = _write(tmp_path, "r.yaml", 'MODEL:\n  ANCHOR_GENERATOR:\n    SIZES: !!python/object/apply:eval ["[[x, x * 2**(1.0/3), x * 2**(2.0/3) ] for x in [32, 64, 128, 256, 512 ]]"]\n')
+    cfg = fresh_cfg()
+    cfg.merge_from_file(p)
+    assert len(cfg.MODEL.ANCHOR_GENERATOR.SIZES) == 5 and abs(cfg.MODEL.ANCHOR_GENERATOR.SIZES[0][1] - 32 * 2 ** (1 / 3)) < 1e-9
+    assert get_cfg() is get_cfg()   # the reference returns the shared global (slender_det/config.py:213-220)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="reference tree only exists in the build container")
+def test_reference_configs_load_unchanged():
+    import glob
+
+    known_broken = {"base_X_101_32x8d_FPN_2x.yaml", "point_rpn_R_50_FPN_1x.yaml", "rep_points_rpn_R_50_FPN_1x.yaml"}   # broken upstream too
+    n = 0
+    for f in glob.glob("/root/reference/configs/**/*.yaml", recursive=True):
+        if os.path.basename(f) in known_broken:
+            continue
+        fresh_cfg().merge_from_file(f)
+        n += 1
+    assert n >= 100
+
+
+def test_registry_and_build_model_cpu():
+    from slenderobjdet_amd.modeling import BACKBONE_REGISTRY, META_ARCH_REGISTRY, build_model
+
+    for name in ("FCOS", "FCOSV2"):
+        assert name in META_ARCH_REGISTRY
+    for name in ("build_resnet_backbone", "build_retinanet_resnet_fpn_backbone", "build_retinanet_resnet_fpn_backbone_use_p5"):
+        assert name in BACKBONE_REGISTRY
+    cfg = fresh_cfg()
+    cfg.MODEL.META_ARCHITECTURE = "FCOSV2"
+    cfg.MODEL.BACKBONE.NAME = "build_retinanet_resnet_fpn_backbone_use_p5"
+    cfg.MODEL.RESNETS.OUT_FEATURES = ["res3", "res4", "res5"]
+    cfg.MODEL.FPN.IN_FEATURES = ["res3", "res4", "res5"]
+    cfg.MODEL.DEVICE = "cpu"
+    m = build_model(cfg)
+    assert m.head.num_logical_params() == 4920666            # FCOSHead alone = 4 920 666 params
+    shapes = m.backbone.output_shape()
+    assert [shapes[k].stride for k in ("p3", "p4", "p5", "p6", "p7")] == [8, 16, 32, 64, 128] and m.backbone.size_divisibility == 32
+    frozen = [n for n, p in m.named_parameters() if not p.requires_grad]
+    assert all(n.startswith(("backbone.bottom_up.stem", "backbone.bottom_up.res2")) for n in frozen) and frozen   # FREEZE_AT 2
+    # the product path refuses to run without the GPU library path (no CPU fallback)
+    from slenderobjdet_amd import _C
+    from slenderobjdet_amd.data import synthetic_batch
+
+    with pytest.raises(_C.SlenderHipError):
+        m(synthetic_batch(1, 64, 64, 0))
+
+
+def test_optimizer_param_groups_follow_reference_rules():
+    from slenderobjdet_amd.layers.nn import ConvGnRelu
+    from slenderobjdet_amd.solver import get_default_optimizer_params
+
+    unit = ConvGnRelu(32)
+    groups = get_default_optimizer_params(unit, base_lr=0.1, weight_decay=1e-4, weight_decay_norm=0.0, bias_lr_factor=2.0, weight_decay_bias=5e-5)
+    by_id = {id(g["params"][0]): g for g in groups}
+    assert by_id[id(unit.conv.weight)]["weight_decay"] == 1e-4 and by_id[id(unit.conv.weight)]["lr"] == 0.1
+    assert by_id[id(unit.conv.bias)]["weight_decay"] == 5e-5 and by_id[id(unit.conv.bias)]["lr"] == 0.2
+    assert by_id[id(unit.gn.weight)]["weight_decay"] == 0.0 and by_id[id(unit.gn.bias)]["weight_decay"] == 0.0
+
+
+def test_structures():
+    from slenderobjdet_amd.structures import Boxes, ImageList, Instances, pairwise_iou
+
+    b = Boxes(torch.tensor([[0.0, 0.0, 10.0, 10.0], [5.0, 5.0, 15.0, 15.0]]))
+    assert torch.allclose(b.area(), torch.tensor([100.0, 100.0]))
+    assert torch.allclose(pairwise_iou(b, b)[0, 1], torch.tensor(25.0 / 175.0))
+    inst = Instances((20, 30), gt_boxes=b, gt_classes=torch.tensor([1, 2]))
+    assert len(inst[inst.gt_classes == 2]) == 1 and inst.image_size == (20, 30)
+    il = ImageList.from_tensors([torch.ones(3, 20, 30), torch.ones(3, 25, 17)], 32)
+    assert tuple(il.tensor.shape) == (2, 3, 32, 32) and il.image_sizes == [(20, 30), (25, 17)]
+    assert il.tensor[1, :, 25:, :].abs().sum() == 0
+
+
+def test_synthetic_batches_are_deterministic():
+    from slenderobjdet_amd.data import synthetic_batch
+
+    a, b = synthetic_batch(2, 64, 96, 5), synthetic_batch(2, 64, 96, 5)
+    assert torch.equal(a[1]["image"], b[1]["image"]) and torch.equal(a[0]["instances"].gt_boxes.tensor, b[0]["instances"].gt_boxes.tensor)
+    bx = a[0]["instances"].gt_boxes.tensor
+    assert (bx[:, 2] - bx[:, 0] >= 2 - 1e-4).all() and (bx[:, 3] - bx[:, 1] >= 2 - 1e-4).all() and a[0]["image"].dtype == torch.uint8
+
+
+def test_warmup_multistep_lr():
+    from slenderobjdet_amd.solver.build import WarmupMultiStepLR
+
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=0.01)
+    sch = WarmupMultiStepLR(opt, (5, 8), 0.1, warmup_factor=0.001, warmup_iters=4)
+    lrs = []
+    for _ in range(10):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    assert abs(lrs[0] - 1e-5) < 1e-12 and abs(lrs[4] - 0.01) < 1e-12 and abs(lrs[5] - 0.001) < 1e-12 and abs(lrs[8] - 0.0001) < 1e-12

@@ -1,0 +1,70 @@
+"""Cross-checks of the oracle's restatements of THIRD-PARTY arithmetic (source absent from the reference tree,
+"parity unpinned") against independent torch built-ins.  CPU only."""
+import torch
+import torch.nn.functional as F
+
+from oracle import deform_conv as odc
+from oracle import losses as ol
+from oracle import nn as onn
+
+
+def test_focal_composition_and_gradcheck():
+    x = torch.randn(50, 7, dtype=torch.float64, requires_grad=True)
+    t = (torch.rand(50, 7) > 0.7).double()
+    # gamma = 0, alpha = -1 reduces to plain BCE-with-logits
+    assert torch.allclose(ol.sigmoid_focal_loss(x, t, -1, 0.0, "sum"), F.binary_cross_entropy_with_logits(x, t, reduction="sum"))
+    # explicit closed form for t == 1: -alpha * (1-p)^gamma * log(p)
+    p = torch.sigmoid(x)
+    closed = (-(0.25 * t * (1 - p) ** 2 * torch.log(p)) - (0.75 * (1 - t) * p ** 2 * torch.log(1 - p))).sum()
+    assert torch.allclose(ol.sigmoid_focal_loss(x, t, 0.25, 2.0, "sum"), closed)
+    assert torch.autograd.gradcheck(lambda a: ol.sigmoid_focal_loss(a, t, 0.25, 2.0, "sum"), (x,))
+
+
+def test_smooth_l1_and_giou():
+    a, b = torch.randn(100), torch.randn(100)
+    assert torch.allclose(ol.smooth_l1_loss(a, b, 0.11), F.smooth_l1_loss(a, b, beta=0.11, reduction="none"))
+    assert torch.allclose(ol.smooth_l1_loss(a, b, 0.0), (a - b).abs())
+    b1 = torch.tensor([[0.0, 0.0, 10.0, 10.0], [0.0, 0.0, 10.0, 10.0], [0.0, 0.0, 2.0, 2.0]])
+    b2 = torch.tensor([[0.0, 0.0, 10.0, 10.0], [5.0, 5.0, 15.0, 15.0], [4.0, 4.0, 6.0, 6.0]])
+    l = ol.giou_loss_xyxy(b1, b2)
+    assert abs(l[0].item()) < 1e-6
+    assert abs(l[1].item() - (1 - (25 / 175 - (225 - 175) / 225))) < 1e-5
+    assert abs(l[2].item() - (1 - (0 - (36 - 8) / 36))) < 1e-5
+
+
+def test_conv_wrappers_roundtrip_layout():
+    x = torch.randn(2, 5, 6, 8)
+    w = torch.randn(4, 3, 3, 8)
+    y = onn.conv2d(x, w, None, 2, 1, 1)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), stride=2, padding=1).permute(0, 2, 3, 1)
+    assert torch.allclose(y, ref)
+    dx, dw = onn.conv2d_backward(x, w, torch.ones_like(y), 2, 1, 1)
+    assert dx.shape == x.shape and dw.shape == w.shape
+
+
+def test_deform_conv_zero_offset_and_gradcheck():
+    torch.manual_seed(0)
+    x = torch.randn(1, 4, 5, 6, dtype=torch.float64)
+    w = torch.randn(3, 4, 3, 3, dtype=torch.float64)
+    off0 = torch.zeros(1, 18, 5, 6, dtype=torch.float64)
+    assert torch.allclose(odc.deform_conv2d(x, off0, w, stride=1, pad=1), F.conv2d(x, w, padding=1))
+    off = (torch.rand(1, 18, 3, 3, dtype=torch.float64) - 0.5) * 1.7 + 0.013   # keep away from integer kinks
+    m = torch.rand(1, 9, 3, 3, dtype=torch.float64)
+    xs = x.clone().requires_grad_(True)
+    ws = w.clone().requires_grad_(True)
+    os_ = off.clone().requires_grad_(True)
+    ms = m.clone().requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a, b, c, d: odc.deform_conv2d(a, b, c, stride=2, pad=1, mask=d), (xs, os_, ws, ms), atol=1e-6)
+
+
+def test_sgd_matches_torch_optim():
+    torch.manual_seed(0)
+    p0, g1, g2 = torch.randn(10), torch.randn(10), torch.randn(10)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([p], lr=0.1, momentum=0.9, weight_decay=1e-2)
+    q, buf = p0.clone(), None
+    for i, g in enumerate((g1, g2)):
+        p.grad = g.clone()
+        opt.step()
+        q, buf = onn.sgd_step(q, g, buf, 0.1, 0.9, 1e-2, first=(i == 0))
+    assert torch.allclose(p.detach(), q, atol=1e-6)
