@@ -55,6 +55,13 @@ class FusedSGD(torch.optim.Optimizer):
         self.arena = arena
         self._base_lr0 = lr
         self._segs, self._nseg = arena.build_segments(self.param_groups, lr)
+        # the schedule multiplies every group's lr by the same factor: recover the current base lr from the first group
+        # whose multiplier (bias lr factor etc.) is non-zero
+        self._ref_group, self._ref_mult = 0, 1.0
+        for i, g in enumerate(self.param_groups):
+            if lr and g["lr"] != 0:
+                self._ref_group, self._ref_mult = i, g["lr"] / lr
+                break
         self._steps = 0
         self.grad_scale = 1.0
         if momentum != 0:
@@ -67,10 +74,7 @@ class FusedSGD(torch.optim.Optimizer):
     def step(self, closure=None):
         # every group carries lr = base_lr(t) * its multiplier; read the schedule from the first group
         g0 = self.param_groups[0]
-        mult0 = getattr(self, "_mult0", None)
-        if mult0 is None:
-            mult0 = self._mult0 = (g0["initial_lr"] if "initial_lr" in g0 else g0["lr"]) / self._base_lr0
-        lr_now = g0["lr"] / mult0 if mult0 else 0.0
+        lr_now = self.param_groups[self._ref_group]["lr"] / self._ref_mult
         a = self.arena
         call("sod_sgd_step", ptr(a.params), ptr(a.grads), ptr(a.momentum), ptr(self._segs), self._nseg, None, float(lr_now),
              float(g0["momentum"]), 1 if g0["nesterov"] else 0, 1 if self._steps == 0 else 0, float(self.grad_scale), stream_ptr())
