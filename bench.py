@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-prof", type=int, default=0, help="print the N most expensive (kernel, shape) groups to stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,7 +148,7 @@ def main():
         }
         if prof:
             agg = {}
-            for kind, flops, e0, e1 in prof:
+            for kind, flops, e0, e1, _desc in prof:
                 a = agg.setdefault(kind, [0.0, 0.0, 0])
                 a[0] += flops
                 a[1] += e0.elapsed_time(e1) * 1e-3
@@ -159,6 +160,13 @@ def main():
                                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": cnt,
                                "avg_launch_us": round(sec / cnt * 1e6, 2),
                                "all_conv": {k: {"TFLOP/s": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / args.steps * 1e3, 3)} for k, v in agg.items()}}
+        if prof and args.dump_prof:
+            per = {}
+            for kind, flops, e0, e1, desc in prof:
+                a = per.setdefault((kind, desc), [0.0, 0.0, 0])
+                a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+            for (kind, desc), (fl, sec, cnt) in sorted(per.items(), key=lambda kv: -kv[1][1])[:args.dump_prof]:
+                print(f"# {kind:10s} NHWCKRs={desc} calls/step {cnt // args.steps:3d} ms/step {sec / args.steps * 1e3:7.3f} TF/s {fl / sec / 1e12:7.1f}", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, args)
         print(json.dumps(out), flush=True)

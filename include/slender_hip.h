@@ -21,6 +21,7 @@ extern "C" {
 #endif
 
 #define SOD_MAX_LEVELS 8
+#define SOD_CONV_MAX_LEVELS 6   /* tensors one multi-level conv launch may cover */
 
 /* conv flags */
 #define SOD_CONV_RELU 1     /* y = max(y, 0) after bias/residual */
@@ -59,6 +60,20 @@ int sod_conv2d_dgrad(const void* dy, const void* wt, const void* accum, const vo
 int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const float* qscale,
                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                      long long dy_img_stride, long long x_img_stride, int splits, void* stream);
+
+/* Multi-level forms: ONE launch applies the same weights to `nlev` tensors (the FPN levels the FCOS towers and
+ * prediction convs share, fcosv2.py:358-380 loops over them). x/y/dy/dx are HOST arrays of device pointers, H/W host
+ * arrays of the per-level input sizes. y_img_stride / dy_img_stride (elements, <=0: dense per level) is common to all
+ * levels, so the per-level outputs can land inside the concatenated (N, sum Hi*Wi, K) buffer. */
+int sod_conv2d_fwd_ml(int nlev, const void* const* x, const void* w, const float* bias, void* const* y,
+                      int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                      long long y_img_stride, int flags, int out_f32, void* stream);
+int sod_conv2d_dgrad_ml(int nlev, const void* const* dy, const void* wt, void* const* dx,
+                        int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                        long long dy_img_stride, void* stream);
+int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, float* dw, const float* qscale,
+                        int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                        long long dy_img_stride, int splits, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * GroupNorm (+ fused ReLU), NHWC bf16 — nn.GroupNorm(32, C) + nn.ReLU in FCOSHead (fcosv2.py:315-336).

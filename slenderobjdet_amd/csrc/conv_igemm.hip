@@ -14,6 +14,7 @@
 // wgrad contracts over pixels, which is the slow axis of both operands: tiles are staged [pixel][128 ch]
 // and fragments are fetched with ds_read_b64_tr_b16 (hardware transpose), swizzled at 32-B granularity.
 #include "common.h"
+#include "../../include/slender_hip.h"
 
 namespace {
 
@@ -21,23 +22,34 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 enum {
   F_BIAS = 1, F_RELU = 2, F_RES = 4, F_RES_UP2 = 8, F_MASK = 16,
 };
+constexpr int MAXLEV = SOD_CONV_MAX_LEVELS;
 
-struct ConvArgs {
+// One "level" = one (N,H,W,C) tensor; a launch may cover several levels that share the weights (the FPN levels of
+// the FCOS towers), so that the small levels do not pay a launch + tail each.
+struct LevelGeo {
   const void* src;     // fwd: x (N,Hs,Ws,Cred); dgrad: dy (N,Hs,Ws,Cred)
-  const void* w;       // [Nout][R*S*Cred]
   void* dst;           // (N,Hp,Wp,Nout) rows at dst_img_stride
-  const float* bias;   // [Nout] or null
   const void* res;     // bf16, indexed like dst (or half-resolution with F_RES_UP2)
   const void* mask;    // bf16, indexed like dst: dst = mask>0 ? v : 0 (ReLU backward)
-  uint32_t src_bytes, w_bytes;
-  int N, Hs, Ws, Cred;
-  int Hp, Wp, Nout;
-  int R, S, stride, pad, dil;
+  uint32_t src_bytes;
+  int Hs, Ws, Hp, Wp, P;
+  int tile0;           // first pixel tile of this level
   int src_img_stride, dst_img_stride, res_img_stride;  // elements
-  int Kred, T, P;      // R*S*Cred, #K-steps, N*Hp*Wp
+  FastDiv div_hw, div_w;
+};
+
+struct ConvArgs {
+  LevelGeo lev[MAXLEV];
+  int nlev;
+  const void* w;       // [Nout][R*S*Cred]
+  const float* bias;   // [Nout] or null
+  uint32_t w_bytes;
+  int N, Cred, Nout;
+  int R, S, stride, pad, dil;
+  int Kred, T;         // R*S*Cred, #K-steps
   int flags;
   int nq_tiles, np_tiles;
-  FastDiv div_hw, div_w, div_cpt /* Cred/64 (fast) or Cred/8 (generic) */, div_s, div_stride;
+  FastDiv div_cpt /* Cred/64 (fast) or Cred/8 (generic) */, div_s, div_stride;
 };
 
 template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32>
@@ -51,11 +63,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int qt = bid % a.nq_tiles, pt = bid / a.nq_tiles;   // q fastest: neighbours share the X tile
+  const int qt = bid % a.nq_tiles;
+  int pt = bid / a.nq_tiles;   // q fastest: neighbours share the X tile
+  int lv = 0;
+#pragma unroll
+  for (int i = 1; i < MAXLEV; ++i)
+    if (i < a.nlev && pt >= a.lev[i].tile0) lv = i;
+  const LevelGeo& g = a.lev[lv];
+  pt -= g.tile0;
   const int q0 = qt * BQ, p0 = pt * BP;
+  const int gP = g.P, gHs = g.Hs, gWs = g.Ws;
 
   auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
-  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src), 0, a.src_bytes, 0x00020000);
+  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.src), 0, g.src_bytes, 0x00020000);
 
   // ---- per-thread staging geometry (rows are fixed for the whole K loop) ----
   const int srow = lane >> 3;                                   // row inside one 8-row wave instruction
@@ -68,14 +88,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   for (int i = 0; i < XI; ++i) {
     const int row = (i * 4 + wave) * 8 + srow;
     const uint32_t p = p0 + row;
-    if (p < (uint32_t)a.P) {
-      const uint32_t n = fd_div(p, a.div_hw);
-      const uint32_t rem = p - n * a.div_hw.d;
-      const uint32_t ph = fd_div(rem, a.div_w);
-      const uint32_t pw = rem - ph * a.div_w.d;
+    if (p < (uint32_t)gP) {
+      const uint32_t n = fd_div(p, g.div_hw);
+      const uint32_t rem = p - n * g.div_hw.d;
+      const uint32_t ph = fd_div(rem, g.div_w);
+      const uint32_t pw = rem - ph * g.div_w.d;
       if (MODE == MODE_FWD) { xh[i] = (int)ph * a.stride - a.pad; xw[i] = (int)pw * a.stride - a.pad; }
       else                  { xh[i] = (int)ph + a.pad;            xw[i] = (int)pw + a.pad; }
-      xoff[i] = n * (uint32_t)a.src_img_stride;
+      xoff[i] = n * (uint32_t)g.src_img_stride;
     } else {
       xh[i] = -(1 << 28); xw[i] = -(1 << 28); xoff[i] = 0;
     }
@@ -125,9 +145,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       int r, s, c;
       uint32_t m = 0xFFFFFFFFu;
       if (GENERIC) {
-        const uint32_t g = (uint32_t)t * 8u + (uint32_t)schunk;     // 8-channel chunk index
-        const uint32_t tap = fd_div(g, a.div_cpt);
-        c = (int)(g - tap * a.div_cpt.d) << 3;
+        const uint32_t gi = (uint32_t)t * 8u + (uint32_t)schunk;     // 8-channel chunk index
+        const uint32_t tap = fd_div(gi, a.div_cpt);
+        c = (int)(gi - tap * a.div_cpt.d) << 3;
         r = (int)fd_div(tap, a.div_s);
         s = (int)tap - r * a.S;
         m = (uint32_t) - (int)(r < a.R);
@@ -135,9 +155,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         r = r_u; s = s_u; c = c0_u + schunk * 8;
       }
       int h, w;
-      m &= src_coord(xh[i], r, a.Hs, h);
-      m &= src_coord(xw[i], s, a.Ws, w);
-      const uint32_t off = (xoff[i] + ((uint32_t)h * (uint32_t)a.Ws + (uint32_t)w) * (uint32_t)a.Cred + (uint32_t)c) * 2u;
+      m &= src_coord(xh[i], r, gHs, h);
+      m &= src_coord(xw[i], s, gWs, w);
+      const uint32_t off = (xoff[i] + ((uint32_t)h * (uint32_t)gWs + (uint32_t)w) * (uint32_t)a.Cred + (uint32_t)c) * 2u;
       const uint32_t voff = (off & m) | (SOD_OOB & ~m);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + W_TILE + (i * 4 + wave) * 1024), 16, voff, 0, 0, 0);
     }
@@ -184,64 +204,131 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
   }
 
-  // ---- epilogue: D[row=q][col=p]; lane holds 4 consecutive q for one pixel ----
-  const bool vec_ok = (a.Nout & 3) == 0;
+  // ---- epilogue ----
+  // The accumulator tile is D[row=q][col=p]: a lane holds 4 consecutive q of ONE pixel, i.e. 8-B pieces scattered over
+  // 16 pixel rows.  Stage the wave's tile through LDS (fp32, [pixel][q]) and read it back so that each lane owns 16
+  // contiguous output bytes and 4-16 lanes cover one pixel's channel run: residual / mask loads and the stores become
+  // full 64-256 B segments.
+  const int Nout = a.Nout;
+  if ((Nout & 7) == 0) {
+    constexpr int QW = FQ * 16;                  // channels per wave tile
+    constexpr int ROWB = QW * 4 + 16;            // fp32 row + 16 B pad (keeps 16-B alignment, spreads banks)
+    constexpr int NH = 2, FH = FP / NH;          // two halves of FH fragments (FH*16 pixel rows) bound the LDS use
+    constexpr int EPL = OUT_F32 ? 4 : 8;         // output elements per lane (16 B)
+    constexpr int LPR = QW / EPL;                // lanes per pixel row
+    constexpr int RPP = 64 / LPR;                // pixel rows per pass
+    static_assert(FP % NH == 0 && 4 * FH * 16 * ROWB <= 2 * STAGE, "epilogue staging must fit the K-loop LDS");
+    __syncthreads();                             // every wave has finished reading the K-loop buffers
+    char* wl = smem + wave * (FH * 16 * ROWB);
+    const int erow = lane / LPR, eq = (lane % LPR) * EPL;
+    const int q = q0 + wq * QW + eq;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+#pragma unroll
+      for (int jj = 0; jj < FH; ++jj)
+#pragma unroll
+        for (int i = 0; i < FQ; ++i)
+          *reinterpret_cast<f32x4_t*>(wl + (jj * 16 + fr) * ROWB + (i * 16 + fg * 4) * 4) = acc[i][h * FH + jj];
+#pragma unroll
+      for (int r0 = 0; r0 < FH * 16; r0 += RPP) {
+        const int row = r0 + erow;
+        const uint32_t p = p0 + (wp * FP + h * FH) * 16 + row;
+        if (p < (uint32_t)gP && q < Nout) {
+          float v[EPL];
+#pragma unroll
+          for (int e = 0; e < EPL; e += 4) {
+            const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(wl + row * ROWB + (eq + e) * 4);
+            v[e] = t4[0]; v[e + 1] = t4[1]; v[e + 2] = t4[2]; v[e + 3] = t4[3];
+          }
+          const uint32_t n = fd_div(p, g.div_hw);
+          const uint32_t rem = p - n * g.div_hw.d;
+          const size_t dst_row = (size_t)n * g.dst_img_stride + (size_t)rem * Nout;
+          if (a.flags & F_BIAS) {
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4) {
+              const f32x4_t b = *reinterpret_cast<const f32x4_t*>(a.bias + q + e);
+              v[e] += b[0]; v[e + 1] += b[1]; v[e + 2] += b[2]; v[e + 3] += b[3];
+            }
+          }
+          if (a.flags & (F_RES | F_RES_UP2)) {
+            size_t res_row;
+            if (a.flags & F_RES_UP2) {
+              const uint32_t ph = fd_div(rem, g.div_w);
+              const uint32_t pw = rem - ph * g.div_w.d;
+              res_row = (size_t)n * g.res_img_stride + (size_t)((ph >> 1) * (g.Wp >> 1) + (pw >> 1)) * Nout;
+            } else {
+              res_row = (size_t)n * g.res_img_stride + (size_t)rem * Nout;
+            }
+            const __bf16* rp = (const __bf16*)g.res + res_row + q;
+            if (EPL == 8) {
+              const bf16x8_t rv = *reinterpret_cast<const bf16x8_t*>(rp);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            } else {
+              const bf16x4_t rv = *reinterpret_cast<const bf16x4_t*>(rp);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+            }
+          }
+          if (a.flags & F_RELU) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (a.flags & F_MASK) {
+            const __bf16* mp = (const __bf16*)g.mask + dst_row + q;
+            if (EPL == 8) {
+              const bf16x8_t mv = *reinterpret_cast<const bf16x8_t*>(mp);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
+            } else {
+              const bf16x4_t mv = *reinterpret_cast<const bf16x4_t*>(mp);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
+            }
+          }
+          if (OUT_F32) {
+            *reinterpret_cast<f32x4_t*>((float*)g.dst + dst_row + q) = f32x4_t{v[0], v[1], v[2], v[3]};
+          } else {
+            bf16x8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e < EPL ? e : 0];
+            *reinterpret_cast<bf16x8_t*>((__bf16*)g.dst + dst_row + q) = o;
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  // scalar fallback (Nout not a multiple of 8): lane holds 4 consecutive q for one pixel
 #pragma unroll
   for (int j = 0; j < FP; ++j) {
     const uint32_t p = p0 + (wp * FP + j) * 16 + fr;
-    if (p >= (uint32_t)a.P) continue;
-    const uint32_t n = fd_div(p, a.div_hw);
-    const uint32_t rem = p - n * a.div_hw.d;
+    if (p >= (uint32_t)gP) continue;
+    const uint32_t n = fd_div(p, g.div_hw);
+    const uint32_t rem = p - n * g.div_hw.d;
     size_t res_row = 0;
     if (a.flags & F_RES_UP2) {
-      const uint32_t ph = fd_div(rem, a.div_w);
-      const uint32_t pw = rem - ph * a.div_w.d;
-      res_row = (size_t)n * a.res_img_stride + (size_t)((ph >> 1) * (a.Wp >> 1) + (pw >> 1)) * a.Nout;
+      const uint32_t ph = fd_div(rem, g.div_w);
+      const uint32_t pw = rem - ph * g.div_w.d;
+      res_row = (size_t)n * g.res_img_stride + (size_t)((ph >> 1) * (g.Wp >> 1) + (pw >> 1)) * Nout;
     } else if (a.flags & F_RES) {
-      res_row = (size_t)n * a.res_img_stride + (size_t)rem * a.Nout;
+      res_row = (size_t)n * g.res_img_stride + (size_t)rem * Nout;
     }
-    const size_t dst_row = (size_t)n * a.dst_img_stride + (size_t)rem * a.Nout;
+    const size_t dst_row = (size_t)n * g.dst_img_stride + (size_t)rem * Nout;
 #pragma unroll
     for (int i = 0; i < FQ; ++i) {
       const int q = q0 + (wq * FQ + i) * 16 + fg * 4;
-      if (q >= a.Nout) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (vec_ok) {
-        if (a.flags & F_BIAS) {
-          const f32x4_t b = *reinterpret_cast<const f32x4_t*>(a.bias + q);
-          v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
-        }
-        if (a.flags & (F_RES | F_RES_UP2)) {
-          const bf16x4_t rv = *reinterpret_cast<const bf16x4_t*>((const __bf16*)a.res + res_row + q);
-          v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
-        }
-        if (a.flags & F_RELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (a.flags & F_MASK) {
-          const bf16x4_t mv = *reinterpret_cast<const bf16x4_t*>((const __bf16*)a.mask + dst_row + q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
-        }
-        if (OUT_F32) {
-          *reinterpret_cast<f32x4_t*>((float*)a.dst + dst_row + q) = f32x4_t{v[0], v[1], v[2], v[3]};
-        } else {
-          bf16x4_t o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-          *reinterpret_cast<bf16x4_t*>((__bf16*)a.dst + dst_row + q) = o;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (q + e >= a.Nout) break;
-          float x = v[e];
-          if (a.flags & F_BIAS) x += a.bias[q + e];
-          if (a.flags & (F_RES | F_RES_UP2)) x += (float)((const __bf16*)a.res)[res_row + q + e];
-          if (a.flags & F_RELU) x = fmaxf(x, 0.f);
-          if (a.flags & F_MASK) x = ((float)((const __bf16*)a.mask)[dst_row + q + e] > 0.f) ? x : 0.f;
-          if (OUT_F32) ((float*)a.dst)[dst_row + q + e] = x;
-          else ((__bf16*)a.dst)[dst_row + q + e] = (__bf16)x;
-        }
+      for (int e = 0; e < 4; ++e) {
+        if (q + e >= Nout) break;
+        float x = acc[i][j][e];
+        if (a.flags & F_BIAS) x += a.bias[q + e];
+        if (a.flags & (F_RES | F_RES_UP2)) x += (float)((const __bf16*)g.res)[res_row + q + e];
+        if (a.flags & F_RELU) x = fmaxf(x, 0.f);
+        if (a.flags & F_MASK) x = ((float)((const __bf16*)g.mask)[dst_row + q + e] > 0.f) ? x : 0.f;
+        if (OUT_F32) ((float*)g.dst)[dst_row + q + e] = x;
+        else ((__bf16*)g.dst)[dst_row + q + e] = (__bf16)x;
       }
     }
   }
@@ -249,19 +336,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 
 // --------------------------------------------------------------------------------------------
 // wgrad: dW[q][tap][c] += sum_p dY[p][q] * X[p shifted by tap][c]
+// The contraction runs over a VIRTUAL pixel index that concatenates the levels (each padded to a multiple of 64), so
+// one launch reduces over all FPN levels that share the weights.
 // --------------------------------------------------------------------------------------------
-struct WgradArgs {
+struct WLevel {
   const void* dy;      // (N,Ho,Wo,K) bf16 rows at dy_img_stride
   const void* x;       // (N,Hx,Wx,C) bf16
+  uint32_t dy_bytes, x_bytes;
+  int Hx, Wx, Ho, Wo, P;
+  int v0;              // first virtual pixel of this level (multiple of 64)
+  int dy_img_stride, x_img_stride;
+  FastDiv div_hw, div_w;
+};
+
+struct WgradArgs {
+  WLevel lev[MAXLEV];
+  int nlev;
   float* dw;           // [K][R][S][C] fp32, accumulated atomically
   const float* qscale; // optional per-output-channel factor (folded FrozenBN scale)
-  uint32_t dy_bytes, x_bytes;
-  int N, Hx, Wx, C, Ho, Wo, K;
+  int N, C, K;
   int R, S, stride, pad, dil;
-  int dy_img_stride, x_img_stride;
-  int P, nz, p_per_split;   // p_per_split multiple of 64
+  int V, nz, v_per_split;   // total virtual pixels; v_per_split multiple of 64
   int QT, CT;
-  FastDiv div_hw, div_w, div_s;
+  FastDiv div_s;
 };
 
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
@@ -277,37 +374,56 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   const int z = bid;
   const int r = tap / a.S, s = tap - r * a.S;
   const int q0 = qt * 128, c0 = ct * 128;
-  const int pbeg = z * a.p_per_split;
-  int pend = pbeg + a.p_per_split; if (pend > a.P) pend = a.P;
-  const int nsteps = (pend - pbeg + 63) >> 6;
-
-  auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, a.dy_bytes, 0x00020000);
-  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  const int vbeg = z * a.v_per_split;
+  int vend = vbeg + a.v_per_split; if (vend > a.V) vend = a.V;
+  const int nsteps = (vend - vbeg) >> 6;
 
   // staging: one wave instruction = 4 pixel rows x 256 B; lane -> (row_in, 16-B slot)
   const int srow = lane >> 4, spos = lane & 15;
   const int sswz = srow | (((wave >> 1) & 1) << 2);       // (row&3) | ((row>>3)&1)<<2, see header
   const int schunk = spos ^ (sswz << 1);                  // logical 16-B chunk (8 channels)
-  const bool qok = (q0 + schunk * 8) < a.K;
-  const bool cok = (c0 + schunk * 8) < a.C;
+  const uint32_t qadd = (uint32_t)(q0 + schunk * 8) * 2u, cadd = (uint32_t)(c0 + schunk * 8) * 2u;
+  const uint32_t qmask = (uint32_t) - (int)((q0 + schunk * 8) < a.K), cmask = (uint32_t) - (int)((c0 + schunk * 8) < a.C);
+
+  // Level geometry lives in registers and is reloaded (wave-uniform branch) only when the virtual pixel index crosses
+  // into the next level; stage() is called with increasing `it`.
+  int cur_lv = 0;
+#pragma unroll
+  for (int i = 1; i < MAXLEV; ++i)
+    if (i < a.nlev && vbeg >= a.lev[i].v0) cur_lv = i;
+  WLevel g = a.lev[cur_lv];
+  int next_v0 = (cur_lv + 1 < a.nlev) ? a.lev[cur_lv + 1].v0 : 0x7fffffff;
+  auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.dy), 0, g.dy_bytes, 0x00020000);
+  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, g.x_bytes, 0x00020000);
 
   auto stage = [&](int it, char* buf) {
+    const int v = vbeg + it * 64;
+    if (v >= next_v0) {
+      ++cur_lv;
+      g = a.lev[cur_lv];
+      next_v0 = (cur_lv + 1 < a.nlev) ? a.lev[cur_lv + 1].v0 : 0x7fffffff;
+      yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.dy), 0, g.dy_bytes, 0x00020000);
+      xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, g.x_bytes, 0x00020000);
+    }
+    const int pbase = v - g.v0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (i * 4 + wave) * 4 + srow;
-      const int p = pbeg + it * 64 + row;
-      uint32_t vy = SOD_OOB, vx = SOD_OOB;
-      if (p < pend) {
-        const uint32_t n = fd_div((uint32_t)p, a.div_hw);
-        const uint32_t rem = (uint32_t)p - n * a.div_hw.d;
-        const uint32_t ho = fd_div(rem, a.div_w);
-        const uint32_t wo = rem - ho * a.div_w.d;
-        if (qok) vy = (n * (uint32_t)a.dy_img_stride + rem * (uint32_t)a.K + (uint32_t)(q0 + schunk * 8)) * 2u;
-        const int hi = (int)ho * a.stride - a.pad + r * a.dil;
-        const int wi = (int)wo * a.stride - a.pad + s * a.dil;
-        if (cok && (unsigned)hi < (unsigned)a.Hx && (unsigned)wi < (unsigned)a.Wx)
-          vx = (n * (uint32_t)a.x_img_stride + (uint32_t)(hi * a.Wx + wi) * (uint32_t)a.C + (uint32_t)(c0 + schunk * 8)) * 2u;
-      }
+      const int p = pbase + row;
+      const uint32_t pm = (uint32_t) - (int)(p < g.P);
+      const uint32_t pc = (uint32_t)p & pm;                      // clamp padding rows to pixel 0 (masked below)
+      const uint32_t n = fd_div(pc, g.div_hw);
+      const uint32_t rem = pc - n * g.div_hw.d;
+      const uint32_t ho = fd_div(rem, g.div_w);
+      const uint32_t wo = rem - ho * g.div_w.d;
+      const uint32_t oy = (n * (uint32_t)g.dy_img_stride + rem * (uint32_t)a.K) * 2u + qadd;
+      const int hi = (int)ho * a.stride - a.pad + r * a.dil;
+      const int wi = (int)wo * a.stride - a.pad + s * a.dil;
+      const uint32_t xm = (uint32_t) - (int)(((unsigned)hi < (unsigned)g.Hx) & ((unsigned)wi < (unsigned)g.Wx));
+      const uint32_t ox = (n * (uint32_t)g.x_img_stride + ((uint32_t)hi * (uint32_t)g.Wx + (uint32_t)wi) * (uint32_t)a.C) * 2u + cadd;
+      const uint32_t my = pm & qmask, mx = pm & cmask & xm;
+      const uint32_t vy = (oy & my) | (SOD_OOB & ~my);
+      const uint32_t vx = (ox & mx) | (SOD_OOB & ~mx);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(buf + (i * 4 + wave) * 1024), 16, vy, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + TILE + (i * 4 + wave) * 1024), 16, vx, 0, 0, 0);
     }
@@ -387,12 +503,22 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   constexpr int BQ = WQ * FQ * 16, BP = WP * FP * 16;
   ConvArgs a = a0;
   a.nq_tiles = (a.Nout + BQ - 1) / BQ;
-  a.np_tiles = (a.P + BP - 1) / BP;
-  const size_t lds = 2 * (size_t)(BQ + BP) * 128;
+  int tiles = 0;
+  for (int l = 0; l < a.nlev; ++l) {
+    a.lev[l].tile0 = tiles;
+    tiles += (a.lev[l].P + BP - 1) / BP;
+  }
+  a.np_tiles = tiles;
+  const size_t lds_full = 2 * (size_t)(BQ + BP) * 128;
+  // a single K-step needs no second staging buffer: a smaller footprint lets 4 blocks share a CU, which is what hides the
+  // load->MFMA->store latency of the memory-bound 1x1 convolutions (C = 64)
+  const size_t epi = 4 * (size_t)(FP / 2) * 16 * (FQ * 64 + 16);
+  size_t lds = a.T == 1 ? (size_t)(BQ + BP) * 128 : lds_full;
+  if (lds < epi) lds = epi;
   auto kern = conv_igemm_kernel<MODE, GENERIC, WQ, WP, FQ, FP, OUT_F32>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
@@ -412,61 +538,153 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   return generic ? launch_conv<MODE, true, 2, 2, 4, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32>(a, st);
 }
 
-int fill_common(ConvArgs& a, int N, int Hs, int Ws, int Cred, int Hp, int Wp, int Nout, int R, int S, int stride,
-                int pad, int dil, long long src_img_stride, long long dst_img_stride, size_t dst_elt) {
-  if (N <= 0 || Hs <= 0 || Ws <= 0 || Hp <= 0 || Wp <= 0 || Nout <= 0 || R <= 0 || S <= 0 || stride <= 0 || dil <= 0 || pad < 0)
-    return SOD_EARG;
+int out_size(int H, int pad, int dil, int R, int stride) { return (H + 2 * pad - dil * (R - 1) - 1) / stride + 1; }
+
+int fill_common(ConvArgs& a, int nlev, int N, int Cred, int Nout, int R, int S, int stride, int pad, int dil) {
+  if (nlev <= 0 || nlev > MAXLEV) return SOD_EARG;
+  if (N <= 0 || Nout <= 0 || R <= 0 || S <= 0 || stride <= 0 || dil <= 0 || pad < 0) return SOD_EARG;
   if (Cred <= 0 || (Cred & 7)) return SOD_EARG;
-  if (src_img_stride < (long long)Hs * Ws * Cred || dst_img_stride < (long long)Hp * Wp * Nout) return SOD_EARG;
-  const unsigned long long sb = (unsigned long long)N * src_img_stride * 2ull;
   const unsigned long long wb = (unsigned long long)Nout * R * S * Cred * 2ull;
-  const unsigned long long db = (unsigned long long)N * dst_img_stride * dst_elt;
-  if (sb >= 0x80000000ull || wb >= 0x80000000ull || db >= 0x200000000ull) return SOD_ESIZE;
-  if ((long long)N * Hp * Wp >= (1ll << 31)) return SOD_ESIZE;
-  a.src_bytes = (uint32_t)sb; a.w_bytes = (uint32_t)wb;
-  a.N = N; a.Hs = Hs; a.Ws = Ws; a.Cred = Cred; a.Hp = Hp; a.Wp = Wp; a.Nout = Nout;
+  if (wb >= 0x80000000ull) return SOD_ESIZE;
+  a.nlev = nlev;
+  a.w_bytes = (uint32_t)wb;
+  a.N = N; a.Cred = Cred; a.Nout = Nout;
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
-  a.src_img_stride = (int)src_img_stride; a.dst_img_stride = (int)dst_img_stride;
-  a.Kred = R * S * Cred; a.T = (a.Kred + 63) / 64; a.P = N * Hp * Wp;
-  a.div_hw = make_fastdiv((uint32_t)(Hp * Wp));
-  a.div_w = make_fastdiv((uint32_t)Wp);
+  a.Kred = R * S * Cred; a.T = (a.Kred + 63) / 64;
   a.div_cpt = make_fastdiv((uint32_t)((Cred & 63) ? Cred / 8 : Cred / 64));
   a.div_s = make_fastdiv((uint32_t)S);
   a.div_stride = make_fastdiv((uint32_t)stride);
   return SOD_OK;
 }
 
-}  // namespace
+// source dims (Hs,Ws) with Cred channels; GEMM-row dims (Hp,Wp) with Nout channels
+int fill_level(ConvArgs& a, int l, const void* src, void* dst, int Hs, int Ws, int Hp, int Wp, long long src_img_stride,
+               long long dst_img_stride, size_t dst_elt) {
+  if (!src || !dst || Hs <= 0 || Ws <= 0 || Hp <= 0 || Wp <= 0) return SOD_EARG;
+  if (src_img_stride <= 0) src_img_stride = (long long)Hs * Ws * a.Cred;
+  if (dst_img_stride <= 0) dst_img_stride = (long long)Hp * Wp * a.Nout;
+  if (src_img_stride < (long long)Hs * Ws * a.Cred || dst_img_stride < (long long)Hp * Wp * a.Nout) return SOD_EARG;
+  const unsigned long long sb = (unsigned long long)a.N * src_img_stride * 2ull;
+  const unsigned long long db = (unsigned long long)a.N * dst_img_stride * dst_elt;
+  if (sb >= 0x80000000ull || db >= 0x200000000ull) return SOD_ESIZE;
+  if ((long long)a.N * Hp * Wp >= (1ll << 31)) return SOD_ESIZE;
+  LevelGeo& g = a.lev[l];
+  g.src = src; g.dst = dst; g.res = nullptr; g.mask = nullptr;
+  g.src_bytes = (uint32_t)sb;
+  g.Hs = Hs; g.Ws = Ws; g.Hp = Hp; g.Wp = Wp; g.P = a.N * Hp * Wp;
+  g.src_img_stride = (int)src_img_stride; g.dst_img_stride = (int)dst_img_stride; g.res_img_stride = 0;
+  g.div_hw = make_fastdiv((uint32_t)(Hp * Wp));
+  g.div_w = make_fastdiv((uint32_t)Wp);
+  return SOD_OK;
+}
 
-#include "../../include/slender_hip.h"
+int launch_wgrad(WgradArgs& a, int splits, hipStream_t st) {
+  a.QT = (a.K + 127) / 128; a.CT = (a.C + 127) / 128;
+  const int tiles = a.QT * a.CT * a.R * a.S;
+  int V = 0;
+  long long Ptot = 0;
+  for (int l = 0; l < a.nlev; ++l) {
+    a.lev[l].v0 = V;
+    V += (a.lev[l].P + 63) / 64 * 64;
+    Ptot += a.lev[l].P;
+  }
+  a.V = V;
+  if (splits <= 0) {
+    // ONE resident wave of blocks (2 per CU): measured on the head shape, 504 blocks run at 718 TFLOP/s where 1548 blocks
+    // (3.02 waves -> a nearly empty 4th round, 3x the atomic traffic) run at 585.  At least 256 pixels per block.
+    static int slots = 0;
+    if (!slots) {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      slots = 2 * (cus > 0 ? cus : 256);
+    }
+    splits = slots / tiles;
+    const int maxs = (int)((Ptot + 255) / 256);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+  }
+  int vps = (V + splits - 1) / splits;
+  vps = (vps + 63) / 64 * 64;
+  a.v_per_split = vps;
+  a.nz = (V + vps - 1) / vps;
+  a.div_s = make_fastdiv((uint32_t)a.S);
+  const size_t lds = 2 * 2 * 64 * 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  SOD_LAUNCH(conv_wgrad_kernel, dim3(a.nz * tiles), dim3(256), lds, st, a);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+int fill_wlevel(WgradArgs& a, int l, const void* dy, const void* x, int H, int W, long long dy_img_stride, long long x_img_stride) {
+  if (!dy || !x || H <= 0 || W <= 0) return SOD_EARG;
+  const int Ho = out_size(H, a.pad, a.dil, a.R, a.stride), Wo = out_size(W, a.pad, a.dil, a.S, a.stride);
+  if (Ho <= 0 || Wo <= 0) return SOD_EARG;
+  if (dy_img_stride <= 0) dy_img_stride = (long long)Ho * Wo * a.K;
+  if (x_img_stride <= 0) x_img_stride = (long long)H * W * a.C;
+  const unsigned long long yb = (unsigned long long)a.N * dy_img_stride * 2ull, xb = (unsigned long long)a.N * x_img_stride * 2ull;
+  if (yb >= 0x80000000ull || xb >= 0x80000000ull || (long long)a.N * Ho * Wo >= (1ll << 30)) return SOD_ESIZE;
+  WLevel& g = a.lev[l];
+  g.dy = dy; g.x = x; g.dy_bytes = (uint32_t)yb; g.x_bytes = (uint32_t)xb;
+  g.Hx = H; g.Wx = W; g.Ho = Ho; g.Wo = Wo; g.P = a.N * Ho * Wo;
+  g.dy_img_stride = (int)dy_img_stride; g.x_img_stride = (int)x_img_stride;
+  g.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
+  g.div_w = make_fastdiv((uint32_t)Wo);
+  return SOD_OK;
+}
+
+}  // namespace
 
 extern "C" int sod_conv2d_fwd(const void* x, const void* w, const float* bias, const void* res, void* y,
                               int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                               long long x_img_stride, long long y_img_stride, long long res_img_stride,
                               int flags, int out_f32, void* stream) {
   if (!x || !w || !y) return SOD_EARG;
-  const int Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
-  const int Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+  const int Ho = out_size(H, pad, dil, R, stride), Wo = out_size(W, pad, dil, S, stride);
   if (Ho <= 0 || Wo <= 0) return SOD_EARG;
-  if (x_img_stride <= 0) x_img_stride = (long long)H * W * C;
-  if (y_img_stride <= 0) y_img_stride = (long long)Ho * Wo * K;
   ConvArgs a{};
-  int rc = fill_common(a, N, H, W, C, Ho, Wo, K, R, S, stride, pad, dil, x_img_stride, y_img_stride, out_f32 ? 4 : 2);
+  int rc = fill_common(a, 1, N, C, K, R, S, stride, pad, dil);
   if (rc) return rc;
-  a.src = x; a.w = w; a.dst = y; a.bias = bias; a.res = res; a.mask = nullptr;
+  rc = fill_level(a, 0, x, y, H, W, Ho, Wo, x_img_stride, y_img_stride, out_f32 ? 4 : 2);
+  if (rc) return rc;
+  a.w = w; a.bias = bias;
   a.flags = 0;
   if (bias) a.flags |= F_BIAS;
   if (flags & SOD_CONV_RELU) a.flags |= F_RELU;
   if (res) {
+    a.lev[0].res = res;
     if (flags & SOD_CONV_RES_UP2) {
       if ((Ho & 1) || (Wo & 1)) return SOD_EARG;
       a.flags |= F_RES_UP2;
-      a.res_img_stride = (int)(res_img_stride > 0 ? res_img_stride : (long long)(Ho / 2) * (Wo / 2) * K);
+      a.lev[0].res_img_stride = (int)(res_img_stride > 0 ? res_img_stride : (long long)(Ho / 2) * (Wo / 2) * K);
     } else {
       a.flags |= F_RES;
-      a.res_img_stride = (int)(res_img_stride > 0 ? res_img_stride : y_img_stride);
+      a.lev[0].res_img_stride = (int)(res_img_stride > 0 ? res_img_stride : a.lev[0].dst_img_stride);
     }
   }
+  hipStream_t st = (hipStream_t)stream;
+  return out_f32 ? dispatch_conv<MODE_FWD, true>(a, st) : dispatch_conv<MODE_FWD, false>(a, st);
+}
+
+extern "C" int sod_conv2d_fwd_ml(int nlev, const void* const* x, const void* w, const float* bias, void* const* y,
+                                 int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                 long long y_img_stride, int flags, int out_f32, void* stream) {
+  if (!x || !w || !y || !H || !W) return SOD_EARG;
+  ConvArgs a{};
+  int rc = fill_common(a, nlev, N, C, K, R, S, stride, pad, dil);
+  if (rc) return rc;
+  for (int l = 0; l < nlev; ++l) {
+    const int Ho = out_size(H[l], pad, dil, R, stride), Wo = out_size(W[l], pad, dil, S, stride);
+    if (Ho <= 0 || Wo <= 0) return SOD_EARG;
+    rc = fill_level(a, l, x[l], y[l], H[l], W[l], Ho, Wo, 0, y_img_stride, out_f32 ? 4 : 2);
+    if (rc) return rc;
+  }
+  a.w = w; a.bias = bias;
+  a.flags = (bias ? F_BIAS : 0) | ((flags & SOD_CONV_RELU) ? F_RELU : 0);
   hipStream_t st = (hipStream_t)stream;
   return out_f32 ? dispatch_conv<MODE_FWD, true>(a, st) : dispatch_conv<MODE_FWD, false>(a, st);
 }
@@ -475,19 +693,35 @@ extern "C" int sod_conv2d_dgrad(const void* dy, const void* wt, const void* accu
                                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                 long long dy_img_stride, long long dx_img_stride, void* stream) {
   if (!dy || !wt || !dx) return SOD_EARG;
-  const int Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
-  const int Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+  const int Ho = out_size(H, pad, dil, R, stride), Wo = out_size(W, pad, dil, S, stride);
   if (Ho <= 0 || Wo <= 0) return SOD_EARG;
-  if (dy_img_stride <= 0) dy_img_stride = (long long)Ho * Wo * K;
-  if (dx_img_stride <= 0) dx_img_stride = (long long)H * W * C;
   ConvArgs a{};
   // GEMM rows are the INPUT pixels (H,W); the gather source is dY (Ho,Wo,K); output channels = C.
-  int rc = fill_common(a, N, Ho, Wo, K, H, W, C, R, S, stride, pad, dil, dy_img_stride, dx_img_stride, 2);
+  int rc = fill_common(a, 1, N, K, C, R, S, stride, pad, dil);
   if (rc) return rc;
-  a.src = dy; a.w = wt; a.dst = dx; a.bias = nullptr; a.res = accum; a.mask = relu_mask;
+  rc = fill_level(a, 0, dy, dx, Ho, Wo, H, W, dy_img_stride, dx_img_stride, 2);
+  if (rc) return rc;
+  a.w = wt; a.bias = nullptr;
   a.flags = 0;
-  if (accum) { a.flags |= F_RES; a.res_img_stride = (int)dx_img_stride; }
-  if (relu_mask) a.flags |= F_MASK;
+  if (accum) { a.flags |= F_RES; a.lev[0].res = accum; a.lev[0].res_img_stride = a.lev[0].dst_img_stride; }
+  if (relu_mask) { a.flags |= F_MASK; a.lev[0].mask = relu_mask; }
+  return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
+}
+
+extern "C" int sod_conv2d_dgrad_ml(int nlev, const void* const* dy, const void* wt, void* const* dx,
+                                   int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                   long long dy_img_stride, void* stream) {
+  if (!dy || !wt || !dx || !H || !W) return SOD_EARG;
+  ConvArgs a{};
+  int rc = fill_common(a, nlev, N, K, C, R, S, stride, pad, dil);
+  if (rc) return rc;
+  for (int l = 0; l < nlev; ++l) {
+    const int Ho = out_size(H[l], pad, dil, R, stride), Wo = out_size(W[l], pad, dil, S, stride);
+    if (Ho <= 0 || Wo <= 0) return SOD_EARG;
+    rc = fill_level(a, l, dy[l], dx[l], Ho, Wo, H[l], W[l], dy_img_stride, 0, 2);
+    if (rc) return rc;
+  }
+  a.w = wt; a.bias = nullptr; a.flags = 0;
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 
@@ -495,44 +729,26 @@ extern "C" int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const 
                                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                 long long dy_img_stride, long long x_img_stride, int splits, void* stream) {
   if (!dy || !x || !dw) return SOD_EARG;
-  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || (C & 7) || (K & 7)) return SOD_EARG;
-  const int Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
-  const int Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
-  if (Ho <= 0 || Wo <= 0) return SOD_EARG;
-  if (dy_img_stride <= 0) dy_img_stride = (long long)Ho * Wo * K;
-  if (x_img_stride <= 0) x_img_stride = (long long)H * W * C;
-  const unsigned long long yb = (unsigned long long)N * dy_img_stride * 2ull, xb = (unsigned long long)N * x_img_stride * 2ull;
-  if (yb >= 0x80000000ull || xb >= 0x80000000ull) return SOD_ESIZE;
+  if (N <= 0 || C <= 0 || K <= 0 || (C & 7) || (K & 7) || R <= 0 || S <= 0 || stride <= 0 || dil <= 0 || pad < 0) return SOD_EARG;
   WgradArgs a{};
-  a.dy = dy; a.x = x; a.dw = dw; a.qscale = qscale; a.dy_bytes = (uint32_t)yb; a.x_bytes = (uint32_t)xb;
-  a.N = N; a.Hx = H; a.Wx = W; a.C = C; a.Ho = Ho; a.Wo = Wo; a.K = K;
+  a.nlev = 1; a.dw = dw; a.qscale = qscale; a.N = N; a.C = C; a.K = K;
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
-  a.dy_img_stride = (int)dy_img_stride; a.x_img_stride = (int)x_img_stride;
-  a.P = N * Ho * Wo;
-  a.QT = (K + 127) / 128; a.CT = (C + 127) / 128;
-  const int tiles = a.QT * a.CT * R * S;
-  if (splits <= 0) {
-    // enough blocks for ~3 waves of the 256 CUs x 2 resident blocks, at least 256 pixels per block
-    splits = (1536 + tiles - 1) / tiles;
-    const int maxs = (a.P + 255) / 256;
-    if (splits > maxs) splits = maxs;
-    if (splits < 1) splits = 1;
+  int rc = fill_wlevel(a, 0, dy, x, H, W, dy_img_stride, x_img_stride);
+  if (rc) return rc;
+  return launch_wgrad(a, splits, (hipStream_t)stream);
+}
+
+extern "C" int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, float* dw, const float* qscale,
+                                   int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                   long long dy_img_stride, int splits, void* stream) {
+  if (!dy || !x || !dw || !H || !W || nlev <= 0 || nlev > MAXLEV) return SOD_EARG;
+  if (N <= 0 || C <= 0 || K <= 0 || (C & 7) || (K & 7) || R <= 0 || S <= 0 || stride <= 0 || dil <= 0 || pad < 0) return SOD_EARG;
+  WgradArgs a{};
+  a.nlev = nlev; a.dw = dw; a.qscale = qscale; a.N = N; a.C = C; a.K = K;
+  a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
+  for (int l = 0; l < nlev; ++l) {
+    int rc = fill_wlevel(a, l, dy[l], x[l], H[l], W[l], dy_img_stride, 0);
+    if (rc) return rc;
   }
-  int pps = (a.P + splits - 1) / splits;
-  pps = (pps + 63) / 64 * 64;
-  a.p_per_split = pps;
-  a.nz = (a.P + pps - 1) / pps;
-  a.div_hw = make_fastdiv((uint32_t)(Ho * Wo));
-  a.div_w = make_fastdiv((uint32_t)Wo);
-  a.div_s = make_fastdiv((uint32_t)S);
-  const size_t lds = 2 * 2 * 64 * 256;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
-  SOD_LAUNCH(conv_wgrad_kernel, dim3(a.nz * tiles), dim3(256), lds, (hipStream_t)stream, a);
-  SOD_CHECK_LAUNCH();
-  return SOD_OK;
+  return launch_wgrad(a, splits, (hipStream_t)stream);
 }

@@ -25,12 +25,12 @@ def _prof_begin():
     return e
 
 
-def _prof_end(kind, flops, e0):
+def _prof_end(kind, flops, e0, desc=None):
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.append((kind, flops, e0, e1))
+    PROFILE.append((kind, flops, e0, e1, desc))
 CONV_RELU = 1
 CONV_RES_UP2 = 2
 
@@ -81,7 +81,7 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
     e0 = _prof_begin()
     call("sod_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
          x_img_stride, y_img_stride, 0, flags, 1 if out_f32 else 0, stream_ptr())
-    _prof_end("conv_fwd", 2.0 * N * Ho * Wo * K * R * S * C, e0)
+    _prof_end("conv_fwd", 2.0 * N * Ho * Wo * K * R * S * C, e0, (N, H, W, C, K, R, stride))
     return out
 
 
@@ -97,7 +97,7 @@ def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=Non
     call("sod_conv2d_dgrad", ptr(dy), ptr(wt), ptr(accum), ptr(relu_mask), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
          dy_img_stride, 0, stream_ptr())
     Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
-    _prof_end("conv_dgrad", 2.0 * N * Ho * Wo * K * R * S * C, e0)
+    _prof_end("conv_dgrad", 2.0 * N * Ho * Wo * K * R * S * C, e0, (N, H, W, C, K, R, stride))
     return out
 
 
@@ -111,7 +111,63 @@ def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img
     call("sod_conv2d_wgrad", ptr(dy), ptr(x), ptr(dw), ptr(qscale), N, H, W, C, K, R, S, stride, pad, dil, dy_img_stride, x_img_stride,
          splits, stream_ptr())
     Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
-    _prof_end("conv_wgrad", 2.0 * N * Ho * Wo * K * R * S * C, e0)
+    _prof_end("conv_wgrad", 2.0 * N * Ho * Wo * K * R * S * C, e0, (N, H, W, C, K, R, stride))
+    return dw
+
+
+def _ptr_arr(ts):
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def conv2d_fwd_ml(xs, w, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, outs=None, y_img_stride=0):
+    """One launch over several (N,Hl,Wl,C) tensors that share the weights (FPN levels). Returns the list of outputs."""
+    _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias")
+    for x in xs:
+        _chk(x, torch.bfloat16, "x")
+    N, C = xs[0].shape[0], xs[0].shape[3]
+    K, R, S, Cw = w.shape
+    if Cw != C:
+        raise _C.SlenderHipError(f"weight channels {Cw} != input channels {C}")
+    hs, ws = [x.shape[1] for x in xs], [x.shape[2] for x in xs]
+    if outs is None:
+        outs = [torch.empty((N,) + conv_out_size(h, wd, R, S, stride, pad, dil) + (K,), dtype=torch.float32 if out_f32 else torch.bfloat16,
+                            device=xs[0].device) for h, wd in zip(hs, ws)]
+    e0 = _prof_begin()
+    call("sod_conv2d_fwd_ml", len(xs), _ptr_arr(xs), ptr(w), ptr(bias), _ptr_arr(outs), N, _int_arr(hs), _int_arr(ws), C, K, R, S,
+         stride, pad, dil, y_img_stride, CONV_RELU if relu else 0, 1 if out_f32 else 0, stream_ptr())
+    fl = sum(2.0 * N * ho * wo * K * R * S * C for ho, wo in (conv_out_size(h, wd, R, S, stride, pad, dil) for h, wd in zip(hs, ws)))
+    _prof_end("conv_fwd", fl, e0, ("ml", N, tuple(hs), C, K, R, stride))
+    return outs
+
+
+def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=None):
+    """dys: per-level dY tensors (or 1-D views into a concatenated buffer with dy_img_stride); returns per-level dX."""
+    _chk(wt, torch.bfloat16, "wt")
+    C, R, S, K = wt.shape
+    if N is None:
+        N = dys[0].shape[0]
+    dev = dys[0].device
+    outs = [torch.empty((N, h, w, C), dtype=torch.bfloat16, device=dev) for h, w in x_hws]
+    e0 = _prof_begin()
+    call("sod_conv2d_dgrad_ml", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]), _int_arr([w for _, w in x_hws]),
+         C, K, R, S, stride, pad, dil, dy_img_stride, stream_ptr())
+    fl = sum(2.0 * N * ho * wo * K * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in x_hws))
+    _prof_end("conv_dgrad", fl, e0, ("ml", N, tuple(h for h, _ in x_hws), C, K, R, stride))
+    return outs
+
+
+def conv2d_wgrad_ml(dys, xs, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, K=None, splits=0, qscale=None):
+    """Accumulates the weight gradient over all levels in one launch."""
+    _chk(dw, torch.float32, "dw")
+    N, C = xs[0].shape[0], xs[0].shape[3]
+    if K is None:
+        K = dys[0].shape[-1]
+    hs, ws = [x.shape[1] for x in xs], [x.shape[2] for x in xs]
+    e0 = _prof_begin()
+    call("sod_conv2d_wgrad_ml", len(xs), _ptr_arr(dys), _ptr_arr(xs), ptr(dw), ptr(qscale), N, _int_arr(hs), _int_arr(ws), C, K, R, S,
+         stride, pad, dil, dy_img_stride, splits, stream_ptr())
+    fl = sum(2.0 * N * ho * wo * K * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in zip(hs, ws)))
+    _prof_end("conv_wgrad", fl, e0, ("ml", N, tuple(hs), C, K, R, stride))
     return dw
 
 

@@ -146,49 +146,67 @@ class HipGroupNorm(nn.Module):
 
 
 class ConvGnRelu(nn.Module):
-    """[Conv3x3(bias) -> GroupNorm(32) -> ReLU] unit of the FCOS towers (fcosv2.py:300-336)."""
+    """[Conv3x3(bias) -> GroupNorm(32) -> ReLU] unit of the FCOS towers (fcosv2.py:300-336), applied to ALL FPN levels at
+    once: the levels share the weights, so the convolution forward / dgrad / wgrad are one multi-level launch each."""
 
     def __init__(self, channels, num_groups=32):
         super().__init__()
         self.conv = HipConv2d(channels, channels, 3, 1, 1, bias=True)
         self.gn = HipGroupNorm(num_groups, channels)
 
-    def forward(self, x):
+    def forward(self, xs):
+        single = isinstance(xs, torch.Tensor)
+        if single:
+            xs = [xs]
         self.conv.prepare()
-        return _ConvGnReluFn.apply(x, self.conv.weight, self)
+        out = _ConvGnReluFn.apply(self.conv.weight, self, *xs)
+        return out[0] if single else list(out)
 
 
 class _ConvGnReluFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, unit):
+    def forward(ctx, weight, unit, *xs):
         conv, gn = unit.conv, unit.gn
-        y1 = HF.conv2d_fwd(x, conv.w_bf16, conv.bias_eff, None, 1, 1, 1)
-        y2, stats = HF.groupnorm_fwd(y1, gn.weight.detach(), gn.bias.detach(), gn.num_groups, gn.eps, relu=True)
-        ctx.unit = unit
-        ctx.save_for_backward(x, y1, stats)
+        y1s = HF.conv2d_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, 1, 1, 1)
+        gw, gb = gn.weight.detach(), gn.bias.detach()
+        y2s, stats = [], []
+        for y1 in y1s:
+            y2, st = HF.groupnorm_fwd(y1, gw, gb, gn.num_groups, gn.eps, relu=True)
+            y2s.append(y2)
+            stats.append(st)
+        ctx.unit, ctx.nl = unit, len(xs)
+        ctx.save_for_backward(*xs, *y1s, *stats)
         arena = _arena_of(conv)
         if arena is not None and conv.weight.requires_grad:
             for p in (conv.weight, conv.bias, gn.weight, gn.bias):
                 arena.note_use(p)
-        return y2
+        return tuple(y2s)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy2):
+    def backward(ctx, *dy2s):
         conv, gn = ctx.unit.conv, ctx.unit.gn
-        x, y1, stats = ctx.saved_tensors
+        nl = ctx.nl
+        saved = ctx.saved_tensors
+        xs, y1s, stats = saved[:nl], saved[nl:2 * nl], saved[2 * nl:]
         arena = _arena_of(conv)
-        dy1 = HF.groupnorm_bwd(dy2.contiguous(), y1, gn.weight.detach(), gn.bias.detach(), stats, gn.num_groups,
-                               arena.grad_view(gn.weight), arena.grad_view(gn.bias), relu=True)
+        gw, gb = gn.weight.detach(), gn.bias.detach()
+        dgw, dgb = arena.grad_view(gn.weight), arena.grad_view(gn.bias)
+        dy1s = [HF.groupnorm_bwd(dy2.contiguous(), y1, gw, gb, st, gn.num_groups, dgw, dgb, relu=True)
+                for dy2, y1, st in zip(dy2s, y1s, stats)]
         arena.mark_ready(gn.weight)
         arena.mark_ready(gn.bias)
-        N, H, W, C = x.shape
-        HF.conv2d_wgrad(dy1, x, arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
+        HF.conv2d_wgrad_ml(dy1s, list(xs), arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
         arena.mark_ready(conv.weight)
-        HF.bias_grad(dy1, arena.grad_view(conv.bias), N, H * W, C)
+        dbias = arena.grad_view(conv.bias)
+        for dy1 in dy1s:
+            N, H, W, C = dy1.shape
+            HF.bias_grad(dy1, dbias, N, H * W, C)
         arena.mark_ready(conv.bias)
-        dx = HF.conv2d_dgrad(dy1, conv.wt_bf16, (H, W), 1, 1, 1) if ctx.needs_input_grad[0] else None
-        return dx, None, None
+        dxs = [None] * nl
+        if any(ctx.needs_input_grad[2:]):
+            dxs = HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, [(x.shape[1], x.shape[2]) for x in xs], 1, 1, 1)
+        return (None, None, *dxs)
 
 
 class _ReluFn(torch.autograd.Function):

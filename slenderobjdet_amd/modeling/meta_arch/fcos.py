@@ -77,15 +77,12 @@ class FCOSHead(nn.Module):
         return sum(p.numel() for p in self.parameters()) - pad_rows * (9 * c + 1)
 
     def run_towers(self, feats):
-        cls_t, box_t = [], []
-        for f in feats:
-            c, b = f, f
-            for unit in self.cls_tower:
-                c = unit(c)
-            for unit in self.bbox_tower:
-                b = unit(b)
-            cls_t.append(c)
-            box_t.append(b)
+        """Every tower unit runs over all FPN levels in one multi-level launch (the levels share the weights)."""
+        cls_t, box_t = list(feats), list(feats)
+        for unit in self.cls_tower:
+            cls_t = unit(cls_t)
+        for unit in self.bbox_tower:
+            box_t = unit(box_t)
         return cls_t, box_t
 
     def predict(self, cls_t, box_t):
@@ -98,13 +95,14 @@ class FCOSHead(nn.Module):
         dev = cls_t[0].device
         cls_buf = torch.empty((N, L, self.kc_pad), dtype=torch.float32, device=dev)
         box_buf = torch.empty((N, L, 8), dtype=torch.float32, device=dev)
-        off = 0
-        for (h, w), c, b in zip(hw, cls_t, box_t):
-            HF.conv2d_fwd(c, self.cls_pred.w_bf16, self.cls_pred.bias_eff, None, 1, 1, 1, out_f32=True,
-                          out=cls_buf.view(-1)[off * self.kc_pad:], y_img_stride=L * self.kc_pad)
-            HF.conv2d_fwd(b, self.box_pred.w_bf16, self.box_pred.bias_eff, None, 1, 1, 1, out_f32=True,
-                          out=box_buf.view(-1)[off * 8:], y_img_stride=L * 8)
+        offs, off = [], 0
+        for h, w in hw:
+            offs.append(off)
             off += h * w
+        HF.conv2d_fwd_ml(list(cls_t), self.cls_pred.w_bf16, self.cls_pred.bias_eff, 1, 1, 1, out_f32=True,
+                         outs=[cls_buf.view(-1)[o * self.kc_pad:] for o in offs], y_img_stride=L * self.kc_pad)
+        HF.conv2d_fwd_ml(list(box_t), self.box_pred.w_bf16, self.box_pred.bias_eff, 1, 1, 1, out_f32=True,
+                         outs=[box_buf.view(-1)[o * 8:] for o in offs], y_img_stride=L * 8)
         return cls_buf, box_buf, hw
 
 
@@ -131,10 +129,8 @@ class _FcosHeadLossFn(torch.autograd.Function):
         ctx.save_for_backward(cls_buf, box_buf, labels, reg_t, ctr_t, stats, *towers)
         arena = _arena_of(head)
         if arena is not None:
-            for _ in range(nl):
-                for p in (head.cls_pred.weight, head.cls_pred.bias, head.box_pred.weight, head.box_pred.bias):
-                    arena.note_use(p)
-            arena.note_use(head.scales)
+            for p in (head.cls_pred.weight, head.cls_pred.bias, head.box_pred.weight, head.box_pred.bias, head.scales):
+                arena.note_use(p)
         return out3
 
     @staticmethod
@@ -165,17 +161,19 @@ class _FcosHeadLossFn(torch.autograd.Function):
                                 model.iou_loss_type, head.norm_reg_targets, g3[1:2], g3[2:3], stats, inv_world,
                                 dbox, 8, ctr_col, dctr, ld_dctr, dctr_col, arena.grad_view(head.scales))
         arena.mark_ready(head.scales)
-        grads_cls, grads_box = [], []
-        off = 0
-        for lvl, (h, w) in enumerate(hw):
-            for (pred, dbuf, kk, tower, outl) in ((head.cls_pred, dcls, kcp, cls_t[lvl], grads_cls), (head.box_pred, dbox, 8, box_t[lvl], grads_box)):
-                dy = dbuf.view(-1)[off * kk:]
-                HF.conv2d_wgrad(dy, tower, arena.grad_view(pred.weight), 3, 3, 1, 1, 1, dy_img_stride=L * kk, K=kk)
-                arena.mark_ready(pred.weight)
-                HF.bias_grad(dy, arena.grad_view(pred.bias), N, h * w, kk, img_stride=L * kk)
-                arena.mark_ready(pred.bias)
-                outl.append(HF.conv2d_dgrad(dy, pred.wt_bf16, (h, w), 1, 1, 1, dy_img_stride=L * kk, dy_shape=(N,)))
+        offs, off = [], 0
+        for h, w in hw:
+            offs.append(off)
             off += h * w
+        grads = []
+        for pred, dbuf, kk, tower in ((head.cls_pred, dcls, kcp, cls_t), (head.box_pred, dbox, 8, box_t)):
+            dys = [dbuf.view(-1)[o * kk:] for o in offs]
+            HF.conv2d_wgrad_ml(dys, list(tower), arena.grad_view(pred.weight), 3, 3, 1, 1, 1, dy_img_stride=L * kk, K=kk)
+            arena.mark_ready(pred.weight)
+            HF.bias_grad(dbuf, arena.grad_view(pred.bias), N, L, kk)
+            arena.mark_ready(pred.bias)
+            grads.append(HF.conv2d_dgrad_ml(dys, pred.wt_bf16, hw, 1, 1, 1, dy_img_stride=L * kk, N=N))
+        grads_cls, grads_box = grads
         return (None, None, None, None, None, None, None, *grads_cls, *grads_box)
 
 

@@ -188,3 +188,45 @@ def test_conv_rejects_bad_args(cuda):
         HF.conv2d_fwd(x, w, None, stride=1, pad=1)
     with pytest.raises(_C.SlenderHipError):
         HF.conv2d_fwd(x.cpu(), w.cpu(), None, stride=1, pad=1)
+
+
+def test_conv_multilevel_matches_per_level(cuda):
+    """One multi-level launch (shared weights over FPN levels) == the per-level oracle results, fwd / dgrad / wgrad,
+    including the concatenated-output form used by the prediction convs."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, C, K = 2, 64, 128
+    hw = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    w = _rand((K, 3, 3, C), 1, 0.05)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(2))
+    xs = [_rand((N, h, ww, C), 10 + i) for i, (h, ww) in enumerate(hw)]
+    dys = [_rand((N, h, ww, K), 20 + i) for i, (h, ww) in enumerate(hw)]
+    wk, wt = HF.weight_prep(w.to(cuda))
+    xd = [x.to(cuda).bfloat16() for x in xs]
+    dyd = [d.to(cuda).bfloat16() for d in dys]
+    ys = HF.conv2d_fwd_ml(xd, wk, b.to(cuda), 1, 1, 1, relu=True)
+    dxs = HF.conv2d_dgrad_ml(dyd, wt, hw, 1, 1, 1)
+    dw = torch.zeros((K, 3, 3, C), device=cuda)
+    HF.conv2d_wgrad_ml(dyd, xd, dw, 3, 3, 1, 1, 1)
+    dw_ref = torch.zeros(K, 3, 3, C)
+    for x, dy, y, dx in zip(xs, dys, ys, dxs):
+        _close(y, onn.conv2d(x, w, b, 1, 1, 1, relu=True), 2 ** -7, "ml fwd")
+        dx_ref, dwr = onn.conv2d_backward(x, w, dy, 1, 1, 1)
+        _close(dx, dx_ref, 2 ** -7, "ml dgrad")
+        dw_ref += dwr
+    _close(dw, dw_ref, 2e-4, "ml wgrad")
+    # concatenated fp32 output + strided gradient input (prediction convs)
+    L = sum(h * ww for h, ww in hw)
+    offs = [sum(h * ww for h, ww in hw[:i]) for i in range(len(hw))]
+    buf = torch.zeros((N, L, K), dtype=torch.float32, device=cuda)
+    HF.conv2d_fwd_ml(xd, wk, None, 1, 1, 1, out_f32=True, outs=[buf.view(-1)[o * K:] for o in offs], y_img_stride=L * K)
+    ref = torch.cat([onn.conv2d(x, w, None, 1, 1, 1).reshape(N, -1, K) for x in xs], 1)
+    _close(buf, ref, 2e-4, "ml concat fwd")
+    gbuf = torch.cat([d.reshape(N, -1, K) for d in dys], 1).to(cuda).bfloat16().contiguous()
+    gviews = [gbuf.view(-1)[o * K:] for o in offs]
+    dxs2 = HF.conv2d_dgrad_ml(gviews, wt, hw, 1, 1, 1, dy_img_stride=L * K, N=N)
+    for dx, dx1 in zip(dxs2, dxs):
+        assert torch.equal(dx, dx1)
+    dw2 = torch.zeros_like(dw)
+    HF.conv2d_wgrad_ml(gviews, xd, dw2, 3, 3, 1, 1, 1, dy_img_stride=L * K, K=K)
+    _close(dw2, dw_ref, 2e-4, "ml concat wgrad")
