@@ -54,6 +54,23 @@ def train_step(model, optimizer, data):
     return total
 
 
+def pmc_traffic(kind):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json: separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md). None if absent."""
+    import glob
+
+    names = {"conv_fwd": "void conv_igemm_kernel<0, false, 2, 2, 4, 4, false>", "conv_dgrad": "void conv_igemm_kernel<1, false, 2, 2, 4, 4, false>",
+             "conv_wgrad": "conv_wgrad_kernel"}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files or kind not in names:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(names[kind])
+        return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)} if k else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(model, args):
     """Time the CPU oracle (oracle/model.py) on a bounded sample of the same workload, host cores of this box."""
     from oracle.model import OracleFCOS
@@ -80,7 +97,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=16)
-    ap.add_argument("--cpu-images", type=int, default=1)
+    ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -157,7 +174,7 @@ def main():
             fl, sec, cnt = agg[kind]
             achieved = fl / sec / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": kind, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": cnt,
+                               "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(kind), "launches": cnt,
                                "avg_launch_us": round(sec / cnt * 1e6, 2),
                                "all_conv": {k: {"TFLOP/s": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / args.steps * 1e3, 3)} for k, v in agg.items()}}
         if prof and args.dump_prof:

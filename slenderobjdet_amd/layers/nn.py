@@ -77,10 +77,14 @@ class HipConv2d(nn.Module):
             return
         w = self.weight.detach()
         if self.frozen_bn:
-            scale = self.bn_weight * torch.rsqrt(self.bn_running_var + 1e-5)
-            shift = self.bn_bias - self.bn_running_mean * scale
-            self.bn_scale = scale.contiguous()
-            self.bias_eff = (shift + (self.bias.detach() * scale if self.bias is not None else 0)).contiguous()
+            bn_key = (self.bn_weight._version, self.bn_bias._version, self.bn_running_mean._version, self.bn_running_var._version,
+                      self.bn_weight.data_ptr(), self.bias._version if self.bias is not None else 0)
+            if bn_key != getattr(self, "_bn_key", None):   # the folded affine is constant: recompute only when buffers change
+                scale = self.bn_weight * torch.rsqrt(self.bn_running_var + 1e-5)
+                shift = self.bn_bias - self.bn_running_mean * scale
+                self.bn_scale = scale.contiguous()
+                self.bias_eff = (shift + (self.bias.detach() * scale if self.bias is not None else 0)).contiguous()
+                self._bn_key = bn_key
         else:
             self.bn_scale = None
             self.bias_eff = self.bias.detach() if self.bias is not None else None

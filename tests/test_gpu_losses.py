@@ -238,3 +238,35 @@ def test_preprocess(cuda):
     assert (out[..., 3:] == 0).all()
     HF.preprocess_image(img.float().to(cuda), out, mean, std)
     assert torch.equal(out[..., :3].float().cpu(), ref)
+
+
+def test_reference_signature_wrappers(cuda):
+    """layers.losses.{sigmoid_focal_loss_jit, iou_loss} keep the reference signatures and are differentiable."""
+    from slenderobjdet_amd.layers.losses import iou_loss, sigmoid_focal_loss_jit
+
+    x = torch.randn(300, 80, generator=_g(0))
+    labels = torch.randint(0, 81, (300,), generator=_g(1))
+    onehot = ol.one_hot_from_labels(labels, 80)
+    xr = x.clone().requires_grad_(True)
+    ref = ol.sigmoid_focal_loss(xr, onehot, 0.25, 2.0, "sum") / 7.0
+    (gref,) = torch.autograd.grad(ref, xr)
+    for tgt in (onehot.to(cuda), labels.to(cuda)):
+        xd = x.to(cuda).requires_grad_(True)
+        out = sigmoid_focal_loss_jit(xd, tgt, alpha=0.25, gamma=2.0, reduction="sum") / 7.0
+        out.backward()
+        _rel(out, ref, 1e-5, "focal wrapper")
+        _rel(xd.grad, gref, 1e-5, "focal wrapper grad")
+    _rel(sigmoid_focal_loss_jit(x.to(cuda), onehot.to(cuda), 0.25, 2.0, "mean"), ol.sigmoid_focal_loss(x, onehot, 0.25, 2.0, "mean"), 1e-5, "mean")
+    pred = torch.rand(50, 4, generator=_g(2)) * 20 + 1
+    tgt = torch.rand(50, 4, generator=_g(3)) * 20 + 1
+    w = torch.rand(50, generator=_g(4))
+    pr = pred.clone().requires_grad_(True)
+    ref = ol.iou_loss_ltrb(pr, tgt, w, "giou") * 0.5
+    (gref,) = torch.autograd.grad(ref, pr)
+    pd = pred.to(cuda).requires_grad_(True)
+    out = iou_loss(pd, tgt.to(cuda), w.to(cuda), loss_type="giou") * 0.5
+    out.backward()
+    _rel(out, ref, 1e-5, "iou wrapper")
+    _rel(pd.grad, gref, 2e-5, "iou wrapper grad")
+    with pytest.raises(NotImplementedError):
+        iou_loss(pd, tgt.to(cuda), None, loss_type="diou")
