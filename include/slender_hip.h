@@ -159,6 +159,35 @@ int sod_fcos_regctr_loss_bwd(const float* box_raw, int ld_box, const float* ctr_
 int sod_fcos_finalize_losses(const float* focal_sum, const float* regctr_sums, const float* stats,
                              float inv_world, float* out3, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Detection operators (detectron2 / torchvision / fvcore)
+ * --------------------------------------------------------------------------------------------------------- */
+/* torchvision.ops.nms behind detectron2.layers.batched_nms (fcosv2.py:241): `order` = indices sorted by descending score
+ * (stable), greedy suppression of IoU > iou_threshold, IoU = inter/(a+b-inter). keep[0..*num_keep) = kept ORIGINAL indices
+ * in score order. mask_ws: sod_nms_workspace_bytes(n) bytes. n <= 65536. */
+long long sod_nms_workspace_bytes(int n);
+int sod_nms(const float* boxes, const long long* order, int n, float iou_threshold, long long* keep, int* num_keep,
+            void* mask_ws, void* stream);
+/* detectron2 ROIAlign(output_size, spatial_scale, sampling_ratio, aligned=True) / ROIAlignRotated (roi_heads/roi_heads.py:48-53).
+ * x: NHWC bf16; rois (R,5) [batch,x1,y1,x2,y2] or, rotated, (R,6) [batch,cx,cy,w,h,angle_deg]; out (R,PH,PW,C) fp32.
+ * bwd accumulates atomically into dx (N,H,W,C) fp32 (zero it first). */
+int sod_roi_align_fwd(const void* x, const float* rois, float* out, int R, int N, int H, int W, int C, int PH, int PW,
+                      float spatial_scale, int sampling_ratio, int rotated, void* stream);
+int sod_roi_align_bwd(const float* dout, const float* rois, float* dx, int R, int N, int H, int W, int C, int PH, int PW,
+                      float spatial_scale, int sampling_ratio, int rotated, void* stream);
+/* fvcore.nn.giou_loss(boxes1, boxes2, eps) on XYXY (retina_rotated.py:240): per-row loss, optional sum, optional gradient
+ * w.r.t. boxes1 scaled by grad_scale[0]. */
+int sod_giou_loss_xyxy(const float* boxes1, const float* boxes2, long long P, float eps, float* elem_out, float* sum_out,
+                       const float* grad_scale, float* dboxes1, float* ws, void* stream);
+/* fvcore.nn.smooth_l1_loss(input, target, beta) (retina_rotated.py:229, rpd.py:389-395) */
+int sod_smooth_l1_loss(const float* input, const float* target, long long n, float beta, float* elem_out, float* sum_out,
+                       const float* grad_scale, float* dinput, float* ws, void* stream);
+/* pairwise_iou + Matcher([lo,hi],[l0,l1,l2],allow_low_quality_matches) of RetinaNet.label_anchors (retina_rotated.py:251-295)
+ * without materialising the G x A matrix. gt_best_ws: G unsigned words. G <= 4096. */
+int sod_anchor_match(const float* gt_boxes, int G, const float* anchors, int A, float thr_lo, float thr_hi,
+                     int label_below, int label_between, int label_above, int allow_low_quality,
+                     float* matched_vals, int* matches, signed char* labels, unsigned* gt_best_ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

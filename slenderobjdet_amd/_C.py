@@ -48,10 +48,17 @@ _SIGS = {
     "sod_fcos_regctr_loss_bwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F,
                                  _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "sod_fcos_finalize_losses": [_P, _P, _P, _F, _P, _P],
+    "sod_nms_workspace_bytes": [_I],
+    "sod_nms": [_P, _P, _I, _F, _P, _P, _P, _P],
+    "sod_roi_align_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
+    "sod_roi_align_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
+    "sod_giou_loss_xyxy": [_P, _P, _L, _F, _P, _P, _P, _P, _P, _P],
+    "sod_smooth_l1_loss": [_P, _P, _L, _F, _P, _P, _P, _P, _P, _P],
+    "sod_anchor_match": [_P, _I, _P, _I, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sod_reduce_workspace_bytes": [],
     "sod_version": [],
 }
-_RESTYPES = {"sod_reduce_workspace_bytes": c_longlong, "sod_version": c_char_p}
+_RESTYPES = {"sod_reduce_workspace_bytes": c_longlong, "sod_nms_workspace_bytes": c_longlong, "sod_version": c_char_p}
 
 
 class SlenderHipError(RuntimeError):

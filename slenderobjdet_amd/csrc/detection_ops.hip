@@ -1,0 +1,388 @@
+// Detection post-/mid-processing operators the reference reaches through detectron2 / torchvision / fvcore
+// (sources absent from the reference tree; semantics restated in SURVEY.md Appendix C.3, C.4, C.5, C.12, C.13, C.14):
+//   nms                      torchvision.ops.nms via detectron2.layers.batched_nms (call sites fcosv2.py:241, rpd.py:781,
+//                            proposal_utils.py:115, roi_heads/fast_rcnn.py:103)
+//   roi_align fwd/bwd        detectron2 ROIAlign(aligned=True) used by ROIPooler (roi_heads/roi_heads.py:48-53)
+//   roi_align_rotated fwd    detectron2 ROIAlignRotated (configs/rotated/Base-RRCNN-FPN.yaml:31-36)
+//   giou / smooth-L1         fvcore.nn.giou_loss / smooth_l1_loss (retina_rotated.py:229,240; rpd.py:389-395)
+//   anchor labelling         pairwise_iou + Matcher(thresholds, labels, allow_low_quality_matches) (retina_rotated.py:251-295)
+// All are HBM/latency-bound gather kernels: coalesced 16-B channel vectors, wavefront reductions, no MFMA.
+#include "common.h"
+#include "../../include/slender_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- NMS
+// boxes are given in descending-score order; mask[i][w] bit b = IoU(box i, box 64*w+b) > thr, only for j > i.
+__device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thr) {
+  const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+  const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+  const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+  const float inter = width * height;
+  const float sa = (a[2] - a[0]) * (a[3] - a[1]);
+  const float sb = (b[2] - b[0]) * (b[3] - b[1]);
+  return inter / (sa + sb - inter) > thr;
+}
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const long long* __restrict__ order, int n,
+                                                      float thr, unsigned long long* __restrict__ mask, int words) {
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;   // only the upper triangle is ever read
+  __shared__ float cbox[64 * 4];
+  const int lane = threadIdx.x;
+  const int cj = cb * 64 + lane;
+  if (cj < n) {
+    const long long o = order[cj];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cbox[lane * 4 + e] = boxes[o * 4 + e];
+  }
+  __syncthreads();
+  const int i = rb * 64 + lane;
+  if (i >= n) return;
+  float a[4];
+  const long long oi = order[i];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) a[e] = boxes[oi * 4 + e];
+  unsigned long long bits = 0;
+  const int cnt = min(64, n - cb * 64);
+  const int start = (rb == cb) ? lane + 1 : 0;
+  for (int j = start; j < cnt; ++j)
+    if (iou_gt(a, cbox + j * 4, thr)) bits |= 1ull << j;
+  mask[(long long)i * words + cb] = bits;
+}
+
+// single workgroup: thread w owns word w of the "removed" bitmap; boxes are visited in score order
+__global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long* __restrict__ mask, const long long* __restrict__ order,
+                                                        int n, int words, long long* __restrict__ keep, int* __restrict__ nkeep) {
+  __shared__ unsigned long long removed[1024];
+  __shared__ int flag;
+  const int w = threadIdx.x;
+  if (w < words) removed[w] = 0;
+  __syncthreads();
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    if (w == 0) flag = (int)((removed[i >> 6] >> (i & 63)) & 1ull);
+    __syncthreads();
+    const bool dead = flag != 0;
+    if (!dead) {
+      if (w == 0) keep[kept] = order[i];
+      ++kept;
+      if (w < words && w >= (i >> 6)) removed[w] |= mask[(long long)i * words + w];
+    }
+    __syncthreads();
+  }
+  if (w == 0) *nkeep = kept;
+}
+
+// ---------------------------------------------------------------------------------------------- ROIAlign (aligned=True)
+struct RoiArgs {
+  const __bf16* x;      // (N,H,W,C) NHWC bf16
+  const float* rois;    // (R,5) [batch, x1,y1,x2,y2]  or (R,6) [batch, cx,cy,w,h,angle_deg] when rotated
+  int R, N, H, W, C, PH, PW, sampling_ratio;
+  float scale;
+  int rotated;
+};
+
+__device__ __forceinline__ void bilinear_setup(float y, float x, int H, int W, int& yl, int& xl, int& yh, int& xh, float w[4], bool& valid) {
+  valid = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  yl = (int)y; xl = (int)x;
+  if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+  if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+  const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+  w[0] = hy * hx; w[1] = hy * lx; w[2] = ly * hx; w[3] = ly * lx;
+}
+
+// one thread = one (roi, ph, pw, 8-channel vector)
+template <bool BWD>
+__global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a, float* __restrict__ out /* fwd (R,PH,PW,C) f32 */,
+                                                        const float* __restrict__ dout, float* __restrict__ dx /* (N,H,W,C) f32 */) {
+  const int c8n = a.C >> 3;
+  const long long total = (long long)a.R * a.PH * a.PW * c8n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c8 = (int)(i % c8n);
+    long long t = i / c8n;
+    const int pw = (int)(t % a.PW); t /= a.PW;
+    const int ph = (int)(t % a.PH);
+    const int r = (int)(t / a.PH);
+    const float* roi = a.rois + (long long)r * (a.rotated ? 6 : 5);
+    const int b = (int)roi[0];
+    float start_h, start_w, roi_h, roi_w, cth = 1.f, sth = 0.f, ctr_h = 0.f, ctr_w = 0.f;
+    if (a.rotated) {
+      ctr_w = roi[1] * a.scale - 0.5f; ctr_h = roi[2] * a.scale - 0.5f;
+      roi_w = roi[3] * a.scale; roi_h = roi[4] * a.scale;
+      const float theta = roi[5] * 3.14159265358979323846f / 180.0f;
+      cth = cosf(theta); sth = sinf(theta);
+      start_h = -roi_h / 2.0f; start_w = -roi_w / 2.0f;
+    } else {
+      start_w = roi[1] * a.scale - 0.5f; start_h = roi[2] * a.scale - 0.5f;
+      roi_w = roi[3] * a.scale - 0.5f - start_w; roi_h = roi[4] * a.scale - 0.5f - start_h;
+    }
+    const float bin_h = roi_h / (float)a.PH, bin_w = roi_w / (float)a.PW;
+    const int gh = a.sampling_ratio > 0 ? a.sampling_ratio : (int)ceilf(roi_h / (float)a.PH);
+    const int gw = a.sampling_ratio > 0 ? a.sampling_ratio : (int)ceilf(roi_w / (float)a.PW);
+    const float count = fmaxf((float)(gh * gw), 1.f);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float g[8];
+    if (BWD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = dout[i * 8 + e] / count;
+    }
+    for (int iy = 0; iy < gh; ++iy) {
+      const float yy = start_h + ph * bin_h + (iy + 0.5f) * bin_h / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        const float xx = start_w + pw * bin_w + (ix + 0.5f) * bin_w / (float)gw;
+        float y = yy, x = xx;
+        if (a.rotated) { y = yy * cth - xx * sth + ctr_h; x = yy * sth + xx * cth + ctr_w; }
+        int yl, xl, yh, xh; float w[4]; bool valid;
+        bilinear_setup(y, x, a.H, a.W, yl, xl, yh, xh, w, valid);
+        if (!valid) continue;
+        const long long base = ((long long)b * a.H) * a.W;
+        const long long o00 = ((base + (long long)yl * a.W + xl) * a.C) + c8 * 8, o01 = ((base + (long long)yl * a.W + xh) * a.C) + c8 * 8;
+        const long long o10 = ((base + (long long)yh * a.W + xl) * a.C) + c8 * 8, o11 = ((base + (long long)yh * a.W + xh) * a.C) + c8 * 8;
+        if (!BWD) {
+          const bf16x8_t v00 = *reinterpret_cast<const bf16x8_t*>(a.x + o00), v01 = *reinterpret_cast<const bf16x8_t*>(a.x + o01);
+          const bf16x8_t v10 = *reinterpret_cast<const bf16x8_t*>(a.x + o10), v11 = *reinterpret_cast<const bf16x8_t*>(a.x + o11);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += w[0] * (float)v00[e] + w[1] * (float)v01[e] + w[2] * (float)v10[e] + w[3] * (float)v11[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            atomicAdd(dx + o00 + e, g[e] * w[0]); atomicAdd(dx + o01 + e, g[e] * w[1]);
+            atomicAdd(dx + o10 + e, g[e] * w[2]); atomicAdd(dx + o11 + e, g[e] * w[3]);
+          }
+        }
+      }
+    }
+    if (!BWD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) out[i * 8 + e] = acc[e] / count;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- box losses on XYXY
+constexpr int RED = 1024;
+__global__ void finish_sum2(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+  __shared__ float red[4];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) v += part[i];
+  v = block_sum_256(v, red);
+  if (threadIdx.x == 0) out[0] = v;
+}
+
+// fvcore giou_loss (eps 1e-7): per-row loss and gradient w.r.t. boxes1
+__global__ __launch_bounds__(256) void giou_xyxy_kernel(const float* __restrict__ b1, const float* __restrict__ b2, long long P, float eps,
+                                                        float* __restrict__ elem, float* __restrict__ part, const float* __restrict__ gscale,
+                                                        float* __restrict__ d1) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float gs = gscale ? gscale[0] : 1.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < P; i += (long long)gridDim.x * 256) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(b1 + i * 4), b = *reinterpret_cast<const f32x4_t*>(b2 + i * 4);
+    const float x1 = a[0], y1 = a[1], x2 = a[2], y2 = a[3], x1g = b[0], y1g = b[1], x2g = b[2], y2g = b[3];
+    const float xk1 = fmaxf(x1, x1g), yk1 = fmaxf(y1, y1g), xk2 = fminf(x2, x2g), yk2 = fminf(y2, y2g);
+    const bool ov = (yk2 > yk1) && (xk2 > xk1);
+    const float inter = ov ? (xk2 - xk1) * (yk2 - yk1) : 0.f;
+    const float uni = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter;
+    const float iou = inter / (uni + eps);
+    const float xc1 = fminf(x1, x1g), yc1 = fminf(y1, y1g), xc2 = fmaxf(x2, x2g), yc2 = fmaxf(y2, y2g);
+    const float ac = (xc2 - xc1) * (yc2 - yc1);
+    const float l = 1.f - (iou - (ac - uni) / (ac + eps));
+    if (elem) elem[i] = l;
+    acc += l;
+    if (d1) {
+      // derivatives of inter / union / hull w.r.t. (x1,y1,x2,y2) of box 1; max/min ties split like torch
+      auto dmax = [](float p, float q) { return p > q ? 1.f : (p == q ? 0.5f : 0.f); };
+      auto dmin = [](float p, float q) { return p < q ? 1.f : (p == q ? 0.5f : 0.f); };
+      const float iw = xk2 - xk1, ih = yk2 - yk1, w1 = x2 - x1, h1 = y2 - y1, cw = xc2 - xc1, ch = yc2 - yc1;
+      const float di[4] = {ov ? -dmax(x1, x1g) * ih : 0.f, ov ? -dmax(y1, y1g) * iw : 0.f, ov ? dmin(x2, x2g) * ih : 0.f, ov ? dmin(y2, y2g) * iw : 0.f};
+      const float da[4] = {-h1, -w1, h1, w1};
+      const float dc[4] = {-dmin(x1, x1g) * ch, -dmin(y1, y1g) * cw, dmax(x2, x2g) * ch, dmax(y2, y2g) * cw};
+      f32x4_t g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float du = da[e] - di[e];
+        const float diou = (di[e] * (uni + eps) - inter * du) / ((uni + eps) * (uni + eps));
+        const float dterm = ((dc[e] - du) * (ac + eps) - (ac - uni) * dc[e]) / ((ac + eps) * (ac + eps));
+        g[e] = -(diou - dterm) * gs;
+      }
+      *reinterpret_cast<f32x4_t*>(d1 + i * 4) = g;
+    }
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0 && part) part[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict__ x, const float* __restrict__ t, long long n, float beta,
+                                                        float* __restrict__ elem, float* __restrict__ part, const float* __restrict__ gscale,
+                                                        float* __restrict__ dx) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float gs = gscale ? gscale[0] : 1.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float d = x[i] - t[i], ad = fabsf(d);
+    float l, g;
+    if (beta < 1e-5f) { l = ad; g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+    else if (ad < beta) { l = 0.5f * d * d / beta; g = d / beta; }
+    else { l = ad - 0.5f * beta; g = d > 0.f ? 1.f : -1.f; }
+    if (elem) elem[i] = l;
+    if (dx) dx[i] = g * gs;
+    acc += l;
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0 && part) part[blockIdx.x] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------- anchor labelling
+// Matcher(thresholds=[lo,hi], labels=[l0,l1,l2], allow_low_quality_matches) over pairwise_iou(gt (G), anchors (A)) without the
+// G x A matrix: pass 1 = per-anchor max/argmax over gts + per-gt max over anchors (atomicMax on float bits, IoU >= 0);
+// pass 2 = thresholds + low-quality promotion (anchor ties with the per-gt best, as `Q == best_per_gt[:, None]`).
+__device__ __forceinline__ float pair_iou(const float* g, const float* a) {
+  const float w = fminf(g[2], a[2]) - fmaxf(g[0], a[0]), h = fminf(g[3], a[3]) - fmaxf(g[1], a[1]);
+  const float inter = fmaxf(w, 0.f) * fmaxf(h, 0.f);
+  const float ag = (g[2] - g[0]) * (g[3] - g[1]), aa = (a[2] - a[0]) * (a[3] - a[1]);
+  return inter > 0.f ? inter / (ag + aa - inter) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void anchor_match1_kernel(const float* __restrict__ gts, int G, const float* __restrict__ anchors, int A,
+                                                            float* __restrict__ best_val, int* __restrict__ best_idx,
+                                                            unsigned* __restrict__ gt_best_bits) {
+  extern __shared__ unsigned lbest[];   // [G]
+  for (int g = threadIdx.x; g < G; g += 256) lbest[g] = 0u;
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < A; i += gridDim.x * 256) {
+    const f32x4_t av = *reinterpret_cast<const f32x4_t*>(anchors + (long long)i * 4);
+    const float a[4] = {av[0], av[1], av[2], av[3]};
+    float bv = -1.f; int bi = 0;
+    for (int g = 0; g < G; ++g) {
+      const float v = pair_iou(gts + g * 4, a);
+      if (v > bv) { bv = v; bi = g; }            // first maximum wins (torch.max(dim=0))
+      atomicMax(&lbest[g], __float_as_uint(v));  // v >= 0: uint order == float order
+    }
+    best_val[i] = bv; best_idx[i] = bi;
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += 256) atomicMax(&gt_best_bits[g], lbest[g]);
+}
+
+__global__ __launch_bounds__(256) void anchor_match2_kernel(const float* __restrict__ gts, int G, const float* __restrict__ anchors, int A,
+                                                            const float* __restrict__ best_val, const unsigned* __restrict__ gt_best_bits,
+                                                            float lo, float hi, int l0, int l1, int l2, int low_quality,
+                                                            signed char* __restrict__ labels) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < A; i += gridDim.x * 256) {
+    const float v = best_val[i];
+    int lab = (v < lo) ? l0 : ((v < hi) ? l1 : l2);
+    if (low_quality) {
+      const f32x4_t av = *reinterpret_cast<const f32x4_t*>(anchors + (long long)i * 4);
+      const float a[4] = {av[0], av[1], av[2], av[3]};
+      for (int g = 0; g < G; ++g)
+        if (pair_iou(gts + g * 4, a) == __uint_as_float(gt_best_bits[g])) { lab = 1; break; }
+    }
+    labels[i] = (signed char)lab;
+  }
+}
+
+inline int nblk(long long n, int cap = RED) {
+  long long g = (n + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" long long sod_nms_workspace_bytes(int n) {
+  const long long words = (n + 63) / 64;
+  return (long long)n * words * 8;
+}
+
+extern "C" int sod_nms(const float* boxes, const long long* order, int n, float iou_threshold, long long* keep, int* num_keep,
+                       void* mask_ws, void* stream) {
+  if (n < 0 || !num_keep || (n > 0 && (!boxes || !order || !keep || !mask_ws))) return SOD_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int), st);
+  const int words = (n + 63) / 64;
+  if (words > 1024) return SOD_ESIZE;   // 65536 boxes per call (detectron2 switches to per-class loops above 40 000)
+  hipError_t e = hipMemsetAsync(mask_ws, 0, (size_t)n * words * 8, st);
+  if (e != hipSuccess) return (int)e;
+  SOD_LAUNCH(nms_mask_kernel, dim3(words, words), dim3(64), 0, st, boxes, order, n, iou_threshold, (unsigned long long*)mask_ws, words);
+  SOD_LAUNCH(nms_scan_kernel, dim3(1), dim3(1024), 0, st, (const unsigned long long*)mask_ws, order, n, words, keep, num_keep);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+static int roi_fill(RoiArgs& a, const void* x, const float* rois, int R, int N, int H, int W, int C, int PH, int PW, float scale,
+                    int sampling_ratio, int rotated) {
+  if (!x || !rois || R < 0 || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || PH <= 0 || PW <= 0) return SOD_EARG;
+  a.x = (const __bf16*)x; a.rois = rois; a.R = R; a.N = N; a.H = H; a.W = W; a.C = C; a.PH = PH; a.PW = PW;
+  a.scale = scale; a.sampling_ratio = sampling_ratio; a.rotated = rotated;
+  return SOD_OK;
+}
+
+extern "C" int sod_roi_align_fwd(const void* x, const float* rois, float* out, int R, int N, int H, int W, int C, int PH, int PW,
+                                 float spatial_scale, int sampling_ratio, int rotated, void* stream) {
+  RoiArgs a{};
+  int rc = roi_fill(a, x, rois, R, N, H, W, C, PH, PW, spatial_scale, sampling_ratio, rotated);
+  if (rc || !out) return rc ? rc : SOD_EARG;
+  if (R == 0) return SOD_OK;
+  SOD_LAUNCH(roi_align_kernel<false>, dim3(nblk((long long)R * PH * PW * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream, a, out, nullptr, nullptr);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_roi_align_bwd(const float* dout, const float* rois, float* dx, int R, int N, int H, int W, int C, int PH, int PW,
+                                 float spatial_scale, int sampling_ratio, int rotated, void* stream) {
+  RoiArgs a{};
+  int rc = roi_fill(a, dx, rois, R, N, H, W, C, PH, PW, spatial_scale, sampling_ratio, rotated);   // x unused in bwd
+  if (rc || !dout || !dx) return rc ? rc : SOD_EARG;
+  if (R == 0) return SOD_OK;
+  SOD_LAUNCH(roi_align_kernel<true>, dim3(nblk((long long)R * PH * PW * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream, a, nullptr, dout, dx);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_giou_loss_xyxy(const float* boxes1, const float* boxes2, long long P, float eps, float* elem_out, float* sum_out,
+                                  const float* grad_scale, float* dboxes1, float* ws, void* stream) {
+  if (!boxes1 || !boxes2 || P < 0 || (sum_out && !ws)) return SOD_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = nblk(P);
+  SOD_LAUNCH(giou_xyxy_kernel, dim3(g), dim3(256), 0, st, boxes1, boxes2, P, eps, elem_out, sum_out ? ws : nullptr, grad_scale, dboxes1);
+  if (sum_out) SOD_LAUNCH(finish_sum2, dim3(1), dim3(256), 0, st, ws, g, sum_out);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_smooth_l1_loss(const float* input, const float* target, long long n, float beta, float* elem_out, float* sum_out,
+                                  const float* grad_scale, float* dinput, float* ws, void* stream) {
+  if (!input || !target || n < 0 || (sum_out && !ws)) return SOD_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = nblk(n);
+  SOD_LAUNCH(smooth_l1_kernel, dim3(g), dim3(256), 0, st, input, target, n, beta, elem_out, sum_out ? ws : nullptr, grad_scale, dinput);
+  if (sum_out) SOD_LAUNCH(finish_sum2, dim3(1), dim3(256), 0, st, ws, g, sum_out);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_anchor_match(const float* gt_boxes, int G, const float* anchors, int A, float thr_lo, float thr_hi,
+                                int label_below, int label_between, int label_above, int allow_low_quality,
+                                float* matched_vals, int* matches, signed char* labels, unsigned* gt_best_ws, void* stream) {
+  if (!anchors || A <= 0 || !matched_vals || !matches || !labels || G < 0 || G > 4096) return SOD_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (G == 0) {   // Matcher on an empty gt set: everything unmatched with the lowest label
+    hipError_t e = hipMemsetAsync(matches, 0, sizeof(int) * A, st);
+    if (e == hipSuccess) e = hipMemsetAsync(matched_vals, 0, sizeof(float) * A, st);
+    if (e == hipSuccess) e = hipMemsetAsync(labels, label_below & 0xff, A, st);
+    return (int)e;
+  }
+  if (!gt_boxes || !gt_best_ws) return SOD_EARG;
+  hipError_t e = hipMemsetAsync(gt_best_ws, 0, sizeof(unsigned) * G, st);
+  if (e != hipSuccess) return (int)e;
+  const int g = nblk(A, 2048);
+  SOD_LAUNCH(anchor_match1_kernel, dim3(g), dim3(256), sizeof(unsigned) * G, st, gt_boxes, G, anchors, A, matched_vals, matches, gt_best_ws);
+  SOD_LAUNCH(anchor_match2_kernel, dim3(g), dim3(256), 0, st, gt_boxes, G, anchors, A, matched_vals, gt_best_ws, thr_lo, thr_hi,
+             label_below, label_between, label_above, allow_low_quality, labels);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}

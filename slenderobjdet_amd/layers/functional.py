@@ -370,3 +370,73 @@ def fcos_finalize_losses(focal_sum, regctr_sums, stats, inv_world):
     out = torch.empty(3, dtype=torch.float32, device=stats.device)
     call("sod_fcos_finalize_losses", ptr(focal_sum), ptr(regctr_sums), ptr(stats), float(inv_world), ptr(out), stream_ptr())
     return out
+
+
+# ----------------------------------------------------------------------------------------------- detection ops
+def nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms contract: kept indices (int64) in descending-score order. Sorting is torch's stable sort (plumbing);
+    the IoU mask and the greedy scan run in the HIP kernels."""
+    _chk(boxes, torch.float32, "boxes"); _chk(scores, torch.float32, "scores")
+    n = boxes.shape[0]
+    dev = boxes.device
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=dev)
+    order = torch.sort(scores, descending=True, stable=True).indices.contiguous()
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    nkeep = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(_C.load().sod_nms_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    call("sod_nms", ptr(boxes), ptr(order), n, float(iou_threshold), ptr(keep), ptr(nkeep), ptr(ws), stream_ptr())
+    return keep[: int(nkeep.item())]
+
+
+def roi_align_fwd(x, rois, output_size, spatial_scale, sampling_ratio=0, rotated=False):
+    """x (N,H,W,C) bf16, rois (R,5|6) f32 -> (R,PH,PW,C) f32 (aligned=True semantics)."""
+    _chk(x, torch.bfloat16, "x"); _chk(rois, torch.float32, "rois")
+    N, H, W, C = x.shape
+    PH, PW = output_size
+    R = rois.shape[0]
+    out = torch.empty((R, PH, PW, C), dtype=torch.float32, device=x.device)
+    call("sod_roi_align_fwd", ptr(x), ptr(rois), ptr(out), R, N, H, W, C, PH, PW, float(spatial_scale), int(sampling_ratio), 1 if rotated else 0, stream_ptr())
+    return out
+
+
+def roi_align_bwd(dout, rois, x_shape, spatial_scale, sampling_ratio=0, rotated=False):
+    _chk(dout, torch.float32, "dout"); _chk(rois, torch.float32, "rois")
+    N, H, W, C = x_shape
+    R, PH, PW, _ = dout.shape
+    dx = torch.zeros((N, H, W, C), dtype=torch.float32, device=dout.device)
+    call("sod_roi_align_bwd", ptr(dout), ptr(rois), ptr(dx), R, N, H, W, C, PH, PW, float(spatial_scale), int(sampling_ratio), 1 if rotated else 0, stream_ptr())
+    return dx
+
+
+def giou_loss_xyxy(b1, b2, eps=1e-7, want_grad=False, grad_scale=None):
+    _chk(b1, torch.float32, "boxes1"); _chk(b2, torch.float32, "boxes2")
+    P = b1.shape[0]
+    elem = torch.empty(P, dtype=torch.float32, device=b1.device)
+    s = torch.empty(1, dtype=torch.float32, device=b1.device)
+    d1 = torch.empty_like(b1) if want_grad else None
+    call("sod_giou_loss_xyxy", ptr(b1), ptr(b2), P, float(eps), ptr(elem), ptr(s), ptr(grad_scale), ptr(d1), ptr(reduce_ws(b1.device)), stream_ptr())
+    return elem, s, d1
+
+
+def smooth_l1_loss(x, t, beta, want_grad=False, grad_scale=None):
+    _chk(x, torch.float32, "input"); _chk(t, torch.float32, "target")
+    elem = torch.empty_like(x)
+    s = torch.empty(1, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if want_grad else None
+    call("sod_smooth_l1_loss", ptr(x), ptr(t), x.numel(), float(beta), ptr(elem), ptr(s), ptr(grad_scale), ptr(dx), ptr(reduce_ws(x.device)), stream_ptr())
+    return elem, s, dx
+
+
+def anchor_match(gt_boxes, anchors, thresholds, labels, allow_low_quality=True):
+    """RetinaNet.label_anchors core: returns (matched_vals f32 (A,), matches i32 (A,), labels i8 (A,))."""
+    _chk(gt_boxes, torch.float32, "gt_boxes"); _chk(anchors, torch.float32, "anchors")
+    A, G = anchors.shape[0], gt_boxes.shape[0]
+    dev = anchors.device
+    vals = torch.empty(A, dtype=torch.float32, device=dev)
+    idx = torch.empty(A, dtype=torch.int32, device=dev)
+    lab = torch.empty(A, dtype=torch.int8, device=dev)
+    ws = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
+    call("sod_anchor_match", ptr(gt_boxes) if G else None, G, ptr(anchors), A, float(thresholds[0]), float(thresholds[1]), int(labels[0]), int(labels[1]),
+         int(labels[2]), 1 if allow_low_quality else 0, ptr(vals), ptr(idx), ptr(lab), ptr(ws), stream_ptr())
+    return vals, idx, lab

@@ -1,0 +1,108 @@
+"""GPU parity for the detection operators: NMS keep indices bit-exact (north_star), ROIAlign / box losses to 1e-5 relative,
+anchor labels bit-exact.  Adversarial cases: score ties, touching boxes, zero-area boxes, empty inputs."""
+import pytest
+import torch
+
+from oracle import detection as od
+from oracle import losses as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(s):
+    return torch.Generator().manual_seed(s)
+
+
+def _boxes(n, seed, size=200.0):
+    g = _g(seed)
+    xy = torch.rand(n, 2, generator=g) * size
+    wh = torch.rand(n, 2, generator=g) * 60 + 1
+    return torch.cat([xy, xy + wh], 1)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 500, 3000])
+@pytest.mark.parametrize("thr", [0.5, 0.6])
+def test_nms_keep_indices_bit_exact(cuda, n, thr):
+    from slenderobjdet_amd.layers import functional as HF
+
+    b = _boxes(n, n)
+    s = torch.rand(n, generator=_g(n + 1))
+    if n > 10:
+        s[5] = s[3]                      # score tie: stable order decides
+        b[7] = b[2]                      # identical boxes (IoU == 1)
+        b[9] = torch.tensor([10.0, 10.0, 10.0, 30.0])   # zero-area box (IoU 0/0 = NaN -> never suppresses)
+        b[11, :2] = b[4, 2:]             # touching corner: IoU == 0
+    keep = HF.nms(b.to(cuda), s.to(cuda), thr)
+    assert torch.equal(keep.cpu(), od.nms(b, s, thr))
+
+
+def test_batched_nms_and_empty(cuda):
+    from slenderobjdet_amd.layers.nms import batched_nms
+
+    b, s = _boxes(800, 3), torch.rand(800, generator=_g(4))
+    idx = torch.randint(0, 80, (800,), generator=_g(5))
+    assert torch.equal(batched_nms(b.to(cuda), s.to(cuda), idx.to(cuda), 0.6).cpu(), od.batched_nms(b, s, idx, 0.6))
+    assert batched_nms(b[:0].to(cuda), s[:0].to(cuda), idx[:0].to(cuda), 0.6).numel() == 0
+
+
+@pytest.mark.parametrize("rotated", [False, True])
+@pytest.mark.parametrize("sampling_ratio", [0, 2])
+def test_roi_align_fwd_bwd(cuda, rotated, sampling_ratio):
+    from oracle import nn as onn
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, C, H, W = 2, 16, 20, 24
+    x = onn.rb(torch.randn(N, C, H, W, generator=_g(0)))
+    if rotated:
+        rois = torch.tensor([[0, 40.0, 36.0, 50.0, 30.0, 30.0], [1, 60.0, 40.0, 20.0, 70.0, -75.0], [0, 5.0, 5.0, 30.0, 12.0, 0.0], [1, 90.0, 70.0, 40.0, 40.0, 45.0]])
+    else:
+        rois = torch.tensor([[0, 8.0, 6.0, 70.0, 60.0], [1, 0.0, 0.0, 95.0, 79.0], [0, 30.5, 20.25, 33.0, 28.0], [1, -10.0, -5.0, 20.0, 30.0], [0, 90.0, 70.0, 120.0, 100.0]])
+    xr = x.clone().requires_grad_(True)
+    ref = od.roi_align(xr, rois, (7, 7), 0.25, sampling_ratio, rotated)
+    out = HF.roi_align_fwd(x.permute(0, 2, 3, 1).contiguous().to(cuda).bfloat16(), rois.to(cuda), (7, 7), 0.25, sampling_ratio, rotated)
+    err = (out.cpu().permute(0, 3, 1, 2) - ref.detach()).abs().max().item()
+    assert err <= 1e-5 * max(ref.abs().max().item(), 1.0), err
+    dout = torch.randn(ref.shape, generator=_g(1))
+    (gref,) = torch.autograd.grad(ref, xr, dout)
+    dx = HF.roi_align_bwd(dout.permute(0, 2, 3, 1).contiguous().to(cuda), rois.to(cuda), (N, H, W, C), 0.25, sampling_ratio, rotated)
+    err = (dx.cpu().permute(0, 3, 1, 2) - gref).abs().max().item()
+    assert err <= 2e-5 * max(gref.abs().max().item(), 1.0), err
+
+
+def test_giou_and_smooth_l1(cuda):
+    from slenderobjdet_amd.layers import functional as HF
+
+    b1, b2 = _boxes(400, 1), _boxes(400, 2)
+    b1[3] = b2[3]
+    b1[5] = torch.tensor([0.0, 0.0, 5.0, 5.0]); b2[5] = torch.tensor([50.0, 50.0, 60.0, 60.0])   # disjoint
+    br = b1.clone().requires_grad_(True)
+    ref = ol.giou_loss_xyxy(br, b2)
+    (gref,) = torch.autograd.grad(ref.sum() * 0.3, br)
+    elem, s, d1 = HF.giou_loss_xyxy(b1.to(cuda), b2.to(cuda), want_grad=True, grad_scale=torch.tensor([0.3], device=cuda))
+    assert (elem.cpu() - ref.detach()).abs().max() < 1e-5 and abs(s.item() - ref.sum().item()) < 1e-3
+    assert (d1.cpu() - gref).abs().max() < 1e-5
+    x, t = torch.randn(1000, generator=_g(3)), torch.randn(1000, generator=_g(4))
+    for beta in (0.11, 0.0):
+        xr = x.clone().requires_grad_(True)
+        ref = ol.smooth_l1_loss(xr, t, beta)
+        (gref,) = torch.autograd.grad(ref.sum(), xr)
+        elem, s, dx = HF.smooth_l1_loss(x.to(cuda), t.to(cuda), beta, want_grad=True)
+        assert (elem.cpu() - ref.detach()).abs().max() < 1e-6 and (dx.cpu() - gref).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("G", [0, 1, 7, 40])
+def test_anchor_match_bit_exact(cuda, G):
+    from slenderobjdet_amd.layers import functional as HF
+
+    anchors = _boxes(5000, 9, 300.0)
+    gts = _boxes(G, 10, 300.0) if G else torch.zeros(0, 4)
+    if G > 2:
+        anchors[17] = gts[1]          # exact match (IoU 1)
+        gts[2] = torch.tensor([1000.0, 1000.0, 1010.0, 1010.0])   # gt overlapping no anchor: detectron2 promotes every IoU==0 anchor
+    q = od.pairwise_iou(gts, anchors) if G else torch.zeros(0, 5000)
+    m_ref, l_ref = od.matcher(q, [0.4, 0.5], [0, -1, 1], True)
+    vals, idx, lab = HF.anchor_match(gts.to(cuda), anchors.to(cuda), [0.4, 0.5], [0, -1, 1], True)
+    assert torch.equal(lab.cpu(), l_ref)
+    if G:
+        assert torch.equal(idx.cpu().long(), m_ref)
+        assert torch.equal(vals.cpu(), q.max(dim=0).values)
