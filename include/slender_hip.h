@@ -188,6 +188,23 @@ int sod_anchor_match(const float* gt_boxes, int G, const float* anchors, int A, 
                      int label_below, int label_between, int label_above, int allow_low_quality,
                      float* matched_vals, int* matches, signed char* labels, unsigned* gt_best_ws, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Deformable convolution v1/v2 — detectron2.layers.DeformConv / ModulatedDeformConv behind DFConv2d
+ * (slender_det/layers/df_conv.py:6-78; rpd.py:147-154,637-642). NHWC; offset fp32 rows of pitch off_ld with channel
+ * 2k = dy, 2k+1 = dx of tap k = (g*KH+i)*KW+j; mask fp32 rows of pitch mask_ld (mask_is_logit: sigmoid applied inside,
+ * as DFConv2d does at df_conv.py:76).  cols = (N,Ho,Wo,KH*KW*C) bf16, channel = tap*C + c; the product with the weights is
+ * sod_conv2d_fwd(cols, w viewed as [K][1][1][KH*KW*C]) and its gradients are the 1x1 dgrad/wgrad on the same view.
+ * col2im: dx_f32 (N,H,W,C) fp32 atomically accumulated (zero it), doffset/dmask pitched like offset/mask (zero them).
+ * --------------------------------------------------------------------------------------------------------- */
+int sod_deform_im2col(const void* x, const float* offset, const float* mask, void* cols,
+                      int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
+                      int off_ld, int mask_ld, int mask_is_logit, void* stream);
+int sod_deform_col2im(const void* dcols, const void* x, const float* offset, const float* mask,
+                      float* dx_f32, float* doffset, float* dmask,
+                      int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
+                      int off_ld, int mask_ld, int mask_is_logit, void* stream);
+int sod_f32_to_bf16(const float* x, void* y, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

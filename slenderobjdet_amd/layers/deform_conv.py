@@ -1,0 +1,141 @@
+"""Deformable convolution modules with the detectron2 / reference names:
+``DeformConv`` / ``ModulatedDeformConv`` (detectron2.layers, source absent) and ``DFConv2d``
+(slender_det/layers/df_conv.py:6-78).  NHWC bf16 activations, fp32 NHWC offsets (channel 2k = dy, 2k+1 = dx).
+"""
+import math
+
+import torch
+from torch import nn
+from torch.autograd.function import once_differentiable
+
+from . import functional as HF
+from .nn import HipConv2d, _arena_of
+
+
+def _ceil8(v):
+    return (v + 7) // 8 * 8
+
+
+class _DeformConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, offset, mask, weight, mod, off_ld, mask_ld, mask_is_logit):
+        k = mod.kernel_size
+        cols = HF.deform_im2col(x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, mod.deformable_groups, off_ld, mask_ld, mask_is_logit)
+        y = HF.conv2d_fwd(cols, mod.w_bf16, mod.bias_eff, None, 1, 0, 1)
+        ctx.mod, ctx.cfg = mod, (off_ld, mask_ld, mask_is_logit)
+        ctx.save_for_backward(x, offset, mask)
+        arena = _arena_of(mod)
+        if arena is not None and mod.weight.requires_grad:
+            arena.note_use(mod.weight)
+            if mod.bias is not None:
+                arena.note_use(mod.bias)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        mod = ctx.mod
+        off_ld, mask_ld, mask_is_logit = ctx.cfg
+        x, offset, mask = ctx.saved_tensors
+        dy = dy.contiguous()
+        k, dg = mod.kernel_size, mod.deformable_groups
+        arena = _arena_of(mod)
+        N, Ho, Wo, K = dy.shape
+        C = x.shape[3]
+        if mod.weight.requires_grad:
+            cols = HF.deform_im2col(x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, off_ld, mask_ld, mask_is_logit)
+            HF.conv2d_wgrad(dy, cols, arena.grad_view(mod.weight).view(K, 1, 1, k * k * C), 1, 1, 1, 0, 1)
+            del cols
+            arena.mark_ready(mod.weight)
+            if mod.bias is not None:
+                HF.bias_grad(dy, arena.grad_view(mod.bias), N, Ho * Wo, K)
+                arena.mark_ready(mod.bias)
+        dcols = HF.conv2d_dgrad(dy, mod.wt_bf16, (Ho, Wo), 1, 0, 1)
+        doff = torch.zeros_like(offset)          # pitched like the offset tensor (mask columns live in the same rows for v2)
+        dmask = None
+        if mask is not None:
+            dmask = doff.view(-1)[mask.storage_offset() - offset.storage_offset():] if mask.untyped_storage().data_ptr() == offset.untyped_storage().data_ptr() else torch.zeros_like(mask)
+        dx32 = HF.deform_col2im(dcols, x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, doff, dmask, off_ld, mask_ld, mask_is_logit)
+        dx = HF.f32_to_bf16(dx32) if ctx.needs_input_grad[0] else None
+        gmask = None
+        if mask is not None and ctx.needs_input_grad[2]:
+            gmask = dmask if dmask.shape == mask.shape else None
+        return dx, doff, gmask, None, None, None, None, None
+
+
+class DeformConv(nn.Module):
+    """detectron2.layers.DeformConv(in, out, kernel_size, stride, padding, dilation, groups, deformable_groups, bias=False)."""
+    modulated = False
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, bias=False):
+        super().__init__()
+        if groups != 1:
+            raise NotImplementedError("grouped deformable convolution is not built")
+        if bias and not self.modulated:
+            raise AssertionError("DeformConv has no bias (detectron2)")
+        if isinstance(kernel_size, (tuple, list)):
+            assert kernel_size[0] == kernel_size[1]
+            kernel_size = kernel_size[0]
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.stride, self.padding, self.dilation, self.deformable_groups = stride, padding, dilation, deformable_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, kernel_size, kernel_size, in_channels))   # KRSC
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight.permute(0, 3, 1, 2), nonlinearity="relu")
+        self._prep_key = None
+        self.w_bf16 = self.wt_bf16 = self.bias_eff = None
+
+    def prepare(self):
+        arena = _arena_of(self)
+        key = (self.weight._version, arena.generation if (arena is not None and self.weight.requires_grad) else -1, self.weight.data_ptr())
+        if key == self._prep_key:
+            return
+        K, k, C = self.out_channels, self.kernel_size, self.in_channels
+        # the GEMM sees a 1x1 convolution over k*k*C "channels" (tap-major, the layout deform_im2col writes)
+        self.w_bf16, self.wt_bf16 = HF.weight_prep(self.weight.detach().contiguous().view(K, 1, 1, k * k * C))
+        self.bias_eff = self.bias.detach() if self.bias is not None else None
+        self._prep_key = key
+
+    def forward(self, x, offset, mask=None, off_ld=0, mask_ld=0, mask_is_logit=False):
+        self.prepare()
+        if self.modulated and mask is None:
+            raise ValueError("ModulatedDeformConv needs a mask")
+        return _DeformConvFn.apply(x, offset, mask if self.modulated else None, self.weight, self, off_ld, mask_ld, mask_is_logit)
+
+
+class ModulatedDeformConv(DeformConv):
+    """detectron2.layers.ModulatedDeformConv (DCNv2): samples are multiplied by a mask; optional bias."""
+    modulated = True
+
+
+class DFConv2d(nn.Module):
+    """slender_det/layers/df_conv.py:6-78: a regular conv predicts the offsets (and mask logits), then DeformConv /
+    ModulatedDeformConv.  The offset conv's output channels are padded to a multiple of 8 (18 -> 24, 27 -> 32) so its
+    gradient can feed the MFMA dgrad/wgrad kernels; the mask sigmoid (df_conv.py:76) is applied inside the gather kernel."""
+
+    def __init__(self, in_channels, out_channels, with_modulated_dcn=True, kernel_size=3, stride=1, groups=1, padding=1, dilation=1,
+                 deformable_groups=1, bias=False):
+        super().__init__()
+        base = kernel_size * kernel_size
+        self.offset_base_channels = base
+        self.with_modulated_dcn = with_modulated_dcn
+        n_off = deformable_groups * base * (3 if with_modulated_dcn else 2)
+        self.n_off, self.n_off_pad = n_off, _ceil8(n_off)
+        self.offset = HipConv2d(in_channels, self.n_off_pad, kernel_size, stride, padding, dilation, bias=True, out_f32=True)
+        fan_in = in_channels * kernel_size * kernel_size
+        bound = math.sqrt(6.0 / (2.0 * fan_in))       # kaiming_uniform_(a=1)
+        with torch.no_grad():
+            self.offset.weight.uniform_(-bound, bound)
+            self.offset.weight[n_off:].zero_()
+            self.offset.bias.zero_()
+        block = ModulatedDeformConv if with_modulated_dcn else DeformConv
+        self.conv = block(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, deformable_groups, bias=bias)
+        self.deformable_groups = deformable_groups
+
+    def forward(self, x):
+        assert x.numel() > 0, "only non-empty tensors are supported"
+        om = self.offset(x)                      # (N,Ho,Wo,n_off_pad) fp32
+        if not self.with_modulated_dcn:
+            return self.conv(x, om, None, off_ld=self.n_off_pad)
+        split = self.offset_base_channels * 2 * self.deformable_groups
+        mask = om.view(-1)[split:]               # same rows, starting at the mask columns
+        return self.conv(x, om, mask, off_ld=self.n_off_pad, mask_ld=self.n_off_pad, mask_is_logit=True)

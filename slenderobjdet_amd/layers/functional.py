@@ -440,3 +440,33 @@ def anchor_match(gt_boxes, anchors, thresholds, labels, allow_low_quality=True):
     call("sod_anchor_match", ptr(gt_boxes) if G else None, G, ptr(anchors), A, float(thresholds[0]), float(thresholds[1]), int(labels[0]), int(labels[1]),
          int(labels[2]), 1 if allow_low_quality else 0, ptr(vals), ptr(idx), ptr(lab), ptr(ws), stream_ptr())
     return vals, idx, lab
+
+
+# ----------------------------------------------------------------------------------------------- deformable conv
+def f32_to_bf16(x):
+    _chk(x, torch.float32, "x")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    call("sod_f32_to_bf16", ptr(x), ptr(y), x.numel(), stream_ptr())
+    return y
+
+
+def deform_im2col(x, offset, mask, ksize, stride, pad, dil, dg=1, off_ld=0, mask_ld=0, mask_is_logit=False):
+    """x (N,H,W,C) bf16; offset/mask fp32 (pitched rows); returns cols (N,Ho,Wo,KH*KW*C) bf16."""
+    _chk(x, torch.bfloat16, "x")
+    N, H, W, C = x.shape
+    KH, KW = ksize
+    Ho, Wo = conv_out_size(H, W, KH, KW, stride, pad, dil)
+    cols = torch.empty((N, Ho, Wo, KH * KW * C), dtype=torch.bfloat16, device=x.device)
+    call("sod_deform_im2col", ptr(x), ptr(offset), ptr(mask), ptr(cols), N, H, W, C, KH, KW, stride, pad, dil, dg, off_ld, mask_ld,
+         1 if mask_is_logit else 0, stream_ptr())
+    return cols
+
+
+def deform_col2im(dcols, x, offset, mask, ksize, stride, pad, dil, dg, doffset, dmask, off_ld=0, mask_ld=0, mask_is_logit=False):
+    """Returns dx fp32 (N,H,W,C); fills the (zero-initialised, pitched) doffset / dmask."""
+    N, H, W, C = x.shape
+    KH, KW = ksize
+    dx = torch.zeros((N, H, W, C), dtype=torch.float32, device=x.device)
+    call("sod_deform_col2im", ptr(dcols), ptr(x), ptr(offset), ptr(mask), ptr(dx), ptr(doffset), ptr(dmask), N, H, W, C, KH, KW, stride, pad, dil,
+         dg, off_ld, mask_ld, 1 if mask_is_logit else 0, stream_ptr())
+    return dx

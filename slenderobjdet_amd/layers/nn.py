@@ -29,12 +29,13 @@ class HipConv2d(nn.Module):
     """
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True,
-                 frozen_bn=False, relu=False, cin_pad=None, mask_input=False, grad_premasked=False):
+                 frozen_bn=False, relu=False, cin_pad=None, mask_input=False, grad_premasked=False, out_f32=False):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.stride, self.padding, self.dilation = kernel_size, stride, padding, dilation
         self.relu, self.mask_input, self.grad_premasked = relu, mask_input, grad_premasked
         self.cin_pad = cin_pad
+        self.out_f32 = out_f32      # fp32 output (offset / prediction convs); its gradient is converted to bf16 for the MFMA kernels
         self.weight = nn.Parameter(torch.empty(out_channels, kernel_size, kernel_size, in_channels))
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         self.frozen_bn = frozen_bn
@@ -102,7 +103,8 @@ class HipConv2d(nn.Module):
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, weight, mod, res_up2):
-        y = HF.conv2d_fwd(x, mod.w_bf16, mod.bias_eff, res, mod.stride, mod.padding, mod.dilation, relu=mod.relu, res_up2=res_up2)
+        y = HF.conv2d_fwd(x, mod.w_bf16, mod.bias_eff, res, mod.stride, mod.padding, mod.dilation, relu=mod.relu, res_up2=res_up2,
+                          out_f32=mod.out_f32)
         ctx.mod, ctx.res_up2, ctx.has_res = mod, res_up2, res is not None
         train_w = mod.weight.requires_grad
         if train_w or x.requires_grad or (res is not None and res.requires_grad):
@@ -119,6 +121,8 @@ class _ConvFn(torch.autograd.Function):
         mod = ctx.mod
         x, y = ctx.saved_tensors
         dy = dy.contiguous()
+        if dy.dtype == torch.float32:
+            dy = HF.f32_to_bf16(dy)
         g = HF.relu_bwd(dy, y) if (mod.relu and not mod.grad_premasked) else dy
         arena = _arena_of(mod)
         N, H, W, C = x.shape
@@ -211,6 +215,37 @@ class _ConvGnReluFn(torch.autograd.Function):
         if any(ctx.needs_input_grad[2:]):
             dxs = HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, [(x.shape[1], x.shape[2]) for x in xs], 1, 1, 1)
         return (None, None, *dxs)
+
+
+class _GnReluFn(torch.autograd.Function):
+    """Stand-alone GroupNorm(+ReLU) (after a deformable tower conv, fcosv2.py:300-336 with USE_DCN_IN_TOWER)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gn, relu):
+        y, stats = HF.groupnorm_fwd(x, gn.weight.detach(), gn.bias.detach(), gn.num_groups, gn.eps, relu=relu)
+        ctx.gn, ctx.relu = gn, relu
+        ctx.save_for_backward(x, stats)
+        arena = _arena_of(gn)
+        if arena is not None:
+            arena.note_use(gn.weight)
+            arena.note_use(gn.bias)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        gn = ctx.gn
+        x, stats = ctx.saved_tensors
+        arena = _arena_of(gn)
+        dx = HF.groupnorm_bwd(dy.contiguous(), x, gn.weight.detach(), gn.bias.detach(), stats, gn.num_groups,
+                              arena.grad_view(gn.weight), arena.grad_view(gn.bias), relu=ctx.relu)
+        arena.mark_ready(gn.weight)
+        arena.mark_ready(gn.bias)
+        return dx, None, None, None
+
+
+def group_norm_relu(x, gn, relu=True):
+    return _GnReluFn.apply(x, gn.weight, gn, relu)
 
 
 class _ReluFn(torch.autograd.Function):

@@ -22,7 +22,8 @@ from torch import nn
 from torch.autograd.function import once_differentiable
 
 from ...layers import functional as HF
-from ...layers.nn import ConvGnRelu, HipConv2d, _arena_of
+from ...layers.deform_conv import DFConv2d
+from ...layers.nn import ConvGnRelu, HipConv2d, HipGroupNorm, _arena_of, group_norm_relu
 from ...structures import Boxes, ImageList, Instances
 from ...utils import comm
 from ..backbone import build_backbone
@@ -37,6 +38,18 @@ def _ceil8(v):
     return (v + 7) // 8 * 8
 
 
+class DcnGnRelu(nn.Module):
+    """[DFConv2d (no bias) -> GroupNorm(32) -> ReLU]: the last tower unit under MODEL.FCOS.USE_DCN_IN_TOWER."""
+
+    def __init__(self, channels, v2):
+        super().__init__()
+        self.conv = DFConv2d(channels, channels, with_modulated_dcn=v2, kernel_size=3, stride=1, padding=1, bias=False)
+        self.gn = HipGroupNorm(32, channels)
+
+    def forward(self, xs):
+        return [group_norm_relu(self.conv(x), self.gn, True) for x in xs]
+
+
 class FCOSHead(nn.Module):
     """fcosv2.py:277-381. ``cls_logits`` (+ ``centerness`` when not CENTERNESS_ON_REG) live in one fused conv
     ``cls_pred`` whose output channels are padded to a multiple of 8; ``bbox_pred`` (+ ``centerness`` when
@@ -49,17 +62,24 @@ class FCOSHead(nn.Module):
         self.fpn_strides = list(cfg.MODEL.FCOS.FPN_STRIDES)
         self.norm_reg_targets = cfg.MODEL.FCOS.NORM_REG_TARGETS
         self.centerness_on_reg = cfg.MODEL.FCOS.CENTERNESS_ON_REG
-        if cfg.MODEL.FCOS.USE_DCN_IN_TOWER:
-            raise NotImplementedError("MODEL.FCOS.USE_DCN_IN_TOWER: the DeformConv tower is not wired into FCOSHead yet")
         n = cfg.MODEL.FCOS.NUM_CONVS
-        self.cls_tower = nn.ModuleList([ConvGnRelu(in_channels) for _ in range(n)])
-        self.bbox_tower = nn.ModuleList([ConvGnRelu(in_channels) for _ in range(n)])
+        self.use_dcn_in_tower = cfg.MODEL.FCOS.USE_DCN_IN_TOWER
+        self.use_dcn_v2 = cfg.MODEL.FCOS.USE_DCN_V2
+
+        def unit(i):   # fcosv2.py:296-336: the LAST tower conv becomes DFConv2d (no bias) when USE_DCN_IN_TOWER
+            if self.use_dcn_in_tower and i == n - 1:
+                return DcnGnRelu(in_channels, self.use_dcn_v2)
+            return ConvGnRelu(in_channels)
+
+        self.cls_tower = nn.ModuleList([unit(i) for i in range(n)])
+        self.bbox_tower = nn.ModuleList([unit(i) for i in range(n)])
         self.kc = self.num_classes + (0 if self.centerness_on_reg else 1)
         self.kc_pad = _ceil8(self.kc)
         self.cls_pred = HipConv2d(in_channels, self.kc_pad, 3, 1, 1, bias=True)
         self.box_pred = HipConv2d(in_channels, 8, 3, 1, 1, bias=True)
         for unit in list(self.cls_tower) + list(self.bbox_tower):
-            unit.conv.init_normal(0.01, 0.0)
+            if isinstance(unit, ConvGnRelu):   # the reference's init loop only touches nn.Conv2d, not DFConv2d (fcos.py:549-550)
+                unit.conv.init_normal(0.01, 0.0)
         bias_value = -math.log((1 - cfg.MODEL.FCOS.PRIOR_PROB) / cfg.MODEL.FCOS.PRIOR_PROB)
         with torch.no_grad():
             self.cls_pred.init_normal(0.01, 0.0)

@@ -1,0 +1,100 @@
+"""GPU parity of DeformConv / ModulatedDeformConv (im2col + MFMA GEMM) against the CPU oracle and the reference's own
+known-answer vectors (tests/golden/deform_conv_kat.npz, from tests/test_deformable_conv.py:67-87)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import deform_conv as odc
+from oracle import nn as onn
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _g(s):
+    return torch.Generator().manual_seed(s)
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def test_reference_kat(cuda):
+    """The two 16-value vectors the reference asserts for detectron2's DeformConv (integer offsets)."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    d = {k: v for k, v in np.load(os.path.join(G, "deform_conv_kat.npz")).items()}
+    x = torch.zeros(1, 8, 4, 4)
+    x[:, :2] = torch.tensor(d["input"])            # pad 2 -> 8 channels
+    w = torch.zeros(8, 8, 3, 3)
+    w[:1, :2] = torch.tensor(d["weight"])          # pad 1 -> 8 output channels
+    wk, _ = HF.weight_prep(w.permute(0, 2, 3, 1).contiguous().reshape(8, 1, 1, 72).to(cuda))
+    for key, off in (("y_dconv_zero", "offsets_2"), ("y_dconv_1", "offsets_1")):
+        offset = _nhwc(torch.tensor(d[off])).to(cuda)
+        cols = HF.deform_im2col(_nhwc(x).to(cuda).bfloat16(), offset, None, (3, 3), 1, 1, 1)
+        y = HF.conv2d_fwd(cols, wk, None, stride=1, pad=0, out_f32=True)
+        np.testing.assert_allclose(y[0, :, :, 0].cpu().numpy(), d[key][0, 0], atol=0.2, rtol=4e-3)   # bf16 inputs (0.1 is not exact)
+
+
+@pytest.mark.parametrize("modulated,dg,stride", [(False, 1, 1), (True, 1, 1), (True, 2, 2), (False, 4, 1)])
+def test_deform_conv_fwd_bwd_vs_oracle(cuda, modulated, dg, stride):
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, C, K, H, W = 2, 64, 32, 9, 11
+    x = onn.rb(torch.randn(N, C, H, W, generator=_g(0)))
+    w = onn.rb(torch.randn(K, C, 3, 3, generator=_g(1)) * 0.1)
+    Ho, Wo = HF.conv_out_size(H, W, 3, 3, stride, 1, 1)
+    off = (torch.rand(N, 18 * dg, Ho, Wo, generator=_g(2)) - 0.5) * 4.3 + 0.017
+    off[0, :, 0, 0] = 9.0                           # far outside: zero contribution
+    mask = torch.rand(N, 9 * dg, Ho, Wo, generator=_g(3)) if modulated else None
+    dy = onn.rb(torch.randn(N, K, Ho, Wo, generator=_g(4)))
+    xs, os_, ws = x.clone().requires_grad_(True), off.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ms = mask.clone().requires_grad_(True) if modulated else None
+    ref = odc.deform_conv2d(xs, os_, ws, None, stride, 1, 1, ms, dg)
+    grads = torch.autograd.grad(ref, [xs, os_, ws] + ([ms] if modulated else []), dy)
+
+    xd = _nhwc(x).to(cuda).bfloat16()
+    offd = _nhwc(off).to(cuda)
+    maskd = _nhwc(mask).to(cuda) if modulated else None
+    w_flat = w.permute(0, 2, 3, 1).contiguous().reshape(K, 1, 1, 9 * C).to(cuda)
+    wk, wt = HF.weight_prep(w_flat)
+    cols = HF.deform_im2col(xd, offd, maskd, (3, 3), stride, 1, 1, dg)
+    y = HF.conv2d_fwd(cols, wk, None, stride=1, pad=0, out_f32=True)
+    tol = 2 ** -7 * ref.abs().max().item()          # cols are rounded to bf16 before the GEMM
+    assert (y.cpu().permute(0, 3, 1, 2) - ref.detach()).abs().max().item() <= tol
+    dyd = _nhwc(dy).to(cuda).bfloat16()
+    dw = torch.zeros(K, 1, 1, 9 * C, device=cuda)
+    HF.conv2d_wgrad(dyd, cols, dw, 1, 1, 1, 0, 1)
+    dw_ref = grads[2].permute(0, 2, 3, 1).reshape(K, 1, 1, 9 * C)
+    assert (dw.cpu() - dw_ref).abs().max().item() <= 2 ** -7 * dw_ref.abs().max().item()
+    dcols = HF.conv2d_dgrad(dyd, wt, (Ho, Wo), 1, 0, 1)
+    doff = torch.zeros_like(offd)
+    dmask = torch.zeros_like(maskd) if modulated else None
+    dx = HF.deform_col2im(dcols, xd, offd, maskd, (3, 3), stride, 1, 1, dg, doff, dmask)
+    for got, want, name in ((dx.cpu().permute(0, 3, 1, 2), grads[0], "dx"), (doff.cpu().permute(0, 3, 1, 2), grads[1], "doffset")):
+        assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item(), name    # dcols are bf16
+    if modulated:
+        assert (dmask.cpu().permute(0, 3, 1, 2) - grads[3]).abs().max().item() <= 2e-2 * grads[3].abs().max().item()
+
+
+@pytest.mark.parametrize("v2", [False, True])
+def test_dfconv2d_module_trains(cuda, v2):
+    """DFConv2d (offset conv + DCN) as an autograd module: gradients reach x, the offset conv and the DCN weights."""
+    from slenderobjdet_amd.layers.arena import ParamArena
+    from slenderobjdet_amd.layers.deform_conv import DFConv2d
+    from slenderobjdet_amd.layers.nn import attach_arena
+
+    torch.manual_seed(0)
+    m = DFConv2d(64, 64, with_modulated_dcn=v2).to(cuda)
+    arena = ParamArena(m)
+    attach_arena(m, arena)
+    x = torch.randn(2, 10, 12, 64, device=cuda).bfloat16().requires_grad_(True)
+    y = m(x)
+    assert y.shape == (2, 10, 12, 64) and y.dtype == torch.bfloat16
+    y.float().square().sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad.float()).all()
+    for p in (m.conv.weight, m.offset.weight, m.offset.bias):
+        assert torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
+    assert (m.offset.weight.grad[m.n_off:] == 0).all()     # padding rows stay inert

@@ -136,3 +136,26 @@ def test_full_size_conv_linearity_and_adjointness(cuda):
     rhs = (dw * wk.float()).sum().item()
     scale = max(abs(lhs), 1.0)
     assert abs(lhs - mid) / scale < 5e-3 and abs(lhs - rhs) / scale < 1e-3, (lhs, mid, rhs)
+
+
+@pytest.mark.parametrize("v2", [True, False])
+def test_fcos_with_dcn_tower_trains(cuda, v2):
+    """configs/fcos/*dcn*.yaml path: MODEL.FCOS.USE_DCN_IN_TOWER (DFConv2d as the last tower conv) runs fwd+bwd+step."""
+    from bench import make_cfg, train_step
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+
+    cfg = make_cfg(18)
+    cfg.MODEL.FCOS.USE_DCN_IN_TOWER = True
+    cfg.MODEL.FCOS.USE_DCN_V2 = v2
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    data = synthetic_batch(2, 256, 256, 5, device="cuda")
+    l0 = float(train_step(model, opt, data))
+    l1 = float(train_step(model, opt, data))
+    assert l0 == l0 and l1 == l1 and l1 < l0 * 1.5
+    dcn = model.head.cls_tower[-1].conv
+    assert dcn.conv.weight.grad.abs().sum() > 0 and dcn.offset.weight.grad.abs().sum() > 0
