@@ -159,3 +159,18 @@ def test_fcos_with_dcn_tower_trains(cuda, v2):
     assert l0 == l0 and l1 == l1 and l1 < l0 * 1.5
     dcn = model.head.cls_tower[-1].conv
     assert dcn.conv.weight.grad.abs().sum() > 0 and dcn.offset.weight.grad.abs().sum() > 0
+
+
+def test_train_net_cli_runs(cuda, tmp_path):
+    """train_net.py with the reference's CLI: config file + overrides, 3 iterations on synthetic batches."""
+    import subprocess
+    import sys
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "train_net.py"), "--config-file", os.path.join(root, "configs/fcos/fcos_R_50_FPN_1x.yaml"),
+           "--num-gpus", "1", "MODEL.RESNETS.DEPTH", "18", "MODEL.RESNETS.RES2_OUT_CHANNELS", "64", "SOLVER.IMS_PER_BATCH", "2",
+           "SOLVER.MAX_ITER", "3", "INPUT.MIN_SIZE_TRAIN", "(256,)", "INPUT.MAX_SIZE_TRAIN", "320", "OUTPUT_DIR", str(tmp_path)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "iter: 3" in out.stdout and "cls_loss" in out.stdout

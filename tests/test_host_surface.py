@@ -132,3 +132,34 @@ def test_warmup_multistep_lr():
         opt.step()
         sch.step()
     assert abs(lrs[0] - 1e-5) < 1e-12 and abs(lrs[4] - 0.01) < 1e-12 and abs(lrs[5] - 0.001) < 1e-12 and abs(lrs[8] - 0.0001) < 1e-12
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/train_net.py"), reason="reference tree only exists in the build container")
+def test_reference_train_net_imports_and_builds_under_dropin(tmp_path):
+    """The reference's own train_net.py (unchanged, read from /root/reference) resolves all its imports against this package and
+    gets as far as cfg setup + Trainer.build_model on CPU."""
+    import runpy
+    import sys
+
+    import slenderobjdet_amd.dropin  # noqa: F401
+    from slenderobjdet_amd.config import get_cfg
+
+    cfg = get_cfg()
+    was_frozen = cfg.is_frozen()
+    cfg.defrost()
+    snapshot = cfg.clone()
+    try:
+        ns = runpy.run_path("/root/reference/train_net.py", run_name="reference_train_net")
+        args = ns["default_argument_parser"]().parse_args(
+            ["--config-file", "/root/reference/configs/fcos/fcos_R_50_FPN_1x.yaml", "--num-gpus", "1", "MODEL.DEVICE", "cpu",
+             "MODEL.WEIGHTS", "", "OUTPUT_DIR", str(tmp_path)])
+        cfg2 = ns["setup"](args)
+        assert cfg2.MODEL.META_ARCHITECTURE == "FCOSV2" and cfg2.MODEL.FCOS.IOU_LOSS_TYPE == "giou"
+        model = ns["Trainer"].build_model(cfg2)
+        assert type(model).__name__ == "FCOSV2"
+    finally:
+        cfg.defrost()
+        for k in list(cfg.keys()):
+            cfg[k] = snapshot[k]
+        if was_frozen:
+            cfg.freeze()
