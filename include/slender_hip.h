@@ -168,6 +168,11 @@ int sod_fcos_finalize_losses(const float* focal_sum, const float* regctr_sums, c
 long long sod_nms_workspace_bytes(int n);
 int sod_nms(const float* boxes, const long long* order, int n, float iou_threshold, long long* keep, int* num_keep,
             void* mask_ws, void* stream);
+/* detectron2 nms_rotated / box_iou_rotated (csrc/nms_rotated, csrc/box_iou_rotated; reached through RRPN / RROIHeads selected by
+ * configs/rotated/Base-RRCNN-FPN.yaml:10-36 and pairwise_iou at retina_rotated.py:276): boxes (n,5) = (cx,cy,w,h,angle_deg). */
+int sod_nms_rotated(const float* boxes, const long long* order, int n, float iou_threshold, long long* keep, int* num_keep,
+                    void* mask_ws, void* stream);
+int sod_box_iou_rotated(const float* boxes1, int n1, const float* boxes2, int n2, float* iou_out, void* stream);
 /* detectron2 ROIAlign(output_size, spatial_scale, sampling_ratio, aligned=True) / ROIAlignRotated (roi_heads/roi_heads.py:48-53).
  * x: NHWC bf16; rois (R,5) [batch,x1,y1,x2,y2] or, rotated, (R,6) [batch,cx,cy,w,h,angle_deg]; out (R,PH,PW,C) fp32.
  * bwd accumulates atomically into dx (N,H,W,C) fp32 (zero it first). */

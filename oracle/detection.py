@@ -117,3 +117,107 @@ def matcher(quality, thresholds, labels, allow_low_quality):
         idx = torch.nonzero(quality == best[:, None])[:, 1]
         out[idx] = 1
     return matches, out
+
+
+# ------------------------------------------------------------------------------------------------ rotated boxes (C.15)
+def _rot_vertices(b):
+    cx, cy, w, h, a = [np.float32(v) for v in b]
+    th = np.float32(a * np.float32(0.01745329251994329577))
+    c2, s2 = np.float32(np.cos(th) * np.float32(0.5)), np.float32(np.sin(th) * np.float32(0.5))
+    p0 = (cx + s2 * h + c2 * w, cy + c2 * h - s2 * w)
+    p1 = (cx - s2 * h + c2 * w, cy - c2 * h - s2 * w)
+    return np.array([p0, p1, (2 * cx - p0[0], 2 * cy - p0[1]), (2 * cx - p1[0], 2 * cy - p1[1])], dtype=np.float32)
+
+
+def _cross(a, b):
+    return np.float32(a[0] * b[1] - b[0] * a[1])
+
+
+def _dot(a, b):
+    return np.float32(a[0] * b[0] + a[1] * b[1])
+
+
+def box_iou_rotated_single(b1, b2):
+    """detectron2 single_box_iou_rotated: polygon clipping by edge intersections + contained vertices, Graham hull, shoelace."""
+    a1, a2 = np.float32(b1[2] * b1[3]), np.float32(b2[2] * b2[3])
+    if a1 < 1e-14 or a2 < 1e-14:
+        return np.float32(0)
+    sx, sy = np.float32((b1[0] + b2[0]) / 2), np.float32((b1[1] + b2[1]) / 2)
+    p1 = _rot_vertices((b1[0] - sx, b1[1] - sy, b1[2], b1[3], b1[4]))
+    p2 = _rot_vertices((b2[0] - sx, b2[1] - sy, b2[2], b2[3], b2[4]))
+    v1 = [p1[(i + 1) % 4] - p1[i] for i in range(4)]
+    v2 = [p2[(i + 1) % 4] - p2[i] for i in range(4)]
+    pts = []
+    for i in range(4):
+        for j in range(4):
+            det = _cross(v2[j], v1[i])
+            if abs(det) <= 1e-14:
+                continue
+            v12 = p2[j] - p1[i]
+            t1, t2 = np.float32(_cross(v2[j], v12) / det), np.float32(_cross(v1[i], v12) / det)
+            if 0 <= t1 <= 1 and 0 <= t2 <= 1:
+                pts.append(p1[i] + v1[i] * t1)
+    for (pa, pb, vb) in ((p1, p2, v2), (p2, p1, v1)):
+        AB, DA = vb[0], vb[3]
+        abab, adad = _dot(AB, AB), _dot(DA, DA)
+        for i in range(4):
+            AP = pa[i] - pb[0]
+            apab, apad = _dot(AP, AB), -_dot(AP, DA)
+            if apab >= 0 and apad >= 0 and apab <= abab and apad <= adad:
+                pts.append(pa[i])
+    if len(pts) <= 2:
+        return np.float32(0)
+    pts = np.array(pts, dtype=np.float32)
+    t = 0
+    for i in range(1, len(pts)):
+        if pts[i][1] < pts[t][1] or (pts[i][1] == pts[t][1] and pts[i][0] < pts[t][0]):
+            t = i
+    q = pts - pts[t]
+    q[[0, t]] = q[[t, 0]]
+    n = len(q)
+    for i in range(1, n - 1):
+        for j in range(1, n - i):
+            c = _cross(q[j], q[j + 1])
+            if c < -1e-6 or (abs(c) < 1e-6 and _dot(q[j], q[j]) > _dot(q[j + 1], q[j + 1])):
+                q[[j, j + 1]] = q[[j + 1, j]]
+    k = 1
+    while k < n and _dot(q[k], q[k]) <= 1e-8:
+        k += 1
+    if k == n:
+        return np.float32(0)
+    hull = [q[0], q[k]]
+    for i in range(k + 1, n):
+        while len(hull) > 1 and _cross(q[i] - hull[-2], hull[-1] - hull[-2]) >= 0:
+            hull.pop()
+        hull.append(q[i])
+    if len(hull) <= 2:
+        return np.float32(0)
+    area = np.float32(0)
+    for i in range(1, len(hull) - 1):
+        area += abs(_cross(hull[i] - hull[0], hull[i + 1] - hull[0]))
+    inter = np.float32(area / 2)
+    return np.float32(inter / (a1 + a2 - inter))
+
+
+def pairwise_iou_rotated(b1, b2):
+    b1, b2 = b1.numpy().astype(np.float32), b2.numpy().astype(np.float32)
+    out = np.zeros((len(b1), len(b2)), dtype=np.float32)
+    with np.errstate(all="ignore"):
+        for i in range(len(b1)):
+            for j in range(len(b2)):
+                out[i, j] = box_iou_rotated_single(b1[i], b2[j])
+    return torch.from_numpy(out)
+
+
+def nms_rotated(boxes, scores, thr):
+    iou = pairwise_iou_rotated(boxes, boxes).numpy()
+    order = torch.sort(scores, descending=True, stable=True).indices.numpy()
+    keep, dead = [], np.zeros(len(boxes), dtype=bool)
+    for pos, i in enumerate(order):
+        if dead[i]:
+            continue
+        keep.append(int(i))
+        for j in order[pos + 1:]:
+            if iou[i, j] > np.float32(thr):
+                dead[j] = True
+    return torch.tensor(keep, dtype=torch.int64)

@@ -24,31 +24,129 @@ __device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thr
   return inter / (sa + sb - inter) > thr;
 }
 
+// ---- rotated boxes (cx, cy, w, h, angle_deg): detectron2 box_iou_rotated ----
+struct P2 { float x, y; };
+__device__ __forceinline__ P2 psub(P2 a, P2 b) { return P2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ float pcross(P2 a, P2 b) { return a.x * b.y - b.x * a.y; }
+__device__ __forceinline__ float pdot(P2 a, P2 b) { return a.x * b.x + a.y * b.y; }
+
+__device__ __forceinline__ void rot_vertices(float cx, float cy, float w, float h, float ang, P2* pts) {
+  const float theta = ang * 0.01745329251994329577f;
+  const float c2 = cosf(theta) * 0.5f, s2 = sinf(theta) * 0.5f;
+  pts[0] = P2{cx + s2 * h + c2 * w, cy + c2 * h - s2 * w};
+  pts[1] = P2{cx - s2 * h + c2 * w, cy - c2 * h - s2 * w};
+  pts[2] = P2{2.f * cx - pts[0].x, 2.f * cy - pts[0].y};
+  pts[3] = P2{2.f * cx - pts[1].x, 2.f * cy - pts[1].y};
+}
+
+__device__ float rot_intersection_area(const P2* p1, const P2* p2) {
+  P2 inter[24];
+  int num = 0;
+  P2 v1[4], v2[4];
+  for (int i = 0; i < 4; ++i) { v1[i] = psub(p1[(i + 1) & 3], p1[i]); v2[i] = psub(p2[(i + 1) & 3], p2[i]); }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const float det = pcross(v2[j], v1[i]);
+      if (fabsf(det) <= 1e-14f) continue;
+      const P2 v12 = psub(p2[j], p1[i]);
+      const float t1 = pcross(v2[j], v12) / det, t2 = pcross(v1[i], v12) / det;
+      if (t1 >= 0.f && t1 <= 1.f && t2 >= 0.f && t2 <= 1.f) inter[num++] = P2{p1[i].x + v1[i].x * t1, p1[i].y + v1[i].y * t1};
+    }
+  {
+    const P2 AB = v2[0], DA = v2[3];
+    const float ABAB = pdot(AB, AB), ADAD = pdot(DA, DA);
+    for (int i = 0; i < 4; ++i) {
+      const P2 AP = psub(p1[i], p2[0]);
+      const float apab = pdot(AP, AB), apad = -pdot(AP, DA);
+      if (apab >= 0.f && apad >= 0.f && apab <= ABAB && apad <= ADAD) inter[num++] = p1[i];
+    }
+  }
+  {
+    const P2 AB = v1[0], DA = v1[3];
+    const float ABAB = pdot(AB, AB), ADAD = pdot(DA, DA);
+    for (int i = 0; i < 4; ++i) {
+      const P2 AP = psub(p2[i], p1[0]);
+      const float apab = pdot(AP, AB), apad = -pdot(AP, DA);
+      if (apab >= 0.f && apad >= 0.f && apab <= ABAB && apad <= ADAD) inter[num++] = p2[i];
+    }
+  }
+  if (num <= 2) return 0.f;
+  // Graham scan
+  int t = 0;
+  for (int i = 1; i < num; ++i)
+    if (inter[i].y < inter[t].y || (inter[i].y == inter[t].y && inter[i].x < inter[t].x)) t = i;
+  const P2 start = inter[t];
+  P2 q[24];
+  for (int i = 0; i < num; ++i) q[i] = psub(inter[i], start);
+  { const P2 tmp = q[0]; q[0] = q[t]; q[t] = tmp; }
+  for (int i = 1; i < num - 1; ++i)          // bubble sort by polar angle around q[0] (as the CUDA path of detectron2)
+    for (int j = 1; j < num - i; ++j) {
+      const float c = pcross(q[j], q[j + 1]);
+      const bool swap = (c < -1e-6f) || (fabsf(c) < 1e-6f && pdot(q[j], q[j]) > pdot(q[j + 1], q[j + 1]));
+      if (swap) { const P2 tmp = q[j]; q[j] = q[j + 1]; q[j + 1] = tmp; }
+    }
+  int k = 1;
+  for (; k < num; ++k)
+    if (pdot(q[k], q[k]) > 1e-8f) break;
+  if (k == num) return 0.f;
+  q[1] = q[k];
+  int m = 2;
+  for (int i = k + 1; i < num; ++i) {
+    while (m > 1 && pcross(psub(q[i], q[m - 2]), psub(q[m - 1], q[m - 2])) >= 0.f) --m;
+    q[m++] = q[i];
+  }
+  if (m <= 2) return 0.f;
+  float area = 0.f;
+  for (int i = 1; i < m - 1; ++i) area += fabsf(pcross(psub(q[i], q[0]), psub(q[i + 1], q[0])));
+  return area / 2.f;
+}
+
+__device__ float iou_rotated(const float* a, const float* b) {
+  const float area1 = a[2] * a[3], area2 = b[2] * b[3];
+  if (area1 < 1e-14f || area2 < 1e-14f) return 0.f;
+  const float sx = (a[0] + b[0]) / 2.f, sy = (a[1] + b[1]) / 2.f;   // centre shift for precision
+  P2 p1[4], p2[4];
+  rot_vertices(a[0] - sx, a[1] - sy, a[2], a[3], a[4], p1);
+  rot_vertices(b[0] - sx, b[1] - sy, b[2], b[3], b[4], p2);
+  const float inter = rot_intersection_area(p1, p2);
+  return inter / (area1 + area2 - inter);
+}
+
+template <int BD>   // BD = 4 axis-aligned XYXY, 5 rotated
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const long long* __restrict__ order, int n,
                                                       float thr, unsigned long long* __restrict__ mask, int words) {
   const int rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb) return;   // only the upper triangle is ever read
-  __shared__ float cbox[64 * 4];
+  __shared__ float cbox[64 * BD];
   const int lane = threadIdx.x;
   const int cj = cb * 64 + lane;
   if (cj < n) {
     const long long o = order[cj];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) cbox[lane * 4 + e] = boxes[o * 4 + e];
+    for (int e = 0; e < BD; ++e) cbox[lane * BD + e] = boxes[o * BD + e];
   }
   __syncthreads();
   const int i = rb * 64 + lane;
   if (i >= n) return;
-  float a[4];
+  float a[BD];
   const long long oi = order[i];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) a[e] = boxes[oi * 4 + e];
+  for (int e = 0; e < BD; ++e) a[e] = boxes[oi * BD + e];
   unsigned long long bits = 0;
   const int cnt = min(64, n - cb * 64);
   const int start = (rb == cb) ? lane + 1 : 0;
-  for (int j = start; j < cnt; ++j)
-    if (iou_gt(a, cbox + j * 4, thr)) bits |= 1ull << j;
+  for (int j = start; j < cnt; ++j) {
+    const bool hit = (BD == 4) ? iou_gt(a, cbox + j * BD, thr) : (iou_rotated(a, cbox + j * BD) > thr);
+    if (hit) bits |= 1ull << j;
+  }
   mask[(long long)i * words + cb] = bits;
+}
+
+__global__ __launch_bounds__(256) void pairwise_iou_rotated_kernel(const float* __restrict__ b1, int n1, const float* __restrict__ b2, int n2,
+                                                                   float* __restrict__ out) {
+  const long long total = (long long)n1 * n2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+    out[i] = iou_rotated(b1 + (i / n2) * 5, b2 + (i % n2) * 5);
 }
 
 // single workgroup: thread w owns word w of the "removed" bitmap; boxes are visited in score order
@@ -307,8 +405,31 @@ extern "C" int sod_nms(const float* boxes, const long long* order, int n, float 
   if (words > 1024) return SOD_ESIZE;   // 65536 boxes per call (detectron2 switches to per-class loops above 40 000)
   hipError_t e = hipMemsetAsync(mask_ws, 0, (size_t)n * words * 8, st);
   if (e != hipSuccess) return (int)e;
-  SOD_LAUNCH(nms_mask_kernel, dim3(words, words), dim3(64), 0, st, boxes, order, n, iou_threshold, (unsigned long long*)mask_ws, words);
+  SOD_LAUNCH(nms_mask_kernel<4>, dim3(words, words), dim3(64), 0, st, boxes, order, n, iou_threshold, (unsigned long long*)mask_ws, words);
   SOD_LAUNCH(nms_scan_kernel, dim3(1), dim3(1024), 0, st, (const unsigned long long*)mask_ws, order, n, words, keep, num_keep);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_nms_rotated(const float* boxes, const long long* order, int n, float iou_threshold, long long* keep, int* num_keep,
+                               void* mask_ws, void* stream) {
+  if (n < 0 || !num_keep || (n > 0 && (!boxes || !order || !keep || !mask_ws))) return SOD_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return (int)hipMemsetAsync(num_keep, 0, sizeof(int), st);
+  const int words = (n + 63) / 64;
+  if (words > 1024) return SOD_ESIZE;
+  hipError_t e = hipMemsetAsync(mask_ws, 0, (size_t)n * words * 8, st);
+  if (e != hipSuccess) return (int)e;
+  SOD_LAUNCH(nms_mask_kernel<5>, dim3(words, words), dim3(64), 0, st, boxes, order, n, iou_threshold, (unsigned long long*)mask_ws, words);
+  SOD_LAUNCH(nms_scan_kernel, dim3(1), dim3(1024), 0, st, (const unsigned long long*)mask_ws, order, n, words, keep, num_keep);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_box_iou_rotated(const float* boxes1, int n1, const float* boxes2, int n2, float* iou_out, void* stream) {
+  if (n1 < 0 || n2 < 0 || ((long long)n1 * n2 > 0 && (!boxes1 || !boxes2 || !iou_out))) return SOD_EARG;
+  if ((long long)n1 * n2 == 0) return SOD_OK;
+  SOD_LAUNCH(pairwise_iou_rotated_kernel, dim3(nblk((long long)n1 * n2, 4096)), dim3(256), 0, (hipStream_t)stream, boxes1, n1, boxes2, n2, iou_out);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

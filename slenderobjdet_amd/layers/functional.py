@@ -389,6 +389,27 @@ def nms(boxes, scores, iou_threshold):
     return keep[: int(nkeep.item())]
 
 
+def nms_rotated(boxes, scores, iou_threshold):
+    """detectron2.layers.nms_rotated: boxes (n,5) = (cx,cy,w,h,angle_deg)."""
+    _chk(boxes, torch.float32, "boxes"); _chk(scores, torch.float32, "scores")
+    n, dev = boxes.shape[0], boxes.device
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=dev)
+    order = torch.sort(scores, descending=True, stable=True).indices.contiguous()
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    nkeep = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(_C.load().sod_nms_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    call("sod_nms_rotated", ptr(boxes), ptr(order), n, float(iou_threshold), ptr(keep), ptr(nkeep), ptr(ws), stream_ptr())
+    return keep[: int(nkeep.item())]
+
+
+def box_iou_rotated(b1, b2):
+    _chk(b1, torch.float32, "boxes1"); _chk(b2, torch.float32, "boxes2")
+    out = torch.empty((b1.shape[0], b2.shape[0]), dtype=torch.float32, device=b1.device)
+    call("sod_box_iou_rotated", ptr(b1), b1.shape[0], ptr(b2), b2.shape[0], ptr(out), stream_ptr())
+    return out
+
+
 def roi_align_fwd(x, rois, output_size, spatial_scale, sampling_ratio=0, rotated=False):
     """x (N,H,W,C) bf16, rois (R,5|6) f32 -> (R,PH,PW,C) f32 (aligned=True semantics)."""
     _chk(x, torch.bfloat16, "x"); _chk(rois, torch.float32, "rois")
