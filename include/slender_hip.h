@@ -210,6 +210,19 @@ int sod_deform_col2im(const void* dcols, const void* x, const float* offset, con
                       int off_ld, int mask_ld, int mask_is_logit, void* stream);
 int sod_f32_to_bf16(const float* x, void* y, long long n, void* stream);
 
+/* RetinaNet (detectron2 RetinaNet; in-tree mirror slender_det/modeling/meta_arch/retina/retina_rotated.py):
+ * sod_retina_targets = tail of label_anchors (:279-291) + Box2BoxTransform.get_deltas (:203-206) for ONE image (weights4 host);
+ * sod_retina_box_loss_* = smooth_l1_loss(pred_deltas[pos], gt_deltas[pos], beta, "sum") (:229) on the pitched prediction buffer
+ * (anchor a of pixel p at p*pitch + a*4) + the EMA loss normaliser (:210-214) kept on the device:
+ * normalizer <- momentum*normalizer + (1-momentum)*max(num_pos,1); sums2 = {loss sum, num_pos}. */
+int sod_retina_targets(const float* anchors, int A, const float* gt_boxes, const int* gt_classes, int G, const int* matches,
+                       const signed char* match_labels, int num_classes, const float* weights4, int* gt_labels, float* gt_deltas,
+                       void* stream);
+int sod_retina_box_loss_fwd(const float* pred, int pitch, const int* gt_labels, const float* gt_deltas, int N, int R, int A,
+                            int num_classes, float beta, float* sums2, float* normalizer, float momentum, float* ws, void* stream);
+int sod_retina_box_loss_bwd(const float* pred, int pitch, const int* gt_labels, const float* gt_deltas, int N, int R, int A,
+                            int num_classes, float beta, const float* grad_num, const float* grad_den, void* dpred_bf16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -382,6 +382,91 @@ __global__ __launch_bounds__(256) void anchor_match2_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------- RetinaNet targets / box loss
+// label_anchors tail (retina_rotated.py:279-291) + Box2BoxTransform.get_deltas for one image
+__global__ __launch_bounds__(256) void retina_targets_kernel(const float* __restrict__ anchors, int A, const float* __restrict__ gts,
+                                                             const int* __restrict__ gt_classes, int G, const int* __restrict__ matches,
+                                                             const signed char* __restrict__ mlabels, int num_classes, float wx, float wy,
+                                                             float ww, float wh, int* __restrict__ gt_labels, float* __restrict__ deltas) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < A; i += gridDim.x * 256) {
+    int lab = num_classes;
+    f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+    if (G > 0) {
+      const int m = matches[i];
+      const int ml = mlabels[i];
+      lab = (ml == 0) ? num_classes : ((ml == -1) ? -1 : gt_classes[m]);
+      const f32x4_t s = *reinterpret_cast<const f32x4_t*>(anchors + (long long)i * 4);
+      const f32x4_t t = *reinterpret_cast<const f32x4_t*>(gts + (long long)m * 4);
+      const float sw = s[2] - s[0], sh = s[3] - s[1], scx = s[0] + 0.5f * sw, scy = s[1] + 0.5f * sh;
+      const float tw = t[2] - t[0], th = t[3] - t[1], tcx = t[0] + 0.5f * tw, tcy = t[1] + 0.5f * th;
+      d = f32x4_t{wx * (tcx - scx) / sw, wy * (tcy - scy) / sh, ww * logf(tw / sw), wh * logf(th / sh)};
+    }
+    gt_labels[i] = lab;
+    *reinterpret_cast<f32x4_t*>(deltas + (long long)i * 4) = d;
+  }
+}
+
+struct RetinaBoxArgs {
+  const float* pred;        // (N, sumHW, pitch) fp32: anchor a of pixel p at p*pitch + a*4
+  const int* labels;        // (N, R)
+  const float* deltas;      // (N, R, 4)
+  int N, R, A, pitch, num_classes;
+  float beta;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void retina_box_kernel(const RetinaBoxArgs a, float* __restrict__ part, const float* __restrict__ gnum,
+                                                         const float* __restrict__ gden, __bf16* __restrict__ dpred) {
+  __shared__ float red[4];
+  float acc = 0.f, npos = 0.f;
+  const float sc = BWD ? gnum[0] / gden[0] : 0.f;
+  const long long total = (long long)a.N * a.R;
+  const long long pix_per_img = a.R / a.A;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / a.R, r = i - n * a.R;
+    const long long px = r / a.A;
+    const int an = (int)(r - px * a.A);
+    const long long po = (n * pix_per_img + px) * a.pitch + an * 4;
+    const int lab = a.labels[i];
+    const bool pos = lab >= 0 && lab != a.num_classes;
+    f32x4_t g = {0.f, 0.f, 0.f, 0.f};
+    if (pos) {
+      npos += 1.f;
+      const f32x4_t p = *reinterpret_cast<const f32x4_t*>(a.pred + po), t = *reinterpret_cast<const f32x4_t*>(a.deltas + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = p[e] - t[e], ad = fabsf(d);
+        if (a.beta < 1e-5f) { acc += ad; g[e] = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+        else if (ad < a.beta) { acc += 0.5f * d * d / a.beta; g[e] = d / a.beta; }
+        else { acc += ad - 0.5f * a.beta; g[e] = d > 0.f ? 1.f : -1.f; }
+      }
+    }
+    if (BWD) {
+      bf16x4_t o = {(__bf16)(g[0] * sc), (__bf16)(g[1] * sc), (__bf16)(g[2] * sc), (__bf16)(g[3] * sc)};
+      *reinterpret_cast<bf16x4_t*>(dpred + po) = o;
+    }
+  }
+  if (!BWD) {
+    acc = block_sum_256(acc, red);
+    npos = block_sum_256(npos, red);
+    if (threadIdx.x == 0) { part[blockIdx.x] = acc; part[RED + blockIdx.x] = npos; }
+  }
+}
+
+// sums[0] = smooth-L1 sum over positives, sums[1] = number of positives; normalizer <- m*normalizer + (1-m)*max(npos,1)
+__global__ void retina_finish_kernel(const float* __restrict__ part, int nblk_, float* __restrict__ sums, float* __restrict__ normalizer,
+                                     float momentum) {
+  __shared__ float red[4];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < nblk_; i += 256) { a += part[i]; b += part[RED + i]; }
+  a = block_sum_256(a, red);
+  b = block_sum_256(b, red);
+  if (threadIdx.x == 0) {
+    sums[0] = a; sums[1] = b;
+    if (normalizer) normalizer[0] = momentum * normalizer[0] + (1.f - momentum) * fmaxf(b, 1.f);
+  }
+}
+
 inline int nblk(long long n, int cap = RED) {
   long long g = (n + 255) / 256;
   if (g > cap) g = cap;
@@ -504,6 +589,37 @@ extern "C" int sod_anchor_match(const float* gt_boxes, int G, const float* ancho
   SOD_LAUNCH(anchor_match1_kernel, dim3(g), dim3(256), sizeof(unsigned) * G, st, gt_boxes, G, anchors, A, matched_vals, matches, gt_best_ws);
   SOD_LAUNCH(anchor_match2_kernel, dim3(g), dim3(256), 0, st, gt_boxes, G, anchors, A, matched_vals, gt_best_ws, thr_lo, thr_hi,
              label_below, label_between, label_above, allow_low_quality, labels);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_retina_targets(const float* anchors, int A, const float* gt_boxes, const int* gt_classes, int G, const int* matches,
+                                  const signed char* match_labels, int num_classes, const float* weights4, int* gt_labels, float* gt_deltas,
+                                  void* stream) {
+  if (!anchors || A <= 0 || !gt_labels || !gt_deltas || !weights4 || (G > 0 && (!gt_boxes || !gt_classes || !matches || !match_labels))) return SOD_EARG;
+  SOD_LAUNCH(retina_targets_kernel, dim3(nblk(A, 2048)), dim3(256), 0, (hipStream_t)stream, anchors, A, gt_boxes, gt_classes, G, matches, match_labels,
+             num_classes, weights4[0], weights4[1], weights4[2], weights4[3], gt_labels, gt_deltas);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_retina_box_loss_fwd(const float* pred, int pitch, const int* gt_labels, const float* gt_deltas, int N, int R, int A,
+                                       int num_classes, float beta, float* sums2, float* normalizer, float momentum, float* ws, void* stream) {
+  if (!pred || !gt_labels || !gt_deltas || !sums2 || !ws || N <= 0 || R <= 0 || A <= 0 || R % A || pitch < A * 4) return SOD_EARG;
+  RetinaBoxArgs a{pred, gt_labels, gt_deltas, N, R, A, pitch, num_classes, beta};
+  hipStream_t st = (hipStream_t)stream;
+  const int g = nblk((long long)N * R);
+  SOD_LAUNCH(retina_box_kernel<false>, dim3(g), dim3(256), 0, st, a, ws, nullptr, nullptr, nullptr);
+  SOD_LAUNCH(retina_finish_kernel, dim3(1), dim3(256), 0, st, ws, g, sums2, normalizer, momentum);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_retina_box_loss_bwd(const float* pred, int pitch, const int* gt_labels, const float* gt_deltas, int N, int R, int A,
+                                       int num_classes, float beta, const float* grad_num, const float* grad_den, void* dpred_bf16, void* stream) {
+  if (!pred || !gt_labels || !gt_deltas || !grad_num || !grad_den || !dpred_bf16 || N <= 0 || R <= 0 || A <= 0 || R % A || pitch < A * 4) return SOD_EARG;
+  RetinaBoxArgs a{pred, gt_labels, gt_deltas, N, R, A, pitch, num_classes, beta};
+  SOD_LAUNCH(retina_box_kernel<true>, dim3(nblk((long long)N * R, 4096)), dim3(256), 0, (hipStream_t)stream, a, nullptr, grad_num, grad_den, (__bf16*)dpred_bf16);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict_
     const long long m = i / K;
     const int k = (int)(i - m * K);
     const float t = dense ? dense[m * K + k] : ((labels[m] == k) ? 1.f : 0.f);
-    const float l = focal_term(x[m * ld + k], t, alpha, gamma);
+    float l = focal_term(x[m * ld + k], t, alpha, gamma);
+    if (!dense && labels[m] < 0) l = 0.f;     // negative label = ignored row (RetinaNet valid_mask, retina_rotated.py:208)
     if (elem) elem[m * K + k] = l;
     acc += l;
   }
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict_
     float g = 0.f;
     if (k < K) {
       const float t = dense ? dense[m * K + k] : ((labels[m] == k) ? 1.f : 0.f);
-      g = focal_grad(x[m * ld + k], t, alpha, gamma) * sc;
+      g = (!dense && labels[m] < 0) ? 0.f : focal_grad(x[m * ld + k], t, alpha, gamma) * sc;
     }
     if (OUT_BF16) ((__bf16*)dx)[i] = (__bf16)g; else ((float*)dx)[i] = g;
   }

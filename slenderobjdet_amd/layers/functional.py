@@ -491,3 +491,24 @@ def deform_col2im(dcols, x, offset, mask, ksize, stride, pad, dil, dg, doffset, 
     call("sod_deform_col2im", ptr(dcols), ptr(x), ptr(offset), ptr(mask), ptr(dx), ptr(doffset), ptr(dmask), N, H, W, C, KH, KW, stride, pad, dil,
          dg, off_ld, mask_ld, 1 if mask_is_logit else 0, stream_ptr())
     return dx
+
+
+# ----------------------------------------------------------------------------------------------- RetinaNet
+def retina_targets(anchors, gt_boxes, gt_classes, matches, match_labels, num_classes, weights, gt_labels_out, gt_deltas_out):
+    G = gt_boxes.shape[0]
+    w = _float_arr(weights)
+    call("sod_retina_targets", ptr(anchors), anchors.shape[0], ptr(gt_boxes) if G else None, ptr(gt_classes) if G else None, G,
+         ptr(matches) if G else None, ptr(match_labels) if G else None, num_classes, ctypes.cast(w, ctypes.c_void_p), ptr(gt_labels_out),
+         ptr(gt_deltas_out), stream_ptr())
+
+
+def retina_box_loss_fwd(pred, pitch, gt_labels, gt_deltas, N, R, A, num_classes, beta, normalizer, momentum):
+    sums = torch.empty(2, dtype=torch.float32, device=pred.device)
+    call("sod_retina_box_loss_fwd", ptr(pred), pitch, ptr(gt_labels), ptr(gt_deltas), N, R, A, num_classes, float(beta), ptr(sums),
+         ptr(normalizer), float(momentum), ptr(reduce_ws(pred.device)), stream_ptr())
+    return sums
+
+
+def retina_box_loss_bwd(pred, pitch, gt_labels, gt_deltas, N, R, A, num_classes, beta, grad_num, grad_den, dpred):
+    call("sod_retina_box_loss_bwd", ptr(pred), pitch, ptr(gt_labels), ptr(gt_deltas), N, R, A, num_classes, float(beta), ptr(grad_num),
+         ptr(grad_den), ptr(dpred), stream_ptr())

@@ -217,6 +217,52 @@ class _ConvGnReluFn(torch.autograd.Function):
         return (None, None, *dxs)
 
 
+class ConvReluML(nn.Module):
+    """[Conv3x3(bias) -> ReLU] tower unit of RetinaNetHead (retina_rotated.py:418-430) over all FPN levels in one launch."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = HipConv2d(channels, channels, 3, 1, 1, bias=True)
+
+    def forward(self, xs):
+        self.conv.prepare()
+        return list(_ConvReluMLFn.apply(self.conv.weight, self, *xs))
+
+
+class _ConvReluMLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, unit, *xs):
+        conv = unit.conv
+        ys = HF.conv2d_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, 1, 1, 1, relu=True)
+        ctx.unit, ctx.nl = unit, len(xs)
+        ctx.save_for_backward(*xs, *ys)
+        arena = _arena_of(conv)
+        if arena is not None and conv.weight.requires_grad:
+            arena.note_use(conv.weight)
+            arena.note_use(conv.bias)
+        return tuple(ys)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        conv, nl = ctx.unit.conv, ctx.nl
+        saved = ctx.saved_tensors
+        xs, ys = saved[:nl], saved[nl:]
+        arena = _arena_of(conv)
+        gs = [HF.relu_bwd(dy.contiguous(), y) for dy, y in zip(dys, ys)]
+        HF.conv2d_wgrad_ml(gs, list(xs), arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
+        arena.mark_ready(conv.weight)
+        dbias = arena.grad_view(conv.bias)
+        for g in gs:
+            N, H, W, C = g.shape
+            HF.bias_grad(g, dbias, N, H * W, C)
+        arena.mark_ready(conv.bias)
+        dxs = [None] * nl
+        if any(ctx.needs_input_grad[2:]):
+            dxs = HF.conv2d_dgrad_ml(gs, conv.wt_bf16, [(x.shape[1], x.shape[2]) for x in xs], 1, 1, 1)
+        return (None, None, *dxs)
+
+
 class _GnReluFn(torch.autograd.Function):
     """Stand-alone GroupNorm(+ReLU) (after a deformable tower conv, fcosv2.py:300-336 with USE_DCN_IN_TOWER)."""
 

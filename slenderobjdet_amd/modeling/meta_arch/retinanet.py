@@ -1,0 +1,200 @@
+"""RetinaNet on the HIP kernels (BASELINE config 3).
+
+Mirror of detectron2's ``RetinaNet`` / ``RetinaNetHead`` as documented by the reference's in-tree copy
+slender_det/modeling/meta_arch/retina/retina_rotated.py:38-474 (forward :129-183, losses :185-249, label_anchors :251-295,
+head :390-474) for axis-aligned boxes, smooth-L1 regression.  Same ``cls(cfg)`` / ``forward(batched_inputs)`` contract and
+loss keys (``loss_cls``, ``loss_box_reg``).
+
+MI355X-first: anchors are labelled by one fused IoU+Matcher kernel per image that never materialises the G x 201 600 matrix;
+the per-level prediction convs are one multi-level launch each writing the concatenated (N, R, K) logits / pitched deltas;
+ignored anchors are skipped by label inside the loss kernels (no boolean gathers); the EMA loss normaliser lives on the device
+(the reference calls ``.item()`` at :210).
+"""
+import math
+
+import torch
+from torch import nn
+from torch.autograd.function import once_differentiable
+
+from ...layers import functional as HF
+from ...layers.nn import ConvReluML, HipConv2d, _arena_of
+from ...structures import ImageList
+from ..anchor_generator import grid_anchors
+from ..backbone import build_backbone
+from .build import META_ARCH_REGISTRY
+from .fcos import FCOSV2
+
+
+def _ceil8(v):
+    return (v + 7) // 8 * 8
+
+
+class RetinaNetHead(nn.Module):
+    def __init__(self, cfg, in_channels, num_anchors):
+        super().__init__()
+        self.num_classes = cfg.MODEL.RETINANET.NUM_CLASSES
+        self.num_anchors = num_anchors
+        n = cfg.MODEL.RETINANET.NUM_CONVS
+        self.cls_subnet = nn.ModuleList([ConvReluML(in_channels) for _ in range(n)])
+        self.bbox_subnet = nn.ModuleList([ConvReluML(in_channels) for _ in range(n)])
+        self.kc = num_anchors * self.num_classes            # 720, a multiple of 8
+        assert self.kc % 8 == 0
+        self.box_pitch = _ceil8(num_anchors * 4)            # 36 -> 40
+        self.cls_score = HipConv2d(in_channels, self.kc, 3, 1, 1, bias=True)
+        self.bbox_pred = HipConv2d(in_channels, self.box_pitch, 3, 1, 1, bias=True)
+        for u in list(self.cls_subnet) + list(self.bbox_subnet):
+            u.conv.init_normal(0.01, 0.0)
+        prior = cfg.MODEL.RETINANET.PRIOR_PROB
+        with torch.no_grad():
+            self.cls_score.init_normal(0.01, -math.log((1 - prior) / prior))
+            self.bbox_pred.init_normal(0.01, 0.0)
+            self.bbox_pred.weight[num_anchors * 4:].zero_()
+
+    def run_towers(self, feats):
+        c, b = list(feats), list(feats)
+        for u in self.cls_subnet:
+            c = u(c)
+        for u in self.bbox_subnet:
+            b = u(b)
+        return c, b
+
+    def predict(self, cls_t, box_t):
+        self.cls_score.prepare()
+        self.bbox_pred.prepare()
+        N = cls_t[0].shape[0]
+        hw = [(t.shape[1], t.shape[2]) for t in cls_t]
+        P = sum(h * w for h, w in hw)
+        dev = cls_t[0].device
+        cls_buf = torch.empty((N, P, self.kc), dtype=torch.float32, device=dev)        # == (N, R, num_classes)
+        box_buf = torch.empty((N, P, self.box_pitch), dtype=torch.float32, device=dev)
+        offs, off = [], 0
+        for h, w in hw:
+            offs.append(off)
+            off += h * w
+        HF.conv2d_fwd_ml(list(cls_t), self.cls_score.w_bf16, self.cls_score.bias_eff, 1, 1, 1, out_f32=True,
+                         outs=[cls_buf.view(-1)[o * self.kc:] for o in offs], y_img_stride=P * self.kc)
+        HF.conv2d_fwd_ml(list(box_t), self.bbox_pred.w_bf16, self.bbox_pred.bias_eff, 1, 1, 1, out_f32=True,
+                         outs=[box_buf.view(-1)[o * self.box_pitch:] for o in offs], y_img_stride=P * self.box_pitch)
+        return cls_buf, box_buf, hw, offs
+
+
+class _RetinaLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, weight, gt_labels, gt_deltas, *towers):
+        head = model.head
+        nl = len(towers) // 2
+        cls_t, box_t = list(towers[:nl]), list(towers[nl:])
+        cls_buf, box_buf, hw, offs = head.predict(cls_t, box_t)
+        N, P = cls_buf.shape[0], cls_buf.shape[1]
+        A, K = head.num_anchors, head.num_classes
+        R = P * A
+        sums = HF.retina_box_loss_fwd(box_buf, head.box_pitch, gt_labels, gt_deltas, N, R, A, K, model.smooth_l1_loss_beta,
+                                      model.loss_normalizer, model.loss_normalizer_momentum)    # also advances the EMA normaliser
+        focal_sum, _ = HF.focal_loss_fwd(cls_buf.view(N * R, K), gt_labels.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma)
+        out = torch.stack([focal_sum[0], sums[0]]) / model.loss_normalizer
+        ctx.model, ctx.geo = model, (hw, offs, N, P, A, K, R)
+        ctx.save_for_backward(cls_buf, box_buf, gt_labels, gt_deltas, model.loss_normalizer.clone(), *towers)
+        arena = _arena_of(head)
+        if arena is not None:
+            for p in (head.cls_score.weight, head.cls_score.bias, head.bbox_pred.weight, head.bbox_pred.bias):
+                arena.note_use(p)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g2):
+        model = ctx.model
+        head = model.head
+        hw, offs, N, P, A, K, R = ctx.geo
+        cls_buf, box_buf, gt_labels, gt_deltas, norm = ctx.saved_tensors[:5]
+        towers = ctx.saved_tensors[5:]
+        nl = len(towers) // 2
+        cls_t, box_t = towers[:nl], towers[nl:]
+        g2 = g2.contiguous().float()
+        arena = _arena_of(head)
+        dev = cls_buf.device
+        dcls = HF.focal_loss_bwd(cls_buf.view(N * R, K), gt_labels.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma,
+                                 scale_num=g2[0:1], scale_den=norm, den_mul=1.0, den_min=1e-12, out_bf16=True).view(N, P, head.kc)
+        dbox = torch.zeros((N, P, head.box_pitch), dtype=torch.bfloat16, device=dev)
+        HF.retina_box_loss_bwd(box_buf, head.box_pitch, gt_labels, gt_deltas, N, R, A, K, model.smooth_l1_loss_beta, g2[1:2], norm, dbox)
+        grads = []
+        for pred, dbuf, kk, tower in ((head.cls_score, dcls, head.kc, cls_t), (head.bbox_pred, dbox, head.box_pitch, box_t)):
+            dys = [dbuf.view(-1)[o * kk:] for o in offs]
+            HF.conv2d_wgrad_ml(dys, list(tower), arena.grad_view(pred.weight), 3, 3, 1, 1, 1, dy_img_stride=P * kk, K=kk)
+            arena.mark_ready(pred.weight)
+            HF.bias_grad(dbuf, arena.grad_view(pred.bias), N, P, kk)
+            arena.mark_ready(pred.bias)
+            grads.append(HF.conv2d_dgrad_ml(dys, pred.wt_bf16, hw, 1, 1, 1, dy_img_stride=P * kk, N=N))
+        return (None, None, None, None, *grads[0], *grads[1])
+
+
+@META_ARCH_REGISTRY.register()
+class RetinaNet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        r = cfg.MODEL.RETINANET
+        self.num_classes = r.NUM_CLASSES
+        self.in_features = r.IN_FEATURES
+        self.focal_loss_alpha, self.focal_loss_gamma = r.FOCAL_LOSS_ALPHA, r.FOCAL_LOSS_GAMMA
+        self.smooth_l1_loss_beta = r.SMOOTH_L1_LOSS_BETA
+        self.box_reg_loss_type = r.BBOX_REG_LOSS_TYPE
+        if self.box_reg_loss_type != "smooth_l1":
+            raise NotImplementedError("RETINANET.BBOX_REG_LOSS_TYPE giou is not wired yet (sod_giou_loss_xyxy exists in the ABI)")
+        self.iou_thresholds, self.iou_labels = list(r.IOU_THRESHOLDS), list(r.IOU_LABELS)
+        self.bbox_reg_weights = tuple(r.BBOX_REG_WEIGHTS)
+        self.score_threshold, self.topk_candidates, self.nms_threshold = r.SCORE_THRESH_TEST, r.TOPK_CANDIDATES_TEST, r.NMS_THRESH_TEST
+        self.max_detections_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
+        self.backbone = build_backbone(cfg)
+        shapes = self.backbone.output_shape()
+        self.strides = [shapes[f].stride for f in self.in_features]
+        ag = cfg.MODEL.ANCHOR_GENERATOR
+        self.anchor_sizes, self.anchor_ratios, self.anchor_offset = [list(s) for s in ag.SIZES], [list(a) for a in ag.ASPECT_RATIOS], ag.OFFSET
+        num_anchors = len(self.anchor_sizes[0]) * len(self.anchor_ratios[0])
+        self.head = RetinaNetHead(cfg, shapes[self.in_features[0]].channels, num_anchors)
+        self.register_buffer("pixel_mean", torch.Tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1))
+        self.register_buffer("pixel_std", torch.Tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1))
+        self._mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
+        self._std = [float(v) for v in cfg.MODEL.PIXEL_STD]
+        self.register_buffer("loss_normalizer", torch.tensor([100.0]))     # retina_rotated.py:87-88
+        self.loss_normalizer_momentum = 0.9
+        self._anchor_cache = {}
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    preprocess_image = FCOSV2.preprocess_image
+
+    def anchors_for(self, level_hw):
+        key = tuple(level_hw)
+        if key not in self._anchor_cache:
+            per_level = grid_anchors(level_hw, self.strides, self.anchor_sizes, self.anchor_ratios, self.anchor_offset, self.device)
+            self._anchor_cache[key] = torch.cat(per_level).contiguous()
+        return self._anchor_cache[key]
+
+    @torch.no_grad()
+    def label_anchors(self, anchors, gt_instances):
+        """retina_rotated.py:251-295 — returns gt_labels (N,R) int32 in {-1, 0..K-1, K} and gt_deltas (N,R,4)."""
+        N, R = len(gt_instances), anchors.shape[0]
+        labels = torch.empty((N, R), dtype=torch.int32, device=anchors.device)
+        deltas = torch.empty((N, R, 4), dtype=torch.float32, device=anchors.device)
+        for i, g in enumerate(gt_instances):
+            boxes = g.gt_boxes.tensor.float().contiguous()
+            classes = g.gt_classes.to(torch.int32).contiguous()
+            _, matches, mlab = HF.anchor_match(boxes, anchors, self.iou_thresholds, self.iou_labels, True)
+            HF.retina_targets(anchors, boxes, classes, matches, mlab, self.num_classes, self.bbox_reg_weights, labels[i], deltas[i])
+        return labels, deltas
+
+    def forward(self, batched_inputs):
+        images = self.preprocess_image(batched_inputs)
+        features = self.backbone(images.tensor)
+        features = [features[f] for f in self.in_features]
+        level_hw = [tuple(f.shape[1:3]) for f in features]
+        anchors = self.anchors_for(level_hw)
+        cls_t, box_t = self.head.run_towers(features)
+        if self.training:
+            gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+            gt_labels, gt_deltas = self.label_anchors(anchors, gt_instances)
+            out = _RetinaLossFn.apply(self, self.head.cls_score.weight, gt_labels, gt_deltas, *cls_t, *box_t)
+            return {"loss_cls": out[0], "loss_box_reg": out[1]}
+        raise NotImplementedError("RetinaNet inference decode is not wired yet (ops: sod_nms, Box2BoxTransform.apply_deltas)")
