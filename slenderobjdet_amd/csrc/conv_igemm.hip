@@ -15,6 +15,7 @@
 // and fragments are fetched with ds_read_b64_tr_b16 (hardware transpose), swizzled at 32-B granularity.
 #include "common.h"
 #include "../../include/slender_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -52,11 +53,19 @@ struct ConvArgs {
   FastDiv div_cpt /* Cred/64 (fast) or Cred/8 (generic) */, div_s, div_stride;
 };
 
-template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32>
+template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int BQ = WQ * FQ * 16, BP = WP * FP * 16;
-  constexpr int W_TILE = BQ * 128, X_TILE = BP * 128, STAGE = W_TILE + X_TILE;
-  constexpr int XI = BP / 32;   // X rows per thread
+  constexpr int ROWB = BK * 2;                 // bytes per LDS row (one pixel / one output channel, BK contraction elements)
+  constexpr int CPR = BK / 8;                  // 16-B chunks per row (8 or 4)
+  constexpr int RPI = 64 / CPR;                // rows one wave instruction (1 KiB) covers
+  constexpr int RPP = 4 * RPI;                 // rows per pass of the 4 waves
+  constexpr int SWS = (BK == 64) ? 1 : 2;      // swizzle = (row >> SWS) & (CPR-1)
+  constexpr int W_TILE = BQ * ROWB, X_TILE = BP * ROWB, STAGE = W_TILE + X_TILE;
+  constexpr int XI = BP / RPP;   // X rows per thread
+  static_assert(BK == 64 || BK == 32, "BK");
+  static_assert(BP % RPP == 0, "tile rows");
+  constexpr bool WFULL = (BQ % RPP == 0);     // every wave stages weight rows in every pass: no wave-dependent branch in the K loop
   static_assert(WQ * WP == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -78,15 +87,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.src), 0, g.src_bytes, 0x00020000);
 
   // ---- per-thread staging geometry (rows are fixed for the whole K loop) ----
-  const int srow = lane >> 3;                                   // row inside one 8-row wave instruction
-  const int spos = lane & 7;                                    // 16-B slot inside the 128-B row
-  const int sswz = (lane >> 4) | ((wave & 1) << 2);             // ((tile_row>>1)&7), see header
+  const int srow = lane / CPR;                                  // row inside one wave instruction
+  const int spos = lane % CPR;                                  // 16-B slot inside the row
+  // tile_row = (i*4 + wave)*RPI + srow ; swizzle = (tile_row >> SWS) & (CPR-1)
+  const int sswz = (BK == 64) ? ((lane >> 4) | ((wave & 1) << 2)) : ((srow >> 2) & 3);
   const int schunk = spos ^ sswz;                               // logical chunk this lane fetches
   int xh[XI], xw[XI];
   uint32_t xoff[XI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const int row = (i * 4 + wave) * 8 + srow;
+    const int row = (i * 4 + wave) * RPI + srow;
     const uint32_t p = p0 + row;
     if (p < (uint32_t)gP) {
       const uint32_t n = fd_div(p, g.div_hw);
@@ -119,24 +129,76 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
   };
 
-  auto stage = [&](int t, char* buf) {
-    // weights: row-major [q][Kred]; K-step t covers flattened contraction [t*64, t*64+64)
+  // LINEAR fast path (the issue port, not the matrix pipe, was the limiter: ~90 VALU per K-step against 32 MFMAs).
+  // When the tap is uniform per K-step (!GENERIC) and the source coordinate is affine in the tap (fwd, or dgrad with
+  // stride 1), the byte offset of a row is rowbase + tapoff(t) with a SCALAR tapoff, and the padding test is one bit of a
+  // per-row tap-validity mask computed once here.  Per K-step and row: one add, one shift/and, one select.
+  const bool linear = !GENERIC && (MODE == MODE_FWD || a.stride == 1) && a.R * a.S <= 64;
+  uint32_t rowbase[XI];
+  unsigned long long tapmask[XI];
+  uint32_t wbase[(BQ + RPP - 1) / RPP];
+  if (linear) {
 #pragma unroll
-    for (int rb = 0; rb < BQ; rb += 32) {
-      if (rb + wave * 8 < BQ) {
-        const int row = rb + wave * 8 + srow;
+    for (int i = 0; i < XI; ++i) {
+      rowbase[i] = (xoff[i] + ((uint32_t)xh[i] * (uint32_t)gWs + (uint32_t)xw[i]) * (uint32_t)a.Cred + (uint32_t)schunk * 8u) * 2u;
+      unsigned long long m = 0;
+      for (int r = 0; r < a.R; ++r)
+        for (int s2 = 0; s2 < a.S; ++s2) {
+          int h, w;
+          const uint32_t ok = src_coord(xh[i], r, gHs, h) & src_coord(xw[i], s2, gWs, w);
+          m |= (unsigned long long)(ok & 1u) << (r * a.S + s2);
+        }
+      tapmask[i] = m;
+    }
+#pragma unroll
+    for (int j = 0; j < (BQ + RPP - 1) / RPP; ++j) {
+      const int row = j * RPP + wave * RPI + srow;
+      const int q = q0 + row;
+      wbase[j] = (q < a.Nout && row < BQ) ? ((uint32_t)q * (uint32_t)a.Kred + (uint32_t)schunk * 8u) * 2u : SOD_OOB;
+    }
+  }
+  const int tap_sign = (MODE == MODE_FWD) ? 1 : -1;
+
+  auto stage = [&](int t, char* buf) {
+    if (linear) {
+      const uint32_t tap = fd_div((uint32_t)t, a.div_cpt);
+      const int c0 = (t - (int)(tap * a.div_cpt.d)) * BK;
+      const int r = (int)fd_div(tap, a.div_s);
+      const int s2 = (int)tap - r * a.S;
+      const uint32_t tapoff = (uint32_t)((tap_sign * (r * a.dil * gWs + s2 * a.dil) * a.Cred + c0) * 2);   // scalar
+      const uint32_t woff = (uint32_t)(t * BK * 2);
+#pragma unroll
+      for (int j = 0; j < (BQ + RPP - 1) / RPP; ++j) {
+        if (WFULL || j * RPP + wave * RPI < BQ) {
+          const uint32_t voff = (wbase[j] == SOD_OOB) ? SOD_OOB : wbase[j] + woff;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, SOD_LDS(buf + (j * RPP + wave * RPI) * ROWB), 16, voff, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const bool ok = (tapmask[i] >> tap) & 1ull;
+        const uint32_t voff = ok ? rowbase[i] + tapoff : SOD_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + W_TILE + (i * 4 + wave) * 1024), 16, voff, 0, 0, 0);
+      }
+      return;
+    }
+    // weights: row-major [q][Kred]; K-step t covers flattened contraction [t*BK, (t+1)*BK)
+#pragma unroll
+    for (int rb = 0; rb < BQ; rb += RPP) {
+      if (WFULL || rb + wave * RPI < BQ) {
+        const int row = rb + wave * RPI + srow;
         const int q = q0 + row;
-        const int kk = t * 64 + schunk * 8;
-        const uint32_t m = (uint32_t) - (int)((q < a.Nout) & (kk < a.Kred));
+        const int kk = t * BK + schunk * 8;
+        const uint32_t m = (uint32_t) - (int)((q < a.Nout) & (kk < a.Kred) & (row < BQ));
         const uint32_t off = ((uint32_t)q * (uint32_t)a.Kred + (uint32_t)kk) * 2u;
         const uint32_t voff = (off & m) | (SOD_OOB & ~m);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, SOD_LDS(buf + (rb + wave * 8) * 128), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, SOD_LDS(buf + (rb + wave * RPI) * ROWB), 16, voff, 0, 0, 0);
       }
     }
     int r_u = 0, s_u = 0, c0_u = 0;
     if (!GENERIC) {
       const uint32_t tap = fd_div((uint32_t)t, a.div_cpt);
-      c0_u = (t - (int)(tap * a.div_cpt.d)) << 6;
+      c0_u = (t - (int)(tap * a.div_cpt.d)) * BK;
       r_u = (int)fd_div(tap, a.div_s);
       s_u = (int)tap - r_u * a.S;
     }
@@ -145,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       int r, s, c;
       uint32_t m = 0xFFFFFFFFu;
       if (GENERIC) {
-        const uint32_t gi = (uint32_t)t * 8u + (uint32_t)schunk;     // 8-channel chunk index
+        const uint32_t gi = (uint32_t)t * (uint32_t)CPR + (uint32_t)schunk;     // 8-channel chunk index
         const uint32_t tap = fd_div(gi, a.div_cpt);
         c = (int)(gi - tap * a.div_cpt.d) << 3;
         r = (int)fd_div(tap, a.div_s);
@@ -170,12 +232,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < FQ; ++i) {
     const int row = (wq * FQ + i) * 16 + fr;
-    aoff[i] = row * 128 + ((fg ^ ((row >> 1) & 7)) << 4);
+    aoff[i] = row * ROWB + ((fg ^ ((row >> SWS) & (CPR - 1))) << 4);
   }
 #pragma unroll
   for (int j = 0; j < FP; ++j) {
     const int row = (wp * FP + j) * 16 + fr;
-    boff[j] = W_TILE + row * 128 + ((fg ^ ((row >> 1) & 7)) << 4);
+    boff[j] = W_TILE + row * ROWB + ((fg ^ ((row >> SWS) & (CPR - 1))) << 4);
   }
 
   f32x4_t acc[FQ][FP];
@@ -190,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     __syncthreads();   // drains this wave's LDS-DMA (vmcnt(0)) and orders all waves' reads of the other buffer
     if (t + 1 < a.T) stage(t + 1, smem + ((t + 1) & 1) * STAGE);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8_t af[FQ], bf[FP];
 #pragma unroll
       for (int i = 0; i < FQ; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(cur + (aoff[i] ^ (ks << 6)));
@@ -212,14 +274,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   const int Nout = a.Nout;
   if ((Nout & 7) == 0) {
     constexpr int QW = FQ * 16;                  // channels per wave tile
-    constexpr int ROWB = QW * 4 + 16;            // fp32 row + 16 B pad (keeps 16-B alignment, spreads banks)
+    constexpr int EROWB = QW * 4 + 16;           // fp32 row + 16 B pad (keeps 16-B alignment, spreads banks)
     constexpr int NH = 2, FH = FP / NH;          // two halves of FH fragments (FH*16 pixel rows) bound the LDS use
     constexpr int EPL = OUT_F32 ? 4 : 8;         // output elements per lane (16 B)
     constexpr int LPR = QW / EPL;                // lanes per pixel row
-    constexpr int RPP = 64 / LPR;                // pixel rows per pass
-    static_assert(FP % NH == 0 && 4 * FH * 16 * ROWB <= 2 * STAGE, "epilogue staging must fit the K-loop LDS");
+    constexpr int ERPP = 64 / LPR;               // pixel rows per pass
+    static_assert(FP % NH == 0, "halves");
     __syncthreads();                             // every wave has finished reading the K-loop buffers
-    char* wl = smem + wave * (FH * 16 * ROWB);
+    char* wl = smem + wave * (FH * 16 * EROWB);
     const int erow = lane / LPR, eq = (lane % LPR) * EPL;
     const int q = q0 + wq * QW + eq;
 #pragma unroll
@@ -228,16 +290,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       for (int jj = 0; jj < FH; ++jj)
 #pragma unroll
         for (int i = 0; i < FQ; ++i)
-          *reinterpret_cast<f32x4_t*>(wl + (jj * 16 + fr) * ROWB + (i * 16 + fg * 4) * 4) = acc[i][h * FH + jj];
+          *reinterpret_cast<f32x4_t*>(wl + (jj * 16 + fr) * EROWB + (i * 16 + fg * 4) * 4) = acc[i][h * FH + jj];
 #pragma unroll
-      for (int r0 = 0; r0 < FH * 16; r0 += RPP) {
+      for (int r0 = 0; r0 < FH * 16; r0 += ERPP) {
         const int row = r0 + erow;
         const uint32_t p = p0 + (wp * FP + h * FH) * 16 + row;
         if (p < (uint32_t)gP && q < Nout) {
           float v[EPL];
 #pragma unroll
           for (int e = 0; e < EPL; e += 4) {
-            const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(wl + row * ROWB + (eq + e) * 4);
+            const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(wl + row * EROWB + (eq + e) * 4);
             v[e] = t4[0]; v[e + 1] = t4[1]; v[e + 2] = t4[2]; v[e + 3] = t4[3];
           }
           const uint32_t n = fd_div(p, g.div_hw);
@@ -498,10 +560,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   }
 }
 
-template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32>
+template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK = 64>
 int launch_conv(const ConvArgs& a0, hipStream_t st) {
   constexpr int BQ = WQ * FQ * 16, BP = WP * FP * 16;
   ConvArgs a = a0;
+  a.T = (a.Kred + BK - 1) / BK;
+  a.div_cpt = make_fastdiv((uint32_t)(GENERIC ? a.Cred / 8 : a.Cred / BK));
   a.nq_tiles = (a.Nout + BQ - 1) / BQ;
   int tiles = 0;
   for (int l = 0; l < a.nlev; ++l) {
@@ -509,16 +573,16 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
     tiles += (a.lev[l].P + BP - 1) / BP;
   }
   a.np_tiles = tiles;
-  const size_t lds_full = 2 * (size_t)(BQ + BP) * 128;
+  const size_t lds_full = 2 * (size_t)(BQ + BP) * BK * 2;
   // a single K-step needs no second staging buffer: a smaller footprint lets 4 blocks share a CU, which is what hides the
   // load->MFMA->store latency of the memory-bound 1x1 convolutions (C = 64)
   const size_t epi = 4 * (size_t)(FP / 2) * 16 * (FQ * 64 + 16);
-  size_t lds = a.T == 1 ? (size_t)(BQ + BP) * 128 : lds_full;
+  size_t lds = a.T == 1 ? (size_t)(BQ + BP) * BK * 2 : lds_full;
   if (lds < epi) lds = epi;
-  auto kern = conv_igemm_kernel<MODE, GENERIC, WQ, WP, FQ, FP, OUT_F32>;
+  auto kern = conv_igemm_kernel<MODE, GENERIC, WQ, WP, FQ, FP, OUT_F32, BK>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_full > epi ? lds_full : epi));
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
@@ -535,6 +599,18 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   } else if (a.Nout <= 64) {
     return generic ? launch_conv<MODE, true, 1, 4, 4, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 1, 4, 4, 4, OUT_F32>(a, st);
   }
+  // BK = 32 halves the LDS footprint (4 resident blocks per CU instead of 2): measured better for the latency-/write-bound
+  // cases — short contractions (1x1 expansions, Kred <= 256) and grids of at most ~2 blocks per CU slot — and worse for the
+  // large compute-bound shapes (head 3x3: 820 vs 699 TFLOP/s).  SOD_CONV_BK=32|64 forces one variant (experiments).
+  static int force_bk = -1;
+  if (force_bk < 0) { const char* e = getenv("SOD_CONV_BK"); force_bk = e ? atoi(e) : 0; }
+  long long blocks = 0;
+  for (int l = 0; l < a.nlev; ++l) blocks += (a.lev[l].P + 127) / 128;
+  blocks *= (a.Nout + 127) / 128;
+  bool use32 = !generic && (a.Cred & 31) == 0 && (a.Kred <= 256 || blocks <= 1024);
+  if (force_bk == 32) use32 = !generic && (a.Cred & 31) == 0;
+  if (force_bk == 64) use32 = false;
+  if (use32) return launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32, 32>(a, st);
   return generic ? launch_conv<MODE, true, 2, 2, 4, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32>(a, st);
 }
 
