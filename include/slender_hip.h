@@ -82,7 +82,8 @@ int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, f
 int sod_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd,
                       int N, int HW, int C, int G, long long img_stride, float eps, int relu, void* stream);
 int sod_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean_rstd,
-                      void* dx, float* dgamma, float* dbeta, float* red_ws /* 2*N*G floats */,
+                      void* dx, float* dgamma, float* dbeta, float* dxsum /* optional [C]: += sum over pixels of dx = bias
+                      gradient of the convolution that produced x */, float* red_ws /* 2*N*G floats */,
                       int N, int HW, int C, int G, long long img_stride, int relu, void* stream);
 
 /* elementwise helpers on bf16 tensors of n elements (n % 8 == 0) */

@@ -17,6 +17,7 @@ struct GnArgs {
   __bf16* y; __bf16* dx; float* stats;      // stats[N][G][2] : (sum,sumsq) then (mean,rstd)
   float* red;                               // bwd: red[N][G][2] = (sum dy*g, sum dy*g*xhat)
   float* dgamma; float* dbeta;
+  float* dxsum;                             // optional: per-channel sum of dx (= bias gradient of the producing conv)
   int N, HW, C, G, cpg, relu;
   long long img_stride;                     // elements between images
   float eps;
@@ -134,16 +135,21 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnArgs a) {
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a, float inv_m) {
+  extern __shared__ float lsum[];   // [C] per-channel sums of dx when a.dxsum
   const int n = blockIdx.y;
   const int c8n = a.C >> 3;
+  if (a.dxsum) {
+    for (int i = threadIdx.x; i < a.C; i += 256) lsum[i] = 0.f;
+    __syncthreads();
+  }
   const int rows_per_iter = 256 / c8n;
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
   const int g = (c8 * 8) / a.cpg;
   const float mean = a.stats[((long long)n * a.G + g) * 2], rstd = a.stats[((long long)n * a.G + g) * 2 + 1];
   const float m1 = a.red[((long long)n * a.G + g) * 2] * inv_m, m2 = a.red[((long long)n * a.G + g) * 2 + 1] * inv_m;
-  float gm[8], bt[8];
+  float gm[8], bt[8], sx[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { gm[e] = a.gamma[c8 * 8 + e]; bt[e] = a.beta[c8 * 8 + e]; }
+  for (int e = 0; e < 8; ++e) { gm[e] = a.gamma[c8 * 8 + e]; bt[e] = a.beta[c8 * 8 + e]; sx[e] = 0.f; }
   const int p0 = blockIdx.x * a.pix_per_block;
   int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
   const long long base = (long long)n * a.img_stride + c8 * 8;
@@ -157,8 +163,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a, float
       float d = (float)gv[e];
       if (a.relu && !(xh * gm[e] + bt[e] > 0.f)) d = 0.f;
       o[e] = (__bf16)(rstd * (d * gm[e] - m1 - xh * m2));
+      sx[e] += (float)o[e];       // the bias gradient is the sum of what the conv's wgrad/dgrad see (the stored bf16 values)
     }
     *reinterpret_cast<bf16x8_t*>(a.dx + base + (long long)p * a.C) = o;
+  }
+  if (a.dxsum) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&lsum[c8 * 8 + e], sx[e]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.C; i += 256) atomicAdd(a.dxsum + i, lsum[i]);
   }
 }
 
@@ -410,7 +423,7 @@ extern "C" int sod_groupnorm_fwd(const void* x, const float* gamma, const float*
 }
 
 extern "C" int sod_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean_rstd,
-                                 void* dx, float* dgamma, float* dbeta, float* red_ws /* 2*N*G floats */,
+                                 void* dx, float* dgamma, float* dbeta, float* dxsum, float* red_ws /* 2*N*G floats */,
                                  int N, int HW, int C, int G, long long img_stride, int relu, void* stream) {
   if (!dy || !x || !gamma || !beta || !mean_rstd || !dx || !dgamma || !dbeta || !red_ws) return SOD_EARG;
   int rc = gn_check(N, HW, C, G);
@@ -419,13 +432,13 @@ extern "C" int sod_groupnorm_bwd(const void* dy, const void* x, const float* gam
   hipStream_t st = (hipStream_t)stream;
   GnArgs a{};
   a.x = (const __bf16*)x; a.dy = (const __bf16*)dy; a.gamma = gamma; a.beta = beta; a.dx = (__bf16*)dx;
-  a.stats = const_cast<float*>(mean_rstd); a.red = red_ws; a.dgamma = dgamma; a.dbeta = dbeta;
+  a.stats = const_cast<float*>(mean_rstd); a.red = red_ws; a.dgamma = dgamma; a.dbeta = dbeta; a.dxsum = dxsum;
   a.N = N; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.relu = relu; a.img_stride = img_stride;
   const int gx = gn_grid(HW, N, a.pix_per_block);
   hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * N * G, st);
   if (e != hipSuccess) return (int)e;
   SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * (G + C), st, a);
-  SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), 0, st, a, 1.f / ((float)HW * (float)a.cpg));
+  SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * C : 0, st, a, 1.f / ((float)HW * (float)a.cpg));
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -192,14 +192,14 @@ def groupnorm_fwd(x, gamma, beta, G, eps=1e-5, relu=False):
     return y, stats
 
 
-def groupnorm_bwd(dy, x, gamma, beta, stats, G, dgamma, dbeta, relu=False):
-    """Returns dx; accumulates dgamma/dbeta (fp32) in place."""
+def groupnorm_bwd(dy, x, gamma, beta, stats, G, dgamma, dbeta, relu=False, dxsum=None):
+    """Returns dx; accumulates dgamma/dbeta (fp32) in place, and (optional) the per-channel sum of dx into ``dxsum``."""
     _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(dgamma, torch.float32, "dgamma"); _chk(dbeta, torch.float32, "dbeta")
     N, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * C)
     dx = torch.empty_like(x)
     red = torch.empty((N, G, 2), dtype=torch.float32, device=x.device)
-    call("sod_groupnorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(stats), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(red),
+    call("sod_groupnorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(stats), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(red),
          N, HW, C, G, 0, 1 if relu else 0, stream_ptr())
     return dx
 

@@ -200,17 +200,14 @@ class _ConvGnReluFn(torch.autograd.Function):
         arena = _arena_of(conv)
         gw, gb = gn.weight.detach(), gn.bias.detach()
         dgw, dgb = arena.grad_view(gn.weight), arena.grad_view(gn.bias)
-        dy1s = [HF.groupnorm_bwd(dy2.contiguous(), y1, gw, gb, st, gn.num_groups, dgw, dgb, relu=True)
+        dbias = arena.grad_view(conv.bias)      # the conv bias gradient (sum of dy1 over pixels) falls out of the GN backward pass
+        dy1s = [HF.groupnorm_bwd(dy2.contiguous(), y1, gw, gb, st, gn.num_groups, dgw, dgb, relu=True, dxsum=dbias)
                 for dy2, y1, st in zip(dy2s, y1s, stats)]
         arena.mark_ready(gn.weight)
         arena.mark_ready(gn.bias)
+        arena.mark_ready(conv.bias)
         HF.conv2d_wgrad_ml(dy1s, list(xs), arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
         arena.mark_ready(conv.weight)
-        dbias = arena.grad_view(conv.bias)
-        for dy1 in dy1s:
-            N, H, W, C = dy1.shape
-            HF.bias_grad(dy1, dbias, N, H * W, C)
-        arena.mark_ready(conv.bias)
         dxs = [None] * nl
         if any(ctx.needs_input_grad[2:]):
             dxs = HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, [(x.shape[1], x.shape[2]) for x in xs], 1, 1, 1)

@@ -8,7 +8,10 @@ convolution weights, ``FREEZE_AT`` stages without gradients, MSRA initialisation
 import torch
 from torch import nn
 
-from ...layers.nn import HipConv2d, max_pool_3x3_s2
+from torch.autograd.function import once_differentiable
+
+from ...layers import functional as HF
+from ...layers.nn import HipConv2d, _arena_of, max_pool_3x3_s2
 from ..shape_spec import ShapeSpec
 from .build import BACKBONE_REGISTRY, Backbone
 
@@ -47,6 +50,92 @@ class BottleneckBlock(nn.Module):
         return self.conv3(out, res=sc)     # relu(conv3 + shortcut) fused in the conv epilogue
 
 
+class _BottleneckStageFn(torch.autograd.Function):
+    """A whole stage of bottleneck blocks as ONE autograd node.  Forward is the plain sequence of fused conv launches; the
+    hand-written backward chains the blocks so that the ReLU mask of a block output and the residual-gradient sum are applied
+    in the dgrad epilogue of the NEXT block's first conv (accumulate + mask), instead of a relu_bwd pass plus an autograd add
+    (6 tensor passes -> 2 per block)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stage):
+        blocks = list(stage)
+        saved = [x]
+        for blk in blocks:
+            for m in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut):
+                if m is not None:
+                    m.prepare()
+            xin = saved[-1] if len(saved) == 1 else saved[-1]
+            sc = _conv(blk.shortcut, xin) if blk.shortcut is not None else xin
+            a = _conv(blk.conv1, xin)
+            b = _conv(blk.conv2, a)
+            out = _conv(blk.conv3, b, res=sc)
+            saved += [a, b, out]
+        ctx.stage = stage
+        train = blocks[0].conv1.weight.requires_grad
+        if train or x.requires_grad:
+            ctx.save_for_backward(*saved)
+            arena = _arena_of(blocks[0].conv1)
+            if train and arena is not None:
+                for blk in blocks:
+                    for m in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut):
+                        if m is not None:
+                            arena.note_use(m.weight)
+        return saved[-1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        blocks = list(ctx.stage)
+        saved = ctx.saved_tensors
+        arena = _arena_of(blocks[0].conv1)
+        g = HF.relu_bwd(dout.contiguous(), saved[-1])
+        dx = None
+        for k in range(len(blocks) - 1, -1, -1):
+            blk = blocks[k]
+            xin, a, b = saved[3 * k], saved[3 * k + 1], saved[3 * k + 2]
+            xin = saved[0] if k == 0 else saved[3 * k]        # block input = previous block's output
+            _wgrad(blk.conv3, g, b, arena)
+            db = _dgrad(blk.conv3, g, b, relu_mask=b)
+            _wgrad(blk.conv2, db, a, arena)
+            da = _dgrad(blk.conv2, db, a, relu_mask=a)
+            _wgrad(blk.conv1, da, xin, arena)
+            if blk.shortcut is not None:
+                _wgrad(blk.shortcut, g, xin, arena)
+            if k == 0:
+                if ctx.needs_input_grad[0]:
+                    if blk.shortcut is not None:
+                        dx = _dgrad(blk.shortcut, g, xin, accum=_dgrad(blk.conv1, da, xin))
+                    else:
+                        dx = _dgrad(blk.conv1, da, xin, accum=g)
+            else:   # previous block's output is post-ReLU: fold its mask and the identity-path gradient into the epilogue
+                if blk.shortcut is not None:
+                    g = _dgrad(blk.shortcut, g, xin, accum=_dgrad(blk.conv1, da, xin), relu_mask=xin)
+                else:
+                    g = _dgrad(blk.conv1, da, xin, accum=g, relu_mask=xin)
+        return dx, None, None
+
+
+def _conv(m, x, res=None):
+    return HF.conv2d_fwd(x, m.w_bf16, m.bias_eff, res, m.stride, m.padding, m.dilation, relu=m.relu)
+
+
+def _wgrad(m, g, x, arena):
+    if m.weight.requires_grad:
+        HF.conv2d_wgrad(g, x, arena.grad_view(m.weight), m.kernel_size, m.kernel_size, m.stride, m.padding, m.dilation, qscale=m.bn_scale)
+        arena.mark_ready(m.weight)
+
+
+def _dgrad(m, g, x, accum=None, relu_mask=None):
+    return HF.conv2d_dgrad(g, m.wt_bf16, (x.shape[1], x.shape[2]), m.stride, m.padding, m.dilation, accum=accum, relu_mask=relu_mask)
+
+
+class BottleneckStage(nn.Sequential):
+    """nn.Sequential of BottleneckBlocks (same parameter names as a plain Sequential) executed as one fused autograd node."""
+
+    def forward(self, x):
+        return _BottleneckStageFn.apply(x, self[0].conv1.weight, self)
+
+
 class BasicBlock(nn.Module):
     def __init__(self, in_channels, out_channels, stride=1):
         super().__init__()
@@ -75,7 +164,7 @@ class ResNet(Backbone):
         cur_stride = stem.stride
         for i, blocks in enumerate(stages):
             name = "res" + str(i + 2)
-            stage = nn.Sequential(*blocks)
+            stage = BottleneckStage(*blocks) if all(isinstance(b, BottleneckBlock) for b in blocks) else nn.Sequential(*blocks)
             self.add_module(name, stage)
             self.stages_and_names.append((stage, name))
             cur_stride = int(cur_stride * blocks[0].stride)

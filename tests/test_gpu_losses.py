@@ -199,8 +199,10 @@ def test_groupnorm(cuda, N, HW, C, G, relu):
     dx_ref, dg_ref, db_ref = onn.group_norm_backward(x, gamma, beta, G, dy, 1e-5, relu)
     dg = torch.zeros(C, device=cuda)
     db = torch.zeros(C, device=cuda)
-    dx = HF.groupnorm_bwd(dy.to(cuda).bfloat16(), x.to(cuda).bfloat16(), gamma.to(cuda), beta.to(cuda), stats, G, dg, db, relu)
+    dsum = torch.zeros(C, device=cuda)
+    dx = HF.groupnorm_bwd(dy.to(cuda).bfloat16(), x.to(cuda).bfloat16(), gamma.to(cuda), beta.to(cuda), stats, G, dg, db, relu, dxsum=dsum)
     _rel(dx, dx_ref, 2 ** -6, "gn dx")
+    _rel(dsum, dx.float().sum(dim=(0, 1, 2)).cpu(), 1e-4, "fused bias gradient (sum of dx)")
     _rel(dg, dg_ref, 2e-3, "gn dgamma")
     _rel(db, db_ref, 2e-3, "gn dbeta")
 
