@@ -53,20 +53,22 @@ struct ConvArgs {
   FastDiv div_cpt /* Cred/64 (fast) or Cred/8 (generic) */, div_s, div_stride;
 };
 
-template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK, int NSTAGE>
+__global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int NW = WQ * WP;                  // waves per workgroup (4 or 8)
   constexpr int BQ = WQ * FQ * 16, BP = WP * FP * 16;
   constexpr int ROWB = BK * 2;                 // bytes per LDS row (one pixel / one output channel, BK contraction elements)
   constexpr int CPR = BK / 8;                  // 16-B chunks per row (8 or 4)
   constexpr int RPI = 64 / CPR;                // rows one wave instruction (1 KiB) covers
-  constexpr int RPP = 4 * RPI;                 // rows per pass of the 4 waves
+  constexpr int RPP = NW * RPI;                // rows per pass of all waves
   constexpr int SWS = (BK == 64) ? 1 : 2;      // swizzle = (row >> SWS) & (CPR-1)
   constexpr int W_TILE = BQ * ROWB, X_TILE = BP * ROWB, STAGE = W_TILE + X_TILE;
   constexpr int XI = BP / RPP;   // X rows per thread
   static_assert(BK == 64 || BK == 32, "BK");
   static_assert(BP % RPP == 0, "tile rows");
   constexpr bool WFULL = (BQ % RPP == 0);     // every wave stages weight rows in every pass: no wave-dependent branch in the K loop
-  static_assert(WQ * WP == 4, "4 waves");
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(NSTAGE == 2 || NSTAGE == 3, "LDS ring depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   uint32_t xoff[XI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const int row = (i * 4 + wave) * RPI + srow;
+    const int row = (i * NW + wave) * RPI + srow;
     const uint32_t p = p0 + row;
     if (p < (uint32_t)gP) {
       const uint32_t n = fd_div(p, g.div_hw);
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       for (int i = 0; i < XI; ++i) {
         const bool ok = (tapmask[i] >> tap) & 1ull;
         const uint32_t voff = ok ? rowbase[i] + tapoff : SOD_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + W_TILE + (i * 4 + wave) * 1024), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + W_TILE + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
       }
       return;
     }
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       m &= src_coord(xw[i], s, gWs, w);
       const uint32_t off = (xoff[i] + ((uint32_t)h * (uint32_t)gWs + (uint32_t)w) * (uint32_t)a.Cred + (uint32_t)c) * 2u;
       const uint32_t voff = (off & m) | (SOD_OOB & ~m);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + W_TILE + (i * 4 + wave) * 1024), 16, voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + W_TILE + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
     }
   };
 
@@ -246,11 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < FP; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  stage(0, smem);
-  for (int t = 0; t < a.T; ++t) {
-    char* cur = smem + (t & 1) * STAGE;
-    __syncthreads();   // drains this wave's LDS-DMA (vmcnt(0)) and orders all waves' reads of the other buffer
-    if (t + 1 < a.T) stage(t + 1, smem + ((t + 1) & 1) * STAGE);
+  auto compute = [&](const char* cur) {
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8_t af[FQ], bf[FP];
@@ -263,6 +261,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < FP; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if constexpr (NSTAGE == 2) {
+    stage(0, smem);
+    for (int t = 0; t < a.T; ++t) {
+      __syncthreads();   // drains this wave's LDS-DMA (vmcnt(0)) and orders all waves' reads of the other buffer
+      if (t + 1 < a.T) stage(t + 1, smem + ((t + 1) & 1) * STAGE);
+      compute(smem + (t & 1) * STAGE);
+    }
+  } else {
+    // 3-deep LDS ring: the tile for step t+2 is requested while step t is computed, so a load has two full steps (~2 k
+    // cycles) to land instead of one.  Counted vmcnt keeps the youngest stage in flight across the (raw) barrier; every
+    // thread issues exactly LPS LDS-DMA loads per stage.
+    constexpr int LPS = BQ / RPP + XI;
+    static_assert(WFULL, "counted vmcnt needs a fixed number of loads per stage");
+    stage(0, smem);
+    if (a.T > 1) stage(1, smem + STAGE);
+    int slot = 0;
+    for (int t = 0; t < a.T; ++t) {
+      if (t + 1 < a.T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // tile t has landed for every wave; every wave has finished computing tile t-1
+      int nslot = slot + 2; if (nslot >= 3) nslot -= 3;
+      if (t + 2 < a.T) stage(t + 2, smem + nslot * STAGE);   // overwrites the buffer of tile t-1
+      compute(smem + slot * STAGE);
+      slot = (slot == 2) ? 0 : slot + 1;
     }
   }
 
@@ -458,6 +483,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.dy), 0, g.dy_bytes, 0x00020000);
   auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, g.x_bytes, 0x00020000);
 
+  // Row state for the INCREMENTAL path (stride 1, "same" geometry, Wo >= 64): consecutive K-steps advance every row by 64
+  // pixels, so (ho, wo) and both byte offsets are updated with a handful of adds/compares instead of two divisions and ~35
+  // VALU per row and step (the wgrad loop was issue-bound: 113 M VALU against 67 M in the forward kernel for equal MFMAs).
+  uint32_t r_oy[4], r_ox[4];
+  int r_ho[4], r_wo[4], r_p[4];
+  bool fast = false;
+  int dh = 0, dw = 0;
+  uint32_t ycorr = 0, xcorr = 0;
+  auto init_rows = [&](int pbase) {
+    fast = (a.stride == 1) && (g.Wo >= 64) && (g.Ho == g.Hx) && (g.Wo == g.Wx);
+    dh = r * a.dil - a.pad; dw = s * a.dil - a.pad;
+    ycorr = (uint32_t)(g.dy_img_stride - g.Ho * g.Wo * a.K) * 2u;
+    xcorr = (uint32_t)(g.x_img_stride - g.Hx * g.Wx * a.C) * 2u;
+    const uint32_t tapshift = (uint32_t)((dh * g.Wx + dw) * a.C * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (i * 4 + wave) * 4 + srow;
+      const int p = pbase + row;
+      const uint32_t n = fd_div((uint32_t)p, g.div_hw);
+      const uint32_t rem = (uint32_t)p - n * g.div_hw.d;
+      const uint32_t ho = fd_div(rem, g.div_w);
+      const uint32_t wo = rem - ho * g.div_w.d;
+      r_p[i] = p; r_ho[i] = (int)ho; r_wo[i] = (int)wo;
+      r_oy[i] = (n * (uint32_t)g.dy_img_stride + rem * (uint32_t)a.K) * 2u + qadd;
+      r_ox[i] = (n * (uint32_t)g.x_img_stride + rem * (uint32_t)a.C) * 2u + cadd + tapshift;
+    }
+  };
+  init_rows(vbeg - g.v0);
+
   auto stage = [&](int it, char* buf) {
     const int v = vbeg + it * 64;
     if (v >= next_v0) {
@@ -466,6 +520,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
       next_v0 = (cur_lv + 1 < a.nlev) ? a.lev[cur_lv + 1].v0 : 0x7fffffff;
       yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.dy), 0, g.dy_bytes, 0x00020000);
       xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, g.x_bytes, 0x00020000);
+      init_rows(v - g.v0);
+    }
+    if (fast) {
+      const uint32_t ystep = (uint32_t)(128 * a.K), xstep = (uint32_t)(128 * a.C);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool pv = r_p[i] < g.P;
+        const bool tv = ((unsigned)(r_ho[i] + dh) < (unsigned)g.Hx) & ((unsigned)(r_wo[i] + dw) < (unsigned)g.Wx);
+        const uint32_t vy = (pv && qmask) ? r_oy[i] : SOD_OOB;
+        const uint32_t vx = (pv && tv && cmask) ? r_ox[i] : SOD_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(buf + (i * 4 + wave) * 1024), 16, vy, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + TILE + (i * 4 + wave) * 1024), 16, vx, 0, 0, 0);
+        // advance this row by 64 pixels (Wo >= 64: at most one column wrap and one image wrap)
+        r_p[i] += 64; r_oy[i] += ystep; r_ox[i] += xstep;
+        int wo = r_wo[i] + 64, ho = r_ho[i];
+        if (wo >= g.Wo) { wo -= g.Wo; ho += 1; }
+        if (ho >= g.Ho) { ho -= g.Ho; r_oy[i] += ycorr; r_ox[i] += xcorr; }
+        r_wo[i] = wo; r_ho[i] = ho;
+      }
+      return;
     }
     const int pbase = v - g.v0;
 #pragma unroll
@@ -560,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   }
 }
 
-template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK = 64>
+template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK = 64, int NSTAGE = 2>
 int launch_conv(const ConvArgs& a0, hipStream_t st) {
   constexpr int BQ = WQ * FQ * 16, BP = WP * FP * 16;
   ConvArgs a = a0;
@@ -573,20 +647,20 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
     tiles += (a.lev[l].P + BP - 1) / BP;
   }
   a.np_tiles = tiles;
-  const size_t lds_full = 2 * (size_t)(BQ + BP) * BK * 2;
+  const size_t lds_full = NSTAGE * (size_t)(BQ + BP) * BK * 2;
   // a single K-step needs no second staging buffer: a smaller footprint lets 4 blocks share a CU, which is what hides the
   // load->MFMA->store latency of the memory-bound 1x1 convolutions (C = 64)
-  const size_t epi = 4 * (size_t)(FP / 2) * 16 * (FQ * 64 + 16);
+  const size_t epi = (size_t)(WQ * WP) * (size_t)(FP / 2) * 16 * (FQ * 64 + 16);
   size_t lds = a.T == 1 ? (size_t)(BQ + BP) * BK * 2 : lds_full;
   if (lds < epi) lds = epi;
-  auto kern = conv_igemm_kernel<MODE, GENERIC, WQ, WP, FQ, FP, OUT_F32, BK>;
+  auto kern = conv_igemm_kernel<MODE, GENERIC, WQ, WP, FQ, FP, OUT_F32, BK, NSTAGE>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_full > epi ? lds_full : epi));
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  SOD_LAUNCH(kern, dim3(a.nq_tiles * a.np_tiles), dim3(256), lds, st, a);
+  SOD_LAUNCH(kern, dim3(a.nq_tiles * a.np_tiles), dim3(64 * WQ * WP), lds, st, a);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -611,6 +685,12 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   if (force_bk == 32) use32 = !generic && (a.Cred & 31) == 0;
   if (force_bk == 64) use32 = false;
   if (use32) return launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32, 32>(a, st);
+  // EXPERIMENT (off by default, SOD_CONV_T256=1): 128(q) x 256(p) tile, 8 waves, 3-deep LDS ring with counted vmcnt, one
+  // workgroup per CU.  Measured SLOWER than two independent 4-wave workgroups per CU with a 2-deep ring on the head shape
+  // (717 vs 813 TFLOP/s fwd): the extra prefetch depth does not pay for coupling 8 waves to one barrier.
+  static int t256 = -1;
+  if (t256 < 0) { const char* e = getenv("SOD_CONV_T256"); t256 = e ? atoi(e) : 0; }
+  if (t256 && !generic && blocks > 2048 && a.Kred >= 512) return launch_conv<MODE, false, 2, 4, 4, 4, OUT_F32, 64, 3>(a, st);
   return generic ? launch_conv<MODE, true, 2, 2, 4, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32>(a, st);
 }
 

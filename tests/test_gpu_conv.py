@@ -137,6 +137,9 @@ def test_conv_dgrad_accum_mask(cuda):
 
 
 WGRAD_CASES = [
+    (1, 5, 70, 64, 64, 3, 1, 1, 1, 0),      # Wo >= 64: incremental row tracking path, column wraps
+    (3, 2, 64, 64, 128, 3, 1, 1, 1, 2),     # Ho*Wo = 128: an image wrap every second step
+    (2, 3, 100, 128, 64, 1, 1, 0, 1, 0),    # 1x1, incremental path
     (2, 13, 21, 64, 128, 3, 1, 1, 1, 0),
     (2, 13, 21, 64, 128, 3, 1, 1, 1, 1),
     (1, 9, 11, 256, 64, 1, 1, 0, 1, 0),

@@ -175,3 +175,60 @@ def test_train_net_cli_runs(cuda, tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "iter: 3" in out.stdout and "cls_loss" in out.stdout
+
+
+def test_fcos_inference_boxes_scores_and_nms_vs_oracle(cuda):
+    """eval-mode forward -> boxes / scores / classes.  The oracle decode + NMS (oracle/inference.py, restating
+    fcosv2.py:194-266) runs on the HIP model's own head outputs, so the comparison covers decode, top-k, sqrt, class-offset NMS
+    (keep set bit-exact) and postprocess: boxes and scores within 1e-3 relative (north_star)."""
+    from oracle import fcos_targets as ot
+    from oracle import inference as oi
+    from slenderobjdet_amd.data import synthetic_batch
+
+    cfg, model, _ = _build(18, seed=3)
+    with torch.no_grad():   # make the random-init head fire: lower the prior bias so a few thousand candidates pass the 0.05 threshold
+        model.head.cls_pred.bias[:80] = -2.0
+        model.head.cls_pred.weight[:80] *= 20
+    model.arena.bump()
+    model.eval()
+    data = synthetic_batch(2, 256, 320, 21, device="cuda")
+    for d in data:
+        d["height"], d["width"] = 512, 640          # exercise detector_postprocess rescaling
+    with torch.no_grad():
+        out = model(data)
+        imgs = model.preprocess_image(data)
+        feats = model.backbone(imgs.tensor)
+        feats = [feats[f] for f in model.in_features]
+        ct, bt = model.head.run_towers(feats)
+        cls_buf, box_buf, hw = model.head.predict(ct, bt)
+    locs = ot.locations(hw, model.fpn_strides)
+    scales = model.head.scales.detach().cpu()
+    bounds = [0]
+    for h, w in hw:
+        bounds.append(bounds[-1] + h * w)
+    for i in range(2):
+        cls_l, reg_l, ctr_l = [], [], []
+        for l in range(5):
+            sl = slice(bounds[l], bounds[l + 1])
+            cls_l.append(cls_buf[i, sl, :80].cpu())
+            reg_l.append(torch.exp(box_buf[i, sl, :4].cpu() * scales[l]))
+            ctr_l.append(box_buf[i, sl, 4:5].cpu())
+        rb, rs, rc, _ = oi.fcos_inference_single_image(locs, cls_l, reg_l, ctr_l, (256, 320))
+        rb, ne = oi.detector_postprocess(rb, (256, 320), 512, 640)
+        rb, rs, rc = rb[ne], rs[ne], rc[ne]
+        inst = out[i]["instances"]
+        assert len(inst) == len(rb) and len(rb) > 10, (len(inst), len(rb))
+        # scores are computed with GPU vs CPU libm (last-ulp differences), so two detections with nearly equal scores may swap
+        # places in the score-ordered output: compare after a canonical (class, x1, y1) ordering.  Keep-index bit-exactness on
+        # identical inputs is covered by tests/test_gpu_detection_ops.py.
+        def canon(b, sc, c):
+            key = c.double() * 1e8 + b[:, 0].double().round() * 1e4 + b[:, 1].double().round()
+            o = torch.argsort(key)
+            return b[o], sc[o], c[o]
+
+        gb, gs, gc = canon(inst.pred_boxes.tensor.cpu(), inst.scores.cpu(), inst.pred_classes.cpu())
+        rb, rs, rc = canon(rb, rs, rc)
+        assert torch.equal(gc, rc)
+        assert (gs - rs).abs().max() <= 1e-3 * rs.abs().max()
+        assert (gb - rb).abs().max() <= 1e-3 * rb.abs().max()
+        assert (inst.scores[:-1] >= inst.scores[1:] - 1e-6).all()          # still emitted in descending score order
