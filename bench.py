@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=16)
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--depth", type=int, default=50, help="ResNet depth (tests use 18; the benchmark is R50)")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-prof", type=int, default=0, help="print the N most expensive (kernel, shape) groups to stderr")
@@ -108,8 +111,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # SOD_BENCH_SHARE_GPU=1 (tests only): every rank uses cuda:0 with the gloo backend, to exercise the data-parallel
+        # path on a single-GPU box; the real launch is one rank per GPU over RCCL ("nccl").
+        share = os.environ.get("SOD_BENCH_SHARE_GPU") == "1"
+        dev_index = 0 if share else local_rank
+        torch.cuda.set_device(dev_index)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -119,7 +129,7 @@ def main():
     from slenderobjdet_amd.modeling import build_model
     from slenderobjdet_amd.solver import build_optimizer
 
-    cfg = make_cfg()
+    cfg = make_cfg(args.depth)
     torch.manual_seed(1 + rank)   # engine/defaults.py:66: SEED + rank
     model = build_model(cfg)
     model.train()
@@ -128,7 +138,7 @@ def main():
         model.arena.bump()
     optimizer = build_optimizer(cfg, model)
     optimizer.grad_scale = 1.0 / world
-    loader = SyntheticCocoBatches(args.batch_per_gpu, 800, 1333, rank=rank, device=dev, pool=2)
+    loader = SyntheticCocoBatches(args.batch_per_gpu, args.height, args.width, rank=rank, device=dev, pool=2)
 
     for _ in range(args.warmup):
         train_step(model, optimizer, next(loader))
@@ -149,6 +159,9 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    dump = os.environ.get("SOD_BENCH_DUMP_PARAMS")
+    if dump:   # tests: replicas must stay bit-identical
+        torch.save(model.arena.params.detach().cpu(), os.path.join(dump, f"params_rank{rank}.pt"))
     loss_val = float(last.detach())
     assert loss_val == loss_val, "loss is NaN"
 

@@ -224,6 +224,22 @@ int sod_retina_box_loss_fwd(const float* pred, int pitch, const int* gt_labels, 
 int sod_retina_box_loss_bwd(const float* pred, int pitch, const int* gt_labels, const float* gt_deltas, int N, int R, int A,
                             int num_classes, float beta, const float* grad_num, const float* grad_den, void* dpred_bf16, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * The reference's own native operators (slender_det._C; bindings slender_det/layers/csrc/vision.cpp:64-80), fp32 NCHW.
+ * BorderAlign: feature (B,4C,H,W), boxes (B,K,4) XYXY in feature coordinates -> out (B,C,K,4)
+ *   (BorderAlign_cuda.cu:94-146; wh is derived from boxes as layers/border_align.py:38 does). bwd accumulates into dfeature (zero it).
+ * CornerPool: directional running max, mode 0 bottom / 1 top / 2 right / 3 left (layers/corner_pool.py:90-116);
+ *   bwd scatters dy to the arg-max (tie_latest=1: torch.cummax indices, the path torch>=1.5 takes; 0: the strict '>' of
+ *   corner_pool.cpp:30-69). dx must be zeroed by the caller.
+ * --------------------------------------------------------------------------------------------------------- */
+int sod_border_align_fwd(const float* feature, const float* boxes, float* out, int B, int C, int K, int H, int W, int pool_size,
+                         void* stream);
+int sod_border_align_bwd(const float* dout, const float* feature, const float* boxes, float* dfeature, int B, int C, int K, int H,
+                         int W, int pool_size, void* stream);
+int sod_corner_pool_fwd(const float* x, float* y, long long planes, int H, int W, int mode, void* stream);
+int sod_corner_pool_bwd(const float* x, const float* dy, float* dx, long long planes, int H, int W, int mode, int tie_latest,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -232,3 +232,27 @@ def test_fcos_inference_boxes_scores_and_nms_vs_oracle(cuda):
         assert (gs - rs).abs().max() <= 1e-3 * rs.abs().max()
         assert (gb - rb).abs().max() <= 1e-3 * rb.abs().max()
         assert (inst.scores[:-1] >= inst.scores[1:] - 1e-6).all()          # still emitted in descending score order
+
+
+def test_bench_two_ranks_data_parallel(cuda, tmp_path):
+    """bench.py under torch.distributed.run with 2 ranks (both on cuda:0, gloo transport — this box has one GPU): the
+    bucketed gradient all-reduce, the normaliser all-reduce, parameter broadcast and the JSON contract all execute, and the
+    two ranks end with bit-identical parameters."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SOD_BENCH_SHARE_GPU="1", SOD_BENCH_DUMP_PARAMS=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--depth", "18", "--batch-per-gpu", "2",
+           "--height", "256", "--width", "320", "--no-roofline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    p0 = torch.load(os.path.join(tmp_path, "params_rank0.pt"))
+    p1 = torch.load(os.path.join(tmp_path, "params_rank1.pt"))
+    assert torch.equal(p0, p1), "replicas diverged: gradient all-reduce / broadcast is broken"
