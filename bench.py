@@ -24,7 +24,11 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MF
 TRAIN_FLOP_PER_IMAGE = 1.1913e12   # fwd + dgrad + wgrad, stem+res2 frozen, 800x1344
 
 
-def make_cfg(depth=50):
+ARCH_NAMES = {"fcos": "FCOS", "retinanet": "RetinaNet", "reppoints": "RepPoints"}
+
+
+def make_cfg(depth=50, arch="fcos"):
+    """BASELINE.json configs[1] (fcos, the headline), configs[2] (retinanet) and configs[3] (reppoints) as config objects."""
     from slenderobjdet_amd.config import fresh_cfg
 
     cfg = fresh_cfg()
@@ -35,6 +39,18 @@ def make_cfg(depth=50):
     cfg.MODEL.RESNETS.DEPTH = depth
     if depth in (18, 34):
         cfg.MODEL.RESNETS.RES2_OUT_CHANNELS = 64
+    if arch in ("retinanet", "reppoints"):      # configs/retina/Base-RetinaNet.yaml
+        cfg.MODEL.BACKBONE.NAME = "build_retinanet_resnet_fpn_backbone"
+        cfg.MODEL.ANCHOR_GENERATOR.SIZES = [[x, x * 2 ** (1.0 / 3), x * 2 ** (2.0 / 3)] for x in [32, 64, 128, 256, 512]]
+        cfg.MODEL.RETINANET.IOU_THRESHOLDS = [0.4, 0.5]
+        cfg.MODEL.RETINANET.IOU_LABELS = [0, -1, 1]
+        cfg.MODEL.META_ARCHITECTURE = "RetinaNet"
+    if arch == "reppoints":                      # configs/rep-points/rep_points_detector_R_50_FPN_1x.yaml
+        cfg.MODEL.META_ARCHITECTURE = "RepPointsDetector"
+        cfg.MODEL.RESNETS.OUT_FEATURES = ["res2", "res3", "res4", "res5"]
+        cfg.MODEL.FPN.IN_FEATURES = ["res2", "res3", "res4", "res5"]
+        cfg.MODEL.FPN.NORM = "GN"
+        cfg.MODEL.PROPOSAL_GENERATOR.SAMPLE_MODE = "points"
     cfg.MODEL.FCOS.CENTER_SAMPLING_RADIUS = 1.5
     cfg.MODEL.FCOS.IOU_LOSS_TYPE = "giou"
     cfg.MODEL.FCOS.CENTERNESS_ON_REG = True
@@ -43,9 +59,17 @@ def make_cfg(depth=50):
     return cfg
 
 
+WORKLOADS = {
+    "fcos": "FCOS R50-FPN (FCOSV2, giou, center-sampling 1.5), fwd+bwd+SGD, synthetic 1333x800 padded to 800x1344 (BASELINE.json configs[1])",
+    "retinanet": "RetinaNet R50-FPN (9 anchors, smooth-L1), fwd+bwd+SGD, synthetic 1333x800 padded to 800x1344 (BASELINE.json configs[2])",
+    "reppoints": "RepPointsDetector R50-FPN(GN) (points matcher, 2 DeformConv/level), fwd+bwd+SGD, synthetic 1333x800 padded to 800x1344 "
+                 "(BASELINE.json configs[3])",
+}
+
+
 def train_step(model, optimizer, data):
     losses = model(data)
-    total = losses["cls_loss"] + losses["reg_loss"] + losses["centerness_loss"]
+    total = sum(losses.values())
     optimizer.zero_grad()
     model.arena.begin_backward()
     total.backward()
@@ -102,6 +126,7 @@ def main():
     ap.add_argument("--depth", type=int, default=50, help="ResNet depth (tests use 18; the benchmark is R50)")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--arch", choices=sorted(ARCH_NAMES), default="fcos", help="fcos = the headline metric (BASELINE.json configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-prof", type=int, default=0, help="print the N most expensive (kernel, shape) groups to stderr")
@@ -129,7 +154,7 @@ def main():
     from slenderobjdet_amd.modeling import build_model
     from slenderobjdet_amd.solver import build_optimizer
 
-    cfg = make_cfg(args.depth)
+    cfg = make_cfg(args.depth, args.arch)
     torch.manual_seed(1 + rank)   # engine/defaults.py:66: SEED + rank
     model = build_model(cfg)
     model.train()
@@ -168,14 +193,14 @@ def main():
     if rank == 0:
         imgs = args.steps * args.batch_per_gpu * world
         out = {
-            "metric": "training img/sec FCOS R50-FPN 1333x800", "value": round(imgs / dt, 3), "unit": "img/s",
+            "metric": f"training img/sec {ARCH_NAMES[args.arch]} R{args.depth}-FPN 1333x800", "value": round(imgs / dt, 3), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "FCOS R50-FPN (FCOSV2, giou, center-sampling 1.5), fwd+bwd+SGD, synthetic 1333x800 padded to 800x1344 "
-                                   "(BASELINE.json configs[1])", "global_batch": args.batch_per_gpu * world, "parallelism": f"dp{world}",
+            "config": {"workload": WORKLOADS[args.arch], "global_batch": args.batch_per_gpu * world, "parallelism": f"dp{world}",
                        "final_loss": round(loss_val, 5)},
-            "model_tflops": round(imgs * TRAIN_FLOP_PER_IMAGE / dt / 1e12, 2),
         }
+        if args.arch == "fcos" and args.depth == 50:
+            out["model_tflops"] = round(imgs * TRAIN_FLOP_PER_IMAGE / dt / 1e12, 2)
         if prof:
             agg = {}
             for kind, flops, e0, e1, _desc in prof:
@@ -197,7 +222,7 @@ def main():
                 a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
             for (kind, desc), (fl, sec, cnt) in sorted(per.items(), key=lambda kv: -kv[1][1])[:args.dump_prof]:
                 print(f"# {kind:10s} NHWCKRs={desc} calls/step {cnt // args.steps:3d} ms/step {sec / args.steps * 1e3:7.3f} TF/s {fl / sec / 1e12:7.1f}", file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.arch == "fcos":
             out["cpu_baseline"] = cpu_baseline(model, args)
         print(json.dumps(out), flush=True)
     if world > 1:

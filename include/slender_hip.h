@@ -90,6 +90,9 @@ int sod_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const f
 int sod_relu_fwd(const void* x, void* y, long long n, void* stream);
 int sod_relu_bwd(const void* dy, const void* y, void* dx, long long n, void* stream);
 int sod_add_bf16(const void* a, const void* b, void* out, long long n, void* stream);
+/* out = a + nearest-2x-upsample(b): a (N,H,W,C), b (N,H/2,W/2,C) — d2 FPN's top-down sum when FPN.NORM != "" (the norm sits
+ * between the lateral conv and the sum, so it cannot ride in the conv epilogue); the configs under configs/rep-points use NORM: "GN" */
+int sod_add_up2_bf16(const void* a, const void* b, void* out, int N, int H, int W, int C, void* stream);
 /* dbias[c] += sum over (n, pixel) of dy — bias gradient of nn.Conv2d(bias=True) */
 int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C, long long img_stride, void* stream);
 /* d2 BasicStem: F.max_pool2d(x, kernel_size=3, stride=2, padding=1) */
@@ -223,6 +226,44 @@ int sod_retina_box_loss_fwd(const float* pred, int pitch, const int* gt_labels, 
                             int num_classes, float beta, float* sums2, float* normalizer, float momentum, float* ws, void* stream);
 int sod_retina_box_loss_bwd(const float* pred, int pitch, const int* gt_labels, const float* gt_deltas, int N, int R, int A,
                             int num_classes, float beta, const float* grad_num, const float* grad_den, void* dpred_bf16, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * RepPointsDetector (slender_det/modeling/meta_arch/reppoints/rpd.py:45-798), X = sum of level pixels, point rows pitched by ld.
+ * sod_reppoints_dcn_offset: out[r,2k] = scale*pts[r,2k+1] - base_y[k], out[r,2k+1] = scale*pts[r,2k] - base_x[k] (xy->yx flip and
+ *   dcn_base_offset of rpd.py:105-110,621-635; subtract_base=0, scale=gradient_mul gives the backward of the same expression).
+ * sod_points2bbox_*: "minmax" transform of rpd.py:221-249 for ONE level: point k = (pts[2k] (+add[2k]))*point_stride + w*grid_stride, ...;
+ *   boxes/argidx are level slices of (N,X,4)/(N,X) buffers (img strides in elements); bwd scatters to the arg points and writes
+ *   whole rows (fp32 and/or bf16).
+ * sod_reppoints_point_match: init-box labels for the batch, mode 0 rep_points_match (matchers/rep_matcher.py:9-101, pos_num=1),
+ *   1 nearest_point_match (:199-223), 2 inside_match (:226-248) with structures/points.py:6-45; gt boxes concatenated with
+ *   box_offsets (N+1); objectness (N,X) int {0,1}, box_labels (N,X,4).  max_gt >= every image's gt count, <= 4096.
+ * sod_reppoints_labels: rpd.py:303-323 after pairwise_iou+Matcher (sod_anchor_match per image, init boxes as anchors):
+ *   cls = gt_classes[match]; matcher label 0 -> num_classes; centre outside the image -> -1 (and objectness 0); refine = gt_boxes[match].
+ * sod_reppoints_box_loss_*: smooth_l1(pred/(4*stride), target/(4*stride), beta, "sum") over selected rows (rpd.py:383-396);
+ *   row selected when bg_label<0 ? label>0 : (0<=label!=bg_label); sums2 = {loss sum, #rows};
+ *   bwd: dpred = mul*grad_num[0]/max(grad_den[0],den_min) * dloss/dpred (zeros on unselected rows).
+ * sod_reppoints_finalize: normalizer <- m*normalizer + (1-m)*refine_sums2[1]/num_images (rpd.py:366-376);
+ *   out3 = {focal/max(1,normalizer), init_weight*init_sum/max(1,init_rows), refine_sum/max(1,normalizer)}.
+ * --------------------------------------------------------------------------------------------------------- */
+int sod_reppoints_dcn_offset(const float* pts, float* out, long long rows, int ld, int num_points, float scale, int subtract_base,
+                             void* stream);
+int sod_points2bbox_fwd(const float* pts, const float* add, int ld, int N, int H, int W, float grid_stride, float point_stride,
+                        int num_points, float* boxes, long long box_img_stride, unsigned* argidx, long long arg_img_stride, void* stream);
+int sod_points2bbox_bwd(const float* dboxes, long long box_img_stride, const unsigned* argidx, long long arg_img_stride, int ld,
+                        int N, int H, int W, float point_stride, int num_points, float* dpts_f32, void* dpts_bf16, void* stream);
+int sod_reppoints_point_match(const float* centers, const float* strides, int X, const int* lvl_start, int num_levels,
+                              const float* gt_boxes, const int* box_offsets, int N, int max_gt, int mode, float scale,
+                              int* objectness, float* box_labels, void* stream);
+int sod_reppoints_labels(const int* matches, const signed char* match_labels, const float* gt_boxes, const int* gt_classes,
+                         const int* box_offsets, const float* centers, const float* image_hw, int N, int X, int num_classes,
+                         int* cls_labels, float* refine_boxes, int* objectness, void* stream);
+int sod_reppoints_box_loss_fwd(const float* pred, const float* target, const int* labels, const float* strides, int N, int X,
+                               int bg_label, float beta, float* sums2, float* ws, void* stream);
+int sod_reppoints_box_loss_bwd(const float* pred, const float* target, const int* labels, const float* strides, int N, int X,
+                               int bg_label, float beta, const float* grad_num, const float* grad_den, float den_min, float mul,
+                               float* dpred, void* stream);
+int sod_reppoints_finalize(const float* focal_sum, const float* init_sums2, const float* refine_sums2, float* normalizer,
+                           float momentum, int num_images, float init_weight, float* out3, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * The reference's own native operators (slender_det._C; bindings slender_det/layers/csrc/vision.cpp:64-80), fp32 NCHW.

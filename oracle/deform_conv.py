@@ -25,7 +25,7 @@ def _bilinear_gather(x, py, px):
     return out
 
 
-def deform_conv2d(x, offset, weight, bias=None, stride=1, pad=0, dil=1, mask=None, deformable_groups=1):
+def deform_conv2d(x, offset, weight, bias=None, stride=1, pad=0, dil=1, mask=None, deformable_groups=1, sample_hook=None):
     """x (N,C,H,W), offset (N, 2*kh*kw*dg, Ho, Wo), weight (K,C,kh,kw), mask (N, kh*kw*dg, Ho, Wo) or None."""
     N, C, H, W = x.shape
     K, _, kh, kw = weight.shape
@@ -46,6 +46,8 @@ def deform_conv2d(x, offset, weight, bias=None, stride=1, pad=0, dil=1, mask=Non
                 s = _bilinear_gather(xs, py, px)
                 if mask is not None:
                     s = s * mask[:, k].unsqueeze(1)
+                if sample_hook is not None:      # e.g. bf16 rounding of the gathered columns (what the HIP path stores)
+                    s = sample_hook(s)
                 out = out + torch.einsum("nchw,kc->nkhw", s, weight[:, g * cg:(g + 1) * cg, i, j])
     if bias is not None:
         out = out + bias.view(1, -1, 1, 1)

@@ -31,6 +31,7 @@ _SIGS = {
     "sod_relu_fwd": [_P, _P, _L, _P],
     "sod_relu_bwd": [_P, _P, _P, _L, _P],
     "sod_add_bf16": [_P, _P, _P, _L, _P],
+    "sod_add_up2_bf16": [_P, _P, _P, _I, _I, _I, _I, _P],
     "sod_bias_grad": [_P, _P, _I, _I, _I, _L, _P],
     "sod_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
     "sod_upsample2x_bwd": [_P, _P, _I, _I, _I, _I, _P],
@@ -67,6 +68,14 @@ _SIGS = {
     "sod_border_align_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sod_corner_pool_fwd": [_P, _P, _L, _I, _I, _I, _P],
     "sod_corner_pool_bwd": [_P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "sod_reppoints_dcn_offset": [_P, _P, _L, _I, _I, _F, _I, _P],
+    "sod_points2bbox_fwd": [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _L, _P, _L, _P],
+    "sod_points2bbox_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _F, _I, _P, _P, _P],
+    "sod_reppoints_point_match": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _F, _P, _P, _P],
+    "sod_reppoints_labels": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "sod_reppoints_box_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
+    "sod_reppoints_box_loss_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _F, _F, _P, _P],
+    "sod_reppoints_finalize": [_P, _P, _P, _P, _F, _I, _F, _P, _P],
     "sod_reduce_workspace_bytes": [],
     "sod_version": [],
 }

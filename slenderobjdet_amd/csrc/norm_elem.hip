@@ -210,6 +210,26 @@ __global__ __launch_bounds__(256) void add_kernel(const __bf16* __restrict__ a, 
   }
 }
 
+// o[n,h,w,:] = a[n,h,w,:] + b[n,h/2,w/2,:]  (FPN top-down path when a normalisation sits between the lateral conv and the sum)
+__global__ __launch_bounds__(256) void add_up2_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, __bf16* __restrict__ o,
+                                                      int N, int H, int W, int C) {
+  const int c8n = C >> 3, Hc = H >> 1, Wc = W >> 1;
+  const long long total = (long long)N * H * W * c8n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c8 = (int)(i % c8n);
+    long long r = i / c8n;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    const bf16x8_t x = reinterpret_cast<const bf16x8_t*>(a)[i];
+    const bf16x8_t y = *reinterpret_cast<const bf16x8_t*>(b + (((long long)n * Hc + (h >> 1)) * Wc + (w >> 1)) * C + c8 * 8);
+    bf16x8_t q;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[e] = (__bf16)((float)x[e] + (float)y[e]);
+    reinterpret_cast<bf16x8_t*>(o)[i] = q;
+  }
+}
+
 // bias gradient: db[c] += sum over rows of dy[row][c]; dy rows may be strided per image
 __global__ __launch_bounds__(256) void channel_sum_kernel(const __bf16* __restrict__ dy, float* __restrict__ db,
                                                           int HW, int C, long long img_stride, int pix_per_block) {
@@ -460,6 +480,14 @@ extern "C" int sod_relu_fwd(const void* x, void* y, long long n, void* stream) {
 extern "C" int sod_add_bf16(const void* a, const void* b, void* out, long long n, void* stream) {
   if (!a || !b || !out || n < 0 || (n & 7)) return SOD_EARG;
   SOD_LAUNCH(add_kernel, dim3(blocks_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, (const __bf16*)b, (__bf16*)out, n / 8);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_add_up2_bf16(const void* a, const void* b, void* out, int N, int H, int W, int C, void* stream) {
+  if (!a || !b || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || (H & 1) || (W & 1)) return SOD_EARG;
+  SOD_LAUNCH(add_up2_kernel, dim3(blocks_for((long long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, (const __bf16*)b,
+             (__bf16*)out, N, H, W, C);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -21,9 +21,9 @@ class _DeformConvFn(torch.autograd.Function):
     def forward(ctx, x, offset, mask, weight, mod, off_ld, mask_ld, mask_is_logit):
         k = mod.kernel_size
         cols = HF.deform_im2col(x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, mod.deformable_groups, off_ld, mask_ld, mask_is_logit)
-        y = HF.conv2d_fwd(cols, mod.w_bf16, mod.bias_eff, None, 1, 0, 1)
+        y = HF.conv2d_fwd(cols, mod.w_bf16, mod.bias_eff, None, 1, 0, 1, relu=mod.relu)
         ctx.mod, ctx.cfg = mod, (off_ld, mask_ld, mask_is_logit)
-        ctx.save_for_backward(x, offset, mask)
+        ctx.save_for_backward(x, offset, mask, y if mod.relu else None)
         arena = _arena_of(mod)
         if arena is not None and mod.weight.requires_grad:
             arena.note_use(mod.weight)
@@ -36,8 +36,10 @@ class _DeformConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         mod = ctx.mod
         off_ld, mask_ld, mask_is_logit = ctx.cfg
-        x, offset, mask = ctx.saved_tensors
+        x, offset, mask, y = ctx.saved_tensors
         dy = dy.contiguous()
+        if mod.relu:
+            dy = HF.relu_bwd(dy, y)
         k, dg = mod.kernel_size, mod.deformable_groups
         arena = _arena_of(mod)
         N, Ho, Wo, K = dy.shape
@@ -64,11 +66,14 @@ class _DeformConvFn(torch.autograd.Function):
 
 
 class DeformConv(nn.Module):
-    """detectron2.layers.DeformConv(in, out, kernel_size, stride, padding, dilation, groups, deformable_groups, bias=False)."""
+    """detectron2.layers.DeformConv(in, out, kernel_size, stride, padding, dilation, groups, deformable_groups, bias=False).
+    ``relu`` (extension): fuse the ReLU that follows the layer (rpd.py:161-167) into the GEMM epilogue."""
     modulated = False
 
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, bias=False):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, bias=False,
+                 relu=False):
         super().__init__()
+        self.relu = relu
         if groups != 1:
             raise NotImplementedError("grouped deformable convolution is not built")
         if bias and not self.modulated:

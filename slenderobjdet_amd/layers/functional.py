@@ -449,14 +449,21 @@ def smooth_l1_loss(x, t, beta, want_grad=False, grad_scale=None):
     return elem, s, dx
 
 
-def anchor_match(gt_boxes, anchors, thresholds, labels, allow_low_quality=True):
-    """RetinaNet.label_anchors core: returns (matched_vals f32 (A,), matches i32 (A,), labels i8 (A,))."""
+def anchor_match(gt_boxes, anchors, thresholds, labels, allow_low_quality=True, out=None):
+    """RetinaNet.label_anchors core: returns (matched_vals f32 (A,), matches i32 (A,), labels i8 (A,)); ``out`` = the three
+    output rows to fill (e.g. rows of batch-sized buffers)."""
     _chk(gt_boxes, torch.float32, "gt_boxes"); _chk(anchors, torch.float32, "anchors")
     A, G = anchors.shape[0], gt_boxes.shape[0]
     dev = anchors.device
-    vals = torch.empty(A, dtype=torch.float32, device=dev)
-    idx = torch.empty(A, dtype=torch.int32, device=dev)
-    lab = torch.empty(A, dtype=torch.int8, device=dev)
+    if out is not None:
+        vals, idx, lab = out
+        _chk(vals, torch.float32, "matched_vals"); _chk(idx, torch.int32, "matches"); _chk(lab, torch.int8, "labels")
+        if vals.numel() != A or idx.numel() != A or lab.numel() != A:
+            raise _C.SlenderHipError("anchor_match: output rows must hold one entry per anchor")
+    else:
+        vals = torch.empty(A, dtype=torch.float32, device=dev)
+        idx = torch.empty(A, dtype=torch.int32, device=dev)
+        lab = torch.empty(A, dtype=torch.int8, device=dev)
     ws = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
     call("sod_anchor_match", ptr(gt_boxes) if G else None, G, ptr(anchors), A, float(thresholds[0]), float(thresholds[1]), int(labels[0]), int(labels[1]),
          int(labels[2]), 1 if allow_low_quality else 0, ptr(vals), ptr(idx), ptr(lab), ptr(ws), stream_ptr())
@@ -512,3 +519,90 @@ def retina_box_loss_fwd(pred, pitch, gt_labels, gt_deltas, N, R, A, num_classes,
 def retina_box_loss_bwd(pred, pitch, gt_labels, gt_deltas, N, R, A, num_classes, beta, grad_num, grad_den, dpred):
     call("sod_retina_box_loss_bwd", ptr(pred), pitch, ptr(gt_labels), ptr(gt_deltas), N, R, A, num_classes, float(beta), ptr(grad_num),
          ptr(grad_den), ptr(dpred), stream_ptr())
+
+
+# ----------------------------------------------------------------------------------------------- FPN with a norm
+def add_up2(a, b):
+    """a + nearest-2x-upsample(b) (d2 FPN top-down sum when a norm follows the lateral conv)."""
+    _chk(a, torch.bfloat16, "a"); _chk(b, torch.bfloat16, "b")
+    N, H, W, C = a.shape
+    if tuple(b.shape) != (N, H // 2, W // 2, C) or H % 2 or W % 2:
+        raise _C.SlenderHipError(f"add_up2: {tuple(a.shape)} is not the 2x upsampling of {tuple(b.shape)}")
+    o = torch.empty_like(a)
+    call("sod_add_up2_bf16", ptr(a), ptr(b), ptr(o), N, H, W, C, stream_ptr())
+    return o
+
+
+# ----------------------------------------------------------------------------------------------- RepPoints
+def reppoints_dcn_offset(pts, num_points, scale=1.0, subtract_base=True):
+    """pts (..., ld) fp32 point rows (x, y interleaved) -> deformable-conv offsets (dy, dx interleaved) minus the kernel grid."""
+    _chk(pts, torch.float32, "pts")
+    ld = pts.shape[-1]
+    out = torch.empty_like(pts)
+    call("sod_reppoints_dcn_offset", ptr(pts), ptr(out), pts.numel() // ld, ld, num_points, float(scale), 1 if subtract_base else 0, stream_ptr())
+    return out
+
+
+def points2bbox_fwd(pts, add, grid_stride, point_stride, num_points, boxes, box_img_stride, arg, arg_img_stride):
+    """One level: pts (N,H,W,ld) fp32 (+ add) -> boxes / arg slices of the concatenated (N,X,4) / (N,X) buffers."""
+    _chk(pts, torch.float32, "pts"); _chk(add, torch.float32, "add")
+    N, H, W, ld = pts.shape
+    call("sod_points2bbox_fwd", ptr(pts), ptr(add), ld, N, H, W, float(grid_stride), float(point_stride), num_points, ptr(boxes), box_img_stride,
+         ptr(arg), arg_img_stride, stream_ptr())
+
+
+def points2bbox_bwd(dboxes, box_img_stride, arg, arg_img_stride, shape, point_stride, num_points, want_f32=True, want_bf16=False):
+    N, H, W, ld = shape
+    d32 = torch.empty(shape, dtype=torch.float32, device=dboxes.device) if want_f32 else None
+    d16 = torch.empty(shape, dtype=torch.bfloat16, device=dboxes.device) if want_bf16 else None
+    call("sod_points2bbox_bwd", ptr(dboxes), box_img_stride, ptr(arg), arg_img_stride, ld, N, H, W, float(point_stride), num_points, ptr(d32), ptr(d16),
+         stream_ptr())
+    return d32, d16
+
+
+RP_MATCH_MODES = {"points": 0, "nearest_points": 1, "inside": 2}
+
+
+def reppoints_point_match(centers, strides, lvl_start, gt_boxes, box_offsets, N, max_gt, mode, scale=4.0):
+    """Batched init-box matcher: returns objectness (N,X) int32 and box labels (N,X,4) fp32."""
+    _chk(centers, torch.float32, "centers"); _chk(strides, torch.float32, "strides"); _chk(gt_boxes, torch.float32, "gt_boxes")
+    _chk(lvl_start, torch.int32, "lvl_start"); _chk(box_offsets, torch.int32, "box_offsets")
+    X = centers.shape[0]
+    obj = torch.empty((N, X), dtype=torch.int32, device=centers.device)
+    blab = torch.empty((N, X, 4), dtype=torch.float32, device=centers.device)
+    call("sod_reppoints_point_match", ptr(centers), ptr(strides), X, ptr(lvl_start), lvl_start.numel() - 1, ptr(gt_boxes) if max_gt else None,
+         ptr(box_offsets), N, int(max_gt), RP_MATCH_MODES[mode] if isinstance(mode, str) else int(mode), float(scale), ptr(obj), ptr(blab), stream_ptr())
+    return obj, blab
+
+
+def reppoints_labels(matches, match_labels, gt_boxes, gt_classes, box_offsets, centers, image_hw, num_classes, objectness=None):
+    """matches/match_labels (N,X) from anchor_match -> cls labels (N,X) int32, refine box labels (N,X,4); zeroes objectness off-image."""
+    N, X = matches.shape
+    cls = torch.empty((N, X), dtype=torch.int32, device=matches.device)
+    rbox = torch.empty((N, X, 4), dtype=torch.float32, device=matches.device)
+    call("sod_reppoints_labels", ptr(matches), ptr(match_labels), ptr(gt_boxes), ptr(gt_classes), ptr(box_offsets), ptr(centers), ptr(image_hw),
+         N, X, num_classes, ptr(cls), ptr(rbox), ptr(objectness), stream_ptr())
+    return cls, rbox
+
+
+def reppoints_box_loss_fwd(pred, target, labels, strides, bg_label, beta):
+    N, X = labels.shape
+    sums = torch.empty(2, dtype=torch.float32, device=pred.device)
+    call("sod_reppoints_box_loss_fwd", ptr(pred), ptr(target), ptr(labels), ptr(strides), N, X, int(bg_label), float(beta), ptr(sums),
+         ptr(reduce_ws(pred.device)), stream_ptr())
+    return sums
+
+
+def reppoints_box_loss_bwd(pred, target, labels, strides, bg_label, beta, grad_num, grad_den, den_min, mul):
+    N, X = labels.shape
+    d = torch.empty_like(pred)
+    call("sod_reppoints_box_loss_bwd", ptr(pred), ptr(target), ptr(labels), ptr(strides), N, X, int(bg_label), float(beta), ptr(grad_num),
+         ptr(grad_den), float(den_min), float(mul), ptr(d), stream_ptr())
+    return d
+
+
+def reppoints_finalize(focal_sum, init_sums, refine_sums, normalizer, momentum, num_images, init_weight):
+    out = torch.empty(3, dtype=torch.float32, device=focal_sum.device)
+    call("sod_reppoints_finalize", ptr(focal_sum), ptr(init_sums), ptr(refine_sums), ptr(normalizer), float(momentum), int(num_images),
+         float(init_weight), ptr(out), stream_ptr())
+    return out

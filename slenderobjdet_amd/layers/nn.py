@@ -260,6 +260,80 @@ class _ConvReluMLFn(torch.autograd.Function):
         return (None, None, *dxs)
 
 
+class ConvML(nn.Module):
+    """A plain Conv2d(bias) shared by all FPN levels, one multi-level launch per pass (RepPoints' 1x1 / 3x3 output convs,
+    rpd.py:156-167).  ``relu``: fused ReLU epilogue; ``out_f32``: fp32 output rows (offsets), whose gradient is converted to
+    bf16 for the MFMA kernels; ``out_channels`` is padded by the caller to a multiple of 8."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, padding=0, relu=False, out_f32=False):
+        super().__init__()
+        self.conv = HipConv2d(in_channels, out_channels, kernel_size, 1, padding, bias=True)
+        self.relu, self.out_f32 = relu, out_f32
+
+    def forward(self, xs):
+        self.conv.prepare()
+        return list(_ConvMLFn.apply(self.conv.weight, self, *xs))
+
+
+class _ConvMLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, unit, *xs):
+        conv = unit.conv
+        ys = HF.conv2d_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, 1, conv.padding, 1, relu=unit.relu, out_f32=unit.out_f32)
+        ctx.unit, ctx.nl = unit, len(xs)
+        ctx.save_for_backward(*xs, *(ys if unit.relu else ()))
+        arena = _arena_of(conv)
+        if arena is not None and conv.weight.requires_grad:
+            arena.note_use(conv.weight)
+            arena.note_use(conv.bias)
+        return tuple(ys)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        unit, nl = ctx.unit, ctx.nl
+        conv = unit.conv
+        saved = ctx.saved_tensors
+        xs, ys = saved[:nl], saved[nl:]
+        arena = _arena_of(conv)
+        gs = []
+        for i, dy in enumerate(dys):
+            dy = dy.contiguous()
+            if dy.dtype == torch.float32:
+                dy = HF.f32_to_bf16(dy)
+            gs.append(HF.relu_bwd(dy, ys[i]) if unit.relu else dy)
+        k = conv.kernel_size
+        HF.conv2d_wgrad_ml(gs, list(xs), arena.grad_view(conv.weight), k, k, 1, conv.padding, 1)
+        arena.mark_ready(conv.weight)
+        dbias = arena.grad_view(conv.bias)
+        for g in gs:
+            N, H, W, C = g.shape
+            HF.bias_grad(g, dbias, N, H * W, C)
+        arena.mark_ready(conv.bias)
+        dxs = [None] * nl
+        if any(ctx.needs_input_grad[2:]):
+            dxs = HF.conv2d_dgrad_ml(gs, conv.wt_bf16, [(x.shape[1], x.shape[2]) for x in xs], 1, conv.padding, 1)
+        return (None, None, *dxs)
+
+
+class _AddUp2Fn(torch.autograd.Function):
+    """a + nearest-2x-upsample(b) (d2 FPN top-down sum) as its own node for FPN.NORM != ""."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return HF.add_up2(a, b)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return (dy if ctx.needs_input_grad[0] else None), (HF.upsample2x_bwd(dy) if ctx.needs_input_grad[1] else None)
+
+
+def add_up2(a, b):
+    return _AddUp2Fn.apply(a, b)
+
+
 class _GnReluFn(torch.autograd.Function):
     """Stand-alone GroupNorm(+ReLU) (after a deformable tower conv, fcosv2.py:300-336 with USE_DCN_IN_TOWER)."""
 

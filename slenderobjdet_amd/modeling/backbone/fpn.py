@@ -8,7 +8,7 @@ import math
 
 from torch import nn
 
-from ...layers.nn import HipConv2d, relu
+from ...layers.nn import HipConv2d, HipGroupNorm, add_up2, group_norm_relu, relu
 from ..shape_spec import ShapeSpec
 from .build import BACKBONE_REGISTRY, Backbone
 from .resnet import build_resnet_backbone
@@ -33,8 +33,9 @@ class LastLevelP6P7(nn.Module):
 class FPN(Backbone):
     def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
         super().__init__()
-        if norm != "":
-            raise NotImplementedError("FPN.NORM != '' (GN laterals) is not wired yet")
+        if norm not in ("", "GN"):
+            raise NotImplementedError(f"FPN.NORM {norm!r}: only '' and 'GN' (configs/rep-points/*.yaml) are built")
+        self.norm = norm
         if fuse_type != "sum":
             raise NotImplementedError("FPN.FUSE_TYPE avg is not built")
         input_shapes = bottom_up.output_shape()
@@ -44,13 +45,17 @@ class FPN(Backbone):
             assert s == 2 * strides[i - 1], f"Strides {s} {strides[i - 1]} are not log2 contiguous"
         lateral, output = [], []
         for idx, ch in enumerate(in_channels):
-            lat = HipConv2d(ch, out_channels, 1, 1, 0)
-            out = HipConv2d(out_channels, out_channels, 3, 1, 1)
+            use_bias = norm == ""          # d2 FPN: the convs lose their bias when a norm follows
+            lat = HipConv2d(ch, out_channels, 1, 1, 0, bias=use_bias)
+            out = HipConv2d(out_channels, out_channels, 3, 1, 1, bias=use_bias)
             lat.init_xavier()
             out.init_xavier()
             stage = int(math.log2(strides[idx]))
             self.add_module(f"fpn_lateral{stage}", lat)
             self.add_module(f"fpn_output{stage}", out)
+            if norm == "GN":               # get_norm("GN", C) = GroupNorm(32, C), applied as Conv2d(..., norm=...) does
+                lat.norm = HipGroupNorm(32, out_channels)
+                out.norm = HipGroupNorm(32, out_channels)
             lateral.append(lat)
             output.append(out)
         self.lateral_convs = lateral[::-1]      # top (coarsest) first
@@ -75,11 +80,18 @@ class FPN(Backbone):
         feats = self.bottom_up(x)
         xs = [feats[f] for f in self.in_features[::-1]]
         results = []
-        prev = self.lateral_convs[0](xs[0])
-        results.append(self.output_convs[0](prev))
-        for feat, lat, out in zip(xs[1:], self.lateral_convs[1:], self.output_convs[1:]):
-            prev = lat(feat, res=prev, res_up2=True)
-            results.insert(0, out(prev))
+        if self.norm == "":
+            prev = self.lateral_convs[0](xs[0])
+            results.append(self.output_convs[0](prev))
+            for feat, lat, out in zip(xs[1:], self.lateral_convs[1:], self.output_convs[1:]):
+                prev = lat(feat, res=prev, res_up2=True)
+                results.insert(0, out(prev))
+        else:
+            prev = group_norm_relu(self.lateral_convs[0](xs[0]), self.lateral_convs[0].norm, relu=False)
+            results.append(group_norm_relu(self.output_convs[0](prev), self.output_convs[0].norm, relu=False))
+            for feat, lat, out in zip(xs[1:], self.lateral_convs[1:], self.output_convs[1:]):
+                prev = add_up2(group_norm_relu(lat(feat), lat.norm, relu=False), prev)
+                results.insert(0, group_norm_relu(out(prev), out.norm, relu=False))
         if self.top_block is not None:
             src = feats.get(self.top_block.in_feature)
             if src is None:

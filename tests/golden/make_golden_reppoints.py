@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""Golden vectors for the RepPoints path, produced by the REFERENCE's own Python (read-only /root/reference) in the build
+container.  Only inputs/outputs (numpy arrays) are written; no reference source is copied.
+
+  * reppoints_matchers.npz — slender_det/modeling/matchers/rep_matcher.py (rep_points_match, nearest_point_match, inside_match)
+    with slender_det/structures/points.py: PURE reference Python (only ``Boxes`` is a 10-line container stub).
+  * reppoints_losses.npz — RepPointsDetector.points2bbox / get_ground_truth / losses (rpd.py:221-402) called unbound on a
+    SimpleNamespace ``self``: reference Python x restated third-party ops (detectron2 pairwise_iou / Matcher, fvcore focal /
+    smooth-L1 are absent everywhere; their restatements below follow SURVEY.md Appendix C.1-C.5).
+
+    python tests/golden/make_golden_reppoints.py
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub(name, **attrs):
+    m = sys.modules.get(name) or types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, rel, package=None):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    if package:
+        mod.__package__ = package
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class Boxes:
+    def __init__(self, t):
+        self.tensor = t
+
+    def get_centers(self):
+        return (self.tensor[:, :2] + self.tensor[:, 2:]) / 2
+
+    def area(self):
+        b = self.tensor
+        return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+    def __getitem__(self, i):
+        return Boxes(self.tensor[i].view(-1, 4))
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+
+def pairwise_iou(b1, b2):
+    """detectron2.structures.pairwise_iou restated."""
+    a1, a2 = b1.area(), b2.area()
+    t1, t2 = b1.tensor, b2.tensor
+    wh = (torch.min(t1[:, None, 2:], t2[:, 2:]) - torch.max(t1[:, None, :2], t2[:, :2])).clamp(min=0)
+    inter = wh.prod(dim=2)
+    return torch.where(inter > 0, inter / (a1[:, None] + a2 - inter), torch.zeros(1, dtype=inter.dtype))
+
+
+class Matcher:
+    """detectron2.modeling.matcher.Matcher restated."""
+
+    def __init__(self, thresholds, labels, allow_low_quality_matches=False):
+        self.thresholds = [-float("inf")] + list(thresholds) + [float("inf")]
+        self.labels, self.allow = labels, allow_low_quality_matches
+
+    def __call__(self, q):
+        vals, matches = q.max(dim=0)
+        lab = matches.new_full(matches.size(), 1, dtype=torch.int8)
+        for l, lo, hi in zip(self.labels, self.thresholds[:-1], self.thresholds[1:]):
+            lab[(vals >= lo) & (vals < hi)] = l
+        if self.allow:
+            best, _ = q.max(dim=1)
+            lab[(q == best[:, None]).nonzero()[:, 1]] = 1
+        return matches, lab
+
+
+def focal_restated(inputs, targets, alpha=-1, gamma=2, reduction="none"):
+    p = torch.sigmoid(inputs)
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = p * targets + (1 - p) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss.sum() if reduction == "sum" else loss
+
+
+def smooth_l1_restated(inp, target, beta, reduction="none"):
+    n = torch.abs(inp - target)
+    loss = torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta) if beta >= 1e-5 else n
+    return loss.sum() if reduction == "sum" else loss
+
+
+class _Reg:
+    def register(self, obj=None):
+        return (lambda f: f) if obj is None else obj
+
+
+class _Storage:
+    def put_scalar(self, *a, **k):
+        pass
+
+
+def install():
+    _stub("cv2")
+    _stub("concern")
+    _stub("concern.webcv2")
+    _stub("concern.support", make_dual=lambda s: (s, s) if isinstance(s, int) else tuple(s))
+    _stub("fvcore")
+    _stub("fvcore.nn", sigmoid_focal_loss_jit=focal_restated, smooth_l1_loss=smooth_l1_restated)
+    _stub("detectron2")
+    _stub("detectron2.utils")
+    _stub("detectron2.utils.memory", retry_if_cuda_oom=lambda f: f)
+    _stub("detectron2.utils.events", get_event_storage=lambda: _Storage())
+    _stub("detectron2.structures", Boxes=Boxes, ImageList=None, Instances=None, pairwise_iou=pairwise_iou)
+    _stub("detectron2.layers", DeformConv=None, cat=torch.cat, batched_nms=None)
+    _stub("detectron2.modeling")
+    _stub("detectron2.modeling.meta_arch", META_ARCH_REGISTRY=_Reg(), RetinaNet=None)
+    _stub("detectron2.modeling.meta_arch.retinanet", permute_to_N_HWA_K=None)
+    _stub("detectron2.modeling.backbone", build_backbone=None)
+    _stub("detectron2.modeling.matcher", Matcher=Matcher)
+    _stub("detectron2.modeling.postprocessing", detector_postprocess=None)
+    # package chain for rep_matcher's ``from ...structures.points import`` relative import
+    _stub("refsd")
+    _stub("refsd.structures")
+    _stub("refsd.modeling")
+    _stub("refsd.modeling.matchers")
+    _load("refsd.structures.points", "slender_det/structures/points.py", "refsd.structures")
+    rm = _load("refsd.modeling.matchers.rep_matcher", "slender_det/modeling/matchers/rep_matcher.py", "refsd.modeling.matchers")
+    _stub("slender_det")
+    _stub("slender_det.modeling")
+    _load("slender_det.modeling.grid_generator", "slender_det/modeling/grid_generator.py")
+    rpd = _load("ref_rpd", "slender_det/modeling/meta_arch/reppoints/rpd.py")
+    return rm, rpd
+
+
+def grid(hw, strides):
+    cs, ss = [], []
+    for (h, w), s in zip(hw, strides):
+        gy, gx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        cs.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), 1) * s)
+        ss.append(torch.full((h * w,), float(s)))
+    return cs, ss
+
+
+def random_boxes(g, n, H, W):
+    cx, cy = torch.rand(n, generator=g) * W, torch.rand(n, generator=g) * H
+    w = torch.exp2(torch.rand(n, generator=g) * 5.0 + 3.0)
+    h = torch.exp2(torch.rand(n, generator=g) * 5.0 + 3.0)
+    b = torch.stack((cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2), 1)
+    b[:, 0::2] = b[:, 0::2].clamp(0, W)
+    b[:, 1::2] = b[:, 1::2].clamp(0, H)
+    keep = ((b[:, 2] - b[:, 0]) > 2) & ((b[:, 3] - b[:, 1]) > 2)
+    return b[keep]
+
+
+def main():
+    assert os.path.isdir(REF), "runs only in the build container (needs /root/reference)"
+    rm, rpd = install()
+    g = torch.Generator().manual_seed(20240)
+    meta = {}
+    hw = [(32, 40), (16, 20), (8, 10), (4, 5), (2, 3)]
+    strides = [8, 16, 32, 64, 128]
+    cs, ss = grid(hw, strides)
+    centers, st = torch.cat(cs), torch.cat(ss)
+
+    # ------------------------------------------------------------------ matchers: pure reference
+    out = {"hw": np.array(hw), "strides": np.array(strides)}
+    cases = [random_boxes(g, n, 256, 320) for n in (1, 3, 7, 15, 30)]
+    cases.append(torch.tensor([[100.0, 100.0, 103.0, 104.0]]))            # tiny box: nothing "inside" -> nearest fallback
+    cases.append(torch.tensor([[10.0, 10.0, 74.0, 74.0], [12.0, 12.0, 76.0, 76.0], [40.0, 40.0, 45.0, 300.0]]))   # competing + slender
+    out["num_cases"] = np.array(len(cases))
+    for i, b in enumerate(cases):
+        out[f"boxes{i}"] = b.numpy()
+        for name, fn in (("points", rm.rep_points_match), ("nearest_points", rm.nearest_point_match), ("inside", rm.inside_match)):
+            o, l = fn(centers, st, Boxes(b))
+            out[f"{name}_obj{i}"] = o.numpy().astype(np.int8)
+            out[f"{name}_box{i}"] = l.numpy()
+    np.savez_compressed(os.path.join(OUT, "reppoints_matchers.npz"), **out)
+    meta["reppoints_matchers.npz"] = "reference: matchers/rep_matcher.py:9-101,199-248 + structures/points.py:6-45 (pure reference Python)"
+
+    # ------------------------------------------------------------------ points2bbox / get_ground_truth / losses
+    R = rpd.RepPointsDetector
+    N, K = 2, 80
+    X = centers.shape[0]
+    self = SimpleNamespace(transform_method="minmax", num_classes=K, matcher=rm.rep_points_match,
+                           bbox_matcher=Matcher([0.4, 0.5], [0, -1, 1], allow_low_quality_matches=True),
+                           loss_normalizer=20, loss_normalizer_momentum=0.9, focal_loss_alpha=0.25, focal_loss_gamma=2.0)
+    oi = [torch.randn(N, 18, h, w, generator=g) * 1.5 for h, w in hw]
+    orf = [o + torch.randn(o.shape, generator=g) * 0.5 for o in oi]
+    pc = [c.clone() for c in cs]
+    init_boxes = rpd.flat_and_concate_levels(R.points2bbox(self, pc, oi, [1, 2, 4, 8, 16]))
+    refine_boxes = rpd.flat_and_concate_levels(R.points2bbox(self, pc, orf, [1, 2, 4, 8, 16]))
+    gtb = [random_boxes(g, 6, 250, 300), random_boxes(g, 11, 256, 320)]
+    gtc = [torch.randint(0, K, (len(b),), generator=g) for b in gtb]
+    sizes = [(250, 300), (256, 320)]
+    inst = [SimpleNamespace(image_size=s, gt_boxes=Boxes(b), gt_classes=c) for s, b, c in zip(sizes, gtb, gtc)]
+    res = {"hw": np.array(hw), "strides": np.array(strides), "image_sizes": np.array(sizes),
+           "init_boxes": init_boxes.numpy(), "refine_boxes": refine_boxes.numpy()}
+    for l in range(len(hw)):
+        res[f"oi{l}"], res[f"or{l}"] = oi[l].numpy(), orf[l].numpy()
+    for i in range(N):
+        res[f"gt_boxes{i}"], res[f"gt_classes{i}"] = gtb[i].numpy(), gtc[i].numpy()
+    logits = torch.randn(N, X, K, generator=g) * 2 - 3
+    res["logits"] = logits.numpy().astype(np.float16)         # inputs are the fp16-rounded values (kept small on disk)
+    logits = torch.from_numpy(res["logits"]).float()
+    for mode, fn in (("points", rm.rep_points_match), ("nearest_points", rm.nearest_point_match), ("inside", rm.inside_match)):
+        self.matcher = fn
+        self.loss_normalizer = 20
+        tg = R.get_ground_truth.__wrapped__(self, centers, st, init_boxes, inst) if hasattr(R.get_ground_truth, "__wrapped__") \
+            else R.get_ground_truth(self, centers, st, init_boxes, inst)
+        obj, ib, cl, rb = tg
+        res[f"{mode}_obj"], res[f"{mode}_init"] = obj.numpy().astype(np.int8), ib.numpy()
+        res[f"{mode}_cls"], res[f"{mode}_refine"] = cl.numpy().astype(np.int16), rb.numpy()
+        lg = logits.clone().requires_grad_(True)
+        b1 = init_boxes.clone().requires_grad_(True)
+        b2 = refine_boxes.clone().requires_grad_(True)
+        d = R.losses(self, lg, b1, b2, obj, ib, cl, rb, st)
+        tot = d["loss_cls"] + d["loss_localization_init"] + d["loss_localization_refine"]
+        gl, g1, g2 = torch.autograd.grad(tot, (lg, b1, b2))
+        res[f"{mode}_losses"] = np.array([float(d[k]) for k in ("loss_cls", "loss_localization_init", "loss_localization_refine")])
+        res[f"{mode}_normalizer"] = np.array(float(self.loss_normalizer))
+        res[f"{mode}_grad_init"], res[f"{mode}_grad_refine"] = g1.numpy(), g2.numpy()
+        res[f"{mode}_grad_logits_sum"] = gl.sum(-1).numpy()
+    np.savez_compressed(os.path.join(OUT, "reppoints_losses.npz"), **res)
+    meta["reppoints_losses.npz"] = ("reference Python (rpd.py:221-402, rep_matcher.py) x restated third-party ops "
+                                    "(pairwise_iou, Matcher, sigmoid_focal_loss_jit, smooth_l1_loss)")
+    mp = os.path.join(OUT, "meta.json")
+    old = json.load(open(mp)) if os.path.exists(mp) else {}
+    old.update(meta)
+    json.dump(old, open(mp, "w"), indent=1, sort_keys=True)
+    for k in meta:
+        print(k, os.path.getsize(os.path.join(OUT, k)))
+
+
+if __name__ == "__main__":
+    main()

@@ -86,6 +86,37 @@ def test_registry_and_build_model_cpu():
         m(synthetic_batch(1, 64, 64, 0))
 
 
+def test_reppoints_and_retinanet_build_from_repo_configs_cpu():
+    """BASELINE configs[2] / configs[3]: the repo's YAMLs resolve through the registries; RepPoints gets the GN-FPN over res2..res5."""
+    from slenderobjdet_amd.modeling import META_ARCH_REGISTRY, build_model
+
+    root = os.path.join(os.path.dirname(__file__), "..", "configs")
+    for name in ("RetinaNet", "RepPointsDetector"):
+        assert name in META_ARCH_REGISTRY
+    cfg = fresh_cfg()
+    cfg.merge_from_file(os.path.join(root, "rep-points", "rep_points_detector_R_50_FPN_1x.yaml"))
+    cfg.MODEL.DEVICE = "cpu"
+    m = build_model(cfg)
+    shapes = m.backbone.output_shape()
+    assert list(shapes) == ["p2", "p3", "p4", "p5", "p6", "p7"] and m.strides == [8, 16, 32, 64, 128]
+    assert m.backbone.fpn_lateral2.bias is None and m.backbone.fpn_lateral2.norm.num_groups == 32     # d2 FPN with NORM "GN"
+    assert m.backbone.top_block.in_feature == "res5" and m.backbone.top_block.p6.in_channels == 2048
+    assert m.sample_mode == "points" and m.deform_cls_conv.bias is None
+    # head parameters of the reference (rpd.py:143-167), pitch padding excluded
+    C = 256
+    ref = 2 * 3 * (C * C * 9 + C + 2 * C) + 2 * C * C * 9 + (C * C * 9 + C) + (C * 18 + 18) + (C * 18 + 18) + (C * 80 + 80)
+    head = [m.cls_conv, m.reg_conv, m.deform_cls_conv, m.deform_reg_conv, m.offsets_init, m.offsets_refine, m.logits]
+    pad = 2 * 6 * (C + 1)
+    assert sum(p.numel() for h in head for p in h.parameters()) - pad == ref
+    cfg2 = fresh_cfg()
+    cfg2.merge_from_file(os.path.join(root, "retina", "retinanet_R_50_FPN_1x.yaml"))
+    cfg2.MODEL.DEVICE = "cpu"
+    assert build_model(cfg2).head.num_anchors == 9
+    cfg.MODEL.PROPOSAL_GENERATOR.SAMPLE_MODE = "bogus"
+    with pytest.raises(AssertionError):
+        build_model(cfg)
+
+
 def test_optimizer_param_groups_follow_reference_rules():
     from slenderobjdet_amd.layers.nn import ConvGnRelu
     from slenderobjdet_amd.solver import get_default_optimizer_params
