@@ -67,6 +67,21 @@ WORKLOADS = {
 }
 
 
+def damp_residual_branches(model, gamma=0.25):
+    """Random-init ResNet-50 with identity FrozenBN doubles the activation variance in every residual block (x256 in std over 16
+    blocks); the reference never sees that because it starts from an ImageNet checkpoint.  FCOS / RepPoints survive it (GroupNorm
+    in the head / FPN), RetinaNet's un-normalised head overflows (loss_cls 7.5e6 at step 0, NaN at step 1).  With no checkpoint
+    available, the RetinaNet benchmark sets the last FrozenBN weight of every block to ``gamma`` — the same kernels and FLOPs, sane
+    numerics."""
+    n = 0
+    with torch.no_grad():
+        for name, m in model.named_modules():
+            if name.endswith(".conv3") and getattr(m, "frozen_bn", False):
+                m.bn_weight.fill_(gamma)
+                n += 1
+    return n
+
+
 def train_step(model, optimizer, data):
     losses = model(data)
     total = sum(losses.values())
@@ -158,6 +173,8 @@ def main():
     torch.manual_seed(1 + rank)   # engine/defaults.py:66: SEED + rank
     model = build_model(cfg)
     model.train()
+    if args.arch == "retinanet" and args.depth >= 50:
+        damp_residual_branches(model)
     if world > 1:   # DDP semantics: identical initial parameters on every rank
         dist.broadcast(model.arena.params, src=0)
         model.arena.bump()

@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from bench import make_cfg  # noqa: E402
+from bench import damp_residual_branches, make_cfg  # noqa: E402
 
 
 def main():
@@ -26,6 +26,8 @@ def main():
     torch.manual_seed(1)
     model = build_model(cfg)
     model.train()
+    if a.arch == "retinanet" and a.depth >= 50:
+        damp_residual_branches(model)
     opt = build_optimizer(cfg, model)
     loader = SyntheticCocoBatches(a.batch, 800, 1333, rank=0, device=torch.device("cuda", 0), pool=2)
     for it in range(a.steps):
