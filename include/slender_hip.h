@@ -228,6 +228,40 @@ int sod_retina_box_loss_bwd(const float* pred, int pitch, const int* gt_labels, 
                             int num_classes, float beta, const float* grad_num, const float* grad_den, void* dpred_bf16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Two-stage path — detectron2 GeneralizedRCNN + RPN/RRPN + StandardROIHeads/RROIHeads as configured by the reference's
+ * configs/rotated/Base-RRCNN-FPN.yaml (BASELINE config 5) and subclassed by proposal_generator/rpn.py:26-356,
+ * meta_arch/rcnn/pvrcnn.py:67-97, roi_heads/roi_heads.py:48-53.  box_dim 4 = XYXY, 5 = (cx, cy, w, h, angle_deg).
+ * sod_anchor_match_rotated: sod_anchor_match with pairwise_iou_rotated (RRPN.label_and_sample_anchors, RROIHeads sampling).
+ * sod_box2box_get_deltas / apply_deltas: Box2BoxTransform / Box2BoxTransformRotated (weights host array of box_dim floats);
+ *   apply: deltas rows of pitch ld hold k class-specific box_dim-vectors, boxes (n, box_dim), out (n, k*box_dim).
+ * sod_bce_logits_loss_*: F.binary_cross_entropy_with_logits(x[l>=0], l[l>=0], "sum"), labels int8 in {-1,0,1} (loss_rpn_cls).
+ * sod_rpn_loc_loss_*: smooth_l1_loss(pred[l==1], target[l==1], beta, "sum") (loss_rpn_loc).
+ * sod_softmax_ce_*: F.cross_entropy(scores, labels, "sum") over rows of pitch ld (labels < 0 ignored); bwd fills the whole pitch.
+ * sod_fastrcnn_box_loss_*: FastRCNNOutputs.smooth_l1_loss — foreground rows (0 <= class < K) use the box_dim columns of their class.
+ * All bwd entry points scale by grad_scale[0] (device) * scale_mul (host: 1/normaliser).
+ * --------------------------------------------------------------------------------------------------------- */
+int sod_anchor_match_rotated(const float* gt_boxes, int G, const float* anchors, int A, float thr_lo, float thr_hi,
+                             int label_below, int label_between, int label_above, int allow_low_quality,
+                             float* matched_vals, int* matches, signed char* labels, unsigned* gt_best_ws, void* stream);
+int sod_box2box_get_deltas(const float* src, const float* tgt, long long n, int box_dim, const float* weights, float* deltas, void* stream);
+int sod_box2box_apply_deltas(const float* deltas, const float* boxes, long long n, int k, int box_dim, int ld, const float* weights,
+                             float scale_clamp, float* out, void* stream);
+int sod_bce_logits_loss_fwd(const float* logits, const signed char* labels, long long n, float* sum_out, float* ws, void* stream);
+int sod_bce_logits_loss_bwd(const float* logits, const signed char* labels, long long n, const float* grad_scale, float scale_mul,
+                            float* dlogits, void* stream);
+int sod_rpn_loc_loss_fwd(const float* pred, const float* target, const signed char* labels, long long n, int box_dim, float beta,
+                         float* sum_out, float* ws, void* stream);
+int sod_rpn_loc_loss_bwd(const float* pred, const float* target, const signed char* labels, long long n, int box_dim, float beta,
+                         const float* grad_scale, float scale_mul, float* dpred, void* stream);
+int sod_softmax_ce_fwd(const float* scores, const int* labels, int R, int C, int ld, float* sum_out, float* ws, void* stream);
+int sod_softmax_ce_bwd(const float* scores, const int* labels, int R, int C, int ld, const float* grad_scale, float scale_mul,
+                       float* dscores, void* stream);
+int sod_fastrcnn_box_loss_fwd(const float* pred, const int* gt_classes, const float* gt_deltas, int R, int K, int box_dim, int ld,
+                              float beta, float* sum_out, float* ws, void* stream);
+int sod_fastrcnn_box_loss_bwd(const float* pred, const int* gt_classes, const float* gt_deltas, int R, int K, int box_dim, int ld,
+                              float beta, const float* grad_scale, float scale_mul, float* dpred, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * RepPointsDetector (slender_det/modeling/meta_arch/reppoints/rpd.py:45-798), X = sum of level pixels, point rows pitched by ld.
  * sod_reppoints_dcn_offset: out[r,2k] = scale*pts[r,2k+1] - base_y[k], out[r,2k+1] = scale*pts[r,2k] - base_x[k] (xy->yx flip and
  *   dcn_base_offset of rpd.py:105-110,621-635; subtract_base=0, scale=gradient_mul gives the backward of the same expression).

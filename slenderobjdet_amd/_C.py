@@ -68,6 +68,17 @@ _SIGS = {
     "sod_border_align_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "sod_corner_pool_fwd": [_P, _P, _L, _I, _I, _I, _P],
     "sod_corner_pool_bwd": [_P, _P, _P, _L, _I, _I, _I, _I, _P],
+    "sod_anchor_match_rotated": [_P, _I, _P, _I, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "sod_box2box_get_deltas": [_P, _P, _L, _I, _P, _P, _P],
+    "sod_box2box_apply_deltas": [_P, _P, _L, _I, _I, _I, _P, _F, _P, _P],
+    "sod_bce_logits_loss_fwd": [_P, _P, _L, _P, _P, _P],
+    "sod_bce_logits_loss_bwd": [_P, _P, _L, _P, _F, _P, _P],
+    "sod_rpn_loc_loss_fwd": [_P, _P, _P, _L, _I, _F, _P, _P, _P],
+    "sod_rpn_loc_loss_bwd": [_P, _P, _P, _L, _I, _F, _P, _F, _P, _P],
+    "sod_softmax_ce_fwd": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "sod_softmax_ce_bwd": [_P, _P, _I, _I, _I, _P, _F, _P, _P],
+    "sod_fastrcnn_box_loss_fwd": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
+    "sod_fastrcnn_box_loss_bwd": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _F, _P, _P],
     "sod_reppoints_dcn_offset": [_P, _P, _L, _I, _I, _F, _I, _P],
     "sod_points2bbox_fwd": [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _L, _P, _L, _P],
     "sod_points2bbox_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _F, _I, _P, _P, _P],

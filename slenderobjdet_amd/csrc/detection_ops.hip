@@ -344,6 +344,14 @@ __device__ __forceinline__ float pair_iou(const float* g, const float* a) {
   return inter > 0.f ? inter / (ag + aa - inter) : 0.f;
 }
 
+// D = 4: XYXY boxes (pairwise_iou); D = 5: (cx, cy, w, h, angle) boxes (pairwise_iou_rotated, RRPN / RROIHeads)
+template <int D>
+__device__ __forceinline__ float match_iou(const float* g, const float* a) {
+  if (D == 4) return pair_iou(g, a);
+  return fmaxf(iou_rotated(g, a), 0.f);
+}
+
+template <int D>
 __global__ __launch_bounds__(256) void anchor_match1_kernel(const float* __restrict__ gts, int G, const float* __restrict__ anchors, int A,
                                                             float* __restrict__ best_val, int* __restrict__ best_idx,
                                                             unsigned* __restrict__ gt_best_bits) {
@@ -351,11 +359,12 @@ __global__ __launch_bounds__(256) void anchor_match1_kernel(const float* __restr
   for (int g = threadIdx.x; g < G; g += 256) lbest[g] = 0u;
   __syncthreads();
   for (int i = blockIdx.x * 256 + threadIdx.x; i < A; i += gridDim.x * 256) {
-    const f32x4_t av = *reinterpret_cast<const f32x4_t*>(anchors + (long long)i * 4);
-    const float a[4] = {av[0], av[1], av[2], av[3]};
+    float a[D];
+#pragma unroll
+    for (int e = 0; e < D; ++e) a[e] = anchors[(long long)i * D + e];
     float bv = -1.f; int bi = 0;
     for (int g = 0; g < G; ++g) {
-      const float v = pair_iou(gts + g * 4, a);
+      const float v = match_iou<D>(gts + g * D, a);
       if (v > bv) { bv = v; bi = g; }            // first maximum wins (torch.max(dim=0))
       atomicMax(&lbest[g], __float_as_uint(v));  // v >= 0: uint order == float order
     }
@@ -365,6 +374,7 @@ __global__ __launch_bounds__(256) void anchor_match1_kernel(const float* __restr
   for (int g = threadIdx.x; g < G; g += 256) atomicMax(&gt_best_bits[g], lbest[g]);
 }
 
+template <int D>
 __global__ __launch_bounds__(256) void anchor_match2_kernel(const float* __restrict__ gts, int G, const float* __restrict__ anchors, int A,
                                                             const float* __restrict__ best_val, const unsigned* __restrict__ gt_best_bits,
                                                             float lo, float hi, int l0, int l1, int l2, int low_quality,
@@ -373,10 +383,11 @@ __global__ __launch_bounds__(256) void anchor_match2_kernel(const float* __restr
     const float v = best_val[i];
     int lab = (v < lo) ? l0 : ((v < hi) ? l1 : l2);
     if (low_quality) {
-      const f32x4_t av = *reinterpret_cast<const f32x4_t*>(anchors + (long long)i * 4);
-      const float a[4] = {av[0], av[1], av[2], av[3]};
+      float a[D];
+#pragma unroll
+      for (int e = 0; e < D; ++e) a[e] = anchors[(long long)i * D + e];
       for (int g = 0; g < G; ++g)
-        if (pair_iou(gts + g * 4, a) == __uint_as_float(gt_best_bits[g])) { lab = 1; break; }
+        if (match_iou<D>(gts + g * D, a) == __uint_as_float(gt_best_bits[g])) { lab = 1; break; }
     }
     labels[i] = (signed char)lab;
   }
@@ -571,9 +582,10 @@ extern "C" int sod_smooth_l1_loss(const float* input, const float* target, long 
   return SOD_OK;
 }
 
-extern "C" int sod_anchor_match(const float* gt_boxes, int G, const float* anchors, int A, float thr_lo, float thr_hi,
-                                int label_below, int label_between, int label_above, int allow_low_quality,
-                                float* matched_vals, int* matches, signed char* labels, unsigned* gt_best_ws, void* stream) {
+template <int D>
+static int anchor_match_impl(const float* gt_boxes, int G, const float* anchors, int A, float thr_lo, float thr_hi,
+                             int label_below, int label_between, int label_above, int allow_low_quality,
+                             float* matched_vals, int* matches, signed char* labels, unsigned* gt_best_ws, void* stream) {
   if (!anchors || A <= 0 || !matched_vals || !matches || !labels || G < 0 || G > 4096) return SOD_EARG;
   hipStream_t st = (hipStream_t)stream;
   if (G == 0) {   // Matcher on an empty gt set: everything unmatched with the lowest label
@@ -586,11 +598,25 @@ extern "C" int sod_anchor_match(const float* gt_boxes, int G, const float* ancho
   hipError_t e = hipMemsetAsync(gt_best_ws, 0, sizeof(unsigned) * G, st);
   if (e != hipSuccess) return (int)e;
   const int g = nblk(A, 2048);
-  SOD_LAUNCH(anchor_match1_kernel, dim3(g), dim3(256), sizeof(unsigned) * G, st, gt_boxes, G, anchors, A, matched_vals, matches, gt_best_ws);
-  SOD_LAUNCH(anchor_match2_kernel, dim3(g), dim3(256), 0, st, gt_boxes, G, anchors, A, matched_vals, gt_best_ws, thr_lo, thr_hi,
+  SOD_LAUNCH(anchor_match1_kernel<D>, dim3(g), dim3(256), sizeof(unsigned) * G, st, gt_boxes, G, anchors, A, matched_vals, matches, gt_best_ws);
+  SOD_LAUNCH(anchor_match2_kernel<D>, dim3(g), dim3(256), 0, st, gt_boxes, G, anchors, A, matched_vals, gt_best_ws, thr_lo, thr_hi,
              label_below, label_between, label_above, allow_low_quality, labels);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
+}
+
+extern "C" int sod_anchor_match(const float* gt_boxes, int G, const float* anchors, int A, float thr_lo, float thr_hi,
+                                int label_below, int label_between, int label_above, int allow_low_quality,
+                                float* matched_vals, int* matches, signed char* labels, unsigned* gt_best_ws, void* stream) {
+  return anchor_match_impl<4>(gt_boxes, G, anchors, A, thr_lo, thr_hi, label_below, label_between, label_above, allow_low_quality, matched_vals,
+                              matches, labels, gt_best_ws, stream);
+}
+
+extern "C" int sod_anchor_match_rotated(const float* gt_boxes, int G, const float* anchors, int A, float thr_lo, float thr_hi,
+                                        int label_below, int label_between, int label_above, int allow_low_quality,
+                                        float* matched_vals, int* matches, signed char* labels, unsigned* gt_best_ws, void* stream) {
+  return anchor_match_impl<5>(gt_boxes, G, anchors, A, thr_lo, thr_hi, label_below, label_between, label_above, allow_low_quality, matched_vals,
+                              matches, labels, gt_best_ws, stream);
 }
 
 extern "C" int sod_retina_targets(const float* anchors, int A, const float* gt_boxes, const int* gt_classes, int G, const int* matches,

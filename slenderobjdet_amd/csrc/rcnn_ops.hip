@@ -1,0 +1,317 @@
+// Two-stage (R-CNN) support kernels — detectron2 GeneralizedRCNN / RPN / RRPN / StandardROIHeads / RROIHeads as selected by
+// configs/rotated/Base-RRCNN-FPN.yaml and the reference's proposal_generator/rpn.py:26-356, roi_heads/roi_heads.py:48-53
+// (third-party sources absent: semantics restated in SURVEY.md §2.3 / Appendix C.4-C.6).  HBM/latency-bound fp32 work:
+//   * Box2BoxTransform / Box2BoxTransformRotated get_deltas and apply_deltas (4- and 5-parameter boxes);
+//   * RPN objectness BCE-with-logits and localisation smooth-L1 over labelled anchors (labels -1 ignore / 0 / 1);
+//   * Fast R-CNN softmax cross-entropy and the class-specific box regression loss.
+#include "common.h"
+#include "../../include/slender_hip.h"
+#include <math.h>
+
+namespace {
+
+constexpr int RC_RED = 1024;
+constexpr float RC_PI = 3.14159265358979323846f;
+
+inline int rc_nblk(long long n, int cap = RC_RED) {
+  long long g = (n + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__global__ void rc_finish(const float* __restrict__ part, int nb, int nsum, float* __restrict__ out) {
+  __shared__ float red[4];
+  for (int s = 0; s < nsum; ++s) {
+    float v = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) v += part[s * RC_RED + i];
+    v = block_sum_256(v, red);
+    if (threadIdx.x == 0) out[s] = v;
+    __syncthreads();
+  }
+}
+
+struct W5 { float w[5]; };
+
+// d2 Box2BoxTransform.get_deltas (XYXY) / Box2BoxTransformRotated.get_deltas (cx, cy, w, h, angle in degrees)
+__global__ __launch_bounds__(256) void get_deltas_kernel(const float* __restrict__ src, const float* __restrict__ tgt, long long n, int D, W5 w,
+                                                         float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float* s = src + i * D;
+    const float* t = tgt + i * D;
+    float* o = out + i * D;
+    if (D == 4) {
+      const float sw = s[2] - s[0], sh = s[3] - s[1], scx = s[0] + 0.5f * sw, scy = s[1] + 0.5f * sh;
+      const float tw = t[2] - t[0], th = t[3] - t[1], tcx = t[0] + 0.5f * tw, tcy = t[1] + 0.5f * th;
+      o[0] = w.w[0] * (tcx - scx) / sw; o[1] = w.w[1] * (tcy - scy) / sh;
+      o[2] = w.w[2] * logf(tw / sw); o[3] = w.w[3] * logf(th / sh);
+    } else {
+      o[0] = w.w[0] * (t[0] - s[0]) / s[2]; o[1] = w.w[1] * (t[1] - s[1]) / s[3];
+      o[2] = w.w[2] * logf(t[2] / s[2]); o[3] = w.w[3] * logf(t[3] / s[3]);
+      float da = t[4] - s[4];
+      da = fmodf(da + 180.f, 360.f);
+      if (da < 0.f) da += 360.f;            // python's % (result takes the sign of the divisor)
+      da -= 180.f;
+      o[4] = da * w.w[4] * RC_PI / 180.f;
+    }
+  }
+}
+
+// apply_deltas: deltas (n, k*D), boxes (n, D) -> out (n, k*D)
+__global__ __launch_bounds__(256) void apply_deltas_kernel(const float* __restrict__ deltas, const float* __restrict__ boxes, long long n, int k,
+                                                           int D, int ld, W5 w, float clampv, float* __restrict__ out) {
+  const long long total = n * k;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / k;
+    const int c = (int)(i - r * k);
+    const float* b = boxes + r * D;
+    const float* d = deltas + r * ld + c * D;
+    float* o = out + (r * k + c) * D;
+    if (D == 4) {
+      const float bw = b[2] - b[0], bh = b[3] - b[1], cx = b[0] + 0.5f * bw, cy = b[1] + 0.5f * bh;
+      const float dx = d[0] / w.w[0], dy = d[1] / w.w[1], dw = fminf(d[2] / w.w[2], clampv), dh = fminf(d[3] / w.w[3], clampv);
+      const float pcx = dx * bw + cx, pcy = dy * bh + cy, pw = expf(dw) * bw, ph = expf(dh) * bh;
+      o[0] = pcx - 0.5f * pw; o[1] = pcy - 0.5f * ph; o[2] = pcx + 0.5f * pw; o[3] = pcy + 0.5f * ph;
+    } else {
+      const float dx = d[0] / w.w[0], dy = d[1] / w.w[1], dw = fminf(d[2] / w.w[2], clampv), dh = fminf(d[3] / w.w[3], clampv);
+      const float da = d[4] / w.w[4];
+      o[0] = dx * b[2] + b[0]; o[1] = dy * b[3] + b[1];
+      o[2] = expf(dw) * b[2]; o[3] = expf(dh) * b[3];
+      float a = da * 180.f / RC_PI + b[4];
+      a = fmodf(a + 180.f, 360.f);
+      if (a < 0.f) a += 360.f;
+      o[4] = a - 180.f;
+    }
+  }
+}
+
+// F.binary_cross_entropy_with_logits(logits[valid], labels[valid], reduction="sum") with labels in {-1 (ignored), 0, 1}
+template <bool BWD>
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ x, const signed char* __restrict__ lab, long long n,
+                                                  float* __restrict__ part, const float* __restrict__ gs, float mul, float* __restrict__ dx) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float sc = BWD ? gs[0] * mul : 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int l = lab[i];
+    const float v = x[i];
+    if (!BWD) {
+      if (l >= 0) acc += fmaxf(v, 0.f) - v * (float)l + log1pf(expf(-fabsf(v)));
+    } else {
+      dx[i] = l >= 0 ? (1.f / (1.f + expf(-v)) - (float)l) * sc : 0.f;
+    }
+  }
+  if (!BWD) {
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  }
+}
+
+// smooth_l1_loss(pred[label == 1], target[label == 1], beta, "sum") over D-vectors
+template <bool BWD>
+__global__ __launch_bounds__(256) void loc_kernel(const float* __restrict__ p, const float* __restrict__ t, const signed char* __restrict__ lab,
+                                                  long long n, int D, float beta, float* __restrict__ part, const float* __restrict__ gs, float mul,
+                                                  float* __restrict__ dp) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float sc = BWD ? gs[0] * mul : 0.f;
+  const long long total = n * D;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const bool pos = lab[i / D] == 1;
+    float g = 0.f;
+    if (pos) {
+      const float d = p[i] - t[i], ad = fabsf(d);
+      if (beta < 1e-5f) { acc += ad; g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+      else if (ad < beta) { acc += 0.5f * d * d / beta; g = d / beta; }
+      else { acc += ad - 0.5f * beta; g = d > 0.f ? 1.f : -1.f; }
+    }
+    if (BWD) dp[i] = g * sc;
+  }
+  if (!BWD) {
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  }
+}
+
+// F.cross_entropy(scores, labels, reduction="sum"): one wave per row (C <= 4096), labels < 0 ignored
+template <bool BWD>
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ x, const int* __restrict__ lab, int R, int C, int ld,
+                                                 float* __restrict__ part, const float* __restrict__ gs, float mul, float* __restrict__ dx) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float sc = BWD ? gs[0] * mul : 0.f;
+  for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+    const float* row = x + (long long)r * ld;
+    const int l = lab[r];
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(row[c] - m);
+    s = wave_sum(s);
+    if (!BWD) {
+      if (l >= 0 && lane == 0) acc += logf(s) + m - row[l];
+    } else {
+      float* drow = dx + (long long)r * ld;
+      for (int c = lane; c < ld; c += 64) {
+        float g = 0.f;
+        if (l >= 0 && c < C) g = (expf(row[c] - m) / s - (c == l ? 1.f : 0.f)) * sc;
+        drow[c] = g;
+      }
+    }
+  }
+  if (!BWD) {
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  }
+}
+
+// FastRCNNOutputs.smooth_l1_loss: rows with 0 <= class < K use the D columns of their class
+template <bool BWD>
+__global__ __launch_bounds__(256) void frcnn_box_kernel(const float* __restrict__ pred, const int* __restrict__ cls, const float* __restrict__ tgt,
+                                                        int R, int K, int D, int ld, float beta, float* __restrict__ part,
+                                                        const float* __restrict__ gs, float mul, float* __restrict__ dp) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float sc = BWD ? gs[0] * mul : 0.f;
+  if (BWD) {
+    const long long total = (long long)R * ld;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+      const int r = (int)(i / ld), c = (int)(i - (long long)r * ld);
+      const int k = cls[r];
+      float g = 0.f;
+      if (k >= 0 && k < K && c >= k * D && c < (k + 1) * D) {
+        const float d = pred[i] - tgt[(long long)r * D + (c - k * D)], ad = fabsf(d);
+        if (beta < 1e-5f) g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        else if (ad < beta) g = d / beta;
+        else g = d > 0.f ? 1.f : -1.f;
+      }
+      dp[i] = g * sc;
+    }
+  } else {
+    const long long total = (long long)R * D;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+      const int r = (int)(i / D), j = (int)(i - (long long)r * D);
+      const int k = cls[r];
+      if (k >= 0 && k < K) {
+        const float d = pred[(long long)r * ld + k * D + j] - tgt[i], ad = fabsf(d);
+        if (beta < 1e-5f) acc += ad;
+        else if (ad < beta) acc += 0.5f * d * d / beta;
+        else acc += ad - 0.5f * beta;
+      }
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  }
+}
+
+inline bool fill_w(W5& w, const float* weights, int D) {
+  if (!weights || (D != 4 && D != 5)) return false;
+  for (int i = 0; i < D; ++i) { w.w[i] = weights[i]; if (!(w.w[i] > 0.f)) return false; }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int sod_box2box_get_deltas(const float* src, const float* tgt, long long n, int box_dim, const float* weights, float* deltas,
+                                      void* stream) {
+  W5 w{};
+  if (!src || !tgt || !deltas || n < 0 || !fill_w(w, weights, box_dim)) return SOD_EARG;
+  if (n == 0) return SOD_OK;
+  SOD_LAUNCH(get_deltas_kernel, dim3(rc_nblk(n, 4096)), dim3(256), 0, (hipStream_t)stream, src, tgt, n, box_dim, w, deltas);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_box2box_apply_deltas(const float* deltas, const float* boxes, long long n, int k, int box_dim, int ld, const float* weights,
+                                        float scale_clamp, float* out, void* stream) {
+  W5 w{};
+  if (!deltas || !boxes || !out || n < 0 || k <= 0 || !fill_w(w, weights, box_dim)) return SOD_EARG;
+  if (ld <= 0) ld = k * box_dim;
+  if (ld < k * box_dim) return SOD_EARG;
+  if (n == 0) return SOD_OK;
+  SOD_LAUNCH(apply_deltas_kernel, dim3(rc_nblk(n * k, 4096)), dim3(256), 0, (hipStream_t)stream, deltas, boxes, n, k, box_dim, ld, w, scale_clamp, out);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_bce_logits_loss_fwd(const float* logits, const signed char* labels, long long n, float* sum_out, float* ws, void* stream) {
+  if (!logits || !labels || !sum_out || !ws || n < 0) return SOD_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = rc_nblk(n);
+  SOD_LAUNCH(bce_kernel<false>, dim3(g), dim3(256), 0, st, logits, labels, n, ws, nullptr, 0.f, nullptr);
+  SOD_LAUNCH(rc_finish, dim3(1), dim3(256), 0, st, ws, g, 1, sum_out);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_bce_logits_loss_bwd(const float* logits, const signed char* labels, long long n, const float* grad_scale, float scale_mul,
+                                       float* dlogits, void* stream) {
+  if (!logits || !labels || !grad_scale || !dlogits || n < 0) return SOD_EARG;
+  SOD_LAUNCH(bce_kernel<true>, dim3(rc_nblk(n, 4096)), dim3(256), 0, (hipStream_t)stream, logits, labels, n, nullptr, grad_scale, scale_mul, dlogits);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_rpn_loc_loss_fwd(const float* pred, const float* target, const signed char* labels, long long n, int box_dim, float beta,
+                                    float* sum_out, float* ws, void* stream) {
+  if (!pred || !target || !labels || !sum_out || !ws || n < 0 || box_dim <= 0) return SOD_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = rc_nblk(n * box_dim);
+  SOD_LAUNCH(loc_kernel<false>, dim3(g), dim3(256), 0, st, pred, target, labels, n, box_dim, beta, ws, nullptr, 0.f, nullptr);
+  SOD_LAUNCH(rc_finish, dim3(1), dim3(256), 0, st, ws, g, 1, sum_out);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_rpn_loc_loss_bwd(const float* pred, const float* target, const signed char* labels, long long n, int box_dim, float beta,
+                                    const float* grad_scale, float scale_mul, float* dpred, void* stream) {
+  if (!pred || !target || !labels || !grad_scale || !dpred || n < 0 || box_dim <= 0) return SOD_EARG;
+  SOD_LAUNCH(loc_kernel<true>, dim3(rc_nblk(n * box_dim, 4096)), dim3(256), 0, (hipStream_t)stream, pred, target, labels, n, box_dim, beta, nullptr,
+             grad_scale, scale_mul, dpred);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_softmax_ce_fwd(const float* scores, const int* labels, int R, int C, int ld, float* sum_out, float* ws, void* stream) {
+  if (!scores || !labels || !sum_out || !ws || R < 0 || C <= 0 || ld < C) return SOD_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = rc_nblk((long long)R * 64);
+  SOD_LAUNCH(ce_kernel<false>, dim3(g), dim3(256), 0, st, scores, labels, R, C, ld, ws, nullptr, 0.f, nullptr);
+  SOD_LAUNCH(rc_finish, dim3(1), dim3(256), 0, st, ws, g, 1, sum_out);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_softmax_ce_bwd(const float* scores, const int* labels, int R, int C, int ld, const float* grad_scale, float scale_mul,
+                                  float* dscores, void* stream) {
+  if (!scores || !labels || !grad_scale || !dscores || R < 0 || C <= 0 || ld < C) return SOD_EARG;
+  if (R == 0) return SOD_OK;
+  SOD_LAUNCH(ce_kernel<true>, dim3(rc_nblk((long long)R * 64, 4096)), dim3(256), 0, (hipStream_t)stream, scores, labels, R, C, ld, nullptr, grad_scale,
+             scale_mul, dscores);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_fastrcnn_box_loss_fwd(const float* pred, const int* gt_classes, const float* gt_deltas, int R, int K, int box_dim, int ld,
+                                         float beta, float* sum_out, float* ws, void* stream) {
+  if (!pred || !gt_classes || !gt_deltas || !sum_out || !ws || R < 0 || K <= 0 || box_dim <= 0 || ld < K * box_dim) return SOD_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = rc_nblk((long long)R * box_dim);
+  SOD_LAUNCH(frcnn_box_kernel<false>, dim3(g), dim3(256), 0, st, pred, gt_classes, gt_deltas, R, K, box_dim, ld, beta, ws, nullptr, 0.f, nullptr);
+  SOD_LAUNCH(rc_finish, dim3(1), dim3(256), 0, st, ws, g, 1, sum_out);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_fastrcnn_box_loss_bwd(const float* pred, const int* gt_classes, const float* gt_deltas, int R, int K, int box_dim, int ld,
+                                         float beta, const float* grad_scale, float scale_mul, float* dpred, void* stream) {
+  if (!pred || !gt_classes || !gt_deltas || !grad_scale || !dpred || R < 0 || K <= 0 || box_dim <= 0 || ld < K * box_dim) return SOD_EARG;
+  if (R == 0) return SOD_OK;
+  SOD_LAUNCH(frcnn_box_kernel<true>, dim3(rc_nblk((long long)R * ld, 4096)), dim3(256), 0, (hipStream_t)stream, pred, gt_classes, gt_deltas, R, K,
+             box_dim, ld, beta, nullptr, grad_scale, scale_mul, dpred);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}

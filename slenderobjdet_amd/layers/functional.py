@@ -465,7 +465,7 @@ def anchor_match(gt_boxes, anchors, thresholds, labels, allow_low_quality=True, 
         idx = torch.empty(A, dtype=torch.int32, device=dev)
         lab = torch.empty(A, dtype=torch.int8, device=dev)
     ws = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
-    call("sod_anchor_match", ptr(gt_boxes) if G else None, G, ptr(anchors), A, float(thresholds[0]), float(thresholds[1]), int(labels[0]), int(labels[1]),
+    call("sod_anchor_match_rotated" if anchors.shape[-1] == 5 else "sod_anchor_match", ptr(gt_boxes) if G else None, G, ptr(anchors), A, float(thresholds[0]), float(thresholds[1]), int(labels[0]), int(labels[1]),
          int(labels[2]), 1 if allow_low_quality else 0, ptr(vals), ptr(idx), ptr(lab), ptr(ws), stream_ptr())
     return vals, idx, lab
 
@@ -606,3 +606,89 @@ def reppoints_finalize(focal_sum, init_sums, refine_sums, normalizer, momentum, 
     call("sod_reppoints_finalize", ptr(focal_sum), ptr(init_sums), ptr(refine_sums), ptr(normalizer), float(momentum), int(num_images),
          float(init_weight), ptr(out), stream_ptr())
     return out
+
+
+# ----------------------------------------------------------------------------------------------- two-stage (R-CNN) path
+def box2box_get_deltas(src, tgt, weights):
+    """Box2BoxTransform(.Rotated).get_deltas: src/tgt (n, 4|5) fp32 -> deltas (n, 4|5)."""
+    _chk(src, torch.float32, "src"); _chk(tgt, torch.float32, "tgt")
+    n, D = src.shape
+    out = torch.empty_like(src)
+    w = _float_arr(weights)
+    call("sod_box2box_get_deltas", ptr(src), ptr(tgt), n, D, ctypes.cast(w, ctypes.c_void_p), ptr(out), stream_ptr())
+    return out
+
+
+def box2box_apply_deltas(deltas, boxes, weights, scale_clamp, k=1, ld=0):
+    """deltas rows (pitch ld, k class-specific vectors) applied to boxes (n, 4|5) -> (n, k*D)."""
+    _chk(deltas, torch.float32, "deltas"); _chk(boxes, torch.float32, "boxes")
+    n, D = boxes.shape
+    out = torch.empty((n, k * D), dtype=torch.float32, device=boxes.device)
+    w = _float_arr(weights)
+    call("sod_box2box_apply_deltas", ptr(deltas), ptr(boxes), n, k, D, ld, ctypes.cast(w, ctypes.c_void_p), float(scale_clamp), ptr(out), stream_ptr())
+    return out
+
+
+def _sum1(dev):
+    return torch.empty(1, dtype=torch.float32, device=dev)
+
+
+def bce_logits_loss_fwd(logits, labels):
+    _chk(logits, torch.float32, "logits"); _chk(labels, torch.int8, "labels")
+    s = _sum1(logits.device)
+    call("sod_bce_logits_loss_fwd", ptr(logits), ptr(labels), logits.numel(), ptr(s), ptr(reduce_ws(logits.device)), stream_ptr())
+    return s
+
+
+def bce_logits_loss_bwd(logits, labels, grad_scale, scale_mul):
+    d = torch.empty_like(logits)
+    call("sod_bce_logits_loss_bwd", ptr(logits), ptr(labels), logits.numel(), ptr(grad_scale), float(scale_mul), ptr(d), stream_ptr())
+    return d
+
+
+def rpn_loc_loss_fwd(pred, target, labels, beta):
+    _chk(pred, torch.float32, "pred"); _chk(target, torch.float32, "target"); _chk(labels, torch.int8, "labels")
+    D = pred.shape[-1]
+    s = _sum1(pred.device)
+    call("sod_rpn_loc_loss_fwd", ptr(pred), ptr(target), ptr(labels), labels.numel(), D, float(beta), ptr(s), ptr(reduce_ws(pred.device)), stream_ptr())
+    return s
+
+
+def rpn_loc_loss_bwd(pred, target, labels, beta, grad_scale, scale_mul):
+    d = torch.empty_like(pred)
+    call("sod_rpn_loc_loss_bwd", ptr(pred), ptr(target), ptr(labels), labels.numel(), pred.shape[-1], float(beta), ptr(grad_scale), float(scale_mul),
+         ptr(d), stream_ptr())
+    return d
+
+
+def softmax_ce_fwd(scores, labels, C):
+    """scores (R, ld) fp32 rows with C valid columns; labels int32 (R,). Returns the SUM of the per-row losses."""
+    _chk(scores, torch.float32, "scores"); _chk(labels, torch.int32, "labels")
+    R, ld = scores.shape
+    s = _sum1(scores.device)
+    call("sod_softmax_ce_fwd", ptr(scores), ptr(labels), R, C, ld, ptr(s), ptr(reduce_ws(scores.device)), stream_ptr())
+    return s
+
+
+def softmax_ce_bwd(scores, labels, C, grad_scale, scale_mul):
+    R, ld = scores.shape
+    d = torch.empty_like(scores)
+    call("sod_softmax_ce_bwd", ptr(scores), ptr(labels), R, C, ld, ptr(grad_scale), float(scale_mul), ptr(d), stream_ptr())
+    return d
+
+
+def fastrcnn_box_loss_fwd(pred, gt_classes, gt_deltas, K, beta):
+    _chk(pred, torch.float32, "pred"); _chk(gt_classes, torch.int32, "gt_classes"); _chk(gt_deltas, torch.float32, "gt_deltas")
+    R, ld = pred.shape
+    s = _sum1(pred.device)
+    call("sod_fastrcnn_box_loss_fwd", ptr(pred), ptr(gt_classes), ptr(gt_deltas), R, K, gt_deltas.shape[-1], ld, float(beta), ptr(s),
+         ptr(reduce_ws(pred.device)), stream_ptr())
+    return s
+
+
+def fastrcnn_box_loss_bwd(pred, gt_classes, gt_deltas, K, beta, grad_scale, scale_mul):
+    R, ld = pred.shape
+    d = torch.empty_like(pred)
+    call("sod_fastrcnn_box_loss_bwd", ptr(pred), ptr(gt_classes), ptr(gt_deltas), R, K, gt_deltas.shape[-1], ld, float(beta), ptr(grad_scale),
+         float(scale_mul), ptr(d), stream_ptr())
+    return d

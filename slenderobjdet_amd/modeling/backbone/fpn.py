@@ -6,6 +6,7 @@ epilogue (``res_up2``), so the top-down path costs no extra memory pass.
 """
 import math
 
+import torch
 from torch import nn
 
 from ...layers.nn import HipConv2d, HipGroupNorm, add_up2, group_norm_relu, relu
@@ -28,6 +29,33 @@ class LastLevelP6P7(nn.Module):
         p6 = self.p6(c5)
         p7 = self.p7(relu(p6))
         return [p6, p7]
+
+
+class _SubsampleFn(torch.autograd.Function):
+    """F.max_pool2d(x, kernel_size=1, stride=2, padding=0) == x[:, ::2, ::2] (NHWC): a strided copy and its scatter-back."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return x[:, ::2, ::2, :].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.zeros(ctx.shape, dtype=dy.dtype, device=dy.device)
+        dx[:, ::2, ::2, :] = dy
+        return dx
+
+
+class LastLevelMaxPool(nn.Module):
+    """d2 LastLevelMaxPool: P6 = max_pool2d(P5, kernel 1, stride 2) (build_resnet_fpn_backbone, used by the R-CNN configs)."""
+
+    def __init__(self):
+        super().__init__()
+        self.num_levels = 1
+        self.in_feature = "p5"
+
+    def forward(self, x):
+        return [_SubsampleFn.apply(x)]
 
 
 class FPN(Backbone):
@@ -121,3 +149,10 @@ def build_retinanet_resnet_fpn_backbone_use_p5(cfg, input_shape: ShapeSpec):
 def build_retinanet_resnet_fpn_backbone(cfg, input_shape: ShapeSpec):
     """detectron2's builder (P6 from res5), used by configs/retina/Base-RetinaNet.yaml."""
     return _build(cfg, input_shape, False)
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_fpn_backbone(cfg, input_shape: ShapeSpec):
+    """detectron2's builder for the R-CNN family (configs/rotated/Base-RRCNN-FPN.yaml:5): FPN over res2..res5 + LastLevelMaxPool."""
+    bottom_up = build_resnet_backbone(cfg, input_shape)
+    return FPN(bottom_up, cfg.MODEL.FPN.IN_FEATURES, cfg.MODEL.FPN.OUT_CHANNELS, cfg.MODEL.FPN.NORM, LastLevelMaxPool(), cfg.MODEL.FPN.FUSE_TYPE)

@@ -1,0 +1,85 @@
+"""GeneralizedRCNN on the HIP kernels — the two-stage meta-architecture that BASELINE config 5
+(configs/rotated/faster_R_101.yaml over Base-RRCNN-FPN.yaml) selects; detectron2's source is absent, the contract is the one the
+reference's own subclass relies on (slender_det/modeling/meta_arch/rcnn/pvrcnn.py:17-64): ``forward(batched_inputs)`` returns
+``{loss_rpn_cls, loss_rpn_loc, loss_cls, loss_box_reg}`` in training and ``[{"instances": Instances}]`` in eval."""
+import torch
+from torch import nn
+
+from ..backbone import build_backbone
+from ..proposal_generator import build_proposal_generator
+from ..roi_heads import build_roi_heads
+from .build import META_ARCH_REGISTRY
+from .fcos import FCOSV2
+
+
+@META_ARCH_REGISTRY.register()
+class GeneralizedRCNN(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.backbone = build_backbone(cfg)
+        shapes = self.backbone.output_shape()
+        self.proposal_generator = build_proposal_generator(cfg, shapes)
+        self.roi_heads = build_roi_heads(cfg, shapes)
+        self.register_buffer("pixel_mean", torch.Tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1))
+        self.register_buffer("pixel_std", torch.Tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1))
+        self._mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
+        self._std = [float(v) for v in cfg.MODEL.PIXEL_STD]
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    preprocess_image = FCOSV2.preprocess_image
+    postprocess = FCOSV2.postprocess
+
+    def forward(self, batched_inputs):
+        if not self.training:
+            return self.inference(batched_inputs)
+        images = self.preprocess_image(batched_inputs)
+        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        features = self.backbone(images.tensor)
+        proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
+        _, detector_losses = self.roi_heads(images, features, proposals, gt_instances)
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        return losses
+
+    @torch.no_grad()
+    def inference(self, batched_inputs, do_postprocess=True):
+        images = self.preprocess_image(batched_inputs)
+        features = self.backbone(images.tensor)
+        proposals, _ = self.proposal_generator(images, features, None)
+        results, _ = self.roi_heads(images, features, proposals, None)
+        if do_postprocess:
+            return self.postprocess(results, batched_inputs, images.image_sizes)
+        return results
+
+
+@META_ARCH_REGISTRY.register()
+class ProposalNetwork(nn.Module):
+    """d2 ProposalNetwork: backbone + proposal generator only (loss_rpn_cls / loss_rpn_loc)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.backbone = build_backbone(cfg)
+        self.proposal_generator = build_proposal_generator(cfg, self.backbone.output_shape())
+        self.register_buffer("pixel_mean", torch.Tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1))
+        self.register_buffer("pixel_std", torch.Tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1))
+        self._mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
+        self._std = [float(v) for v in cfg.MODEL.PIXEL_STD]
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    preprocess_image = FCOSV2.preprocess_image
+
+    def forward(self, batched_inputs):
+        images = self.preprocess_image(batched_inputs)
+        features = self.backbone(images.tensor)
+        gt = [x["instances"].to(self.device) for x in batched_inputs] if "instances" in batched_inputs[0] else None
+        proposals, losses = self.proposal_generator(images, features, gt)
+        if self.training:
+            return losses
+        return [{"proposals": p} for p in proposals]

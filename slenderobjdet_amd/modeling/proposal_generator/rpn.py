@@ -1,0 +1,239 @@
+"""RPN / RRPN on the HIP kernels (BASELINE config 5: configs/rotated/Base-RRCNN-FPN.yaml selects ``RRPN`` + ``StandardRPNHead`` +
+``RotatedAnchorGenerator``; the reference's own subclass slender_det/modeling/proposal_generator/rpn.py:26-356 extends d2's ``RPN``).
+
+detectron2's sources are absent everywhere; semantics restated: shared 3x3 conv + ReLU, 1x1 objectness
+(A channels) and 1x1 anchor deltas (A*box_dim channels, anchor-major); anchors labelled by IoU + Matcher([0.3, 0.7], [0, -1, 1],
+low-quality on), 256 sampled per image at <= 50 % positives; ``loss_rpn_cls`` = BCE-with-logits(sum) and ``loss_rpn_loc`` =
+smooth-L1(sum, beta 0) both divided by 256 * N; proposals = per-level top-k by logit, decode, clip, drop empty, class(level)-aware
+NMS 0.7, top post_nms_topk.
+
+MI355X-first: the three head convs are one multi-level launch each (levels share weights); anchor labelling is the fused
+IoU + Matcher kernel (axis-aligned or rotated) that never builds the G x A matrix; both losses run over ALL anchors with the int8
+label as mask (no boolean gathers).
+"""
+import math
+
+import torch
+from torch import nn
+from torch.autograd.function import once_differentiable
+
+from ...layers import functional as HF
+from ...layers.nms import batched_nms, batched_nms_rotated
+from ...layers.nn import ConvML
+from ...structures import Boxes, Instances, RotatedBoxes
+from ...utils.registry import Registry
+from ..anchor_generator import build_anchor_generator
+from ..box_regression import Box2BoxTransform, Box2BoxTransformRotated
+
+PROPOSAL_GENERATOR_REGISTRY = Registry("PROPOSAL_GENERATOR")
+RPN_HEAD_REGISTRY = Registry("RPN_HEAD")
+
+
+def _ceil8(v):
+    return (v + 7) // 8 * 8
+
+
+def subsample_labels(labels, num_samples, positive_fraction, bg_label):
+    """detectron2.modeling.sampling.subsample_labels: random positives (not -1, not bg) up to the fraction, negatives fill the rest."""
+    positive = torch.nonzero((labels != -1) & (labels != bg_label), as_tuple=False).squeeze(1)
+    negative = torch.nonzero(labels == bg_label, as_tuple=False).squeeze(1)
+    num_pos = min(positive.numel(), int(num_samples * positive_fraction))
+    num_neg = min(negative.numel(), num_samples - num_pos)
+    perm1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
+    perm2 = torch.randperm(negative.numel(), device=negative.device)[:num_neg]
+    return positive[perm1], negative[perm2]
+
+
+@RPN_HEAD_REGISTRY.register()
+class StandardRPNHead(nn.Module):
+    def __init__(self, cfg, input_shape, num_anchors, box_dim):
+        super().__init__()
+        C = input_shape[0].channels
+        self.num_anchors, self.box_dim = num_anchors, box_dim
+        self.obj_pad, self.delta_pad = _ceil8(num_anchors), _ceil8(num_anchors * box_dim)
+        self.conv = ConvML(C, C, 3, 1, relu=True)
+        self.objectness_logits = ConvML(C, self.obj_pad, 1, 0, out_f32=True)
+        self.anchor_deltas = ConvML(C, self.delta_pad, 1, 0, out_f32=True)
+        with torch.no_grad():
+            for m in (self.conv, self.objectness_logits, self.anchor_deltas):
+                m.conv.init_normal(0.01, 0.0)
+            self.objectness_logits.conv.weight[num_anchors:].zero_()
+            self.anchor_deltas.conv.weight[num_anchors * box_dim:].zero_()
+
+    def forward(self, features):
+        t = self.conv(features)
+        return self.objectness_logits(t), self.anchor_deltas(t)      # per level (N,H,W,obj_pad) / (N,H,W,delta_pad) fp32
+
+
+class _RpnLossFn(torch.autograd.Function):
+    """RPN.losses over per-level padded head outputs -> [loss_rpn_cls, loss_rpn_loc] (before loss weights)."""
+
+    @staticmethod
+    def forward(ctx, rpn, gt_labels, gt_deltas, *outs):
+        nl = len(outs) // 2
+        logits, deltas = rpn.compact(outs[:nl], outs[nl:])
+        N = logits.shape[0]
+        norm = float(rpn.batch_size_per_image * N)
+        s_cls = HF.bce_logits_loss_fwd(logits, gt_labels)
+        s_loc = HF.rpn_loc_loss_fwd(deltas, gt_deltas, gt_labels, rpn.smooth_l1_beta)
+        ctx.rpn, ctx.nl, ctx.norm = rpn, nl, norm
+        ctx.shapes = [tuple(o.shape) for o in outs]
+        ctx.save_for_backward(logits, deltas, gt_labels, gt_deltas)
+        return torch.cat([s_cls, s_loc]) / norm
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g2):
+        rpn, nl = ctx.rpn, ctx.nl
+        logits, deltas, gt_labels, gt_deltas = ctx.saved_tensors
+        g2 = g2.contiguous().float()
+        dl = HF.bce_logits_loss_bwd(logits, gt_labels, g2[0:1], 1.0 / ctx.norm)
+        dd = HF.rpn_loc_loss_bwd(deltas, gt_deltas, gt_labels, rpn.smooth_l1_beta, g2[1:2], 1.0 / ctx.norm)
+        A, D = rpn.head.num_anchors, rpn.head.box_dim
+        N = logits.shape[0]
+        g_log, g_del, off = [], [], 0
+        for l in range(nl):
+            _, H, W, pl = ctx.shapes[l]
+            pd = ctx.shapes[nl + l][3]
+            n = H * W * A
+            a = torch.zeros((N, H, W, pl), dtype=torch.float32, device=logits.device)
+            a[..., :A] = dl[:, off:off + n].view(N, H, W, A)
+            b = torch.zeros((N, H, W, pd), dtype=torch.float32, device=logits.device)
+            b[..., :A * D] = dd[:, off:off + n].reshape(N, H, W, A * D)
+            g_log.append(a)
+            g_del.append(b)
+            off += n
+        return (None, None, None, *g_log, *g_del)
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class RPN(nn.Module):
+    box_dim = 4
+    rotated = False
+
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        r = cfg.MODEL.RPN
+        self.in_features = list(r.IN_FEATURES)
+        shapes = [input_shape[f] for f in self.in_features]
+        self.anchor_generator = build_anchor_generator(cfg, shapes)
+        assert self.anchor_generator.box_dim == self.box_dim, "ANCHOR_GENERATOR.NAME does not match the proposal generator's box type"
+        na = self.anchor_generator.num_cell_anchors
+        assert len(set(na)) == 1, "each level must have the same number of cell anchors"
+        self.head = RPN_HEAD_REGISTRY.get(r.HEAD_NAME)(cfg, shapes, na[0], self.box_dim)
+        self.box2box_transform = (Box2BoxTransformRotated if self.rotated else Box2BoxTransform)(weights=r.BBOX_REG_WEIGHTS)
+        self.iou_thresholds, self.iou_labels = list(r.IOU_THRESHOLDS), list(r.IOU_LABELS)
+        self.batch_size_per_image, self.positive_fraction = r.BATCH_SIZE_PER_IMAGE, r.POSITIVE_FRACTION
+        self.smooth_l1_beta = r.SMOOTH_L1_BETA
+        self.loss_weight = {"loss_rpn_cls": r.LOSS_WEIGHT, "loss_rpn_loc": r.BBOX_REG_LOSS_WEIGHT * r.LOSS_WEIGHT}
+        self.pre_nms_topk = {True: r.PRE_NMS_TOPK_TRAIN, False: r.PRE_NMS_TOPK_TEST}
+        self.post_nms_topk = {True: r.POST_NMS_TOPK_TRAIN, False: r.POST_NMS_TOPK_TEST}
+        self.nms_thresh = r.NMS_THRESH
+        self.min_box_size = float(cfg.MODEL.PROPOSAL_GENERATOR.MIN_SIZE)
+        self.last_targets = None
+
+    # ------------------------------------------------------------------ helpers
+    def compact(self, logits_l, deltas_l):
+        """Per-level padded NHWC rows -> (N, sum HWA) logits and (N, sum HWA, D) deltas in d2's (h, w, a) order."""
+        A, D = self.head.num_anchors, self.head.box_dim
+        N = logits_l[0].shape[0]
+        lg = torch.cat([x[..., :A].reshape(N, -1) for x in logits_l], dim=1).contiguous()
+        dl = torch.cat([x[..., :A * D].reshape(N, -1, D) for x in deltas_l], dim=1).contiguous()
+        return lg, dl
+
+    def _box_type(self):
+        return RotatedBoxes if self.rotated else Boxes
+
+    @torch.no_grad()
+    def label_and_sample_anchors(self, anchors, gt_instances):
+        """Returns gt_labels (N, R) int8 in {-1, 0, 1} and the matched gt boxes (N, R, D)."""
+        R = anchors.shape[0]
+        N = len(gt_instances)
+        dev = anchors.device
+        labels = torch.empty((N, R), dtype=torch.int8, device=dev)
+        matched = torch.zeros((N, R, self.box_dim), dtype=torch.float32, device=dev)
+        for i, g in enumerate(gt_instances):
+            boxes = g.gt_boxes.tensor.float().contiguous()
+            _, matches, mlab = HF.anchor_match(boxes, anchors, self.iou_thresholds, self.iou_labels, True)
+            pos, neg = subsample_labels(mlab, self.batch_size_per_image, self.positive_fraction, 0)
+            lab = labels[i]
+            lab.fill_(-1)
+            lab[pos] = 1
+            lab[neg] = 0
+            if len(boxes):
+                matched[i] = boxes[matches.long()]
+        return labels, matched
+
+    @torch.no_grad()
+    def anchor_deltas_for(self, anchors, matched):
+        return torch.stack([self.box2box_transform.get_deltas(anchors, m) for m in matched])
+
+    @torch.no_grad()
+    def predict_proposals(self, anchors_l, logits_l, deltas_l, image_sizes):
+        A, D = self.head.num_anchors, self.head.box_dim
+        N = logits_l[0].shape[0]
+        training = self.training
+        topk_scores, topk_props, level_ids = [], [], []
+        batch_idx = torch.arange(N, device=logits_l[0].device)
+        for lvl, (anc, lg, dl) in enumerate(zip(anchors_l, logits_l, deltas_l)):
+            lg = lg[..., :A].reshape(N, -1)
+            dl = dl[..., :A * D].reshape(-1, D).contiguous()
+            props = self.box2box_transform.apply_deltas(dl, anc.unsqueeze(0).expand(N, -1, -1).reshape(-1, D).contiguous()).view(N, -1, D)
+            num = min(self.pre_nms_topk[training], lg.shape[1])
+            sc, idx = lg.topk(num, dim=1)            # d2: sort(descending) then the first num
+            topk_scores.append(sc)
+            topk_props.append(props[batch_idx[:, None], idx])
+            level_ids.append(torch.full((num,), lvl, dtype=torch.int64, device=lg.device))
+        topk_scores, topk_props, level_ids = torch.cat(topk_scores, 1), torch.cat(topk_props, 1), torch.cat(level_ids, 0)
+        results = []
+        BoxT = self._box_type()
+        for n, image_size in enumerate(image_sizes):
+            boxes, scores, lvl = BoxT(topk_props[n].clone()), topk_scores[n], level_ids
+            valid = torch.isfinite(boxes.tensor).all(dim=1) & torch.isfinite(scores)
+            if not bool(valid.all()):
+                if training:
+                    raise FloatingPointError(f"Predicted boxes or scores contain Inf/NaN. Training has diverged. (image {n}: "
+                                             f"{int((~torch.isfinite(boxes.tensor)).sum())} box values, {int((~torch.isfinite(scores)).sum())} scores)")
+                boxes, scores, lvl = boxes[valid], scores[valid], lvl[valid]
+            boxes.clip(image_size)
+            keep = boxes.nonempty(threshold=self.min_box_size)
+            if int(keep.sum()) != len(boxes):
+                boxes, scores, lvl = boxes[keep], scores[keep], lvl[keep]
+            nms_fn = batched_nms_rotated if self.rotated else batched_nms
+            keep = nms_fn(boxes.tensor, scores, lvl, self.nms_thresh)[: self.post_nms_topk[training]]
+            res = Instances(tuple(image_size))
+            res.proposal_boxes = boxes[keep]
+            res.objectness_logits = scores[keep]
+            results.append(res)
+        return results
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, images, features, gt_instances=None):
+        feats = [features[f] for f in self.in_features]
+        hw = [(f.shape[1], f.shape[2]) for f in feats]
+        anchors_l = self.anchor_generator(hw, feats[0].device)
+        logits_l, deltas_l = self.head(feats)
+        losses = {}
+        if self.training:
+            anchors = torch.cat(anchors_l).contiguous()
+            gt_labels, matched = self.label_and_sample_anchors(anchors, gt_instances)
+            gt_deltas = self.anchor_deltas_for(anchors, matched)
+            self.last_targets = (gt_labels, matched, gt_deltas)
+            out = _RpnLossFn.apply(self, gt_labels, gt_deltas, *logits_l, *deltas_l)
+            losses = {"loss_rpn_cls": out[0] * self.loss_weight["loss_rpn_cls"], "loss_rpn_loc": out[1] * self.loss_weight["loss_rpn_loc"]}
+        proposals = self.predict_proposals(anchors_l, [x.detach() for x in logits_l], [x.detach() for x in deltas_l], images.image_sizes)
+        return proposals, losses
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class RRPN(RPN):
+    """d2 RRPN: rotated anchors, pairwise_iou_rotated matching, Box2BoxTransformRotated, rotated NMS."""
+    box_dim = 5
+    rotated = True
+
+
+def build_proposal_generator(cfg, input_shape):
+    name = cfg.MODEL.PROPOSAL_GENERATOR.NAME
+    if name == "PrecomputedProposals":
+        return None
+    return PROPOSAL_GENERATOR_REGISTRY.get(name)(cfg, input_shape)

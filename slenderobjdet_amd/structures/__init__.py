@@ -1,6 +1,7 @@
 """``detectron2.structures`` subset the hot path touches (reference call sites: fcosv2.py:14, fcos/utils.py:170-175):
 Boxes, Instances, ImageList (semantics restated from SURVEY.md Appendix C.4 / C.8)."""
 import itertools
+import math
 from typing import Any, Dict, List, Tuple
 
 import torch
@@ -213,3 +214,77 @@ class ImageList:
         for img, pad_img in zip(tensors, batch):
             pad_img[..., : img.shape[-2], : img.shape[-1]].copy_(img)
         return ImageList(batch.contiguous(), sizes)
+
+
+class RotatedBoxes(Boxes):
+    """detectron2.structures.RotatedBoxes (source absent): (N,5) = (cx, cy, w, h, angle in degrees, CCW positive)."""
+
+    def __init__(self, tensor):
+        device = tensor.device if isinstance(tensor, torch.Tensor) else torch.device("cpu")
+        tensor = torch.as_tensor(tensor, dtype=torch.float32, device=device)
+        if tensor.numel() == 0:
+            tensor = tensor.reshape((0, 5)).to(dtype=torch.float32, device=device)
+        assert tensor.dim() == 2 and tensor.size(-1) == 5, tensor.size()
+        self.tensor = tensor
+
+    def clone(self):
+        return RotatedBoxes(self.tensor.clone())
+
+    def to(self, *args, **kwargs):
+        return RotatedBoxes(self.tensor.to(*args, **kwargs))
+
+    def area(self):
+        return self.tensor[:, 2] * self.tensor[:, 3]
+
+    def normalize_angles(self):
+        self.tensor[:, 4] = (self.tensor[:, 4] + 180.0) % 360.0 - 180.0
+
+    def clip(self, box_size, clip_angle_threshold: float = 1.0):
+        """Only nearly-horizontal boxes are clipped (to XYXY, clamp, back), as d2 does."""
+        h, w = box_size
+        self.normalize_angles()
+        idx = torch.where(torch.abs(self.tensor[:, 4]) <= clip_angle_threshold)[0]
+        x1 = self.tensor[idx, 0] - self.tensor[idx, 2] / 2.0
+        y1 = self.tensor[idx, 1] - self.tensor[idx, 3] / 2.0
+        x2 = self.tensor[idx, 0] + self.tensor[idx, 2] / 2.0
+        y2 = self.tensor[idx, 1] + self.tensor[idx, 3] / 2.0
+        x1.clamp_(min=0, max=w); y1.clamp_(min=0, max=h); x2.clamp_(min=0, max=w); y2.clamp_(min=0, max=h)
+        self.tensor[idx, 0] = (x1 + x2) / 2.0
+        self.tensor[idx, 1] = (y1 + y2) / 2.0
+        self.tensor[idx, 2] = torch.min(self.tensor[idx, 2], x2 - x1)
+        self.tensor[idx, 3] = torch.min(self.tensor[idx, 3], y2 - y1)
+
+    def nonempty(self, threshold: float = 0.0):
+        return (self.tensor[:, 2] > threshold) & (self.tensor[:, 3] > threshold)
+
+    def get_centers(self):
+        return self.tensor[:, :2]
+
+    def scale(self, scale_x, scale_y):
+        self.tensor[:, 0] *= scale_x
+        self.tensor[:, 1] *= scale_y
+        theta = self.tensor[:, 4] * math.pi / 180.0
+        c, s = torch.cos(theta), torch.sin(theta)
+        self.tensor[:, 2] *= torch.sqrt((scale_x * c) ** 2 + (scale_y * s) ** 2)
+        self.tensor[:, 3] *= torch.sqrt((scale_x * s) ** 2 + (scale_y * c) ** 2)
+        self.tensor[:, 4] = torch.atan2(scale_x * s, scale_y * c) * 180 / math.pi
+
+    def __getitem__(self, item):
+        if isinstance(item, int):
+            return RotatedBoxes(self.tensor[item].view(1, -1))
+        return RotatedBoxes(self.tensor[item])
+
+    def __repr__(self):
+        return "RotatedBoxes(" + str(self.tensor) + ")"
+
+    @classmethod
+    def cat(cls, boxes_list):
+        if len(boxes_list) == 0:
+            return cls(torch.empty(0))
+        return cls(torch.cat([b.tensor for b in boxes_list], dim=0))
+
+
+def pairwise_iou_rotated(boxes1: RotatedBoxes, boxes2: RotatedBoxes):
+    from ..layers import functional as HF
+
+    return HF.box_iou_rotated(boxes1.tensor.float().contiguous(), boxes2.tensor.float().contiguous())
