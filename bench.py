@@ -24,7 +24,7 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MF
 TRAIN_FLOP_PER_IMAGE = 1.1913e12   # fwd + dgrad + wgrad, stem+res2 frozen, 800x1344
 
 
-ARCH_NAMES = {"fcos": "FCOS", "retinanet": "RetinaNet", "reppoints": "RepPoints"}
+ARCH_NAMES = {"fcos": "FCOS", "retinanet": "RetinaNet", "reppoints": "RepPoints", "rrcnn": "rotated Faster R-CNN"}
 
 
 def make_cfg(depth=50, arch="fcos"):
@@ -45,6 +45,29 @@ def make_cfg(depth=50, arch="fcos"):
         cfg.MODEL.RETINANET.IOU_THRESHOLDS = [0.4, 0.5]
         cfg.MODEL.RETINANET.IOU_LABELS = [0, -1, 1]
         cfg.MODEL.META_ARCHITECTURE = "RetinaNet"
+    if arch == "rrcnn":                          # configs/rotated/faster_R_101.yaml over Base-RRCNN-FPN.yaml
+        cfg.MODEL.META_ARCHITECTURE = "GeneralizedRCNN"
+        cfg.MODEL.BACKBONE.NAME = "build_resnet_fpn_backbone"
+        cfg.MODEL.RESNETS.OUT_FEATURES = ["res2", "res3", "res4", "res5"]
+        cfg.MODEL.FPN.IN_FEATURES = ["res2", "res3", "res4", "res5"]
+        cfg.MODEL.PROPOSAL_GENERATOR.NAME = "RRPN"
+        cfg.MODEL.ANCHOR_GENERATOR.NAME = "RotatedAnchorGenerator"
+        cfg.MODEL.ANCHOR_GENERATOR.SIZES = [[32], [64], [128], [256], [512]]
+        cfg.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS = [[0.5, 1.0, 2.0]]
+        cfg.MODEL.ANCHOR_GENERATOR.ANGLES = [[45, 0, -45]]
+        cfg.MODEL.RPN.HEAD_NAME = "StandardRPNHead"
+        cfg.MODEL.RPN.BBOX_REG_WEIGHTS = (1.0, 1.0, 1.0, 1.0, 1.0)
+        cfg.MODEL.RPN.IN_FEATURES = ["p2", "p3", "p4", "p5", "p6"]
+        cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, cfg.MODEL.RPN.PRE_NMS_TOPK_TEST = 2000, 1000
+        cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN, cfg.MODEL.RPN.POST_NMS_TOPK_TEST = 1000, 1000
+        cfg.MODEL.ROI_HEADS.NAME = "RROIHeads"
+        cfg.MODEL.ROI_HEADS.IN_FEATURES = ["p2", "p3", "p4", "p5"]
+        cfg.MODEL.ROI_BOX_HEAD.NAME = "FastRCNNConvFCHead"
+        cfg.MODEL.ROI_BOX_HEAD.NUM_FC = 2
+        cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION = 7
+        cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE = "ROIAlignRotated"
+        cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS = (10.0, 5.0, 5.0, 5.0, 1.0)
+        cfg.SOLVER.BASE_LR = 0.02
     if arch == "reppoints":                      # configs/rep-points/rep_points_detector_R_50_FPN_1x.yaml
         cfg.MODEL.META_ARCHITECTURE = "RepPointsDetector"
         cfg.MODEL.RESNETS.OUT_FEATURES = ["res2", "res3", "res4", "res5"]
@@ -62,6 +85,8 @@ def make_cfg(depth=50, arch="fcos"):
 WORKLOADS = {
     "fcos": "FCOS R50-FPN (FCOSV2, giou, center-sampling 1.5), fwd+bwd+SGD, synthetic 1333x800 padded to 800x1344 (BASELINE.json configs[1])",
     "retinanet": "RetinaNet R50-FPN (9 anchors, smooth-L1), fwd+bwd+SGD, synthetic 1333x800 padded to 800x1344 (BASELINE.json configs[2])",
+    "rrcnn": "GeneralizedRCNN + RRPN + RROIHeads (rotated boxes, ROIAlignRotated, rotated NMS), fwd+bwd+SGD, synthetic 1333x800 padded to 800x1344 "
+             "(BASELINE.json configs[4])",
     "reppoints": "RepPointsDetector R50-FPN(GN) (points matcher, 2 DeformConv/level), fwd+bwd+SGD, synthetic 1333x800 padded to 800x1344 "
                  "(BASELINE.json configs[3])",
 }
@@ -173,14 +198,14 @@ def main():
     torch.manual_seed(1 + rank)   # engine/defaults.py:66: SEED + rank
     model = build_model(cfg)
     model.train()
-    if args.arch == "retinanet" and args.depth >= 50:
+    if args.arch in ("retinanet", "rrcnn") and args.depth >= 50:
         damp_residual_branches(model)
     if world > 1:   # DDP semantics: identical initial parameters on every rank
         dist.broadcast(model.arena.params, src=0)
         model.arena.bump()
     optimizer = build_optimizer(cfg, model)
     optimizer.grad_scale = 1.0 / world
-    loader = SyntheticCocoBatches(args.batch_per_gpu, args.height, args.width, rank=rank, device=dev, pool=2)
+    loader = SyntheticCocoBatches(args.batch_per_gpu, args.height, args.width, rank=rank, device=dev, pool=2, rotated=args.arch == "rrcnn")
 
     for _ in range(args.warmup):
         train_step(model, optimizer, next(loader))

@@ -5,10 +5,11 @@ uint8 images, G ~ clamp(Poisson(7), 1, 50) boxes, log-uniform 16..600 px sides, 
 """
 import torch
 
-from ..structures import Boxes, Instances
+from ..structures import Boxes, Instances, RotatedBoxes
 
 
-def synthetic_batch(n_images, height, width, seed=1234, num_classes=80, device="cpu", max_boxes=50):
+def synthetic_batch(n_images, height, width, seed=1234, num_classes=80, device="cpu", max_boxes=50, rotated=False):
+    """``rotated``: gt boxes as RotatedBoxes (cx, cy, w, h, angle ~ U(-90, 90)) — SURVEY.md §8(d), the rotated R-CNN configuration."""
     g = torch.Generator().manual_seed(int(seed))
     out = []
     for _ in range(n_images):
@@ -32,6 +33,9 @@ def synthetic_batch(n_images, height, width, seed=1234, num_classes=80, device="
         inst = Instances((height, width))
         inst.gt_boxes = Boxes(torch.stack([x1, y1, x2, y2], dim=1))
         inst.gt_classes = torch.randint(0, num_classes, (G,), generator=g)
+        if rotated:
+            ang = torch.rand(G, generator=g) * 180.0 - 90.0
+            inst.gt_boxes = RotatedBoxes(torch.stack([(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1, ang], dim=1))
         if device != "cpu":
             img = img.to(device)
             inst = inst.to(device)
@@ -42,9 +46,9 @@ def synthetic_batch(n_images, height, width, seed=1234, num_classes=80, device="
 class SyntheticCocoBatches:
     """Infinite iterator of per-rank batches; seed = base + rank*1000 + iteration (SURVEY.md §8 d)."""
 
-    def __init__(self, images_per_rank, height=800, width=1333, rank=0, base_seed=1234, device="cpu", pool=4):
+    def __init__(self, images_per_rank, height=800, width=1333, rank=0, base_seed=1234, device="cpu", pool=4, rotated=False):
         self.n, self.h, self.w, self.rank, self.base, self.device = images_per_rank, height, width, rank, base_seed, device
-        self._pool = [synthetic_batch(self.n, self.h, self.w, self.base + rank * 1000 + i, device=device) for i in range(pool)]
+        self._pool = [synthetic_batch(self.n, self.h, self.w, self.base + rank * 1000 + i, device=device, rotated=rotated) for i in range(pool)]
         self._it = 0
 
     def __iter__(self):

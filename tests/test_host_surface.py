@@ -117,6 +117,33 @@ def test_reppoints_and_retinanet_build_from_repo_configs_cpu():
         build_model(cfg)
 
 
+def test_rotated_rcnn_builds_from_repo_config_cpu():
+    """BASELINE configs[4]: GeneralizedRCNN + RRPN + RROIHeads resolve through the registries with the reference's keys."""
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.modeling.proposal_generator import PROPOSAL_GENERATOR_REGISTRY, RPN_HEAD_REGISTRY
+    from slenderobjdet_amd.modeling.roi_heads import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
+
+    for reg, names in ((PROPOSAL_GENERATOR_REGISTRY, ("RPN", "RRPN")), (RPN_HEAD_REGISTRY, ("StandardRPNHead",)),
+                       (ROI_HEADS_REGISTRY, ("StandardROIHeads", "RROIHeads")), (ROI_BOX_HEAD_REGISTRY, ("FastRCNNConvFCHead",))):
+        for n in names:
+            assert n in reg
+    cfg = fresh_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(__file__), "..", "configs", "rotated", "faster_R_101.yaml"))
+    cfg.MODEL.DEVICE = "cpu"
+    m = build_model(cfg)
+    assert list(m.backbone.output_shape()) == ["p2", "p3", "p4", "p5", "p6"] and len(m.backbone.bottom_up.res4) == 23
+    rpn, roi = m.proposal_generator, m.roi_heads
+    assert rpn.head.num_anchors == 9 and rpn.box_dim == 5 and roi.box_pooler.rotated and roi.box_pooler.scales == [0.25, 0.125, 0.0625, 0.03125]
+    # detectron2's parameter counts for this head: RPN 3x3 + 9 logits + 45 deltas; FC 12544->1024->1024; 81 scores + 400 deltas
+    C = 256
+    ref_rpn = (C * C * 9 + C) + (C * 9 + 9) + (C * 45 + 45)
+    ref_roi = (12544 * 1024 + 1024) + (1024 * 1024 + 1024) + (1024 * 81 + 81) + (1024 * 400 + 400)
+    pad_rpn = (16 - 9) * (C + 1) + (48 - 45) * (C + 1)
+    pad_roi = (88 - 81) * (1024 + 1)
+    assert sum(p.numel() for p in rpn.parameters()) - pad_rpn == ref_rpn
+    assert sum(p.numel() for p in roi.parameters()) - pad_roi == ref_roi
+
+
 def test_optimizer_param_groups_follow_reference_rules():
     from slenderobjdet_amd.layers.nn import ConvGnRelu
     from slenderobjdet_amd.solver import get_default_optimizer_params
