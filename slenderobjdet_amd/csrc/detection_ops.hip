@@ -104,6 +104,12 @@ __device__ float rot_intersection_area(const P2* p1, const P2* p2) {
 __device__ float iou_rotated(const float* a, const float* b) {
   const float area1 = a[2] * a[3], area2 = b[2] * b[3];
   if (area1 < 1e-14f || area2 < 1e-14f) return 0.f;
+  {   // disjoint circumscribed circles => empty intersection => IoU exactly 0 (skips the polygon clipping for almost every pair)
+    const float dx = a[0] - b[0], dy = a[1] - b[1];
+    const float ra = 0.5f * sqrtf(a[2] * a[2] + a[3] * a[3]), rb = 0.5f * sqrtf(b[2] * b[2] + b[3] * b[3]);
+    const float rs = ra + rb;
+    if (dx * dx + dy * dy > rs * rs * 1.0001f) return 0.f;
+  }
   const float sx = (a[0] + b[0]) / 2.f, sy = (a[1] + b[1]) / 2.f;   // centre shift for precision
   P2 p1[4], p2[4];
   rot_vertices(a[0] - sx, a[1] - sy, a[2], a[3], a[4], p1);
@@ -118,12 +124,14 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   const int rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb) return;   // only the upper triangle is ever read
   __shared__ float cbox[64 * BD];
+  __shared__ float crad[64];      // rotated: circumscribed-circle radius of each column box
   const int lane = threadIdx.x;
   const int cj = cb * 64 + lane;
   if (cj < n) {
     const long long o = order[cj];
 #pragma unroll
     for (int e = 0; e < BD; ++e) cbox[lane * BD + e] = boxes[o * BD + e];
+    if (BD == 5) crad[lane] = 0.5f * sqrtf(cbox[lane * BD + 2] * cbox[lane * BD + 2] + cbox[lane * BD + 3] * cbox[lane * BD + 3]);
   }
   __syncthreads();
   const int i = rb * 64 + lane;
@@ -132,11 +140,17 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   const long long oi = order[i];
 #pragma unroll
   for (int e = 0; e < BD; ++e) a[e] = boxes[oi * BD + e];
+  const float ra = BD == 5 ? 0.5f * sqrtf(a[2] * a[2] + a[3] * a[3]) : 0.f;
   unsigned long long bits = 0;
   const int cnt = min(64, n - cb * 64);
   const int start = (rb == cb) ? lane + 1 : 0;
   for (int j = start; j < cnt; ++j) {
-    const bool hit = (BD == 4) ? iou_gt(a, cbox + j * BD, thr) : (iou_rotated(a, cbox + j * BD) > thr);
+    bool hit;
+    if (BD == 4) hit = iou_gt(a, cbox + j * BD, thr);
+    else {
+      const float dx = a[0] - cbox[j * BD], dy = a[1] - cbox[j * BD + 1], rs = ra + crad[j];
+      hit = (dx * dx + dy * dy <= rs * rs * 1.0001f) && (iou_rotated(a, cbox + j * BD) > thr);   // disjoint circles: IoU is exactly 0
+    }
     if (hit) bits |= 1ull << j;
   }
   mask[(long long)i * words + cb] = bits;
@@ -149,24 +163,45 @@ __global__ __launch_bounds__(256) void pairwise_iou_rotated_kernel(const float* 
     out[i] = iou_rotated(b1 + (i / n2) * 5, b2 + (i % n2) * 5);
 }
 
-// single workgroup: thread w owns word w of the "removed" bitmap; boxes are visited in score order
+// single workgroup, boxes visited in score order in chunks of 64: wave 0 resolves a chunk against the chunk's own 64x64 diagonal
+// block of the suppression matrix with wave shuffles (no barrier per box), then thread w ORs the rows of the chunk's survivors
+// into word w of the "removed" bitmap.  2 barriers per 64 boxes instead of 2 per box (10 000 candidates: 3.5 ms -> ~0.5 ms).
 __global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long* __restrict__ mask, const long long* __restrict__ order,
                                                         int n, int words, long long* __restrict__ keep, int* __restrict__ nkeep) {
   __shared__ unsigned long long removed[1024];
-  __shared__ int flag;
+  __shared__ unsigned long long chunk_keep;
   const int w = threadIdx.x;
   if (w < words) removed[w] = 0;
   __syncthreads();
   int kept = 0;
-  for (int i = 0; i < n; ++i) {
-    if (w == 0) flag = (int)((removed[i >> 6] >> (i & 63)) & 1ull);
-    __syncthreads();
-    const bool dead = flag != 0;
-    if (!dead) {
-      if (w == 0) keep[kept] = order[i];
-      ++kept;
-      if (w < words && w >= (i >> 6)) removed[w] |= mask[(long long)i * words + w];
+  for (int c = 0; c < words; ++c) {
+    const int cnt = min(64, n - c * 64);
+    if (w < 64) {
+      const long long i = (long long)c * 64 + w;
+      const unsigned long long diag = (w < cnt) ? mask[i * words + c] : 0ull;
+      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+      unsigned long long rem = removed[c], kb = 0ull;
+      for (int j = 0; j < cnt; ++j) {
+        const unsigned long long dj = ((unsigned long long)__shfl(dhi, j, 64) << 32) | (unsigned long long)__shfl(dlo, j, 64);
+        if (!((rem >> j) & 1ull)) { kb |= 1ull << j; rem |= dj; }
+      }
+      if (w == 0) chunk_keep = kb;
     }
+    __syncthreads();
+    const unsigned long long kb = chunk_keep;
+    {   // all 1024 threads: word ww = w % words, row slice sl = w / words of `slices`; independent loads, merged with ds_or_b64
+      const int slices = 1024 / words;          // words <= 1024
+      const int ww = w % words, sl = w / words;
+      if (sl < slices && ww > c) {
+        unsigned long long acc = 0ull;
+#pragma unroll 4
+        for (int j = sl; j < cnt; j += slices)
+          if ((kb >> j) & 1ull) acc |= mask[((long long)c * 64 + j) * words + ww];
+        if (acc) atomicOr(&removed[ww], acc);
+      }
+    }
+    if (w < 64 && ((kb >> w) & 1ull)) keep[kept + __popcll(kb & ((1ull << w) - 1ull))] = order[(long long)c * 64 + w];
+    kept += __popcll(kb);
     __syncthreads();
   }
   if (w == 0) *nkeep = kept;
