@@ -67,7 +67,7 @@ def make_cfg(depth=50, arch="fcos"):
         cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION = 7
         cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE = "ROIAlignRotated"
         cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS = (10.0, 5.0, 5.0, 5.0, 1.0)
-        cfg.SOLVER.BASE_LR = 0.0005     # the reference trains at 0.02 from an ImageNet checkpoint; random init diverges there
+        cfg.SOLVER.BASE_LR = 0.002      # the reference trains at 0.02 from an ImageNet checkpoint; random init diverges there
     if arch == "reppoints":                      # configs/rep-points/rep_points_detector_R_50_FPN_1x.yaml
         cfg.MODEL.META_ARCHITECTURE = "RepPointsDetector"
         cfg.MODEL.RESNETS.OUT_FEATURES = ["res2", "res3", "res4", "res5"]
@@ -103,6 +103,9 @@ def damp_residual_branches(model, gamma=0.25):
         for name, m in model.named_modules():
             if name.endswith(".conv3") and getattr(m, "frozen_bn", False):
                 m.bn_weight.fill_(gamma)
+                n += 1
+            if name.endswith("stem.conv1") and getattr(m, "frozen_bn", False):
+                m.bn_weight.fill_(1.0 / 64)     # pixel-range inputs (PIXEL_STD = 1): a trained stem BN brings them to O(1)
                 n += 1
     return n
 

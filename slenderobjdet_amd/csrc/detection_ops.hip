@@ -9,6 +9,7 @@
 // All are HBM/latency-bound gather kernels: coalesced 16-B channel vectors, wavefront reductions, no MFMA.
 #include "common.h"
 #include "../../include/slender_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -293,6 +294,106 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a, float* 
       for (int e = 0; e < 8; ++e) out[i * 8 + e] = acc[e] / count;
     }
   }
+}
+
+// Tiled ROIAlign backward: one workgroup per (roi, 32-channel chunk) accumulates dX for the roi's footprint in 16x16-pixel LDS
+// tiles in fixed point (ds_add_u32, see deform_conv.hip for the measurement behind that choice) and flushes each tile with one
+// global atomic per touched element, instead of 4 corners x samples x channels global atomics per bin.  Scale: an element
+// receives at most sum_bins |g_bin| <= 64 * max|g| (the bilinear weights of a bin's samples, divided by the sample count, sum to
+// <= 1), so 2^(24 - ex) with max|g| < 2^ex cannot overflow 31 bits.
+constexpr int ROI_T = 16;    // tile edge (pixels)
+constexpr int ROI_CC = 32;   // channels per workgroup
+__global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(const RoiArgs a, const float* __restrict__ dout, float* __restrict__ dx) {
+  constexpr int PS = ROI_CC + 1, L = ROI_CC / 8;
+  __shared__ int win[ROI_T * ROI_T * PS];
+  __shared__ float smax[4];
+  const int tid = threadIdx.x, r = blockIdx.x, c0 = blockIdx.y * ROI_CC;
+  const int cl = tid % L, bl = tid / L, nb = a.PH * a.PW;
+  const float* roi = a.rois + (long long)r * (a.rotated ? 6 : 5);
+  const int b = (int)roi[0];
+  float start_h, start_w, roi_h, roi_w, cth = 1.f, sth = 0.f, ctr_h = 0.f, ctr_w = 0.f;
+  float fx0, fx1, fy0, fy1;   // footprint bounds (feature coordinates) of all sample points
+  if (a.rotated) {
+    ctr_w = roi[1] * a.scale - 0.5f; ctr_h = roi[2] * a.scale - 0.5f;
+    roi_w = roi[3] * a.scale; roi_h = roi[4] * a.scale;
+    const float theta = roi[5] * 3.14159265358979323846f / 180.0f;
+    cth = cosf(theta); sth = sinf(theta);
+    start_h = -roi_h / 2.0f; start_w = -roi_w / 2.0f;
+    const float ex = 0.5f * (fabsf(roi_w * cth) + fabsf(roi_h * sth)), ey = 0.5f * (fabsf(roi_w * sth) + fabsf(roi_h * cth));
+    fx0 = ctr_w - ex; fx1 = ctr_w + ex; fy0 = ctr_h - ey; fy1 = ctr_h + ey;
+  } else {
+    start_w = roi[1] * a.scale - 0.5f; start_h = roi[2] * a.scale - 0.5f;
+    roi_w = roi[3] * a.scale - 0.5f - start_w; roi_h = roi[4] * a.scale - 0.5f - start_h;
+    fx0 = fminf(start_w, start_w + roi_w); fx1 = fmaxf(start_w, start_w + roi_w);
+    fy0 = fminf(start_h, start_h + roi_h); fy1 = fmaxf(start_h, start_h + roi_h);
+  }
+  const float bin_h = roi_h / (float)a.PH, bin_w = roi_w / (float)a.PW;
+  const int gh = a.sampling_ratio > 0 ? a.sampling_ratio : (int)ceilf(roi_h / (float)a.PH);
+  const int gw = a.sampling_ratio > 0 ? a.sampling_ratio : (int)ceilf(roi_w / (float)a.PW);
+  const float count = fmaxf((float)(gh * gw), 1.f);
+  // pixel window that can receive anything (samples outside [-1, H] x [-1, W] are dropped; the rest clamp into the map)
+  const int wx0 = max(0, (int)floorf(fmaxf(fx0, -1.f))), wx1 = min(a.W - 1, (int)floorf(fminf(fx1, (float)a.W)) + 1);
+  const int wy0 = max(0, (int)floorf(fmaxf(fy0, -1.f))), wy1 = min(a.H - 1, (int)floorf(fminf(fy1, (float)a.H)) + 1);
+  if (wx1 < wx0 || wy1 < wy0 || gh <= 0 || gw <= 0) return;
+  // fixed-point scale from max |g| of this (roi, chunk)
+  float gmax = 0.f;
+  for (int bin = bl; bin < nb; bin += 256 / L) {
+    const float* gp = dout + ((long long)r * nb + bin) * a.C + c0 + cl * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gmax = fmaxf(gmax, fabsf(gp[e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+  if ((tid & 63) == 0) smax[tid >> 6] = gmax;
+  __syncthreads();
+  gmax = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+  if (gmax == 0.f || !(gmax < 3.0e38f)) return;   // nothing to add / non-finite gradient (the loss is already non-finite then)
+  int ex = 0;
+  (void)frexpf(gmax, &ex);
+  const float S = ldexpf(1.f, 24 - ex) / count, invS = ldexpf(1.f, ex - 24);
+  const long long base = ((long long)b * a.H) * a.W;
+  for (int ty = wy0; ty <= wy1; ty += ROI_T)
+    for (int tx = wx0; tx <= wx1; tx += ROI_T) {
+      for (int i = tid; i < ROI_T * ROI_T * PS; i += 256) win[i] = 0;
+      __syncthreads();
+      for (int bin = bl; bin < nb; bin += 256 / L) {
+        const int ph = bin / a.PW, pw = bin - ph * a.PW;
+        const float* gp = dout + ((long long)r * nb + bin) * a.C + c0 + cl * 8;
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = gp[e] * S;
+        for (int iy = 0; iy < gh; ++iy) {
+          const float yy = start_h + ph * bin_h + (iy + 0.5f) * bin_h / (float)gh;
+          for (int ix = 0; ix < gw; ++ix) {
+            const float xx = start_w + pw * bin_w + (ix + 0.5f) * bin_w / (float)gw;
+            float y = yy, x = xx;
+            if (a.rotated) { y = yy * cth - xx * sth + ctr_h; x = yy * sth + xx * cth + ctr_w; }
+            int yl, xl, yh, xh; float w[4]; bool valid;
+            bilinear_setup(y, x, a.H, a.W, yl, xl, yh, xh, w, valid);
+            if (!valid) continue;
+            const int ys[2] = {yl - ty, yh - ty}, xs[2] = {xl - tx, xh - tx};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int py = ys[k >> 1], px = xs[k & 1];
+              if (py < 0 || py >= ROI_T || px < 0 || px >= ROI_T) continue;
+              int* wp = win + (py * ROI_T + px) * PS + cl * 8;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) atomicAdd(wp + e, __float2int_rn(g[e] * w[k]));
+            }
+          }
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < ROI_T * ROI_T * ROI_CC; i += 256) {
+        const int c = i % ROI_CC, p = i / ROI_CC;
+        const int q = win[p * PS + c];
+        if (q != 0) {
+          const int py = ty + p / ROI_T, px = tx + p % ROI_T;
+          atomicAdd(dx + ((base + (long long)py * a.W + px) * a.C) + c0 + c, (float)q * invS);
+        }
+      }
+      __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- box losses on XYXY
@@ -590,6 +691,12 @@ extern "C" int sod_roi_align_bwd(const float* dout, const float* rois, float* dx
   int rc = roi_fill(a, dx, rois, R, N, H, W, C, PH, PW, spatial_scale, sampling_ratio, rotated);   // x unused in bwd
   if (rc || !dout || !dx) return rc ? rc : SOD_EARG;
   if (R == 0) return SOD_OK;
+  static const int plain = getenv("SOD_ROI_PLAIN") ? atoi(getenv("SOD_ROI_PLAIN")) : 0;
+  if (!plain && C % ROI_CC == 0 && C / ROI_CC <= 65535) {
+    SOD_LAUNCH(roi_align_bwd_tile_kernel, dim3(R, C / ROI_CC), dim3(256), 0, (hipStream_t)stream, a, dout, dx);
+    SOD_CHECK_LAUNCH();
+    return SOD_OK;
+  }
   SOD_LAUNCH(roi_align_kernel<true>, dim3(nblk((long long)R * PH * PW * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream, a, nullptr, dout, dx);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
