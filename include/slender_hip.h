@@ -264,7 +264,9 @@ int sod_fastrcnn_box_loss_bwd(const float* pred, const int* gt_classes, const fl
 /* ---------------------------------------------------------------------------------------------------------
  * RepPointsDetector (slender_det/modeling/meta_arch/reppoints/rpd.py:45-798), X = sum of level pixels, point rows pitched by ld.
  * sod_reppoints_dcn_offset: out[r,2k] = scale*pts[r,2k+1] - base_y[k], out[r,2k+1] = scale*pts[r,2k] - base_x[k] (xy->yx flip and
- *   dcn_base_offset of rpd.py:105-110,621-635; subtract_base=0, scale=gradient_mul gives the backward of the same expression).
+ *   dcn_base_offset of rpd.py:105-110,621-635; subtract_base=0, scale=gradient_mul gives the backward of the same expression);
+ *   flip_xy=0 keeps the channel order (PointSetHead "Supervised Offset", meta/heads/pointset_head.py:137-140, subtracts the base
+ *   from the un-flipped points).
  * sod_points2bbox_*: "minmax" transform of rpd.py:221-249 for ONE level: point k = (pts[2k] (+add[2k]))*point_stride + w*grid_stride, ...;
  *   boxes/argidx are level slices of (N,X,4)/(N,X) buffers (img strides in elements); bwd scatters to the arg points and writes
  *   whole rows (fp32 and/or bf16).
@@ -280,7 +282,7 @@ int sod_fastrcnn_box_loss_bwd(const float* pred, const int* gt_classes, const fl
  *   out3 = {focal/max(1,normalizer), init_weight*init_sum/max(1,init_rows), refine_sum/max(1,normalizer)}.
  * --------------------------------------------------------------------------------------------------------- */
 int sod_reppoints_dcn_offset(const float* pts, float* out, long long rows, int ld, int num_points, float scale, int subtract_base,
-                             void* stream);
+                             int flip_xy, void* stream);
 int sod_points2bbox_fwd(const float* pts, const float* add, int ld, int N, int H, int W, float grid_stride, float point_stride,
                         int num_points, float* boxes, long long box_img_stride, unsigned* argidx, long long arg_img_stride, void* stream);
 int sod_points2bbox_bwd(const float* dboxes, long long box_img_stride, const unsigned* argidx, long long arg_img_stride, int ld,

@@ -1,0 +1,221 @@
+"""Oracle PointSetHead (CPU, fp32, NCHW, plain torch) — TEST INFRASTRUCTURE, never imported by the product path.
+
+Restates slender_det/modeling/meta_arch/meta/heads/pointset_head.py (``_forward`` :101-156, ``losses`` :158-325, ``pts_to_bbox``
+:327-349 "minmax", ``point_targets`` :352-412, ``bbox_targets`` :415-470, ``inference_single_image`` :511-581) with
+meta_head.py:21-104 and heads/utils.py:14-80.  Pinned against tests/golden/pointset_head_{empty,sup,unsup}.npz, produced by the
+reference's own Python (tests/golden/make_golden_reppoints.py; DeformConv / focal / smooth-L1 / pairwise_iou are restated there
+because detectron2 and fvcore exist nowhere).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import detection as od
+from . import losses as ol
+from .deform_conv import deform_conv2d
+from .model import _RoundSTE
+from .reppoints import center_grid
+
+
+def point_targets(points, pts_strides, gt_boxes, gt_labels, num_classes, scale=4):
+    """pointset_head.py:352-412: nearest point of the gt's level, earliest strict minimum wins."""
+    if points.shape[0] == 0 or gt_boxes.shape[0] == 0:
+        raise ValueError("No gt or bboxes")
+    lvl = torch.log2(pts_strides).int()
+    lmin, lmax = int(lvl.min()), int(lvl.max())
+    ctr = (gt_boxes[:, :2] + gt_boxes[:, 2:]) / 2
+    wh = (gt_boxes[:, 2:] - gt_boxes[:, :2]).clamp(min=1e-6)
+    glvl = ((torch.log2(wh[:, 0] / scale) + torch.log2(wh[:, 1] / scale)) / 2).int().clamp(lmin, lmax)
+    P = points.shape[0]
+    assigned = torch.zeros(P, dtype=torch.long)
+    adist = torch.full((P,), float("inf"))
+    arange = torch.arange(P)
+    for g in range(gt_boxes.shape[0]):
+        sel = lvl == glvl[g]
+        d = ((points[sel] - ctr[g:g + 1]) / wh[g:g + 1]).norm(dim=1)
+        md, mi = torch.topk(d, 1, largest=False)
+        idx = arange[sel][mi]
+        better = md < adist[idx]
+        idx = idx[better]
+        assigned[idx] = g + 1
+        adist[idx] = md[better]
+    boxes = torch.zeros(P, 4)
+    labels = torch.full((P,), num_classes, dtype=torch.long)
+    pos = assigned > 0
+    labels[pos] = gt_labels[assigned[pos] - 1].long()
+    boxes[pos] = gt_boxes[assigned[pos] - 1]
+    return boxes, labels
+
+
+def bbox_targets(cand, gt_boxes, gt_labels, num_classes, pos_thr=0.5, neg_thr=0.4):
+    """pointset_head.py:415-470 (MaxIoU assign with gt_max_matching; the candidates are clamped to >= 0 first)."""
+    cand = cand.clamp(min=0)
+    ov = od.pairwise_iou(cand, gt_boxes)
+    labels = torch.full((ov.shape[0],), num_classes, dtype=torch.long)
+    mx, am = ov.max(dim=1)
+    gmx, _ = ov.max(dim=0)
+    fg = mx >= pos_thr
+    labels[fg] = gt_labels[am[fg]].long()
+    tie = torch.nonzero(ov == gmx)[:, 0]
+    labels[tie] = gt_labels[am[tie]].long()
+    boxes = torch.zeros(ov.shape[0], 4)
+    fg = (labels >= 0) & (labels != num_classes)
+    boxes[fg] = gt_boxes[am[fg]]
+    return boxes, labels
+
+
+def pts_to_bbox(pts):
+    x, y = pts[:, 0::2], pts[:, 1::2]
+    return torch.stack((x.min(1)[0], y.min(1)[0], x.max(1)[0], y.max(1)[0]), 1)
+
+
+def losses(centers, pts_strides, cls_outs, pts_init, pts_refine, gt_boxes, gt_classes, num_classes, num_points=9, scale=4, alpha=0.25,
+           gamma=2.0, w_cls=1.0, w_init=0.5, w_refine=1.0):
+    """pointset_head.py:158-325.  cls_outs (N,X,K), pts_* (N,X,2P); centers (X,2), pts_strides (X,)."""
+    pred_cls, pred_init, pred_refine, tgt_cls, tgt_init, tgt_refine = [], [], [], [], [], []
+    npi = npr = 0
+    norm = (scale * pts_strides).reshape(-1, 1)
+    rep = centers.repeat(1, num_points)
+    st = pts_strides.reshape(-1, 1)
+    for i in range(cls_outs.shape[0]):
+        ib_t, il_t = point_targets(centers, pts_strides, gt_boxes[i], gt_classes[i], num_classes, scale)
+        init_box = pts_to_bbox(pts_init[i] * st + rep)
+        fg = (il_t >= 0) & (il_t != num_classes)
+        pred_init.append(init_box[fg] / norm[fg]); tgt_init.append(ib_t[fg] / norm[fg]); npi += int(fg.sum())
+        rb_t, rl_t = bbox_targets(init_box.detach(), gt_boxes[i], gt_classes[i], num_classes)
+        refine_box = pts_to_bbox(pts_refine[i] * st + rep)
+        fg = (rl_t >= 0) & (rl_t != num_classes)
+        pred_refine.append(refine_box[fg] / norm[fg]); tgt_refine.append(rb_t[fg] / norm[fg]); npr += int(fg.sum())
+        t = torch.zeros_like(cls_outs[i])
+        t[fg, rl_t[fg]] = 1
+        pred_cls.append(cls_outs[i]); tgt_cls.append(t)
+    loss_cls = ol.sigmoid_focal_loss(torch.cat(pred_cls), torch.cat(tgt_cls), alpha, gamma, "sum") / max(1, npr) * w_cls
+    loss_init = ol.smooth_l1_loss(torch.cat(pred_init), torch.cat(tgt_init), 0.11, "sum") / max(1, npi) * w_init
+    loss_refine = ol.smooth_l1_loss(torch.cat(pred_refine), torch.cat(tgt_refine), 0.11, "sum") / max(1, npr) * w_refine
+    return {"loss_cls": loss_cls, "loss_pts_init": loss_init, "loss_pts_refine": loss_refine}
+
+
+def inference_single_image(logits, boxes, bounds, image_size, topk, score_thr, nms_thr, max_det):
+    """pointset_head.py:511-581 for one image: logits (X,K), decoded refine boxes (X,4)."""
+    K = logits.shape[1]
+    B, S, C = [], [], []
+    for l in range(len(bounds) - 1):
+        sl = slice(bounds[l], bounds[l + 1])
+        b = boxes[sl].clone()
+        b[:, 0::2] = b[:, 0::2].clamp(0, image_size[1])
+        b[:, 1::2] = b[:, 1::2].clamp(0, image_size[0])
+        p = logits[sl].flatten().sigmoid()
+        k = min(topk, p.shape[0])
+        prob, idx = p.sort(descending=True)
+        prob, idx = prob[:k], idx[:k]
+        keep = prob > score_thr
+        prob, idx = prob[keep], idx[keep]
+        B.append(b[idx // K]); S.append(prob); C.append(idx % K)
+    B, S, C = torch.cat(B), torch.cat(S), torch.cat(C)
+    keep = od.batched_nms(B, S, C, nms_thr)[:max_det]
+    return B[keep], S[keep], C[keep]
+
+
+class OraclePointSetHead:
+    """Functional PointSetHead over fp32 tensors (conv weights KCRS) named like the product modules."""
+
+    def __init__(self, params, cfg, emulate_bf16=False):
+        self.p, self.c, self.emu = params, cfg, emulate_bf16
+
+    @classmethod
+    def from_reference_arrays(cls, arrays, feat_adaption, res_refine):
+        """``param:<reference state_dict name>`` arrays of the golden fixture -> product-style names."""
+        ref = {k[len("param:"):]: torch.tensor(v.astype("float32")).requires_grad_(True) for k, v in arrays.items() if k.startswith("param:")}
+        p = {}
+        for tower in ("cls_subnet", "loc_subnet"):
+            for i in range(3):
+                p[f"{tower}.{i}.conv.weight"], p[f"{tower}.{i}.conv.bias"] = ref[f"{tower}.{3 * i}.weight"], ref[f"{tower}.{3 * i}.bias"]
+                p[f"{tower}.{i}.gn.weight"], p[f"{tower}.{i}.gn.bias"] = ref[f"{tower}.{3 * i + 1}.weight"], ref[f"{tower}.{3 * i + 1}.bias"]
+        ren = {"loc_init_conv": "loc_init_conv.conv", "loc_init_out": "loc_init_out.conv", "cls_out": "logits", "loc_refine_out": "offsets_refine",
+               "offset_conv": "offset_conv.conv", "offset_conv_cls": "offset_conv_cls.conv", "offset_conv_loc": "offset_conv_loc.conv",
+               "cls_conv": "cls_conv.conv" if feat_adaption == "Empty" else "cls_conv",
+               "loc_refine_conv": "loc_refine_conv.conv" if feat_adaption == "Empty" else "loc_refine_conv"}
+        for k, v in ref.items():
+            base, leaf = k.rsplit(".", 1)
+            if base in ren:
+                p[f"{ren[base]}.{leaf}"] = v
+        cfg = dict(fa=feat_adaption, res=bool(res_refine), npts=9, K=80, gmul=0.1, strides=[8, 16, 32, 64, 128], scale=4, w=(1.0, 0.5, 1.0), alpha=0.25, gamma=2.0)
+        return cls(p, cfg)
+
+    @classmethod
+    def from_hip_head(cls, head, emulate_bf16=False):
+        from slenderobjdet_amd.layers.deform_conv import DeformConv
+        from slenderobjdet_amd.layers.nn import HipConv2d, HipGroupNorm
+
+        p = {}
+        for name, m in head.named_modules():
+            if isinstance(m, (HipConv2d, DeformConv)):
+                p[name + ".weight"] = m.weight.detach().float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+                if m.bias is not None:
+                    p[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(True)
+            elif isinstance(m, HipGroupNorm):
+                p[name + ".weight"] = m.weight.detach().float().cpu().clone().requires_grad_(True)
+                p[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(True)
+        cfg = dict(fa=head.feat_adaption, res=head.res_refine, npts=head.num_points, K=head.num_classes, gmul=head.gradient_mul,
+                   strides=list(head.fpn_strides), scale=head.point_base_scale, w=(head.loss_cls_weight, head.loss_init_weight, head.loss_refine_weight),
+                   alpha=head.focal_loss_alpha, gamma=head.focal_loss_gamma)
+        return cls(p, cfg, emulate_bf16)
+
+    def _r(self, x):
+        return _RoundSTE.apply(x) if self.emu else x
+
+    def _conv(self, name, x, pad, relu=False, rows=None, f32_out=False):
+        w, b = self._r(self.p[name + ".weight"]), self.p[name + ".bias"]
+        if rows is not None:
+            w, b = w[:rows], b[:rows]
+        y = F.conv2d(x, w, b, padding=pad)
+        if relu:
+            y = torch.relu(y)
+        return y if f32_out else self._r(y)
+
+    def _tower(self, name, x):
+        for i in range(3):
+            y = self._conv(f"{name}.{i}.conv", x, 1)
+            x = self._r(torch.relu(F.group_norm(y, 32, self.p[f"{name}.{i}.gn.weight"], self.p[f"{name}.{i}.gn.bias"], 1e-5)))
+        return x
+
+    def forward(self, feats):
+        """-> cls (N,X,K), pts_init (N,X,18), pts_refine (N,X,18), hw."""
+        c = self.c
+        n2 = 2 * c["npts"]
+        base = torch.arange(-1, 2, dtype=torch.float32)
+        base_off = torch.stack((base.repeat_interleave(3), base.repeat(3)), 1).reshape(1, -1, 1, 1)
+        hook = (lambda s: _RoundSTE.apply(s)) if self.emu else None
+        C, I, R = [], [], []
+        for f in feats:
+            N = f.shape[0]
+            cf, lf = self._tower("cls_subnet", f), self._tower("loc_subnet", f)
+            oi = self._conv("loc_init_out.conv", self._conv("loc_init_conv.conv", lf, 1, relu=True), 0, rows=n2, f32_out=True)
+            if c["fa"] == "Empty":
+                cfa = self._conv("cls_conv.conv", cf, 1, relu=True)
+                lfa = self._conv("loc_refine_conv.conv", lf, 1, relu=True)
+            else:
+                if c["fa"] == "Unsupervised Offset":
+                    oc = ol_ = self._conv("offset_conv.conv", lf, 0, rows=n2, f32_out=True)
+                elif c["fa"] == "Split Unsup Offset":
+                    oc = self._conv("offset_conv_cls.conv", lf, 0, rows=n2, f32_out=True)
+                    ol_ = self._conv("offset_conv_loc.conv", lf, 0, rows=n2, f32_out=True)
+                else:
+                    oc = ol_ = (1 - c["gmul"]) * oi.detach() + c["gmul"] * oi - base_off
+                cfa = self._r(torch.relu(deform_conv2d(cf, oc, self._r(self.p["cls_conv.weight"]), None, 1, 1, 1, sample_hook=hook)))
+                lfa = self._r(torch.relu(deform_conv2d(lf, ol_, self._r(self.p["loc_refine_conv.weight"]), None, 1, 1, 1, sample_hook=hook)))
+            co = self._conv("logits", cfa, 0, f32_out=True)
+            ro = self._conv("offsets_refine", lfa, 0, rows=n2, f32_out=True)
+            if c["res"]:
+                ro = ro + oi.detach()
+            C.append(co.permute(0, 2, 3, 1).reshape(N, -1, co.shape[1]))
+            I.append(oi.permute(0, 2, 3, 1).reshape(N, -1, n2))
+            R.append(ro.permute(0, 2, 3, 1).reshape(N, -1, n2))
+        return torch.cat(C, 1), torch.cat(I, 1), torch.cat(R, 1), [tuple(f.shape[2:]) for f in feats]
+
+    def losses(self, feats, gt_boxes, gt_classes):
+        c = self.c
+        cls, pi, pr, hw = self.forward(feats)
+        centers, st = center_grid(hw, c["strides"])
+        return losses(centers, st, cls, pi, pr, gt_boxes, gt_classes, c["K"], c["npts"], c["scale"], c["alpha"], c["gamma"], *c["w"])

@@ -25,14 +25,14 @@ inline int rp_nblk(long long n, int cap = RP_RED) {
 // out[r, 2k] = scale * in[r, 2k+1] - by[k] ; out[r, 2k+1] = scale * in[r, 2k] - bx[k]   (by = k / ks - pad, bx = k % ks - pad)
 // Forward: scale 1, subtract_base 1.  Backward is the same permutation with scale = gradient_mul and no base.
 __global__ __launch_bounds__(256) void rp_dcn_offset_kernel(const float* __restrict__ in, float* __restrict__ out, long long rows, int ld,
-                                                            int npts, int ks, float scale, int sub_base) {
+                                                            int npts, int ks, float scale, int sub_base, int flip) {
   const long long total = rows * ld;
   const int pad = (ks - 1) / 2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int j = (int)(i % ld);
     float v = 0.f;
     if (j < 2 * npts) {
-      v = scale * in[i - j + (j ^ 1)];
+      v = scale * in[i - j + (flip ? (j ^ 1) : j)];
       if (sub_base) {
         const int k = j >> 1;
         v -= (float)(((j & 1) == 0 ? k / ks : k % ks) - pad);
@@ -362,14 +362,14 @@ __global__ void rp_finalize_kernel(const float* __restrict__ focal_sum, const fl
 }  // namespace
 
 extern "C" int sod_reppoints_dcn_offset(const float* pts, float* out, long long rows, int ld, int num_points, float scale, int subtract_base,
-                                        void* stream) {
+                                        int flip_xy, void* stream) {
   if (!pts || !out || rows < 0 || num_points <= 0 || ld < 2 * num_points) return SOD_EARG;
   int ks = 1;
   while (ks * ks < num_points) ++ks;
   if (ks * ks != num_points || !(ks & 1)) return SOD_EARG;
   if (rows == 0) return SOD_OK;
   SOD_LAUNCH(rp_dcn_offset_kernel, dim3(rp_nblk(rows * ld, 8192)), dim3(256), 0, (hipStream_t)stream, pts, out, rows, ld, num_points, ks, scale,
-             subtract_base);
+             subtract_base, flip_xy);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -534,12 +534,13 @@ def add_up2(a, b):
 
 
 # ----------------------------------------------------------------------------------------------- RepPoints
-def reppoints_dcn_offset(pts, num_points, scale=1.0, subtract_base=True):
+def reppoints_dcn_offset(pts, num_points, scale=1.0, subtract_base=True, flip_xy=True):
     """pts (..., ld) fp32 point rows (x, y interleaved) -> deformable-conv offsets (dy, dx interleaved) minus the kernel grid."""
     _chk(pts, torch.float32, "pts")
     ld = pts.shape[-1]
     out = torch.empty_like(pts)
-    call("sod_reppoints_dcn_offset", ptr(pts), ptr(out), pts.numel() // ld, ld, num_points, float(scale), 1 if subtract_base else 0, stream_ptr())
+    call("sod_reppoints_dcn_offset", ptr(pts), ptr(out), pts.numel() // ld, ld, num_points, float(scale), 1 if subtract_base else 0,
+         1 if flip_xy else 0, stream_ptr())
     return out
 
 

@@ -3,3 +3,4 @@ from .fcos import FCOS, FCOSV2, FCOSHead
 from .retinanet import RetinaNet, RetinaNetHead
 from .reppoints import RepPointsDetector
 from .rcnn import GeneralizedRCNN, ProposalNetwork
+from .meta import MEAT_HEADS_REGISTRY, AblationMetaArch, PointSetHead

@@ -31,15 +31,15 @@ class _DcnOffsetFn(torch.autograd.Function):
     """dcn_offset = flip_xy((1 - m) * pts.detach() + m * pts) - dcn_base_offset   (rpd.py:621-635)."""
 
     @staticmethod
-    def forward(ctx, pts, num_points, gradient_mul):
-        ctx.cfg = (num_points, gradient_mul)
-        return HF.reppoints_dcn_offset(pts, num_points, 1.0, True)
+    def forward(ctx, pts, num_points, gradient_mul, flip_xy=True):
+        ctx.cfg = (num_points, gradient_mul, flip_xy)
+        return HF.reppoints_dcn_offset(pts, num_points, 1.0, True, flip_xy)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, doff):
-        num_points, gradient_mul = ctx.cfg
-        return HF.reppoints_dcn_offset(doff.contiguous(), num_points, gradient_mul, False), None, None
+        num_points, gradient_mul, flip_xy = ctx.cfg
+        return HF.reppoints_dcn_offset(doff.contiguous(), num_points, gradient_mul, False, flip_xy), None, None, None
 
 
 class _RepPointsLossFn(torch.autograd.Function):
@@ -56,10 +56,11 @@ class _RepPointsLossFn(torch.autograd.Function):
         centers, strides, lvl_start = model.point_grid(hw)
         obj, init_lab, cls, refine_lab = model.get_ground_truth(centers, strides, lvl_start, init_boxes, gt_instances, image_sizes)
         focal_sum, _ = HF.focal_loss_fwd(logits_buf.view(N * X, K), cls.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma)
+        strides = model.box_norm(strides)        # the box losses divide by 4 * this
         init_sums = HF.reppoints_box_loss_fwd(init_boxes, init_lab, obj, strides, -1, model.smooth_l1_beta)
         refine_sums = HF.reppoints_box_loss_fwd(refine_boxes, refine_lab, cls, strides, K, model.smooth_l1_beta)
-        out3 = HF.reppoints_finalize(focal_sum, init_sums, refine_sums, model.loss_normalizer, model.loss_normalizer_momentum, N,
-                                     model.loss_init_weight)
+        out3 = HF.reppoints_finalize(focal_sum, init_sums, refine_sums, model.loss_normalizer, model.loss_normalizer_momentum,
+                                     model.normalizer_images(N), model.loss_init_weight)
         ctx.model, ctx.geo, ctx.nl = model, geo, nl
         ctx.save_for_backward(logits_buf, init_boxes, init_arg, refine_boxes, refine_arg, obj, init_lab, cls, refine_lab, strides,
                               init_sums, model.loss_normalizer.clone(), *oi, *cf, *rf)
@@ -187,6 +188,13 @@ class RepPointsDetector(nn.Module):
 
     preprocess_image = FCOSV2.preprocess_image
     postprocess = FCOSV2.postprocess
+    res_refine = True                       # offsets_refine(...) + offsets_init.detach()  (rpd.py:639-642)
+
+    def box_norm(self, strides):            # smooth-L1 inputs are divided by 4 * stride (rpd.py:384,392)
+        return strides
+
+    def normalizer_images(self, n):         # num_foreground = #fg / N feeds the EMA normaliser (rpd.py:366-376)
+        return n
 
     # ------------------------------------------------------------------ geometry
     def point_grid(self, hw):
@@ -244,7 +252,8 @@ class RepPointsDetector(nn.Module):
             o, s, ps = offs[l], self.strides[l], self.point_scales[l]
             HF.points2bbox_fwd(oi[l], None, s, ps, self.num_points, init_boxes.view(-1)[o * 4:], X * 4, init_arg.view(-1)[o:], X)
             # offsets_refine(...) + offsets_init.detach()  (rpd.py:639-642)
-            HF.points2bbox_fwd(rdelta[l], oi[l], s, ps, self.num_points, refine_boxes.view(-1)[o * 4:], X * 4, refine_arg.view(-1)[o:], X)
+            HF.points2bbox_fwd(rdelta[l], oi[l] if self.res_refine else None, s, ps, self.num_points, refine_boxes.view(-1)[o * 4:], X * 4,
+                               refine_arg.view(-1)[o:], X)
         return logits_buf, rdelta, init_boxes, init_arg, refine_boxes, refine_arg, (hw, offs, X)
 
     # ------------------------------------------------------------------ targets (rpd.py:276-333)

@@ -168,6 +168,97 @@ def random_boxes(g, n, H, W):
     return b[keep]
 
 
+class _OracleDeformConv(torch.nn.Module):
+    """Stand-in for detectron2.layers.DeformConv (absent): the restated op of oracle/deform_conv.py, itself pinned by the
+    reference's own known-answer test (tests/golden/deform_conv_kat.npz)."""
+
+    def __init__(self, cin, cout, k, stride, pad):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.empty(cout, cin, k, k))
+        torch.nn.init.kaiming_uniform_(self.weight, nonlinearity="relu")
+        self.stride, self.pad = stride, pad
+
+    def forward(self, x, offset):
+        sys.path.insert(0, os.path.join(OUT, "..", ".."))
+        from oracle.deform_conv import deform_conv2d
+
+        return deform_conv2d(x, offset, self.weight, None, self.stride, self.pad, 1)
+
+
+def pointset_head_golden(g):
+    """PointSetHead (meta/heads/pointset_head.py + meta_head.py + utils.py) built and run by the reference's own Python on CPU:
+    towers, init / refine points, feature adaption, point_targets, bbox_targets, the three losses and parameter gradients."""
+    from detectron2 import layers as d2l
+
+    class Registry:
+        def __init__(self, name):
+            self.m = {}
+
+        def register(self, obj=None):
+            if obj is None:
+                return lambda o: self.register(o)
+            self.m[obj.__name__] = obj
+            return obj
+
+        def get(self, n):
+            return self.m[n]
+
+    _stub("detectron2.utils.registry", Registry=Registry)
+    d2l.ShapeSpec = SimpleNamespace
+    d2l.get_norm = lambda norm, c: torch.nn.GroupNorm(32, c) if norm == "GN" else None
+    d2l.DeformConv = _OracleDeformConv
+    d2l.cat = torch.cat
+    _stub("refheads")
+    _load("refheads.meta_head", "slender_det/modeling/meta_arch/meta/heads/meta_head.py", "refheads")
+    _load("refheads.utils", "slender_det/modeling/meta_arch/meta/heads/utils.py", "refheads")
+    psh = _load("refheads.pointset_head", "slender_det/modeling/meta_arch/meta/heads/pointset_head.py", "refheads")
+    meta = {}
+    C = 32
+    hw = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    strides = [8, 16, 32, 64, 128]
+    for tag, fa, res in (("empty", "Empty", True), ("sup", "Supervised Offset", True), ("unsup", "Unsupervised Offset", False)):
+        head_params = SimpleNamespace(
+            IN_FEATURES=["p3", "p4", "p5", "p6", "p7"], FPN_STRIDES=strides, NUM_CLASSES=80, FEAT_CHANNELS=C, STACK_CONVS=3, NORM="GN",
+            FEAT_ADAPTION=fa, RES_REFINE=res, LOC_FEAT_CHANNELS=C, GRADIENT_MUL=0.1, PRIOR_PROB=0.01, FOCAL_LOSS_GAMMA=2.0,
+            FOCAL_LOSS_ALPHA=0.25, LOSS_CLS_WEIGHT=1.0, LOSS_LOC_INIT_WEIGHT=0.5, LOSS_LOC_REFINE_WEIGHT=1.0, SCORE_THRESH_TEST=0.05,
+            TOPK_CANDIDATES_TEST=1000, NMS_THRESH_TEST=0.5, NUM_POINTS=9, POINT_BASE_SCALE=4, TRANSFORM_METHOD="minmax", MOMENT_MUL=0.01)
+        cfg = SimpleNamespace(MODEL=SimpleNamespace(META_ARCH=head_params), TEST=SimpleNamespace(DETECTIONS_PER_IMAGE=100))
+        torch.manual_seed(7)
+        head = psh.PointSetHead(cfg, [SimpleNamespace(channels=C, stride=s) for s in strides])
+        with torch.no_grad():      # larger-than-init weights so that boxes / IoUs are not degenerate; fp16-representable values on disk
+            for n, p in head.named_parameters():
+                if n.endswith("weight") and p.dim() == 4 and "subnet" not in n:
+                    p.mul_(6.0)
+                p.copy_(p.half().float())
+        head.train()
+        feats = [(torch.randn(2, C, h, w, generator=g) * 1.5).half().float() for h, w in hw]
+        gtb = [random_boxes(g, 5, 128, 160), random_boxes(g, 8, 128, 160)]
+        gtc = [torch.randint(0, 80, (len(b),), generator=g) for b in gtb]
+        inst = [SimpleNamespace(gt_boxes=Boxes(b), gt_classes=c) for b, c in zip(gtb, gtc)]
+        Boxes.to = lambda self, *a, **k: self
+        images = SimpleNamespace(image_sizes=[(128, 160), (128, 160)])
+        losses = head(images, feats, inst)
+        tot = sum(losses.values())
+        params = dict(head.named_parameters())
+        grads = torch.autograd.grad(tot, list(params.values()), allow_unused=True)
+        out = {"hw": np.array(hw), "strides": np.array(strides), "channels": np.array(C), "res_refine": np.array(res),
+               "losses": np.array([float(losses[k]) for k in ("loss_cls", "loss_pts_init", "loss_pts_refine")])}
+        for l, f in enumerate(feats):
+            out[f"feat{l}"] = f.numpy().astype(np.float16)
+        for i in range(2):
+            out[f"gt_boxes{i}"], out[f"gt_classes{i}"] = gtb[i].numpy(), gtc[i].numpy()
+        for (n, p), gr in zip(params.items(), grads):
+            out["param:" + n] = p.detach().numpy().astype(np.float16)
+            out["gradnorm:" + n] = np.array(0.0 if gr is None else float(gr.norm()))
+        for n in ("cls_out.weight", "loc_refine_out.weight", "loc_init_out.weight"):
+            out["grad:" + n] = grads[list(params).index(n)].numpy()
+        np.savez_compressed(os.path.join(OUT, f"pointset_head_{tag}.npz"), **out)
+        meta[f"pointset_head_{tag}.npz"] = ("reference: meta/heads/pointset_head.py:19-470 + meta_head.py:21-104 + utils.py (reference Python"
+                                            + (" x restated DeformConv" if fa != "Empty" else "") + " x restated focal / smooth-L1 / pairwise_iou)")
+        print(tag, {k: float(v) for k, v in losses.items()})
+    return meta
+
+
 def main():
     assert os.path.isdir(REF), "runs only in the build container (needs /root/reference)"
     rm, rpd = install()
@@ -239,6 +330,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "reppoints_losses.npz"), **res)
     meta["reppoints_losses.npz"] = ("reference Python (rpd.py:221-402, rep_matcher.py) x restated third-party ops "
                                     "(pairwise_iou, Matcher, sigmoid_focal_loss_jit, smooth_l1_loss)")
+    meta.update(pointset_head_golden(g))
     mp = os.path.join(OUT, "meta.json")
     old = json.load(open(mp)) if os.path.exists(mp) else {}
     old.update(meta)

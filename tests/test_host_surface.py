@@ -144,6 +144,26 @@ def test_rotated_rcnn_builds_from_repo_config_cpu():
     assert sum(p.numel() for p in roi.parameters()) - pad_roi == ref_roi
 
 
+def test_ablation_meta_arch_builds_from_repo_config_cpu():
+    """AblationMetaArch resolves its head through MEAT_HEADS_REGISTRY (the reference's spelling) from META_ARCH.NAME."""
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.modeling.meta_arch import MEAT_HEADS_REGISTRY
+
+    assert "PointSetHead" in MEAT_HEADS_REGISTRY
+    cfg = fresh_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(__file__), "..", "configs", "ablation_studies", "pointset", "supervised_adaptive.yaml"))
+    cfg.MODEL.DEVICE = "cpu"
+    m = build_model(cfg)
+    h = m.head
+    assert h.feat_adaption == "Supervised Offset" and h.res_refine and h.cls_conv.bias is None and h.stacked_convs == 3
+    C = 256      # reference parameter count of this head (pointset_head.py:19-88), pitch padding excluded
+    ref = 2 * 3 * (C * C * 9 + C + 2 * C) + (C * C * 9 + C) + (C * 18 + 18) + 2 * (C * C * 9) + (C * 80 + 80) + (C * 18 + 18)
+    assert sum(p.numel() for p in h.parameters()) - 2 * 6 * (C + 1) == ref
+    cfg.MODEL.META_ARCH.NAME = "LRTBHead"
+    with pytest.raises(KeyError):
+        build_model(cfg)
+
+
 def test_optimizer_param_groups_follow_reference_rules():
     from slenderobjdet_amd.layers.nn import ConvGnRelu
     from slenderobjdet_amd.solver import get_default_optimizer_params
