@@ -104,7 +104,7 @@ class _BottleneckStageFn(torch.autograd.Function):
             if k == 0:
                 if ctx.needs_input_grad[0]:
                     if blk.shortcut is not None:
-                        dx = _dgrad(blk.shortcut, g, xin, accum=_dgrad(blk.conv1, da, xin))
+                        dx = _dgrad_pair_into_input(blk, g, da, xin)
                     else:
                         dx = _dgrad(blk.conv1, da, xin, accum=g)
             else:   # previous block's output is post-ReLU: fold its mask and the identity-path gradient into the epilogue
@@ -127,6 +127,21 @@ def _wgrad(m, g, x, arena):
 
 def _dgrad(m, g, x, accum=None, relu_mask=None):
     return HF.conv2d_dgrad(g, m.wt_bf16, (x.shape[1], x.shape[2]), m.stride, m.padding, m.dilation, accum=accum, relu_mask=relu_mask)
+
+
+def _dgrad_pair_into_input(blk, g, da, xin):
+    """d(block input) = dgrad(shortcut, g) + dgrad(conv1, da).  When both are 1x1 stride-2 convolutions (STRIDE_IN_1X1) only the even
+    (h, w) positions of the input receive gradient: the two data-gradients run as stride-1 GEMMs on the (Ho, Wo) grid (4x fewer MFMA
+    work than masking the odd positions of the full grid) and the sum is scattered into a zero tensor."""
+    sc, c1 = blk.shortcut, blk.conv1
+    if all(m.kernel_size == 1 and m.stride == 2 and m.padding == 0 for m in (sc, c1)):
+        Ho, Wo = g.shape[1], g.shape[2]
+        part = HF.conv2d_dgrad(da, c1.wt_bf16, (Ho, Wo), 1, 0, 1)
+        comp = HF.conv2d_dgrad(g, sc.wt_bf16, (Ho, Wo), 1, 0, 1, accum=part)
+        dx = torch.zeros(xin.shape, dtype=comp.dtype, device=comp.device)
+        dx[:, ::2, ::2, :] = comp
+        return dx
+    return _dgrad(sc, g, xin, accum=_dgrad(c1, da, xin))
 
 
 class BottleneckStage(nn.Sequential):
