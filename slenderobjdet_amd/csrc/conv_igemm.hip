@@ -441,6 +441,7 @@ struct WgradArgs {
   int nlev;
   float* dw;           // [K][R][S][C] fp32, accumulated atomically
   const float* qscale; // optional per-output-channel factor (folded FrozenBN scale)
+  int dbg_plain_store; // timing experiment only (SOD_WGRAD_PLAIN=1): racy plain stores instead of atomics
   int N, C, K;
   int R, S, stride, pad, dil;
   int V, nz, v_per_split;   // total virtual pixels; v_per_split multiple of 64
@@ -628,7 +629,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = c0 + (wc * 4 + j) * 16 + fr;
-        if (c < a.C) atomicAdd(a.dw + ((size_t)q * RS + tap) * a.C + c, acc[i][j][e] * qs);
+        if (c < a.C) {
+          if (a.dbg_plain_store) a.dw[((size_t)q * RS + tap) * a.C + c] = acc[i][j][e] * qs;
+          else atomicAdd(a.dw + ((size_t)q * RS + tap) * a.C + c, acc[i][j][e] * qs);
+        }
       }
     }
   }
@@ -764,6 +768,8 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st) {
   a.v_per_split = vps;
   a.nz = (V + vps - 1) / vps;
   a.div_s = make_fastdiv((uint32_t)a.S);
+  static const int dbg_plain = getenv("SOD_WGRAD_PLAIN") ? atoi(getenv("SOD_WGRAD_PLAIN")) : 0;
+  a.dbg_plain_store = dbg_plain;
   const size_t lds = 2 * 2 * 64 * 256;
   static bool attr_done = false;
   if (!attr_done) {

@@ -197,4 +197,45 @@ class RetinaNet(nn.Module):
             gt_labels, gt_deltas = self.label_anchors(anchors, gt_instances)
             out = _RetinaLossFn.apply(self, self.head.cls_score.weight, gt_labels, gt_deltas, *cls_t, *box_t)
             return {"loss_cls": out[0], "loss_box_reg": out[1]}
-        raise NotImplementedError("RetinaNet inference decode is not wired yet (ops: sod_nms, Box2BoxTransform.apply_deltas)")
+        with torch.no_grad():
+            cls_buf, box_buf, hw, offs = self.head.predict(cls_t, box_t)
+            results = self.inference(level_hw, cls_buf, box_buf, offs, images.image_sizes)
+        return self.postprocess(results, batched_inputs, images.image_sizes)
+
+    @torch.no_grad()
+    def inference(self, level_hw, cls_buf, box_buf, offs, image_sizes):
+        """retina_rotated.py:296-377: per level sigmoid over (HWA x K), top-k, score threshold, decode the surviving anchors
+        (Box2BoxTransform.apply_deltas, one kernel), class-aware NMS, top detections."""
+        from ...layers.nms import batched_nms
+        from ...structures import Boxes, Instances
+        from ..box_regression import Box2BoxTransform
+
+        A, K = self.head.num_anchors, self.num_classes
+        transform = Box2BoxTransform(weights=self.bbox_reg_weights)
+        anchors_l = grid_anchors(level_hw, self.strides, self.anchor_sizes, self.anchor_ratios, self.anchor_offset, self.device)
+        P = cls_buf.shape[1]
+        bounds = list(offs) + [P]
+        results = []
+        for i, image_size in enumerate(image_sizes):
+            B, S, C = [], [], []
+            for l, anc in enumerate(anchors_l):
+                sl = slice(bounds[l], bounds[l + 1])
+                p = cls_buf[i, sl].reshape(-1).sigmoid()                       # (HW*A*K,), anchor-major then class
+                deltas = box_buf[i, sl, : A * 4].reshape(-1, 4)
+                k = min(self.topk_candidates, deltas.shape[0])
+                prob, idx = p.sort(descending=True)
+                prob, idx = prob[:k], idx[:k]
+                keep = prob > self.score_threshold
+                prob, idx = prob[keep], idx[keep]
+                a_idx, c_idx = idx // K, idx % K
+                B.append(transform.apply_deltas(deltas[a_idx].contiguous(), anc[a_idx].contiguous()))
+                S.append(prob)
+                C.append(c_idx)
+            B, S, C = torch.cat(B), torch.cat(S), torch.cat(C)
+            keep = batched_nms(B, S, C, self.nms_threshold)[: self.max_detections_per_image]
+            r = Instances(tuple(image_size))
+            r.pred_boxes, r.scores, r.pred_classes = Boxes(B[keep]), S[keep], C[keep]
+            results.append(r)
+        return results
+
+    postprocess = FCOSV2.postprocess

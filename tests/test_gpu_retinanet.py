@@ -73,3 +73,50 @@ def train_step_retina(model, opt, data):
     model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
     opt.step()
     return total.detach()
+
+
+def test_retinanet_inference_matches_oracle(cuda):
+    """retina_rotated.py:296-377: decode + class-aware NMS of the product path's own predictions against the oracle contract."""
+    from oracle import detection as od
+    from oracle import rcnn as orc
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.modeling.anchor_generator import grid_anchors
+
+    cfg = _cfg()
+    cfg.MODEL.RETINANET.SCORE_THRESH_TEST = 0.02
+    torch.manual_seed(6)
+    model = build_model(cfg)
+    model.eval()
+    data = synthetic_batch(2, 256, 320, 31, device="cuda")
+    for d in data:
+        d.pop("instances")
+    with torch.no_grad():
+        imgs = model.preprocess_image(data)
+        feats = model.backbone(imgs.tensor)
+        feats = [feats[f] for f in model.in_features]
+        hw = [tuple(f.shape[1:3]) for f in feats]
+        ct, bt = model.head.run_towers(feats)
+        cls_buf, box_buf, _, offs = model.head.predict(ct, bt)
+        res = model.inference(hw, cls_buf, box_buf, offs, imgs.image_sizes)
+    anchors_l = grid_anchors(hw, [8, 16, 32, 64, 128], model.anchor_sizes, model.anchor_ratios)
+    bounds = list(offs) + [cls_buf.shape[1]]
+    for i, r in enumerate(res):
+        B, S, C = [], [], []
+        for l, anc in enumerate(anchors_l):
+            sl = slice(bounds[l], bounds[l + 1])
+            p = cls_buf[i, sl].cpu().reshape(-1).sigmoid()
+            deltas = box_buf[i, sl, :36].cpu().reshape(-1, 4)
+            k = min(model.topk_candidates, deltas.shape[0])
+            prob, idx = p.sort(descending=True)
+            prob, idx = prob[:k], idx[:k]
+            keep = prob > model.score_threshold
+            prob, idx = prob[keep], idx[keep]
+            B.append(orc.apply_deltas(deltas[idx // 80], anc[idx // 80], (1.0, 1.0, 1.0, 1.0))); S.append(prob); C.append(idx % 80)
+        B, S, C = torch.cat(B), torch.cat(S), torch.cat(C)
+        keep = od.batched_nms(B, S, C, model.nms_threshold)[: model.max_detections_per_image]
+        assert len(r) == len(keep) and len(keep) > 0
+        key = lambda b, c: sorted(zip(c.tolist(), [tuple(round(v, 1) for v in x) for x in b.tolist()]))
+        assert key(r.pred_boxes.tensor.cpu(), r.pred_classes.cpu()) == key(B[keep], C[keep])
+    out = model(data)
+    assert len(out) == 2 and "instances" in out[0]
