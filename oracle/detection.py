@@ -119,6 +119,20 @@ def matcher(quality, thresholds, labels, allow_low_quality):
     return matches, out
 
 
+def topk_matcher(quality, thresholds, labels, topk):
+    """slender_det/modeling/matchers/topk_matcher.py:38-85 (reference's own code; pinned by tests/golden/topk_matcher.npz)."""
+    G, A = quality.shape
+    if quality.numel() == 0:
+        return torch.zeros(A, dtype=torch.int64), torch.full((A,), labels[0], dtype=torch.int8)
+    th = [-float("inf")] + list(thresholds) + [float("inf")]
+    vals, matches = quality.max(dim=0)
+    out = torch.full((A,), 1, dtype=torch.int8)
+    for l, lo, hi in zip(labels, th[:-1], th[1:]):
+        out[(vals >= lo) & (vals < hi)] = l
+    out[quality.topk(k=topk, dim=1)[1]] = 1
+    return matches, out
+
+
 # ------------------------------------------------------------------------------------------------ rotated boxes (C.15)
 def _rot_vertices(b):
     cx, cy, w, h, a = [np.float32(v) for v in b]

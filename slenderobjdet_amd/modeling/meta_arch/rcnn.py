@@ -57,6 +57,27 @@ class GeneralizedRCNN(nn.Module):
 
 
 @META_ARCH_REGISTRY.register()
+class ProposalVisibleRCNN(GeneralizedRCNN):
+    """slender_det/modeling/meta_arch/rcnn/pvrcnn.py:10-63: inference results carry the (rescaled) proposals next to the instances."""
+
+    @torch.no_grad()
+    def inference(self, batched_inputs, do_postprocess=True):
+        from ..postprocessing import detector_postprocess
+
+        images = self.preprocess_image(batched_inputs)
+        features = self.backbone(images.tensor)
+        proposals, _ = self.proposal_generator(images, features, None)
+        results, _ = self.roi_heads(images, features, proposals, None)
+        if not do_postprocess:
+            return results
+        out = []
+        for res, prop, inp, size in zip(results, proposals, batched_inputs, images.image_sizes):
+            h, w = inp.get("height", size[0]), inp.get("width", size[1])
+            out.append({"instances": detector_postprocess(res, h, w), "proposals": detector_postprocess(prop, h, w)})
+        return out
+
+
+@META_ARCH_REGISTRY.register()
 class ProposalNetwork(nn.Module):
     """d2 ProposalNetwork: backbone + proposal generator only (loss_rpn_cls / loss_rpn_loc)."""
 

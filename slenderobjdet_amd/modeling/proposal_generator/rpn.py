@@ -232,6 +232,46 @@ class RRPN(RPN):
     rotated = True
 
 
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class RPNWNM(RPN):
+    """slender_det/modeling/proposal_generator/rpn.py:26-356 "Region Proposal Network With New Matcher": d2's RPN whose anchor matcher
+    comes from ``cfg.MODEL.RPN.MATCHER.TYPE`` (matchers/__init__.py:8-22): "Origin" = Matcher(low-quality on), "TopK" = TopKMatcher
+    (matchers/topk_matcher.py:7-85: threshold labels, then the TOPK best anchors of every gt box become positive)."""
+
+    def __init__(self, cfg, input_shape):
+        super().__init__(cfg, input_shape)
+        m = cfg.MODEL.RPN.MATCHER
+        if m.TYPE not in ("Origin", "TopK"):
+            raise AssertionError(f"Matcher Type doesn't exist! Expected one in ['Origin', 'TopK'], But got {m.TYPE}")
+        self.matcher_type, self.matcher_topk = m.TYPE, m.TOPK
+        if self.matcher_type == "TopK":
+            assert self.iou_thresholds[0] > 0
+
+    @torch.no_grad()
+    def label_and_sample_anchors(self, anchors, gt_instances):
+        if self.matcher_type == "Origin":
+            return super().label_and_sample_anchors(anchors, gt_instances)
+        from ...structures import pairwise_iou
+
+        R, N, dev = anchors.shape[0], len(gt_instances), anchors.device
+        labels = torch.empty((N, R), dtype=torch.int8, device=dev)
+        matched = torch.zeros((N, R, self.box_dim), dtype=torch.float32, device=dev)
+        for i, g in enumerate(gt_instances):
+            boxes = g.gt_boxes.tensor.float().contiguous()
+            _, matches, mlab = HF.anchor_match(boxes, anchors, self.iou_thresholds, self.iou_labels, False)
+            if len(boxes):      # top-k anchors of every gt (rows of the G x R IoU matrix; G is small)
+                q = pairwise_iou(Boxes(boxes), Boxes(anchors))
+                mlab[q.topk(k=self.matcher_topk, dim=1)[1].reshape(-1)] = 1
+            pos, neg = subsample_labels(mlab, self.batch_size_per_image, self.positive_fraction, 0)
+            lab = labels[i]
+            lab.fill_(-1)
+            lab[pos] = 1
+            lab[neg] = 0
+            if len(boxes):
+                matched[i] = boxes[matches.long()]
+        return labels, matched
+
+
 def build_proposal_generator(cfg, input_shape):
     name = cfg.MODEL.PROPOSAL_GENERATOR.NAME
     if name == "PrecomputedProposals":

@@ -317,5 +317,16 @@ class RROIHeads(StandardROIHeads):
     rotated = True
 
 
+@ROI_HEADS_REGISTRY.register()
+class ProposalVisibleHead(StandardROIHeads):
+    """slender_det/modeling/meta_arch/rcnn/pvrcnn.py:66-97: StandardROIHeads whose inference also hands the proposals back."""
+
+    def forward(self, images, features, proposals, targets=None):
+        out, losses = super().forward(images, features, proposals, targets)
+        if self.training:
+            return out, losses
+        return out, {"proposals": proposals}
+
+
 def build_roi_heads(cfg, input_shape):
     return ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, input_shape)

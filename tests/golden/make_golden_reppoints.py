@@ -331,6 +331,16 @@ def main():
     meta["reppoints_losses.npz"] = ("reference Python (rpd.py:221-402, rep_matcher.py) x restated third-party ops "
                                     "(pairwise_iou, Matcher, sigmoid_focal_loss_jit, smooth_l1_loss)")
     meta.update(pointset_head_golden(g))
+    # ------------------------------------------------------------------ TopKMatcher: pure reference
+    sys.modules["detectron2.layers"].nonzero_tuple = lambda x: x.nonzero(as_tuple=True)
+    tk = _load("ref_topk_matcher", "slender_det/modeling/matchers/topk_matcher.py")
+    gtb = random_boxes(g, 9, 256, 320)
+    anc = random_boxes(g, 900, 256, 320)
+    q = pairwise_iou(Boxes(gtb), Boxes(anc))
+    m, lab = tk.TopKMatcher([0.3, 0.7], [0, -1, 1], 10)(q)
+    np.savez_compressed(os.path.join(OUT, "topk_matcher.npz"), gt=gtb.numpy(), anchors=anc.numpy(), quality=q.numpy(), matches=m.numpy(),
+                        labels=lab.numpy())
+    meta["topk_matcher.npz"] = "reference: matchers/topk_matcher.py:7-85 (pure reference Python on a restated pairwise_iou matrix)"
     mp = os.path.join(OUT, "meta.json")
     old = json.load(open(mp)) if os.path.exists(mp) else {}
     old.update(meta)

@@ -300,3 +300,54 @@ def test_rcnn_proposals_and_inference_vs_oracle(cuda, rotated):
             assert len(key(res.pred_boxes.tensor.cpu(), res.pred_classes.cpu()) ^ key(rb, rc)) <= (4 if rotated else 0)
     out = model(data)
     assert len(out) == 2 and "instances" in out[0]
+
+
+def test_reference_rcnn_variants(cuda):
+    """The reference's own subclasses: RPNWNM with the TopK matcher (proposal_generator/rpn.py:26-356, matchers/topk_matcher.py),
+    ProposalVisibleRCNN / ProposalVisibleHead (meta_arch/rcnn/pvrcnn.py): labels drawn from the oracle's pools, a training step,
+    and inference that returns the proposals next to the instances."""
+    from oracle import detection as od
+    from oracle import rcnn as orc
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+
+    cfg = _cfg(False)
+    cfg.MODEL.META_ARCHITECTURE = "ProposalVisibleRCNN"
+    cfg.MODEL.PROPOSAL_GENERATOR.NAME = "RPNWNM"
+    cfg.MODEL.RPN.MATCHER.TYPE = "TopK"
+    cfg.MODEL.RPN.MATCHER.TOPK = 10
+    cfg.MODEL.ROI_HEADS.NAME = "ProposalVisibleHead"
+    torch.manual_seed(8)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    data = _data(2, 96, 128, 23, False)
+    losses = model(data)
+    rpn = model.proposal_generator
+    hw = [(24, 32), (12, 16), (6, 8), (3, 4), (2, 2)]
+    ag = cfg.MODEL.ANCHOR_GENERATOR
+    anchors = torch.cat(orc.anchors(hw, [4, 8, 16, 32, 64], ag.SIZES, ag.ASPECT_RATIOS, None))
+    gt_labels = rpn.last_targets[0].cpu()
+    for i, d in enumerate(data):
+        gtb = d["instances"].gt_boxes.tensor.cpu()
+        q = od.pairwise_iou(gtb, anchors)
+        _, lab = od.topk_matcher(q, [0.3, 0.7], [0, -1, 1], 10)
+        # torch.topk breaks IoU ties differently on CPU and GPU: an anchor is a legitimate top-k pick when its IoU reaches the gt's
+        # 10th-largest value; everything else must follow the threshold labels
+        tie_ok = (q >= q.topk(10, dim=1).values[:, -1:]).any(0)
+        mine = gt_labels[i]
+        assert ((lab[mine == 1] == 1) | tie_ok[mine == 1]).all()
+        assert ((lab[mine == 0] == 0) | tie_ok[mine == 0]).all()
+        assert (mine == 1).sum() == min(int((lab == 1).sum()), 32) and (lab == 1).sum() >= 10
+    for g in opt.param_groups:
+        g["lr"] = 1e-5
+    total = sum(losses.values())
+    opt.zero_grad()
+    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    opt.step()
+    assert float(total) == float(total)
+    model.eval()
+    for d in data:
+        d.pop("instances")
+    out = model(data)
+    assert len(out) == 2 and set(out[0]) == {"instances", "proposals"} and len(out[0]["proposals"]) > 0

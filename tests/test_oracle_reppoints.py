@@ -59,3 +59,16 @@ def test_ground_truth_and_losses_match_reference(mode):
     np.testing.assert_allclose(g1.numpy(), d[f"{mode}_grad_init"], rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(g2.numpy(), d[f"{mode}_grad_refine"], rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(gl.sum(-1).numpy(), d[f"{mode}_grad_logits_sum"], rtol=1e-4, atol=1e-7)
+
+
+def test_topk_matcher_matches_reference():
+    """slender_det/modeling/matchers/topk_matcher.py (the matcher RPNWNM selects with MODEL.RPN.MATCHER.TYPE = "TopK")."""
+    from oracle import detection as od
+
+    d = _load("topk_matcher.npz")
+    q = od.pairwise_iou(torch.tensor(d["gt"]), torch.tensor(d["anchors"]))
+    np.testing.assert_array_equal(q.numpy(), d["quality"])
+    m, lab = od.topk_matcher(q, [0.3, 0.7], [0, -1, 1], 10)
+    np.testing.assert_array_equal(m.numpy(), d["matches"])
+    np.testing.assert_array_equal(lab.numpy(), d["labels"])
+    assert (lab == 1).sum() >= 9 * 10 - 20 and (lab == 0).any()
