@@ -249,6 +249,12 @@ int sod_box2box_apply_deltas(const float* deltas, const float* boxes, long long 
 int sod_bce_logits_loss_fwd(const float* logits, const signed char* labels, long long n, float* sum_out, float* ws, void* stream);
 int sod_bce_logits_loss_bwd(const float* logits, const signed char* labels, long long n, const float* grad_scale, float scale_mul,
                             float* dlogits, void* stream);
+/* F.binary_cross_entropy_with_logits(x[fg], t[fg], "sum") with float targets, fg = rows with 0 <= label != bg_label: the centerness
+ * loss of the LRTB head (meta/heads/lrtb_head.py:236-238; FCOSV2 has it fused in sod_fcos_regctr_loss_*) */
+int sod_bce_logits_soft_fwd(const float* logits, const float* targets, const int* labels, int bg_label, long long n, float* sum_out,
+                            float* ws, void* stream);
+int sod_bce_logits_soft_bwd(const float* logits, const float* targets, const int* labels, int bg_label, long long n,
+                            const float* grad_scale, float scale_mul, float* dlogits, void* stream);
 int sod_rpn_loc_loss_fwd(const float* pred, const float* target, const signed char* labels, long long n, int box_dim, float beta,
                          float* sum_out, float* ws, void* stream);
 int sod_rpn_loc_loss_bwd(const float* pred, const float* target, const signed char* labels, long long n, int box_dim, float beta,

@@ -73,6 +73,8 @@ _SIGS = {
     "sod_box2box_apply_deltas": [_P, _P, _L, _I, _I, _I, _P, _F, _P, _P],
     "sod_bce_logits_loss_fwd": [_P, _P, _L, _P, _P, _P],
     "sod_bce_logits_loss_bwd": [_P, _P, _L, _P, _F, _P, _P],
+    "sod_bce_logits_soft_fwd": [_P, _P, _P, _I, _L, _P, _P, _P],
+    "sod_bce_logits_soft_bwd": [_P, _P, _P, _I, _L, _P, _F, _P, _P],
     "sod_rpn_loc_loss_fwd": [_P, _P, _P, _L, _I, _F, _P, _P, _P],
     "sod_rpn_loc_loss_bwd": [_P, _P, _P, _L, _I, _F, _P, _F, _P, _P],
     "sod_softmax_ce_fwd": [_P, _P, _I, _I, _I, _P, _P, _P],

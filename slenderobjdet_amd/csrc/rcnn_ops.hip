@@ -107,6 +107,31 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ x, c
   }
 }
 
+// F.binary_cross_entropy_with_logits(x[fg], t[fg], reduction="sum") with float targets; fg = rows with 0 <= label != bg
+// (the centerness loss of the LRTB / FCOS heads, meta/heads/lrtb_head.py:236-238)
+template <bool BWD>
+__global__ __launch_bounds__(256) void bce_soft_kernel(const float* __restrict__ x, const float* __restrict__ t, const int* __restrict__ lab, int bg,
+                                                       long long n, float* __restrict__ part, const float* __restrict__ gs, float mul,
+                                                       float* __restrict__ dx) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float sc = BWD ? gs[0] * mul : 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int l = lab[i];
+    const bool sel = l >= 0 && l != bg;
+    const float v = x[i];
+    if (!BWD) {
+      if (sel) acc += fmaxf(v, 0.f) - v * t[i] + log1pf(expf(-fabsf(v)));
+    } else {
+      dx[i] = sel ? (1.f / (1.f + expf(-v)) - t[i]) * sc : 0.f;
+    }
+  }
+  if (!BWD) {
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  }
+}
+
 // smooth_l1_loss(pred[label == 1], target[label == 1], beta, "sum") over D-vectors
 template <bool BWD>
 __global__ __launch_bounds__(256) void loc_kernel(const float* __restrict__ p, const float* __restrict__ t, const signed char* __restrict__ lab,
@@ -251,6 +276,26 @@ extern "C" int sod_bce_logits_loss_bwd(const float* logits, const signed char* l
                                        float* dlogits, void* stream) {
   if (!logits || !labels || !grad_scale || !dlogits || n < 0) return SOD_EARG;
   SOD_LAUNCH(bce_kernel<true>, dim3(rc_nblk(n, 4096)), dim3(256), 0, (hipStream_t)stream, logits, labels, n, nullptr, grad_scale, scale_mul, dlogits);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_bce_logits_soft_fwd(const float* logits, const float* targets, const int* labels, int bg_label, long long n, float* sum_out,
+                                       float* ws, void* stream) {
+  if (!logits || !targets || !labels || !sum_out || !ws || n < 0) return SOD_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = rc_nblk(n);
+  SOD_LAUNCH(bce_soft_kernel<false>, dim3(g), dim3(256), 0, st, logits, targets, labels, bg_label, n, ws, nullptr, 0.f, nullptr);
+  SOD_LAUNCH(rc_finish, dim3(1), dim3(256), 0, st, ws, g, 1, sum_out);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_bce_logits_soft_bwd(const float* logits, const float* targets, const int* labels, int bg_label, long long n,
+                                       const float* grad_scale, float scale_mul, float* dlogits, void* stream) {
+  if (!logits || !targets || !labels || !grad_scale || !dlogits || n < 0) return SOD_EARG;
+  SOD_LAUNCH(bce_soft_kernel<true>, dim3(rc_nblk(n, 4096)), dim3(256), 0, (hipStream_t)stream, logits, targets, labels, bg_label, n, nullptr,
+             grad_scale, scale_mul, dlogits);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -693,3 +693,19 @@ def fastrcnn_box_loss_bwd(pred, gt_classes, gt_deltas, K, beta, grad_scale, scal
     call("sod_fastrcnn_box_loss_bwd", ptr(pred), ptr(gt_classes), ptr(gt_deltas), R, K, gt_deltas.shape[-1], ld, float(beta), ptr(grad_scale),
          float(scale_mul), ptr(d), stream_ptr())
     return d
+
+
+def bce_logits_soft_fwd(logits, targets, labels, bg_label):
+    """BCE-with-logits (sum) with float targets over the rows whose int32 label is a foreground class."""
+    _chk(logits, torch.float32, "logits"); _chk(targets, torch.float32, "targets"); _chk(labels, torch.int32, "labels")
+    s = _sum1(logits.device)
+    call("sod_bce_logits_soft_fwd", ptr(logits), ptr(targets), ptr(labels), int(bg_label), logits.numel(), ptr(s), ptr(reduce_ws(logits.device)),
+         stream_ptr())
+    return s
+
+
+def bce_logits_soft_bwd(logits, targets, labels, bg_label, grad_scale, scale_mul=1.0):
+    d = torch.empty_like(logits)
+    call("sod_bce_logits_soft_bwd", ptr(logits), ptr(targets), ptr(labels), int(bg_label), logits.numel(), ptr(grad_scale), float(scale_mul), ptr(d),
+         stream_ptr())
+    return d

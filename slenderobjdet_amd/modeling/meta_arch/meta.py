@@ -229,3 +229,266 @@ class AblationMetaArch(nn.Module):
             return self.postprocess(self.head(images, features), batched_inputs, images.image_sizes)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         return self.head(images, features, gt_instances)
+
+
+# ------------------------------------------------------------------------------------------------ LRTBHead
+class _ScaleMulFn(torch.autograd.Function):
+    """``Scale`` (slender_det/layers/scale.py:5-11) of one FPN level with the five scalars stored as one arena parameter."""
+
+    @staticmethod
+    def forward(ctx, x, scales, level, owner):
+        ctx.level, ctx.owner = level, owner
+        ctx.save_for_backward(x, scales)
+        arena = getattr(owner, "_arena", None)
+        if arena is not None:
+            arena.note_use(scales)
+        return x * scales[level]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scales = ctx.saved_tensors
+        arena = getattr(ctx.owner, "_arena", None)
+        g = (dy * x).sum()
+        if arena is not None:
+            arena.grad_view(scales)[ctx.level] += g
+            arena.mark_ready(scales)
+            return dy * scales[ctx.level], None, None, None
+        ds = torch.zeros_like(scales)
+        ds[ctx.level] = g
+        return dy * scales[ctx.level], ds, None, None
+
+
+class _LrtbLossFn(torch.autograd.Function):
+    """LRTBHead.losses (meta/heads/lrtb_head.py:190-258): focal + two centerness-weighted IoU losses + centerness BCE."""
+
+    @staticmethod
+    def forward(ctx, head, cls, ctr, init, refine, labels, reg_t, ctr_t, stats, inv_world):
+        K = head.num_classes
+        lab, rt, ct = labels.view(-1), reg_t.view(-1, 4), ctr_t.view(-1)
+        cls2, init2, ref2, ctr2 = cls.reshape(-1, K).contiguous(), init.reshape(-1, 4).contiguous(), refine.reshape(-1, 4).contiguous(), ctr.reshape(-1).contiguous()
+        focal, _ = HF.focal_loss_fwd(cls2, lab, None, head.focal_loss_alpha, head.focal_loss_gamma)
+        s_init, _ = HF.iou_loss_fwd(init2, rt, ct, head.iou_loss_type, mask=lab, mask_bg=K)
+        s_ref, _ = HF.iou_loss_fwd(ref2, rt, ct, head.iou_loss_type, mask=lab, mask_bg=K)
+        s_ctr = HF.bce_logits_soft_fwd(ctr2, ct, lab, K)
+        npos = torch.clamp(stats[0:1] * inv_world, min=1.0)
+        sctr = torch.where(stats[0:1] > 0, stats[1:2] * inv_world, torch.ones_like(stats[1:2]))   # no positives: the sums are 0 anyway
+        ctx.head, ctx.inv_world, ctx.shapes = head, inv_world, (cls.shape, ctr.shape, init.shape, refine.shape)
+        ctx.save_for_backward(cls2, ctr2, init2, ref2, lab, rt, ct, stats, npos, sctr)
+        return torch.cat([focal / npos, s_init / sctr, s_ref / sctr, s_ctr / npos])
+
+    @staticmethod
+    def backward(ctx, g4):
+        head = ctx.head
+        cls2, ctr2, init2, ref2, lab, rt, ct, stats, npos, sctr = ctx.saved_tensors
+        K = head.num_classes
+        g4 = g4.contiguous().float()
+        dcls = HF.focal_loss_bwd(cls2, lab, None, head.focal_loss_alpha, head.focal_loss_gamma, scale_num=g4[0:1], scale_den=stats[0:1],
+                                 den_mul=ctx.inv_world, den_min=1.0)
+        dinit = HF.iou_loss_bwd(init2, rt, ct, head.iou_loss_type, mask=lab, mask_bg=K, grad_scale=(g4[1:2] / sctr).contiguous())
+        dref = HF.iou_loss_bwd(ref2, rt, ct, head.iou_loss_type, mask=lab, mask_bg=K, grad_scale=(g4[2:3] / sctr).contiguous())
+        dctr = HF.bce_logits_soft_bwd(ctr2, ct, lab, K, (g4[3:4] / npos).contiguous())
+        s = ctx.shapes
+        return None, dcls.view(s[0]), dctr.view(s[1]), dinit.view(s[2]), dref.view(s[3]), None, None, None, None, None
+
+
+@MEAT_HEADS_REGISTRY.register()
+class LRTBHead(nn.Module):
+    """slender_det/modeling/meta_arch/meta/heads/lrtb_head.py:24-375: FCOS-style left/right/top/bottom distances predicted twice
+    (init, then refined on adapted features), FCOS targets (fcos/utils.py), centerness-weighted IoU losses, centerness BCE.
+    Quirks reproduced: ``lrtb_to_points`` (heads/utils.py:20-23) reads the channels as (l, r, t, b) although the targets are
+    (l, t, r, b); "Supervised Offset" only controls taps 0 and 8 of the 3x3 kernel, the other seven come from ``offset_conv_extend``."""
+
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        h = cfg.MODEL.META_ARCH
+        self.in_channels = input_shape[0].channels
+        self.in_features, self.fpn_strides = list(h.IN_FEATURES), list(h.FPN_STRIDES)
+        self.num_classes, self.feat_channels, self.stacked_convs, self.norm = h.NUM_CLASSES, h.FEAT_CHANNELS, h.STACK_CONVS, h.NORM
+        self.feat_adaption, self.res_refine = h.FEAT_ADAPTION, h.RES_REFINE
+        self.gradient_mul, self.prior_prob = h.GRADIENT_MUL, h.PRIOR_PROB
+        self.focal_loss_gamma, self.focal_loss_alpha = h.FOCAL_LOSS_GAMMA, h.FOCAL_LOSS_ALPHA
+        self.loss_cls_weight, self.loss_loc_init_weight, self.loss_loc_refine_weight = h.LOSS_CLS_WEIGHT, h.LOSS_LOC_INIT_WEIGHT, h.LOSS_LOC_REFINE_WEIGHT
+        self.score_threshold, self.topk_candidates, self.nms_threshold = h.SCORE_THRESH_TEST, h.TOPK_CANDIDATES_TEST, h.NMS_THRESH_TEST
+        self.max_detections_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
+        assert h.NUM_POINTS == 2, "LRTBHead: NUM_POINTS must be 2 (lrtb_head.py:32)"
+        self.center_sampling_radius, self.norm_reg_targets = h.CENTER_SAMPLING_RADIUS, h.NORM_REG_TARGETS
+        self.centerness_on_loc, self.iou_loss_type = h.CENTERNESS_ON_LOC, h.IOU_LOSS_TYPE
+        self.slender_centerness = h.SLENDER_CENTERNESS
+        if self.feat_adaption not in FEAT_ADAPTION_METHODS:
+            raise AssertionError(f"{self.feat_adaption} {type(self.feat_adaption)}")
+        if self.norm not in ("GN", ""):
+            raise NotImplementedError(f"META_ARCH.NORM {self.norm!r}: only 'GN' and '' are built")
+        C = self.feat_channels
+        assert self.in_channels == C == h.LOC_FEAT_CHANNELS == 256, "LRTBHead is built for 256-channel features"
+        unit = ConvGnRelu if self.norm == "GN" else ConvReluML
+        self.cls_subnet = nn.ModuleList([unit(C) for _ in range(self.stacked_convs)])
+        self.loc_subnet = nn.ModuleList([unit(C) for _ in range(self.stacked_convs)])
+        self.loc_init_conv = ConvML(C, C, 3, 1, relu=True)
+        self.loc_init_out = ConvML(C, 8, 1, 0, out_f32=True)                  # 4 distances (+4 pad)
+        if self.feat_adaption == "Empty":
+            self.cls_conv = ConvML(C, C, 3, 1, relu=True)
+            self.loc_refine_conv = ConvML(C, C, 3, 1, relu=True)
+        else:
+            self.cls_conv = DeformConv(C, C, 3, 1, 1, relu=True)
+            self.loc_refine_conv = DeformConv(C, C, 3, 1, 1, relu=True)
+        if self.feat_adaption == "Unsupervised Offset":
+            self.offset_conv = ConvML(C, 24, 1, 0, out_f32=True)
+        elif self.feat_adaption == "Split Unsup Offset":
+            self.offset_conv_cls = ConvML(C, 24, 1, 0, out_f32=True)
+            self.offset_conv_loc = ConvML(C, 24, 1, 0, out_f32=True)
+        elif self.feat_adaption == "Supervised Offset":
+            self.offset_conv_extend = ConvML(C, 16, 1, 0, out_f32=True)      # 14 offsets (+2 pad)
+        K = self.num_classes
+        self.kc = K + (0 if self.centerness_on_loc else 1)                   # cls_out (+ ctn_out) fused, like FCOSHead.cls_pred
+        self.cls_pred = ConvML(C, (self.kc + 7) // 8 * 8, 1, 0, out_f32=True)
+        self.box_pred = ConvML(C, 8, 1, 0, out_f32=True)                      # loc_refine_out (4) (+ ctn_out when CENTERNESS_ON_LOC)
+        self.scales_init = nn.Parameter(torch.ones(len(self.fpn_strides)))
+        self.scales_refine = nn.Parameter(torch.ones(len(self.fpn_strides)))
+        with torch.no_grad():
+            for u in list(self.cls_subnet) + list(self.loc_subnet):
+                u.conv.init_normal(0.01, 0.0)
+            named = [self.loc_init_conv, self.loc_init_out, self.cls_pred, self.box_pred]
+            named += [m for m in (self.cls_conv, self.loc_refine_conv) if isinstance(m, ConvML)]
+            named += [getattr(self, n) for n in ("offset_conv", "offset_conv_cls", "offset_conv_loc", "offset_conv_extend") if hasattr(self, n)]
+            for m in named:
+                m.conv.init_normal(0.01, 0.0)
+            self.loc_init_out.conv.weight[4:].zero_()
+            self.cls_pred.conv.weight[self.kc:].zero_()
+            self.box_pred.conv.weight[5 if self.centerness_on_loc else 4:].zero_()
+            self.cls_pred.conv.bias[:K].fill_(-math.log((1 - self.prior_prob) / self.prior_prob))
+            for n, rows in (("offset_conv", 18), ("offset_conv_cls", 18), ("offset_conv_loc", 18), ("offset_conv_extend", 14)):
+                if hasattr(self, n):
+                    getattr(self, n).conv.weight[rows:].zero_()
+        self.register_buffer("_dev_probe", torch.zeros(1))
+        self.last_targets = None
+
+    @property
+    def device(self):
+        return self._dev_probe.device
+
+    def _decode(self, raw, scales, level):
+        z = _ScaleMulFn.apply(raw, scales, level, self)
+        return torch.relu(z) * self.fpn_strides[level] if self.norm_reg_targets else torch.exp(z)
+
+    def run_head(self, features):
+        """-> per level: cls logits (N,H,W,K), centerness logits (N,H,W), init / refine distances (N,H,W,4), all fp32."""
+        nl, K = len(features), self.num_classes
+        cls_f, loc_f = list(features), list(features)
+        for u in self.cls_subnet:
+            cls_f = u(cls_f)
+        for u in self.loc_subnet:
+            loc_f = u(loc_f)
+        raw_init = self.loc_init_out(self.loc_init_conv(loc_f))
+        init = [self._decode(raw_init[l][..., :4], self.scales_init, l) for l in range(nl)]
+        if self.feat_adaption == "Empty":
+            cf, lf = self.cls_conv(cls_f), self.loc_refine_conv(loc_f)
+        else:
+            if self.feat_adaption == "Unsupervised Offset":
+                off_c = off_l = self.offset_conv(loc_f)
+            elif self.feat_adaption == "Split Unsup Offset":
+                off_c, off_l = self.offset_conv_cls(loc_f), self.offset_conv_loc(loc_f)
+            else:
+                ext = self.offset_conv_extend(loc_f)
+                off_c = []
+                for l in range(nl):
+                    gm = (1 - self.gradient_mul) * init[l].detach() + self.gradient_mul * init[l]
+                    # lrtb_to_points reads (l, r, t, b): [-ch0, -ch2, ch1, ch3]; dcn_base_offset[[0, 1, -2, -1]] = [-1, -1, 1, 1]
+                    d = torch.stack((-gm[..., 0], -gm[..., 2], gm[..., 1], gm[..., 3]), dim=-1) / self.fpn_strides[l]
+                    d = d - d.new_tensor([-1.0, -1.0, 1.0, 1.0])
+                    pad = d.new_zeros(d.shape[:-1] + (6,))
+                    off_c.append(torch.cat((d[..., 0:2], ext[l][..., :14], d[..., 2:4], pad), dim=-1).contiguous())
+                off_l = off_c
+            cf = [self.cls_conv(cls_f[l], off_c[l], off_ld=24) for l in range(nl)]
+            lf = [self.loc_refine_conv(loc_f[l], off_l[l], off_ld=24) for l in range(nl)]
+        cp, bp = self.cls_pred(cf), self.box_pred(lf)
+        cls = [cp[l][..., :K] for l in range(nl)]
+        ctr = [bp[l][..., 4] if self.centerness_on_loc else cp[l][..., K] for l in range(nl)]
+        refine = []
+        for l in range(nl):
+            r = self._decode(bp[l][..., :4], self.scales_refine, l)
+            refine.append(r + init[l].detach() if self.res_refine else r)
+        return cls, ctr, init, refine
+
+    def forward(self, images, features, gt_instances=None):
+        import torch.distributed as dist
+
+        from ...utils import comm
+        from .fcos import SIZES_OF_INTEREST
+
+        N = features[0].shape[0]
+        hw = [(f.shape[1], f.shape[2]) for f in features]
+        cls, ctr, init, refine = self.run_head(features)
+        K = self.num_classes
+        cat = lambda ts, c: torch.cat([t.reshape(N, -1, c) if c > 1 else t.reshape(N, -1) for t in ts], dim=1)
+        cls_all, ctr_all, init_all, ref_all = cat(cls, K), cat(ctr, 1), cat(init, 4), cat(refine, 4)
+        if not self.training:
+            with torch.no_grad():
+                return self.inference(hw, cls_all, ctr_all, ref_all, images.image_sizes)
+        dev = cls_all.device
+        counts = [len(g) for g in gt_instances]
+        offs = torch.tensor([0] + counts, dtype=torch.int64).cumsum(0).to(torch.int32).to(dev, non_blocking=True)
+        if sum(counts) > 0:
+            boxes = torch.cat([g.gt_boxes.tensor for g in gt_instances]).float().contiguous()
+            classes = torch.cat([g.gt_classes for g in gt_instances]).to(torch.int32).contiguous()
+        else:
+            boxes, classes = torch.zeros((1, 4), dtype=torch.float32, device=dev), torch.zeros((1,), dtype=torch.int32, device=dev)
+        with torch.no_grad():
+            labels, reg_t, ctr_t, stats = HF.fcos_assign(boxes, classes, offs, N, hw, self.fpn_strides, SIZES_OF_INTEREST,
+                                                         self.center_sampling_radius, K)
+            if self.slender_centerness:
+                # compute_slender_centerness_targets (fcos/utils.py:302-312): centerness ** (0.5 * min(w/h, h/w)) on the positives;
+                # the assignment kernel returns sqrt(centerness), so raise it to the ratio itself
+                fg = (labels >= 0) & (labels != K)
+                r = (reg_t[..., 0] + reg_t[..., 2]) / (reg_t[..., 1] + reg_t[..., 3])
+                ratio = torch.minimum(r, 1.0 / r)
+                ctr_t = torch.where(fg, torch.pow(ctr_t, ratio), torch.zeros_like(ctr_t)).contiguous()
+                stats = torch.stack((stats[0], ctr_t.sum()))
+            world = comm.get_world_size()
+            if world > 1:
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        self.last_targets = (labels, reg_t, ctr_t, stats)
+        out = _LrtbLossFn.apply(self, cls_all, ctr_all, init_all, ref_all, labels, reg_t, ctr_t, stats, 1.0 / float(world))
+        return {"loss_cls": out[0] * self.loss_cls_weight, "centerness_loss": out[3] * self.loss_cls_weight,
+                "loss_loc_init": out[1] * self.loss_loc_init_weight, "loss_loc_refine": out[2] * self.loss_loc_refine_weight}
+
+    @torch.no_grad()
+    def inference(self, hw, cls_all, ctr_all, ref_all, image_sizes):
+        """lrtb_head.py:283-375: per level score threshold on the class probability, times centerness, top-k, decode, sqrt, NMS."""
+        from ...layers.nms import batched_nms
+
+        dev = cls_all.device
+        bounds = [0]
+        for h, w in hw:
+            bounds.append(bounds[-1] + h * w)
+        locs = []
+        for (h, w), s in zip(hw, self.fpn_strides):
+            ys = torch.arange(0, h * s, step=s, dtype=torch.float32, device=dev)
+            xs = torch.arange(0, w * s, step=s, dtype=torch.float32, device=dev)
+            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+            locs.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), dim=1) + s // 2)
+        results = []
+        for i, image_size in enumerate(image_sizes):
+            B, S, C = [], [], []
+            for l in range(len(hw)):
+                sl = slice(bounds[l], bounds[l + 1])
+                p = cls_all[i, sl].sigmoid()
+                keep = p > self.score_threshold
+                p = p * ctr_all[i, sl].sigmoid()[:, None]
+                sc = p[keep]
+                idx = keep.nonzero()
+                loc_i, class_i = idx[:, 0], idx[:, 1]
+                reg_i, locs_i = ref_all[i, sl][loc_i], locs[l][loc_i]
+                n_keep = int(keep.sum())
+                top_n = min(n_keep, self.topk_candidates)
+                if n_keep > top_n:
+                    sc, ti = sc.topk(top_n, sorted=False)
+                    class_i, reg_i, locs_i = class_i[ti], reg_i[ti], locs_i[ti]
+                B.append(torch.stack([locs_i[:, 0] - reg_i[:, 0], locs_i[:, 1] - reg_i[:, 1], locs_i[:, 0] + reg_i[:, 2], locs_i[:, 1] + reg_i[:, 3]], dim=1))
+                S.append(torch.sqrt(sc))
+                C.append(class_i)
+            B, S, C = torch.cat(B), torch.cat(S), torch.cat(C)
+            keep = batched_nms(B, S, C, self.nms_threshold)[: self.max_detections_per_image]
+            r = Instances(tuple(image_size))
+            r.pred_boxes, r.scores, r.pred_classes = Boxes(B[keep]), S[keep], C[keep]
+            results.append(r)
+        return results

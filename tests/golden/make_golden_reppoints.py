@@ -259,6 +259,78 @@ def pointset_head_golden(g):
     return meta
 
 
+def lrtb_head_golden(g):
+    """LRTBHead (meta/heads/lrtb_head.py) built and run by the reference's own Python on CPU, three configurations."""
+    iou_mod = _load("ref_iou_loss2", "slender_det/layers/iou_loss.py")
+    scale_mod = _load("ref_scale2", "slender_det/layers/scale.py")
+    sys.modules["slender_det.layers"] = types.ModuleType("slender_det.layers")
+    sys.modules["slender_det.layers"].iou_loss, sys.modules["slender_det.layers"].Scale = iou_mod.iou_loss, scale_mod.Scale
+    for n in ("refma", "refma.meta", "refma.meta.heads", "refma.fcos"):
+        _stub(n)
+    _load("refma.fcos.utils", "slender_det/modeling/meta_arch/fcos/utils.py", "refma.fcos")
+    _load("refma.meta.heads.meta_head", "slender_det/modeling/meta_arch/meta/heads/meta_head.py", "refma.meta.heads")
+    _load("refma.meta.heads.utils", "slender_det/modeling/meta_arch/meta/heads/utils.py", "refma.meta.heads")
+    lh = _load("refma.meta.heads.lrtb_head", "slender_det/modeling/meta_arch/meta/heads/lrtb_head.py", "refma.meta.heads")
+    meta = {}
+    C = 32
+    hw = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    strides = [8, 16, 32, 64, 128]
+    cases = (("empty", dict(fa="Empty", res=False, norm_reg=True, ctr_on_loc=True, iou="giou", slender=False, radius=1.5)),
+             ("sup", dict(fa="Supervised Offset", res=False, norm_reg=True, ctr_on_loc=True, iou="giou", slender=True, radius=1.5)),
+             ("unsup", dict(fa="Unsupervised Offset", res=True, norm_reg=False, ctr_on_loc=False, iou="iou", slender=False, radius=0.0)))
+    for tag, c in cases:
+        hp = SimpleNamespace(
+            NAME="LRTBHead", IN_FEATURES=["p3", "p4", "p5", "p6", "p7"], FPN_STRIDES=strides, NUM_CLASSES=80, FEAT_CHANNELS=C, STACK_CONVS=3, NORM="GN",
+            FEAT_ADAPTION=c["fa"], RES_REFINE=c["res"], LOC_FEAT_CHANNELS=C, GRADIENT_MUL=0.1, PRIOR_PROB=0.01, FOCAL_LOSS_GAMMA=2.0,
+            FOCAL_LOSS_ALPHA=0.25, LOSS_CLS_WEIGHT=1.0, LOSS_LOC_INIT_WEIGHT=0.5, LOSS_LOC_REFINE_WEIGHT=1.0, SCORE_THRESH_TEST=0.05,
+            TOPK_CANDIDATES_TEST=1000, NMS_THRESH_TEST=0.5, NUM_POINTS=2, CENTER_SAMPLING_RADIUS=c["radius"], NORM_REG_TARGETS=c["norm_reg"],
+            CENTERNESS_ON_LOC=c["ctr_on_loc"], IOU_LOSS_TYPE=c["iou"], PRE_NMS_THRESH=0.05, PRE_NMS_TOP_N=1000, SLENDER_CENTERNESS=c["slender"])
+        cfg = SimpleNamespace(MODEL=SimpleNamespace(META_ARCH=hp), TEST=SimpleNamespace(DETECTIONS_PER_IMAGE=100))
+        torch.manual_seed(11)
+        head = lh.LRTBHead(cfg, [SimpleNamespace(channels=C, stride=s) for s in strides])
+        with torch.no_grad():
+            for n, p in head.named_parameters():
+                if n.endswith("weight") and p.dim() == 4 and "subnet" not in n:
+                    p.mul_(4.0)
+                if "scales" in n:
+                    p.add_(torch.rand(p.shape, generator=g) * 0.4 - 0.2)
+                if n in ("loc_init_out.bias", "loc_refine_out.bias"):
+                    p.fill_(0.75)      # keeps relu(z) * stride (NORM_REG_TARGETS) away from the all-zero box
+                p.copy_(p.half().float())
+        head.train()
+        feats = [(torch.randn(2, C, h, w, generator=g) * 1.5).half().float() for h, w in hw]
+        gtb = [random_boxes(g, 5, 128, 160), random_boxes(g, 8, 128, 160)]
+        gtc = [torch.randint(0, 80, (len(b),), generator=g) for b in gtb]
+        inst = [SimpleNamespace(gt_boxes=Boxes(b), gt_classes=c_, __len__=None) for b, c_ in zip(gtb, gtc)]
+
+        class _I(SimpleNamespace):
+            def __len__(self):
+                return len(self.gt_classes)
+
+        inst = [_I(gt_boxes=Boxes(b), gt_classes=c_) for b, c_ in zip(gtb, gtc)]
+        images = SimpleNamespace(image_sizes=[(128, 160), (128, 160)])
+        losses = head(images, feats, inst)
+        params = dict(head.named_parameters())
+        grads = torch.autograd.grad(sum(losses.values()), list(params.values()), allow_unused=True)
+        keys = ("loss_cls", "centerness_loss", "loss_loc_init", "loss_loc_refine")
+        out = {"hw": np.array(hw), "strides": np.array(strides), "channels": np.array(C), "losses": np.array([float(losses[k]) for k in keys]),
+               "cfg": np.array(json.dumps(c))}
+        for l, f in enumerate(feats):
+            out[f"feat{l}"] = f.numpy().astype(np.float16)
+        for i in range(2):
+            out[f"gt_boxes{i}"], out[f"gt_classes{i}"] = gtb[i].numpy(), gtc[i].numpy()
+        for (n, p), gr in zip(params.items(), grads):
+            out["param:" + n] = p.detach().numpy().astype(np.float16)
+            out["gradnorm:" + n] = np.array(0.0 if gr is None else float(gr.norm()))
+        for n in ("cls_out.weight", "loc_refine_out.weight", "loc_init_out.weight", "ctn_out.weight"):
+            out["grad:" + n] = grads[list(params).index(n)].numpy()
+        np.savez_compressed(os.path.join(OUT, f"lrtb_head_{tag}.npz"), **out)
+        meta[f"lrtb_head_{tag}.npz"] = ("reference: meta/heads/lrtb_head.py:24-258 + meta_head.py + heads/utils.py + fcos/utils.py + layers/iou_loss.py"
+                                        " (reference Python" + (" x restated DeformConv" if c["fa"] != "Empty" else "") + " x restated focal)")
+        print("lrtb", tag, {k: float(v) for k, v in losses.items()})
+    return meta
+
+
 def main():
     assert os.path.isdir(REF), "runs only in the build container (needs /root/reference)"
     rm, rpd = install()
@@ -331,6 +403,7 @@ def main():
     meta["reppoints_losses.npz"] = ("reference Python (rpd.py:221-402, rep_matcher.py) x restated third-party ops "
                                     "(pairwise_iou, Matcher, sigmoid_focal_loss_jit, smooth_l1_loss)")
     meta.update(pointset_head_golden(g))
+    meta.update(lrtb_head_golden(g))
     # ------------------------------------------------------------------ TopKMatcher: pure reference
     sys.modules["detectron2.layers"].nonzero_tuple = lambda x: x.nonzero(as_tuple=True)
     tk = _load("ref_topk_matcher", "slender_det/modeling/matchers/topk_matcher.py")

@@ -1,0 +1,142 @@
+"""GPU parity of AblationMetaArch + LRTBHead against oracle/lrtb.py, which is pinned to the reference's own head
+by tests/test_oracle_lrtb.py."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("Empty", False, True, True, "giou", False, 1.5), ("Supervised Offset", False, True, True, "giou", True, 1.5),
+         ("Unsupervised Offset", True, False, False, "iou", False, 0.0), ("Split Unsup Offset", False, True, True, "linear_iou", False, 1.5)]
+
+
+def _cfg(fa, res, norm_reg, ctr_on_loc, iou, slender, radius):
+    from bench import make_cfg
+
+    cfg = make_cfg(18)
+    cfg.MODEL.META_ARCHITECTURE = "AblationMetaArch"
+    cfg.MODEL.BACKBONE.NAME = "build_retinanet_resnet_fpn_backbone"
+    m = cfg.MODEL.META_ARCH
+    m.NAME, m.NUM_POINTS, m.FEAT_ADAPTION, m.RES_REFINE = "LRTBHead", 2, fa, res
+    m.NORM_REG_TARGETS, m.CENTERNESS_ON_LOC, m.IOU_LOSS_TYPE, m.SLENDER_CENTERNESS, m.CENTER_SAMPLING_RADIUS = norm_reg, ctr_on_loc, iou, slender, radius
+    return cfg
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0].split()[0] for c in CASES])
+def test_lrtb_head_vs_oracle(cuda, case):
+    from oracle import fcos_targets as ot
+    from oracle import lrtb as olr
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+
+    cfg = _cfg(*case)
+    torch.manual_seed(9)
+    model = build_model(cfg)
+    model.train()
+    head = model.head
+    with torch.no_grad():      # away from the degenerate all-zero box of relu(z) * stride at init
+        head.loc_init_out.conv.bias[:4].fill_(0.75)
+        head.box_pred.conv.bias[:4].fill_(0.75)
+        head.scales_init.add_(torch.linspace(-0.2, 0.2, 5, device=head.scales_init.device))
+    model.arena.bump()
+    opt = build_optimizer(cfg, model)
+    data = synthetic_batch(2, 192, 256, 14, device="cuda")
+    got = model(data)
+    assert set(got) == {"loss_cls", "centerness_loss", "loss_loc_init", "loss_loc_refine"}
+    K, N = 80, 2
+    with torch.no_grad():
+        imgs = model.preprocess_image(data)
+        feats = model.backbone(imgs.tensor)
+        feats = [feats[f] for f in head.in_features]
+        cls, ctr, init, refine = head.run_head(feats)
+    hw = [(f.shape[1], f.shape[2]) for f in feats]
+    cat = lambda ts, c: torch.cat([t.reshape(N, -1, c) if c > 1 else t.reshape(N, -1) for t in ts], 1).cpu()
+    cls_a, ctr_a, init_a, ref_a = cat(cls, K), cat(ctr, 1), cat(init, 4), cat(refine, 4)
+    gtb = [d["instances"].gt_boxes.tensor.cpu() for d in data]
+    gtc = [d["instances"].gt_classes.cpu() for d in data]
+    # 1. targets: bit-exact labels / regression targets, centerness (standard or slender) to fp32 rounding
+    labels, reg_t = ot.targets_for_batch(hw, head.fpn_strides, gtb, gtc, head.center_sampling_radius, K)
+    lab_h, reg_h, ctr_h, stats = (t.cpu() for t in head.last_targets)
+    assert torch.equal(lab_h.long(), labels) and torch.equal(reg_h, reg_t)
+    fg = labels != K
+    assert fg.sum() > 0
+    from oracle import losses as ol
+
+    ct = olr.slender_centerness_targets(reg_t[fg]) if head.slender_centerness else ol.centerness_targets(reg_t[fg])
+    assert torch.allclose(ctr_h[fg], ct, rtol=1e-5, atol=1e-6) and abs(float(stats[1]) - float(ct.sum())) < 1e-3
+    # 2. the four losses from the product path's own predictions
+    ref = olr.losses(labels.reshape(-1), reg_t.reshape(-1, 4), cls_a.reshape(-1, K), ctr_a.reshape(-1), init_a.reshape(-1, 4), ref_a.reshape(-1, 4), K,
+                     0.25, 2.0, head.iou_loss_type, head.slender_centerness, (1.0, 0.5, 1.0))
+    for k in ref:
+        a, b = float(got[k].detach()), float(ref[k])
+        assert abs(a - b) <= 3e-4 * max(abs(b), 1e-3), (k, a, b)
+    # 3. head forward against the oracle head (bf16 storage emulated) on the same FPN features
+    o = olr.OracleLRTBHead.from_hip_head(head, emulate_bf16=True)
+    with torch.no_grad():
+        c2, t2, i2, r2, _ = o.forward([f.float().cpu().permute(0, 3, 1, 2) for f in feats])
+    for name, a, b in (("cls", cls_a, c2), ("ctr", ctr_a, t2), ("init", init_a, i2), ("refine", ref_a, r2)):
+        err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-6)
+        assert err < 3e-2, (name, err)
+    # 4. gradients: finite everywhere, scales and prediction rows trained, padding rows zero; a few steps reduce the loss
+    total = sum(got.values())
+    opt.zero_grad()
+    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    for name, p in head.named_parameters():
+        assert torch.isfinite(p.grad).all(), name
+    assert head.scales_init.grad.abs().sum() > 0 and head.scales_refine.grad.abs().sum() > 0
+    assert (head.loc_init_out.conv.weight.grad[4:] == 0).all() and head.loc_init_out.conv.weight.grad[:4].abs().sum() > 0
+    nb = 5 if head.centerness_on_loc else 4
+    assert (head.box_pred.conv.weight.grad[nb:] == 0).all() and head.box_pred.conv.weight.grad[:nb].abs().sum() > 0
+    for g in opt.param_groups:
+        g["lr"] = 0.002
+    ls = []
+    for _ in range(6):
+        losses = model(data)
+        t = sum(losses.values())
+        opt.zero_grad()
+        model.arena.begin_backward(); t.backward(); model.arena.finish_backward()
+        opt.step()
+        ls.append(float(t.detach()))
+    assert all(v == v for v in ls) and ls[-1] < ls[0], ls
+
+
+def test_lrtb_inference_matches_oracle(cuda):
+    from oracle import lrtb as olr
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+
+    cfg = _cfg("Empty", False, True, True, "giou", False, 1.5)
+    cfg.MODEL.META_ARCH.SCORE_THRESH_TEST = 0.011
+    torch.manual_seed(10)
+    model = build_model(cfg)
+    model.eval()
+    head = model.head
+    with torch.no_grad():
+        head.box_pred.conv.bias[:4].fill_(0.75)
+    model.arena.bump()
+    data = synthetic_batch(2, 192, 256, 15, device="cuda")
+    for d in data:
+        d.pop("instances")
+    N, K = 2, 80
+    with torch.no_grad():
+        imgs = model.preprocess_image(data)
+        feats = model.backbone(imgs.tensor)
+        feats = [feats[f] for f in head.in_features]
+        cls, ctr, init, refine = head.run_head(feats)
+        hw = [(f.shape[1], f.shape[2]) for f in feats]
+        cat = lambda ts, c: torch.cat([t.reshape(N, -1, c) if c > 1 else t.reshape(N, -1) for t in ts], 1)
+        cls_a, ctr_a, ref_a = cat(cls, K), cat(ctr, 1), cat(refine, 4)
+        res = head.inference(hw, cls_a, ctr_a, ref_a, imgs.image_sizes)
+    bounds, locs = [0], []
+    for (h, w), s in zip(hw, head.fpn_strides):
+        bounds.append(bounds[-1] + h * w)
+        gy, gx = torch.meshgrid(torch.arange(0, h * s, s, dtype=torch.float32), torch.arange(0, w * s, s, dtype=torch.float32), indexing="ij")
+        locs.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), 1) + s // 2)
+    for i, r in enumerate(res):
+        B, S, C = olr.inference_single_image(locs, cls_a[i].cpu(), ctr_a[i].cpu(), ref_a[i].cpu(), bounds, head.score_threshold, head.topk_candidates,
+                                             head.nms_threshold, head.max_detections_per_image)
+        assert len(r) == len(B) and len(B) > 0
+        key = lambda b, c: sorted(zip(c.tolist(), [tuple(round(v, 1) for v in x) for x in b.tolist()]))
+        assert key(r.pred_boxes.tensor.cpu(), r.pred_classes.cpu()) == key(B, C)
+    out = model(data)
+    assert len(out) == 2 and "instances" in out[0]
