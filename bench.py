@@ -126,14 +126,18 @@ def pmc_traffic(kind):
     --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md). None if absent."""
     import glob
 
-    names = {"conv_fwd": "void conv_igemm_kernel<0, false, 2, 2, 4, 4, false>", "conv_dgrad": "void conv_igemm_kernel<1, false, 2, 2, 4, 4, false>",
-             "conv_wgrad": "conv_wgrad_kernel"}
+    prefixes = {"conv_fwd": "void conv_igemm_kernel<0, false, 2, 2, 4, 4, false, 64", "conv_dgrad": "void conv_igemm_kernel<1, false, 2, 2, 4, 4, false, 64",
+                "conv_wgrad": "conv_wgrad_kernel"}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not files or kind not in names:
+    if not files or kind not in prefixes:
         return None
     try:
-        k = json.load(open(files[-1]))["kernels"].get(names[kind])
-        return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "source": os.path.relpath(files[-1], ROOT)} if k else None
+        kernels = json.load(open(files[-1]))["kernels"]
+        hits = [(v["launches"], k, v) for k, v in kernels.items() if k.startswith(prefixes[kind])]
+        if not hits:
+            return None
+        _, name, k = max(hits)
+        return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "kernel": name, "source": os.path.relpath(files[-1], ROOT)}
     except Exception:
         return None
 
