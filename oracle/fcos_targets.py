@@ -37,7 +37,7 @@ def _center_region_mask(boxes, strides, pts_per_level, xs, ys, radius):
     return d.min(dim=-1).values > 0
 
 
-def targets_for_image(locs, pts_per_level, strides, boxes, classes, radius, num_classes, sizes=SIZES_OF_INTEREST):
+def targets_for_image(locs, pts_per_level, strides, boxes, classes, radius, num_classes, sizes=SIZES_OF_INTEREST, return_inds=False):
     """One image of compute_targets_for_locations (utils.py:160-212).
     Returns labels (L,) int64 (background = num_classes) and reg targets (L,4) fp32."""
     xs, ys = locs[:, 0], locs[:, 1]
@@ -60,6 +60,8 @@ def targets_for_image(locs, pts_per_level, strides, boxes, classes, radius, num_
     labels = classes.long()[idx].clone()
     labels[best == INF] = num_classes
     reg = ltrb[torch.arange(L), idx]
+    if return_inds:
+        return labels, reg, idx
     return labels, reg
 
 

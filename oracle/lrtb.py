@@ -25,8 +25,34 @@ def slender_centerness_targets(reg):
     return torch.pow(c, 0.5 * ratio)
 
 
-def losses(labels, reg_t, cls, ctr, init, refine, num_classes, alpha=0.25, gamma=2.0, iou_type="iou", slender=False, w=(1.0, 0.5, 1.0), world=1):
-    """lrtb_head.py:190-258 on flattened predictions (M rows)."""
+def topk_locations(level_hw, strides, gt_boxes, gt_classes, radius, num_classes, topk=5):
+    """Selection part of compute_topk_targets_for_locations (fcos/utils.py:215-292): per gt box the top-k positive locations by
+    centerness (all of them when there are at most k).  Returns labels (N,L), reg (N,L,4), mask (N,L) bool."""
+    locs = ot.locations(level_hw, strides)
+    pts = [len(l) for l in locs]
+    allp = torch.cat(locs)
+    labs, regs, masks = [], [], []
+    for b, c in zip(gt_boxes, gt_classes):
+        lab, reg, idx = ot.targets_for_image(allp, pts, strides, b.float(), c, radius, num_classes, return_inds=True)
+        fg = (lab >= 0) & (lab != num_classes)
+        m = torch.zeros(len(lab), dtype=torch.bool)
+        for g in range(len(b)):
+            sel = (idx == g) & fg
+            n = int(sel.sum())
+            if n > topk:
+                score = ol.centerness_targets(reg[sel])
+                _, inds = torch.topk(score, topk, sorted=False)
+                m[sel.nonzero()[inds]] = True
+            elif n > 0:
+                m[sel.nonzero()] = True
+        labs.append(lab); regs.append(reg); masks.append(m)
+    return torch.stack(labs), torch.stack(regs), torch.stack(masks)
+
+
+def losses(labels, reg_t, cls, ctr, init, refine, num_classes, alpha=0.25, gamma=2.0, iou_type="iou", slender=False, w=(1.0, 0.5, 1.0), world=1,
+           topk_mask=None):
+    """lrtb_head.py:190-258 on flattened predictions (M rows); ``topk_mask`` (M,) bool = lrtb_topk_head.py:234-243: the init loss runs
+    over those rows with the STANDARD centerness as weight and its sum as normaliser."""
     fg = (labels >= 0) & (labels != num_classes)
     pos_avg = max(int(fg.sum()) / float(world), 1.0)
     onehot = ol.one_hot_from_labels(labels, num_classes).to(cls.dtype)
@@ -34,7 +60,11 @@ def losses(labels, reg_t, cls, ctr, init, refine, num_classes, alpha=0.25, gamma
     if int(fg.sum()) > 0:
         ct = slender_centerness_targets(reg_t[fg]) if slender else ol.centerness_targets(reg_t[fg])
         s = float(ct.sum()) / float(world)
-        l_init = ol.iou_loss_ltrb(init[fg], reg_t[fg], ct, iou_type) / s
+        if topk_mask is None:
+            l_init = ol.iou_loss_ltrb(init[fg], reg_t[fg], ct, iou_type) / s
+        else:
+            ct_k = ol.centerness_targets(reg_t[topk_mask])
+            l_init = ol.iou_loss_ltrb(init[topk_mask], reg_t[topk_mask], ct_k, iou_type) / (float(ct_k.sum()) / float(world))
         l_ref = ol.iou_loss_ltrb(refine[fg], reg_t[fg], ct, iou_type) / s
         l_ctr = F.binary_cross_entropy_with_logits(ctr[fg], ct, reduction="sum") / pos_avg
     else:
@@ -161,10 +191,15 @@ class OracleLRTBHead(OraclePointSetHead):
             I.append(init.permute(0, 2, 3, 1).reshape(N, -1, 4)); R.append(ref.permute(0, 2, 3, 1).reshape(N, -1, 4))
         return torch.cat(C, 1), torch.cat(T, 1), torch.cat(I, 1), torch.cat(R, 1), [tuple(f.shape[2:]) for f in feats]
 
-    def losses(self, feats, gt_boxes, gt_classes):
+    def losses(self, feats, gt_boxes, gt_classes, topk=False):
         c = self.c
         cls, ctr, init, ref, hw = self.forward(feats)
-        labels, reg_t = ot.targets_for_batch(hw, c["strides"], gt_boxes, gt_classes, c["radius"], c["K"])
         K = c["K"]
+        mask = None
+        if topk:
+            labels, reg_t, mask = topk_locations(hw, c["strides"], gt_boxes, gt_classes, c["radius"], K)
+            mask = mask.reshape(-1)
+        else:
+            labels, reg_t = ot.targets_for_batch(hw, c["strides"], gt_boxes, gt_classes, c["radius"], K)
         return losses(labels.reshape(-1), reg_t.reshape(-1, 4), cls.reshape(-1, K), ctr.reshape(-1), init.reshape(-1, 4), ref.reshape(-1, 4), K,
-                      c["alpha"], c["gamma"], c["iou_type"], c["slender"], c["w"])
+                      c["alpha"], c["gamma"], c["iou_type"], c["slender"], c["w"], topk_mask=mask)

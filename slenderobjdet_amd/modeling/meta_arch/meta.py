@@ -262,33 +262,38 @@ class _LrtbLossFn(torch.autograd.Function):
     """LRTBHead.losses (meta/heads/lrtb_head.py:190-258): focal + two centerness-weighted IoU losses + centerness BCE."""
 
     @staticmethod
-    def forward(ctx, head, cls, ctr, init, refine, labels, reg_t, ctr_t, stats, inv_world):
+    def forward(ctx, head, cls, ctr, init, refine, labels, reg_t, ctr_t, stats, inv_world, init_labels=None, init_ctr=None):
+        """``init_labels`` / ``init_ctr`` (LRTBTopkHead): the init-box loss runs over another row selection with its own weights;
+        ``stats`` then carries a third entry, the sum of those weights."""
         K = head.num_classes
         lab, rt, ct = labels.view(-1), reg_t.view(-1, 4), ctr_t.view(-1)
+        lab_i = lab if init_labels is None else init_labels.view(-1)
+        ct_i = ct if init_ctr is None else init_ctr.view(-1)
         cls2, init2, ref2, ctr2 = cls.reshape(-1, K).contiguous(), init.reshape(-1, 4).contiguous(), refine.reshape(-1, 4).contiguous(), ctr.reshape(-1).contiguous()
         focal, _ = HF.focal_loss_fwd(cls2, lab, None, head.focal_loss_alpha, head.focal_loss_gamma)
-        s_init, _ = HF.iou_loss_fwd(init2, rt, ct, head.iou_loss_type, mask=lab, mask_bg=K)
+        s_init, _ = HF.iou_loss_fwd(init2, rt, ct_i, head.iou_loss_type, mask=lab_i, mask_bg=K)
         s_ref, _ = HF.iou_loss_fwd(ref2, rt, ct, head.iou_loss_type, mask=lab, mask_bg=K)
         s_ctr = HF.bce_logits_soft_fwd(ctr2, ct, lab, K)
         npos = torch.clamp(stats[0:1] * inv_world, min=1.0)
         sctr = torch.where(stats[0:1] > 0, stats[1:2] * inv_world, torch.ones_like(stats[1:2]))   # no positives: the sums are 0 anyway
+        sctr_i = sctr if init_labels is None else torch.where(stats[0:1] > 0, stats[2:3] * inv_world, torch.ones_like(stats[2:3]))
         ctx.head, ctx.inv_world, ctx.shapes = head, inv_world, (cls.shape, ctr.shape, init.shape, refine.shape)
-        ctx.save_for_backward(cls2, ctr2, init2, ref2, lab, rt, ct, stats, npos, sctr)
-        return torch.cat([focal / npos, s_init / sctr, s_ref / sctr, s_ctr / npos])
+        ctx.save_for_backward(cls2, ctr2, init2, ref2, lab, rt, ct, stats, npos, sctr, lab_i, ct_i, sctr_i)
+        return torch.cat([focal / npos, s_init / sctr_i, s_ref / sctr, s_ctr / npos])
 
     @staticmethod
     def backward(ctx, g4):
         head = ctx.head
-        cls2, ctr2, init2, ref2, lab, rt, ct, stats, npos, sctr = ctx.saved_tensors
+        cls2, ctr2, init2, ref2, lab, rt, ct, stats, npos, sctr, lab_i, ct_i, sctr_i = ctx.saved_tensors
         K = head.num_classes
         g4 = g4.contiguous().float()
         dcls = HF.focal_loss_bwd(cls2, lab, None, head.focal_loss_alpha, head.focal_loss_gamma, scale_num=g4[0:1], scale_den=stats[0:1],
                                  den_mul=ctx.inv_world, den_min=1.0)
-        dinit = HF.iou_loss_bwd(init2, rt, ct, head.iou_loss_type, mask=lab, mask_bg=K, grad_scale=(g4[1:2] / sctr).contiguous())
+        dinit = HF.iou_loss_bwd(init2, rt, ct_i, head.iou_loss_type, mask=lab_i, mask_bg=K, grad_scale=(g4[1:2] / sctr_i).contiguous())
         dref = HF.iou_loss_bwd(ref2, rt, ct, head.iou_loss_type, mask=lab, mask_bg=K, grad_scale=(g4[2:3] / sctr).contiguous())
         dctr = HF.bce_logits_soft_bwd(ctr2, ct, lab, K, (g4[3:4] / npos).contiguous())
         s = ctx.shapes
-        return None, dcls.view(s[0]), dctr.view(s[1]), dinit.view(s[2]), dref.view(s[3]), None, None, None, None, None
+        return None, dcls.view(s[0]), dctr.view(s[1]), dinit.view(s[2]), dref.view(s[3]), None, None, None, None, None, None, None
 
 
 @MEAT_HEADS_REGISTRY.register()
@@ -435,6 +440,7 @@ class LRTBHead(nn.Module):
         with torch.no_grad():
             labels, reg_t, ctr_t, stats = HF.fcos_assign(boxes, classes, offs, N, hw, self.fpn_strides, SIZES_OF_INTEREST,
                                                          self.center_sampling_radius, K)
+            ctr_std = ctr_t
             if self.slender_centerness:
                 # compute_slender_centerness_targets (fcos/utils.py:302-312): centerness ** (0.5 * min(w/h, h/w)) on the positives;
                 # the assignment kernel returns sqrt(centerness), so raise it to the ratio itself
@@ -443,13 +449,18 @@ class LRTBHead(nn.Module):
                 ratio = torch.minimum(r, 1.0 / r)
                 ctr_t = torch.where(fg, torch.pow(ctr_t, ratio), torch.zeros_like(ctr_t)).contiguous()
                 stats = torch.stack((stats[0], ctr_t.sum()))
+            init_labels, init_ctr, stats = self.init_selection(hw, labels, reg_t, ctr_std, stats)
             world = comm.get_world_size()
             if world > 1:
                 dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         self.last_targets = (labels, reg_t, ctr_t, stats)
-        out = _LrtbLossFn.apply(self, cls_all, ctr_all, init_all, ref_all, labels, reg_t, ctr_t, stats, 1.0 / float(world))
+        out = _LrtbLossFn.apply(self, cls_all, ctr_all, init_all, ref_all, labels, reg_t, ctr_t, stats, 1.0 / float(world), init_labels, init_ctr)
         return {"loss_cls": out[0] * self.loss_cls_weight, "centerness_loss": out[3] * self.loss_cls_weight,
                 "loss_loc_init": out[1] * self.loss_loc_init_weight, "loss_loc_refine": out[2] * self.loss_loc_refine_weight}
+
+    def init_selection(self, hw, labels, reg_t, ctr_std, stats):
+        """Rows and weights of the init-box loss: LRTBHead uses the foreground rows and the (possibly slender) centerness."""
+        return None, None, stats
 
     @torch.no_grad()
     def inference(self, hw, cls_all, ctr_all, ref_all, image_sizes):
@@ -492,3 +503,48 @@ class LRTBHead(nn.Module):
             r.pred_boxes, r.scores, r.pred_classes = Boxes(B[keep]), S[keep], C[keep]
             results.append(r)
         return results
+
+
+@MEAT_HEADS_REGISTRY.register()
+class LRTBTopkHead(LRTBHead):
+    """slender_det/modeling/meta_arch/meta/heads/lrtb_topk_head.py:23-368: LRTBHead whose INIT boxes are only supervised at the top-k
+    (5) positive locations of every gt box, ranked by the standard centerness target (fcos/utils.py:215-292,
+    ``compute_topk_targets_for_locations``), with those centerness values as weights and their sum as the normaliser.  Inference
+    thresholds on PRE_NMS_THRESH / PRE_NMS_TOP_N (:322,:336) instead of SCORE_THRESH_TEST / TOPK_CANDIDATES_TEST."""
+    topk_per_box = 5
+
+    def __init__(self, cfg, input_shape):
+        super().__init__(cfg, input_shape)
+        h = cfg.MODEL.META_ARCH
+        self.score_threshold, self.topk_candidates = h.PRE_NMS_THRESH, h.PRE_NMS_TOP_N
+        self.last_topk = None
+
+    def init_selection(self, hw, labels, reg_t, ctr_std, stats):
+        K, dev = self.num_classes, labels.device
+        N, L = labels.shape
+        locs = []
+        for (h, w), s in zip(hw, self.fpn_strides):
+            ys = torch.arange(0, h * s, step=s, dtype=torch.float32, device=dev)
+            xs = torch.arange(0, w * s, step=s, dtype=torch.float32, device=dev)
+            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+            locs.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), dim=1) + s // 2)
+        locs = torch.cat(locs)
+        topk = torch.zeros((N, L), dtype=torch.bool, device=dev)
+        for i in range(N):
+            fg = ((labels[i] >= 0) & (labels[i] != K)).nonzero().squeeze(1)
+            if fg.numel() == 0:
+                continue
+            r = reg_t[i, fg]
+            # the gt box a positive location regresses to identifies its gt (locations_to_gt_inds of the reference)
+            box = torch.stack((locs[fg, 0] - r[:, 0], locs[fg, 1] - r[:, 1], locs[fg, 0] + r[:, 2], locs[fg, 1] + r[:, 3]), dim=1)
+            uniq, inv = torch.unique((box * 8).round().to(torch.int64), dim=0, return_inverse=True)
+            score = ctr_std[i, fg]
+            for g in range(uniq.shape[0]):
+                rows = (inv == g).nonzero().squeeze(1)
+                if rows.numel() > self.topk_per_box:
+                    rows = rows[torch.topk(score[rows], self.topk_per_box, sorted=False)[1]]
+                topk[i, fg[rows]] = True
+        self.last_topk = topk
+        init_labels = torch.where(topk, labels, torch.full_like(labels, K)).contiguous()
+        stats = torch.cat((stats, (ctr_std * topk).sum().reshape(1)))
+        return init_labels, ctr_std.contiguous(), stats

@@ -277,7 +277,9 @@ def lrtb_head_golden(g):
     strides = [8, 16, 32, 64, 128]
     cases = (("empty", dict(fa="Empty", res=False, norm_reg=True, ctr_on_loc=True, iou="giou", slender=False, radius=1.5)),
              ("sup", dict(fa="Supervised Offset", res=False, norm_reg=True, ctr_on_loc=True, iou="giou", slender=True, radius=1.5)),
-             ("unsup", dict(fa="Unsupervised Offset", res=True, norm_reg=False, ctr_on_loc=False, iou="iou", slender=False, radius=0.0)))
+             ("unsup", dict(fa="Unsupervised Offset", res=True, norm_reg=False, ctr_on_loc=False, iou="iou", slender=False, radius=0.0)),
+             ("topk", dict(fa="Empty", res=False, norm_reg=True, ctr_on_loc=True, iou="giou", slender=False, radius=0.0, topk=True)))
+    lt = _load("refma.meta.heads.lrtb_topk_head", "slender_det/modeling/meta_arch/meta/heads/lrtb_topk_head.py", "refma.meta.heads")
     for tag, c in cases:
         hp = SimpleNamespace(
             NAME="LRTBHead", IN_FEATURES=["p3", "p4", "p5", "p6", "p7"], FPN_STRIDES=strides, NUM_CLASSES=80, FEAT_CHANNELS=C, STACK_CONVS=3, NORM="GN",
@@ -287,7 +289,7 @@ def lrtb_head_golden(g):
             CENTERNESS_ON_LOC=c["ctr_on_loc"], IOU_LOSS_TYPE=c["iou"], PRE_NMS_THRESH=0.05, PRE_NMS_TOP_N=1000, SLENDER_CENTERNESS=c["slender"])
         cfg = SimpleNamespace(MODEL=SimpleNamespace(META_ARCH=hp), TEST=SimpleNamespace(DETECTIONS_PER_IMAGE=100))
         torch.manual_seed(11)
-        head = lh.LRTBHead(cfg, [SimpleNamespace(channels=C, stride=s) for s in strides])
+        head = (lt.LRTBTopkHead if c.get("topk") else lh.LRTBHead)(cfg, [SimpleNamespace(channels=C, stride=s) for s in strides])
         with torch.no_grad():
             for n, p in head.named_parameters():
                 if n.endswith("weight") and p.dim() == 4 and "subnet" not in n:

@@ -12,7 +12,7 @@ from oracle.lrtb import OracleLRTBHead
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("tag", ["empty", "sup", "unsup"])
+@pytest.mark.parametrize("tag", ["empty", "sup", "unsup", "topk"])
 def test_lrtb_head_losses_and_gradients_match_reference(tag):
     d = {k: v for k, v in np.load(os.path.join(G, f"lrtb_head_{tag}.npz")).items()}
     c = json.loads(str(d["cfg"]))
@@ -22,7 +22,7 @@ def test_lrtb_head_losses_and_gradients_match_reference(tag):
     feats = [torch.tensor(d[f"feat{l}"].astype(np.float32)) for l in range(5)]
     gtb = [torch.tensor(d[f"gt_boxes{i}"]) for i in range(2)]
     gtc = [torch.tensor(d[f"gt_classes{i}"]) for i in range(2)]
-    out = o.losses(feats, gtb, gtc)
+    out = o.losses(feats, gtb, gtc, topk=bool(c.get("topk")))
     got = np.array([float(out[k].detach()) for k in ("loss_cls", "centerness_loss", "loss_loc_init", "loss_loc_refine")])
     np.testing.assert_allclose(got, d["losses"], rtol=3e-5)
     # gradients of the un-fused reference convs = row blocks of the fused product-style convs
