@@ -159,9 +159,16 @@ def test_ablation_meta_arch_builds_from_repo_config_cpu():
     C = 256      # reference parameter count of this head (pointset_head.py:19-88), pitch padding excluded
     ref = 2 * 3 * (C * C * 9 + C + 2 * C) + (C * C * 9 + C) + (C * 18 + 18) + 2 * (C * C * 9) + (C * 80 + 80) + (C * 18 + 18)
     assert sum(p.numel() for p in h.parameters()) - 2 * 6 * (C + 1) == ref
-    cfg.MODEL.META_ARCH.NAME = "LRTBHead"
+    for name in ("LRTBHead", "LRTBTopkHead"):
+        assert name in MEAT_HEADS_REGISTRY
+    cfg.MODEL.META_ARCH.NAME = "AnchorHead"          # not built: must fail loudly at the registry
     with pytest.raises(KeyError):
         build_model(cfg)
+    cfg2 = fresh_cfg()
+    cfg2.merge_from_file(os.path.join(os.path.dirname(__file__), "..", "configs", "ablation_studies", "lrtb", "base.yaml"))
+    cfg2.MODEL.DEVICE = "cpu"
+    h2 = build_model(cfg2).head
+    assert type(h2).__name__ == "LRTBHead" and h2.norm_reg_targets and h2.centerness_on_loc and h2.iou_loss_type == "giou" and not h2.res_refine
 
 
 def test_optimizer_param_groups_follow_reference_rules():
