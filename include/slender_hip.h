@@ -85,6 +85,13 @@ int sod_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const f
                       void* dx, float* dgamma, float* dbeta, float* dxsum /* optional [C]: += sum over pixels of dx = bias
                       gradient of the convolution that produced x */, float* red_ws /* 2*N*G floats */,
                       int N, int HW, int C, int G, long long img_stride, int relu, void* stream);
+/* The same GroupNorm over several FPN levels that share gamma/beta (FCOS / RepPoints towers): one launch per pass instead of one per
+ * level. x/y/dy/dx: arrays of nlev device pointers (dense (N,hw[l],C) bf16); mean_rstd / red_ws: nlev consecutive [N][G][2] blocks. */
+int sod_groupnorm_fwd_ml(int nlev, const void* const* x, const float* gamma, const float* beta, void* const* y, float* mean_rstd,
+                         int N, const int* hw, int C, int G, float eps, int relu, void* stream);
+int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void* const* x, const float* gamma, const float* beta,
+                         const float* mean_rstd, void* const* dx, float* dgamma, float* dbeta, float* dxsum, float* red_ws,
+                         int N, const int* hw, int C, int G, int relu, void* stream);
 
 /* elementwise helpers on bf16 tensors of n elements (n % 8 == 0) */
 int sod_relu_fwd(const void* x, void* y, long long n, void* stream);

@@ -28,6 +28,8 @@ _SIGS = {
     "sod_conv2d_wgrad_ml": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P],
     "sod_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _F, _I, _P],
     "sod_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
+    "sod_groupnorm_fwd_ml": [_I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P],
+    "sod_groupnorm_bwd_ml": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
     "sod_relu_fwd": [_P, _P, _L, _P],
     "sod_relu_bwd": [_P, _P, _P, _L, _P],
     "sod_add_bf16": [_P, _P, _P, _L, _P],

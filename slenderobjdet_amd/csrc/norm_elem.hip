@@ -24,7 +24,7 @@ struct GnArgs {
   int pix_per_block;
 };
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
+__device__ __forceinline__ void gn_stats_body(const GnArgs& a, const int bx) {
   extern __shared__ float lsum[];   // [G][2]
   const int n = blockIdx.y;
   const int c8n = a.C >> 3;                 // vectors per pixel
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
   __syncthreads();
   const int rows_per_iter = 256 / c8n;      // host guarantees c8n divides 256
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
-  const int p0 = blockIdx.x * a.pix_per_block;
+  const int p0 = bx * a.pix_per_block;
   int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
   float s = 0.f, ss = 0.f;
   const __bf16* base = a.x + (long long)n * a.img_stride + c8 * 8;
@@ -48,18 +48,43 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
   for (int i = threadIdx.x; i < a.G * 2; i += 256) atomicAdd(a.stats + (long long)n * a.G * 2 + i, lsum[i]);
 }
 
-__global__ void gn_finalize_stats_kernel(float* stats, int NG, float inv_m, float eps) {
+// ---- multi-level wrappers: one launch covers all FPN levels of a shared-weight GroupNorm (levels differ in HW only) ----
+constexpr int GN_MAX_LEVELS = 6;
+struct GnLevel {
+  const __bf16* x; const __bf16* dy; __bf16* y; __bf16* dx; float* stats; float* red;
+  long long img_stride; int HW, pix_per_block, blk0; float inv_m;
+};
+struct GnML {
+  GnLevel lev[GN_MAX_LEVELS];
+  int nlev;
+  const float* gamma; const float* beta; float* dgamma; float* dbeta; float* dxsum;
+  int N, C, G, cpg, relu; float eps;
+};
+
+__device__ __forceinline__ int gn_pick(const GnML& m, GnArgs& a) {
+  int l = 0;
+  while (l + 1 < m.nlev && (int)blockIdx.x >= m.lev[l + 1].blk0) ++l;
+  const GnLevel& L = m.lev[l];
+  a.x = L.x; a.dy = L.dy; a.y = L.y; a.dx = L.dx; a.stats = L.stats; a.red = L.red; a.img_stride = L.img_stride; a.HW = L.HW;
+  a.pix_per_block = L.pix_per_block;
+  a.gamma = m.gamma; a.beta = m.beta; a.dgamma = m.dgamma; a.dbeta = m.dbeta; a.dxsum = m.dxsum;
+  a.N = m.N; a.C = m.C; a.G = m.G; a.cpg = m.cpg; a.relu = m.relu; a.eps = m.eps;
+  return l;
+}
+
+__global__ void gn_finalize_stats_kernel(const GnML m) {
+  const GnLevel& L = m.lev[blockIdx.y];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < NG) {
-    const float mean = stats[i * 2] * inv_m;
-    float var = stats[i * 2 + 1] * inv_m - mean * mean;
+  if (i < m.N * m.G) {
+    const float mean = L.stats[i * 2] * L.inv_m;
+    float var = L.stats[i * 2 + 1] * L.inv_m - mean * mean;
     var = fmaxf(var, 0.f);
-    stats[i * 2] = mean;
-    stats[i * 2 + 1] = rsqrtf(var + eps);
+    L.stats[i * 2] = mean;
+    L.stats[i * 2 + 1] = rsqrtf(var + m.eps);
   }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
+__device__ __forceinline__ void gn_apply_body(const GnArgs& a, const int bx) {
   const int n = blockIdx.y;
   const int c8n = a.C >> 3;
   const int rows_per_iter = 256 / c8n;
@@ -72,7 +97,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
     const float gm = a.gamma[c8 * 8 + e], bt = a.beta[c8 * 8 + e];
     sc[e] = rstd * gm; sh[e] = bt - mean * rstd * gm;
   }
-  const int p0 = blockIdx.x * a.pix_per_block;
+  const int p0 = bx * a.pix_per_block;
   int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
   const long long base = (long long)n * a.img_stride + c8 * 8;
   for (int p = p0 + prow; p < p1; p += rows_per_iter) {
@@ -88,7 +113,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnArgs a) {
+__device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx) {
   extern __shared__ float lsum[];   // [G][2] group sums, then [C][2] per-channel (dgamma, dbeta) partials
   const int n = blockIdx.y;
   const int c8n = a.C >> 3;
@@ -104,7 +129,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnArgs a) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) { gm[e] = a.gamma[c8 * 8 + e]; bt[e] = a.beta[c8 * 8 + e]; dg[e] = 0.f; db[e] = 0.f; }
   float s1 = 0.f, s2 = 0.f;
-  const int p0 = blockIdx.x * a.pix_per_block;
+  const int p0 = bx * a.pix_per_block;
   int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
   const long long base = (long long)n * a.img_stride + c8 * 8;
   for (int p = p0 + prow; p < p1; p += rows_per_iter) {
@@ -134,7 +159,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a, float inv_m) {
+__device__ __forceinline__ void gn_bwd_apply_body(const GnArgs& a, const int bx, const float inv_m) {
   extern __shared__ float lsum[];   // [C] per-channel sums of dx when a.dxsum
   const int n = blockIdx.y;
   const int c8n = a.C >> 3;
@@ -150,7 +175,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a, float
   float gm[8], bt[8], sx[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { gm[e] = a.gamma[c8 * 8 + e]; bt[e] = a.beta[c8 * 8 + e]; sx[e] = 0.f; }
-  const int p0 = blockIdx.x * a.pix_per_block;
+  const int p0 = bx * a.pix_per_block;
   int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
   const long long base = (long long)n * a.img_stride + c8 * 8;
   for (int p = p0 + prow; p < p1; p += rows_per_iter) {
@@ -173,6 +198,27 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnArgs a, float
     __syncthreads();
     for (int i = threadIdx.x; i < a.C; i += 256) atomicAdd(a.dxsum + i, lsum[i]);
   }
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnML m) {
+  GnArgs a;
+  const int l = gn_pick(m, a);
+  gn_stats_body(a, (int)blockIdx.x - m.lev[l].blk0);
+}
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnML m) {
+  GnArgs a;
+  const int l = gn_pick(m, a);
+  gn_apply_body(a, (int)blockIdx.x - m.lev[l].blk0);
+}
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnML m) {
+  GnArgs a;
+  const int l = gn_pick(m, a);
+  gn_bwd_reduce_body(a, (int)blockIdx.x - m.lev[l].blk0);
+}
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnML m) {
+  GnArgs a;
+  const int l = gn_pick(m, a);
+  gn_bwd_apply_body(a, (int)blockIdx.x - m.lev[l].blk0, m.lev[l].inv_m);
 }
 
 // ------------------------------------------------------------------ elementwise (8 x bf16 per lane)
@@ -421,46 +467,90 @@ int gn_grid(int HW, int N, int& ppb) {
 
 }  // namespace
 
-extern "C" int sod_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd,
-                                 int N, int HW, int C, int G, long long img_stride, float eps, int relu, void* stream) {
+static int gn_fill(GnML& m, int nlev, const int* hw, int N, int C, int G, float eps, int relu, const long long* img_strides) {
+  if (nlev <= 0 || nlev > GN_MAX_LEVELS || !hw) return SOD_EARG;
+  m.nlev = nlev; m.N = N; m.C = C; m.G = G; m.cpg = C / G; m.relu = relu; m.eps = eps;
+  int blk = 0;
+  for (int l = 0; l < nlev; ++l) {
+    int rc = gn_check(N, hw[l], C, G);
+    if (rc) return rc;
+    GnLevel& L = m.lev[l];
+    L.HW = hw[l];
+    L.img_stride = (img_strides && img_strides[l] > 0) ? img_strides[l] : (long long)hw[l] * C;
+    // ~1024 / N blocks per level for the largest level, proportionally fewer for the small ones (>= 64 pixels per block)
+    int gx = 1024 / (N > 0 ? N : 1);
+    if (gx < 1) gx = 1;
+    int ppb = (hw[0] + gx - 1) / gx;
+    if (ppb < 64) ppb = 64;
+    L.pix_per_block = ppb;
+    L.blk0 = blk;
+    blk += (hw[l] + ppb - 1) / ppb;
+    L.inv_m = 1.f / ((float)hw[l] * (float)m.cpg);
+  }
+  return blk;     // total blocks in x (positive) or a negative status
+}
+
+extern "C" int sod_groupnorm_fwd_ml(int nlev, const void* const* x, const float* gamma, const float* beta, void* const* y, float* mean_rstd,
+                                    int N, const int* hw, int C, int G, float eps, int relu, void* stream) {
   if (!x || !gamma || !beta || !y || !mean_rstd) return SOD_EARG;
-  int rc = gn_check(N, HW, C, G);
-  if (rc) return rc;
-  if (img_stride <= 0) img_stride = (long long)HW * C;
+  GnML m{};
+  const int gx = gn_fill(m, nlev, hw, N, C, G, eps, relu, nullptr);
+  if (gx <= 0) return gx ? gx : SOD_EARG;
+  m.gamma = gamma; m.beta = beta;
+  for (int l = 0; l < nlev; ++l) {
+    if (!x[l] || !y[l]) return SOD_EARG;
+    m.lev[l].x = (const __bf16*)x[l]; m.lev[l].y = (__bf16*)y[l]; m.lev[l].stats = mean_rstd + (size_t)l * N * G * 2;
+  }
   hipStream_t st = (hipStream_t)stream;
-  GnArgs a{};
-  a.x = (const __bf16*)x; a.gamma = gamma; a.beta = beta; a.y = (__bf16*)y; a.stats = mean_rstd;
-  a.N = N; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.relu = relu; a.img_stride = img_stride; a.eps = eps;
-  const int gx = gn_grid(HW, N, a.pix_per_block);
-  hipError_t e = hipMemsetAsync(mean_rstd, 0, sizeof(float) * 2 * N * G, st);
+  hipError_t e = hipMemsetAsync(mean_rstd, 0, sizeof(float) * 2 * N * G * nlev, st);
   if (e != hipSuccess) return (int)e;
-  SOD_LAUNCH(gn_stats_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * G, st, a);
-  SOD_LAUNCH(gn_finalize_stats_kernel, dim3((N * G + 255) / 256), dim3(256), 0, st, mean_rstd, N * G,
-                     1.f / ((float)HW * (float)a.cpg), eps);
-  SOD_LAUNCH(gn_apply_kernel, dim3(gx, N), dim3(256), 0, st, a);
+  SOD_LAUNCH(gn_stats_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * G, st, m);
+  SOD_LAUNCH(gn_finalize_stats_kernel, dim3((N * G + 255) / 256, nlev), dim3(256), 0, st, m);
+  SOD_LAUNCH(gn_apply_kernel, dim3(gx, N), dim3(256), 0, st, m);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
+}
+
+extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void* const* x, const float* gamma, const float* beta,
+                                    const float* mean_rstd, void* const* dx, float* dgamma, float* dbeta, float* dxsum,
+                                    float* red_ws /* 2*N*G*nlev floats */, int N, const int* hw, int C, int G, int relu, void* stream) {
+  if (!dy || !x || !gamma || !beta || !mean_rstd || !dx || !dgamma || !dbeta || !red_ws) return SOD_EARG;
+  GnML m{};
+  const int gx = gn_fill(m, nlev, hw, N, C, G, 0.f, relu, nullptr);
+  if (gx <= 0) return gx ? gx : SOD_EARG;
+  m.gamma = gamma; m.beta = beta; m.dgamma = dgamma; m.dbeta = dbeta; m.dxsum = dxsum;
+  for (int l = 0; l < nlev; ++l) {
+    if (!x[l] || !dy[l] || !dx[l]) return SOD_EARG;
+    m.lev[l].x = (const __bf16*)x[l]; m.lev[l].dy = (const __bf16*)dy[l]; m.lev[l].dx = (__bf16*)dx[l];
+    m.lev[l].stats = const_cast<float*>(mean_rstd) + (size_t)l * N * G * 2; m.lev[l].red = red_ws + (size_t)l * N * G * 2;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * N * G * nlev, st);
+  if (e != hipSuccess) return (int)e;
+  SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * (G + C), st, m);
+  SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * C : 0, st, m);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd,
+                                 int N, int HW, int C, int G, long long img_stride, float eps, int relu, void* stream) {
+  if (!x || !y) return SOD_EARG;
+  if (img_stride > 0 && img_stride != (long long)HW * C) return SOD_EARG;     // dense images only
+  const void* xs[1] = {x};
+  void* ys[1] = {y};
+  return sod_groupnorm_fwd_ml(1, xs, gamma, beta, ys, mean_rstd, N, &HW, C, G, eps, relu, stream);
 }
 
 extern "C" int sod_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean_rstd,
                                  void* dx, float* dgamma, float* dbeta, float* dxsum, float* red_ws /* 2*N*G floats */,
                                  int N, int HW, int C, int G, long long img_stride, int relu, void* stream) {
-  if (!dy || !x || !gamma || !beta || !mean_rstd || !dx || !dgamma || !dbeta || !red_ws) return SOD_EARG;
-  int rc = gn_check(N, HW, C, G);
-  if (rc) return rc;
-  if (img_stride <= 0) img_stride = (long long)HW * C;
-  hipStream_t st = (hipStream_t)stream;
-  GnArgs a{};
-  a.x = (const __bf16*)x; a.dy = (const __bf16*)dy; a.gamma = gamma; a.beta = beta; a.dx = (__bf16*)dx;
-  a.stats = const_cast<float*>(mean_rstd); a.red = red_ws; a.dgamma = dgamma; a.dbeta = dbeta; a.dxsum = dxsum;
-  a.N = N; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.relu = relu; a.img_stride = img_stride;
-  const int gx = gn_grid(HW, N, a.pix_per_block);
-  hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * N * G, st);
-  if (e != hipSuccess) return (int)e;
-  SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * (G + C), st, a);
-  SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * C : 0, st, a, 1.f / ((float)HW * (float)a.cpg));
-  SOD_CHECK_LAUNCH();
-  return SOD_OK;
+  if (!dy || !x || !dx) return SOD_EARG;
+  if (img_stride > 0 && img_stride != (long long)HW * C) return SOD_EARG;
+  const void* dys[1] = {dy};
+  const void* xs[1] = {x};
+  void* dxs[1] = {dx};
+  return sod_groupnorm_bwd_ml(1, dys, xs, gamma, beta, mean_rstd, dxs, dgamma, dbeta, dxsum, red_ws, N, &HW, C, G, relu, stream);
 }
 
 extern "C" int sod_relu_bwd(const void* dy, const void* y, void* dx, long long n, void* stream) {

@@ -204,6 +204,34 @@ def groupnorm_bwd(dy, x, gamma, beta, stats, G, dgamma, dbeta, relu=False, dxsum
     return dx
 
 
+def groupnorm_fwd_ml(xs, gamma, beta, G, eps=1e-5, relu=False):
+    """GroupNorm(+ReLU) of several (N,Hl,Wl,C) levels sharing gamma/beta in one launch per pass. Returns (ys, stats (nl,N,G,2))."""
+    _chk(gamma, torch.float32, "gamma"); _chk(beta, torch.float32, "beta")
+    for x in xs:
+        _chk(x, torch.bfloat16, "x")
+    N, C = xs[0].shape[0], xs[0].shape[-1]
+    hw = [x.numel() // (N * C) for x in xs]
+    ys = [torch.empty_like(x) for x in xs]
+    stats = torch.empty((len(xs), N, G, 2), dtype=torch.float32, device=xs[0].device)
+    call("sod_groupnorm_fwd_ml", len(xs), _ptr_arr(xs), ptr(gamma), ptr(beta), _ptr_arr(ys), ptr(stats), N, ctypes.cast(_int_arr(hw), ctypes.c_void_p),
+         C, G, eps, 1 if relu else 0, stream_ptr())
+    return ys, stats
+
+
+def groupnorm_bwd_ml(dys, xs, gamma, beta, stats, G, dgamma, dbeta, relu=False, dxsum=None):
+    """Backward of groupnorm_fwd_ml: returns the list of dx; accumulates dgamma / dbeta (and dxsum) in place."""
+    _chk(dgamma, torch.float32, "dgamma"); _chk(dbeta, torch.float32, "dbeta"); _chk(stats, torch.float32, "stats")
+    for t in list(dys) + list(xs):
+        _chk(t, torch.bfloat16, "dy/x")
+    N, C = xs[0].shape[0], xs[0].shape[-1]
+    hw = [x.numel() // (N * C) for x in xs]
+    dxs = [torch.empty_like(x) for x in xs]
+    red = torch.empty((len(xs), N, G, 2), dtype=torch.float32, device=xs[0].device)
+    call("sod_groupnorm_bwd_ml", len(xs), _ptr_arr(dys), _ptr_arr(xs), ptr(gamma), ptr(beta), ptr(stats), _ptr_arr(dxs), ptr(dgamma), ptr(dbeta),
+         ptr(dxsum), ptr(red), N, ctypes.cast(_int_arr(hw), ctypes.c_void_p), C, G, 1 if relu else 0, stream_ptr())
+    return dxs
+
+
 def relu_fwd(x):
     _chk(x, torch.bfloat16, "x")
     y = torch.empty_like(x)

@@ -177,13 +177,9 @@ class _ConvGnReluFn(torch.autograd.Function):
         conv, gn = unit.conv, unit.gn
         y1s = HF.conv2d_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, 1, 1, 1)
         gw, gb = gn.weight.detach(), gn.bias.detach()
-        y2s, stats = [], []
-        for y1 in y1s:
-            y2, st = HF.groupnorm_fwd(y1, gw, gb, gn.num_groups, gn.eps, relu=True)
-            y2s.append(y2)
-            stats.append(st)
+        y2s, stats = HF.groupnorm_fwd_ml(y1s, gw, gb, gn.num_groups, gn.eps, relu=True)      # all levels in one launch per pass
         ctx.unit, ctx.nl = unit, len(xs)
-        ctx.save_for_backward(*xs, *y1s, *stats)
+        ctx.save_for_backward(*xs, *y1s, stats)
         arena = _arena_of(conv)
         if arena is not None and conv.weight.requires_grad:
             for p in (conv.weight, conv.bias, gn.weight, gn.bias):
@@ -196,13 +192,12 @@ class _ConvGnReluFn(torch.autograd.Function):
         conv, gn = ctx.unit.conv, ctx.unit.gn
         nl = ctx.nl
         saved = ctx.saved_tensors
-        xs, y1s, stats = saved[:nl], saved[nl:2 * nl], saved[2 * nl:]
+        xs, y1s, stats = saved[:nl], saved[nl:2 * nl], saved[2 * nl]
         arena = _arena_of(conv)
         gw, gb = gn.weight.detach(), gn.bias.detach()
         dgw, dgb = arena.grad_view(gn.weight), arena.grad_view(gn.bias)
         dbias = arena.grad_view(conv.bias)      # the conv bias gradient (sum of dy1 over pixels) falls out of the GN backward pass
-        dy1s = [HF.groupnorm_bwd(dy2.contiguous(), y1, gw, gb, st, gn.num_groups, dgw, dgb, relu=True, dxsum=dbias)
-                for dy2, y1, st in zip(dy2s, y1s, stats)]
+        dy1s = HF.groupnorm_bwd_ml([d.contiguous() for d in dy2s], list(y1s), gw, gb, stats, gn.num_groups, dgw, dgb, relu=True, dxsum=dbias)
         arena.mark_ready(gn.weight)
         arena.mark_ready(gn.bias)
         arena.mark_ready(conv.bias)
