@@ -195,12 +195,15 @@ def test_fcos_inference_boxes_scores_and_nms_vs_oracle(cuda):
     for d in data:
         d["height"], d["width"] = 512, 640          # exercise detector_postprocess rescaling
     with torch.no_grad():
-        out = model(data)
+        assert len(model(data)) == 2                 # the public entry point
+        # GroupNorm statistics are accumulated with float atomics, so two forward passes differ in the last bits and a candidate
+        # sitting on the 0.05 threshold may flip: decode ONE set of tower outputs on both sides
         imgs = model.preprocess_image(data)
         feats = model.backbone(imgs.tensor)
         feats = [feats[f] for f in model.in_features]
         ct, bt = model.head.run_towers(feats)
         cls_buf, box_buf, hw = model.head.predict(ct, bt)
+        out = model.postprocess(model.inference(hw, ct, bt, imgs.image_sizes), data, imgs.image_sizes)
     locs = ot.locations(hw, model.fpn_strides)
     scales = model.head.scales.detach().cpu()
     bounds = [0]
