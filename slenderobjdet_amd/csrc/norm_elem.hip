@@ -382,6 +382,39 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
   }
 }
 
+// The same for EVERY trainable convolution of a model in one launch (61 launches of ~7 us each per FCOS step otherwise):
+// entries sorted by their first global element index; a thread finds its entry by binary search.
+struct PrepEntry {
+  long long elem0;      // first global element of this entry (prefix sum of K*RS*C)
+  long long src_off;    // fp32 offset into the parameter arena
+  long long krsc_off;   // bf16 offset into the KRSC compute arena
+  long long crsk_off;   // bf16 offset into the CRSK compute arena
+  long long scale_off;  // fp32 offset into the scale array, or -1
+  int K, RS, C, Cpad;
+};
+__global__ __launch_bounds__(256) void weight_prep_batched_kernel(const float* __restrict__ params, const float* __restrict__ scales,
+                                                                  const PrepEntry* __restrict__ tab, int n, long long total,
+                                                                  __bf16* __restrict__ krsc, __bf16* __restrict__ crsk) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tab[mid].elem0 <= i) lo = mid; else hi = mid - 1;
+    }
+    const PrepEntry e = tab[lo];
+    const long long j = i - e.elem0;
+    const int c = (int)(j % e.C);
+    const long long r = j / e.C;
+    const int t = (int)(r % e.RS);
+    const int k = (int)(r / e.RS);
+    float v = params[e.src_off + j];
+    if (e.scale_off >= 0) v *= scales[e.scale_off + k];
+    const __bf16 b = (__bf16)v;
+    krsc[e.krsc_off + ((long long)k * e.RS + t) * e.Cpad + c] = b;
+    crsk[e.crsk_off + ((long long)c * e.RS + t) * e.K + k] = b;
+  }
+}
+
 // per-output-channel scaling of a weight gradient (chain rule through the folded FrozenBN scale)
 __global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ g, const float* __restrict__ scale, int K, long long row) {
   const long long total = (long long)K * row;
@@ -615,6 +648,15 @@ extern "C" int sod_weight_prep(const float* w, const float* scale, void* w_krsc,
   if (!w || (!w_krsc && !w_crsk) || K <= 0 || RS <= 0 || C <= 0 || Cpad < C) return SOD_EARG;
   SOD_LAUNCH(weight_prep_kernel, dim3(blocks_for((long long)K * RS * C)), dim3(256), 0, (hipStream_t)stream, w, scale,
                      (__bf16*)w_krsc, (__bf16*)w_crsk, K, RS, C, Cpad);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_weight_prep_batched(const float* params, const float* scales, const void* table_dev, int n, long long total_elems,
+                                       void* krsc_arena, void* crsk_arena, void* stream) {
+  if (!params || !table_dev || n <= 0 || total_elems <= 0 || !krsc_arena || !crsk_arena) return SOD_EARG;
+  SOD_LAUNCH(weight_prep_batched_kernel, dim3(blocks_for(total_elems, 8192)), dim3(256), 0, (hipStream_t)stream, params, scales,
+             (const PrepEntry*)table_dev, n, total_elems, (__bf16*)krsc_arena, (__bf16*)crsk_arena);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -70,6 +70,46 @@ class ParamArena:
         self._comm_stream = None
         self._handles = []
 
+    # ------------------------------------------------------------------ bf16 compute copies of every trainable conv weight
+    def setup_batched_prep(self, model):
+        """One launch per step re-derives the bf16 KRSC / CRSK copies (FrozenBN scale folded) of ALL trainable convolution weights
+        from the fp32 arena, into two persistent bf16 arenas whose views the modules keep (``w_bf16`` / ``wt_bf16``)."""
+        mods = [m for m in model.modules() if getattr(m, "batched_prep_shape", None) is not None and m.weight.requires_grad
+                and id(m.weight) in self.index and getattr(m, "cin_pad", None) in (None, m.weight.shape[-1])]
+        self._prep_mods, self._prep_gen = mods, -1
+        if not mods or self.device.type != "cuda":
+            self._prep_mods = []
+            return
+        tab = np.zeros(len(mods), dtype=np.dtype([("e0", "<i8"), ("src", "<i8"), ("ko", "<i8"), ("co", "<i8"), ("so", "<i8"), ("K", "<i4"),
+                                                 ("RS", "<i4"), ("C", "<i4"), ("Cp", "<i4")]))
+        e0 = ko = so = 0
+        for i, m in enumerate(mods):
+            K, RS, C = m.batched_prep_shape()
+            n = K * RS * C
+            tab[i] = (e0, self.index[id(m.weight)][0], ko, ko, so if m.frozen_bn_scale() else -1, K, RS, C, C)
+            e0 += n
+            ko += (n + 63) // 64 * 64
+            so += K if m.frozen_bn_scale() else 0
+        self._prep_total = e0
+        self._krsc = torch.zeros(ko, dtype=torch.bfloat16, device=self.device)
+        self._crsk = torch.zeros(ko, dtype=torch.bfloat16, device=self.device)
+        self._scales = torch.ones(max(so, 1), dtype=torch.float32, device=self.device)
+        self._prep_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
+        for i, m in enumerate(mods):
+            K, RS, C = m.batched_prep_shape()
+            n, off = K * RS * C, int(tab[i]["ko"])
+            m.bind_batched_prep(self._krsc[off:off + n], self._crsk[off:off + n],
+                                self._scales[int(tab[i]["so"]):int(tab[i]["so"]) + K] if m.frozen_bn_scale() else None)
+
+    def prep_all(self):
+        from .._C import call, ptr, stream_ptr
+
+        call("sod_weight_prep_batched", ptr(self.params), ptr(self._scales), ptr(self._prep_tab), len(self._prep_mods), int(self._prep_total),
+             ptr(self._krsc), ptr(self._crsk), stream_ptr())
+        self._prep_gen = self.generation
+        for m in self._prep_mods:       # every registered weight is fresh now
+            m._prep_ver = (m.weight._version, m.weight.data_ptr())
+
     # ------------------------------------------------------------------ bookkeeping
     def grad_view(self, p):
         off, n = self.index[id(p)]

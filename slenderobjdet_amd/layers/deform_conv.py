@@ -89,10 +89,32 @@ class DeformConv(nn.Module):
         self._prep_key = None
         self.w_bf16 = self.wt_bf16 = self.bias_eff = None
 
+    # batched weight preparation (layers/arena.py): the GEMM view is (K, 1, 1, k*k*C)
+    frozen_bn = False
+
+    def batched_prep_shape(self):
+        return self.out_channels, 1, self.kernel_size * self.kernel_size * self.in_channels
+
+    def frozen_bn_scale(self):
+        return False
+
+    def bind_batched_prep(self, krsc, crsk, scale_view):
+        K, n = self.out_channels, self.kernel_size * self.kernel_size * self.in_channels
+        self._b_krsc, self._b_crsk = krsc.view(K, 1, 1, n), crsk.view(n, 1, 1, K)
+        self._prep_ver = None
+
     def prepare(self):
         arena = _arena_of(self)
         key = (self.weight._version, arena.generation if (arena is not None and self.weight.requires_grad) else -1, self.weight.data_ptr())
         if key == self._prep_key:
+            return
+        if arena is not None and getattr(self, "_b_krsc", None) is not None and self.weight.requires_grad:
+            ver = (self.weight._version, self.weight.data_ptr())
+            if arena._prep_gen != arena.generation or ver != self._prep_ver:
+                arena.prep_all()
+            self.w_bf16, self.wt_bf16 = self._b_krsc, self._b_crsk
+            self.bias_eff = self.bias.detach() if self.bias is not None else None
+            self._prep_ver, self._prep_key = ver, key
             return
         K, k, C = self.out_channels, self.kernel_size, self.in_channels
         # the GEMM sees a 1x1 convolution over k*k*C "channels" (tap-major, the layout deform_im2col writes)

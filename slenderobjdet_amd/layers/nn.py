@@ -69,6 +69,40 @@ class HipConv2d(nn.Module):
     def weight_kcrs(self):
         return self.weight.detach().permute(0, 3, 1, 2).contiguous()
 
+    # ---- batched weight preparation (layers/arena.py: one launch for all trainable convs instead of one per conv) ----
+    def batched_prep_shape(self):
+        K, R, S, C = self.weight.shape
+        return K, R * S, C
+
+    def frozen_bn_scale(self):
+        return self.frozen_bn
+
+    def bind_batched_prep(self, krsc, crsk, scale_view):
+        K, R, S, C = self.weight.shape
+        self._b_krsc, self._b_crsk, self._b_scale = krsc.view(K, R, S, C), crsk.view(C, R, S, K), scale_view
+        self._prep_ver = None
+
+    def _prepare_batched(self, arena, key):
+        if self.frozen_bn:
+            bn_key = (self.bn_weight._version, self.bn_bias._version, self.bn_running_mean._version, self.bn_running_var._version,
+                      self.bn_weight.data_ptr(), self.bias._version if self.bias is not None else 0)
+            if bn_key != getattr(self, "_bn_key", None):
+                scale = self.bn_weight * torch.rsqrt(self.bn_running_var + 1e-5)
+                shift = self.bn_bias - self.bn_running_mean * scale
+                self._b_scale.copy_(scale)
+                self.bn_scale = self._b_scale
+                self.bias_eff = (shift + (self.bias.detach() * scale if self.bias is not None else 0)).contiguous()
+                self._bn_key = bn_key
+                arena._prep_gen = -1
+        else:
+            self.bn_scale = None
+            self.bias_eff = self.bias.detach() if self.bias is not None else None
+        ver = (self.weight._version, self.weight.data_ptr())
+        if arena._prep_gen != arena.generation or ver != self._prep_ver:
+            arena.prep_all()
+        self.w_bf16, self.wt_bf16 = self._b_krsc, self._b_crsk
+        self._prep_ver, self._prep_key = ver, key
+
     def prepare(self, force=False):
         """(Re)build the bf16 compute copies when the master weights changed."""
         arena = _arena_of(self)
@@ -76,6 +110,8 @@ class HipConv2d(nn.Module):
                arena.generation if (arena is not None and self.weight.requires_grad) else -1, self.weight.data_ptr())
         if not force and key == self._prep_key:
             return
+        if arena is not None and getattr(self, "_b_krsc", None) is not None and self.weight.requires_grad:
+            return self._prepare_batched(arena, key)
         w = self.weight.detach()
         if self.frozen_bn:
             bn_key = (self.bn_weight._version, self.bn_bias._version, self.bn_running_mean._version, self.bn_running_var._version,

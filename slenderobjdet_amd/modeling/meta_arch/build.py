@@ -18,5 +18,6 @@ def build_model(cfg):
     if torch.device(cfg.MODEL.DEVICE).type == "cuda":
         arena = ParamArena(model)
         attach_arena(model, arena)
+        arena.setup_batched_prep(model)
         model.arena = arena
     return model
