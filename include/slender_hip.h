@@ -319,6 +319,16 @@ int sod_reppoints_box_loss_bwd(const float* pred, const float* target, const int
 int sod_reppoints_finalize(const float* focal_sum, const float* init_sums2, const float* refine_sums2, float* normalizer,
                            float momentum, int num_images, float init_weight, float* out3, void* stream);
 
+/* BBOX_REG_LOSS_TYPE "giou" of RetinaNet (retina_rotated.py:236-245) and AnchorHead (meta/heads/anchor_head.py:366-374): positives decode
+ * their deltas against the anchor (Box2BoxTransform.apply_deltas) and take fvcore giou_loss (eps 1e-7) against the matched gt box
+ * (matched_boxes (N,R,4)); same sums2 / EMA-normaliser / pitched bf16 gradient contract as sod_retina_box_loss_*. */
+int sod_retina_giou_loss_fwd(const float* pred, int pitch, const int* gt_labels, const float* anchors, const float* matched_boxes,
+                             int N, int R, int A, int num_classes, const float* weights4, float scale_clamp, float* sums2,
+                             float* normalizer, float momentum, float* ws, void* stream);
+int sod_retina_giou_loss_bwd(const float* pred, int pitch, const int* gt_labels, const float* anchors, const float* matched_boxes,
+                             int N, int R, int A, int num_classes, const float* weights4, float scale_clamp,
+                             const float* grad_num, const float* grad_den, void* dpred_bf16, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * The reference's own native operators (slender_det._C; bindings slender_det/layers/csrc/vision.cpp:64-80), fp32 NCHW.
  * BorderAlign: feature (B,4C,H,W), boxes (B,K,4) XYXY in feature coordinates -> out (B,C,K,4)

@@ -34,7 +34,18 @@ def label_anchors(anchors, gt_boxes, gt_classes, thresholds, labels, num_classes
     return torch.stack(out_l), torch.stack(out_b)
 
 
-def losses(anchors, pred_logits, pred_deltas, gt_labels, matched_boxes, num_classes, alpha, gamma, beta, weights, normalizer, momentum=0.9):
+def apply_deltas(deltas, boxes, weights, clamp=4.135166556742356):
+    """Box2BoxTransform.apply_deltas on XYXY boxes."""
+    w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    cx, cy = boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h
+    dx, dy = deltas[:, 0] / weights[0], deltas[:, 1] / weights[1]
+    dw, dh = (deltas[:, 2] / weights[2]).clamp(max=clamp), (deltas[:, 3] / weights[3]).clamp(max=clamp)
+    pcx, pcy, pw, ph = dx * w + cx, dy * h + cy, torch.exp(dw) * w, torch.exp(dh) * h
+    return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), 1)
+
+
+def losses(anchors, pred_logits, pred_deltas, gt_labels, matched_boxes, num_classes, alpha, gamma, beta, weights, normalizer, momentum=0.9,
+           box_reg_loss_type="smooth_l1"):
     """pred_logits (N,R,K), pred_deltas (N,R,4). Returns (dict, new_normalizer)."""
     gt_deltas = torch.stack([get_deltas(anchors, k, weights) for k in matched_boxes])
     valid = gt_labels >= 0
@@ -42,5 +53,9 @@ def losses(anchors, pred_logits, pred_deltas, gt_labels, matched_boxes, num_clas
     normalizer = momentum * normalizer + (1 - momentum) * max(int(pos.sum()), 1)
     target = torch.nn.functional.one_hot(gt_labels[valid].long(), num_classes + 1)[:, :-1].to(pred_logits.dtype)
     loss_cls = ol.sigmoid_focal_loss(pred_logits[valid], target, alpha, gamma, "sum")
-    loss_box = ol.smooth_l1_loss(pred_deltas[pos], gt_deltas[pos], beta, "sum")
+    if box_reg_loss_type == "giou":       # retina_rotated.py:236-242
+        pred_boxes = torch.stack([apply_deltas(k, anchors, weights) for k in pred_deltas])
+        loss_box = ol.giou_loss_xyxy(pred_boxes[pos], (matched_boxes if torch.is_tensor(matched_boxes) else torch.stack(list(matched_boxes)))[pos], "sum")
+    else:
+        loss_box = ol.smooth_l1_loss(pred_deltas[pos], gt_deltas[pos], beta, "sum")
     return {"loss_cls": loss_cls / normalizer, "loss_box_reg": loss_box / normalizer}, normalizer

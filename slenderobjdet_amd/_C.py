@@ -63,6 +63,8 @@ _SIGS = {
     "sod_anchor_match": [_P, _I, _P, _I, _F, _F, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "sod_retina_targets": [_P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P],
     "sod_retina_box_loss_fwd": [_P, _I, _P, _P, _I, _I, _I, _I, _F, _P, _P, _F, _P, _P],
+    "sod_retina_giou_loss_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _F, _P, _P],
+    "sod_retina_giou_loss_bwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P],
     "sod_retina_box_loss_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "sod_deform_im2col": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sod_deform_col2im": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -600,6 +600,88 @@ __global__ __launch_bounds__(256) void retina_box_kernel(const RetinaBoxArgs a, 
   }
 }
 
+// fvcore giou_loss of ONE pair and its gradient w.r.t. the first box (same arithmetic as giou_xyxy_kernel)
+__device__ __forceinline__ float giou_pair(const float* a, const float* b, float eps, float* g /* may be null */) {
+  const float x1 = a[0], y1 = a[1], x2 = a[2], y2 = a[3], x1g = b[0], y1g = b[1], x2g = b[2], y2g = b[3];
+  const float xk1 = fmaxf(x1, x1g), yk1 = fmaxf(y1, y1g), xk2 = fminf(x2, x2g), yk2 = fminf(y2, y2g);
+  const bool ov = (yk2 > yk1) && (xk2 > xk1);
+  const float inter = ov ? (xk2 - xk1) * (yk2 - yk1) : 0.f;
+  const float uni = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter;
+  const float iou = inter / (uni + eps);
+  const float xc1 = fminf(x1, x1g), yc1 = fminf(y1, y1g), xc2 = fmaxf(x2, x2g), yc2 = fmaxf(y2, y2g);
+  const float ac = (xc2 - xc1) * (yc2 - yc1);
+  if (g) {
+    auto dmax = [](float p, float q) { return p > q ? 1.f : (p == q ? 0.5f : 0.f); };
+    auto dmin = [](float p, float q) { return p < q ? 1.f : (p == q ? 0.5f : 0.f); };
+    const float iw = xk2 - xk1, ih = yk2 - yk1, w1 = x2 - x1, h1 = y2 - y1, cw = xc2 - xc1, ch = yc2 - yc1;
+    const float di[4] = {ov ? -dmax(x1, x1g) * ih : 0.f, ov ? -dmax(y1, y1g) * iw : 0.f, ov ? dmin(x2, x2g) * ih : 0.f, ov ? dmin(y2, y2g) * iw : 0.f};
+    const float da[4] = {-h1, -w1, h1, w1};
+    const float dc[4] = {-dmin(x1, x1g) * ch, -dmin(y1, y1g) * cw, dmax(x2, x2g) * ch, dmax(y2, y2g) * cw};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float du = da[e] - di[e];
+      const float diou = (di[e] * (uni + eps) - inter * du) / ((uni + eps) * (uni + eps));
+      const float dterm = ((dc[e] - du) * (ac + eps) - (ac - uni) * dc[e]) / ((ac + eps) * (ac + eps));
+      g[e] = -(diou - dterm);
+    }
+  }
+  return 1.f - (iou - (ac - uni) / (ac + eps));
+}
+
+// RetinaNet BBOX_REG_LOSS_TYPE "giou" (retina_rotated.py:236-245; AnchorHead, meta/heads/anchor_head.py:366-374): positives decode
+// their deltas against the anchor (Box2BoxTransform.apply_deltas) and take giou_loss against the matched gt box; backward chains
+// d(giou)/d(box) through the decode into the pitched bf16 delta gradient.
+struct RetinaGiouArgs {
+  const float* pred; const int* labels; const float* anchors; const float* gt; // pred (N,P,pitch), labels (N,R), anchors (R,4), gt (N,R,4)
+  int N, R, A, pitch, num_classes;
+  float wx, wy, ww, wh, clampv;
+};
+template <bool BWD>
+__global__ __launch_bounds__(256) void retina_giou_kernel(const RetinaGiouArgs a, float* __restrict__ part, const float* __restrict__ gnum,
+                                                          const float* __restrict__ gden, __bf16* __restrict__ dpred) {
+  __shared__ float red[4];
+  float acc = 0.f, npos = 0.f;
+  const float sc = BWD ? gnum[0] / gden[0] : 0.f;
+  const long long total = (long long)a.N * a.R, pix_per_img = a.R / a.A;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / a.R, r = i - n * a.R, px = r / a.A;
+    const int an = (int)(r - px * a.A);
+    const long long po = (n * pix_per_img + px) * a.pitch + an * 4;
+    const int lab = a.labels[i];
+    const bool pos = lab >= 0 && lab != a.num_classes;
+    f32x4_t gd = {0.f, 0.f, 0.f, 0.f};
+    if (pos) {
+      npos += 1.f;
+      const f32x4_t d = *reinterpret_cast<const f32x4_t*>(a.pred + po), anc = *reinterpret_cast<const f32x4_t*>(a.anchors + r * 4);
+      const f32x4_t gt = *reinterpret_cast<const f32x4_t*>(a.gt + i * 4);
+      const float aw = anc[2] - anc[0], ah = anc[3] - anc[1], acx = anc[0] + 0.5f * aw, acy = anc[1] + 0.5f * ah;
+      const float dw = d[2] / a.ww, dh = d[3] / a.wh;
+      const bool cw_ = dw > a.clampv, ch_ = dh > a.clampv;
+      const float pw = expf(cw_ ? a.clampv : dw) * aw, ph = expf(ch_ ? a.clampv : dh) * ah;
+      const float pcx = d[0] / a.wx * aw + acx, pcy = d[1] / a.wy * ah + acy;
+      const float box[4] = {pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph};
+      const float gb[4] = {gt[0], gt[1], gt[2], gt[3]};
+      float g[4];
+      acc += giou_pair(box, gb, 1e-7f, BWD ? g : nullptr);
+      if (BWD) {
+        gd[0] = (g[0] + g[2]) * aw / a.wx;
+        gd[1] = (g[1] + g[3]) * ah / a.wy;
+        gd[2] = cw_ ? 0.f : (g[2] - g[0]) * 0.5f * pw / a.ww;
+        gd[3] = ch_ ? 0.f : (g[3] - g[1]) * 0.5f * ph / a.wh;
+      }
+    }
+    if (BWD) {
+      bf16x4_t o = {(__bf16)(gd[0] * sc), (__bf16)(gd[1] * sc), (__bf16)(gd[2] * sc), (__bf16)(gd[3] * sc)};
+      *reinterpret_cast<bf16x4_t*>(dpred + po) = o;
+    }
+  }
+  if (!BWD) {
+    acc = block_sum_256(acc, red);
+    npos = block_sum_256(npos, red);
+    if (threadIdx.x == 0) { part[blockIdx.x] = acc; part[RED + blockIdx.x] = npos; }
+  }
+}
+
 // sums[0] = smooth-L1 sum over positives, sums[1] = number of positives; normalizer <- m*normalizer + (1-m)*max(npos,1)
 __global__ void retina_finish_kernel(const float* __restrict__ part, int nblk_, float* __restrict__ sums, float* __restrict__ normalizer,
                                      float momentum) {
@@ -779,6 +861,40 @@ extern "C" int sod_retina_box_loss_fwd(const float* pred, int pitch, const int* 
   const int g = nblk((long long)N * R);
   SOD_LAUNCH(retina_box_kernel<false>, dim3(g), dim3(256), 0, st, a, ws, nullptr, nullptr, nullptr);
   SOD_LAUNCH(retina_finish_kernel, dim3(1), dim3(256), 0, st, ws, g, sums2, normalizer, momentum);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+static int retina_giou_fill(RetinaGiouArgs& a, const float* pred, int pitch, const int* labels, const float* anchors, const float* gt, int N, int R,
+                            int A, int K, const float* w4, float clampv) {
+  if (!pred || !labels || !anchors || !gt || !w4 || N <= 0 || R <= 0 || A <= 0 || R % A || pitch < A * 4) return SOD_EARG;
+  for (int i = 0; i < 4; ++i) if (!(w4[i] > 0.f)) return SOD_EARG;
+  a = RetinaGiouArgs{pred, labels, anchors, gt, N, R, A, pitch, K, w4[0], w4[1], w4[2], w4[3], clampv};
+  return SOD_OK;
+}
+
+extern "C" int sod_retina_giou_loss_fwd(const float* pred, int pitch, const int* gt_labels, const float* anchors, const float* matched_boxes,
+                                        int N, int R, int A, int num_classes, const float* weights4, float scale_clamp, float* sums2,
+                                        float* normalizer, float momentum, float* ws, void* stream) {
+  RetinaGiouArgs a{};
+  int rc = retina_giou_fill(a, pred, pitch, gt_labels, anchors, matched_boxes, N, R, A, num_classes, weights4, scale_clamp);
+  if (rc || !sums2 || !ws) return rc ? rc : SOD_EARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int g = nblk((long long)N * R);
+  SOD_LAUNCH(retina_giou_kernel<false>, dim3(g), dim3(256), 0, st, a, ws, nullptr, nullptr, nullptr);
+  SOD_LAUNCH(retina_finish_kernel, dim3(1), dim3(256), 0, st, ws, g, sums2, normalizer, momentum);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_retina_giou_loss_bwd(const float* pred, int pitch, const int* gt_labels, const float* anchors, const float* matched_boxes,
+                                        int N, int R, int A, int num_classes, const float* weights4, float scale_clamp,
+                                        const float* grad_num, const float* grad_den, void* dpred_bf16, void* stream) {
+  RetinaGiouArgs a{};
+  int rc = retina_giou_fill(a, pred, pitch, gt_labels, anchors, matched_boxes, N, R, A, num_classes, weights4, scale_clamp);
+  if (rc || !grad_num || !grad_den || !dpred_bf16) return rc ? rc : SOD_EARG;
+  SOD_LAUNCH(retina_giou_kernel<true>, dim3(nblk((long long)N * R, 4096)), dim3(256), 0, (hipStream_t)stream, a, nullptr, grad_num, grad_den,
+             (__bf16*)dpred_bf16);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -737,3 +737,18 @@ def bce_logits_soft_bwd(logits, targets, labels, bg_label, grad_scale, scale_mul
     call("sod_bce_logits_soft_bwd", ptr(logits), ptr(targets), ptr(labels), int(bg_label), logits.numel(), ptr(grad_scale), float(scale_mul), ptr(d),
          stream_ptr())
     return d
+
+
+def retina_giou_loss_fwd(pred, pitch, gt_labels, anchors, matched_boxes, N, R, A, num_classes, weights, scale_clamp, normalizer, momentum):
+    """GIoU box regression of RetinaNet / AnchorHead on the pitched delta buffer; advances the EMA normaliser; returns [sum, num_pos]."""
+    sums = torch.empty(2, dtype=torch.float32, device=pred.device)
+    w = _float_arr(weights)
+    call("sod_retina_giou_loss_fwd", ptr(pred), pitch, ptr(gt_labels), ptr(anchors), ptr(matched_boxes), N, R, A, num_classes,
+         ctypes.cast(w, ctypes.c_void_p), float(scale_clamp), ptr(sums), ptr(normalizer), float(momentum), ptr(reduce_ws(pred.device)), stream_ptr())
+    return sums
+
+
+def retina_giou_loss_bwd(pred, pitch, gt_labels, anchors, matched_boxes, N, R, A, num_classes, weights, scale_clamp, grad_num, grad_den, dpred):
+    w = _float_arr(weights)
+    call("sod_retina_giou_loss_bwd", ptr(pred), pitch, ptr(gt_labels), ptr(anchors), ptr(matched_boxes), N, R, A, num_classes,
+         ctypes.cast(w, ctypes.c_void_p), float(scale_clamp), ptr(grad_num), ptr(grad_den), ptr(dpred), stream_ptr())

@@ -88,8 +88,12 @@ class _RetinaLossFn(torch.autograd.Function):
         N, P = cls_buf.shape[0], cls_buf.shape[1]
         A, K = head.num_anchors, head.num_classes
         R = P * A
-        sums = HF.retina_box_loss_fwd(box_buf, head.box_pitch, gt_labels, gt_deltas, N, R, A, K, model.smooth_l1_loss_beta,
-                                      model.loss_normalizer, model.loss_normalizer_momentum)    # also advances the EMA normaliser
+        if model.box_reg_loss_type == "giou":       # gt_deltas then holds the matched gt BOXES (N,R,4)
+            sums = HF.retina_giou_loss_fwd(box_buf, head.box_pitch, gt_labels, model.anchors_for(hw), gt_deltas, N, R, A, K, model.bbox_reg_weights,
+                                           model.scale_clamp, model.loss_normalizer, model.loss_normalizer_momentum)
+        else:
+            sums = HF.retina_box_loss_fwd(box_buf, head.box_pitch, gt_labels, gt_deltas, N, R, A, K, model.smooth_l1_loss_beta,
+                                          model.loss_normalizer, model.loss_normalizer_momentum)    # also advances the EMA normaliser
         focal_sum, _ = HF.focal_loss_fwd(cls_buf.view(N * R, K), gt_labels.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma)
         out = torch.stack([focal_sum[0], sums[0]]) / model.loss_normalizer
         ctx.model, ctx.geo = model, (hw, offs, N, P, A, K, R)
@@ -116,7 +120,11 @@ class _RetinaLossFn(torch.autograd.Function):
         dcls = HF.focal_loss_bwd(cls_buf.view(N * R, K), gt_labels.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma,
                                  scale_num=g2[0:1], scale_den=norm, den_mul=1.0, den_min=1e-12, out_bf16=True).view(N, P, head.kc)
         dbox = torch.zeros((N, P, head.box_pitch), dtype=torch.bfloat16, device=dev)
-        HF.retina_box_loss_bwd(box_buf, head.box_pitch, gt_labels, gt_deltas, N, R, A, K, model.smooth_l1_loss_beta, g2[1:2], norm, dbox)
+        if model.box_reg_loss_type == "giou":
+            HF.retina_giou_loss_bwd(box_buf, head.box_pitch, gt_labels, model.anchors_for(hw), gt_deltas, N, R, A, K, model.bbox_reg_weights,
+                                    model.scale_clamp, g2[1:2], norm, dbox)
+        else:
+            HF.retina_box_loss_bwd(box_buf, head.box_pitch, gt_labels, gt_deltas, N, R, A, K, model.smooth_l1_loss_beta, g2[1:2], norm, dbox)
         grads = []
         for pred, dbuf, kk, tower in ((head.cls_score, dcls, head.kc, cls_t), (head.bbox_pred, dbox, head.box_pitch, box_t)):
             dys = [dbuf.view(-1)[o * kk:] for o in offs]
@@ -138,8 +146,9 @@ class RetinaNet(nn.Module):
         self.focal_loss_alpha, self.focal_loss_gamma = r.FOCAL_LOSS_ALPHA, r.FOCAL_LOSS_GAMMA
         self.smooth_l1_loss_beta = r.SMOOTH_L1_LOSS_BETA
         self.box_reg_loss_type = r.BBOX_REG_LOSS_TYPE
-        if self.box_reg_loss_type != "smooth_l1":
-            raise NotImplementedError("RETINANET.BBOX_REG_LOSS_TYPE giou is not wired yet (sod_giou_loss_xyxy exists in the ABI)")
+        if self.box_reg_loss_type not in ("smooth_l1", "giou"):
+            raise ValueError(f"Invalid bbox reg loss type '{self.box_reg_loss_type}'")          # retina_rotated.py:243-244
+        self.scale_clamp = math.log(1000.0 / 16)
         self.iou_thresholds, self.iou_labels = list(r.IOU_THRESHOLDS), list(r.IOU_LABELS)
         self.bbox_reg_weights = tuple(r.BBOX_REG_WEIGHTS)
         self.score_threshold, self.topk_candidates, self.nms_threshold = r.SCORE_THRESH_TEST, r.TOPK_CANDIDATES_TEST, r.NMS_THRESH_TEST
@@ -183,6 +192,8 @@ class RetinaNet(nn.Module):
             classes = g.gt_classes.to(torch.int32).contiguous()
             _, matches, mlab = HF.anchor_match(boxes, anchors, self.iou_thresholds, self.iou_labels, True)
             HF.retina_targets(anchors, boxes, classes, matches, mlab, self.num_classes, self.bbox_reg_weights, labels[i], deltas[i])
+            if self.box_reg_loss_type == "giou":      # the GIoU loss compares decoded boxes with the matched gt boxes themselves
+                deltas[i] = boxes[matches.long()] if len(boxes) else 0.0
         return labels, deltas
 
     def forward(self, batched_inputs):
