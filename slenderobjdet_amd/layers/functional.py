@@ -643,6 +643,8 @@ def box2box_get_deltas(src, tgt, weights):
     _chk(src, torch.float32, "src"); _chk(tgt, torch.float32, "tgt")
     n, D = src.shape
     out = torch.empty_like(src)
+    if n == 0:
+        return out
     w = _float_arr(weights)
     call("sod_box2box_get_deltas", ptr(src), ptr(tgt), n, D, ctypes.cast(w, ctypes.c_void_p), ptr(out), stream_ptr())
     return out
@@ -653,6 +655,8 @@ def box2box_apply_deltas(deltas, boxes, weights, scale_clamp, k=1, ld=0):
     _chk(deltas, torch.float32, "deltas"); _chk(boxes, torch.float32, "boxes")
     n, D = boxes.shape
     out = torch.empty((n, k * D), dtype=torch.float32, device=boxes.device)
+    if n == 0:
+        return out
     w = _float_arr(weights)
     call("sod_box2box_apply_deltas", ptr(deltas), ptr(boxes), n, k, D, ld, ctypes.cast(w, ctypes.c_void_p), float(scale_clamp), ptr(out), stream_ptr())
     return out

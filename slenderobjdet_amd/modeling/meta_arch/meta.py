@@ -548,3 +548,227 @@ class LRTBTopkHead(LRTBHead):
         init_labels = torch.where(topk, labels, torch.full_like(labels, K)).contiguous()
         stats = torch.cat((stats, (ctr_std * topk).sum().reshape(1)))
         return init_labels, ctr_std.contiguous(), stats
+
+
+# ------------------------------------------------------------------------------------------------ AnchorHead
+class _InitBoxLossFn(torch.autograd.Function):
+    """smooth_l1(pred[fg] / (4 stride), gt[fg] / (4 stride), 0.11, "sum") / max(#fg, 1)   (meta/heads/anchor_head.py:353-361)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, obj, strides):
+        pred = pred.contiguous()
+        sums = HF.reppoints_box_loss_fwd(pred, target, obj, strides, -1, 0.11)
+        ctx.save_for_backward(pred, target, obj, strides, sums)
+        return sums[0:1] / torch.clamp(sums[1:2], min=1.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, obj, strides, sums = ctx.saved_tensors
+        return HF.reppoints_box_loss_bwd(pred, target, obj, strides, -1, 0.11, g.contiguous().float(), sums[1:2], 1.0, 1.0), None, None, None
+
+
+@MEAT_HEADS_REGISTRY.register()
+class AnchorHead(nn.Module):
+    """slender_det/modeling/meta_arch/meta/heads/anchor_head.py:25-527: a RetinaNet head (A anchors per location, 3x3 ``cls_out`` /
+    ``loc_refine_out``) on the unified GN towers with a feature-adaption layer in {none, unsupervised, split, supervised}, plus an
+    auxiliary "init box" (two corner points per location, scaled by 1/2/4/8/16, supervised at the nearest point of every gt box,
+    ``nearest_point_match``).  Anchor labelling, focal / smooth-L1 / GIoU losses and the EMA normaliser are RetinaNet's
+    (retinanet.py: ``_RetinaLossFn``); the init loss is the stride-normalised smooth-L1 kernel of the RepPoints path.
+    ``RES_REFINE`` must be False, as in the reference's configs (its residual add mixes 4- and 4A-channel tensors)."""
+
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        from .retinanet import RetinaNetHead
+
+        h = cfg.MODEL.META_ARCH
+        self.in_channels = input_shape[0].channels
+        self.in_features, self.fpn_strides = list(h.IN_FEATURES), list(h.FPN_STRIDES)
+        self.strides = [s.stride for s in input_shape]
+        self.num_classes, self.feat_channels, self.stacked_convs, self.norm = h.NUM_CLASSES, h.FEAT_CHANNELS, h.STACK_CONVS, h.NORM
+        self.feat_adaption, self.res_refine = h.FEAT_ADAPTION, h.RES_REFINE
+        self.gradient_mul, self.prior_prob = h.GRADIENT_MUL, h.PRIOR_PROB
+        self.focal_loss_gamma, self.focal_loss_alpha = h.FOCAL_LOSS_GAMMA, h.FOCAL_LOSS_ALPHA
+        self.loss_cls_weight, self.loss_loc_init_weight, self.loss_loc_refine_weight = h.LOSS_CLS_WEIGHT, h.LOSS_LOC_INIT_WEIGHT, h.LOSS_LOC_REFINE_WEIGHT
+        self.score_threshold, self.topk_candidates, self.nms_threshold = h.SCORE_THRESH_TEST, h.TOPK_CANDIDATES_TEST, h.NMS_THRESH_TEST
+        self.max_detections_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
+        self.box_reg_loss_type = h.BBOX_REG_LOSS_TYPE
+        if self.box_reg_loss_type not in ("smooth_l1", "giou"):
+            raise ValueError(f"Invalid bbox reg loss type '{self.box_reg_loss_type}'")
+        if self.feat_adaption not in (None, "none", "unsupervised", "split", "supervised"):
+            raise AssertionError(self.feat_adaption)                    # anchor_head.py:104
+        if self.res_refine:
+            raise NotImplementedError("AnchorHead with RES_REFINE adds a 4-channel tensor to 4A channels in the reference; not built")
+        if self.norm not in ("GN", ""):
+            raise NotImplementedError(f"META_ARCH.NORM {self.norm!r}: only 'GN' and '' are built")
+        ag = cfg.MODEL.ANCHOR_GENERATOR
+        self.anchor_sizes, self.anchor_ratios, self.anchor_offset = [list(s) for s in ag.SIZES], [list(a) for a in ag.ASPECT_RATIOS], ag.OFFSET
+        self.num_anchors = len(self.anchor_sizes[0]) * len(self.anchor_ratios[0])
+        self.bbox_reg_weights = tuple(h.BBOX_REG_WEIGHTS)
+        self.iou_thresholds, self.iou_labels = list(h.IOU_THRESHOLDS), list(h.IOU_LABELS)
+        self.smooth_l1_loss_beta = 0.11
+        self.scale_clamp = math.log(1000.0 / 16)
+        C = self.feat_channels
+        assert self.in_channels == C == h.LOC_FEAT_CHANNELS == 256, "AnchorHead is built for 256-channel features"
+        unit = ConvGnRelu if self.norm == "GN" else ConvReluML
+        self.cls_subnet = nn.ModuleList([unit(C) for _ in range(self.stacked_convs)])
+        self.loc_subnet = nn.ModuleList([unit(C) for _ in range(self.stacked_convs)])
+        self.loc_init_conv = ConvML(C, C, 3, 1, relu=True)
+        self.loc_init_out = ConvML(C, 8, 3, 1, out_f32=True)                 # 3x3 -> (x1, y1, x2, y2) offsets (+4 pad)
+        fa = self.feat_adaption
+        if fa in (None, "none"):
+            self.cls_conv, self.loc_refine_conv = ConvML(C, C, 3, 1, relu=True), ConvML(C, C, 3, 1, relu=True)
+        else:
+            self.cls_conv, self.loc_refine_conv = DeformConv(C, C, 3, 1, 1, relu=True), DeformConv(C, C, 3, 1, 1, relu=True)
+            if fa == "unsupervised":
+                self.offset_conv = ConvML(C, 24, 1, 0, out_f32=True)
+            elif fa == "split":
+                self.offset_conv_cls, self.offset_conv_loc = ConvML(C, 24, 1, 0, out_f32=True), ConvML(C, 24, 1, 0, out_f32=True)
+            else:
+                self.offset_conv = ConvML(C, 16, 1, 0, out_f32=True)         # 14 offsets (+2 pad)
+        self.kc = self.num_anchors * self.num_classes
+        assert self.kc % 8 == 0
+        self.box_pitch = (self.num_anchors * 4 + 7) // 8 * 8
+        self.cls_score = HipConv2d(C, self.kc, 3, 1, 1, bias=True)           # cls_out
+        self.bbox_pred = HipConv2d(C, self.box_pitch, 3, 1, 1, bias=True)    # loc_refine_out
+        with torch.no_grad():         # anchor_head.py:123-137 (offset convs and DeformConv keep their default init there)
+            for u in list(self.cls_subnet) + list(self.loc_subnet):
+                u.conv.init_normal(0.01, 0.0)
+            mods = [self.loc_init_conv.conv, self.loc_init_out.conv, self.cls_score, self.bbox_pred]
+            mods += [m.conv for m in (self.cls_conv, self.loc_refine_conv) if isinstance(m, ConvML)]
+            for m in mods:
+                m.init_normal(0.01, 0.0)
+            self.loc_init_out.conv.weight[4:].zero_()
+            self.bbox_pred.weight[self.num_anchors * 4:].zero_()
+            self.cls_score.bias.fill_(-math.log((1 - self.prior_prob) / self.prior_prob))
+            for n, rows in (("offset_conv", 14 if fa == "supervised" else 18), ("offset_conv_cls", 18), ("offset_conv_loc", 18)):
+                if hasattr(self, n):
+                    conv = getattr(self, n).conv
+                    bound = 1.0 / math.sqrt(C)                               # nn.Conv2d default init (kaiming_uniform_(a=sqrt(5)))
+                    conv.weight.uniform_(-bound, bound)
+                    conv.bias.uniform_(-bound, bound)
+                    conv.weight[rows:].zero_()
+                    conv.bias[rows:].zero_()
+        self.register_buffer("loss_normalizer", torch.tensor([100.0]))      # anchor_head.py:62-63
+        self.loss_normalizer_momentum = 0.9
+        self._anchor_cache, self._grid_cache = {}, {}
+        self._predict = RetinaNetHead.predict
+        self.last_targets = None
+
+    # attribute names _RetinaLossFn reads from ``model`` and ``model.head``
+    @property
+    def head(self):
+        return self
+
+    @property
+    def device(self):
+        return self.loss_normalizer.device
+
+    def predict(self, cls_t, box_t):
+        return self._predict(self, cls_t, box_t)
+
+    point_grid = RepPointsDetector.point_grid
+
+    def anchors_for(self, level_hw):
+        from ..anchor_generator import grid_anchors
+
+        key = tuple(level_hw)
+        if key not in self._anchor_cache:
+            per_level = grid_anchors(level_hw, self.strides, self.anchor_sizes, self.anchor_ratios, self.anchor_offset, self.device)
+            self._anchor_cache[key] = torch.cat(per_level).contiguous()
+        return self._anchor_cache[key]
+
+    def run_head(self, features):
+        """-> cls towers, box towers (inputs of the 3x3 prediction convs), raw init offsets per level (N,H,W,8)."""
+        nl = len(features)
+        cls_f, loc_f = list(features), list(features)
+        for u in self.cls_subnet:
+            cls_f = u(cls_f)
+        for u in self.loc_subnet:
+            loc_f = u(loc_f)
+        raw = self.loc_init_out(self.loc_init_conv(loc_f))
+        fa = self.feat_adaption
+        if fa in (None, "none"):
+            return self.cls_conv(cls_f), self.loc_refine_conv(loc_f), raw
+        if fa == "unsupervised":
+            off_c = off_l = self.offset_conv(loc_f)
+        elif fa == "split":
+            off_c, off_l = self.offset_conv_cls(loc_f), self.offset_conv_loc(loc_f)
+        else:       # supervised (anchor_head.py:192-209): [flip_xy(grad_mul(init)), offset_conv(loc_feat)] - dcn_base_offset
+            ext = self.offset_conv(loc_f)
+            base = torch.tensor([[i, j] for i in (-1.0, 0.0, 1.0) for j in (-1.0, 0.0, 1.0)], device=raw[0].device).reshape(-1)
+            off_c = []
+            for l in range(nl):
+                r4 = raw[l][..., :4]
+                gm = (1 - self.gradient_mul) * r4.detach() + self.gradient_mul * r4
+                flipped = torch.stack((gm[..., 1], gm[..., 0], gm[..., 3], gm[..., 2]), dim=-1)
+                off = torch.cat((flipped, ext[l][..., :14]), dim=-1) - base
+                off_c.append(torch.cat((off, off.new_zeros(off.shape[:-1] + (6,))), dim=-1).contiguous())
+            off_l = off_c
+        cf = [self.cls_conv(cls_f[l], off_c[l], off_ld=24) for l in range(nl)]
+        lf = [self.loc_refine_conv(loc_f[l], off_l[l], off_ld=24) for l in range(nl)]
+        return cf, lf, raw
+
+    def init_boxes(self, raw, hw):
+        """loc_out_init * factor + (cx, cy, cx, cy)  (anchor_head.py:213-219) concatenated to (N, X, 4)."""
+        centers, _, _ = self.point_grid(hw)
+        N = raw[0].shape[0]
+        out, o = [], 0
+        for l, (h, w) in enumerate(hw):
+            c = centers[o:o + h * w]
+            out.append(raw[l][..., :4].reshape(N, h * w, 4) * float(2 ** l) + torch.cat((c, c), dim=1))
+            o += h * w
+        return torch.cat(out, dim=1)
+
+    @torch.no_grad()
+    def label_anchors(self, anchors, gt_instances):
+        """anchor_head.py:394-434 (RetinaNet.label_anchors); for "giou" the second output holds the matched gt boxes."""
+        N, R = len(gt_instances), anchors.shape[0]
+        labels = torch.empty((N, R), dtype=torch.int32, device=anchors.device)
+        deltas = torch.empty((N, R, 4), dtype=torch.float32, device=anchors.device)
+        for i, g in enumerate(gt_instances):
+            boxes = g.gt_boxes.tensor.float().contiguous()
+            classes = g.gt_classes.to(torch.int32).contiguous()
+            _, matches, mlab = HF.anchor_match(boxes, anchors, self.iou_thresholds, self.iou_labels, True)
+            HF.retina_targets(anchors, boxes, classes, matches, mlab, self.num_classes, self.bbox_reg_weights, labels[i], deltas[i])
+            if self.box_reg_loss_type == "giou":
+                deltas[i] = boxes[matches.long()] if len(boxes) else 0.0
+        return labels, deltas
+
+    @torch.no_grad()
+    def init_targets(self, hw, gt_instances, image_sizes):
+        """get_ground_truth (anchor_head.py:241-283): nearest_point_match per image, off-image centres switched off."""
+        centers, strides, lvl_start = self.point_grid(hw)
+        counts = [len(g) for g in gt_instances]
+        if min(counts) == 0:
+            raise ValueError("No gt or bboxes")
+        dev = centers.device
+        box_off = torch.tensor([0] + counts, dtype=torch.int64).cumsum(0).to(torch.int32).to(dev, non_blocking=True)
+        boxes = torch.cat([g.gt_boxes.tensor for g in gt_instances]).float().contiguous()
+        obj, lab = HF.reppoints_point_match(centers, strides, lvl_start, boxes, box_off, len(counts), max(counts), "nearest_points", 4.0)
+        hwt = torch.tensor([[float(h), float(w)] for h, w in image_sizes], dtype=torch.float32).to(dev, non_blocking=True)
+        invalid = (centers[None, :, 0] >= hwt[:, 1:2]) | (centers[None, :, 1] >= hwt[:, 0:1])
+        return obj.masked_fill(invalid, 0).contiguous(), lab, strides
+
+    def forward(self, images, features, gt_instances=None):
+        from .retinanet import _RetinaLossFn
+
+        hw = [(f.shape[1], f.shape[2]) for f in features]
+        cls_t, box_t, raw = self.run_head(features)
+        if not self.training:
+            with torch.no_grad():
+                cls_buf, box_buf, _, offs = self.predict(cls_t, box_t)
+                return self.inference(hw, cls_buf, box_buf, offs, images.image_sizes)
+        anchors = self.anchors_for(hw)
+        gt_labels, gt_deltas = self.label_anchors(anchors, gt_instances)
+        obj, init_lab, strides = self.init_targets(hw, gt_instances, images.image_sizes)
+        self.last_targets = (gt_labels, gt_deltas, obj, init_lab)
+        out = _RetinaLossFn.apply(self, self.cls_score.weight, gt_labels, gt_deltas, *cls_t, *box_t)
+        init = _InitBoxLossFn.apply(self.init_boxes(raw, hw), init_lab, obj, strides)
+        return {"loss_cls": out[0] * self.loss_cls_weight, "loss_loc_init": init[0] * self.loss_loc_init_weight,
+                "loss_loc_refine": out[1] * self.loss_loc_refine_weight}
+
+    @torch.no_grad()
+    def inference(self, level_hw, cls_buf, box_buf, offs, image_sizes):
+        from .retinanet import RetinaNet
+
+        return RetinaNet.inference(self, level_hw, cls_buf, box_buf, offs, image_sizes)

@@ -259,6 +259,96 @@ def pointset_head_golden(g):
     return meta
 
 
+def anchor_head_golden(g, rm):
+    """AnchorHead (meta/heads/anchor_head.py) built and run by the reference's own Python on CPU; detectron2 / fvcore pieces restated."""
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from oracle import losses as ol
+    from oracle import rcnn as orc
+
+    class B2B:
+        def __init__(self, weights):
+            self.weights = weights
+
+        def get_deltas(self, src, tgt):
+            return orc.get_deltas(src, tgt, self.weights)
+
+        def apply_deltas(self, deltas, boxes):
+            return orc.apply_deltas(deltas, boxes, self.weights)
+
+    sizes = [[x, x * 2 ** (1.0 / 3), x * 2 ** (2.0 / 3)] for x in [32, 64, 128, 256, 512]]
+    ratios = [[0.5, 1.0, 2.0]]
+
+    class AG:
+        num_cell_anchors = [9] * 5
+
+        def __call__(self, features):
+            hw = [tuple(f.shape[-2:]) for f in features]
+            return [Boxes(a) for a in orc.anchors(hw, [8, 16, 32, 64, 128], sizes, ratios)]
+
+    Boxes.cat = classmethod(lambda cls, bl: cls(torch.cat([b.tensor for b in bl])))
+    _stub("detectron2.modeling.box_regression", Box2BoxTransform=B2B)
+    _stub("detectron2.modeling.anchor_generator", build_anchor_generator=lambda cfg, shp: AG())
+    sys.modules["fvcore.nn"].giou_loss = lambda a, b, reduction="none": ol.giou_loss_xyxy(a, b, reduction)
+    _stub("slender_det.modeling.matchers", nearest_point_match=rm.nearest_point_match)
+    for n in ("refah", "refah.heads"):
+        _stub(n)
+    _load("refah.heads.meta_head", "slender_det/modeling/meta_arch/meta/heads/meta_head.py", "refah.heads")
+    _load("refah.heads.utils", "slender_det/modeling/meta_arch/meta/heads/utils.py", "refah.heads")
+    ah = _load("refah.heads.anchor_head", "slender_det/modeling/meta_arch/meta/heads/anchor_head.py", "refah.heads")
+    meta = {}
+    C = 32
+    hw = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    strides = [8, 16, 32, 64, 128]
+    for tag, fa, box_loss in (("none", "none", "giou"), ("sup", "supervised", "smooth_l1"), ("unsup", "unsupervised", "giou")):
+        hp = SimpleNamespace(
+            IN_FEATURES=["p3", "p4", "p5", "p6", "p7"], FPN_STRIDES=strides, NUM_CLASSES=80, FEAT_CHANNELS=C, STACK_CONVS=3, NORM="GN",
+            FEAT_ADAPTION=fa, RES_REFINE=False, LOC_FEAT_CHANNELS=C, GRADIENT_MUL=0.1, PRIOR_PROB=0.01, FOCAL_LOSS_GAMMA=2.0, FOCAL_LOSS_ALPHA=0.25,
+            LOSS_CLS_WEIGHT=1.0, LOSS_LOC_INIT_WEIGHT=0.5, LOSS_LOC_REFINE_WEIGHT=1.0, SCORE_THRESH_TEST=0.05, TOPK_CANDIDATES_TEST=1000,
+            NMS_THRESH_TEST=0.5, BBOX_REG_LOSS_TYPE=box_loss, BBOX_REG_WEIGHTS=(1.0, 1.0, 1.0, 1.0), IOU_THRESHOLDS=[0.4, 0.5], IOU_LABELS=[0, -1, 1])
+        cfg = SimpleNamespace(MODEL=SimpleNamespace(META_ARCH=hp), TEST=SimpleNamespace(DETECTIONS_PER_IMAGE=100))
+        torch.manual_seed(13)
+        head = ah.AnchorHead(cfg, [SimpleNamespace(channels=C, stride=s) for s in strides])
+        with torch.no_grad():
+            for n, p in head.named_parameters():
+                if n.endswith("weight") and p.dim() == 4 and "subnet" not in n:
+                    p.mul_(5.0)
+                p.copy_(p.half().float())
+        head.train()
+        feats = [(torch.randn(2, C, h, w, generator=g) * 1.5).half().float() for h, w in hw]
+        gtb = [random_boxes(g, 5, 128, 160), random_boxes(g, 8, 128, 160)]
+        gtc = [torch.randint(0, 80, (len(b),), generator=g) for b in gtb]
+
+        class _I(SimpleNamespace):
+            def __len__(self):
+                return len(self.gt_classes)
+
+        sizes_img = [(120, 150), (128, 160)]
+        inst = [_I(gt_boxes=Boxes(b), gt_classes=c_, image_size=s) for b, c_, s in zip(gtb, gtc, sizes_img)]
+        images = SimpleNamespace(image_sizes=sizes_img)
+        losses = head(images, feats, inst)
+        params = dict(head.named_parameters())
+        grads = torch.autograd.grad(sum(losses.values()), list(params.values()), allow_unused=True)
+        keys = ("loss_cls", "loss_loc_init", "loss_loc_refine")
+        out = {"hw": np.array(hw), "strides": np.array(strides), "channels": np.array(C), "losses": np.array([float(losses[k]) for k in keys]),
+               "normalizer": np.array(float(head.loss_normalizer)), "image_sizes": np.array(sizes_img),
+               "cfg": np.array(json.dumps(dict(fa=fa, box_loss=box_loss)))}
+        for l, f in enumerate(feats):
+            out[f"feat{l}"] = f.numpy().astype(np.float16)
+        for i in range(2):
+            out[f"gt_boxes{i}"], out[f"gt_classes{i}"] = gtb[i].numpy(), gtc[i].numpy()
+        for (n, p), gr in zip(params.items(), grads):
+            out["param:" + n] = p.detach().numpy().astype(np.float16)
+            out["gradnorm:" + n] = np.array(0.0 if gr is None else float(gr.norm()))
+        for n in ("loc_refine_out.weight", "loc_init_out.weight"):
+            out["grad:" + n] = grads[list(params).index(n)].numpy()
+        np.savez_compressed(os.path.join(OUT, f"anchor_head_{tag}.npz"), **out)
+        meta[f"anchor_head_{tag}.npz"] = ("reference: meta/heads/anchor_head.py:25-434 + meta_head.py + matchers/rep_matcher.py (reference Python x "
+                                          "restated anchor generator / Box2BoxTransform / Matcher / focal / giou / smooth-L1"
+                                          + (" / DeformConv" if fa != "none" else "") + ")")
+        print("anchor", tag, {k: float(v) for k, v in losses.items()}, float(head.loss_normalizer))
+    return meta
+
+
 def lrtb_head_golden(g):
     """LRTBHead (meta/heads/lrtb_head.py) built and run by the reference's own Python on CPU, three configurations."""
     iou_mod = _load("ref_iou_loss2", "slender_det/layers/iou_loss.py")
@@ -406,6 +496,7 @@ def main():
                                     "(pairwise_iou, Matcher, sigmoid_focal_loss_jit, smooth_l1_loss)")
     meta.update(pointset_head_golden(g))
     meta.update(lrtb_head_golden(g))
+    meta.update(anchor_head_golden(g, rm))
     # ------------------------------------------------------------------ TopKMatcher: pure reference
     sys.modules["detectron2.layers"].nonzero_tuple = lambda x: x.nonzero(as_tuple=True)
     tk = _load("ref_topk_matcher", "slender_det/modeling/matchers/topk_matcher.py")

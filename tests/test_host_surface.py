@@ -159,9 +159,9 @@ def test_ablation_meta_arch_builds_from_repo_config_cpu():
     C = 256      # reference parameter count of this head (pointset_head.py:19-88), pitch padding excluded
     ref = 2 * 3 * (C * C * 9 + C + 2 * C) + (C * C * 9 + C) + (C * 18 + 18) + 2 * (C * C * 9) + (C * 80 + 80) + (C * 18 + 18)
     assert sum(p.numel() for p in h.parameters()) - 2 * 6 * (C + 1) == ref
-    for name in ("LRTBHead", "LRTBTopkHead"):
+    for name in ("LRTBHead", "LRTBTopkHead", "AnchorHead"):
         assert name in MEAT_HEADS_REGISTRY
-    cfg.MODEL.META_ARCH.NAME = "AnchorHead"          # not built: must fail loudly at the registry
+    cfg.MODEL.META_ARCH.NAME = "NoSuchHead"          # unknown heads fail loudly at the registry
     with pytest.raises(KeyError):
         build_model(cfg)
     cfg2 = fresh_cfg()
