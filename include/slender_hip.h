@@ -74,6 +74,9 @@ int sod_conv2d_dgrad_ml(int nlev, const void* const* dy, const void* wt, void* c
 int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, float* dw, const float* qscale,
                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                         long long dy_img_stride, int splits, void* stream);
+/* Optional caller-owned scratch (fp32, >= 32 MiB recommended) for the current device: weight gradients whose output has few 128x128
+ * tiles then write per-split partial tiles and sum them in a second kernel instead of contending on global atomics. NULL disables. */
+int sod_conv_set_workspace(void* ws, long long bytes);
 
 /* ---------------------------------------------------------------------------------------------------------
  * GroupNorm (+ fused ReLU), NHWC bf16 — nn.GroupNorm(32, C) + nn.ReLU in FCOSHead (fcosv2.py:315-336).

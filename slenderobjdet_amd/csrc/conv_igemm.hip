@@ -442,6 +442,7 @@ struct WgradArgs {
   float* dw;           // [K][R][S][C] fp32, accumulated atomically
   const float* qscale; // optional per-output-channel factor (folded FrozenBN scale)
   int dbg_plain_store; // timing experiment only (SOD_WGRAD_PLAIN=1): racy plain stores instead of atomics
+  float* partial;      // optional [nz][tiles][128][128] fp32: blocks store their partial tile, wgrad_reduce_kernel sums the splits
   int N, C, K;
   int R, S, stride, pad, dil;
   int V, nz, v_per_split;   // total virtual pixels; v_per_split multiple of 64
@@ -619,6 +620,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 
   // D[row=q][col=c]
   const int fr = lane & 15, fg = lane >> 4;
+  float* ptile = a.partial ? a.partial + ((size_t)z * (a.QT * a.CT * RS) + ((size_t)qt * a.CT + ct) * RS + tap) * (128 * 128) : nullptr;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -630,11 +632,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
       for (int j = 0; j < 4; ++j) {
         const int c = c0 + (wc * 4 + j) * 16 + fr;
         if (c < a.C) {
-          if (a.dbg_plain_store) a.dw[((size_t)q * RS + tap) * a.C + c] = acc[i][j][e] * qs;
+          if (a.partial) ptile[((wq * 4 + i) * 16 + fg * 4 + e) * 128 + (wc * 4 + j) * 16 + fr] = acc[i][j][e];
+          else if (a.dbg_plain_store) a.dw[((size_t)q * RS + tap) * a.C + c] = acc[i][j][e] * qs;
           else atomicAdd(a.dw + ((size_t)q * RS + tap) * a.C + c, acc[i][j][e] * qs);
         }
       }
     }
+  }
+}
+
+// Second stage of the split-over-pixels weight gradient for shapes with FEW output tiles (many splits per tile): the splits'
+// partial tiles are summed here instead of hammering one 64-KB tile with nz x 16 K global atomics (measured: 15-50 us per call).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
+  const int RS = a.R * a.S, tiles = a.QT * a.CT * RS;
+  const long long total = (long long)tiles * 128 * 32;          // float4 columns
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i & 31), row = (int)((i >> 5) & 127);
+    int t = (int)(i >> 12);
+    const int tap = t % RS; t /= RS;
+    const int ct = t % a.CT, qt = t / a.CT;
+    const int q = qt * 128 + row, c = ct * 128 + c4 * 4;
+    if (q >= a.K || c >= a.C) continue;
+    const float* src = a.partial + ((size_t)(i >> 12) * 128 + row) * 128 + c4 * 4;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    // blockIdx.y = chunk of splits (keeps >= 512 workgroups in flight for 4-tile shapes); chunks meet in dw with one atomic each
+    const int zc = (a.nz + (int)gridDim.y - 1) / (int)gridDim.y, z0 = (int)blockIdx.y * zc;
+    const int z1 = min(a.nz, z0 + zc);
+    for (int z = z0; z < z1; ++z) acc += *reinterpret_cast<const f32x4_t*>(src + (size_t)z * tiles * (128 * 128));
+    const float qs = a.qscale ? a.qscale[q] : 1.f;
+    float* dst = a.dw + ((size_t)q * RS + tap) * a.C + c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < a.C) atomicAdd(dst + e, acc[e] * qs);
   }
 }
 
@@ -738,7 +767,7 @@ int fill_level(ConvArgs& a, int l, const void* src, void* dst, int Hs, int Ws, i
   return SOD_OK;
 }
 
-int launch_wgrad(WgradArgs& a, int splits, hipStream_t st) {
+int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, long long ws_bytes = 0) {
   a.QT = (a.K + 127) / 128; a.CT = (a.C + 127) / 128;
   const int tiles = a.QT * a.CT * a.R * a.S;
   int V = 0;
@@ -777,7 +806,20 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
+  // two-stage reduction when few tiles share many splits (1x1 convs of the backbone, 3x3 convs with <= 128 channels)
+  // Measured on the FCOS R50 step: 447.4 vs 447.5 img/s (the 4-tile shapes gain <= 10 %, the rest lose the reduce launch), so this
+  // stays an opt-in experiment (SOD_WGRAD_TWO_STAGE=1 and a registered workspace).
+  static const int two_stage = getenv("SOD_WGRAD_TWO_STAGE") ? atoi(getenv("SOD_WGRAD_TWO_STAGE")) : 0;
+  const long long need = (long long)a.nz * tiles * 128 * 128 * (long long)sizeof(float);
+  a.partial = (two_stage && ws && a.nz >= 8 && tiles <= 32 && need <= ws_bytes) ? ws : nullptr;
   SOD_LAUNCH(conv_wgrad_kernel, dim3(a.nz * tiles), dim3(256), lds, st, a);
+  if (a.partial) {
+    const int gx = (tiles * 128 * 32 + 255) / 256;
+    int gy = (1024 + gx - 1) / gx;            // ~1024 workgroups in total
+    if (gy > a.nz) gy = a.nz;
+    if (gy < 1) gy = 1;
+    SOD_LAUNCH(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, a);
+  }
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -887,6 +929,25 @@ extern "C" int sod_conv2d_dgrad_ml(int nlev, const void* const* dy, const void* 
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 
+// caller-owned scratch for the two-stage weight-gradient reduction, registered per device (used in stream order by the launches
+// that follow; one compute stream per process, as everywhere in this library)
+static float* g_wgrad_ws[16] = {nullptr};
+static long long g_wgrad_ws_bytes[16] = {0};
+
+extern "C" int sod_conv_set_workspace(void* ws, long long bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || bytes < 0) return SOD_EARG;
+  g_wgrad_ws[dev] = (float*)ws;
+  g_wgrad_ws_bytes[dev] = ws ? bytes : 0;
+  return SOD_OK;
+}
+
+static int launch_wgrad_ws(WgradArgs& a, int splits, hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return launch_wgrad(a, splits, st);
+  return launch_wgrad(a, splits, st, g_wgrad_ws[dev], g_wgrad_ws_bytes[dev]);
+}
+
 extern "C" int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const float* qscale,
                                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                                 long long dy_img_stride, long long x_img_stride, int splits, void* stream) {
@@ -897,7 +958,7 @@ extern "C" int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const 
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   int rc = fill_wlevel(a, 0, dy, x, H, W, dy_img_stride, x_img_stride);
   if (rc) return rc;
-  return launch_wgrad(a, splits, (hipStream_t)stream);
+  return launch_wgrad_ws(a, splits, (hipStream_t)stream);
 }
 
 extern "C" int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, float* dw, const float* qscale,
@@ -912,5 +973,5 @@ extern "C" int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* 
     int rc = fill_wlevel(a, l, dy[l], x[l], H[l], W[l], dy_img_stride, 0);
     if (rc) return rc;
   }
-  return launch_wgrad(a, splits, (hipStream_t)stream);
+  return launch_wgrad_ws(a, splits, (hipStream_t)stream);
 }

@@ -4,6 +4,7 @@ Tensor conventions: activations are NHWC ``torch.bfloat16`` CUDA tensors, conv w
 bf16 ("KRSC"), losses/targets are fp32/int32.  Every function launches on ``torch.cuda.current_stream()``.
 """
 import ctypes
+import os
 
 import torch
 
@@ -101,9 +102,23 @@ def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=Non
     return out
 
 
+_wgrad_ws = {}
+
+
+def _ensure_wgrad_ws(device):
+    """Registers (once per device) the scratch the opt-in two-stage weight-gradient reduction uses (SOD_WGRAD_TWO_STAGE=1)."""
+    if os.environ.get("SOD_WGRAD_TWO_STAGE") != "1":
+        return
+    if device.index not in _wgrad_ws:
+        ws = torch.empty(40 << 20, dtype=torch.uint8, device=device)
+        call("sod_conv_set_workspace", ptr(ws), ws.numel())
+        _wgrad_ws[device.index] = ws
+
+
 def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img_stride=0, K=None, x_shape=None, splits=0, qscale=None):
     """Accumulates into dw (K,R,S,C) fp32."""
     _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(dw, torch.float32, "dw")
+    _ensure_wgrad_ws(dw.device)
     N, H, W, C = x_shape if x_shape is not None else x.shape
     if K is None:
         K = dy.shape[-1]
@@ -159,6 +174,7 @@ def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=N
 def conv2d_wgrad_ml(dys, xs, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, K=None, splits=0, qscale=None):
     """Accumulates the weight gradient over all levels in one launch."""
     _chk(dw, torch.float32, "dw")
+    _ensure_wgrad_ws(dw.device)
     N, C = xs[0].shape[0], xs[0].shape[3]
     if K is None:
         K = dys[0].shape[-1]
