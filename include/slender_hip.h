@@ -114,8 +114,9 @@ int sod_upsample2x_bwd(const void* g, void* dprev, int N, int Hc, int Wc, int C,
  * transposed bf16 [C][RS][K] copy for dgrad */
 int sod_weight_prep(const float* w, const float* scale, void* w_krsc, void* w_crsk, int K, int RS, int C, int Cpad, void* stream);
 /* sod_weight_prep for all trainable convolutions of a model in one launch: table_dev = n entries
- * {int64 elem0, src_off, krsc_off, crsk_off, scale_off (-1: none); int32 K, RS, C, Cpad} sorted by elem0 (prefix sums of K*RS*C),
- * offsets in elements into params (fp32), the two bf16 compute arenas and scales (fp32). */
+ * {int64 tile0, src_off, krsc_off, crsk_off, scale_off (-1: none); int32 K, RS, C, Cpad} sorted by tile0 = prefix sums of the
+ * per-weight tile counts ceil(K/64)*RS*ceil(C/64) (total_elems = their sum); offsets in elements into params (fp32), the two bf16
+ * compute arenas and scales (fp32). */
 int sod_weight_prep_batched(const float* params, const float* scales, const void* table_dev, int n, long long total_elems,
                             void* krsc_arena, void* crsk_arena, void* stream);
 int sod_scale_rows(float* g, const float* scale, int K, long long row, void* stream);

@@ -385,33 +385,67 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
 // The same for EVERY trainable convolution of a model in one launch (61 launches of ~7 us each per FCOS step otherwise):
 // entries sorted by their first global element index; a thread finds its entry by binary search.
 struct PrepEntry {
-  long long elem0;      // first global element of this entry (prefix sum of K*RS*C)
+  long long elem0;      // first global TILE of this entry (prefix sum of tiles: ceil(K/64) * RS * ceil(C/64))
   long long src_off;    // fp32 offset into the parameter arena
   long long krsc_off;   // bf16 offset into the KRSC compute arena
   long long crsk_off;   // bf16 offset into the CRSK compute arena
   long long scale_off;  // fp32 offset into the scale array, or -1
   int K, RS, C, Cpad;
 };
+// One workgroup = one 64(k) x 64(c) tile of one tap of one weight: coalesced fp32 reads, coalesced KRSC bf16 writes, transpose through
+// LDS, coalesced CRSK writes (the element-wise version wrote 2-byte values with a stride of K elements: 0.42 ms per step for 32 M
+// parameters; this one moves the same 256 MB at HBM speed).
 __global__ __launch_bounds__(256) void weight_prep_batched_kernel(const float* __restrict__ params, const float* __restrict__ scales,
-                                                                  const PrepEntry* __restrict__ tab, int n, long long total,
+                                                                  const PrepEntry* __restrict__ tab, int n, long long total_tiles,
                                                                   __bf16* __restrict__ krsc, __bf16* __restrict__ crsk) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+  __shared__ __bf16 tile[64][66];
+  for (long long tb = blockIdx.x; tb < total_tiles; tb += gridDim.x) {
     int lo = 0, hi = n - 1;
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
-      if (tab[mid].elem0 <= i) lo = mid; else hi = mid - 1;
+      if (tab[mid].elem0 <= tb) lo = mid; else hi = mid - 1;
     }
     const PrepEntry e = tab[lo];
-    const long long j = i - e.elem0;
-    const int c = (int)(j % e.C);
-    const long long r = j / e.C;
-    const int t = (int)(r % e.RS);
-    const int k = (int)(r / e.RS);
-    float v = params[e.src_off + j];
-    if (e.scale_off >= 0) v *= scales[e.scale_off + k];
-    const __bf16 b = (__bf16)v;
-    krsc[e.krsc_off + ((long long)k * e.RS + t) * e.Cpad + c] = b;
-    crsk[e.crsk_off + ((long long)c * e.RS + t) * e.K + k] = b;
+    const int ct_n = (e.C + 63) >> 6;
+    long long j = tb - e.elem0;
+    const int ct = (int)(j % ct_n); j /= ct_n;
+    const int t = (int)(j % e.RS);
+    const int kt = (int)(j / e.RS);
+    const int k0 = kt * 64, c0 = ct * 64;
+    // load + KRSC store: thread -> (row = tid / 16 + 16 * pass, 4 consecutive c)
+    const int lc = (threadIdx.x & 15) * 4, lr = threadIdx.x >> 4;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = lr + pass * 16, k = k0 + r;
+      if (k < e.K) {
+        const float sc = e.scale_off >= 0 ? scales[e.scale_off + k] : 1.f;
+        const long long rowoff = ((long long)k * e.RS + t) * e.C + c0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = lc + q;
+          __bf16 b = (__bf16)0.f;
+          if (c0 + c < e.C) {
+            b = (__bf16)(params[e.src_off + rowoff + c] * sc);
+            krsc[e.krsc_off + ((long long)k * e.RS + t) * e.Cpad + c0 + c] = b;
+          }
+          tile[r][c] = b;
+        }
+      }
+    }
+    __syncthreads();
+    // CRSK store: thread -> (c row = tid / 16 + 16 * pass, 4 consecutive k)
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int cr = lr + pass * 16, c = c0 + cr;
+      if (c < e.C) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = k0 + lc + q;
+          if (k < e.K) crsk[e.crsk_off + ((long long)c * e.RS + t) * e.K + k] = tile[lc + q][cr];
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -655,7 +689,7 @@ extern "C" int sod_weight_prep(const float* w, const float* scale, void* w_krsc,
 extern "C" int sod_weight_prep_batched(const float* params, const float* scales, const void* table_dev, int n, long long total_elems,
                                        void* krsc_arena, void* crsk_arena, void* stream) {
   if (!params || !table_dev || n <= 0 || total_elems <= 0 || !krsc_arena || !crsk_arena) return SOD_EARG;
-  SOD_LAUNCH(weight_prep_batched_kernel, dim3(blocks_for(total_elems, 8192)), dim3(256), 0, (hipStream_t)stream, params, scales,
+  SOD_LAUNCH(weight_prep_batched_kernel, dim3((unsigned)(total_elems < 16384 ? total_elems : 16384)), dim3(256), 0, (hipStream_t)stream, params, scales,
              (const PrepEntry*)table_dev, n, total_elems, (__bf16*)krsc_arena, (__bf16*)crsk_arena);
   SOD_CHECK_LAUNCH();
   return SOD_OK;

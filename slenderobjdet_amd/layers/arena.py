@@ -87,7 +87,7 @@ class ParamArena:
             K, RS, C = m.batched_prep_shape()
             n = K * RS * C
             tab[i] = (e0, self.index[id(m.weight)][0], ko, ko, so if m.frozen_bn_scale() else -1, K, RS, C, C)
-            e0 += n
+            e0 += ((K + 63) // 64) * RS * ((C + 63) // 64)          # 64x64 tiles of this weight
             ko += (n + 63) // 64 * 64
             so += K if m.frozen_bn_scale() else 0
         self._prep_total = e0

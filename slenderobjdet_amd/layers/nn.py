@@ -81,18 +81,26 @@ class HipConv2d(nn.Module):
         K, R, S, C = self.weight.shape
         self._b_krsc, self._b_crsk, self._b_scale = krsc.view(K, R, S, C), crsk.view(C, R, S, K), scale_view
         self._prep_ver = None
+        if self.frozen_bn:          # fold now, so that the first step needs ONE batched launch, not one per FrozenBN conv
+            self._fold_bn()
+
+    def _bn_state(self):
+        return (self.bn_weight._version, self.bn_bias._version, self.bn_running_mean._version, self.bn_running_var._version,
+                self.bn_weight.data_ptr(), self.bias._version if self.bias is not None else 0)
+
+    @torch.no_grad()
+    def _fold_bn(self):
+        scale = self.bn_weight * torch.rsqrt(self.bn_running_var + 1e-5)
+        shift = self.bn_bias - self.bn_running_mean * scale
+        self._b_scale.copy_(scale)
+        self.bn_scale = self._b_scale
+        self.bias_eff = (shift + (self.bias.detach() * scale if self.bias is not None else 0)).contiguous()
+        self._bn_key = self._bn_state()
 
     def _prepare_batched(self, arena, key):
         if self.frozen_bn:
-            bn_key = (self.bn_weight._version, self.bn_bias._version, self.bn_running_mean._version, self.bn_running_var._version,
-                      self.bn_weight.data_ptr(), self.bias._version if self.bias is not None else 0)
-            if bn_key != getattr(self, "_bn_key", None):
-                scale = self.bn_weight * torch.rsqrt(self.bn_running_var + 1e-5)
-                shift = self.bn_bias - self.bn_running_mean * scale
-                self._b_scale.copy_(scale)
-                self.bn_scale = self._b_scale
-                self.bias_eff = (shift + (self.bias.detach() * scale if self.bias is not None else 0)).contiguous()
-                self._bn_key = bn_key
+            if self._bn_state() != getattr(self, "_bn_key", None):     # buffers changed (checkpoint load): re-fold and re-prepare
+                self._fold_bn()
                 arena._prep_gen = -1
         else:
             self.bn_scale = None
