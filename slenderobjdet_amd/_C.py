@@ -150,10 +150,10 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
+def stream_ptr(stream=None):
     import torch
 
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p((stream if stream is not None else torch.cuda.current_stream()).cuda_stream)
 
 
 def reduce_workspace_floats():

@@ -161,8 +161,12 @@ class ParamArena:
         if self.device.type == "cuda":
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
+            from . import functional as HF
+            side = HF.wgrad_side_stream(self.device)
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
+                if side is not None:        # weight gradients of this bucket were enqueued on the wgrad side stream
+                    self._comm_stream.wait_stream(side)
                 h = dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)
         else:
             h = dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True)

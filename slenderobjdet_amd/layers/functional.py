@@ -16,22 +16,66 @@ IOU_TYPES = {"iou": 0, "linear_iou": 1, "giou": 2}
 # Optional per-launch timing of the convolution kernels (bench.py roofline): a list that receives
 # (kind, algorithmic_flops, start_event, end_event); events are recorded on the stream the kernel is launched on.
 PROFILE = None
+PROFILE_KINDS = None      # optional set of kinds to time (None = all); bench.py times only the forward conv launches by default
 
 
-def _prof_begin():
-    if PROFILE is None:
+def _prof_begin(stream=None, kind=None):
+    if PROFILE is None or (PROFILE_KINDS is not None and kind not in PROFILE_KINDS):
         return None
     e = torch.cuda.Event(enable_timing=True)
-    e.record()
+    e.record(stream)
     return e
 
 
-def _prof_end(kind, flops, e0, desc=None):
+def _prof_end(kind, flops, e0, desc=None, stream=None):
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
-    e1.record()
+    e1.record(stream)
     PROFILE.append((kind, flops, e0, e1, desc))
+
+
+# Weight gradients have no consumer until the optimizer (or the bucket all-reduce), while the data gradient of the same layer is on
+# the critical path of backward.  Inside an autograd backward pass the wgrad launches therefore go to a per-device SIDE stream:
+# the hardware interleaves the two queues, so the tail of one kernel's grid is filled by the other's workgroups.  The main stream
+# joins the side stream in an end-of-backward callback (and the all-reduce stream waits for it per bucket, arena._launch_bucket).
+# SOD_WGRAD_STREAM=0 keeps everything on one stream.
+WGRAD_SIDE_STREAM = os.environ.get("SOD_WGRAD_STREAM", "1") != "0"
+_side_streams = {}
+_side_join_queued = False
+
+
+def wgrad_side_stream(device):
+    """The side stream of ``device`` if wgrad work may be pending on it in this backward pass, else None."""
+    return _side_streams.get(device.index) if _side_join_queued else None
+
+
+def _wgrad_join():
+    global _side_join_queued
+    _side_join_queued = False
+    for idx, side in _side_streams.items():
+        torch.cuda.current_stream(idx).wait_stream(side)
+
+
+def _wgrad_stream(device, tensors):
+    """Returns the stream to launch a wgrad on (None = current stream)."""
+    global _side_join_queued
+    if not WGRAD_SIDE_STREAM or device.type != "cuda":
+        return None
+    if not _side_join_queued:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_wgrad_join)
+        except RuntimeError:     # not inside a backward pass (op-level calls): nobody would join, stay on the current stream
+            return None
+        _side_join_queued = True
+    side = _side_streams.get(device.index)
+    if side is None:
+        side = _side_streams[device.index] = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)     # the caching allocator must not recycle dy / x under the side-stream kernel
+    return side
 CONV_RELU = 1
 CONV_RES_UP2 = 2
 
@@ -79,7 +123,7 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
     if out is None:
         out = torch.empty((N, Ho, Wo, K), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     flags = (CONV_RELU if relu else 0) | (CONV_RES_UP2 if res_up2 else 0)
-    e0 = _prof_begin()
+    e0 = _prof_begin(None, "conv_fwd")
     call("sod_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
          x_img_stride, y_img_stride, 0, flags, 1 if out_f32 else 0, stream_ptr())
     _prof_end("conv_fwd", 2.0 * N * Ho * Wo * K * R * S * C, e0, (N, H, W, C, K, R, stride))
@@ -94,7 +138,7 @@ def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=Non
     H, W = x_hw
     if out is None:
         out = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=dy.device)
-    e0 = _prof_begin()
+    e0 = _prof_begin(None, "conv_dgrad")
     call("sod_conv2d_dgrad", ptr(dy), ptr(wt), ptr(accum), ptr(relu_mask), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
          dy_img_stride, 0, stream_ptr())
     Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
@@ -122,11 +166,12 @@ def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img
     N, H, W, C = x_shape if x_shape is not None else x.shape
     if K is None:
         K = dy.shape[-1]
-    e0 = _prof_begin()
+    side = _wgrad_stream(dw.device, (dy, x))
+    e0 = _prof_begin(side, "conv_wgrad")
     call("sod_conv2d_wgrad", ptr(dy), ptr(x), ptr(dw), ptr(qscale), N, H, W, C, K, R, S, stride, pad, dil, dy_img_stride, x_img_stride,
-         splits, stream_ptr())
+         splits, stream_ptr(side))
     Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
-    _prof_end("conv_wgrad", 2.0 * N * Ho * Wo * K * R * S * C, e0, (N, H, W, C, K, R, stride))
+    _prof_end("conv_wgrad", 2.0 * N * Ho * Wo * K * R * S * C, e0, (N, H, W, C, K, R, stride), side)
     return dw
 
 
@@ -147,7 +192,7 @@ def conv2d_fwd_ml(xs, w, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=
     if outs is None:
         outs = [torch.empty((N,) + conv_out_size(h, wd, R, S, stride, pad, dil) + (K,), dtype=torch.float32 if out_f32 else torch.bfloat16,
                             device=xs[0].device) for h, wd in zip(hs, ws)]
-    e0 = _prof_begin()
+    e0 = _prof_begin(None, "conv_fwd")
     call("sod_conv2d_fwd_ml", len(xs), _ptr_arr(xs), ptr(w), ptr(bias), _ptr_arr(outs), N, _int_arr(hs), _int_arr(ws), C, K, R, S,
          stride, pad, dil, y_img_stride, CONV_RELU if relu else 0, 1 if out_f32 else 0, stream_ptr())
     fl = sum(2.0 * N * ho * wo * K * R * S * C for ho, wo in (conv_out_size(h, wd, R, S, stride, pad, dil) for h, wd in zip(hs, ws)))
@@ -163,7 +208,7 @@ def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=N
         N = dys[0].shape[0]
     dev = dys[0].device
     outs = [torch.empty((N, h, w, C), dtype=torch.bfloat16, device=dev) for h, w in x_hws]
-    e0 = _prof_begin()
+    e0 = _prof_begin(None, "conv_dgrad")
     call("sod_conv2d_dgrad_ml", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]), _int_arr([w for _, w in x_hws]),
          C, K, R, S, stride, pad, dil, dy_img_stride, stream_ptr())
     fl = sum(2.0 * N * ho * wo * K * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in x_hws))
@@ -179,11 +224,12 @@ def conv2d_wgrad_ml(dys, xs, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, 
     if K is None:
         K = dys[0].shape[-1]
     hs, ws = [x.shape[1] for x in xs], [x.shape[2] for x in xs]
-    e0 = _prof_begin()
+    side = _wgrad_stream(dw.device, list(dys) + list(xs))
+    e0 = _prof_begin(side, "conv_wgrad")
     call("sod_conv2d_wgrad_ml", len(xs), _ptr_arr(dys), _ptr_arr(xs), ptr(dw), ptr(qscale), N, _int_arr(hs), _int_arr(ws), C, K, R, S,
-         stride, pad, dil, dy_img_stride, splits, stream_ptr())
+         stride, pad, dil, dy_img_stride, splits, stream_ptr(side))
     fl = sum(2.0 * N * ho * wo * K * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in zip(hs, ws)))
-    _prof_end("conv_wgrad", fl, e0, ("ml", N, tuple(hs), C, K, R, stride))
+    _prof_end("conv_wgrad", fl, e0, ("ml", N, tuple(hs), C, K, R, stride), side)
     return dw
 
 
