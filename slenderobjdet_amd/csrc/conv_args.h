@@ -1,0 +1,48 @@
+// Argument blocks shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_igemm256.hip).
+#pragma once
+#include "common.h"
+#include "../../include/slender_hip.h"
+
+namespace sodconv {
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+enum {
+  F_BIAS = 1, F_RELU = 2, F_RES = 4, F_RES_UP2 = 8, F_MASK = 16,
+};
+constexpr int MAXLEV = SOD_CONV_MAX_LEVELS;
+
+// One "level" = one (N,H,W,C) tensor; a launch may cover several levels that share the weights (the FPN levels of
+// the FCOS towers), so that the small levels do not pay a launch + tail each.
+struct LevelGeo {
+  const void* src;     // fwd: x (N,Hs,Ws,Cred); dgrad: dy (N,Hs,Ws,Cred)
+  void* dst;           // (N,Hp,Wp,Nout) rows at dst_img_stride
+  const void* res;     // bf16, indexed like dst (or half-resolution with F_RES_UP2)
+  const void* mask;    // bf16, indexed like dst: dst = mask>0 ? v : 0 (ReLU backward)
+  uint32_t src_bytes;
+  int Hs, Ws, Hp, Wp, P;
+  int tile0;           // first pixel tile of this level
+  int pstart;          // first pixel this launch covers (a launch may handle only the tail of a level, see dispatch_conv)
+  int src_img_stride, dst_img_stride, res_img_stride;  // elements
+  FastDiv div_hw, div_w;
+};
+
+struct ConvArgs {
+  LevelGeo lev[MAXLEV];
+  int nlev;
+  const void* w;       // [Nout][R*S*Cred]
+  const float* bias;   // [Nout] or null
+  uint32_t w_bytes;
+  int N, Cred, Nout;
+  int R, S, stride, pad, dil;
+  int Kred, T;         // R*S*Cred, #K-steps
+  int flags;
+  int nq_tiles, np_tiles;
+  FastDiv div_cpt /* Cred/64 (fast) or Cred/8 (generic) */, div_s, div_stride;
+};
+
+// conv_igemm256.hip: 256x256x64 tile, 8 waves, 8-phase main loop.  Returns SOD_EARG when the shape is outside its fast path.
+bool conv256_supported(const ConvArgs& a, int mode);
+// max_pt_tiles > 0 launches only the first max_pt_tiles pixel tiles (the caller covers the rest with the 128x128 kernel).
+int launch_conv256(const ConvArgs& a, int mode, bool out_f32, int max_pt_tiles, hipStream_t st);
+
+}  // namespace sodconv

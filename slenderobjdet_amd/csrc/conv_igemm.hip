@@ -13,45 +13,12 @@
 //
 // wgrad contracts over pixels, which is the slow axis of both operands: tiles are staged [pixel][128 ch]
 // and fragments are fetched with ds_read_b64_tr_b16 (hardware transpose), swizzled at 32-B granularity.
-#include "common.h"
-#include "../../include/slender_hip.h"
+#include "conv_args.h"
 #include <stdlib.h>
 
+using namespace sodconv;
+
 namespace {
-
-enum { MODE_FWD = 0, MODE_DGRAD = 1 };
-enum {
-  F_BIAS = 1, F_RELU = 2, F_RES = 4, F_RES_UP2 = 8, F_MASK = 16,
-};
-constexpr int MAXLEV = SOD_CONV_MAX_LEVELS;
-
-// One "level" = one (N,H,W,C) tensor; a launch may cover several levels that share the weights (the FPN levels of
-// the FCOS towers), so that the small levels do not pay a launch + tail each.
-struct LevelGeo {
-  const void* src;     // fwd: x (N,Hs,Ws,Cred); dgrad: dy (N,Hs,Ws,Cred)
-  void* dst;           // (N,Hp,Wp,Nout) rows at dst_img_stride
-  const void* res;     // bf16, indexed like dst (or half-resolution with F_RES_UP2)
-  const void* mask;    // bf16, indexed like dst: dst = mask>0 ? v : 0 (ReLU backward)
-  uint32_t src_bytes;
-  int Hs, Ws, Hp, Wp, P;
-  int tile0;           // first pixel tile of this level
-  int src_img_stride, dst_img_stride, res_img_stride;  // elements
-  FastDiv div_hw, div_w;
-};
-
-struct ConvArgs {
-  LevelGeo lev[MAXLEV];
-  int nlev;
-  const void* w;       // [Nout][R*S*Cred]
-  const float* bias;   // [Nout] or null
-  uint32_t w_bytes;
-  int N, Cred, Nout;
-  int R, S, stride, pad, dil;
-  int Kred, T;         // R*S*Cred, #K-steps
-  int flags;
-  int nq_tiles, np_tiles;
-  FastDiv div_cpt /* Cred/64 (fast) or Cred/8 (generic) */, div_s, div_stride;
-};
 
 template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK, int NSTAGE>
 __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvArgs a) {
@@ -82,7 +49,7 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
     if (i < a.nlev && pt >= a.lev[i].tile0) lv = i;
   const LevelGeo& g = a.lev[lv];
   pt -= g.tile0;
-  const int q0 = qt * BQ, p0 = pt * BP;
+  const int q0 = qt * BQ, p0 = g.pstart + pt * BP;
   const int gP = g.P, gHs = g.Hs, gWs = g.Ws;
 
   auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
@@ -677,9 +644,10 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   int tiles = 0;
   for (int l = 0; l < a.nlev; ++l) {
     a.lev[l].tile0 = tiles;
-    tiles += (a.lev[l].P + BP - 1) / BP;
+    tiles += (a.lev[l].P - a.lev[l].pstart + BP - 1) / BP;
   }
   a.np_tiles = tiles;
+  if (tiles == 0) return SOD_OK;
   const size_t lds_full = NSTAGE * (size_t)(BQ + BP) * BK * 2;
   // a single K-step needs no second staging buffer: a smaller footprint lets 4 blocks share a CU, which is what hides the
   // load->MFMA->store latency of the memory-bound 1x1 convolutions (C = 64)
@@ -698,9 +666,48 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   return SOD_OK;
 }
 
+int g_conv256_mode = -1;   // -1: read SOD_CONV256 (default 1); 0 off; 1 heuristic; 2 every supported shape
+
 template <int MODE, bool OUT_F32>
 int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   const bool generic = (a.Cred & 63) != 0;
+  // 256x256 8-phase kernel (conv_igemm256.hip) for the large compute-bound shapes.  SOD_CONV256=0 disables it, =2 forces it for
+  // every shape it supports (parity tests).
+  static int cus = 0;
+  int& c256 = g_conv256_mode;
+  if (c256 < 0 || cus == 0) {
+    if (c256 < 0) { const char* e = getenv("SOD_CONV256"); c256 = e ? atoi(e) : 1; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  bool any_start = false;
+  for (int l = 0; l < a.nlev; ++l) any_start |= a.lev[l].pstart != 0;
+  if (c256 && !any_start && conv256_supported(a, MODE)) {
+    const int nq = (a.Nout + 255) / 256;
+    long long pt256 = 0;
+    for (int l = 0; l < a.nlev; ++l) pt256 += (a.lev[l].P + 255) / 256;
+    const long long b256 = pt256 * nq;
+    if (c256 == 2) return launch_conv256(a, MODE, OUT_F32, 0, st);
+    if (a.Nout >= 256 && (a.Nout & 255) == 0 && a.Kred >= 1024 && b256 >= 2 * cus) {
+      // Measured (16 x FPN levels, 256 -> 256 3x3): 1020-1040 TFLOP/s against 840-930 for the 128x128 kernel; shapes with fewer than
+      // two rounds of tiles (res4 conv2: 263 tiles) are faster on the 128x128 kernel.
+      // One workgroup per CU: a partial last round of 256x256 tiles wastes up to a whole round.  Whole rounds go to the 256 kernel,
+      // a remainder below half a round is computed by the 128x128 kernel (two workgroups per CU, 4x smaller tiles) instead
+      // (P3 output conv, 4.1 rounds: 1035 -> 1075 TFLOP/s).
+      const long long full = b256 / cus * cus, rem = b256 - full;
+      if (rem == 0 || rem * 2 >= (long long)cus || (full / nq) * nq != full) return launch_conv256(a, MODE, OUT_F32, 0, st);
+      int main_pt = (int)(full / nq);
+      int rc = launch_conv256(a, MODE, OUT_F32, main_pt, st);
+      if (rc) return rc;
+      ConvArgs tail = a;
+      for (int l = 0; l < tail.nlev; ++l) {
+        const int tl = (tail.lev[l].P + 255) / 256;
+        if (main_pt >= tl) { tail.lev[l].pstart = tail.lev[l].P; main_pt -= tl; }
+        else { tail.lev[l].pstart = main_pt * 256; main_pt = 0; }
+      }
+      return dispatch_conv<MODE, OUT_F32>(tail, st);
+    }
+  }
   if (a.Nout <= 16) {
     return generic ? launch_conv<MODE, true, 1, 4, 1, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 1, 4, 1, 4, OUT_F32>(a, st);
   } else if (a.Nout <= 64) {
@@ -712,7 +719,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   static int force_bk = -1;
   if (force_bk < 0) { const char* e = getenv("SOD_CONV_BK"); force_bk = e ? atoi(e) : 0; }
   long long blocks = 0;
-  for (int l = 0; l < a.nlev; ++l) blocks += (a.lev[l].P + 127) / 128;
+  for (int l = 0; l < a.nlev; ++l) blocks += (a.lev[l].P - a.lev[l].pstart + 127) / 128;
   blocks *= (a.Nout + 127) / 128;
   bool use32 = !generic && (a.Cred & 31) == 0 && (a.Kred <= 256 || blocks <= 1024);
   if (force_bk == 32) use32 = !generic && (a.Cred & 31) == 0;
@@ -758,7 +765,7 @@ int fill_level(ConvArgs& a, int l, const void* src, void* dst, int Hs, int Ws, i
   if (sb >= 0x80000000ull || db >= 0x200000000ull) return SOD_ESIZE;
   if ((long long)a.N * Hp * Wp >= (1ll << 31)) return SOD_ESIZE;
   LevelGeo& g = a.lev[l];
-  g.src = src; g.dst = dst; g.res = nullptr; g.mask = nullptr;
+  g.src = src; g.dst = dst; g.res = nullptr; g.mask = nullptr; g.pstart = 0;
   g.src_bytes = (uint32_t)sb;
   g.Hs = Hs; g.Ws = Ws; g.Hp = Hp; g.Wp = Wp; g.P = a.N * Hp * Wp;
   g.src_img_stride = (int)src_img_stride; g.dst_img_stride = (int)dst_img_stride; g.res_img_stride = 0;
@@ -933,6 +940,12 @@ extern "C" int sod_conv2d_dgrad_ml(int nlev, const void* const* dy, const void* 
 // that follow; one compute stream per process, as everywhere in this library)
 static float* g_wgrad_ws[16] = {nullptr};
 static long long g_wgrad_ws_bytes[16] = {0};
+
+extern "C" int sod_conv_set_tile256(int mode) {
+  if (mode < -1 || mode > 2) return SOD_EARG;
+  g_conv256_mode = mode;
+  return SOD_OK;
+}
 
 extern "C" int sod_conv_set_workspace(void* ws, long long bytes) {
   int dev = 0;

@@ -233,3 +233,86 @@ def test_conv_multilevel_matches_per_level(cuda):
     dw2 = torch.zeros_like(dw)
     HF.conv2d_wgrad_ml(gviews, xd, dw2, 3, 3, 1, 1, 1, dy_img_stride=L * K, K=K)
     _close(dw2, dw_ref, 2e-4, "ml concat wgrad")
+
+
+# ---- 256x256x64 8-phase kernel (conv_igemm256.hip), forced through sod_conv_set_tile256
+T256_CASES = [
+    # (N, H, W, C, K, R, stride, pad, dil)
+    (2, 13, 21, 64, 256, 3, 1, 1, 1),     # one q-tile, ragged pixel tiles
+    (1, 9, 11, 256, 64, 1, 1, 0, 1),      # Nout < 256 (weight rows out of range), T = 4
+    (2, 14, 18, 64, 64, 3, 2, 1, 1),      # stride 2 forward
+    (3, 25, 42, 256, 512, 3, 1, 1, 1),    # two q-tiles
+    (1, 10, 10, 64, 64, 3, 1, 2, 2),      # dilation
+    (1, 6, 7, 64, 72, 1, 1, 0, 1),        # a single K-tile (prologue/tail only)
+    (1, 12, 10, 128, 256, 5, 1, 2, 1),    # 25 taps
+]
+
+
+@pytest.fixture
+def tile256(cuda):
+    from slenderobjdet_amd import _C
+
+    _C.call("sod_conv_set_tile256", 2)
+    yield
+    _C.call("sod_conv_set_tile256", -1)
+
+
+@pytest.mark.parametrize("case", T256_CASES)
+@pytest.mark.parametrize("out_f32", [True, False])
+def test_conv256_fwd(cuda, tile256, case, out_f32):
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K, R, st, pad, dil = case
+    x = _rand((N, H, W, C), 11)
+    w = _rand((K, R, R, C), 12, 0.05)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(13))
+    res = _rand(tuple(onn.conv2d(x, w, b, st, pad, dil).shape), 14)
+    ref = onn.conv2d(x, w, b, st, pad, dil, res=res, relu=True)
+    y = HF.conv2d_fwd(x.to(cuda).bfloat16(), w.to(cuda).bfloat16(), b.to(cuda), res=res.to(cuda).bfloat16(), stride=st, pad=pad, dil=dil,
+                      relu=True, out_f32=out_f32)
+    torch.cuda.synchronize()
+    _close(y, ref, 2e-4 if out_f32 else 2 ** -7, f"conv256 fwd {case}")
+
+
+@pytest.mark.parametrize("case", [c for c in T256_CASES if c[6] == 1])
+def test_conv256_dgrad(cuda, tile256, case):
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K, R, st, pad, dil = case
+    x = _rand((N, H, W, C), 21).requires_grad_(True)
+    w = _rand((K, R, R, C), 22, 0.05)
+    y = onn.conv2d(x, w, None, st, pad, dil)
+    dy = _rand(tuple(y.shape), 23)
+    y.backward(dy)
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    dx = HF.conv2d_dgrad(dy.to(cuda).bfloat16(), wt.to(cuda).bfloat16(), (H, W), st, pad, dil)
+    torch.cuda.synchronize()
+    _close(dx, x.grad, 2 ** -7, f"conv256 dgrad {case}")
+
+
+def test_conv256_split_rounds_and_levels(cuda):
+    """Default policy: whole rounds of 256x256 tiles on the 8-phase kernel, the short remainder (starting in the middle of a level)
+    on the 128x128 kernel; result must equal the 128x128-only result bit for bit (same bf16 rounding of the same fp32 sums is not
+    guaranteed across tilings, so compare against the oracle instead) and cover every pixel exactly once."""
+    from slenderobjdet_amd import _C
+    from slenderobjdet_amd.layers import functional as HF
+
+    props = torch.cuda.get_device_properties(0)
+    cus = props.multi_processor_count
+    N, C, K = 2, 128, 256
+    # level 0 alone has a little more than two rounds of tiles; level 1 adds a few more
+    h0 = 64
+    w0 = (2 * cus * 256 + 40 * 256) // (N * h0) + 1
+    hw = [(h0, w0), (9, 11)]
+    xs = [_rand((N, h, w, C), 31 + i) for i, (h, w) in enumerate(hw)]
+    wgt = _rand((K, 3, 3, C), 33, 0.05)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(34))
+    refs = [onn.conv2d(x, wgt, b, 1, 1, 1, relu=True) for x in xs]
+    _C.call("sod_conv_set_tile256", 1)
+    try:
+        ys = HF.conv2d_fwd_ml([x.to(cuda).bfloat16() for x in xs], wgt.to(cuda).bfloat16(), b.to(cuda), 1, 1, 1, relu=True)
+        torch.cuda.synchronize()
+    finally:
+        _C.call("sod_conv_set_tile256", -1)
+    for y, ref, (h, w) in zip(ys, refs, hw):
+        _close(y, ref, 2 ** -7, f"split conv256 level {h}x{w}")
