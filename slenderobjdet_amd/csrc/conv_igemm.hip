@@ -682,7 +682,9 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   }
   bool any_start = false;
   for (int l = 0; l < a.nlev; ++l) any_start |= a.lev[l].pstart != 0;
-  if (c256 && !any_start && conv256_supported(a, MODE)) {
+  static int c256_dgrad = -1;
+  if (c256_dgrad < 0) { const char* e = getenv("SOD_CONV256_DGRAD"); c256_dgrad = e ? atoi(e) : 1; }
+  if (c256 && !any_start && conv256_supported(a, MODE) && (MODE == MODE_FWD || c256_dgrad || c256 == 2)) {
     const int nq = (a.Nout + 255) / 256;
     long long pt256 = 0;
     for (int l = 0; l < a.nlev; ++l) pt256 += (a.lev[l].P + 255) / 256;

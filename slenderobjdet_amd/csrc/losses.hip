@@ -92,6 +92,58 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict_
   }
 }
 
+// Vectorised forms for the training path (class-index labels, K % 4 == 0, rows 16-B aligned, M*ld_out < 2^31): one thread = 4
+// consecutive classes of one location; the row index comes from a 32-bit multiply-high division and the label is read once per 4
+// elements.  (The scalar kernels above spend most of their time in a 64-bit division per element: 199 us for the 16 x 22400 x 80
+// FCOS logits, 0.57 TB/s.)
+__global__ __launch_bounds__(256) void focal_fwd_vec4_kernel(const float* __restrict__ x, const int* __restrict__ labels, uint32_t total4,
+                                                             FastDiv div_k4, int ld, float alpha, float gamma, float* __restrict__ elem,
+                                                             int K, float* __restrict__ part) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
+    const uint32_t m = fd_div(i, div_k4);
+    const int k = (int)(i - m * div_k4.d) * 4;
+    const int lab = labels[m];
+    const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(x + (size_t)m * ld + k);
+    f32x4_t lv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lv[e] = (lab < 0) ? 0.f : focal_term(xv[e], (lab == k + e) ? 1.f : 0.f, alpha, gamma);
+    if (elem) *reinterpret_cast<f32x4_t*>(elem + (size_t)m * K + k) = lv;
+    acc += (lv[0] + lv[1]) + (lv[2] + lv[3]);
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void focal_bwd_vec4_kernel(const float* __restrict__ x, const int* __restrict__ labels, uint32_t total4,
+                                                             FastDiv div_k4, int K, int ld, float alpha, float gamma,
+                                                             const float* __restrict__ scale_num, const float* __restrict__ scale_den,
+                                                             float den_mul, float den_min, void* __restrict__ dx, int ld_out) {
+  float sc = scale_num ? scale_num[0] : 1.f;
+  if (scale_den) sc /= fmaxf(scale_den[0] * den_mul, den_min);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
+    const uint32_t m = fd_div(i, div_k4);
+    const int k = (int)(i - m * div_k4.d) * 4;       // column of the (padded) output row
+    f32x4_t gv = {0.f, 0.f, 0.f, 0.f};
+    if (k < K) {                                      // K % 4 == 0: a group is entirely inside or entirely padding
+      const int lab = labels[m];
+      if (lab >= 0) {
+        const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(x + (size_t)m * ld + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[e] = focal_grad(xv[e], (lab == k + e) ? 1.f : 0.f, alpha, gamma) * sc;
+      }
+    }
+    if (OUT_BF16) {
+      bf16x4_t o = {(__bf16)gv[0], (__bf16)gv[1], (__bf16)gv[2], (__bf16)gv[3]};
+      *reinterpret_cast<bf16x4_t*>((__bf16*)dx + (size_t)m * ld_out + k) = o;
+    } else {
+      *reinterpret_cast<f32x4_t*>((float*)dx + (size_t)m * ld_out + k) = gv;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // IoU family loss on LTRB distances (reference: layers/iou_loss.py:4-37)
 // ---------------------------------------------------------------------------------------------
@@ -407,8 +459,14 @@ extern "C" int sod_sigmoid_focal_loss_fwd(const float* logits, const int* labels
                                           float* sum_out, float* ws, void* stream) {
   if (!logits || (!labels && !dense_targets) || !sum_out || !ws || M < 0 || K <= 0 || ld < K) return SOD_EARG;
   hipStream_t st = (hipStream_t)stream;
-  const int g = grid_for(M * K);
-  SOD_LAUNCH(focal_fwd_kernel, dim3(g), dim3(256), 0, st, logits, labels, dense_targets, M, K, ld, alpha, gamma, elem_out, ws);
+  const bool vec = labels && !dense_targets && (K & 3) == 0 && (ld & 3) == 0 && M * (long long)K < (1ll << 31) &&
+                   ((uintptr_t)logits & 15) == 0 && ((uintptr_t)elem_out & 15) == 0;
+  const int g = vec ? grid_for(M * K / 4) : grid_for(M * K);
+  if (vec)
+    SOD_LAUNCH(focal_fwd_vec4_kernel, dim3(g), dim3(256), 0, st, logits, labels, (uint32_t)(M * K / 4), make_fastdiv((uint32_t)(K / 4)), ld, alpha,
+               gamma, elem_out, K, ws);
+  else
+    SOD_LAUNCH(focal_fwd_kernel, dim3(g), dim3(256), 0, st, logits, labels, dense_targets, M, K, ld, alpha, gamma, elem_out, ws);
   SOD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, g, 1, sum_out, 0);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
@@ -420,6 +478,19 @@ extern "C" int sod_sigmoid_focal_loss_bwd(const float* logits, const int* labels
                                           void* dlogits, int ld_out, int out_bf16, void* stream) {
   if (!logits || (!labels && !dense_targets) || !dlogits || M < 0 || K <= 0 || ld < K || ld_out < K) return SOD_EARG;
   hipStream_t st = (hipStream_t)stream;
+  const bool vec = labels && !dense_targets && (K & 3) == 0 && (ld & 3) == 0 && (ld_out & 3) == 0 && M * (long long)ld_out < (1ll << 31) &&
+                   ((uintptr_t)logits & 15) == 0 && ((uintptr_t)dlogits & 15) == 0;
+  if (vec) {
+    const uint32_t total4 = (uint32_t)(M * ld_out / 4);
+    const int gv = grid_for(M * ld_out / 4) * 2;
+    const FastDiv d = make_fastdiv((uint32_t)(ld_out / 4));
+    if (out_bf16)
+      SOD_LAUNCH(focal_bwd_vec4_kernel<true>, dim3(gv), dim3(256), 0, st, logits, labels, total4, d, K, ld, alpha, gamma, scale_num, scale_den, den_mul, den_min, dlogits, ld_out);
+    else
+      SOD_LAUNCH(focal_bwd_vec4_kernel<false>, dim3(gv), dim3(256), 0, st, logits, labels, total4, d, K, ld, alpha, gamma, scale_num, scale_den, den_mul, den_min, dlogits, ld_out);
+    SOD_CHECK_LAUNCH();
+    return SOD_OK;
+  }
   const int g = grid_for(M * ld_out) * 2;
   if (out_bf16)
     SOD_LAUNCH(focal_bwd_kernel<true>, dim3(g), dim3(256), 0, st, logits, labels, dense_targets, M, K, ld, alpha, gamma, scale_num, scale_den, den_mul, den_min, dlogits, ld_out);

@@ -463,6 +463,23 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
                                                   float lr_host, float momentum, int nesterov, int first_step, float grad_scale) {
   const float base_lr = lr_dev ? lr_dev[0] : lr_host;
   const SgdSeg sg = segs[blockIdx.y];
+  const float step = base_lr * sg.lr_mult;
+  if (((sg.begin | sg.end) & 3) == 0) {      // arena segments are 64-float aligned: 16-B accesses
+    for (long long i = sg.begin + ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < sg.end; i += (long long)gridDim.x * 1024) {
+      const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(g + i);
+      f32x4_t pv = *reinterpret_cast<const f32x4_t*>(p + i);
+      f32x4_t d = gv * grad_scale + sg.wd * pv;
+      if (momentum != 0.f) {
+        f32x4_t b = d;
+        if (!first_step) b = momentum * *reinterpret_cast<const f32x4_t*>(m + i) + d;
+        *reinterpret_cast<f32x4_t*>(m + i) = b;
+        d = nesterov ? d + momentum * b : b;
+      }
+      pv -= step * d;
+      *reinterpret_cast<f32x4_t*>(p + i) = pv;
+    }
+    return;
+  }
   for (long long i = sg.begin + (long long)blockIdx.x * 256 + threadIdx.x; i < sg.end; i += (long long)gridDim.x * 256) {
     float d = g[i] * grad_scale + sg.wd * p[i];
     if (momentum != 0.f) {
@@ -470,7 +487,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
       m[i] = b;
       d = nesterov ? d + momentum * b : b;
     }
-    p[i] -= base_lr * sg.lr_mult * d;
+    p[i] -= step * d;
   }
 }
 
