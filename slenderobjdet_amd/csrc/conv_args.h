@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "../../include/slender_hip.h"
+#include <stdlib.h>
 
 namespace sodconv {
 
@@ -38,7 +39,19 @@ struct ConvArgs {
   int flags;
   int nq_tiles, np_tiles;
   FastDiv div_cpt /* Cred/64 (fast) or Cred/8 (generic) */, div_s, div_stride;
+  FastDiv div_rs;      // R*S
+  int tap_inner;       // linear path: K-step order (channel chunk outer, tap inner) - the taps of one chunk re-read the same cache lines
 };
+
+// K-step order of the linear staging path: (channel chunk outer, tap inner) makes the R*S taps of one 64-channel chunk re-read the
+// same cache lines back to back.  Measured on the FCOS head (16 x 5 levels, 256 -> 256 3x3): L2 fetch traffic of the 256x256 kernel
+// 707 -> 205 MB per launch (algorithmic: 184 MB) at equal time; the 128x128 kernel's traffic does not change, so it keeps the
+// (tap outer) order.  SOD_CONV_TAP_INNER=0|1 forces one order for both kernels.
+inline int conv_tap_inner(int dflt) {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("SOD_CONV_TAP_INNER"); v = e ? atoi(e) : -1; }
+  return v < 0 ? dflt : v;
+}
 
 // conv_igemm256.hip: 256x256x64 tile, 8 waves, 8-phase main loop.  Returns SOD_EARG when the shape is outside its fast path.
 bool conv256_supported(const ConvArgs& a, int mode);

@@ -130,12 +130,20 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
 
   auto stage = [&](int t, char* buf) {
     if (linear) {
-      const uint32_t tap = fd_div((uint32_t)t, a.div_cpt);
-      const int c0 = (t - (int)(tap * a.div_cpt.d)) * BK;
+      uint32_t tap;
+      int c0;
+      if (a.tap_inner) {
+        const uint32_t cc = fd_div((uint32_t)t, a.div_rs);
+        tap = (uint32_t)t - cc * a.div_rs.d;
+        c0 = (int)cc * BK;
+      } else {
+        tap = fd_div((uint32_t)t, a.div_cpt);
+        c0 = (t - (int)(tap * a.div_cpt.d)) * BK;
+      }
       const int r = (int)fd_div(tap, a.div_s);
       const int s2 = (int)tap - r * a.S;
       const uint32_t tapoff = (uint32_t)((tap_sign * (r * a.dil * gWs + s2 * a.dil) * a.Cred + c0) * 2);   // scalar
-      const uint32_t woff = (uint32_t)(t * BK * 2);
+      const uint32_t woff = (uint32_t)(((int)tap * a.Cred + c0) * 2);
 #pragma unroll
       for (int j = 0; j < (BQ + RPP - 1) / RPP; ++j) {
         if (WFULL || j * RPP + wave * RPI < BQ) {
@@ -417,8 +425,12 @@ struct WgradArgs {
   FastDiv div_s;
 };
 
+// KP = pixels per K-step: 64 (two resident workgroups per CU) or 32 (half the LDS: three to four per CU, which is what the
+// latency of the transposing ds_read_b64_tr_b16 fragment reads wants - they need more waves per SIMD than ds_read_b128).
+template <int KP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
-  constexpr int TILE = 64 * 256, STAGE = 2 * TILE;   // [64 pixels][128 ch] bf16, two operands
+  constexpr int TILE = KP * 256, STAGE = 2 * TILE;   // [KP pixels][128 ch] bf16, two operands
+  constexpr int NI = KP / 16;                        // staged rows per thread and operand
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   const int q0 = qt * 128, c0 = ct * 128;
   const int vbeg = z * a.v_per_split;
   int vend = vbeg + a.v_per_split; if (vend > a.V) vend = a.V;
-  const int nsteps = (vend - vbeg) >> 6;
+  const int nsteps = (vend - vbeg) / KP;
 
   // staging: one wave instruction = 4 pixel rows x 256 B; lane -> (row_in, 16-B slot)
   const int srow = lane >> 4, spos = lane & 15;
@@ -455,19 +467,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   // Row state for the INCREMENTAL path (stride 1, "same" geometry, Wo >= 64): consecutive K-steps advance every row by 64
   // pixels, so (ho, wo) and both byte offsets are updated with a handful of adds/compares instead of two divisions and ~35
   // VALU per row and step (the wgrad loop was issue-bound: 113 M VALU against 67 M in the forward kernel for equal MFMAs).
-  uint32_t r_oy[4], r_ox[4];
-  int r_ho[4], r_wo[4], r_p[4];
+  uint32_t r_oy[NI], r_ox[NI];
+  int r_ho[NI], r_wo[NI], r_p[NI];
   bool fast = false;
   int dh = 0, dw = 0;
   uint32_t ycorr = 0, xcorr = 0;
   auto init_rows = [&](int pbase) {
-    fast = (a.stride == 1) && (g.Wo >= 64) && (g.Ho == g.Hx) && (g.Wo == g.Wx);
+    fast = (a.stride == 1) && (g.Wo >= KP) && (g.Ho == g.Hx) && (g.Wo == g.Wx);
     dh = r * a.dil - a.pad; dw = s * a.dil - a.pad;
     ycorr = (uint32_t)(g.dy_img_stride - g.Ho * g.Wo * a.K) * 2u;
     xcorr = (uint32_t)(g.x_img_stride - g.Hx * g.Wx * a.C) * 2u;
     const uint32_t tapshift = (uint32_t)((dh * g.Wx + dw) * a.C * 2);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int row = (i * 4 + wave) * 4 + srow;
       const int p = pbase + row;
       const uint32_t n = fd_div((uint32_t)p, g.div_hw);
@@ -482,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   init_rows(vbeg - g.v0);
 
   auto stage = [&](int it, char* buf) {
-    const int v = vbeg + it * 64;
+    const int v = vbeg + it * KP;
     if (v >= next_v0) {
       ++cur_lv;
       g = a.lev[cur_lv];
@@ -492,18 +504,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
       init_rows(v - g.v0);
     }
     if (fast) {
-      const uint32_t ystep = (uint32_t)(128 * a.K), xstep = (uint32_t)(128 * a.C);
+      const uint32_t ystep = (uint32_t)(2 * KP * a.K), xstep = (uint32_t)(2 * KP * a.C);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NI; ++i) {
         const bool pv = r_p[i] < g.P;
         const bool tv = ((unsigned)(r_ho[i] + dh) < (unsigned)g.Hx) & ((unsigned)(r_wo[i] + dw) < (unsigned)g.Wx);
         const uint32_t vy = (pv && qmask) ? r_oy[i] : SOD_OOB;
         const uint32_t vx = (pv && tv && cmask) ? r_ox[i] : SOD_OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(buf + (i * 4 + wave) * 1024), 16, vy, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + TILE + (i * 4 + wave) * 1024), 16, vx, 0, 0, 0);
-        // advance this row by 64 pixels (Wo >= 64: at most one column wrap and one image wrap)
-        r_p[i] += 64; r_oy[i] += ystep; r_ox[i] += xstep;
-        int wo = r_wo[i] + 64, ho = r_ho[i];
+        // advance this row by KP pixels (Wo >= KP: at most one column wrap and one image wrap)
+        r_p[i] += KP; r_oy[i] += ystep; r_ox[i] += xstep;
+        int wo = r_wo[i] + KP, ho = r_ho[i];
         if (wo >= g.Wo) { wo -= g.Wo; ho += 1; }
         if (ho >= g.Ho) { ho -= g.Ho; r_oy[i] += ycorr; r_ox[i] += xcorr; }
         r_wo[i] = wo; r_ho[i] = ho;
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     }
     const int pbase = v - g.v0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int row = (i * 4 + wave) * 4 + srow;
       const int p = pbase + row;
       const uint32_t pm = (uint32_t) - (int)(p < g.P);
@@ -557,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     __syncthreads();
     if (it + 1 < nsteps) stage(it + 1, smem + ((it + 1) & 1) * STAGE);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KP / 32; ++ks) {
       bf16x8_t af[4], bf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -640,6 +652,8 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
   a.T = (a.Kred + BK - 1) / BK;
   a.div_cpt = make_fastdiv((uint32_t)(GENERIC ? a.Cred / 8 : a.Cred / BK));
+  a.div_rs = make_fastdiv((uint32_t)(a.R * a.S));
+  a.tap_inner = conv_tap_inner(0);
   a.nq_tiles = (a.Nout + BQ - 1) / BQ;
   int tiles = 0;
   for (int l = 0; l < a.nlev; ++l) {
@@ -682,8 +696,10 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   }
   bool any_start = false;
   for (int l = 0; l < a.nlev; ++l) any_start |= a.lev[l].pstart != 0;
+  // Data gradients stay on the 128x128 kernel by default: beside the side-stream wgrad blocks a 128-KB workgroup rarely finds a free
+  // CU (FCOS R50 step 490 vs 487.5 img/s); SOD_CONV256_DGRAD=1 enables the 256 kernel for them.
   static int c256_dgrad = -1;
-  if (c256_dgrad < 0) { const char* e = getenv("SOD_CONV256_DGRAD"); c256_dgrad = e ? atoi(e) : 1; }
+  if (c256_dgrad < 0) { const char* e = getenv("SOD_CONV256_DGRAD"); c256_dgrad = e ? atoi(e) : 0; }
   if (c256 && !any_start && conv256_supported(a, MODE) && (MODE == MODE_FWD || c256_dgrad || c256 == 2)) {
     const int nq = (a.Nout + 255) / 256;
     long long pt256 = 0;
@@ -787,15 +803,27 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
     Ptot += a.lev[l].P;
   }
   a.V = V;
+  // Pixels per K-step: 64 (64 KB LDS, 156 VGPRs) or 32 (32 KB, 118 VGPRs).  Stand-alone (batch 16), 32 with four workgroups per CU wins
+  // when the output has many tiles (3x3 with >= 256 channels: P3 head shape 686-706 -> 734 TFLOP/s, res5 conv2 504-550 -> 640) and
+  // loses when few tiles share many splits (1x1 convs: twice the atomics).  In the training step the wgrad kernels run on the side
+  // stream BESIDE the data-gradient kernels, and there the small footprint matters more than the stand-alone rate: a 32-KB block
+  // fits next to two 64-KB conv workgroups on a CU.  Measured on the FCOS R50 step: 64/2-per-CU everywhere 461-463 img/s; 32 with
+  // 3-4 per CU for the many-tile shapes 481; 32 with 2 per CU for the rest as well 487.  SOD_WGRAD_KP=32|64 forces one size.
+  static const int kp_env = getenv("SOD_WGRAD_KP") ? atoi(getenv("SOD_WGRAD_KP")) : 0;
+  static const int kp_small = getenv("SOD_WGRAD_KP_SMALL") ? atoi(getenv("SOD_WGRAD_KP_SMALL")) : 32;
+  static const int pc_small = getenv("SOD_WGRAD_PC_SMALL") ? atoi(getenv("SOD_WGRAD_PC_SMALL")) : 2;
+  const int kp = kp_env ? kp_env : (tiles >= 36 ? 32 : kp_small);
   if (splits <= 0) {
-    // ONE resident wave of blocks (2 per CU): measured on the head shape, 504 blocks run at 718 TFLOP/s where 1548 blocks
+    // ONE resident wave of blocks (2 or 4 per CU): measured on the head shape, 504 blocks run at 718 TFLOP/s where 1548 blocks
     // (3.02 waves -> a nearly empty 4th round, 3x the atomic traffic) run at 585.  At least 256 pixels per block.
-    static int slots = 0;
-    if (!slots) {
-      int dev = 0, cus = 256;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      slots = 2 * (cus > 0 ? cus : 256);
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
+    static const int per_cu_env = getenv("SOD_WGRAD_PER_CU") ? atoi(getenv("SOD_WGRAD_PER_CU")) : 0;
+    static const int pc_big = getenv("SOD_WGRAD_PC_BIG") ? atoi(getenv("SOD_WGRAD_PC_BIG")) : 3;
+    const int slots = (per_cu_env > 0 ? per_cu_env : (tiles >= 36 ? (kp == 32 ? pc_big : 2) : pc_small)) * cus;
     splits = slots / tiles;
     const int maxs = (int)((Ptot + 255) / 256);
     if (splits > maxs) splits = maxs;
@@ -811,7 +839,7 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
   const size_t lds = 2 * 2 * 64 * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
@@ -821,7 +849,8 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
   static const int two_stage = getenv("SOD_WGRAD_TWO_STAGE") ? atoi(getenv("SOD_WGRAD_TWO_STAGE")) : 0;
   const long long need = (long long)a.nz * tiles * 128 * 128 * (long long)sizeof(float);
   a.partial = (two_stage && ws && a.nz >= 8 && tiles <= 32 && need <= ws_bytes) ? ws : nullptr;
-  SOD_LAUNCH(conv_wgrad_kernel, dim3(a.nz * tiles), dim3(256), lds, st, a);
+  if (kp == 32) SOD_LAUNCH(conv_wgrad_kernel<32>, dim3(a.nz * tiles), dim3(256), lds / 2, st, a);
+  else SOD_LAUNCH(conv_wgrad_kernel<64>, dim3(a.nz * tiles), dim3(256), lds, st, a);
   if (a.partial) {
     const int gx = (tiles * 128 * 32 + 255) / 256;
     int gy = (1024 + gx - 1) / gx;            // ~1024 workgroups in total
