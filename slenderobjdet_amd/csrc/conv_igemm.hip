@@ -740,6 +740,9 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   for (int l = 0; l < a.nlev; ++l) blocks += (a.lev[l].P - a.lev[l].pstart + 127) / 128;
   blocks *= (a.Nout + 127) / 128;
   bool use32 = !generic && (a.Cred & 31) == 0 && (a.Kred <= 256 || blocks <= 1024);
+  static int dgrad_bk = -1;
+  if (dgrad_bk < 0) { const char* e = getenv("SOD_DGRAD_BK"); dgrad_bk = e ? atoi(e) : 0; }
+  if (MODE == MODE_DGRAD && dgrad_bk == 32) use32 = !generic && (a.Cred & 31) == 0;
   if (force_bk == 32) use32 = !generic && (a.Cred & 31) == 0;
   if (force_bk == 64) use32 = false;
   if (use32) return launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32, 32>(a, st);
