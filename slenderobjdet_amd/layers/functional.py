@@ -317,7 +317,8 @@ def add_bf16(a, b):
 
 def bias_grad(dy, dbias, N, HW, C, img_stride=0):
     _chk(dy, torch.bfloat16, "dy"); _chk(dbias, torch.float32, "dbias")
-    call("sod_bias_grad", ptr(dy), ptr(dbias), N, HW, C, img_stride, stream_ptr())
+    side = _wgrad_stream(dbias.device, (dy,))      # like the weight gradient: only the optimizer / all-reduce consumes it
+    call("sod_bias_grad", ptr(dy), ptr(dbias), N, HW, C, img_stride, stream_ptr(side))
     return dbias
 
 
