@@ -228,7 +228,7 @@ def main():
     prof_all, prof_steps = [], 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        sample = not args.no_roofline and (args.dump_prof or i % 4 == 0)
+        sample = (not args.no_roofline) and bool(args.dump_prof or i % 4 == 0)
         HF.PROFILE = prof_all if sample else None
         prof_steps += int(sample)
         last = train_step(model, optimizer, next(loader))

@@ -9,7 +9,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslender_hip.so")
+# SOD_HIP_LIB: another build of the same library (A/B experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("SOD_HIP_LIB") or os.path.join(_HERE, "libslender_hip.so")
 
 _lib = None
 

@@ -27,6 +27,7 @@
 // slot nobody reads), so the counted wait is uniform from prologue to tail.
 #include "conv_args.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace sodconv {
 namespace {
@@ -233,32 +234,34 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
   char* wl = smem + wave * (16 * EROWB);
   const int erow = lane / LPR, eq = (lane % LPR) * EPL;
   const int q = q0 + wr * QW + eq;
+  constexpr int NP = 16 / ERPP;                    // passes per 16-pixel fragment column
+  using RV = typename std::conditional<EPL == 8, bf16x8_t, bf16x4_t>::type;
+  const bool qok = q < Nout;
+  float bv[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) bv[e] = 0.f;
+  if ((a.flags & F_BIAS) && qok) {
+#pragma unroll
+    for (int e = 0; e < EPL; e += 4) {
+      const f32x4_t b = *reinterpret_cast<const f32x4_t*>(a.bias + q + e);
+      bv[e] = b[0]; bv[e + 1] = b[1]; bv[e + 2] = b[2]; bv[e + 3] = b[3];
+    }
+  }
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) {
+    // residual / mask operands of the 16 pixel rows are requested before the accumulators go through LDS (one exposed latency)
+    RV resv[NP], maskv[NP];
+    size_t drow[NP];
+    bool ok[NP];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      *reinterpret_cast<f32x4_t*>(wl + fr * EROWB + (i * 16 + fg * 4) * 4) = acc[i][jj];
-#pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += ERPP) {
-      const int row = r0 + erow;
-      const uint32_t p = (uint32_t)(p0 + wc * 64 + jj * 16 + row);
-      if (p < (uint32_t)gP && q < Nout) {
-        float v[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; e += 4) {
-          const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(wl + row * EROWB + (eq + e) * 4);
-          v[e] = t4[0]; v[e + 1] = t4[1]; v[e + 2] = t4[2]; v[e + 3] = t4[3];
-        }
+    for (int k = 0; k < NP; ++k) {
+      const uint32_t p = (uint32_t)(p0 + wc * 64 + jj * 16 + k * ERPP + erow);
+      ok[k] = (p < (uint32_t)gP) && qok;
+      drow[k] = 0;
+      if (ok[k]) {
         const uint32_t n = fd_div(p, g.div_hw);
         const uint32_t rem = p - n * g.div_hw.d;
-        const size_t dst_row = (size_t)n * g.dst_img_stride + (size_t)rem * Nout;
-        if (a.flags & F_BIAS) {
-#pragma unroll
-          for (int e = 0; e < EPL; e += 4) {
-            const f32x4_t b = *reinterpret_cast<const f32x4_t*>(a.bias + q + e);
-            v[e] += b[0]; v[e + 1] += b[1]; v[e + 2] += b[2]; v[e + 3] += b[3];
-          }
-        }
+        drow[k] = (size_t)n * g.dst_img_stride + (size_t)rem * Nout;
         if (a.flags & (F_RES | F_RES_UP2)) {
           size_t res_row;
           if (a.flags & F_RES_UP2) {
@@ -268,40 +271,47 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
           } else {
             res_row = (size_t)n * g.res_img_stride + (size_t)rem * Nout;
           }
-          const __bf16* rp = (const __bf16*)g.res + res_row + q;
-          if constexpr (EPL == 8) {
-            const bf16x8_t rv = *reinterpret_cast<const bf16x8_t*>(rp);
+          resv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.res + res_row + q);
+        }
+        if (a.flags & F_MASK) maskv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.mask + drow[k] + q);
+      }
+    }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-          } else {
-            const bf16x4_t rv = *reinterpret_cast<const bf16x4_t*>(rp);
+    for (int i = 0; i < 8; ++i)
+      *reinterpret_cast<f32x4_t*>(wl + fr * EROWB + (i * 16 + fg * 4) * 4) = acc[i][jj];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-          }
+    for (int k = 0; k < NP; ++k) {
+      const int row = k * ERPP + erow;
+      if (ok[k]) {
+        float v[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) {
+          const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(wl + row * EROWB + (eq + e) * 4);
+          v[e] = t4[0]; v[e + 1] = t4[1]; v[e + 2] = t4[2]; v[e + 3] = t4[3];
+        }
+        if (a.flags & F_BIAS) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) v[e] += bv[e];
+        }
+        if (a.flags & (F_RES | F_RES_UP2)) {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) v[e] += (float)resv[k][e];
         }
         if (a.flags & F_RELU) {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (a.flags & F_MASK) {
-          const __bf16* mp = (const __bf16*)g.mask + dst_row + q;
-          if constexpr (EPL == 8) {
-            const bf16x8_t mv = *reinterpret_cast<const bf16x8_t*>(mp);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
-          } else {
-            const bf16x4_t mv = *reinterpret_cast<const bf16x4_t*>(mp);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
-          }
+          for (int e = 0; e < EPL; ++e) v[e] = ((float)maskv[k][e] > 0.f) ? v[e] : 0.f;
         }
         if constexpr (OUT_F32) {
-          *reinterpret_cast<f32x4_t*>((float*)g.dst + dst_row + q) = f32x4_t{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4_t*>((float*)g.dst + drow[k] + q) = f32x4_t{v[0], v[1], v[2], v[3]};
         } else {
           bf16x8_t o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
-          *reinterpret_cast<bf16x8_t*>((__bf16*)g.dst + dst_row + q) = o;
+          *reinterpret_cast<bf16x8_t*>((__bf16*)g.dst + drow[k] + q) = o;
         }
       }
     }

@@ -70,7 +70,10 @@ def _wgrad_stream(device, tensors):
         _side_join_queued = True
     side = _side_streams.get(device.index)
     if side is None:
-        side = _side_streams[device.index] = torch.cuda.Stream(device=device)
+        # lowest HIP stream priority (range on MI355X: 1 .. -1): the data-gradient chain is the critical path.  Measured 491.5-492.3
+        # (low) / 491.8 (normal) / 483-484 (high) img/s
+        prio = int(os.environ.get("SOD_WGRAD_PRIO", "1"))
+        side = _side_streams[device.index] = torch.cuda.Stream(device=device, priority=prio)
     side.wait_stream(torch.cuda.current_stream(device))
     for t in tensors:
         if t is not None:
