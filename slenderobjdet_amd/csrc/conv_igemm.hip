@@ -581,10 +581,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   for (int it = 0; it < nsteps; ++it) {
     char* cur = smem + (it & 1) * STAGE;
     __syncthreads();
-    if (it + 1 < nsteps) stage(it + 1, smem + ((it + 1) & 1) * STAGE);
+    // ALL fragment reads of this K-step are issued BEFORE the next tile's LDS-DMA: hipcc puts an s_waitcnt vmcnt(0) in front of a
+    // ds_read_b64_tr_b16 that follows an outstanding LDS-DMA (it cannot tell the two LDS ranges apart), which drained the prefetch
+    // before the MFMAs and left only inter-workgroup overlap.  In this order the wait falls right after the barrier's own vmcnt(0).
+    constexpr int KS = KP / 32;
+    bf16x8_t af[KS][4], bf[KS][4];
 #pragma unroll
-    for (int ks = 0; ks < KP / 32; ++ks) {
-      bf16x8_t af[4], bf[4];
+    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4_t*)SOD_LDS(cur + aoff[i] + ks * 8192 + 1024));
         s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        af[i] = __builtin_bit_cast(bf16x8_t, v);
+        af[ks][i] = __builtin_bit_cast(bf16x8_t, v);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -601,33 +604,55 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4_t*)SOD_LDS(cur + boff[j] + ks * 8192 + 1024));
         s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bf[j] = __builtin_bit_cast(bf16x8_t, v);
+        bf[ks][j] = __builtin_bit_cast(bf16x8_t, v);
       }
+    }
+    if (it + 1 < nsteps) stage(it + 1, smem + ((it + 1) & 1) * STAGE);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
   }
 
   // D[row=q][col=c]
   const int fr = lane & 15, fg = lane >> 4;
   float* ptile = a.partial ? a.partial + ((size_t)z * (a.QT * a.CT * RS) + ((size_t)qt * a.CT + ct) * RS + tap) * (128 * 128) : nullptr;
+  // The 16 per-row scale factors are fetched in one batch up front: a load inside the loop makes the compiler wait vmcnt(0) before
+  // its use, and vmcnt also counts the atomics already in flight - every row then waited for all earlier (contended) atomics.
+  float qsv[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = q0 + (wq * 4 + i) * 16 + fg * 4 + e;
+      qsv[i][e] = (a.qscale && q < a.K) ? a.qscale[q] : 1.f;
+    }
+  if (!a.partial) {      // scale first (one wait for the batch of loads), so that nothing below depends on a load
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] *= qsv[i][e];
+  }
+  const int mode = a.partial ? 0 : (a.dbg_plain_store ? 1 : 2);      // wave-uniform, hoisted out of the element loops
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int q = q0 + (wq * 4 + i) * 16 + fg * 4 + e;
       if (q >= a.K) continue;
-      const float qs = a.qscale ? a.qscale[q] : 1.f;
+      float* drow = a.dw + ((size_t)q * RS + tap) * a.C;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = c0 + (wc * 4 + j) * 16 + fr;
         if (c < a.C) {
-          if (a.partial) ptile[((wq * 4 + i) * 16 + fg * 4 + e) * 128 + (wc * 4 + j) * 16 + fr] = acc[i][j][e];
-          else if (a.dbg_plain_store) a.dw[((size_t)q * RS + tap) * a.C + c] = acc[i][j][e] * qs;
-          else atomicAdd(a.dw + ((size_t)q * RS + tap) * a.C + c, acc[i][j][e] * qs);
+          if (mode == 2) atomicAdd(drow + c, acc[i][j][e]);
+          else if (mode == 0) ptile[((wq * 4 + i) * 16 + fg * 4 + e) * 128 + (wc * 4 + j) * 16 + fr] = acc[i][j][e];
+          else drow[c] = acc[i][j][e];
         }
       }
     }
