@@ -845,14 +845,14 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
     Ptot += a.lev[l].P;
   }
   a.V = V;
-  // Pixels per K-step: 64 (64 KB LDS, 156 VGPRs) or 32 (32 KB, 118 VGPRs).  Stand-alone (batch 16), 32 with four workgroups per CU wins
-  // when the output has many tiles (3x3 with >= 256 channels: P3 head shape 686-706 -> 734 TFLOP/s, res5 conv2 504-550 -> 640) and
-  // loses when few tiles share many splits (1x1 convs: twice the atomics).  In the training step the wgrad kernels run on the side
-  // stream BESIDE the data-gradient kernels, and there the small footprint matters more than the stand-alone rate: a 32-KB block
-  // fits next to two 64-KB conv workgroups on a CU.  Measured on the FCOS R50 step: 64/2-per-CU everywhere 461-463 img/s; 32 with
-  // 3-4 per CU for the many-tile shapes 481; 32 with 2 per CU for the rest as well 487.  SOD_WGRAD_KP=32|64 forces one size.
+  // Pixels per K-step: 64 (64 KB LDS, 175 VGPRs, two workgroups per CU) or 32 (32 KB, 132 VGPRs, three per CU).  In the training
+  // step the wgrad kernels run on the side stream BESIDE the data-gradient kernels, so the LDS footprint counts as well as the
+  // stand-alone rate.  Measured on the FCOS R50 step (same box, after the read-before-stage loop order): 32 / 3 per CU for the
+  // many-tile shapes (3x3 with >= 256 channels) and 64 / 2 per CU for the rest 510.6-510.9 img/s; 64 everywhere 509-511; 32
+  // everywhere 504-508.  (Before that loop fix the prefetch was drained by a compiler-inserted vmcnt(0) and 32 everywhere won by 5 %.)
+  // SOD_WGRAD_KP=32|64 forces one size.
   static const int kp_env = getenv("SOD_WGRAD_KP") ? atoi(getenv("SOD_WGRAD_KP")) : 0;
-  static const int kp_small = getenv("SOD_WGRAD_KP_SMALL") ? atoi(getenv("SOD_WGRAD_KP_SMALL")) : 32;
+  static const int kp_small = getenv("SOD_WGRAD_KP_SMALL") ? atoi(getenv("SOD_WGRAD_KP_SMALL")) : 64;
   static const int pc_small = getenv("SOD_WGRAD_PC_SMALL") ? atoi(getenv("SOD_WGRAD_PC_SMALL")) : 2;
   const int kp = kp_env ? kp_env : (tiles >= 36 ? 32 : kp_small);
   if (splits <= 0) {
