@@ -25,11 +25,11 @@ struct GnArgs {
 };
 
 __device__ __forceinline__ void gn_stats_body(const GnArgs& a, const int bx) {
-  extern __shared__ float lsum[];   // [G][2]
+  // Block reduction through plain LDS stores: ds_add_f32 runs at 0.33 lanes/clk/CU on gfx950 (tools/micro/lds_atomic.hip), 40x
+  // below ds_write/ds_read, and these kernels ended every block with 2-18 of them per thread.
+  extern __shared__ float lsum[];   // [256][2] per-thread partials
   const int n = blockIdx.y;
   const int c8n = a.C >> 3;                 // vectors per pixel
-  for (int i = threadIdx.x; i < a.G * 2; i += 256) lsum[i] = 0.f;
-  __syncthreads();
   const int rows_per_iter = 256 / c8n;      // host guarantees c8n divides 256
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
   const int p0 = bx * a.pix_per_block;
@@ -41,11 +41,16 @@ __device__ __forceinline__ void gn_stats_body(const GnArgs& a, const int bx) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s += f; ss += f * f; }
   }
-  const int g = (c8 * 8) / a.cpg;
-  atomicAdd(&lsum[g * 2], s);
-  atomicAdd(&lsum[g * 2 + 1], ss);
+  lsum[threadIdx.x * 2] = s;
+  lsum[threadIdx.x * 2 + 1] = ss;
   __syncthreads();
-  for (int i = threadIdx.x; i < a.G * 2; i += 256) atomicAdd(a.stats + (long long)n * a.G * 2 + i, lsum[i]);
+  if ((int)threadIdx.x < c8n) {             // thread i sums the rows of channel vector i: one global atomic pair per vector
+    float ts = 0.f, tss = 0.f;
+    for (int r = 0; r < rows_per_iter; ++r) { ts += lsum[(r * c8n + threadIdx.x) * 2]; tss += lsum[(r * c8n + threadIdx.x) * 2 + 1]; }
+    const int g = ((int)threadIdx.x * 8) / a.cpg;
+    atomicAdd(a.stats + ((long long)n * a.G + g) * 2, ts);
+    atomicAdd(a.stats + ((long long)n * a.G + g) * 2 + 1, tss);
+  }
 }
 
 // ---- multi-level wrappers: one launch covers all FPN levels of a shared-weight GroupNorm (levels differ in HW only) ----
@@ -114,13 +119,9 @@ __device__ __forceinline__ void gn_apply_body(const GnArgs& a, const int bx) {
 }
 
 __device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx) {
-  extern __shared__ float lsum[];   // [G][2] group sums, then [C][2] per-channel (dgamma, dbeta) partials
+  extern __shared__ float lsum[];   // [256][18] per-thread partials: dgamma[8], dbeta[8], s1, s2
   const int n = blockIdx.y;
   const int c8n = a.C >> 3;
-  float* lgrp = lsum;
-  float* lch = lsum + a.G * 2;
-  for (int i = threadIdx.x; i < a.G * 2 + a.C * 2; i += 256) lsum[i] = 0.f;
-  __syncthreads();
   const int rows_per_iter = 256 / c8n;
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
   const int g = (c8 * 8) / a.cpg;
@@ -144,29 +145,35 @@ __device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx
       s1 += d * gm[e]; s2 += d * gm[e] * xh;
     }
   }
-  atomicAdd(&lgrp[g * 2], s1);
-  atomicAdd(&lgrp[g * 2 + 1], s2);
+  // block-level reduction through plain LDS stores (see gn_stats_body), then one global atomic per channel per block
+  float* mine = lsum + threadIdx.x * 18;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {   // block-level reduction in LDS first: one global atomic per channel per block
-    atomicAdd(&lch[(c8 * 8 + e) * 2], dg[e]);
-    atomicAdd(&lch[(c8 * 8 + e) * 2 + 1], db[e]);
-  }
+  for (int e = 0; e < 8; ++e) { mine[e] = dg[e]; mine[8 + e] = db[e]; }
+  mine[16] = s1; mine[17] = s2;
   __syncthreads();
-  for (int i = threadIdx.x; i < a.G * 2; i += 256) atomicAdd(a.red + (long long)n * a.G * 2 + i, lgrp[i]);
-  for (int i = threadIdx.x; i < a.C; i += 256) {   // fp32 accumulation into the grad arena
-    atomicAdd(a.dgamma + i, lch[i * 2]);
-    atomicAdd(a.dbeta + i, lch[i * 2 + 1]);
+  for (int i = threadIdx.x; i < a.C; i += 256) {   // channel i = vector i/8, element i%8; rows r*c8n + vector
+    float tg = 0.f, tb = 0.f;
+    for (int r = 0; r < rows_per_iter; ++r) {
+      const float* src = lsum + (r * c8n + (i >> 3)) * 18 + (i & 7);
+      tg += src[0]; tb += src[8];
+    }
+    atomicAdd(a.dgamma + i, tg);                   // fp32 accumulation into the grad arena
+    atomicAdd(a.dbeta + i, tb);
+  }
+  if ((int)threadIdx.x < c8n) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int r = 0; r < rows_per_iter; ++r) { t1 += lsum[(r * c8n + threadIdx.x) * 18 + 16]; t2 += lsum[(r * c8n + threadIdx.x) * 18 + 17]; }
+    const int gg = ((int)threadIdx.x * 8) / a.cpg;
+    atomicAdd(a.red + ((long long)n * a.G + gg) * 2, t1);
+    atomicAdd(a.red + ((long long)n * a.G + gg) * 2 + 1, t2);
   }
 }
 
+
 __device__ __forceinline__ void gn_bwd_apply_body(const GnArgs& a, const int bx, const float inv_m) {
-  extern __shared__ float lsum[];   // [C] per-channel sums of dx when a.dxsum
+  extern __shared__ float lsum[];   // [256][8] per-thread sums of dx when a.dxsum
   const int n = blockIdx.y;
   const int c8n = a.C >> 3;
-  if (a.dxsum) {
-    for (int i = threadIdx.x; i < a.C; i += 256) lsum[i] = 0.f;
-    __syncthreads();
-  }
   const int rows_per_iter = 256 / c8n;
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
   const int g = (c8 * 8) / a.cpg;
@@ -194,9 +201,13 @@ __device__ __forceinline__ void gn_bwd_apply_body(const GnArgs& a, const int bx,
   }
   if (a.dxsum) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(&lsum[c8 * 8 + e], sx[e]);
+    for (int e = 0; e < 8; ++e) lsum[threadIdx.x * 8 + e] = sx[e];
     __syncthreads();
-    for (int i = threadIdx.x; i < a.C; i += 256) atomicAdd(a.dxsum + i, lsum[i]);
+    for (int i = threadIdx.x; i < a.C; i += 256) {
+      float t = 0.f;
+      for (int r = 0; r < rows_per_iter; ++r) t += lsum[(r * c8n + (i >> 3)) * 8 + (i & 7)];
+      atomicAdd(a.dxsum + i, t);
+    }
   }
 }
 
@@ -279,11 +290,9 @@ __global__ __launch_bounds__(256) void add_up2_kernel(const __bf16* __restrict__
 // bias gradient: db[c] += sum over rows of dy[row][c]; dy rows may be strided per image
 __global__ __launch_bounds__(256) void channel_sum_kernel(const __bf16* __restrict__ dy, float* __restrict__ db,
                                                           int HW, int C, long long img_stride, int pix_per_block) {
-  extern __shared__ float lsum[];   // [C]
+  extern __shared__ float lsum[];   // [256][8] per-thread partials
   const int n = blockIdx.y;
   const int c8n = C >> 3;
-  for (int i = threadIdx.x; i < C; i += 256) lsum[i] = 0.f;
-  __syncthreads();
   const int rows_per_iter = 256 / c8n;
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -297,10 +306,14 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const __bf16* __restri
       for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(&lsum[c8 * 8 + e], s[e]);
+    for (int e = 0; e < 8; ++e) lsum[threadIdx.x * 8 + e] = s[e];      // plain stores, not ds_add_f32 (see gn_stats_body)
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) atomicAdd(db + i, lsum[i]);
+  for (int i = threadIdx.x; i < C; i += 256) {
+    float t = 0.f;
+    for (int r = 0; r < rows_per_iter; ++r) t += lsum[(r * c8n + (i >> 3)) * 8 + (i & 7)];
+    atomicAdd(db + i, t);
+  }
 }
 
 // 3x3 stride-2 pad-1 max pool, NHWC bf16 (detectron2 BasicStem)
@@ -588,7 +601,7 @@ extern "C" int sod_groupnorm_fwd_ml(int nlev, const void* const* x, const float*
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(mean_rstd, 0, sizeof(float) * 2 * N * G * nlev, st);
   if (e != hipSuccess) return (int)e;
-  SOD_LAUNCH(gn_stats_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * G, st, m);
+  SOD_LAUNCH(gn_stats_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * 256, st, m);
   SOD_LAUNCH(gn_finalize_stats_kernel, dim3((N * G + 255) / 256, nlev), dim3(256), 0, st, m);
   SOD_LAUNCH(gn_apply_kernel, dim3(gx, N), dim3(256), 0, st, m);
   SOD_CHECK_LAUNCH();
@@ -611,8 +624,8 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * N * G * nlev, st);
   if (e != hipSuccess) return (int)e;
-  SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * (G + C), st, m);
-  SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * C : 0, st, m);
+  SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 18 * 256, st, m);
+  SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * 8 * 256 : 0, st, m);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -673,7 +686,7 @@ extern "C" int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C,
   if (c8n > 256) return SOD_EARG;
   int ppb;
   const int gx = gn_grid(HW, N, ppb);
-  SOD_LAUNCH(channel_sum_kernel, dim3(gx, N), dim3(256), sizeof(float) * C, (hipStream_t)stream, (const __bf16*)dy, dbias, HW, C, img_stride, ppb);
+  SOD_LAUNCH(channel_sum_kernel, dim3(gx, N), dim3(256), sizeof(float) * 8 * 256, (hipStream_t)stream, (const __bf16*)dy, dbias, HW, C, img_stride, ppb);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
