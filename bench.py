@@ -126,18 +126,22 @@ def pmc_traffic(kind):
     --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md). None if absent."""
     import glob
 
-    prefixes = {"conv_fwd": "void conv_igemm_kernel<0, false, 2, 2, 4, 4, false, 64", "conv_dgrad": "void conv_igemm_kernel<1, false, 2, 2, 4, 4, false, 64",
-                "conv_wgrad": "conv_wgrad_kernel"}
+    prefixes = {"conv_fwd": ("void conv_igemm_kernel<0, false, 2, 2, 4, 4, false, 64", "void conv_igemm_kernel<0, ", "void sodconv::conv_igemm256_kernel<0, "),
+                "conv_dgrad": ("void conv_igemm_kernel<1, false, 2, 2, 4, 4, false, 64", "void conv_igemm_kernel<1, ", "void sodconv::conv_igemm256_kernel<1, "),
+                "conv_wgrad": ("void conv_wgrad_kernel", "conv_wgrad_kernel")}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
     if not files or kind not in prefixes:
         return None
     try:
         kernels = json.load(open(files[-1]))["kernels"]
-        hits = [(v["launches"], k, v) for k, v in kernels.items() if k.startswith(prefixes[kind])]
+        hits = [(v["launches"], k, v) for k, v in kernels.items() if k.startswith(prefixes[kind][0])]
         if not hits:
             return None
         _, name, k = max(hits)
-        return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "kernel": name, "source": os.path.relpath(files[-1], ROOT)}
+        family = {kk: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "launches": v["launches"]}
+                  for kk, v in kernels.items() if any(kk.startswith(pf) for pf in prefixes[kind])}
+        return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "kernel": name, "source": os.path.relpath(files[-1], ROOT),
+                "all_variants": family}
     except Exception:
         return None
 

@@ -692,7 +692,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   a.T = (a.Kred + BK - 1) / BK;
   a.div_cpt = make_fastdiv((uint32_t)(GENERIC ? a.Cred / 8 : a.Cred / BK));
   a.div_rs = make_fastdiv((uint32_t)(a.R * a.S));
-  a.tap_inner = conv_tap_inner(0);
+  a.tap_inner = conv_tap_inner(BQ <= 16 ? 1 : 0);   // few output channels: the pixel operand is all the traffic (box_pred fwd 0.223 -> 0.111 ms)
   a.nq_tiles = (a.Nout + BQ - 1) / BQ;
   int tiles = 0;
   for (int l = 0; l < a.nlev; ++l) {
