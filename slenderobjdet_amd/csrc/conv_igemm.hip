@@ -771,14 +771,18 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     return generic ? launch_conv<MODE, true, 1, 4, 4, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 1, 4, 4, 4, OUT_F32>(a, st);
   }
   // BK = 32 halves the LDS footprint (4 resident blocks per CU instead of 2): measured better for the latency-/write-bound
-  // cases — short contractions (1x1 expansions, Kred <= 256) and grids of at most ~2 blocks per CU slot — and worse for the
-  // large compute-bound shapes (head 3x3: 820 vs 699 TFLOP/s).  SOD_CONV_BK=32|64 forces one variant (experiments).
+  // cases - short contractions - and worse for the large compute-bound shapes (head 3x3: 820 vs 699 TFLOP/s).
+  // SOD_CONV_BK=32|64 forces one variant (experiments).
   static int force_bk = -1;
   if (force_bk < 0) { const char* e = getenv("SOD_CONV_BK"); force_bk = e ? atoi(e) : 0; }
   long long blocks = 0;
   for (int l = 0; l < a.nlev; ++l) blocks += (a.lev[l].P - a.lev[l].pstart + 127) / 128;
   blocks *= (a.Nout + 127) / 128;
-  bool use32 = !generic && (a.Cred & 31) == 0 && (a.Kred <= 256 || blocks <= 1024);
+  // Re-measured per shape after the epilogue fix (serial run, best of the two variants 19.4 vs 19.9 ms of conv per step): grids that fit
+  // one round of two blocks per CU want BK = 64 (P5/P6 3x3: 44 vs 54 us); otherwise BK = 32 also wins for Kred <= 512 (the 512-channel
+  // 1x1 convs: 276 vs 300 us) and for the 128-channel 3x3 convs.
+  bool use32 = !generic && (a.Cred & 31) == 0 && blocks > 512 &&
+               (a.Kred <= 512 || blocks <= 1024 || (a.Cred <= 128 && a.Kred <= 1152));
   static int dgrad_bk = -1;
   if (dgrad_bk < 0) { const char* e = getenv("SOD_DGRAD_BK"); dgrad_bk = e ? atoi(e) : 0; }
   if (MODE == MODE_DGRAD && dgrad_bk == 32) use32 = !generic && (a.Cred & 31) == 0;
