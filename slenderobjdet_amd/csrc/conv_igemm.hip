@@ -768,6 +768,9 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   if (a.Nout <= 16) {
     return generic ? launch_conv<MODE, true, 1, 4, 1, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 1, 4, 1, 4, OUT_F32>(a, st);
   } else if (a.Nout <= 64) {
+    static int n64_bk = -1;
+    if (n64_bk < 0) { const char* e = getenv("SOD_CONV_N64_BK"); n64_bk = e ? atoi(e) : 32; }   // 4 blocks per CU for the res2-sized convs: +0.3 % on the step
+    if (!generic && n64_bk == 32 && (a.Cred & 31) == 0) return launch_conv<MODE, false, 1, 4, 4, 4, OUT_F32, 32>(a, st);
     return generic ? launch_conv<MODE, true, 1, 4, 4, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 1, 4, 4, 4, OUT_F32>(a, st);
   }
   // BK = 32 halves the LDS footprint (4 resident blocks per CU instead of 2): measured better for the latency-/write-bound
