@@ -47,7 +47,7 @@ struct ConvArgs {
 // same cache lines back to back.  Measured on the FCOS head (16 x 5 levels, 256 -> 256 3x3): L2 fetch traffic of the 256x256 kernel
 // 707 -> 205 MB per launch (algorithmic: 184 MB) at equal time; the 16-channel variant of the 128x128 kernel (box / centerness
 // prediction, Nout = 8) halves its time (1.59 GB of L2 fetches per launch before); the other variants measure equal and keep the
-// (tap outer) order their model-level parity tests were pinned with.  SOD_CONV_TAP_INNER=0|1 forces one order for all kernels.
+// (tap outer) order their model-level parity tests were pinned with.  SOD_CONV_TAP_INNER=0|1 forces one order for every variant of the 128x128 kernel (the 256x256 kernel always uses tap-inner).
 inline int conv_tap_inner(int dflt) {
   static int v = -2;
   if (v == -2) { const char* e = getenv("SOD_CONV_TAP_INNER"); v = e ? atoi(e) : -1; }

@@ -131,16 +131,11 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
 
   auto stage = [&](int t, char* buf) {
     if (linear) {
-      uint32_t tap;
-      int c0;
-      if (a.tap_inner) {
-        const uint32_t cc = fd_div((uint32_t)t, a.div_rs);
-        tap = (uint32_t)t - cc * a.div_rs.d;
-        c0 = (int)cc * BK;
-      } else {
-        tap = fd_div((uint32_t)t, a.div_cpt);
-        c0 = (t - (int)(tap * a.div_cpt.d)) * BK;
-      }
+      // both K orders computed with scalar multiply-highs and selected (no branch in the K loop)
+      const uint32_t cc = (__umulhi((uint32_t)t, a.div_rs.mul) + (uint32_t)t) >> a.div_rs.shr;
+      const uint32_t tap_o = (__umulhi((uint32_t)t, a.div_cpt.mul) + (uint32_t)t) >> a.div_cpt.shr;
+      const uint32_t tap = a.tap_inner ? (uint32_t)t - cc * a.div_rs.d : tap_o;
+      const int c0 = (a.tap_inner ? (int)cc : t - (int)(tap_o * a.div_cpt.d)) * BK;
       const int r = (int)fd_div(tap, a.div_s);
       const int s2 = (int)tap - r * a.S;
       const uint32_t tapoff = (uint32_t)((tap_sign * (r * a.dil * gWs + s2 * a.dil) * a.Cred + c0) * 2);   // scalar

@@ -119,21 +119,18 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
 
   // Loop-invariant scalars in registers (no kernarg reloads, i.e. no lgkmcnt waits, inside the K loop); branch-free staging:
   // a dead K-tile (kt >= T) ORs the out-of-range bit into the weight offset and selects tap 31, whose mask bit is never set.
-  const uint32_t cpt_mul = a.div_cpt.mul, cpt_shr = a.div_cpt.shr, cpt_d = a.div_cpt.d;
   const uint32_t s_mul = a.div_s.mul, s_shr = a.div_s.shr;
   const uint32_t rs_mul = a.div_rs.mul, rs_shr = a.div_rs.shr, rs_d = a.div_rs.d;
-  const int tap_inner = a.tap_inner, aCred = a.Cred;
+  const int aCred = a.Cred;
   const int aS = a.S, row_step = a.dil * gWs * a.Cred * 2 * tap_sign, col_step = a.dil * a.Cred * 2 * tap_sign;
 
   auto stage_a = [&](int u, int kt) {     // weight rows of sub-block u (a0 / a1) of K-tile kt
     char* dst = smem + (kt & 1) * BUF + u * UNIT + wave * 1024;
     const bool live = kt < T;
     const uint32_t kk = live ? (uint32_t)kt : 0u;
-    uint32_t woff = kk * 128u;
-    if (tap_inner) {
-      const uint32_t cc = (__umulhi(kk, rs_mul) + kk) >> rs_shr;
-      woff = ((kk - cc * rs_d) * (uint32_t)aCred + cc * 64u) * 2u;
-    }
+    // K-tile kk = (channel chunk cc, tap): weights [Nout][tap][C] -> byte offset (tap*C + cc*64)*2
+    const uint32_t cc = (__umulhi(kk, rs_mul) + kk) >> rs_shr;
+    const uint32_t woff = ((kk - cc * rs_d) * (uint32_t)aCred + cc * 64u) * 2u;
     const uint32_t dead = live ? 0u : SOD_OOB;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -145,13 +142,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
     char* dst = smem + (kt & 1) * BUF + (2 + u) * UNIT + wave * 1024;
     const bool live = kt < T;
     const uint32_t kk = live ? (uint32_t)kt : 0u;
-    uint32_t tap = (__umulhi(kk, cpt_mul) + kk) >> cpt_shr;
-    int c0 = (int)(kk - tap * cpt_d) * 128;
-    if (tap_inner) {
-      const uint32_t cc = (__umulhi(kk, rs_mul) + kk) >> rs_shr;
-      tap = kk - cc * rs_d;
-      c0 = (int)cc * 128;
-    }
+    const uint32_t cc = (__umulhi(kk, rs_mul) + kk) >> rs_shr;
+    const uint32_t tap = kk - cc * rs_d;
+    const int c0 = (int)cc * 128;
     const int r = (int)((__umulhi(tap, s_mul) + tap) >> s_shr);
     const int s2 = (int)tap - r * aS;
     const uint32_t tapoff = (uint32_t)(r * row_step + s2 * col_step + c0);
@@ -324,7 +317,7 @@ int launch256(const ConvArgs& a0, int max_pt_tiles, hipStream_t st) {
   a.T = a.Kred / 64;
   a.div_cpt = make_fastdiv((uint32_t)(a.Cred / 64));
   a.div_rs = make_fastdiv((uint32_t)(a.R * a.S));
-  a.tap_inner = conv_tap_inner(1);
+  a.tap_inner = 1;      // this kernel always walks K as (channel chunk outer, tap inner), see conv_args.h
   a.nq_tiles = (a.Nout + 255) / 256;
   int tiles = 0;
   for (int l = 0; l < a.nlev; ++l) {
