@@ -119,6 +119,9 @@ class ParamArena:
         return g
 
     def zero_grad(self):
+        if self.device.type == "cuda":
+            from . import functional as HF
+            HF.wgrad_join()          # never clear the arena under weight-gradient kernels still running on the side stream
         self.grads.zero_()
 
     def bump(self):
@@ -177,6 +180,9 @@ class ParamArena:
         every all-reduce.  Gradients hold the SUM over ranks afterwards; the optimizer applies 1/world."""
         if self._pending is None:
             return
+        if self.device.type == "cuda":
+            from . import functional as HF
+            HF.wgrad_join()
         for bi in range(len(self.buckets)):
             if not self._launched[bi]:
                 self._launch_bucket(bi)

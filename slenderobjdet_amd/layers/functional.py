@@ -57,6 +57,14 @@ def _wgrad_join():
         torch.cuda.current_stream(idx).wait_stream(side)
 
 
+def wgrad_join():
+    """Make the current stream(s) wait for every weight-gradient launch enqueued so far.  The end-of-backward callback does this
+    on the normal path; the optimizer and the bucket reducer call it again so that a backward pass that ended in an exception (the
+    callback never ran) cannot leave gradients in flight.  A no-op when no side stream exists."""
+    if _side_streams:
+        _wgrad_join()
+
+
 def _wgrad_stream(device, tensors):
     """Returns the stream to launch a wgrad on (None = current stream)."""
     global _side_join_queued

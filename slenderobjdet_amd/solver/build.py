@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from .. import _C
 from .._C import call, ptr, stream_ptr
+from ..layers import functional as HF
 from ..layers.nn import HipGroupNorm
 
 _NORM_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm, nn.GroupNorm, nn.InstanceNorm1d,
@@ -76,6 +77,7 @@ class FusedSGD(torch.optim.Optimizer):
         g0 = self.param_groups[0]
         lr_now = self.param_groups[self._ref_group]["lr"] / self._ref_mult
         a = self.arena
+        HF.wgrad_join()
         call("sod_sgd_step", ptr(a.params), ptr(a.grads), ptr(a.momentum), ptr(self._segs), self._nseg, None, float(lr_now),
              float(g0["momentum"]), 1 if g0["nesterov"] else 0, 1 if self._steps == 0 else 0, float(self.grad_scale), stream_ptr())
         self._steps += 1
