@@ -121,20 +121,31 @@ def train_step(model, optimizer, data):
     return total
 
 
-def pmc_traffic(kind):
+def variant_kernel_name(code, mode=0):
+    """sod_conv_last_variant() code -> the kernel name rocprofv3 prints (slender_hip.h)."""
+    if code == 256:
+        return f"void sodconv::conv_igemm256_kernel<{mode}, false>"
+    bq, bp, bk = code // 100000, (code // 100) % 1000, code % 100
+    generic, bk = bk & 1, bk & ~1
+    wq, wp, fq, fp = {(16, 256): (1, 4, 1, 4), (64, 256): (1, 4, 4, 4), (128, 128): (2, 2, 4, 4), (128, 256): (2, 4, 4, 4)}.get((bq, bp), (0, 0, 0, 0))
+    return f"void conv_igemm_kernel<{mode}, {'true' if generic else 'false'}, {wq}, {wp}, {fq}, {fp}, false, {bk}, "
+
+
+def pmc_traffic(kind, kernel_prefix=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json: separate
     --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md). None if absent."""
     import glob
 
-    prefixes = {"conv_fwd": ("void conv_igemm_kernel<0, false, 2, 2, 4, 4, false, 64", "void conv_igemm_kernel<0, ", "void sodconv::conv_igemm256_kernel<0, "),
-                "conv_dgrad": ("void conv_igemm_kernel<1, false, 2, 2, 4, 4, false, 64", "void conv_igemm_kernel<1, ", "void sodconv::conv_igemm256_kernel<1, "),
+    prefixes = {"conv_fwd": ("void conv_igemm_kernel<0, ", "void sodconv::conv_igemm256_kernel<0, "),
+                "conv_dgrad": ("void conv_igemm_kernel<1, ", "void sodconv::conv_igemm256_kernel<1, "),
                 "conv_wgrad": ("void conv_wgrad_kernel", "conv_wgrad_kernel")}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
     if not files or kind not in prefixes:
         return None
     try:
         kernels = json.load(open(files[-1]))["kernels"]
-        hits = [(v["launches"], k, v) for k, v in kernels.items() if k.startswith(prefixes[kind][0])]
+        want = kernel_prefix or prefixes[kind][0]
+        hits = [(v["launches"], k, v) for k, v in kernels.items() if k.startswith(want)]
         if not hits:
             return None
         _, name, k = max(hits)
@@ -263,23 +274,33 @@ def main():
         if args.arch == "fcos" and args.depth == 50:
             out["model_tflops"] = round(imgs * TRAIN_FLOP_PER_IMAGE / dt / 1e12, 2)
         if prof:
-            agg = {}
-            for kind, flops, e0, e1, _desc in prof:
+            agg, by_var = {}, {}
+            for kind, flops, e0, e1, _desc, variant in prof:
+                sec_ = e0.elapsed_time(e1) * 1e-3
                 a = agg.setdefault(kind, [0.0, 0.0, 0])
-                a[0] += flops
-                a[1] += e0.elapsed_time(e1) * 1e-3
-                a[2] += 1
-            kind = "conv_fwd"
-            fl, sec, cnt = agg[kind]
+                a[0] += flops; a[1] += sec_; a[2] += 1
+                if kind == "conv_fwd":
+                    b = by_var.setdefault(variant, [0.0, 0.0, 0])
+                    b[0] += flops; b[1] += sec_; b[2] += 1
+            # the dominant kernel = the forward conv kernel variant that does the largest share of the forward convolution FLOPs (the
+            # 256x256 kernel: 55 % of them); every variant is listed in "forward_conv_variants" (the HBM-bound 1x1 convs of the
+            # 128x128 BK=32 variant take slightly more TIME at a sixth of the FLOPs) and the average over all of them in "all_conv"
+            var = max(by_var, key=lambda v: by_var[v][0])
+            fl, sec, cnt = by_var[var]
             achieved = fl / sec / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": kind, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(kind), "launches": cnt, "sampled_steps": prof_steps,
-                               "avg_launch_us": round(sec / cnt * 1e6, 2),
+            kname = variant_kernel_name(var)
+            out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic("conv_fwd", kname), "launches": cnt,
+                               "sampled_steps": prof_steps, "avg_launch_us": round(sec / cnt * 1e6, 2),
+                               "ms_per_step": round(sec / prof_steps * 1e3, 3),
+                               "forward_conv_variants": {variant_kernel_name(v): {"TFLOP/s": round(x[0] / x[1] / 1e12, 2), "ms_per_step": round(x[1] / prof_steps * 1e3, 3),
+                                                                                  "launches_per_step": x[2] // prof_steps}
+                                                         for v, x in sorted(by_var.items(), key=lambda kv: -kv[1][1])},
                                "all_conv": {k: {"TFLOP/s": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / prof_steps * 1e3, 3),
                                                 "overlapped": k != "conv_fwd" and HF.WGRAD_SIDE_STREAM} for k, v in agg.items()}}
         if prof and args.dump_prof:
             per = {}
-            for kind, flops, e0, e1, desc in prof:
+            for kind, flops, e0, e1, desc, _variant in prof:
                 a = per.setdefault((kind, desc), [0.0, 0.0, 0])
                 a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
             for (kind, desc), (fl, sec, cnt) in sorted(per.items(), key=lambda kv: -kv[1][1])[:args.dump_prof]:

@@ -21,6 +21,8 @@ using namespace sodconv;
 
 namespace {
 
+thread_local int g_last_variant = 0;   // kernel variant chosen by the last forward / data-gradient dispatch (sod_conv_last_variant)
+
 template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK, int NSTAGE>
 __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int NW = WQ * WP;                  // waves per workgroup (4 or 8)
@@ -702,6 +704,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   const size_t epi = (size_t)(WQ * WP) * (size_t)(FP / 2) * 16 * (FQ * 64 + 16);
   size_t lds = a.T == 1 ? (size_t)(BQ + BP) * BK * 2 : lds_full;
   if (lds < epi) lds = epi;
+  g_last_variant = BQ * 100000 + BP * 100 + BK + (GENERIC ? 1 : 0);
   auto kern = conv_igemm_kernel<MODE, GENERIC, WQ, WP, FQ, FP, OUT_F32, BK, NSTAGE>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -739,7 +742,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     long long pt256 = 0;
     for (int l = 0; l < a.nlev; ++l) pt256 += (a.lev[l].P + 255) / 256;
     const long long b256 = pt256 * nq;
-    if (c256 == 2) return launch_conv256(a, MODE, OUT_F32, 0, st);
+    if (c256 == 2) { g_last_variant = 256; return launch_conv256(a, MODE, OUT_F32, 0, st); }
     if (a.Nout >= 256 && (a.Nout & 255) == 0 && a.Kred >= 1024 && b256 >= 2 * cus) {
       // Measured (16 x FPN levels, 256 -> 256 3x3): 1020-1040 TFLOP/s against 840-930 for the 128x128 kernel; shapes with fewer than
       // two rounds of tiles (res4 conv2: 263 tiles) are faster on the 128x128 kernel.
@@ -747,7 +750,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
       // a remainder below half a round is computed by the 128x128 kernel (two workgroups per CU, 4x smaller tiles) instead
       // (P3 output conv, 4.1 rounds: 1035 -> 1075 TFLOP/s).
       const long long full = b256 / cus * cus, rem = b256 - full;
-      if (rem == 0 || rem * 2 >= (long long)cus || (full / nq) * nq != full) return launch_conv256(a, MODE, OUT_F32, 0, st);
+      if (rem == 0 || rem * 2 >= (long long)cus || (full / nq) * nq != full) { g_last_variant = 256; return launch_conv256(a, MODE, OUT_F32, 0, st); }
       int main_pt = (int)(full / nq);
       int rc = launch_conv256(a, MODE, OUT_F32, main_pt, st);
       if (rc) return rc;
@@ -757,7 +760,9 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
         if (main_pt >= tl) { tail.lev[l].pstart = tail.lev[l].P; main_pt -= tl; }
         else { tail.lev[l].pstart = main_pt * 256; main_pt = 0; }
       }
-      return dispatch_conv<MODE, OUT_F32>(tail, st);
+      rc = dispatch_conv<MODE, OUT_F32>(tail, st);
+      g_last_variant = 256;      // whole rounds on the 256 kernel (+ a short 128x128 tail launch)
+      return rc;
     }
   }
   if (a.Nout <= 16) {
@@ -1015,6 +1020,8 @@ extern "C" int sod_conv2d_dgrad_ml(int nlev, const void* const* dy, const void* 
 // that follow; one compute stream per process, as everywhere in this library)
 static float* g_wgrad_ws[16] = {nullptr};
 static long long g_wgrad_ws_bytes[16] = {0};
+
+extern "C" int sod_conv_last_variant(void) { return g_last_variant; }
 
 extern "C" int sod_conv_set_tile256(int mode) {
   if (mode < -1 || mode > 2) return SOD_EARG;

@@ -32,7 +32,8 @@ def _prof_end(kind, flops, e0, desc=None, stream=None):
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record(stream)
-    PROFILE.append((kind, flops, e0, e1, desc))
+    variant = int(_C.load().sod_conv_last_variant()) if kind in ("conv_fwd", "conv_dgrad") else 0
+    PROFILE.append((kind, flops, e0, e1, desc, variant))
 
 
 # Weight gradients have no consumer until the optimizer (or the bucket all-reduce), while the data gradient of the same layer is on
