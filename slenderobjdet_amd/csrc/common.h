@@ -37,8 +37,8 @@ static inline FastDiv make_fastdiv(uint32_t d) {
   return f;
 }
 __device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) {
-  if (f.d == 1) return n;
-  uint32_t t = __umulhi(n, f.mul);
+  // d == 1 is encoded as mul = 0, shr = 0 and needs no special case: a branch here ends up inside every K loop that divides
+  const uint32_t t = __umulhi(n, f.mul);
   return (t + n) >> f.shr;               // n < 2^31 => no overflow
 }
 
