@@ -636,6 +636,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
         for (int e = 0; e < 4; ++e) acc[i][j][e] *= qsv[i][e];
   }
   const int mode = a.partial ? 0 : (a.dbg_plain_store ? 1 : 2);      // wave-uniform, hoisted out of the element loops
+  if (mode == 2 && q0 + 128 <= a.K && c0 + 128 <= a.C) {             // full tile: 64 atomics in straight-line code
+    float* d0 = a.dw + ((size_t)(q0 + wq * 64 + fg * 4) * RS + tap) * a.C + c0 + wc * 64 + fr;
+    const size_t qstride = (size_t)RS * a.C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(d0 + (size_t)(i * 16 + e) * qstride + j * 16, acc[i][j][e]);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
