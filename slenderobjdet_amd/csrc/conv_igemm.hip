@@ -105,7 +105,9 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
   // When the tap is uniform per K-step (!GENERIC) and the source coordinate is affine in the tap (fwd, or dgrad with
   // stride 1), the byte offset of a row is rowbase + tapoff(t) with a SCALAR tapoff, and the padding test is one bit of a
   // per-row tap-validity mask computed once here.  Per K-step and row: one add, one shift/and, one select.
-  const bool linear = !GENERIC && (MODE == MODE_FWD || a.stride == 1) && a.R * a.S <= 64;
+  // forward non-generic kernels are always linear (the host routes R*S > 64 to the generic kernel): a compile-time constant there,
+  // so the gather path and its branch drop out of the forward K loop
+  const bool linear = !GENERIC && (MODE == MODE_FWD || (a.stride == 1 && a.R * a.S <= 64));
   uint32_t rowbase[XI];
   unsigned long long tapmask[XI];
   uint32_t wbase[(BQ + RPP - 1) / RPP];
@@ -732,7 +734,7 @@ int g_conv256_mode = -1;   // -1: read SOD_CONV256 (default 1); 0 off; 1 heurist
 
 template <int MODE, bool OUT_F32>
 int dispatch_conv(const ConvArgs& a, hipStream_t st) {
-  const bool generic = (a.Cred & 63) != 0;
+  const bool generic = (a.Cred & 63) != 0 || a.R * a.S > 64;      // the linear path keeps one validity bit per tap in 64-bit masks
   // 256x256 8-phase kernel (conv_igemm256.hip) for the large compute-bound shapes.  SOD_CONV256=0 disables it, =2 forces it for
   // every shape it supports (parity tests).
   static int cus = 0;
