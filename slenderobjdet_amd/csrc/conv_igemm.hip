@@ -440,7 +440,16 @@ struct WgradArgs {
 
 // KP = pixels per K-step: 64 (two resident workgroups per CU) or 32 (half the LDS: three to four per CU, which is what the
 // latency of the transposing ds_read_b64_tr_b16 fragment reads wants - they need more waves per SIMD than ds_read_b128).
-template <int KP>
+// inline-asm transposing LDS read: invisible to hipcc's memory model, so it does not put a vmcnt(0) in front of it while LDS-DMA
+// loads of OTHER ring slots are in flight (the builtin form does).  The caller waits lgkmcnt(0) + sched_barrier(0) before any use.
+template <int OFF>
+__device__ __forceinline__ s16x4_t lds_tr_read_asm(uint32_t addr) {
+  s16x4_t r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+
+template <int KP, int NSTAGE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int TILE = KP * 256, STAGE = 2 * TILE;   // [KP pixels][128 ch] bf16, two operands
   constexpr int NI = KP / 16;                        // staged rows per thread and operand
@@ -576,6 +585,54 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (NSTAGE == 3) {
+    // Three-slot LDS ring with a counted wait: the tile two K-steps ahead is requested while this one is computed, so a load has
+    // two K-steps to land.  The split-over-pixels wgrad is latency-bound with a one-step prefetch (res4 conv2: 2 700 cycles per
+    // 32-pixel step for 256 cycles of MFMA per wave, three workgroups per CU).  Every thread issues exactly LPS LDS-DMA loads per
+    // stage() call, on every path.
+    static_assert(KP == 32, "ring variant is built for 32-pixel steps");
+    constexpr int LPS = NI * 2;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)SOD_LDS(smem);
+    if (nsteps > 0) stage(0, smem);
+    if (nsteps > 1) stage(1, smem + STAGE);
+    int slot = 0;
+    for (int it = 0; it < nsteps; ++it) {
+      if (it + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // tile `it` has landed for every wave; every wave has finished reading tile it-1
+      const uint32_t cb = lds0 + (uint32_t)(slot * STAGE);
+      s16x4_t alo[4], ahi[4], blo[4], bhi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        alo[i] = lds_tr_read_asm<0>(cb + aoff[i]);
+        ahi[i] = lds_tr_read_asm<1024>(cb + aoff[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        blo[j] = lds_tr_read_asm<0>(cb + boff[j]);
+        bhi[j] = lds_tr_read_asm<1024>(cb + boff[j]);
+      }
+      int ns = slot + 2; if (ns >= 3) ns -= 3;
+      if (it + 2 < nsteps) stage(it + 2, smem + ns * STAGE);   // overwrites the slot of tile it-1
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);                       // nothing that uses the fragments may move above the wait
+      bf16x8_t af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s16x8_t v = {alo[i][0], alo[i][1], alo[i][2], alo[i][3], ahi[i][0], ahi[i][1], ahi[i][2], ahi[i][3]};
+        af[i] = __builtin_bit_cast(bf16x8_t, v);
+        s16x8_t w = {blo[i][0], blo[i][1], blo[i][2], blo[i][3], bhi[i][0], bhi[i][1], bhi[i][2], bhi[i][3]};
+        bf[i] = __builtin_bit_cast(bf16x8_t, w);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      slot = (slot == 2) ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
   if (nsteps > 0) stage(0, smem);
   for (int it = 0; it < nsteps; ++it) {
     char* cur = smem + (it & 1) * STAGE;
@@ -614,6 +671,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+  }
   }
 
   // D[row=q][col=c]
@@ -901,7 +959,7 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
   const size_t lds = 2 * 2 * 64 * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
@@ -911,8 +969,10 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
   static const int two_stage = getenv("SOD_WGRAD_TWO_STAGE") ? atoi(getenv("SOD_WGRAD_TWO_STAGE")) : 0;
   const long long need = (long long)a.nz * tiles * 128 * 128 * (long long)sizeof(float);
   a.partial = (two_stage && ws && a.nz >= 8 && tiles <= 32 && need <= ws_bytes) ? ws : nullptr;
-  if (kp == 32) SOD_LAUNCH(conv_wgrad_kernel<32>, dim3(a.nz * tiles), dim3(256), lds / 2, st, a);
-  else SOD_LAUNCH(conv_wgrad_kernel<64>, dim3(a.nz * tiles), dim3(256), lds, st, a);
+  static const int ring = getenv("SOD_WGRAD_RING") ? atoi(getenv("SOD_WGRAD_RING")) : 1;
+  if (kp == 32 && ring) SOD_LAUNCH((conv_wgrad_kernel<32, 3>), dim3(a.nz * tiles), dim3(256), 3 * 2 * 32 * 256, st, a);
+  else if (kp == 32) SOD_LAUNCH((conv_wgrad_kernel<32, 2>), dim3(a.nz * tiles), dim3(256), lds / 2, st, a);
+  else SOD_LAUNCH((conv_wgrad_kernel<64, 2>), dim3(a.nz * tiles), dim3(256), lds, st, a);
   if (a.partial) {
     const int gx = (tiles * 128 * 32 + 255) / 256;
     int gy = (1024 + gx - 1) / gx;            // ~1024 workgroups in total
