@@ -923,7 +923,7 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
     Ptot += a.lev[l].P;
   }
   a.V = V;
-  // Pixels per K-step: 64 (64 KB LDS, 175 VGPRs, two workgroups per CU) or 32 (32 KB, 132 VGPRs, three per CU).  In the training
+  // Pixels per K-step: 64 (64 KB LDS, 175 VGPRs, two workgroups per CU) or 32 (three-slot ring: 48 KB, 131 VGPRs, two per CU).  In the training
   // step the wgrad kernels run on the side stream BESIDE the data-gradient kernels, so the LDS footprint counts as well as the
   // stand-alone rate.  Measured on the FCOS R50 step (same box, after the read-before-stage loop order): 32 / 3 per CU for the
   // many-tile shapes (3x3 with >= 256 channels) and 64 / 2 per CU for the rest 510.6-510.9 img/s; 64 everywhere 509-511; 32
@@ -942,7 +942,7 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
     static const int per_cu_env = getenv("SOD_WGRAD_PER_CU") ? atoi(getenv("SOD_WGRAD_PER_CU")) : 0;
-    static const int pc_big = getenv("SOD_WGRAD_PC_BIG") ? atoi(getenv("SOD_WGRAD_PC_BIG")) : 3;
+    static const int pc_big = getenv("SOD_WGRAD_PC_BIG") ? atoi(getenv("SOD_WGRAD_PC_BIG")) : 2;   // 2 x 48 KB (ring) leaves 64 KB of LDS per CU for a data-gradient workgroup: 541.7 vs 538.2 img/s for 3
     const int slots = (per_cu_env > 0 ? per_cu_env : (tiles >= 36 ? (kp == 32 ? pc_big : 2) : pc_small)) * cus;
     splits = slots / tiles;
     const int maxs = (int)((Ptot + 255) / 256);
