@@ -804,10 +804,11 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   }
   bool any_start = false;
   for (int l = 0; l < a.nlev; ++l) any_start |= a.lev[l].pstart != 0;
-  // Data gradients stay on the 128x128 kernel by default: beside the side-stream wgrad blocks a 128-KB workgroup rarely finds a free
-  // CU (FCOS R50 step 490 vs 487.5 img/s); SOD_CONV256_DGRAD=1 enables the 256 kernel for them.
+  // Data gradients use the 256 kernel as well (SOD_CONV256_DGRAD=0 keeps them on the 128x128 kernel).  Beside the wgrad side stream
+  // the answer depends on what the wgrad blocks leave free: with 3-4 small wgrad workgroups per CU the 128-KB workgroup rarely found
+  // a CU (490 vs 487.5 img/s in favour of 128x128); with two ring workgroups per CU and the faster wgrad it wins 542.4 vs 536.0.
   static int c256_dgrad = -1;
-  if (c256_dgrad < 0) { const char* e = getenv("SOD_CONV256_DGRAD"); c256_dgrad = e ? atoi(e) : 0; }
+  if (c256_dgrad < 0) { const char* e = getenv("SOD_CONV256_DGRAD"); c256_dgrad = e ? atoi(e) : 1; }
   if (c256 && !any_start && conv256_supported(a, MODE) && (MODE == MODE_FWD || c256_dgrad || c256 == 2)) {
     const int nq = (a.Nout + 255) / 256;
     long long pt256 = 0;
