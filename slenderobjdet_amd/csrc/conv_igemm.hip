@@ -924,14 +924,13 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
     Ptot += a.lev[l].P;
   }
   a.V = V;
-  // Pixels per K-step: 64 (64 KB LDS, 175 VGPRs, two workgroups per CU) or 32 (three-slot ring: 48 KB, 131 VGPRs, two per CU).  In the training
-  // step the wgrad kernels run on the side stream BESIDE the data-gradient kernels, so the LDS footprint counts as well as the
-  // stand-alone rate.  Measured on the FCOS R50 step (same box, after the read-before-stage loop order): 32 / 3 per CU for the
-  // many-tile shapes (3x3 with >= 256 channels) and 64 / 2 per CU for the rest 510.6-510.9 img/s; 64 everywhere 509-511; 32
-  // everywhere 504-508.  (Before that loop fix the prefetch was drained by a compiler-inserted vmcnt(0) and 32 everywhere won by 5 %.)
-  // SOD_WGRAD_KP=32|64 forces one size.
+  // Pixels per K-step: 64 (two slots, 64 KB LDS, 175 VGPRs) or 32 (three-slot ring, 48 KB, 131 VGPRs; the default for every shape).  In
+  // the training step the wgrad kernels run on the side stream BESIDE the data-gradient kernels, so the LDS footprint counts as well as
+  // the stand-alone rate, and the best setting moved every time one of the kernels changed.  Last sweep on the FCOS R50 step (same box;
+  // 256x256 data gradients): ring everywhere, 3 workgroups per CU for the many-tile shapes and 2 for the rest 550.8-551.5 img/s; 2 / 2
+  // 549.4-550.5; 64-pixel steps for the few-tile shapes 544-547.  SOD_WGRAD_KP=32|64 forces one size, SOD_WGRAD_PC_BIG / _PC_SMALL the counts.
   static const int kp_env = getenv("SOD_WGRAD_KP") ? atoi(getenv("SOD_WGRAD_KP")) : 0;
-  static const int kp_small = getenv("SOD_WGRAD_KP_SMALL") ? atoi(getenv("SOD_WGRAD_KP_SMALL")) : 64;
+  static const int kp_small = getenv("SOD_WGRAD_KP_SMALL") ? atoi(getenv("SOD_WGRAD_KP_SMALL")) : 32;
   static const int pc_small = getenv("SOD_WGRAD_PC_SMALL") ? atoi(getenv("SOD_WGRAD_PC_SMALL")) : 2;
   const int kp = kp_env ? kp_env : (tiles >= 36 ? 32 : kp_small);
   if (splits <= 0) {
@@ -943,7 +942,7 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
     static const int per_cu_env = getenv("SOD_WGRAD_PER_CU") ? atoi(getenv("SOD_WGRAD_PER_CU")) : 0;
-    static const int pc_big = getenv("SOD_WGRAD_PC_BIG") ? atoi(getenv("SOD_WGRAD_PC_BIG")) : 2;   // 2 x 48 KB (ring) leaves 64 KB of LDS per CU for a data-gradient workgroup: 541.7 vs 538.2 img/s for 3
+    static const int pc_big = getenv("SOD_WGRAD_PC_BIG") ? atoi(getenv("SOD_WGRAD_PC_BIG")) : 3;
     const int slots = (per_cu_env > 0 ? per_cu_env : (tiles >= 36 ? (kp == 32 ? pc_big : 2) : pc_small)) * cus;
     splits = slots / tiles;
     const int maxs = (int)((Ptot + 255) / 256);
