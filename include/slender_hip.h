@@ -77,7 +77,7 @@ int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, f
 /* Optional caller-owned scratch (fp32, >= 32 MiB recommended) for the current device: weight gradients whose output has few 128x128
  * tiles then write per-split partial tiles and sum them in a second kernel instead of contending on global atomics. NULL disables. */
 int sod_conv_set_workspace(void* ws, long long bytes);
-/* Tile policy of sod_conv2d_fwd / _dgrad (process-wide): 1 (default, or env SOD_CONV256) = shapes with >= 2 rounds of 256x256 output
+/* Tile policy of sod_conv2d_fwd / _dgrad (process-wide): 1 (default, or env SOD_CONV256) = shapes with >= 1 round of 256x256 output
  * tiles, Nout % 256 == 0 and R*S*C >= 1024 run on the 256x256x64 8-phase kernel (whole rounds; a short remainder goes to the
  * 128x128 kernel); 0 = 128x128 kernel only; 2 = the 256 kernel for every shape it supports (tests); -1 = re-read the env. */
 int sod_conv_set_tile256(int mode);

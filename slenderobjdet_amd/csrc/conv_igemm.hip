@@ -815,9 +815,11 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     for (int l = 0; l < a.nlev; ++l) pt256 += (a.lev[l].P + 255) / 256;
     const long long b256 = pt256 * nq;
     if (c256 == 2) { g_last_variant = 256; return launch_conv256(a, MODE, OUT_F32, 0, st); }
-    if (a.Nout >= 256 && (a.Nout & 255) == 0 && a.Kred >= 1024 && b256 >= 2 * cus) {
-      // Measured (16 x FPN levels, 256 -> 256 3x3): 1020-1040 TFLOP/s against 840-930 for the 128x128 kernel; shapes with fewer than
-      // two rounds of tiles (res4 conv2: 263 tiles) are faster on the 128x128 kernel.
+    static const int min_rounds = getenv("SOD_CONV256_MIN_ROUNDS") ? atoi(getenv("SOD_CONV256_MIN_ROUNDS")) : 1;
+    if (a.Nout >= 256 && (a.Nout & 255) == 0 && a.Kred >= 1024 && b256 >= (long long)min_rounds * cus) {
+      // Measured (16 x FPN levels, 256 -> 256 3x3): 1020-1040 TFLOP/s against 840-930 for the 128x128 kernel.  Shapes with barely more
+      // than one round of tiles (res4 conv2: 263 tiles = one round + a 7-tile remainder launch) measured slower stand-alone but win in
+      // the training step (545.8-546.3 vs 541.2-542.9 img/s), so one full round is enough (SOD_CONV256_MIN_ROUNDS).
       // One workgroup per CU: a partial last round of 256x256 tiles wastes up to a whole round.  Whole rounds go to the 256 kernel,
       // a remainder below half a round is computed by the 128x128 kernel (two workgroups per CU, 4x smaller tiles) instead
       // (P3 output conv, 4.1 rounds: 1035 -> 1075 TFLOP/s).
