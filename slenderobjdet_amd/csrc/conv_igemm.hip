@@ -816,7 +816,8 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     const long long b256 = pt256 * nq;
     if (c256 == 2) { g_last_variant = 256; return launch_conv256(a, MODE, OUT_F32, 0, st); }
     static const int min_rounds = getenv("SOD_CONV256_MIN_ROUNDS") ? atoi(getenv("SOD_CONV256_MIN_ROUNDS")) : 1;
-    if (a.Nout >= 256 && (a.Nout & 255) == 0 && a.Kred >= 1024 && b256 >= (long long)min_rounds * cus) {
+    static const int min_k = getenv("SOD_CONV256_MIN_K") ? atoi(getenv("SOD_CONV256_MIN_K")) : 1024;
+    if (a.Nout >= 256 && (a.Nout & 255) == 0 && a.Kred >= min_k && b256 >= (long long)min_rounds * cus) {
       // Measured (16 x FPN levels, 256 -> 256 3x3): 1020-1040 TFLOP/s against 840-930 for the 128x128 kernel.  Shapes with barely more
       // than one round of tiles (res4 conv2: 263 tiles = one round + a 7-tile remainder launch) measured slower stand-alone but win in
       // the training step (545.8-546.3 vs 541.2-542.9 img/s), so one full round is enough (SOD_CONV256_MIN_ROUNDS).
