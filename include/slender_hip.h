@@ -137,6 +137,10 @@ int sod_sgd_step(float* params, const float* grads, float* momentum_buf, const v
  * mean3/std3 are HOST pointers. */
 int sod_preprocess_image(const void* img, int is_uint8, int C, int H, int W, void* out, int Hp, int Wp, int Cpad,
                          const float* mean3, const float* std3, void* stream);
+/* The same for a whole batch in one launch: imgs / H / W are HOST arrays of n (<= 64) device pointers and sizes (all images of
+ * one dtype); out is the (n, Hp, Wp, 8) batch buffer. */
+int sod_preprocess_batch(int n, const void* const* imgs, int is_uint8, int C, const int* H, const int* W, void* out, int Hp, int Wp,
+                         int Cpad, const float* mean3, const float* std3, void* stream);
 int sod_nchw_f32_to_nhwc_bf16(const float* x, void* y, int N, int C, int HW, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------

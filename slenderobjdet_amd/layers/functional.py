@@ -365,6 +365,26 @@ def preprocess_image(img, out, mean, std):
     return out
 
 
+def preprocess_batch(imgs, out, mean, std):
+    """imgs: list of (C,H,W) uint8/float32 CUDA tensors of one dtype -> out (n,Hp,Wp,8) bf16, one launch."""
+    dt = imgs[0].dtype
+    if dt not in (torch.uint8, torch.float32) or any(i.dtype != dt for i in imgs) or len(imgs) > 64:
+        for i, im in enumerate(imgs):
+            preprocess_image(im.contiguous() if im.dtype in (torch.uint8, torch.float32) else im.float().contiguous(), out[i], mean, std)
+        return out
+    _chk(out, torch.bfloat16, "out")
+    imgs = [i.contiguous() for i in imgs]
+    for i in imgs:
+        _chk(i, None, "image")
+    n, Hp, Wp, Cp = out.shape
+    C = imgs[0].shape[0]
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    call("sod_preprocess_batch", len(imgs), _ptr_arr(imgs), 1 if dt == torch.uint8 else 0, C, _int_arr([i.shape[1] for i in imgs]),
+         _int_arr([i.shape[2] for i in imgs]), ptr(out), Hp, Wp, Cp, ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p), stream_ptr())
+    return out
+
+
 def nchw_f32_to_nhwc_bf16(x):
     _chk(x, torch.float32, "x")
     N, C, H, W = x.shape

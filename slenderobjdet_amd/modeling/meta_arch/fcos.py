@@ -374,10 +374,8 @@ class FCOSV2(nn.Module):
         sizes = [(int(i.shape[-2]), int(i.shape[-1])) for i in imgs]
         Hp, Wp = ImageList.padded_size(sizes, self.backbone.size_divisibility)
         batch = torch.empty((len(imgs), Hp, Wp, 8), dtype=torch.bfloat16, device=self.device)
-        for i, im in enumerate(imgs):
-            if im.dtype != torch.uint8:
-                im = im.float()
-            HF.preprocess_image(im.contiguous(), batch[i], self._mean, self._std)
+        imgs = [im if im.dtype == torch.uint8 else im.float() for im in imgs]
+        HF.preprocess_batch(imgs, batch, self._mean, self._std)       # one launch for the batch
         return ImageList(batch, sizes)
 
 

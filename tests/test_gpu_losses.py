@@ -242,6 +242,22 @@ def test_preprocess(cuda):
     assert torch.equal(out[..., :3].float().cpu(), ref)
 
 
+def test_preprocess_batch_ragged(cuda):
+    """One launch for the whole batch (sod_preprocess_batch): images of different sizes, bit-equal to the oracle per image."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    sizes = [(37, 53), (64, 40), (1, 1), (50, 64)]
+    imgs = [torch.randint(0, 256, (3, h, w), dtype=torch.uint8, generator=_g(10 + i)) for i, (h, w) in enumerate(sizes)]
+    mean, std = [103.53, 116.28, 123.675], [1.0, 1.0, 57.0]
+    for cast in (lambda t: t, lambda t: t.float()):
+        out = torch.full((len(imgs), 64, 64, 8), 7.0, dtype=torch.bfloat16, device=cuda)
+        HF.preprocess_batch([cast(i).to(cuda) for i in imgs], out, mean, std)
+        for i, im in enumerate(imgs):
+            ref = onn.rb(onn.preprocess(im, mean, std, 64, 64))
+            assert torch.equal(out[i, ..., :3].float().cpu(), ref), i
+        assert (out[..., 3:] == 0).all()
+
+
 def test_reference_signature_wrappers(cuda):
     """layers.losses.{sigmoid_focal_loss_jit, iou_loss} keep the reference signatures and are differentiable."""
     from slenderobjdet_amd.layers.losses import iou_loss, sigmoid_focal_loss_jit
