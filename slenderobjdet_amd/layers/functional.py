@@ -43,6 +43,7 @@ def _prof_end(kind, flops, e0, desc=None, stream=None):
 # SOD_WGRAD_STREAM=0 keeps everything on one stream.
 WGRAD_SIDE_STREAM = os.environ.get("SOD_WGRAD_STREAM", "1") != "0"
 _side_streams = {}
+_side_keep = []
 _side_join_queued = False
 
 
@@ -56,6 +57,7 @@ def _wgrad_join():
     _side_join_queued = False
     for idx, side in _side_streams.items():
         torch.cuda.current_stream(idx).wait_stream(side)
+    _side_keep.clear()      # the main stream now waits for every side-stream reader: the operands may go back to its pool
 
 
 def wgrad_join():
@@ -84,9 +86,11 @@ def _wgrad_stream(device, tensors):
         prio = int(os.environ.get("SOD_WGRAD_PRIO", "1"))
         side = _side_streams[device.index] = torch.cuda.Stream(device=device, priority=prio)
     side.wait_stream(torch.cuda.current_stream(device))
-    for t in tensors:
-        if t is not None:
-            t.record_stream(side)     # the caching allocator must not recycle dy / x under the side-stream kernel
+    # The operands (dY, X) must outlive the side-stream kernel.  They are kept referenced until the join instead of
+    # Tensor.record_stream(): with record_stream the allocator cannot reuse a block until a GPU-side event has completed, and since the
+    # host runs several steps ahead of the GPU the pool grew from 10 GB to 52 GB; held references are released in main-stream order
+    # right after the join is enqueued, so the pool stays at its single-stream size plus one backward pass of gradients.
+    _side_keep.extend(t for t in tensors if t is not None)
     return side
 CONV_RELU = 1
 CONV_RES_UP2 = 2
