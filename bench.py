@@ -289,8 +289,10 @@ def main():
             fl, sec, cnt = by_var[var]
             achieved = fl / sec / 1e12
             kname = variant_kernel_name(var)
+            tr = pmc_traffic("conv_fwd", kname)      # HBM bytes per launch of that kernel from the committed PMC passes (or None)
             out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic("conv_fwd", kname), "launches": cnt,
+                               "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": (tr or {}).get("hbm_bytes_per_launch"),
+                               "traffic_detail": tr, "launches": cnt,
                                "sampled_steps": prof_steps, "avg_launch_us": round(sec / cnt * 1e6, 2),
                                "ms_per_step": round(sec / prof_steps * 1e3, 3),
                                "forward_conv_variants": {variant_kernel_name(v): {"TFLOP/s": round(x[0] / x[1] / 1e12, 2), "ms_per_step": round(x[1] / prof_steps * 1e3, 3),
