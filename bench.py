@@ -211,6 +211,7 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
+    from slenderobjdet_amd import _C
     from slenderobjdet_amd.data import SyntheticCocoBatches
     from slenderobjdet_amd.layers import functional as HF
     from slenderobjdet_amd.modeling import build_model
@@ -240,11 +241,14 @@ def main():
         # not per-kernel durations; they are only collected for --dump-prof.
         # Event pairs cost ~11 us of queue bubbles each, so only every 4th timed step carries them (all steps with --dump-prof).
         HF.PROFILE_KINDS = None if args.dump_prof else {"conv_fwd"}
+        HF.PROFILE_LIB = not args.dump_prof     # default: the library's own hipEvent pair around each forward conv kernel
     prof_all, prof_steps = [], 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         sample = (not args.no_roofline) and bool(args.dump_prof or i % 4 == 0)
         HF.PROFILE = prof_all if sample else None
+        if HF.PROFILE_LIB:
+            _C.call("sod_conv_prof_enable", 1 if sample else 0)
         prof_steps += int(sample)
         last = train_step(model, optimizer, next(loader))
     if world > 1:
@@ -252,6 +256,22 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, HF.PROFILE = prof_all, None
+    if HF.PROFILE_LIB:
+        import ctypes
+        _C.call("sod_conv_prof_enable", 0)
+        nfw = sum(1 for p_ in prof if p_[0] == "conv_fwd")
+        ms, var, frac, mode = (ctypes.c_float * max(nfw, 1))(), (ctypes.c_int * max(nfw, 1))(), (ctypes.c_float * max(nfw, 1))(), (ctypes.c_int * max(nfw, 1))()
+        got = _C.load().sod_conv_prof_collect(ms, var, frac, mode, nfw)
+        assert got == nfw, f"library recorded {got} forward conv dispatches, host {nfw}"
+        j, filled = 0, []
+        for kind, flops, e0, e1, desc, variant in prof:
+            if kind == "conv_fwd":
+                assert mode[j] == 0
+                filled.append((kind, flops * frac[j], ms[j] * 1e-3, desc, var[j]))
+                j += 1
+        prof = filled
+    else:
+        prof = [(k, fl, e0.elapsed_time(e1) * 1e-3, d, v) for k, fl, e0, e1, d, v in prof]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -275,8 +295,7 @@ def main():
             out["model_tflops"] = round(imgs * TRAIN_FLOP_PER_IMAGE / dt / 1e12, 2)
         if prof:
             agg, by_var = {}, {}
-            for kind, flops, e0, e1, _desc, variant in prof:
-                sec_ = e0.elapsed_time(e1) * 1e-3
+            for kind, flops, sec_, _desc, variant in prof:
                 a = agg.setdefault(kind, [0.0, 0.0, 0])
                 a[0] += flops; a[1] += sec_; a[2] += 1
                 if kind == "conv_fwd":
@@ -302,9 +321,9 @@ def main():
                                                 "overlapped": k != "conv_fwd" and HF.WGRAD_SIDE_STREAM} for k, v in agg.items()}}
         if prof and args.dump_prof:
             per = {}
-            for kind, flops, e0, e1, desc, _variant in prof:
+            for kind, flops, sec_, desc, _variant in prof:
                 a = per.setdefault((kind, desc), [0.0, 0.0, 0])
-                a[0] += flops; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+                a[0] += flops; a[1] += sec_; a[2] += 1
             for (kind, desc), (fl, sec, cnt) in sorted(per.items(), key=lambda kv: -kv[1][1])[:args.dump_prof]:
                 print(f"# {kind:10s} NHWCKRs={desc} calls/step {cnt // prof_steps:3d} ms/step {sec / prof_steps * 1e3:7.3f} TF/s {fl / sec / 1e12:7.1f}", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline and args.arch == "fcos":

@@ -84,6 +84,12 @@ int sod_conv_set_tile256(int mode);
 /* Which kernel the last sod_conv2d_fwd / _dgrad call of this thread dispatched to (profiling aid): 256 = the 256x256x64 kernel
  * (possibly followed by a short 128x128 tail launch), otherwise BQ*100000 + BP*100 + BK (+1 for the generic-channel path). */
 int sod_conv_last_variant(void);
+/* In-library timing of the conv launches of the calling thread: while enabled, every sod_conv2d_fwd / _dgrad dispatch records one
+ * hipEvent pair on the launch stream right around its main kernel.  sod_conv_prof_collect synchronises, writes duration (ms),
+ * kernel variant (as above), the main kernel's share of the dispatch's output pixels (1 unless a 128x128 tail launch followed) and
+ * mode (0 fwd / 1 dgrad) of up to max dispatches in call order, clears the list and returns the count (capacity 8192). */
+int sod_conv_prof_enable(int on);
+int sod_conv_prof_collect(float* ms, int* variant, float* frac, int* mode, int max);
 
 /* ---------------------------------------------------------------------------------------------------------
  * GroupNorm (+ fused ReLU), NHWC bf16 — nn.GroupNorm(32, C) + nn.ReLU in FCOSHead (fcosv2.py:315-336).

@@ -41,6 +41,8 @@ _SIGS = {
     "sod_conv_set_workspace": [_P, _L],
     "sod_conv_set_tile256": [_I],
     "sod_conv_last_variant": [],
+    "sod_conv_prof_enable": [_I],
+    "sod_conv_prof_collect": [_P, _P, _P, _P, _I],
     "sod_weight_prep_batched": [_P, _P, _P, _I, _L, _P, _P, _P],
     "sod_weight_prep": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sod_scale_rows": [_P, _P, _I, _L, _P],

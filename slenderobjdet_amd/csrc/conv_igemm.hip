@@ -23,6 +23,31 @@ namespace {
 
 thread_local int g_last_variant = 0;   // kernel variant chosen by the last forward / data-gradient dispatch (sod_conv_last_variant)
 
+// Optional in-library timing of the forward / data-gradient launches of the calling thread (sod_conv_prof_enable / _collect): one
+// hipEvent pair per top-level dispatch, recorded on the launch stream right around the MAIN kernel (for a split dispatch the 256x256
+// launch; `frac` is its share of the output pixels), so that the durations are comparable with rocprofv3's per-kernel figures.
+struct ConvProf {
+  hipEvent_t* ev = nullptr;
+  int* variant = nullptr;
+  int* mode = nullptr;
+  float* frac = nullptr;
+  int cap = 0, n = 0, on = 0, depth = 0;
+};
+thread_local ConvProf g_prof;
+inline int prof_begin(hipStream_t st) {
+  ConvProf& p = g_prof;
+  if (!p.on || p.depth || p.n >= p.cap) return -1;
+  (void)hipEventRecord(p.ev[2 * p.n], st);
+  return p.n;
+}
+inline void prof_end(int i, hipStream_t st, int variant, float frac, int mode) {
+  if (i < 0) return;
+  ConvProf& p = g_prof;
+  (void)hipEventRecord(p.ev[2 * i + 1], st);
+  p.variant[i] = variant; p.frac[i] = frac; p.mode[i] = mode;
+  p.n = i + 1;
+}
+
 template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK, int NSTAGE>
 __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int NW = WQ * WP;                  // waves per workgroup (4 or 8)
@@ -783,7 +808,9 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
+  const int pi = prof_begin(st);
   SOD_LAUNCH(kern, dim3(a.nq_tiles * a.np_tiles), dim3(64 * WQ * WP), lds, st, a);
+  prof_end(pi, st, g_last_variant, 1.f, MODE);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -814,7 +841,13 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     long long pt256 = 0;
     for (int l = 0; l < a.nlev; ++l) pt256 += (a.lev[l].P + 255) / 256;
     const long long b256 = pt256 * nq;
-    if (c256 == 2) { g_last_variant = 256; return launch_conv256(a, MODE, OUT_F32, 0, st); }
+    if (c256 == 2) {
+      g_last_variant = 256;
+      const int pi = prof_begin(st);
+      const int rc = launch_conv256(a, MODE, OUT_F32, 0, st);
+      prof_end(pi, st, 256, 1.f, MODE);
+      return rc;
+    }
     static const int min_rounds = getenv("SOD_CONV256_MIN_ROUNDS") ? atoi(getenv("SOD_CONV256_MIN_ROUNDS")) : 1;
     static const int min_k = getenv("SOD_CONV256_MIN_K") ? atoi(getenv("SOD_CONV256_MIN_K")) : 1024;
     if (a.Nout >= 256 && (a.Nout & 255) == 0 && a.Kred >= min_k && b256 >= (long long)min_rounds * cus) {
@@ -825,9 +858,19 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
       // a remainder below half a round is computed by the 128x128 kernel (two workgroups per CU, 4x smaller tiles) instead
       // (P3 output conv, 4.1 rounds: 1035 -> 1075 TFLOP/s).
       const long long full = b256 / cus * cus, rem = b256 - full;
-      if (rem == 0 || rem * 2 >= (long long)cus || (full / nq) * nq != full) { g_last_variant = 256; return launch_conv256(a, MODE, OUT_F32, 0, st); }
+      if (rem == 0 || rem * 2 >= (long long)cus || (full / nq) * nq != full) {
+        g_last_variant = 256;
+        const int pi = prof_begin(st);
+        const int rc = launch_conv256(a, MODE, OUT_F32, 0, st);
+        prof_end(pi, st, 256, 1.f, MODE);
+        return rc;
+      }
       int main_pt = (int)(full / nq);
+      long long ptot = 0;
+      for (int l = 0; l < a.nlev; ++l) ptot += a.lev[l].P;
+      const int pi = prof_begin(st);
       int rc = launch_conv256(a, MODE, OUT_F32, main_pt, st);
+      prof_end(pi, st, 256, (float)((double)main_pt * 256.0 / (double)ptot), MODE);     // main tiles are full 256-pixel tiles
       if (rc) return rc;
       ConvArgs tail = a;
       for (int l = 0; l < tail.nlev; ++l) {
@@ -835,7 +878,9 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
         if (main_pt >= tl) { tail.lev[l].pstart = tail.lev[l].P; main_pt -= tl; }
         else { tail.lev[l].pstart = main_pt * 256; main_pt = 0; }
       }
+      ++g_prof.depth;            // the tail launch belongs to this dispatch: no event pair of its own
       rc = dispatch_conv<MODE, OUT_F32>(tail, st);
+      --g_prof.depth;
       g_last_variant = 256;      // whole rounds on the 256 kernel (+ a short 128x128 tail launch)
       return rc;
     }
@@ -1098,6 +1143,37 @@ static float* g_wgrad_ws[16] = {nullptr};
 static long long g_wgrad_ws_bytes[16] = {0};
 
 extern "C" int sod_conv_last_variant(void) { return g_last_variant; }
+
+extern "C" int sod_conv_prof_enable(int on) {
+  ConvProf& p = g_prof;
+  if (on && !p.ev) {
+    constexpr int CAP = 8192;
+    p.ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * CAP);
+    p.variant = (int*)malloc(sizeof(int) * CAP);
+    p.mode = (int*)malloc(sizeof(int) * CAP);
+    p.frac = (float*)malloc(sizeof(float) * CAP);
+    if (!p.ev || !p.variant || !p.mode || !p.frac) return SOD_EARG;
+    for (int i = 0; i < 2 * CAP; ++i)
+      if (hipEventCreate(&p.ev[i]) != hipSuccess) return SOD_EARG;
+    p.cap = CAP;
+  }
+  p.on = on ? 1 : 0;
+  return SOD_OK;
+}
+
+extern "C" int sod_conv_prof_collect(float* ms, int* variant, float* frac, int* mode, int max) {
+  ConvProf& p = g_prof;
+  const int n = p.n < max ? p.n : max;
+  if (n > 0 && (!ms || !variant || !frac || !mode)) return SOD_EARG;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(p.ev[2 * i + 1]) != hipSuccess) return SOD_EARG;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]) != hipSuccess) return SOD_EARG;
+    ms[i] = t; variant[i] = p.variant[i]; frac[i] = p.frac[i]; mode[i] = p.mode[i];
+  }
+  p.n = 0;
+  return n;
+}
 
 extern "C" int sod_conv_set_tile256(int mode) {
   if (mode < -1 || mode > 2) return SOD_EARG;

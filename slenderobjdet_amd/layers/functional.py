@@ -19,9 +19,14 @@ PROFILE = None
 PROFILE_KINDS = None      # optional set of kinds to time (None = all); bench.py times only the forward conv launches by default
 
 
+PROFILE_LIB = False       # forward convs are timed by the library's own hipEvent pairs (sod_conv_prof_*), not by torch events
+
+
 def _prof_begin(stream=None, kind=None):
     if PROFILE is None or (PROFILE_KINDS is not None and kind not in PROFILE_KINDS):
         return None
+    if PROFILE_LIB and kind == "conv_fwd":
+        return "lib"
     e = torch.cuda.Event(enable_timing=True)
     e.record(stream)
     return e
@@ -29,6 +34,9 @@ def _prof_begin(stream=None, kind=None):
 
 def _prof_end(kind, flops, e0, desc=None, stream=None):
     if e0 is None:
+        return
+    if e0 == "lib":       # duration, variant and FLOP share are filled in from sod_conv_prof_collect (same call order)
+        PROFILE.append((kind, flops, None, None, desc, None))
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record(stream)
