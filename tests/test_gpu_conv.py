@@ -316,3 +316,28 @@ def test_conv256_split_rounds_and_levels(cuda):
         _C.call("sod_conv_set_tile256", -1)
     for y, ref, (h, w) in zip(ys, refs, hw):
         _close(y, ref, 2 ** -7, f"split conv256 level {h}x{w}")
+
+
+def test_conv_prof_event_pairs(cuda):
+    """sod_conv_prof_enable / _collect: one hipEvent pair per forward dispatch of this thread, in call order, with the kernel variant."""
+    import ctypes
+
+    from slenderobjdet_amd import _C
+    from slenderobjdet_amd.layers import functional as HF
+
+    x = _rand((2, 24, 32, 64), 41).to(cuda).bfloat16()
+    w1 = _rand((128, 3, 3, 64), 42, 0.05).to(cuda).bfloat16()
+    w2 = _rand((8, 3, 3, 64), 43, 0.05).to(cuda).bfloat16()
+    _C.call("sod_conv_prof_enable", 1)
+    try:
+        HF.conv2d_fwd(x, w1, None, stride=1, pad=1)
+        HF.conv2d_fwd(x, w2, None, stride=1, pad=1, out_f32=True)
+    finally:
+        _C.call("sod_conv_prof_enable", 0)
+    HF.conv2d_fwd(x, w1, None, stride=1, pad=1)          # not recorded
+    ms, var, frac, mode = (ctypes.c_float * 8)(), (ctypes.c_int * 8)(), (ctypes.c_float * 8)(), (ctypes.c_int * 8)()
+    n = _C.load().sod_conv_prof_collect(ms, var, frac, mode, 8)
+    assert n == 2
+    assert all(0.0 < ms[i] < 50.0 for i in range(2)) and mode[0] == 0 and mode[1] == 0 and frac[0] == 1.0
+    assert var[0] // 100000 == 128 and var[1] // 100000 == 16          # BQ of the two tile variants
+    assert _C.load().sod_conv_prof_collect(ms, var, frac, mode, 8) == 0   # cleared
