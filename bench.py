@@ -245,7 +245,7 @@ def main():
     prof_all, prof_steps = [], 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        sample = (not args.no_roofline) and bool(args.dump_prof or i % 4 == 0)
+        sample = (not args.no_roofline) and bool(args.dump_prof or (i % 4 == 0 and prof_steps < 48))   # the library keeps 8192 event pairs
         HF.PROFILE = prof_all if sample else None
         if HF.PROFILE_LIB:
             _C.call("sod_conv_prof_enable", 1 if sample else 0)
@@ -262,7 +262,9 @@ def main():
         nfw = sum(1 for p_ in prof if p_[0] == "conv_fwd")
         ms, var, frac, mode = (ctypes.c_float * max(nfw, 1))(), (ctypes.c_int * max(nfw, 1))(), (ctypes.c_float * max(nfw, 1))(), (ctypes.c_int * max(nfw, 1))()
         got = _C.load().sod_conv_prof_collect(ms, var, frac, mode, nfw)
-        assert got == nfw, f"library recorded {got} forward conv dispatches, host {nfw}"
+        if got != nfw:      # never fail the measurement over the instrumentation: drop the roofline instead
+            print(f"# roofline skipped: library recorded {got} forward conv dispatches, host {nfw}", file=sys.stderr)
+            prof, got = [p_ for p_ in prof if p_[0] != "conv_fwd"], 0
         j, filled = 0, []
         for kind, flops, e0, e1, desc, variant in prof:
             if kind == "conv_fwd":
@@ -293,7 +295,7 @@ def main():
         }
         if args.arch == "fcos" and args.depth == 50:
             out["model_tflops"] = round(imgs * TRAIN_FLOP_PER_IMAGE / dt / 1e12, 2)
-        if prof:
+        if prof and any(p_[0] == "conv_fwd" for p_ in prof):
             agg, by_var = {}, {}
             for kind, flops, sec_, _desc, variant in prof:
                 a = agg.setdefault(kind, [0.0, 0.0, 0])
