@@ -65,13 +65,24 @@ def bbox_targets(cand, gt_boxes, gt_labels, num_classes, pos_thr=0.5, neg_thr=0.
     return boxes, labels
 
 
-def pts_to_bbox(pts):
+def pts_to_bbox(pts, method="minmax", moment_transfer=None, moment_mul=0.01):
+    """pointset_head.py:306-346: "minmax", "partial_minmax" (first four points) and "moment" (mean +- std * exp(moment_transfer), the
+    gradient of moment_transfer scaled by moment_mul; torch.std = unbiased)."""
     x, y = pts[:, 0::2], pts[:, 1::2]
-    return torch.stack((x.min(1)[0], y.min(1)[0], x.max(1)[0], y.max(1)[0]), 1)
+    if method == "partial_minmax":
+        x, y = x[:, :4], y[:, :4]
+    if method in ("minmax", "partial_minmax"):
+        return torch.stack((x.min(1)[0], y.min(1)[0], x.max(1)[0], y.max(1)[0]), 1)
+    if method != "moment":
+        raise ValueError(method)
+    mt = moment_transfer * moment_mul + moment_transfer.detach() * (1 - moment_mul)
+    mx, my = x.mean(1), y.mean(1)
+    hw_, hh = x.std(1) * mt[0].exp(), y.std(1) * mt[1].exp()
+    return torch.stack((mx - hw_, my - hh, mx + hw_, my + hh), 1)
 
 
 def losses(centers, pts_strides, cls_outs, pts_init, pts_refine, gt_boxes, gt_classes, num_classes, num_points=9, scale=4, alpha=0.25,
-           gamma=2.0, w_cls=1.0, w_init=0.5, w_refine=1.0):
+           gamma=2.0, w_cls=1.0, w_init=0.5, w_refine=1.0, method="minmax", moment_transfer=None, moment_mul=0.01):
     """pointset_head.py:158-325.  cls_outs (N,X,K), pts_* (N,X,2P); centers (X,2), pts_strides (X,)."""
     pred_cls, pred_init, pred_refine, tgt_cls, tgt_init, tgt_refine = [], [], [], [], [], []
     npi = npr = 0
@@ -80,11 +91,11 @@ def losses(centers, pts_strides, cls_outs, pts_init, pts_refine, gt_boxes, gt_cl
     st = pts_strides.reshape(-1, 1)
     for i in range(cls_outs.shape[0]):
         ib_t, il_t = point_targets(centers, pts_strides, gt_boxes[i], gt_classes[i], num_classes, scale)
-        init_box = pts_to_bbox(pts_init[i] * st + rep)
+        init_box = pts_to_bbox(pts_init[i] * st + rep, method, moment_transfer, moment_mul)
         fg = (il_t >= 0) & (il_t != num_classes)
         pred_init.append(init_box[fg] / norm[fg]); tgt_init.append(ib_t[fg] / norm[fg]); npi += int(fg.sum())
         rb_t, rl_t = bbox_targets(init_box.detach(), gt_boxes[i], gt_classes[i], num_classes)
-        refine_box = pts_to_bbox(pts_refine[i] * st + rep)
+        refine_box = pts_to_bbox(pts_refine[i] * st + rep, method, moment_transfer, moment_mul)
         fg = (rl_t >= 0) & (rl_t != num_classes)
         pred_refine.append(refine_box[fg] / norm[fg]); tgt_refine.append(rb_t[fg] / norm[fg]); npr += int(fg.sum())
         t = torch.zeros_like(cls_outs[i])
@@ -124,7 +135,7 @@ class OraclePointSetHead:
         self.p, self.c, self.emu = params, cfg, emulate_bf16
 
     @classmethod
-    def from_reference_arrays(cls, arrays, feat_adaption, res_refine):
+    def from_reference_arrays(cls, arrays, feat_adaption, res_refine, method="minmax"):
         """``param:<reference state_dict name>`` arrays of the golden fixture -> product-style names."""
         ref = {k[len("param:"):]: torch.tensor(v.astype("float32")).requires_grad_(True) for k, v in arrays.items() if k.startswith("param:")}
         p = {}
@@ -137,10 +148,15 @@ class OraclePointSetHead:
                "cls_conv": "cls_conv.conv" if feat_adaption == "Empty" else "cls_conv",
                "loc_refine_conv": "loc_refine_conv.conv" if feat_adaption == "Empty" else "loc_refine_conv"}
         for k, v in ref.items():
+            if "." not in k:          # moment_transfer (a bare parameter of the head)
+                continue
             base, leaf = k.rsplit(".", 1)
             if base in ren:
                 p[f"{ren[base]}.{leaf}"] = v
-        cfg = dict(fa=feat_adaption, res=bool(res_refine), npts=9, K=80, gmul=0.1, strides=[8, 16, 32, 64, 128], scale=4, w=(1.0, 0.5, 1.0), alpha=0.25, gamma=2.0)
+        if "moment_transfer" in ref:
+            p["moment_transfer"] = ref["moment_transfer"]
+        cfg = dict(fa=feat_adaption, res=bool(res_refine), npts=9, K=80, gmul=0.1, strides=[8, 16, 32, 64, 128], scale=4, w=(1.0, 0.5, 1.0), alpha=0.25, gamma=2.0,
+                   method=method, moment_mul=0.01)
         return cls(p, cfg)
 
     @classmethod
@@ -157,9 +173,12 @@ class OraclePointSetHead:
             elif isinstance(m, HipGroupNorm):
                 p[name + ".weight"] = m.weight.detach().float().cpu().clone().requires_grad_(True)
                 p[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(True)
+        if getattr(head, "moment_transfer", None) is not None:
+            p["moment_transfer"] = head.moment_transfer.detach().float().cpu().clone().requires_grad_(True)
         cfg = dict(fa=head.feat_adaption, res=head.res_refine, npts=head.num_points, K=head.num_classes, gmul=head.gradient_mul,
                    strides=list(head.fpn_strides), scale=head.point_base_scale, w=(head.loss_cls_weight, head.loss_init_weight, head.loss_refine_weight),
-                   alpha=head.focal_loss_alpha, gamma=head.focal_loss_gamma)
+                   alpha=head.focal_loss_alpha, gamma=head.focal_loss_gamma, method=getattr(head, "transform_method", "minmax"),
+                   moment_mul=getattr(head, "moment_mul", 0.01))
         return cls(p, cfg, emulate_bf16)
 
     def _r(self, x):
@@ -218,4 +237,5 @@ class OraclePointSetHead:
         c = self.c
         cls, pi, pr, hw = self.forward(feats)
         centers, st = center_grid(hw, c["strides"])
-        return losses(centers, st, cls, pi, pr, gt_boxes, gt_classes, c["K"], c["npts"], c["scale"], c["alpha"], c["gamma"], *c["w"])
+        return losses(centers, st, cls, pi, pr, gt_boxes, gt_classes, c["K"], c["npts"], c["scale"], c["alpha"], c["gamma"], *c["w"],
+                      method=c.get("method", "minmax"), moment_transfer=self.p.get("moment_transfer"), moment_mul=c.get("moment_mul", 0.01))

@@ -216,12 +216,16 @@ def pointset_head_golden(g):
     C = 32
     hw = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
     strides = [8, 16, 32, 64, 128]
-    for tag, fa, res in (("empty", "Empty", True), ("sup", "Supervised Offset", True), ("unsup", "Unsupervised Offset", False)):
+    cases = [("empty", "Empty", True, "minmax", g), ("sup", "Supervised Offset", True, "minmax", g), ("unsup", "Unsupervised Offset", False, "minmax", g)]
+    # the other two TRANSFORM_METHODs (pointset_head.py:322-343), on their own generators so that the fixtures above keep their bytes
+    cases += [("partial", "Empty", True, "partial_minmax", torch.Generator().manual_seed(2101)),
+              ("moment", "Empty", False, "moment", torch.Generator().manual_seed(2102))]
+    for tag, fa, res, method, g in cases:
         head_params = SimpleNamespace(
             IN_FEATURES=["p3", "p4", "p5", "p6", "p7"], FPN_STRIDES=strides, NUM_CLASSES=80, FEAT_CHANNELS=C, STACK_CONVS=3, NORM="GN",
             FEAT_ADAPTION=fa, RES_REFINE=res, LOC_FEAT_CHANNELS=C, GRADIENT_MUL=0.1, PRIOR_PROB=0.01, FOCAL_LOSS_GAMMA=2.0,
             FOCAL_LOSS_ALPHA=0.25, LOSS_CLS_WEIGHT=1.0, LOSS_LOC_INIT_WEIGHT=0.5, LOSS_LOC_REFINE_WEIGHT=1.0, SCORE_THRESH_TEST=0.05,
-            TOPK_CANDIDATES_TEST=1000, NMS_THRESH_TEST=0.5, NUM_POINTS=9, POINT_BASE_SCALE=4, TRANSFORM_METHOD="minmax", MOMENT_MUL=0.01)
+            TOPK_CANDIDATES_TEST=1000, NMS_THRESH_TEST=0.5, NUM_POINTS=9, POINT_BASE_SCALE=4, TRANSFORM_METHOD=method, MOMENT_MUL=0.01)
         cfg = SimpleNamespace(MODEL=SimpleNamespace(META_ARCH=head_params), TEST=SimpleNamespace(DETECTIONS_PER_IMAGE=100))
         torch.manual_seed(7)
         head = psh.PointSetHead(cfg, [SimpleNamespace(channels=C, stride=s) for s in strides])
@@ -230,6 +234,8 @@ def pointset_head_golden(g):
                 if n.endswith("weight") and p.dim() == 4 and "subnet" not in n:
                     p.mul_(6.0)
                 p.copy_(p.half().float())
+            if method == "moment":      # a non-trivial, fp16-representable moment_transfer
+                head.moment_transfer.copy_(torch.tensor([0.375, -0.25]))
         head.train()
         feats = [(torch.randn(2, C, h, w, generator=g) * 1.5).half().float() for h, w in hw]
         gtb = [random_boxes(g, 5, 128, 160), random_boxes(g, 8, 128, 160)]
@@ -250,7 +256,7 @@ def pointset_head_golden(g):
         for (n, p), gr in zip(params.items(), grads):
             out["param:" + n] = p.detach().numpy().astype(np.float16)
             out["gradnorm:" + n] = np.array(0.0 if gr is None else float(gr.norm()))
-        for n in ("cls_out.weight", "loc_refine_out.weight", "loc_init_out.weight"):
+        for n in ("cls_out.weight", "loc_refine_out.weight", "loc_init_out.weight") + (("moment_transfer",) if method == "moment" else ()):
             out["grad:" + n] = grads[list(params).index(n)].numpy()
         np.savez_compressed(os.path.join(OUT, f"pointset_head_{tag}.npz"), **out)
         meta[f"pointset_head_{tag}.npz"] = ("reference: meta/heads/pointset_head.py:19-470 + meta_head.py:21-104 + utils.py (reference Python"
