@@ -326,6 +326,15 @@ int sod_points2bbox_fwd(const float* pts, const float* add, int ld, int N, int H
                         int num_points, float* boxes, long long box_img_stride, unsigned* argidx, long long arg_img_stride, void* stream);
 int sod_points2bbox_bwd(const float* dboxes, long long box_img_stride, const unsigned* argidx, long long arg_img_stride, int ld,
                         int N, int H, int W, float point_stride, int num_points, float* dpts_f32, void* dpts_bf16, void* stream);
+/* TRANSFORM_METHOD "moment" (meta/heads/pointset_head.py:328-343): box = mean -+ std * exp(moment_transfer[0|1]) over the num_points
+ * points (torch.std: unbiased); "partial_minmax" (:322-327) is sod_points2bbox_* with num_points = 4 and the full row pitch ld.
+ * bwd recomputes the moments from pts (+ add), writes d(pts) rows of ld floats and ACCUMULATES moment_mul * d(moment_transfer) into
+ * dmoment2 (the reference scales that gradient with grad_mul, :333-334). */
+int sod_points2bbox_moment_fwd(const float* pts, const float* add, int ld, int N, int H, int W, float grid_stride, float point_stride,
+                               int num_points, const float* moment_transfer, float* boxes, long long box_img_stride, void* stream);
+int sod_points2bbox_moment_bwd(const float* dboxes, long long box_img_stride, const float* pts, const float* add, int ld, int N, int H,
+                               int W, float grid_stride, float point_stride, int num_points, const float* moment_transfer,
+                               float moment_mul, float* dpts_f32, void* dpts_bf16, float* dmoment2, void* stream);
 int sod_reppoints_point_match(const float* centers, const float* strides, int X, const int* lvl_start, int num_levels,
                               const float* gt_boxes, const int* box_offsets, int N, int max_gt, int mode, float scale,
                               int* objectness, float* box_labels, void* stream);

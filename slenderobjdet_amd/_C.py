@@ -96,6 +96,8 @@ _SIGS = {
     "sod_reppoints_dcn_offset": [_P, _P, _L, _I, _I, _F, _I, _I, _P],
     "sod_points2bbox_fwd": [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _L, _P, _L, _P],
     "sod_points2bbox_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _F, _I, _P, _P, _P],
+    "sod_points2bbox_moment_fwd": [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _L, _P],
+    "sod_points2bbox_moment_bwd": [_P, _L, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _F, _P, _P, _P, _P],
     "sod_reppoints_point_match": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _F, _P, _P, _P],
     "sod_reppoints_labels": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "sod_reppoints_box_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P],

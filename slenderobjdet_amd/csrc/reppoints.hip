@@ -102,6 +102,81 @@ __global__ __launch_bounds__(256) void p2b_bwd_kernel(const P2BArgs a, const flo
   }
 }
 
+// "moment" transform (meta/heads/pointset_head.py:328-343): box = mean -+ std * exp(moment_transfer), torch.std = unbiased.
+// The backward recomputes the moments from the points (nothing but the boxes is stored by the forward).
+__device__ __forceinline__ void p2b_moments(const P2BArgs& a, long long i, float cx, float cy, float& mx, float& my, float& sx, float& sy) {
+  const float* r = a.pts + i * a.ld;
+  const float* q = a.add ? a.add + i * a.ld : nullptr;
+  float s1x = 0.f, s1y = 0.f;
+  for (int k = 0; k < a.npts; ++k) {
+    float vx = r[2 * k], vy = r[2 * k + 1];
+    if (q) { vx += q[2 * k]; vy += q[2 * k + 1]; }
+    s1x += vx * a.pt_stride + cx; s1y += vy * a.pt_stride + cy;
+  }
+  mx = s1x / (float)a.npts; my = s1y / (float)a.npts;
+  float s2x = 0.f, s2y = 0.f;
+  for (int k = 0; k < a.npts; ++k) {
+    float vx = r[2 * k], vy = r[2 * k + 1];
+    if (q) { vx += q[2 * k]; vy += q[2 * k + 1]; }
+    const float dx = vx * a.pt_stride + cx - mx, dy = vy * a.pt_stride + cy - my;
+    s2x += dx * dx; s2y += dy * dy;
+  }
+  sx = sqrtf(s2x / (float)(a.npts - 1)); sy = sqrtf(s2y / (float)(a.npts - 1));
+}
+
+__global__ __launch_bounds__(256) void p2b_moment_fwd_kernel(const P2BArgs a, const float* __restrict__ mt) {
+  const long long HW = (long long)a.H * a.W, total = HW * a.N;
+  const float ew = expf(mt[0]), eh = expf(mt[1]);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / HW, p = i - n * HW;
+    const int h = (int)(p / a.W), w = (int)(p - (long long)h * a.W);
+    float mx, my, sx, sy;
+    p2b_moments(a, i, (float)w * a.grid_stride, (float)h * a.grid_stride, mx, my, sx, sy);
+    const f32x4_t b = {mx - sx * ew, my - sy * eh, mx + sx * ew, my + sy * eh};
+    *reinterpret_cast<f32x4_t*>(a.boxes + n * a.box_img_stride + p * 4) = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void p2b_moment_bwd_kernel(const P2BArgs a, const float* __restrict__ dboxes, const float* __restrict__ mt,
+                                                             float moment_mul, float* __restrict__ dpts32, __bf16* __restrict__ dpts16,
+                                                             float* __restrict__ dmt) {
+  __shared__ float red[4];
+  const long long HW = (long long)a.H * a.W, total = HW * a.N;
+  const float ew = expf(mt[0]), eh = expf(mt[1]);
+  float gw = 0.f, gh = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long n = i / HW, p = i - n * HW;
+    const int h = (int)(p / a.W), w = (int)(p - (long long)h * a.W);
+    const float cx = (float)w * a.grid_stride, cy = (float)h * a.grid_stride;
+    float mx, my, sx, sy;
+    p2b_moments(a, i, cx, cy, mx, my, sx, sy);
+    const f32x4_t d = *reinterpret_cast<const f32x4_t*>(dboxes + n * a.box_img_stride + p * 4);
+    const float dmx = d[0] + d[2], dmy = d[1] + d[3], dhw = d[2] - d[0], dhh = d[3] - d[1];
+    gw += dhw * sx * ew; gh += dhh * sy * eh;
+    const float inv_n = 1.f / (float)a.npts;
+    const float kx = sx > 0.f ? dhw * ew / ((float)(a.npts - 1) * sx) : 0.f, ky = sy > 0.f ? dhh * eh / ((float)(a.npts - 1) * sy) : 0.f;
+    const float* r = a.pts + i * a.ld;
+    const float* q = a.add ? a.add + i * a.ld : nullptr;
+    for (int j = 0; j < a.ld; ++j) {
+      float v = 0.f;
+      if (j < 2 * a.npts) {
+        float pv = r[j];
+        if (q) pv += q[j];
+        if (j & 1) v = dmy * inv_n + ky * (pv * a.pt_stride + cy - my);
+        else       v = dmx * inv_n + kx * (pv * a.pt_stride + cx - mx);
+        v *= a.pt_stride;
+      }
+      if (dpts32) dpts32[i * a.ld + j] = v;
+      if (dpts16) dpts16[i * a.ld + j] = (__bf16)v;
+    }
+  }
+  if (dmt) {      // d(moment_transfer): grad_mul scales the gradient by moment_mul (pointset_head.py:333-334)
+    gw = block_sum_256(gw, red);
+    gh = block_sum_256(gh, red);
+    if (threadIdx.x == 0) { atomicAdd(dmt, gw * moment_mul); atomicAdd(dmt + 1, gh * moment_mul); }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ init-box matchers
 struct RpMatchArgs {
   const float* centers;   // (X, 2) x, y
@@ -405,6 +480,32 @@ extern "C" int sod_points2bbox_bwd(const float* dboxes, long long box_img_stride
   if (rc) return rc;
   a.arg = const_cast<unsigned*>(argidx);
   SOD_LAUNCH(p2b_bwd_kernel, dim3(rp_nblk((long long)N * H * W, 8192)), dim3(256), 0, (hipStream_t)stream, a, dboxes, dpts_f32, (__bf16*)dpts_bf16);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_points2bbox_moment_fwd(const float* pts, const float* add, int ld, int N, int H, int W, float grid_stride, float point_stride,
+                                          int num_points, const float* moment_transfer, float* boxes, long long box_img_stride, void* stream) {
+  if (!pts || !boxes || !moment_transfer || num_points < 2) return SOD_EARG;
+  P2BArgs a{};
+  int rc = p2b_fill(a, ld, N, H, W, grid_stride, point_stride, num_points, box_img_stride, 0);
+  if (rc) return rc;
+  a.pts = pts; a.add = add; a.boxes = boxes; a.arg = nullptr;
+  SOD_LAUNCH(p2b_moment_fwd_kernel, dim3(rp_nblk((long long)N * H * W, 8192)), dim3(256), 0, (hipStream_t)stream, a, moment_transfer);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_points2bbox_moment_bwd(const float* dboxes, long long box_img_stride, const float* pts, const float* add, int ld, int N, int H,
+                                          int W, float grid_stride, float point_stride, int num_points, const float* moment_transfer,
+                                          float moment_mul, float* dpts_f32, void* dpts_bf16, float* dmoment2, void* stream) {
+  if (!dboxes || !pts || !moment_transfer || (!dpts_f32 && !dpts_bf16) || num_points < 2) return SOD_EARG;
+  P2BArgs a{};
+  int rc = p2b_fill(a, ld, N, H, W, grid_stride, point_stride, num_points, box_img_stride, 0);
+  if (rc) return rc;
+  a.pts = pts; a.add = add;
+  SOD_LAUNCH(p2b_moment_bwd_kernel, dim3(rp_nblk((long long)N * H * W, 1024)), dim3(256), 0, (hipStream_t)stream, a, dboxes, moment_transfer,
+             moment_mul, dpts_f32, (__bf16*)dpts_bf16, dmoment2);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

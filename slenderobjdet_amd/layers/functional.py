@@ -696,6 +696,26 @@ def points2bbox_bwd(dboxes, box_img_stride, arg, arg_img_stride, shape, point_st
     return d32, d16
 
 
+def points2bbox_moment_fwd(pts, add, grid_stride, point_stride, num_points, moment_transfer, boxes, box_img_stride):
+    """TRANSFORM_METHOD "moment": one level, boxes = mean -+ std * exp(moment_transfer)."""
+    _chk(pts, torch.float32, "pts"); _chk(add, torch.float32, "add"); _chk(moment_transfer, torch.float32, "moment_transfer")
+    N, H, W, ld = pts.shape
+    call("sod_points2bbox_moment_fwd", ptr(pts), ptr(add), ld, N, H, W, float(grid_stride), float(point_stride), num_points, ptr(moment_transfer),
+         ptr(boxes), box_img_stride, stream_ptr())
+
+
+def points2bbox_moment_bwd(dboxes, box_img_stride, pts, add, grid_stride, point_stride, num_points, moment_transfer, moment_mul, dmoment,
+                           want_f32=True, want_bf16=False):
+    """-> d(pts) as fp32 and/or bf16 (N,H,W,ld); accumulates moment_mul * d(moment_transfer) into ``dmoment`` (2 floats)."""
+    _chk(pts, torch.float32, "pts"); _chk(add, torch.float32, "add"); _chk(dmoment, torch.float32, "dmoment")
+    N, H, W, ld = pts.shape
+    d32 = torch.empty(pts.shape, dtype=torch.float32, device=pts.device) if want_f32 else None
+    d16 = torch.empty(pts.shape, dtype=torch.bfloat16, device=pts.device) if want_bf16 else None
+    call("sod_points2bbox_moment_bwd", ptr(dboxes), box_img_stride, ptr(pts), ptr(add), ld, N, H, W, float(grid_stride), float(point_stride), num_points,
+         ptr(moment_transfer), float(moment_mul), ptr(d32), ptr(d16), ptr(dmoment), stream_ptr())
+    return d32, d16
+
+
 RP_MATCH_MODES = {"points": 0, "nearest_points": 1, "inside": 2}
 
 

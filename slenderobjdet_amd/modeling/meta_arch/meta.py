@@ -50,8 +50,11 @@ class PointSetHead(nn.Module):
         self.score_threshold, self.topk_candidates, self.nms_threshold = h.SCORE_THRESH_TEST, h.TOPK_CANDIDATES_TEST, h.NMS_THRESH_TEST
         self.max_detections_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
         self.num_points, self.point_base_scale = h.NUM_POINTS, h.POINT_BASE_SCALE
-        if h.TRANSFORM_METHOD != "minmax":
-            raise NotImplementedError(f"META_ARCH.TRANSFORM_METHOD {h.TRANSFORM_METHOD!r}: only 'minmax' (the default) is built")
+        self.transform_method, self.moment_mul = h.TRANSFORM_METHOD, float(h.MOMENT_MUL)     # pointset_head.py:26-31
+        if self.transform_method not in ("minmax", "partial_minmax", "moment"):
+            raise ValueError(f"META_ARCH.TRANSFORM_METHOD {self.transform_method!r}")
+        self.box_points = 4 if self.transform_method == "partial_minmax" else self.num_points
+        self.moment_transfer = nn.Parameter(torch.zeros(2)) if self.transform_method == "moment" else None
         if self.feat_adaption not in FEAT_ADAPTION_METHODS:
             raise AssertionError(f"{self.feat_adaption} {type(self.feat_adaption)}")
         if self.norm not in ("GN", ""):

@@ -62,13 +62,16 @@ class _RepPointsLossFn(torch.autograd.Function):
         out3 = HF.reppoints_finalize(focal_sum, init_sums, refine_sums, model.loss_normalizer, model.loss_normalizer_momentum,
                                      model.normalizer_images(N), model.loss_init_weight)
         ctx.model, ctx.geo, ctx.nl = model, geo, nl
+        ctx.moment = getattr(model, "transform_method", "minmax") == "moment"
         ctx.save_for_backward(logits_buf, init_boxes, init_arg, refine_boxes, refine_arg, obj, init_lab, cls, refine_lab, strides,
-                              init_sums, model.loss_normalizer.clone(), *oi, *cf, *rf)
+                              init_sums, model.loss_normalizer.clone(), *oi, *cf, *rf, *(rdelta if ctx.moment else ()))
         model.last_targets = (obj, init_lab, cls, refine_lab)
         arena = _arena_of(model.logits)
         if arena is not None:
             for p in (model.logits.weight, model.logits.bias, model.offsets_refine.weight, model.offsets_refine.bias):
                 arena.note_use(p)
+            if ctx.moment:
+                arena.note_use(model.moment_transfer)
         return out3
 
     @staticmethod
@@ -77,9 +80,10 @@ class _RepPointsLossFn(torch.autograd.Function):
         model, (hw, offs, X), nl = ctx.model, ctx.geo, ctx.nl
         logits_buf, init_boxes, init_arg, refine_boxes, refine_arg, obj, init_lab, cls, refine_lab, strides, init_sums, norm = ctx.saved_tensors[:12]
         rest = ctx.saved_tensors[12:]
-        oi, cf, rf = rest[:nl], rest[nl:2 * nl], rest[2 * nl:]
+        oi, cf, rf = rest[:nl], rest[nl:2 * nl], rest[2 * nl:3 * nl]
+        rdelta = rest[3 * nl:]
         g3 = g3.contiguous().float()
-        N, K, P, ld = logits_buf.shape[0], model.num_classes, model.num_points, model.pts_ld
+        N, K, P, ld = logits_buf.shape[0], model.num_classes, getattr(model, "box_points", model.num_points), model.pts_ld
         arena = _arena_of(model.logits)
         # classification branch
         dlogits = HF.focal_loss_bwd(logits_buf.view(N * X, K), cls.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma,
@@ -98,10 +102,22 @@ class _RepPointsLossFn(torch.autograd.Function):
         for l, (h, w) in enumerate(hw):
             o, ps = offs[l], model.point_scales[l]
             shape = (N, h, w, ld)
+            if ctx.moment:
+                mt, dmt = model.moment_transfer.detach(), arena.grad_view(model.moment_transfer)
+                add = oi[l] if model.res_refine else None
+                _, d16 = HF.points2bbox_moment_bwd(d_refine.view(-1)[o * 4:], X * 4, rdelta[l], add, model.strides[l], ps, model.num_points, mt,
+                                                   model.moment_mul, dmt, want_f32=False, want_bf16=True)
+                d32, _ = HF.points2bbox_moment_bwd(d_init.view(-1)[o * 4:], X * 4, oi[l], None, model.strides[l], ps, model.num_points, mt,
+                                                   model.moment_mul, dmt)
+                drd.append(d16)
+                doi.append(d32)
+                continue
             _, d16 = HF.points2bbox_bwd(d_refine.view(-1)[o * 4:], X * 4, refine_arg.view(-1)[o:], X, shape, ps, P, want_f32=False, want_bf16=True)
             d32, _ = HF.points2bbox_bwd(d_init.view(-1)[o * 4:], X * 4, init_arg.view(-1)[o:], X, shape, ps, P)
             drd.append(d16)
             doi.append(d32)
+        if ctx.moment:
+            arena.mark_ready(model.moment_transfer)
         ref = model.offsets_refine
         HF.conv2d_wgrad_ml(drd, list(rf), arena.grad_view(ref.weight), 1, 1, 1, 0, 1)
         arena.mark_ready(ref.weight)
@@ -248,11 +264,19 @@ class RepPointsDetector(nn.Module):
         refine_boxes = torch.empty((N, X, 4), dtype=torch.float32, device=dev)
         init_arg = torch.empty((N, X), dtype=torch.int32, device=dev)
         refine_arg = torch.empty((N, X), dtype=torch.int32, device=dev)
+        method = getattr(self, "transform_method", "minmax")
+        bp = getattr(self, "box_points", self.num_points)         # "partial_minmax": the first four points only (pointset_head.py:322-327)
         for l in range(len(hw)):
             o, s, ps = offs[l], self.strides[l], self.point_scales[l]
-            HF.points2bbox_fwd(oi[l], None, s, ps, self.num_points, init_boxes.view(-1)[o * 4:], X * 4, init_arg.view(-1)[o:], X)
+            if method == "moment":                                # mean -+ std * exp(moment_transfer) (pointset_head.py:328-343)
+                mt = self.moment_transfer.detach()
+                HF.points2bbox_moment_fwd(oi[l], None, s, ps, self.num_points, mt, init_boxes.view(-1)[o * 4:], X * 4)
+                HF.points2bbox_moment_fwd(rdelta[l], oi[l] if self.res_refine else None, s, ps, self.num_points, mt,
+                                          refine_boxes.view(-1)[o * 4:], X * 4)
+                continue
+            HF.points2bbox_fwd(oi[l], None, s, ps, bp, init_boxes.view(-1)[o * 4:], X * 4, init_arg.view(-1)[o:], X)
             # offsets_refine(...) + offsets_init.detach()  (rpd.py:639-642)
-            HF.points2bbox_fwd(rdelta[l], oi[l] if self.res_refine else None, s, ps, self.num_points, refine_boxes.view(-1)[o * 4:], X * 4,
+            HF.points2bbox_fwd(rdelta[l], oi[l] if self.res_refine else None, s, ps, bp, refine_boxes.view(-1)[o * 4:], X * 4,
                                refine_arg.view(-1)[o:], X)
         return logits_buf, rdelta, init_boxes, init_arg, refine_boxes, refine_arg, (hw, offs, X)
 
