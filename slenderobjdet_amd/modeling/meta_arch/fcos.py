@@ -271,8 +271,9 @@ class FCOSV2(nn.Module):
             # targets first: they depend only on the ground truth, so the normaliser all-reduce overlaps the backbone
             labels, reg_t, ctr_t, stats = self.get_ground_truth(level_hw, gt_instances)
             world = comm.get_world_size()
-            if world > 1:
-                dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+            stats_work = None
+            if world > 1:       # asynchronous: the compute stream only waits for it in front of the loss node, a whole forward pass later
+                stats_work = dist.all_reduce(stats, op=dist.ReduceOp.SUM, async_op=True)
 
         features = self.backbone(images.tensor)
         features = [features[f] for f in self.in_features]
@@ -280,6 +281,8 @@ class FCOSV2(nn.Module):
         cls_t, box_t = self.head.run_towers(features)
 
         if self.training:
+            if stats_work is not None:
+                stats_work.wait()
             out3 = _FcosHeadLossFn.apply(self, self.head.scales, labels, reg_t, ctr_t, stats, 1.0 / float(world), *cls_t, *box_t)
             return dict(cls_loss=out3[0], reg_loss=out3[1], centerness_loss=out3[2])
         results = self.inference(level_hw, cls_t, box_t, images.image_sizes)
