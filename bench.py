@@ -131,34 +131,85 @@ def variant_kernel_name(code, mode=0):
     return f"void conv_igemm_kernel<{mode}, {'true' if generic else 'false'}, {wq}, {wp}, {fq}, {fp}, false, {bk}, "
 
 
-def pmc_traffic(kind, kernel_prefix=None):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json: separate
-    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md). None if absent."""
+KIND_MODE = {"conv_fwd": 0, "conv_dgrad": 1, "conv_wgrad": 2}
+
+
+def kernel_name(kind, code):
+    """(kind, sod_conv_prof_collect variant code) -> the kernel name rocprofv3 prints."""
+    if kind == "conv_wgrad":
+        if code == 256:
+            return "sodconv::conv_wgrad256_kernel"
+        return f"void conv_wgrad_kernel<{code // 1000}, {code % 1000}>"
+    return variant_kernel_name(code, KIND_MODE[kind])
+
+
+def roofline_report(prof, prof_steps, args, side_stream):
+    """`roofline` = the conv kernel with the most GPU time in the sampled steps (duration = hipEvent interval on its launch
+    stream, algorithmic FLOPs = 2*N*Ho*Wo*K*R*S*C with UN-padded channel counts); every other kernel in `kernels`;
+    `backbone_convs` = ResNet body + FPN, the convolutions north_star's >= 0.5 x MFMA target is stated for; `head_convs` = the rest."""
+    by_k, groups, kinds = {}, {}, {}
+    for kind, flops, sec, desc, variant in prof:
+        for tab, key in ((by_k, (kind, variant)), (kinds, kind), (groups, "head_convs" if desc and desc[0] == "ml" else "backbone_convs")):
+            a = tab.setdefault(key, [0.0, 0.0, 0])
+            a[0] += flops; a[1] += sec; a[2] += 1
+
+    def row(v, name=None):
+        fl, sec, cnt = v
+        r = {"TFLOP/s": round(fl / sec / 1e12, 2), "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4), "ms_per_step": round(sec / prof_steps * 1e3, 3),
+             "launches_per_step": round(cnt / prof_steps, 1), "tflop_per_step": round(fl / prof_steps / 1e12, 3)}
+        if name:
+            r["kernel"] = name
+        return r
+
+    dom = max(by_k, key=lambda k: by_k[k][1])
+    fl, sec, cnt = by_k[dom]
+    kname = kernel_name(*dom)
+    tr = pmc_traffic(dom[0], kname)
+    overlapped = bool(side_stream)
+    rep = {"bound": "mfma", "kernel": kname, "achieved": round(fl / sec / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4), "traffic": (tr or {}).get("hbm_bytes_per_launch"),
+           "traffic_source": (tr or {}).get("source"),
+           "selection": "kernel with the largest share of conv GPU time in the sampled steps", "launches": cnt, "sampled_steps": prof_steps,
+           "avg_launch_us": round(sec / cnt * 1e6, 2), "ms_per_step": round(sec / prof_steps * 1e3, 3),
+           "flops": "algorithmic, un-padded channels", "backward_kernels_overlap": overlapped,
+           "kernels": [row(v, kernel_name(*k)) for k, v in sorted(by_k.items(), key=lambda kv: -kv[1][1])],
+           "by_pass": {k: row(v) for k, v in kinds.items()}}
+    if args.arch == "fcos":
+        # with two backward streams the per-kernel intervals of dgrad and wgrad overlap in wall time: the sum of intervals is an
+        # UPPER bound of the GPU time those convs take, so these fractions are lower bounds
+        for gname, v in groups.items():
+            rep[gname] = row(v)
+            rep[gname]["note"] = "sum of per-launch intervals; backward intervals overlap in wall time (lower bound)" if overlapped else "sum of per-launch intervals"
+    return rep
+
+
+def pmc_traffic(kind, kernel_name_):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary (profiles/*_pmc.json: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if absent."""
     import glob
 
-    prefixes = {"conv_fwd": ("void conv_igemm_kernel<0, ", "void sodconv::conv_igemm256_kernel<0, "),
-                "conv_dgrad": ("void conv_igemm_kernel<1, ", "void sodconv::conv_igemm256_kernel<1, "),
-                "conv_wgrad": ("void conv_wgrad_kernel", "conv_wgrad_kernel")}
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not files or kind not in prefixes:
+    def norm(x):
+        return x.replace(";", ",").replace(" ", "").replace("void", "")
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.getmtime)
+    if not files:
         return None
     try:
         kernels = json.load(open(files[-1]))["kernels"]
-        want = kernel_prefix or prefixes[kind][0]
-        hits = [(v["launches"], k, v) for k, v in kernels.items() if k.startswith(want)]
+        want = norm(kernel_name_)
+        hits = [(v["launches"], k, v) for k, v in kernels.items() if want in norm(k)]
         if not hits:
             return None
         _, name, k = max(hits)
-        family = {kk: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "launches": v["launches"]}
-                  for kk, v in kernels.items() if any(kk.startswith(pf) for pf in prefixes[kind])}
-        return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "kernel": name, "source": os.path.relpath(files[-1], ROOT),
-                "all_variants": family}
+        return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "kernel": name, "source": os.path.relpath(files[-1], ROOT)}
     except Exception:
         return None
 
 
 def cpu_baseline(model, args):
-    """Time the CPU oracle (oracle/model.py) on a bounded sample of the same workload, host cores of this box."""
+    """Time the CPU oracle (oracle/model.py) on a bounded sample of the same workload, host cores of this box.  SURVEY.md §8(d) asks
+    for 3 warm-up + 10 timed iterations; a 16-image CPU step takes ~20 s, so the sample is bounded to ``--cpu-images`` images per step
+    and ``--cpu-warmup`` + ``--cpu-steps`` steps (stated in `sample`)."""
     from oracle.model import OracleFCOS
     from slenderobjdet_amd.data import synthetic_batch
 
@@ -167,14 +218,55 @@ def cpu_baseline(model, args):
     n = args.cpu_images
     oracle = OracleFCOS.from_hip_model(model)
     data = synthetic_batch(n, 800, 1333, 4321, device="cpu")
+
+    def step():
+        losses = oracle.losses(data)
+        total = sum(losses.values())
+        grads = torch.autograd.grad(total, list(oracle.trainable().values()))
+        oracle.sgd_step(dict(zip(oracle.trainable().keys(), grads)), {}, 0.01)
+
     t0 = time.time()
-    losses = oracle.losses(data)
-    total = sum(losses.values())
-    grads = torch.autograd.grad(total, list(oracle.trainable().values()))
-    oracle.sgd_step(dict(zip(oracle.trainable().keys(), grads)), {}, 0.01)
-    dt = time.time() - t0
-    return {"value": round(n / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic 1333x800 image(s), 1 full training step (fwd+bwd+SGD) of the fp32 CPU oracle, {dt:.1f} s"}
+    for _ in range(args.cpu_warmup):
+        step()
+    t1 = time.time()
+    for _ in range(args.cpu_steps):
+        step()
+    dt = time.time() - t1
+    cpu = ""
+    try:
+        cpu = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
+    return {"value": round(n * args.cpu_steps / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"{n} synthetic 1333x800 image(s) per step, {args.cpu_warmup} warm-up + {args.cpu_steps} timed full training steps (fwd+bwd+SGD) of the "
+                      f"fp32 CPU oracle, {dt:.1f} s timed ({time.time() - t0:.1f} s in all); host: {os.cpu_count()} logical CPUs, {cpu}"}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """``python bench.py --gpus N`` (N > 1, no launcher around it): start the N ranks ourselves, one process per GPU, as the
+    reference's train_net.py does through detectron2's ``launch`` (/root/reference/train_net.py:185-195).  This process has not
+    touched the GPU yet (``torch.cuda.device_count()`` does not initialise it on this image) and never will: the ranks are fresh
+    children of ``torch.distributed.run``; rank 0 prints the JSON line, which is relayed unchanged."""
+    import subprocess
+
+    share = os.environ.get("SOD_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if not share and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s)", file=sys.stderr)
+        sys.exit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rc = subprocess.call(cmd, env=env)
+    sys.exit(rc)
 
 
 def main():
@@ -183,7 +275,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=16)
-    ap.add_argument("--cpu-images", type=int, default=8)
+    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--cpu-warmup", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--depth", type=int, default=50, help="ResNet depth (tests use 18; the benchmark is R50)")
     ap.add_argument("--height", type=int, default=800)
@@ -194,7 +288,12 @@ def main():
     ap.add_argument("--dump-prof", type=int, default=0, help="print the N most expensive (kernel, shape) groups to stderr")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args, sys.argv[1:])         # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} does not match the launcher's WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -236,16 +335,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     if not args.no_roofline:
-        # HIP events on the launch stream around every FORWARD conv launch of the timed steps.  The backward launches run two at a
-        # time (dgrad on the main stream, wgrad on the side stream, layers/functional.py), so their event intervals overlap and are
-        # not per-kernel durations; they are only collected for --dump-prof.
-        # Event pairs cost ~11 us of queue bubbles each, so only every 4th timed step carries them (all steps with --dump-prof).
-        HF.PROFILE_KINDS = None if args.dump_prof else {"conv_fwd"}
-        HF.PROFILE_LIB = not args.dump_prof     # default: the library's own hipEvent pair around each forward conv kernel
+        # The library records one hipEvent pair on the LAUNCH stream around the main kernel of every conv dispatch (forward, data
+        # gradient, weight gradient: sod_conv_prof_enable) of the sampled steps.  Inside backward the data-gradient chain (main
+        # stream) and the weight gradients (side stream, layers/functional.py) share the GPU, so a backward kernel's interval is its
+        # duration AS EXECUTED in the step (rocprofv3 --kernel-trace reports the same begin/end), not its stand-alone time.
+        # An event pair costs a few us of queue bubbles, so only every 8th timed step carries them (all steps with --dump-prof).
+        HF.PROFILE_KINDS = None
+        HF.PROFILE_LIB = True
     prof_all, prof_steps = [], 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        sample = (not args.no_roofline) and bool(args.dump_prof or (i % 4 == 0 and prof_steps < 48))   # the library keeps 8192 event pairs
+        sample = (not args.no_roofline) and bool(args.dump_prof or i % 8 == 0) and prof_steps < 12     # the library keeps 8192 event pairs
         HF.PROFILE = prof_all if sample else None
         if HF.PROFILE_LIB:
             _C.call("sod_conv_prof_enable", 1 if sample else 0)
@@ -259,21 +359,17 @@ def main():
     if HF.PROFILE_LIB:
         import ctypes
         _C.call("sod_conv_prof_enable", 0)
-        nfw = sum(1 for p_ in prof if p_[0] == "conv_fwd")
-        ms, var, frac, mode = (ctypes.c_float * max(nfw, 1))(), (ctypes.c_int * max(nfw, 1))(), (ctypes.c_float * max(nfw, 1))(), (ctypes.c_int * max(nfw, 1))()
-        got = _C.load().sod_conv_prof_collect(ms, var, frac, mode, nfw)
-        if got != nfw:      # never fail the measurement over the instrumentation: drop the roofline instead
-            print(f"# roofline skipped: library recorded {got} forward conv dispatches, host {nfw}", file=sys.stderr)
-            prof, got = [p_ for p_ in prof if p_[0] != "conv_fwd"], 0
-        j, filled = 0, []
-        for kind, flops, e0, e1, desc, variant in prof:
-            if kind == "conv_fwd":
-                assert mode[j] == 0
-                filled.append((kind, flops * frac[j], ms[j] * 1e-3, desc, var[j]))
-                j += 1
-        prof = filled
-    else:
-        prof = [(k, fl, e0.elapsed_time(e1) * 1e-3, d, v) for k, fl, e0, e1, d, v in prof]
+        n = len(prof)
+        ms, var, frac, mode = (ctypes.c_float * max(n, 1))(), (ctypes.c_int * max(n, 1))(), (ctypes.c_float * max(n, 1))(), (ctypes.c_int * max(n, 1))()
+        got = _C.load().sod_conv_prof_collect(ms, var, frac, mode, n)
+        kinds = {"conv_fwd": 0, "conv_dgrad": 1, "conv_wgrad": 2}
+        if got != n or any(kinds[p_[0]] != mode[j] for j, p_ in enumerate(prof)):
+            # never fail the measurement over the instrumentation: drop the roofline instead
+            print(f"# roofline skipped: library recorded {got} conv dispatches, host {n} (or their order differs)", file=sys.stderr)
+            prof = []
+        else:
+            prof = [(kind, flops * frac[j], ms[j] * 1e-3, desc, var[j]) for j, (kind, flops, _e0, _e1, desc, _v) in enumerate(prof)]
+        HF.PROFILE_LIB = False
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -295,32 +391,8 @@ def main():
         }
         if args.arch == "fcos" and args.depth == 50:
             out["model_tflops"] = round(imgs * TRAIN_FLOP_PER_IMAGE / dt / 1e12, 2)
-        if prof and any(p_[0] == "conv_fwd" for p_ in prof):
-            agg, by_var = {}, {}
-            for kind, flops, sec_, _desc, variant in prof:
-                a = agg.setdefault(kind, [0.0, 0.0, 0])
-                a[0] += flops; a[1] += sec_; a[2] += 1
-                if kind == "conv_fwd":
-                    b = by_var.setdefault(variant, [0.0, 0.0, 0])
-                    b[0] += flops; b[1] += sec_; b[2] += 1
-            # the dominant kernel = the forward conv kernel variant that does the largest share of the forward convolution FLOPs (the
-            # 256x256 kernel: 55 % of them); every variant is listed in "forward_conv_variants" (the HBM-bound 1x1 convs of the
-            # 128x128 BK=32 variant take slightly more TIME at a sixth of the FLOPs) and the average over all of them in "all_conv"
-            var = max(by_var, key=lambda v: by_var[v][0])
-            fl, sec, cnt = by_var[var]
-            achieved = fl / sec / 1e12
-            kname = variant_kernel_name(var)
-            tr = pmc_traffic("conv_fwd", kname)      # HBM bytes per launch of that kernel from the committed PMC passes (or None)
-            out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": (tr or {}).get("hbm_bytes_per_launch"),
-                               "traffic_detail": tr, "launches": cnt,
-                               "sampled_steps": prof_steps, "avg_launch_us": round(sec / cnt * 1e6, 2),
-                               "ms_per_step": round(sec / prof_steps * 1e3, 3),
-                               "forward_conv_variants": {variant_kernel_name(v): {"TFLOP/s": round(x[0] / x[1] / 1e12, 2), "ms_per_step": round(x[1] / prof_steps * 1e3, 3),
-                                                                                  "launches_per_step": x[2] // prof_steps}
-                                                         for v, x in sorted(by_var.items(), key=lambda kv: -kv[1][1])},
-                               "all_conv": {k: {"TFLOP/s": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / prof_steps * 1e3, 3),
-                                                "overlapped": k != "conv_fwd" and HF.WGRAD_SIDE_STREAM} for k, v in agg.items()}}
+        if prof:
+            out["roofline"] = roofline_report(prof, prof_steps, args, HF.WGRAD_SIDE_STREAM)
         if prof and args.dump_prof:
             per = {}
             for kind, flops, sec_, desc, _variant in prof:

@@ -7,7 +7,11 @@
  *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the call returns without synchronising;
  *   - return value: 0 = ok, SOD_EARG (-1) bad argument / unsupported shape, SOD_ESIZE (-2) tensor exceeds the
  *     32-bit buffer addressing range (2 GiB per operand), >0 = hipError_t of a failed launch;
- *   - no global mutable state besides one-time kernel attribute set-up; re-entrant per stream.
+ *   - re-entrant per stream.  Process-wide state is limited to (a) one-time kernel attribute set-up and cached device properties
+ *     (the library assumes every GPU of the process is the same model; one process per GPU is the supported deployment), (b) the
+ *     tile-policy and experiment knobs read from SOD_* environment variables on first use and sod_conv_set_tile256, which select
+ *     between kernels with identical contracts, and (c) the profiling aids sod_conv_prof_* (process-wide list) / sod_conv_last_variant (per thread).
+ *     Scratch memory is never cached inside the library: every entry point that needs a workspace takes it as an argument.
  *
  * Each declaration cites the reference interface it replaces (paths under wanzysky/SlenderObjDet; "d2" =
  * detectron2 @ 8bc84a2ff8a0b5787ec and "fvcore" are the un-vendored third-party packages the reference calls,
@@ -55,11 +59,20 @@ int sod_conv2d_fwd(const void* x, const void* w, const float* bias, const void* 
 int sod_conv2d_dgrad(const void* dy, const void* wt, const void* accum, const void* relu_mask, void* dx,
                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                      long long dy_img_stride, long long dx_img_stride, void* stream);
-/* dw[k,r,s,c] += qscale[k] * sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,hi,wi,c]   (fp32, atomically accumulated: zero it once
- * per step; qscale optional = the folded FrozenBatchNorm2d scale, chain rule through w_eff = w * scale) */
+/* dw[k,r,s,c] += qscale[k] * sum_{n,ho,wo} dy[n,ho,wo,k] * x[n,hi,wi,c]   (fp32, accumulated: zero it once per step; qscale
+ * optional = the folded FrozenBatchNorm2d scale, chain rule through w_eff = w * scale).
+ * ws / ws_bytes: caller-owned scratch (16-B aligned; sod_conv2d_wgrad_workspace_bytes() is enough for every shape), used in stream
+ * order by this call only.  With it, shapes with K and C multiples of 256 run on the 256x256 8-wave kernel, whose pixel splits meet
+ * in fp32 slabs summed in a fixed order; the other shapes add their splits into dw with fp32 atomics.  ws == NULL: atomics only.
+ * flags: SOD_WGRAD_DETERMINISTIC = never use atomics (every shape goes through slabs; SOD_EARG if the workspace is too small), the
+ * result is then bit-identical from run to run.  splits > 0 forces the 128x128 kernel with that many pixel splits, splits < 0 the
+ * 256x256 kernel (SOD_EARG when the shape or the workspace does not allow it); 0 = the library chooses. */
+#define SOD_WGRAD_DETERMINISTIC 1
+long long sod_conv2d_wgrad_workspace_bytes(void);
 int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const float* qscale,
                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                     long long dy_img_stride, long long x_img_stride, int splits, void* stream);
+                     long long dy_img_stride, long long x_img_stride, int splits, int flags,
+                     void* ws, long long ws_bytes, void* stream);
 
 /* Multi-level forms: ONE launch applies the same weights to `nlev` tensors (the FPN levels the FCOS towers and
  * prediction convs share, fcosv2.py:358-380 loops over them). x/y/dy/dx are HOST arrays of device pointers, H/W host
@@ -73,10 +86,7 @@ int sod_conv2d_dgrad_ml(int nlev, const void* const* dy, const void* wt, void* c
                         long long dy_img_stride, void* stream);
 int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, float* dw, const float* qscale,
                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
-                        long long dy_img_stride, int splits, void* stream);
-/* Optional caller-owned scratch (fp32, >= 32 MiB recommended) for the current device: weight gradients whose output has few 128x128
- * tiles then write per-split partial tiles and sum them in a second kernel instead of contending on global atomics. NULL disables. */
-int sod_conv_set_workspace(void* ws, long long bytes);
+                        long long dy_img_stride, int splits, int flags, void* ws, long long ws_bytes, void* stream);
 /* Tile policy of sod_conv2d_fwd / _dgrad (process-wide): 1 (default, or env SOD_CONV256) = shapes with >= 1 round of 256x256 output
  * tiles, Nout % 256 == 0 and R*S*C >= 1024 run on the 256x256x64 8-phase kernel (whole rounds; a short remainder goes to the
  * 128x128 kernel); 0 = 128x128 kernel only; 2 = the 256 kernel for every shape it supports (tests); -1 = re-read the env. */
@@ -84,10 +94,12 @@ int sod_conv_set_tile256(int mode);
 /* Which kernel the last sod_conv2d_fwd / _dgrad call of this thread dispatched to (profiling aid): 256 = the 256x256x64 kernel
  * (possibly followed by a short 128x128 tail launch), otherwise BQ*100000 + BP*100 + BK (+1 for the generic-channel path). */
 int sod_conv_last_variant(void);
-/* In-library timing of the conv launches of the calling thread: while enabled, every sod_conv2d_fwd / _dgrad dispatch records one
- * hipEvent pair on the launch stream right around its main kernel.  sod_conv_prof_collect synchronises, writes duration (ms),
- * kernel variant (as above), the main kernel's share of the dispatch's output pixels (1 unless a 128x128 tail launch followed) and
- * mode (0 fwd / 1 dgrad) of up to max dispatches in call order, clears the list and returns the count (capacity 8192). */
+/* In-library timing of the conv launches of the process (forward on the caller's thread, backward on autograd's): while enabled, every sod_conv2d_fwd / _dgrad / _wgrad dispatch
+ * records one hipEvent pair on ITS launch stream right around its main kernel (for a weight gradient: the kernel plus its slab
+ * reduce).  sod_conv_prof_collect synchronises, writes duration (ms), kernel variant (as above; weight gradients: 256 = the
+ * 256x256 kernel, 32003 / 32002 / 64002 = pixels per K-step and LDS slots of the 128x128 kernel), the main kernel's share of the
+ * dispatch's output pixels (1 unless a 128x128 tail launch followed) and mode (0 fwd / 1 dgrad / 2 wgrad) of up to max dispatches
+ * in call order, clears the list and returns the count (capacity 8192). */
 int sod_conv_prof_enable(int on);
 int sod_conv_prof_collect(float* ms, int* variant, float* frac, int* mode, int max);
 

@@ -23,10 +23,11 @@ _F = c_float
 _SIGS = {
     "sod_conv2d_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _I, _P],
     "sod_conv2d_dgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _P],
-    "sod_conv2d_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _P],
+    "sod_conv2d_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _I, _P, _L, _P],
+    "sod_conv2d_wgrad_workspace_bytes": [],
     "sod_conv2d_fwd_ml": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P],
     "sod_conv2d_dgrad_ml": [_I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
-    "sod_conv2d_wgrad_ml": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P],
+    "sod_conv2d_wgrad_ml": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P, _L, _P],
     "sod_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _F, _I, _P],
     "sod_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
     "sod_groupnorm_fwd_ml": [_I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P],
@@ -38,7 +39,6 @@ _SIGS = {
     "sod_bias_grad": [_P, _P, _I, _I, _I, _L, _P],
     "sod_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
     "sod_upsample2x_bwd": [_P, _P, _I, _I, _I, _I, _P],
-    "sod_conv_set_workspace": [_P, _L],
     "sod_conv_set_tile256": [_I],
     "sod_conv_last_variant": [],
     "sod_conv_prof_enable": [_I],
@@ -106,7 +106,7 @@ _SIGS = {
     "sod_reduce_workspace_bytes": [],
     "sod_version": [],
 }
-_RESTYPES = {"sod_reduce_workspace_bytes": c_longlong, "sod_nms_workspace_bytes": c_longlong, "sod_version": c_char_p}
+_RESTYPES = {"sod_reduce_workspace_bytes": c_longlong, "sod_conv2d_wgrad_workspace_bytes": c_longlong, "sod_nms_workspace_bytes": c_longlong, "sod_version": c_char_p}
 
 
 class SlenderHipError(RuntimeError):

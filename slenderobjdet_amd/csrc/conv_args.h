@@ -59,4 +59,42 @@ bool conv256_supported(const ConvArgs& a, int mode);
 // max_pt_tiles > 0 launches only the first max_pt_tiles pixel tiles (the caller covers the rest with the 128x128 kernel).
 int launch_conv256(const ConvArgs& a, int mode, bool out_f32, int max_pt_tiles, hipStream_t st);
 
+// --------------------------------------------------------------------------------------------
+// wgrad: dW[q][tap][c] += sum_p dY[p][q] * X[p shifted by tap][c]
+// The contraction runs over a VIRTUAL pixel index that concatenates the levels (each padded to a multiple of 64), so
+// one launch reduces over all FPN levels that share the weights.  (conv_igemm.hip: 128x128 tiles; conv_wgrad256.hip: 256x256.)
+// --------------------------------------------------------------------------------------------
+struct WLevel {
+  const void* dy;      // (N,Ho,Wo,K) bf16 rows at dy_img_stride
+  const void* x;       // (N,Hx,Wx,C) bf16
+  uint32_t dy_bytes, x_bytes;
+  int Hx, Wx, Ho, Wo, P;
+  int v0;              // first virtual pixel of this level (multiple of 64)
+  int dy_img_stride, x_img_stride;
+  FastDiv div_hw, div_w;
+};
+
+struct WgradArgs {
+  WLevel lev[MAXLEV];
+  int nlev;
+  float* dw;           // [K][R][S][C] fp32, accumulated
+  const float* qscale; // optional per-output-channel factor (folded FrozenBN scale)
+  int dbg_plain_store; // timing experiment only (SOD_WGRAD_PLAIN=1): racy plain stores instead of atomics
+  float* partial;      // optional fp32 slabs: blocks store their partial tile, a reduce kernel sums the splits
+  int det;             // deterministic: the reduce kernel adds into dw with plain read-modify-writes in a fixed order
+  int N, C, K;
+  int R, S, stride, pad, dil;
+  int V, nz, v_per_split;   // total virtual pixels; v_per_split multiple of 64
+  int QT, CT;
+  FastDiv div_s;
+};
+
+enum { WGRAD_DETERMINISTIC = 1 };   // sod_conv2d_wgrad flags
+
+// conv_wgrad256.hip: 256(q) x 256(c) output tile per workgroup of 8 waves, one workgroup per CU, split over pixels with fp32 slabs in
+// the caller's workspace and a fixed-order reduce kernel (no atomics anywhere).
+bool wgrad256_supported(const WgradArgs& a);
+long long wgrad256_workspace_bytes(const WgradArgs& a, int cus);
+int launch_wgrad256(WgradArgs& a, int cus, float* ws, long long ws_bytes, hipStream_t st);
+
 }  // namespace sodconv

@@ -16,6 +16,7 @@
 #include "conv_args.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <atomic>
 
 using namespace sodconv;
 
@@ -23,29 +24,35 @@ namespace {
 
 thread_local int g_last_variant = 0;   // kernel variant chosen by the last forward / data-gradient dispatch (sod_conv_last_variant)
 
-// Optional in-library timing of the forward / data-gradient launches of the calling thread (sod_conv_prof_enable / _collect): one
-// hipEvent pair per top-level dispatch, recorded on the launch stream right around the MAIN kernel (for a split dispatch the 256x256
-// launch; `frac` is its share of the output pixels), so that the durations are comparable with rocprofv3's per-kernel figures.
+// Optional in-library timing of the conv launches (sod_conv_prof_enable / _collect): one hipEvent pair per top-level dispatch,
+// recorded on the launch stream right around the MAIN kernel (for a split dispatch the 256x256 launch; `frac` is its share of the
+// output pixels), so that the durations are comparable with rocprofv3's per-kernel figures.  The list is process-wide: autograd runs
+// the backward pass on its own thread, and its dispatches belong to the same step as the forward ones.  Slots are reserved with an
+// atomic counter; the nesting depth (tail launches of a split dispatch) is a per-thread property.
 struct ConvProf {
   hipEvent_t* ev = nullptr;
   int* variant = nullptr;
   int* mode = nullptr;
   float* frac = nullptr;
-  int cap = 0, n = 0, on = 0, depth = 0;
+  int cap = 0;
+  std::atomic<int> n{0};
+  std::atomic<int> on{0};
 };
-thread_local ConvProf g_prof;
+ConvProf g_prof;
+thread_local int g_prof_depth = 0;
 inline int prof_begin(hipStream_t st) {
   ConvProf& p = g_prof;
-  if (!p.on || p.depth || p.n >= p.cap) return -1;
-  (void)hipEventRecord(p.ev[2 * p.n], st);
-  return p.n;
+  if (!p.on.load(std::memory_order_relaxed) || g_prof_depth) return -1;
+  const int i = p.n.fetch_add(1);
+  if (i >= p.cap) { p.n.store(p.cap); return -1; }
+  (void)hipEventRecord(p.ev[2 * i], st);
+  return i;
 }
 inline void prof_end(int i, hipStream_t st, int variant, float frac, int mode) {
   if (i < 0) return;
   ConvProf& p = g_prof;
   (void)hipEventRecord(p.ev[2 * i + 1], st);
   p.variant[i] = variant; p.frac[i] = frac; p.mode[i] = mode;
-  p.n = i + 1;
 }
 
 template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK, int NSTAGE>
@@ -434,35 +441,6 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
   }
 }
 
-// --------------------------------------------------------------------------------------------
-// wgrad: dW[q][tap][c] += sum_p dY[p][q] * X[p shifted by tap][c]
-// The contraction runs over a VIRTUAL pixel index that concatenates the levels (each padded to a multiple of 64), so
-// one launch reduces over all FPN levels that share the weights.
-// --------------------------------------------------------------------------------------------
-struct WLevel {
-  const void* dy;      // (N,Ho,Wo,K) bf16 rows at dy_img_stride
-  const void* x;       // (N,Hx,Wx,C) bf16
-  uint32_t dy_bytes, x_bytes;
-  int Hx, Wx, Ho, Wo, P;
-  int v0;              // first virtual pixel of this level (multiple of 64)
-  int dy_img_stride, x_img_stride;
-  FastDiv div_hw, div_w;
-};
-
-struct WgradArgs {
-  WLevel lev[MAXLEV];
-  int nlev;
-  float* dw;           // [K][R][S][C] fp32, accumulated atomically
-  const float* qscale; // optional per-output-channel factor (folded FrozenBN scale)
-  int dbg_plain_store; // timing experiment only (SOD_WGRAD_PLAIN=1): racy plain stores instead of atomics
-  float* partial;      // optional [nz][tiles][128][128] fp32: blocks store their partial tile, wgrad_reduce_kernel sums the splits
-  int N, C, K;
-  int R, S, stride, pad, dil;
-  int V, nz, v_per_split;   // total virtual pixels; v_per_split multiple of 64
-  int QT, CT;
-  FastDiv div_s;
-};
-
 // KP = pixels per K-step: 64 (two resident workgroups per CU) or 32 (half the LDS: three to four per CU, which is what the
 // latency of the transposing ds_read_b64_tr_b16 fragment reads wants - they need more waves per SIMD than ds_read_b128).
 // inline-asm transposing LDS read: invisible to hipcc's memory model, so it does not put a vmcnt(0) in front of it while LDS-DMA
@@ -772,6 +750,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
     for (int z = z0; z < z1; ++z) acc += *reinterpret_cast<const f32x4_t*>(src + (size_t)z * tiles * (128 * 128));
     const float qs = a.qscale ? a.qscale[q] : 1.f;
     float* dst = a.dw + ((size_t)q * RS + tap) * a.C + c;
+    if (a.det) {       // gridDim.y == 1: this thread owns the four elements, fixed summation order
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < a.C) dst[e] += acc[e] * qs;
+      continue;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       if (c + e < a.C) atomicAdd(dst + e, acc[e] * qs);
@@ -878,9 +862,9 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
         if (main_pt >= tl) { tail.lev[l].pstart = tail.lev[l].P; main_pt -= tl; }
         else { tail.lev[l].pstart = main_pt * 256; main_pt = 0; }
       }
-      ++g_prof.depth;            // the tail launch belongs to this dispatch: no event pair of its own
+      ++g_prof_depth;            // the tail launch belongs to this dispatch: no event pair of its own
       rc = dispatch_conv<MODE, OUT_F32>(tail, st);
-      --g_prof.depth;
+      --g_prof_depth;
       g_last_variant = 256;      // whole rounds on the 256 kernel (+ a short 128x128 tail launch)
       return rc;
     }
@@ -961,7 +945,40 @@ int fill_level(ConvArgs& a, int l, const void* src, void* dst, int Hs, int Ws, i
   return SOD_OK;
 }
 
-int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, long long ws_bytes = 0) {
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// Which kernel a weight gradient goes to.  SOD_WGRAD256: 0 = never, 1 (default) = shapes with K, C multiples of 256 whose blocks get
+// at least SOD_WGRAD256_MIN_KT K-tiles of work each, 2 = every supported shape (parity tests).
+bool use_wgrad256(const WgradArgs& a, float* ws, long long ws_bytes) {
+  static const int mode = getenv("SOD_WGRAD256") ? atoi(getenv("SOD_WGRAD256")) : 1;
+  static const int min_kt = getenv("SOD_WGRAD256_MIN_KT") ? atoi(getenv("SOD_WGRAD256_MIN_KT")) : 6;
+  if (!mode || !ws || !wgrad256_supported(a)) return false;
+  const int cus = device_cus();
+  if (wgrad256_workspace_bytes(a, cus) > ws_bytes) return false;
+  if (mode == 2) return true;
+  long long V = 0;
+  for (int l = 0; l < a.nlev; ++l) V += (a.lev[l].P + 63) / 64 * 64;
+  const long long tiles = (long long)(a.K / 256) * (a.C / 256) * a.R * a.S;
+  const long long nz = cus / tiles > 0 ? cus / tiles : 1;
+  return V / 64 >= nz * min_kt;
+}
+
+int launch_wgrad(WgradArgs& a, int splits, int flags, hipStream_t st, float* ws = nullptr, long long ws_bytes = 0) {
+  a.det = (flags & WGRAD_DETERMINISTIC) ? 1 : 0;
+  if (splits < 0 && (!ws || !wgrad256_supported(a) || wgrad256_workspace_bytes(a, device_cus()) > ws_bytes)) return SOD_EARG;
+  if (splits < 0 || (splits == 0 && use_wgrad256(a, ws, ws_bytes))) {
+    const int pi = prof_begin(st);
+    const int rc = launch_wgrad256(a, device_cus(), ws, ws_bytes, st);
+    prof_end(pi, st, 256, 1.f, 2);
+    return rc;
+  }
   a.QT = (a.K + 127) / 128; a.CT = (a.C + 127) / 128;
   const int tiles = a.QT * a.CT * a.R * a.S;
   int V = 0;
@@ -984,11 +1001,7 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
   if (splits <= 0) {
     // ONE resident wave of blocks (2 or 4 per CU): measured on the head shape, 504 blocks run at 718 TFLOP/s where 1548 blocks
     // (3.02 waves -> a nearly empty 4th round, 3x the atomic traffic) run at 585.  At least 256 pixels per block.
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
+    const int cus = device_cus();
     static const int per_cu_env = getenv("SOD_WGRAD_PER_CU") ? atoi(getenv("SOD_WGRAD_PER_CU")) : 0;
     static const int pc_big = getenv("SOD_WGRAD_PC_BIG") ? atoi(getenv("SOD_WGRAD_PC_BIG")) : 3;
     const int slots = (per_cu_env > 0 ? per_cu_env : (tiles >= 36 ? (kp == 32 ? pc_big : 2) : pc_small)) * cus;
@@ -1011,13 +1024,19 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  // two-stage reduction when few tiles share many splits (1x1 convs of the backbone, 3x3 convs with <= 128 channels)
-  // Measured on the FCOS R50 step: 447.4 vs 447.5 img/s (the 4-tile shapes gain <= 10 %, the rest lose the reduce launch), so this
-  // stays an opt-in experiment (SOD_WGRAD_TWO_STAGE=1 and a registered workspace).
+  // Two-stage reduction (fp32 partial tiles in the workspace + wgrad_reduce_kernel).  Deterministic mode always takes it and sums in
+  // a fixed order with plain read-modify-writes; otherwise it is an opt-in experiment for shapes where few tiles share many splits
+  // (SOD_WGRAD_TWO_STAGE=1: 447.4 vs 447.5 img/s on the FCOS R50 step) and the blocks meet in dW with fp32 atomics.
   static const int two_stage = getenv("SOD_WGRAD_TWO_STAGE") ? atoi(getenv("SOD_WGRAD_TWO_STAGE")) : 0;
   const long long need = (long long)a.nz * tiles * 128 * 128 * (long long)sizeof(float);
-  a.partial = (two_stage && ws && a.nz >= 8 && tiles <= 32 && need <= ws_bytes) ? ws : nullptr;
+  if (a.det) {
+    if (!ws || need > ws_bytes) return SOD_EARG;      // deterministic mode never falls back to atomics
+    a.partial = ws;
+  } else {
+    a.partial = (two_stage && ws && a.nz >= 8 && tiles <= 32 && need <= ws_bytes) ? ws : nullptr;
+  }
   static const int ring = getenv("SOD_WGRAD_RING") ? atoi(getenv("SOD_WGRAD_RING")) : 1;
+  const int pi = prof_begin(st);
   if (kp == 32 && ring) SOD_LAUNCH((conv_wgrad_kernel<32, 3>), dim3(a.nz * tiles), dim3(256), 3 * 2 * 32 * 256, st, a);
   else if (kp == 32) SOD_LAUNCH((conv_wgrad_kernel<32, 2>), dim3(a.nz * tiles), dim3(256), lds / 2, st, a);
   else SOD_LAUNCH((conv_wgrad_kernel<64, 2>), dim3(a.nz * tiles), dim3(256), lds, st, a);
@@ -1025,9 +1044,10 @@ int launch_wgrad(WgradArgs& a, int splits, hipStream_t st, float* ws = nullptr, 
     const int gx = (tiles * 128 * 32 + 255) / 256;
     int gy = (1024 + gx - 1) / gx;            // ~1024 workgroups in total
     if (gy > a.nz) gy = a.nz;
-    if (gy < 1) gy = 1;
+    if (gy < 1 || a.det) gy = 1;
     SOD_LAUNCH(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, a);
   }
+  prof_end(pi, st, kp == 32 ? (ring ? 32003 : 32002) : 64002, 1.f, 2);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -1137,11 +1157,6 @@ extern "C" int sod_conv2d_dgrad_ml(int nlev, const void* const* dy, const void* 
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 
-// caller-owned scratch for the two-stage weight-gradient reduction, registered per device (used in stream order by the launches
-// that follow; one compute stream per process, as everywhere in this library)
-static float* g_wgrad_ws[16] = {nullptr};
-static long long g_wgrad_ws_bytes[16] = {0};
-
 extern "C" int sod_conv_last_variant(void) { return g_last_variant; }
 
 extern "C" int sod_conv_prof_enable(int on) {
@@ -1157,13 +1172,14 @@ extern "C" int sod_conv_prof_enable(int on) {
       if (hipEventCreate(&p.ev[i]) != hipSuccess) return SOD_EARG;
     p.cap = CAP;
   }
-  p.on = on ? 1 : 0;
+  p.on.store(on ? 1 : 0);
   return SOD_OK;
 }
 
 extern "C" int sod_conv_prof_collect(float* ms, int* variant, float* frac, int* mode, int max) {
   ConvProf& p = g_prof;
-  const int n = p.n < max ? p.n : max;
+  const int have = p.n.load();
+  const int n = have < max ? have : max;
   if (n > 0 && (!ms || !variant || !frac || !mode)) return SOD_EARG;
   for (int i = 0; i < n; ++i) {
     if (hipEventSynchronize(p.ev[2 * i + 1]) != hipSuccess) return SOD_EARG;
@@ -1171,7 +1187,7 @@ extern "C" int sod_conv_prof_collect(float* ms, int* variant, float* frac, int* 
     if (hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]) != hipSuccess) return SOD_EARG;
     ms[i] = t; variant[i] = p.variant[i]; frac[i] = p.frac[i]; mode[i] = p.mode[i];
   }
-  p.n = 0;
+  p.n.store(0);
   return n;
 }
 
@@ -1181,37 +1197,28 @@ extern "C" int sod_conv_set_tile256(int mode) {
   return SOD_OK;
 }
 
-extern "C" int sod_conv_set_workspace(void* ws, long long bytes) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || bytes < 0) return SOD_EARG;
-  g_wgrad_ws[dev] = (float*)ws;
-  g_wgrad_ws_bytes[dev] = ws ? bytes : 0;
-  return SOD_OK;
-}
-
-static int launch_wgrad_ws(WgradArgs& a, int splits, hipStream_t st) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return launch_wgrad(a, splits, st);
-  return launch_wgrad(a, splits, st, g_wgrad_ws[dev], g_wgrad_ws_bytes[dev]);
-}
-
 extern "C" int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const float* qscale,
                                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                                long long dy_img_stride, long long x_img_stride, int splits, void* stream) {
-  if (!dy || !x || !dw) return SOD_EARG;
+                                long long dy_img_stride, long long x_img_stride, int splits, int flags,
+                                void* ws, long long ws_bytes, void* stream) {
+  if (!dy || !x || !dw || ws_bytes < 0 || ((uintptr_t)ws & 15)) return SOD_EARG;
   if (N <= 0 || C <= 0 || K <= 0 || (C & 7) || (K & 7) || R <= 0 || S <= 0 || stride <= 0 || dil <= 0 || pad < 0) return SOD_EARG;
   WgradArgs a{};
   a.nlev = 1; a.dw = dw; a.qscale = qscale; a.N = N; a.C = C; a.K = K;
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   int rc = fill_wlevel(a, 0, dy, x, H, W, dy_img_stride, x_img_stride);
   if (rc) return rc;
-  return launch_wgrad_ws(a, splits, (hipStream_t)stream);
+  return launch_wgrad(a, splits, flags, (hipStream_t)stream, (float*)ws, ws ? ws_bytes : 0);
 }
+
+// Workspace that lets every shape of one launch take the slab path: one 256x256 fp32 partial tile per CU plus the rounding of the
+// split count, doubled for grids of more than one round (tiles > CUs).
+extern "C" long long sod_conv2d_wgrad_workspace_bytes(void) { return 160ll << 20; }
 
 extern "C" int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, float* dw, const float* qscale,
                                    int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
-                                   long long dy_img_stride, int splits, void* stream) {
-  if (!dy || !x || !dw || !H || !W || nlev <= 0 || nlev > MAXLEV) return SOD_EARG;
+                                   long long dy_img_stride, int splits, int flags, void* ws, long long ws_bytes, void* stream) {
+  if (!dy || !x || !dw || !H || !W || nlev <= 0 || nlev > MAXLEV || ws_bytes < 0 || ((uintptr_t)ws & 15)) return SOD_EARG;
   if (N <= 0 || C <= 0 || K <= 0 || (C & 7) || (K & 7) || R <= 0 || S <= 0 || stride <= 0 || dil <= 0 || pad < 0) return SOD_EARG;
   WgradArgs a{};
   a.nlev = nlev; a.dw = dw; a.qscale = qscale; a.N = N; a.C = C; a.K = K;
@@ -1220,5 +1227,5 @@ extern "C" int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* 
     int rc = fill_wlevel(a, l, dy[l], x[l], H[l], W[l], dy_img_stride, 0);
     if (rc) return rc;
   }
-  return launch_wgrad_ws(a, splits, (hipStream_t)stream);
+  return launch_wgrad(a, splits, flags, (hipStream_t)stream, (float*)ws, ws ? ws_bytes : 0);
 }

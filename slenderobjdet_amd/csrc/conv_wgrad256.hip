@@ -1,0 +1,341 @@
+// Convolution weight gradient, 256(q) x 256(c) output tile per workgroup, 8 waves, 4-phase K-tile loop (gfx950).
+//
+//   dW[q][tap][c] += sum_p dY[p][q] * X[p shifted by tap][c]          (replaces ATen's conv backward-weight under the d2 ResNet/FPN
+//   and FCOSHead convolutions: slender_det/modeling/backbone/fpn.py:94-115, slender_det/modeling/meta_arch/fcos/fcosv2.py:277-381)
+//
+// The contraction runs over pixels, the slow axis of both NHWC operands.  Structure = conv_igemm256.hip (one workgroup of 8 waves per
+// CU, LDS-DMA staging that is never drained inside the loop, two wave rows staggered by one barrier) with transposed operand reads:
+//
+//   * wave (wr, wc) = (wave>>2, wave&3) owns 128(q) x 64(c) outputs = 8x4 MFMA 16x16x32 accumulators:
+//       q in {u*128 + wr*64 + [0,64)}, c in {u*128 + wc*32 + [0,32)}, u = 0, 1;
+//   * a K-tile = 64 pixels.  It is staged as FOUR 16-KB units [64 pixels][128 channels] (rows of 256 B, each one contiguous 256-B run
+//     of global memory): Ya0 / Ya1 = dY channels q0 + {0..127} / {128..255}, Xb0 / Xb1 = X channels c0 + {0..127} / {128..255};
+//     LDS = 2 K-tiles x 4 units = 128 KB; the 32-B chunks of a row are XOR-swizzled with (row&3) | ((row>>3)&1)<<2 on the SOURCE
+//     side, which makes the transposing reads conflict-free;
+//   * fragments come from ds_read_b64_tr_b16 (hardware transpose: a 16-lane group fetches 4 pixel rows x 16 channels and every lane
+//     receives 4 consecutive pixels of ONE channel = half an MFMA operand register pair);
+//   * phases, waits and hazards exactly as in conv_igemm256.hip: quadrants (a0,b0) (a0,b1) (a1,b1) (a1,b0), 16 MFMAs each, one unit
+//     (two LDS-DMA instructions per thread) issued inside every MFMA cluster, `s_waitcnt vmcnt(6)` + raw s_barrier per phase, a unit
+//     issued in phase p retired by the wait of phase p+4 and first read in phase >= p+5.
+//
+// Split over pixels: the launch is ONE workgroup per CU, tiles x nz blocks; every block stores its 256x256 fp32 partial tile as a
+// slab (fragment order: 16-B stores, 1 KB per wave instruction) into the caller's workspace and wgrad256_reduce_kernel sums the nz
+// slabs of a tile in fixed order and adds the result (x folded FrozenBN scale) into dW with plain read-modify-writes: no atomics,
+// bit-identical from run to run.  The 9 taps of one pixel range are consecutive block ids (same XCD after the remap): they share the
+// dY tile and overlapping X rows in that XCD's L2.
+#include "conv_args.h"
+#include <stdlib.h>
+
+namespace sodconv {
+namespace {
+
+constexpr int WROWB = 256;             // bytes per LDS row: 128 channels of one pixel
+constexpr int WUNIT = 64 * WROWB;      // 16 KB
+constexpr int WBUF = 4 * WUNIT;        // one K-tile: [Ya0][Ya1][Xb0][Xb1]
+constexpr int WLDS_BYTES = 2 * WBUF;   // 128 KB
+constexpr int SLAB = 256 * 256;        // floats per partial tile
+
+template <int OFF>
+__device__ __forceinline__ s16x4_t tr_read(uint32_t addr) {
+  s16x4_t r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+
+__device__ __forceinline__ bf16x8_t pack8(s16x4_t lo, s16x4_t hi) {
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int SA, int SB, int KS>
+__device__ __forceinline__ void wmma_half(f32x4_t (&acc)[8][4], const bf16x8_t (&af)[4][2], const bf16x8_t (&bf)[2][2]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      acc[SA * 4 + i][SB * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][KS], bf[j][KS], acc[SA * 4 + i][SB * 2 + j], 0, 0, 0);
+}
+
+// PACK runs after the lgkmcnt(0) + sched_barrier: nothing that touches the raw fragment registers may be scheduled above the wait
+// (the transposing reads are inline asm, invisible to the compiler's own wait insertion).
+#define SODW_PHASE(SA, SB, BFR, PACK, STAGE)                              \
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        \
+  __builtin_amdgcn_s_barrier();                                           \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      \
+  __builtin_amdgcn_sched_barrier(0);                                      \
+  PACK;                                                                   \
+  __builtin_amdgcn_s_setprio(1);                                          \
+  wmma_half<SA, SB, 0>(acc, af, BFR);                                     \
+  STAGE;                                                                  \
+  wmma_half<SA, SB, 1>(acc, af, BFR);                                     \
+  __builtin_amdgcn_s_setprio(0);                                          \
+  __builtin_amdgcn_s_barrier();
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int RS = a.R * a.S;
+  const int tile = (int)(bid % (uint32_t)(a.QT * a.CT * RS));
+  const int z = (int)(bid / (uint32_t)(a.QT * a.CT * RS));
+  const int tap = tile % RS;
+  const int ct = (tile / RS) % a.CT, qt = tile / (RS * a.CT);
+  const int r = tap / a.S, s = tap - r * a.S;
+  const int q0 = qt * 256, c0 = ct * 256;
+  const int vbeg = z * a.v_per_split;
+  int vend = vbeg + a.v_per_split; if (vend > a.V) vend = a.V;
+  const int T = (vend - vbeg) >> 6;
+
+  // ---- staging geometry: one wave instruction = 4 pixel rows x 256 B; lane -> (row in the group of 4, 16-B slot)
+  const int srow = lane >> 4, spos = lane & 15;
+  const int sswz = srow | (((wave >> 1) & 1) << 2);          // (L&3) | ((L>>3)&1)<<2 for L = (j*8+wave)*4+srow
+  const int schunk = spos ^ (sswz << 1);                     // logical 16-B chunk (8 channels) this lane fetches
+  const uint32_t qadd0 = (uint32_t)(q0 + schunk * 8) * 2u, cadd0 = (uint32_t)(c0 + schunk * 8) * 2u;   // unit 1: + 256 B
+
+  int cur_lv = 0;
+#pragma unroll
+  for (int i = 1; i < MAXLEV; ++i)
+    if (i < a.nlev && vbeg >= a.lev[i].v0) cur_lv = i;
+  WLevel g = a.lev[cur_lv];
+  int next_v0 = (cur_lv + 1 < a.nlev) ? a.lev[cur_lv + 1].v0 : 0x7fffffff;
+  auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.dy), 0, g.dy_bytes, 0x00020000);
+  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, g.x_bytes, 0x00020000);
+
+  // ---- per-thread row state: this thread stages pixel rows L_j = (j*8+wave)*4+srow, j = 0, 1, of every K-tile.
+  // st_* describe the K-tile `st_kt`; voy / vox are the byte offsets the staging uses (out-of-range = zero fill).
+  uint32_t r_oy[2], r_ox[2];
+  int r_ho[2], r_wo[2], r_p[2];
+  uint32_t voy[2], vox[2];
+  bool fast = false;
+  int dh = 0, dw = 0;
+  uint32_t ycorr = 0, xcorr = 0;
+  auto init_rows = [&](int pbase) {      // full computation (two divisions per row)
+    fast = (a.stride == 1) && (g.Wo >= 64) && (g.Ho == g.Hx) && (g.Wo == g.Wx);
+    dh = r * a.dil - a.pad; dw = s * a.dil - a.pad;
+    ycorr = (uint32_t)(g.dy_img_stride - g.Ho * g.Wo * a.K) * 2u;
+    xcorr = (uint32_t)(g.x_img_stride - g.Hx * g.Wx * a.C) * 2u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int p = pbase + (j * 8 + wave) * 4 + srow;
+      const bool pv = p < g.P;
+      const uint32_t pc = pv ? (uint32_t)p : 0u;
+      const uint32_t n = fd_div(pc, g.div_hw);
+      const uint32_t rem = pc - n * g.div_hw.d;
+      const uint32_t ho = fd_div(rem, g.div_w);
+      const uint32_t wo = rem - ho * g.div_w.d;
+      const int hi = (int)ho * a.stride + dh, wi = (int)wo * a.stride + dw;
+      const bool tv = ((unsigned)hi < (unsigned)g.Hx) & ((unsigned)wi < (unsigned)g.Wx);
+      r_p[j] = p; r_ho[j] = (int)ho; r_wo[j] = (int)wo;
+      r_oy[j] = (n * (uint32_t)g.dy_img_stride + rem * (uint32_t)a.K) * 2u;
+      r_ox[j] = (n * (uint32_t)g.x_img_stride + (uint32_t)(hi * g.Wx + wi) * (uint32_t)a.C) * 2u;
+      voy[j] = pv ? r_oy[j] : SOD_OOB;
+      vox[j] = (pv && tv) ? r_ox[j] : SOD_OOB;
+    }
+  };
+  // Moves the row state to K-tile kt (called with kt = previous + 1).  Dead tiles (kt >= T) stage zeros into slots nobody reads.
+  auto advance = [&](int kt) {
+    if (kt >= T) { voy[0] = voy[1] = vox[0] = vox[1] = SOD_OOB; return; }
+    const int v = vbeg + kt * 64;
+    if (v >= next_v0) {                  // wave-uniform: the virtual pixel index crosses into the next level
+      ++cur_lv;
+      g = a.lev[cur_lv];
+      next_v0 = (cur_lv + 1 < a.nlev) ? a.lev[cur_lv + 1].v0 : 0x7fffffff;
+      yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.dy), 0, g.dy_bytes, 0x00020000);
+      xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, g.x_bytes, 0x00020000);
+      init_rows(v - g.v0);
+      return;
+    }
+    if (!fast) { init_rows(v - g.v0); return; }
+    // incremental path (stride 1, "same" geometry, Wo >= 64): +64 pixels = at most one column wrap and one image wrap
+    const uint32_t ystep = (uint32_t)(128 * a.K), xstep = (uint32_t)(128 * a.C);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      r_p[j] += 64; r_oy[j] += ystep; r_ox[j] += xstep;
+      int wo = r_wo[j] + 64, ho = r_ho[j];
+      if (wo >= g.Wo) { wo -= g.Wo; ho += 1; }
+      if (ho >= g.Ho) { ho -= g.Ho; r_oy[j] += ycorr; r_ox[j] += xcorr; }
+      r_wo[j] = wo; r_ho[j] = ho;
+      const bool pv = r_p[j] < g.P;
+      const bool tv = ((unsigned)(ho + dh) < (unsigned)g.Hx) & ((unsigned)(wo + dw) < (unsigned)g.Wx);
+      voy[j] = pv ? r_oy[j] : SOD_OOB;
+      vox[j] = (pv && tv) ? r_ox[j] : SOD_OOB;
+    }
+  };
+
+  auto stage_a = [&](int u, int kt) {     // dY channels q0 + u*128 + [0,128) of K-tile kt (row state must describe kt)
+    char* dst = smem + (kt & 1) * WBUF + u * WUNIT + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(dst + j * 8192), 16, voy[j] + qadd0 + (uint32_t)(u * 256), 0, 0, 0);
+  };
+  auto stage_b = [&](int u, int kt) {     // X channels c0 + u*128 + [0,128)
+    char* dst = smem + (kt & 1) * WBUF + (2 + u) * WUNIT + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(dst + j * 8192), 16, vox[j] + cadd0 + (uint32_t)(u * 256), 0, 0, 0);
+  };
+
+  // ---- transposed fragment reads: lane 4q+p of a 16-lane group addresses pixel row q, channels 4p..4p+3 of the 16-channel block
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = lane >> 4;
+  const int tswz = tq | ((tg & 1) << 2);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)SOD_LDS(smem);
+  uint32_t aoff[4], boff[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = (uint32_t)(8 * tg + tq) * 256u + (uint32_t)(((wr * 4 + i) ^ tswz) * 32) + tp * 8;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) boff[j] = 2 * WUNIT + (uint32_t)(8 * tg + tq) * 256u + (uint32_t)(((wc * 2 + j) ^ tswz) * 32) + tp * 8;
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[4][2], bf0[2][2], bf1[2][2];
+  s16x4_t ar[4][2][2], br[2][2][2];       // raw halves [tile][k-step][lo/hi]
+
+#define SODW_READ_A(BASE, U)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
+    const uint32_t ad = (BASE) + (U) * WUNIT + aoff[i];                                        \
+    ar[i][0][0] = tr_read<0>(ad); ar[i][0][1] = tr_read<1024>(ad);                             \
+    ar[i][1][0] = tr_read<8192>(ad); ar[i][1][1] = tr_read<8192 + 1024>(ad);                   \
+  }
+#define SODW_READ_B(BASE, U)                                                                   \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                              \
+    const uint32_t ad = (BASE) + (U) * WUNIT + boff[j];                                        \
+    br[j][0][0] = tr_read<0>(ad); br[j][0][1] = tr_read<1024>(ad);                             \
+    br[j][1][0] = tr_read<8192>(ad); br[j][1][1] = tr_read<8192 + 1024>(ad);                   \
+  }
+#define SODW_PACK_A                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) { af[i][0] = pack8(ar[i][0][0], ar[i][0][1]); af[i][1] = pack8(ar[i][1][0], ar[i][1][1]); }
+#define SODW_PACK_B(BFR)                                                                       \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) { BFR[j][0] = pack8(br[j][0][0], br[j][0][1]); BFR[j][1] = pack8(br[j][1][0], br[j][1][1]); }
+
+  // ---- prologue: K-tile 0 complete, first two units of K-tile 1
+  init_rows(vbeg - g.v0);
+  stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
+  advance(1);
+  stage_a(0, 1); stage_b(0, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();       // wave row 1 runs one barrier behind wave row 0
+
+  for (int k = 0; k < T; ++k) {
+    const uint32_t cur = lds0 + (uint32_t)((k & 1) * WBUF);
+    // phase 0: quadrant (a0, b0)
+    SODW_READ_B(cur, 0)
+    SODW_READ_A(cur, 0)
+    SODW_PHASE(0, 0, bf0, SODW_PACK_B(bf0) SODW_PACK_A, stage_b(1, k + 1))
+    // phase 1: quadrant (a0, b1)
+    SODW_READ_B(cur, 1)
+    SODW_PHASE(0, 1, bf1, SODW_PACK_B(bf1), stage_a(1, k + 1))
+    // phase 2: quadrant (a1, b1); the row state moves on to K-tile k+2 inside the MFMA cluster
+    SODW_READ_A(cur, 1)
+    SODW_PHASE(1, 1, bf1, SODW_PACK_A, advance(k + 2); stage_a(0, k + 2))
+    // phase 3: quadrant (a1, b0), b0 still in registers
+    SODW_PHASE(1, 0, bf0, , stage_b(0, k + 2))
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: the partial tile goes to the workspace in FRAGMENT order (16 B per lane, 1 KB per wave instruction)
+  float* slab = a.partial + ((size_t)z * (size_t)(a.QT * a.CT * RS) + (size_t)tile) * SLAB + (size_t)wave * (32 * 256) + (size_t)lane * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(slab + (i * 4 + j) * 256) = acc[i][j];
+}
+
+// Sums the nz slabs of every tile in z order and adds the result into dW.  One thread = one float4 of the fragment-ordered slab.
+__global__ __launch_bounds__(256) void wgrad256_reduce_kernel(const WgradArgs a) {
+  const int RS = a.R * a.S, tiles = a.QT * a.CT * RS;
+  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;        // < tiles * 16384
+  const int lane = idx & 63, frag = (idx >> 6) & 255, tile = (int)(idx >> 14);
+  if (tile >= tiles) return;
+  const float* src = a.partial + (size_t)tile * SLAB + (size_t)(idx & 16383u) * 4;
+  const size_t zstride = (size_t)tiles * SLAB;
+  f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int zz = 0;
+  for (; zz + 4 <= a.nz; zz += 4) {     // four independent loads in flight; the summation ORDER is fixed by the code, not by timing
+    const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(src + (size_t)zz * zstride);
+    const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(src + (size_t)(zz + 1) * zstride);
+    const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(src + (size_t)(zz + 2) * zstride);
+    const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(src + (size_t)(zz + 3) * zstride);
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  }
+  for (; zz < a.nz; ++zz) s0 += *reinterpret_cast<const f32x4_t*>(src + (size_t)zz * zstride);
+  const f32x4_t sum = (s0 + s1) + (s2 + s3);
+  const int wave = frag >> 5, i = (frag >> 2) & 7, j = frag & 3;
+  const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, fg = lane >> 4;
+  const int tap = tile % RS, ct = (tile / RS) % a.CT, qt = tile / (RS * a.CT);
+  const int c = ct * 256 + (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + fr;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int q = qt * 256 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fg * 4 + e;
+    float* dst = a.dw + ((size_t)q * RS + tap) * a.C + c;
+    *dst += sum[e] * (a.qscale ? a.qscale[q] : 1.f);
+  }
+}
+
+int splits_for(const WgradArgs& a, int cus, int* vps_out) {
+  const int tiles = (a.K / 256) * (a.C / 256) * a.R * a.S;
+  int V = 0;
+  for (int l = 0; l < a.nlev; ++l) V += (a.lev[l].P + 63) / 64 * 64;
+  const int kt = V / 64;
+  int nz = cus / tiles;
+  if (nz < 1) nz = 1;
+  if (nz > kt) nz = kt;
+  int per = (kt + nz - 1) / nz;          // K-tiles per block
+  nz = (kt + per - 1) / per;
+  *vps_out = per * 64;
+  return nz;
+}
+
+}  // namespace
+
+bool wgrad256_supported(const WgradArgs& a) {
+  if ((a.K & 255) || (a.C & 255)) return false;
+  long long V = 0;
+  for (int l = 0; l < a.nlev; ++l) V += (a.lev[l].P + 63) / 64 * 64;
+  return V >= 64 && V < (1ll << 30);
+}
+
+long long wgrad256_workspace_bytes(const WgradArgs& a, int cus) {
+  int vps = 0;
+  const int nz = splits_for(a, cus, &vps);
+  const long long tiles = (long long)(a.K / 256) * (a.C / 256) * a.R * a.S;
+  return (long long)nz * tiles * SLAB * (long long)sizeof(float);
+}
+
+int launch_wgrad256(WgradArgs& a, int cus, float* ws, long long ws_bytes, hipStream_t st) {
+  if (!wgrad256_supported(a)) return SOD_EARG;
+  a.QT = a.K / 256; a.CT = a.C / 256;
+  const int tiles = a.QT * a.CT * a.R * a.S;
+  int V = 0;
+  for (int l = 0; l < a.nlev; ++l) {
+    a.lev[l].v0 = V;
+    V += (a.lev[l].P + 63) / 64 * 64;
+  }
+  a.V = V;
+  int vps = 0;
+  a.nz = splits_for(a, cus, &vps);
+  a.v_per_split = vps;
+  a.div_s = make_fastdiv((uint32_t)a.S);
+  const long long need = (long long)a.nz * tiles * SLAB * (long long)sizeof(float);
+  if (!ws || need > ws_bytes) return SOD_EARG;
+  if ((long long)tiles * 16384 >= (1ll << 31)) return SOD_ESIZE;
+  a.partial = ws;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WLDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  SOD_LAUNCH(conv_wgrad256_kernel, dim3(a.nz * tiles), dim3(512), WLDS_BYTES, st, a);
+  SOD_LAUNCH(wgrad256_reduce_kernel, dim3(tiles * 64), dim3(256), 0, st, a);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+}  // namespace sodconv

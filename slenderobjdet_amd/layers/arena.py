@@ -67,6 +67,7 @@ class ParamArena:
                     self._bucket_of[id(p)] = bi
         self._pending = None
         self._uses = {}
+        self._counting = True
         self._comm_stream = None
         self._handles = []
 
@@ -129,8 +130,21 @@ class ParamArena:
 
     # ------------------------------------------------------------------ data parallel
     def note_use(self, p):
-        """Called in forward for every use of a trainable parameter (shared head weights are used once per level)."""
+        """Called in forward for every use of a trainable parameter (shared head weights are used once per level).  Forwards that
+        build no graph (torch.no_grad(): evaluation hooks between steps, smoke checks) must not count: their uses would never be
+        matched by a mark_ready and every bucket of the next step would wait for finish_backward instead of overlapping."""
+        if not self._counting:
+            return
         self._uses[id(p)] = self._uses.get(id(p), 0) + 1
+
+    def on_forward(self, recording):
+        """Forward pre-hook of the model that owns the arena (layers/nn.py:attach_arena).  ``recording`` = grad mode is on and the
+        model is training: only such forwards are followed by a backward pass.  (note_use itself runs inside
+        autograd.Function.forward, where grad mode always reads off.)  A recording forward starts a fresh count: uses left over by
+        a forward whose backward never ran would otherwise keep the buckets from launching early."""
+        self._counting = bool(recording)
+        if recording:
+            self._uses.clear()
 
     def begin_backward(self):
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1

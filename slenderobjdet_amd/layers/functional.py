@@ -19,13 +19,13 @@ PROFILE = None
 PROFILE_KINDS = None      # optional set of kinds to time (None = all); bench.py times only the forward conv launches by default
 
 
-PROFILE_LIB = False       # forward convs are timed by the library's own hipEvent pairs (sod_conv_prof_*), not by torch events
+PROFILE_LIB = False       # conv launches are timed by the library's own hipEvent pairs (sod_conv_prof_*), not by torch events
 
 
 def _prof_begin(stream=None, kind=None):
     if PROFILE is None or (PROFILE_KINDS is not None and kind not in PROFILE_KINDS):
         return None
-    if PROFILE_LIB and kind == "conv_fwd":
+    if PROFILE_LIB and kind in ("conv_fwd", "conv_dgrad", "conv_wgrad"):
         return "lib"
     e = torch.cuda.Event(enable_timing=True)
     e.record(stream)
@@ -135,7 +135,7 @@ def conv_out_size(H, W, R, S, stride, pad, dil):
 
 
 def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, res_up2=False, out_f32=False,
-               out=None, y_img_stride=0, x_img_stride=0, x_shape=None):
+               out=None, y_img_stride=0, x_img_stride=0, x_shape=None, c_real=None):
     """x (N,H,W,C) bf16, w (K,R,S,C) bf16 -> y (N,Ho,Wo,K). ``out``/``y_img_stride`` let the result land inside a
     larger (N, L, K) buffer; ``x_shape`` overrides (N,H,W,C) when x is such a view."""
     _chk(x, torch.bfloat16, "x"); _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias"); _chk(res, torch.bfloat16, "res")
@@ -150,7 +150,8 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
     e0 = _prof_begin(None, "conv_fwd")
     call("sod_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
          x_img_stride, y_img_stride, 0, flags, 1 if out_f32 else 0, stream_ptr())
-    _prof_end("conv_fwd", 2.0 * N * Ho * Wo * K * R * S * C, e0, (N, H, W, C, K, R, stride))
+    # c_real / k_real: un-padded channel counts, so that the profile counts ALGORITHMIC work (stem: 3 of its 8 input channels)
+    _prof_end("conv_fwd", 2.0 * N * Ho * Wo * K * R * S * (c_real or C), e0, (N, H, W, C, K, R, stride))
     return out
 
 
@@ -170,32 +171,38 @@ def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=Non
     return out
 
 
+# Deterministic reductions (weight-gradient pixel splits and GroupNorm statistics summed in a fixed order, no float atomics): the
+# results are bit-identical from run to run.  Off by default (the atomic forms are a little faster on the few-tile shapes);
+# SOD_DETERMINISTIC=1 or ``functional.DETERMINISTIC = True`` turns it on (the loss-parity tests do).
+DETERMINISTIC = os.environ.get("SOD_DETERMINISTIC", "0") == "1"
+WGRAD_DETERMINISTIC = 1     # slender_hip.h SOD_WGRAD_DETERMINISTIC
+
 _wgrad_ws = {}
 
 
-def _ensure_wgrad_ws(device):
-    """Registers (once per device) the scratch the opt-in two-stage weight-gradient reduction uses (SOD_WGRAD_TWO_STAGE=1)."""
-    if os.environ.get("SOD_WGRAD_TWO_STAGE") != "1":
-        return
-    if device.index not in _wgrad_ws:
-        ws = torch.empty(40 << 20, dtype=torch.uint8, device=device)
-        call("sod_conv_set_workspace", ptr(ws), ws.numel())
-        _wgrad_ws[device.index] = ws
+def wgrad_workspace(device, stream=None):
+    """Per-(device, stream) scratch for the weight-gradient slabs (caller-owned, used in stream order by one launch at a time)."""
+    key = (device.index, (stream or torch.cuda.current_stream(device)).cuda_stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None:
+        ws = _wgrad_ws[key] = torch.empty(int(_C.load().sod_conv2d_wgrad_workspace_bytes()), dtype=torch.uint8, device=device)
+    return ws
 
 
-def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img_stride=0, K=None, x_shape=None, splits=0, qscale=None):
+def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img_stride=0, K=None, x_shape=None, splits=0, qscale=None,
+                 k_real=None, c_real=None):
     """Accumulates into dw (K,R,S,C) fp32."""
     _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(dw, torch.float32, "dw")
-    _ensure_wgrad_ws(dw.device)
     N, H, W, C = x_shape if x_shape is not None else x.shape
     if K is None:
         K = dy.shape[-1]
     side = _wgrad_stream(dw.device, (dy, x))
+    ws = wgrad_workspace(dw.device, side)
     e0 = _prof_begin(side, "conv_wgrad")
     call("sod_conv2d_wgrad", ptr(dy), ptr(x), ptr(dw), ptr(qscale), N, H, W, C, K, R, S, stride, pad, dil, dy_img_stride, x_img_stride,
-         splits, stream_ptr(side))
+         splits, WGRAD_DETERMINISTIC if DETERMINISTIC else 0, ptr(ws), ws.numel(), stream_ptr(side))
     Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
-    _prof_end("conv_wgrad", 2.0 * N * Ho * Wo * K * R * S * C, e0, (N, H, W, C, K, R, stride), side)
+    _prof_end("conv_wgrad", 2.0 * N * Ho * Wo * (k_real or K) * R * S * (c_real or C), e0, (N, H, W, C, K, R, stride), side)
     return dw
 
 
@@ -203,7 +210,7 @@ def _ptr_arr(ts):
     return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
 
 
-def conv2d_fwd_ml(xs, w, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, outs=None, y_img_stride=0):
+def conv2d_fwd_ml(xs, w, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=False, outs=None, y_img_stride=0, k_real=None):
     """One launch over several (N,Hl,Wl,C) tensors that share the weights (FPN levels). Returns the list of outputs."""
     _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias")
     for x in xs:
@@ -219,12 +226,12 @@ def conv2d_fwd_ml(xs, w, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=
     e0 = _prof_begin(None, "conv_fwd")
     call("sod_conv2d_fwd_ml", len(xs), _ptr_arr(xs), ptr(w), ptr(bias), _ptr_arr(outs), N, _int_arr(hs), _int_arr(ws), C, K, R, S,
          stride, pad, dil, y_img_stride, CONV_RELU if relu else 0, 1 if out_f32 else 0, stream_ptr())
-    fl = sum(2.0 * N * ho * wo * K * R * S * C for ho, wo in (conv_out_size(h, wd, R, S, stride, pad, dil) for h, wd in zip(hs, ws)))
+    fl = sum(2.0 * N * ho * wo * (k_real or K) * R * S * C for ho, wo in (conv_out_size(h, wd, R, S, stride, pad, dil) for h, wd in zip(hs, ws)))
     _prof_end("conv_fwd", fl, e0, ("ml", N, tuple(hs), C, K, R, stride))
     return outs
 
 
-def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=None):
+def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=None, k_real=None):
     """dys: per-level dY tensors (or 1-D views into a concatenated buffer with dy_img_stride); returns per-level dX."""
     _chk(wt, torch.bfloat16, "wt")
     C, R, S, K = wt.shape
@@ -235,24 +242,24 @@ def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=N
     e0 = _prof_begin(None, "conv_dgrad")
     call("sod_conv2d_dgrad_ml", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]), _int_arr([w for _, w in x_hws]),
          C, K, R, S, stride, pad, dil, dy_img_stride, stream_ptr())
-    fl = sum(2.0 * N * ho * wo * K * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in x_hws))
+    fl = sum(2.0 * N * ho * wo * (k_real or K) * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in x_hws))
     _prof_end("conv_dgrad", fl, e0, ("ml", N, tuple(h for h, _ in x_hws), C, K, R, stride))
     return outs
 
 
-def conv2d_wgrad_ml(dys, xs, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, K=None, splits=0, qscale=None):
+def conv2d_wgrad_ml(dys, xs, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, K=None, splits=0, qscale=None, k_real=None):
     """Accumulates the weight gradient over all levels in one launch."""
     _chk(dw, torch.float32, "dw")
-    _ensure_wgrad_ws(dw.device)
     N, C = xs[0].shape[0], xs[0].shape[3]
     if K is None:
         K = dys[0].shape[-1]
-    hs, ws = [x.shape[1] for x in xs], [x.shape[2] for x in xs]
+    hs, ws_ = [x.shape[1] for x in xs], [x.shape[2] for x in xs]
     side = _wgrad_stream(dw.device, list(dys) + list(xs))
+    ws = wgrad_workspace(dw.device, side)
     e0 = _prof_begin(side, "conv_wgrad")
-    call("sod_conv2d_wgrad_ml", len(xs), _ptr_arr(dys), _ptr_arr(xs), ptr(dw), ptr(qscale), N, _int_arr(hs), _int_arr(ws), C, K, R, S,
-         stride, pad, dil, dy_img_stride, splits, stream_ptr(side))
-    fl = sum(2.0 * N * ho * wo * K * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in zip(hs, ws)))
+    call("sod_conv2d_wgrad_ml", len(xs), _ptr_arr(dys), _ptr_arr(xs), ptr(dw), ptr(qscale), N, _int_arr(hs), _int_arr(ws_), C, K, R, S,
+         stride, pad, dil, dy_img_stride, splits, WGRAD_DETERMINISTIC if DETERMINISTIC else 0, ptr(ws), ws.numel(), stream_ptr(side))
+    fl = sum(2.0 * N * ho * wo * (k_real or K) * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in zip(hs, ws_)))
     _prof_end("conv_wgrad", fl, e0, ("ml", N, tuple(hs), C, K, R, stride), side)
     return dw
 

@@ -148,7 +148,7 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, weight, mod, res_up2):
         y = HF.conv2d_fwd(x, mod.w_bf16, mod.bias_eff, res, mod.stride, mod.padding, mod.dilation, relu=mod.relu, res_up2=res_up2,
-                          out_f32=mod.out_f32)
+                          out_f32=mod.out_f32, c_real=mod.in_channels if mod.cin_pad else None)
         ctx.mod, ctx.res_up2, ctx.has_res = mod, res_up2, res is not None
         train_w = mod.weight.requires_grad
         if train_w or x.requires_grad or (res is not None and res.requires_grad):
@@ -448,3 +448,5 @@ class Scale(nn.Module):
 def attach_arena(model, arena):
     for m in model.modules():
         m._arena = arena
+    # uses are counted only in forwards that will be followed by a backward pass (ParamArena.on_forward)
+    model.register_forward_pre_hook(lambda mod, inputs: arena.on_forward(torch.is_grad_enabled() and mod.training))

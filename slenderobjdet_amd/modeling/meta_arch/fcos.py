@@ -146,9 +146,9 @@ class FCOSHead(nn.Module):
             offs.append(off)
             off += h * w
         HF.conv2d_fwd_ml(list(cls_t), self.cls_pred.w_bf16, self.cls_pred.bias_eff, 1, 1, 1, out_f32=True,
-                         outs=[cls_buf.view(-1)[o * self.kc_pad:] for o in offs], y_img_stride=L * self.kc_pad)
+                         outs=[cls_buf.view(-1)[o * self.kc_pad:] for o in offs], y_img_stride=L * self.kc_pad, k_real=self.kc)
         HF.conv2d_fwd_ml(list(box_t), self.box_pred.w_bf16, self.box_pred.bias_eff, 1, 1, 1, out_f32=True,
-                         outs=[box_buf.view(-1)[o * 8:] for o in offs], y_img_stride=L * 8)
+                         outs=[box_buf.view(-1)[o * 8:] for o in offs], y_img_stride=L * 8, k_real=5 if self.centerness_on_reg else 4)
         return cls_buf, box_buf, hw
 
 
@@ -212,13 +212,13 @@ class _FcosHeadLossFn(torch.autograd.Function):
             offs.append(off)
             off += h * w
         grads = []
-        for pred, dbuf, kk, tower in ((head.cls_pred, dcls, kcp, cls_t), (head.box_pred, dbox, 8, box_t)):
+        for pred, dbuf, kk, tower, kr in ((head.cls_pred, dcls, kcp, cls_t, head.kc), (head.box_pred, dbox, 8, box_t, 5 if head.centerness_on_reg else 4)):
             dys = [dbuf.view(-1)[o * kk:] for o in offs]
-            HF.conv2d_wgrad_ml(dys, list(tower), arena.grad_view(pred.weight), 3, 3, 1, 1, 1, dy_img_stride=L * kk, K=kk)
+            HF.conv2d_wgrad_ml(dys, list(tower), arena.grad_view(pred.weight), 3, 3, 1, 1, 1, dy_img_stride=L * kk, K=kk, k_real=kr)
             arena.mark_ready(pred.weight)
             HF.bias_grad(dbuf, arena.grad_view(pred.bias), N, L, kk)
             arena.mark_ready(pred.bias)
-            grads.append(HF.conv2d_dgrad_ml(dys, pred.wt_bf16, hw, 1, 1, 1, dy_img_stride=L * kk, N=N))
+            grads.append(HF.conv2d_dgrad_ml(dys, pred.wt_bf16, hw, 1, 1, 1, dy_img_stride=L * kk, N=N, k_real=kr))
         grads_cls, grads_box = grads
         return (None, None, None, None, None, None, None, *grads_cls, *grads_box)
 

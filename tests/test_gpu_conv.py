@@ -170,6 +170,96 @@ def test_conv_wgrad(cuda, case):
     _close(dw, 2 * dw_ref, 2e-4, f"wgrad accumulate {case}")
 
 
+# the 256x256 8-wave weight-gradient kernel (conv_wgrad256.hip), forced with splits = -1: (N, H, W, C, K, R, stride, pad, dil)
+WGRAD256_CASES = [
+    (2, 40, 72, 256, 256, 3, 1, 1, 1),     # incremental row path (Wo >= 64), 9 tiles, column and image wraps
+    (2, 13, 21, 256, 256, 3, 1, 1, 1),     # division path (Wo < 64), ragged last K-tile
+    (1, 9, 70, 512, 256, 1, 1, 0, 1),      # 1x1, two channel tiles
+    (2, 16, 24, 256, 512, 1, 2, 0, 1),     # stride-2 1x1 (shortcut), two output-channel tiles
+    (1, 10, 66, 256, 256, 3, 1, 2, 2),     # dilation on the incremental path
+    (1, 3, 5, 256, 256, 3, 1, 1, 1),       # a single, mostly padded K-tile
+    (3, 25, 42, 512, 512, 3, 1, 1, 1),     # res5 conv2 geometry: 36 tiles
+]
+
+
+@pytest.mark.parametrize("case", WGRAD256_CASES)
+def test_conv_wgrad256(cuda, case):
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K, R, st, pad, dil = case
+    x = _rand((N, H, W, C), 1)
+    w = _rand((K, R, R, C), 2, 0.05)
+    Ho, Wo = HF.conv_out_size(H, W, R, R, st, pad, dil)
+    dy = _rand((N, Ho, Wo, K), 3)
+    _, dw_ref = onn.conv2d_backward(x, w, dy, st, pad, dil)
+    qs = torch.rand(K, generator=torch.Generator().manual_seed(5)) + 0.5
+    dyd, xd = dy.to(cuda).bfloat16(), x.to(cuda).bfloat16()
+    dw = torch.zeros((K, R, R, C), dtype=torch.float32, device=cuda)
+    HF.conv2d_wgrad(dyd, xd, dw, R, R, st, pad, dil, splits=-1)
+    _close(dw, dw_ref, 2e-4, f"wgrad256 {case}")
+    first = dw.clone()
+    HF.conv2d_wgrad(dyd, xd, dw, R, R, st, pad, dil, splits=-1)      # accumulation semantics
+    _close(dw, 2 * dw_ref, 2e-4, f"wgrad256 accumulate {case}")
+    dw2 = torch.zeros_like(dw)
+    HF.conv2d_wgrad(dyd, xd, dw2, R, R, st, pad, dil, splits=-1)     # fixed summation order: bit-identical from run to run
+    assert torch.equal(dw2, first)
+    dw3 = torch.zeros_like(dw)
+    HF.conv2d_wgrad(dyd, xd, dw3, R, R, st, pad, dil, splits=-1, qscale=qs.to(cuda))
+    _close(dw3, dw_ref * qs.view(-1, 1, 1, 1), 2e-4, f"wgrad256 qscale {case}")
+
+
+def test_conv_wgrad256_multilevel(cuda):
+    """One launch over three levels that share the weights (the FCOS tower geometry): the virtual pixel index crosses levels and
+    switches between the incremental and the division row paths."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, C, K = 2, 256, 256
+    hws = [(20, 68), (10, 34), (5, 17)]
+    xs = [_rand((N, h, w, C), 10 + i) for i, (h, w) in enumerate(hws)]
+    dys = [_rand((N, h, w, K), 20 + i) for i, (h, w) in enumerate(hws)]
+    wz = torch.zeros((K, 3, 3, C))
+    ref = sum(onn.conv2d_backward(x, wz, dy, 1, 1, 1)[1] for x, dy in zip(xs, dys))
+    dw = torch.zeros((K, 3, 3, C), dtype=torch.float32, device=cuda)
+    HF.conv2d_wgrad_ml([d.to(cuda).bfloat16() for d in dys], [x.to(cuda).bfloat16() for x in xs], dw, 3, 3, 1, 1, 1, splits=-1)
+    _close(dw, ref, 2e-4, "wgrad256 multi-level")
+
+
+def test_conv_wgrad256_rejects_unsupported(cuda):
+    from slenderobjdet_amd import _C
+    from slenderobjdet_amd.layers import functional as HF
+
+    dy = torch.zeros((1, 8, 8, 128), dtype=torch.bfloat16, device=cuda)      # K = 128: not a multiple of 256
+    x = torch.zeros((1, 8, 8, 256), dtype=torch.bfloat16, device=cuda)
+    dw = torch.zeros((128, 1, 1, 256), dtype=torch.float32, device=cuda)
+    with pytest.raises(_C.SlenderHipError):
+        HF.conv2d_wgrad(dy, x, dw, 1, 1, 1, 0, 1, splits=-1)
+
+
+@pytest.mark.parametrize("case", [(2, 13, 21, 64, 128, 3, 1, 1, 1), (2, 11, 13, 256, 80, 3, 1, 1, 1), (2, 3, 100, 128, 64, 1, 1, 0, 1)])
+def test_conv_wgrad_deterministic_mode(cuda, case):
+    """SOD_WGRAD_DETERMINISTIC: the 128x128 kernel's pixel splits meet in slabs summed in a fixed order (no float atomics)."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K, R, st, pad, dil = case
+    x = _rand((N, H, W, C), 1)
+    w = _rand((K, R, R, C), 2, 0.05)
+    Ho, Wo = HF.conv_out_size(H, W, R, R, st, pad, dil)
+    dy = _rand((N, Ho, Wo, K), 3)
+    _, dw_ref = onn.conv2d_backward(x, w, dy, st, pad, dil)
+    prev = HF.DETERMINISTIC
+    HF.DETERMINISTIC = True
+    try:
+        outs = []
+        for _ in range(3):
+            dw = torch.zeros((K, R, R, C), dtype=torch.float32, device=cuda)
+            HF.conv2d_wgrad(dy.to(cuda).bfloat16(), x.to(cuda).bfloat16(), dw, R, R, st, pad, dil)
+            outs.append(dw)
+    finally:
+        HF.DETERMINISTIC = prev
+    _close(outs[0], dw_ref, 2e-4, f"deterministic wgrad {case}")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_weight_prep(cuda):
     from slenderobjdet_amd.layers import functional as HF
 

@@ -238,7 +238,7 @@ def test_fcos_inference_boxes_scores_and_nms_vs_oracle(cuda):
 
 
 def test_bench_two_ranks_data_parallel(cuda, tmp_path):
-    """bench.py under torch.distributed.run with 2 ranks (both on cuda:0, gloo transport — this box has one GPU): the
+    """``python bench.py --gpus 2`` spawns 2 ranks itself (both on cuda:0, gloo transport — this box has one GPU): the
     bucketed gradient all-reduce, the normaliser all-reduce, parameter broadcast and the JSON contract all execute, and the
     two ranks end with bit-identical parameters."""
     import json
@@ -248,8 +248,8 @@ def test_bench_two_ranks_data_parallel(cuda, tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SOD_BENCH_SHARE_GPU="1", SOD_BENCH_DUMP_PARAMS=str(tmp_path))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--depth", "18", "--batch-per-gpu", "2",
+    # bench.py starts its own ranks (as train_net.py does through detectron2's launch): no launcher around it here
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--depth", "18", "--batch-per-gpu", "2",
            "--height", "256", "--width", "320", "--no-roofline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]

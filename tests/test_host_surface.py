@@ -248,3 +248,24 @@ def test_reference_train_net_imports_and_builds_under_dropin(tmp_path):
             cfg[k] = snapshot[k]
         if was_frozen:
             cfg.freeze()
+
+
+def test_bench_gpus_flag_fails_loudly_without_the_gpus():
+    """``python bench.py --gpus N`` starts N ranks itself; on a node with fewer than N GPUs it must refuse (exit 2, message),
+    not silently run one rank (round-1 finding).  A launcher whose WORLD_SIZE disagrees with --gpus is refused too."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 2
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SOD_BENCH_SHARE_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode == 2 and f"--gpus {n}" in out.stderr, (out.returncode, out.stderr[-500:])
+    assert not any(l.startswith("{") for l in out.stdout.splitlines())
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=root)
+    assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
