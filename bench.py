@@ -143,7 +143,7 @@ def kernel_name(kind, code):
     return variant_kernel_name(code, KIND_MODE[kind])
 
 
-def roofline_report(prof, prof_steps, args, side_stream):
+def roofline_report(prof, prof_steps, args):
     """`roofline` = the conv kernel with the most GPU time in the sampled steps (duration = hipEvent interval on its launch
     stream, algorithmic FLOPs = 2*N*Ho*Wo*K*R*S*C with UN-padded channel counts); every other kernel in `kernels`;
     `backbone_convs` = ResNet body + FPN, the convolutions north_star's >= 0.5 x MFMA target is stated for; `head_convs` = the rest."""
@@ -165,21 +165,18 @@ def roofline_report(prof, prof_steps, args, side_stream):
     fl, sec, cnt = by_k[dom]
     kname = kernel_name(*dom)
     tr = pmc_traffic(dom[0], kname)
-    overlapped = bool(side_stream)
     rep = {"bound": "mfma", "kernel": kname, "achieved": round(fl / sec / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4), "traffic": (tr or {}).get("hbm_bytes_per_launch"),
            "traffic_source": (tr or {}).get("source"),
            "selection": "kernel with the largest share of conv GPU time in the sampled steps", "launches": cnt, "sampled_steps": prof_steps,
            "avg_launch_us": round(sec / cnt * 1e6, 2), "ms_per_step": round(sec / prof_steps * 1e3, 3),
-           "flops": "algorithmic, un-padded channels", "backward_kernels_overlap": overlapped,
+           "flops": "algorithmic, un-padded channels",
+           "sampling": "every 8th timed step; sampled steps run the weight gradients on the main stream so that every interval is one kernel's duration",
            "kernels": [row(v, kernel_name(*k)) for k, v in sorted(by_k.items(), key=lambda kv: -kv[1][1])],
            "by_pass": {k: row(v) for k, v in kinds.items()}}
     if args.arch == "fcos":
-        # with two backward streams the per-kernel intervals of dgrad and wgrad overlap in wall time: the sum of intervals is an
-        # UPPER bound of the GPU time those convs take, so these fractions are lower bounds
         for gname, v in groups.items():
             rep[gname] = row(v)
-            rep[gname]["note"] = "sum of per-launch intervals; backward intervals overlap in wall time (lower bound)" if overlapped else "sum of per-launch intervals"
     return rep
 
 
@@ -336,13 +333,16 @@ def main():
     torch.cuda.synchronize()
     if not args.no_roofline:
         # The library records one hipEvent pair on the LAUNCH stream around the main kernel of every conv dispatch (forward, data
-        # gradient, weight gradient: sod_conv_prof_enable) of the sampled steps.  Inside backward the data-gradient chain (main
-        # stream) and the weight gradients (side stream, layers/functional.py) share the GPU, so a backward kernel's interval is its
-        # duration AS EXECUTED in the step (rocprofv3 --kernel-trace reports the same begin/end), not its stand-alone time.
-        # An event pair costs a few us of queue bubbles, so only every 8th timed step carries them (all steps with --dump-prof).
+        # gradient, weight gradient: sod_conv_prof_enable) of the sampled steps.  In a normal step the data-gradient chain (main
+        # stream) and the weight gradients (side stream, layers/functional.py) share the GPU, and the interval of a backward kernel
+        # would then include the time it shares the chip with another kernel.  The SAMPLED steps therefore launch the weight
+        # gradients on the main stream (what SOD_WGRAD_STREAM=0 does for a whole run; profiles/*_serial_kernel_stats.csv is the
+        # rocprofv3 summary of such a run): intervals are per-kernel durations.  A sampled step is ~5 % slower and carries a few us
+        # of queue bubbles per event pair, so only every 8th timed step is sampled (all steps with --dump-prof); `value` includes them.
         HF.PROFILE_KINDS = None
         HF.PROFILE_LIB = True
     prof_all, prof_steps = [], 0
+    side_default = HF.WGRAD_SIDE_STREAM
     t0 = time.perf_counter()
     for i in range(args.steps):
         sample = (not args.no_roofline) and bool(args.dump_prof or i % 8 == 0) and prof_steps < 12     # the library keeps 8192 event pairs
@@ -350,7 +350,9 @@ def main():
         if HF.PROFILE_LIB:
             _C.call("sod_conv_prof_enable", 1 if sample else 0)
         prof_steps += int(sample)
+        HF.WGRAD_SIDE_STREAM = side_default and not sample
         last = train_step(model, optimizer, next(loader))
+    HF.WGRAD_SIDE_STREAM = side_default
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -392,7 +394,7 @@ def main():
         if args.arch == "fcos" and args.depth == 50:
             out["model_tflops"] = round(imgs * TRAIN_FLOP_PER_IMAGE / dt / 1e12, 2)
         if prof:
-            out["roofline"] = roofline_report(prof, prof_steps, args, HF.WGRAD_SIDE_STREAM)
+            out["roofline"] = roofline_report(prof, prof_steps, args)
         if prof and args.dump_prof:
             per = {}
             for kind, flops, sec_, desc, _variant in prof:

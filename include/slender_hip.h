@@ -106,20 +106,25 @@ int sod_conv_prof_collect(float* ms, int* variant, float* frac, int* mode, int m
 /* ---------------------------------------------------------------------------------------------------------
  * GroupNorm (+ fused ReLU), NHWC bf16 — nn.GroupNorm(32, C) + nn.ReLU in FCOSHead (fcosv2.py:315-336).
  * mean_rstd: [N][G][2] fp32 (saved for backward). C/G must be a multiple of 8.
+ * det_ws / det_ws_bytes (also sod_bias_grad): optional caller-owned fp32 scratch.  NULL: block partial sums meet in float atomics
+ * (run-to-run differences in the last bits).  Non-NULL: deterministic mode - every block stores its partials into the scratch and a
+ * second kernel adds them in a fixed order (bit-identical results; SOD_EARG if the scratch is too small:
+ * 4 * blocks * N * (C/4 + 3*C) bytes with blocks <= 1024/N + levels; sod_conv2d_wgrad_workspace_bytes() always suffices).
  * --------------------------------------------------------------------------------------------------------- */
 int sod_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd,
-                      int N, int HW, int C, int G, long long img_stride, float eps, int relu, void* stream);
+                      int N, int HW, int C, int G, long long img_stride, float eps, int relu,
+                      float* det_ws, long long det_ws_bytes, void* stream);
 int sod_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean_rstd,
                       void* dx, float* dgamma, float* dbeta, float* dxsum /* optional [C]: += sum over pixels of dx = bias
                       gradient of the convolution that produced x */, float* red_ws /* 2*N*G floats */,
-                      int N, int HW, int C, int G, long long img_stride, int relu, void* stream);
+                      int N, int HW, int C, int G, long long img_stride, int relu, float* det_ws, long long det_ws_bytes, void* stream);
 /* The same GroupNorm over several FPN levels that share gamma/beta (FCOS / RepPoints towers): one launch per pass instead of one per
  * level. x/y/dy/dx: arrays of nlev device pointers (dense (N,hw[l],C) bf16); mean_rstd / red_ws: nlev consecutive [N][G][2] blocks. */
 int sod_groupnorm_fwd_ml(int nlev, const void* const* x, const float* gamma, const float* beta, void* const* y, float* mean_rstd,
-                         int N, const int* hw, int C, int G, float eps, int relu, void* stream);
+                         int N, const int* hw, int C, int G, float eps, int relu, float* det_ws, long long det_ws_bytes, void* stream);
 int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void* const* x, const float* gamma, const float* beta,
                          const float* mean_rstd, void* const* dx, float* dgamma, float* dbeta, float* dxsum, float* red_ws,
-                         int N, const int* hw, int C, int G, int relu, void* stream);
+                         int N, const int* hw, int C, int G, int relu, float* det_ws, long long det_ws_bytes, void* stream);
 
 /* elementwise helpers on bf16 tensors of n elements (n % 8 == 0) */
 int sod_relu_fwd(const void* x, void* y, long long n, void* stream);
@@ -129,7 +134,7 @@ int sod_add_bf16(const void* a, const void* b, void* out, long long n, void* str
  * between the lateral conv and the sum, so it cannot ride in the conv epilogue); the configs under configs/rep-points use NORM: "GN" */
 int sod_add_up2_bf16(const void* a, const void* b, void* out, int N, int H, int W, int C, void* stream);
 /* dbias[c] += sum over (n, pixel) of dy — bias gradient of nn.Conv2d(bias=True) */
-int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C, long long img_stride, void* stream);
+int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C, long long img_stride, float* det_ws, long long det_ws_bytes, void* stream);
 /* d2 BasicStem: F.max_pool2d(x, kernel_size=3, stride=2, padding=1) */
 int sod_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, void* stream);
 /* backward of F.interpolate(scale_factor=2, mode="nearest") in d2 FPN */

@@ -28,15 +28,15 @@ _SIGS = {
     "sod_conv2d_fwd_ml": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P],
     "sod_conv2d_dgrad_ml": [_I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "sod_conv2d_wgrad_ml": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P, _L, _P],
-    "sod_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _F, _I, _P],
-    "sod_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
-    "sod_groupnorm_fwd_ml": [_I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P],
-    "sod_groupnorm_bwd_ml": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
+    "sod_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _F, _I, _P, _L, _P],
+    "sod_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P, _L, _P],
+    "sod_groupnorm_fwd_ml": [_I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _F, _I, _P, _L, _P],
+    "sod_groupnorm_bwd_ml": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _L, _P],
     "sod_relu_fwd": [_P, _P, _L, _P],
     "sod_relu_bwd": [_P, _P, _P, _L, _P],
     "sod_add_bf16": [_P, _P, _P, _L, _P],
     "sod_add_up2_bf16": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "sod_bias_grad": [_P, _P, _I, _I, _I, _L, _P],
+    "sod_bias_grad": [_P, _P, _I, _I, _I, _L, _P, _L, _P],
     "sod_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
     "sod_upsample2x_bwd": [_P, _P, _I, _I, _I, _I, _P],
     "sod_conv_set_tile256": [_I],

@@ -202,7 +202,11 @@ __global__ __launch_bounds__(256) void dcn_col2im_tile_kernel(const DcnArgs a, i
       if (a.mask && a.mask_logit) m = 1.f / (1.f + expf(-m));
       const bf16x8_t dcv = *reinterpret_cast<const bf16x8_t*>(a.dcols + (pix * taps + tap) * a.C + cch);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dmax = fmaxf(dmax, fabsf((float)dcv[e] * m));
+      for (int e = 0; e < 8; ++e) {
+        const float v = (float)dcv[e] * m;
+        dmax = fmaxf(dmax, fabsf(v));      // fmaxf drops NaNs: they are tracked separately (a NaN gradient must stay a NaN)
+        if (v != v) dmax = __builtin_inff();
+      }
     }
   }
 #pragma unroll
@@ -212,9 +216,13 @@ __global__ __launch_bounds__(256) void dcn_col2im_tile_kernel(const DcnArgs a, i
   dmax = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
   int ex = 0;
   (void)frexpf(dmax, &ex);
-  const float S = ldexpf(1.f, 20 - ex), invS = ldexpf(1.f, ex - 20);
+  // fixed-point quantum: a window cell receives at most 64 pixels x taps contributions of magnitude < 2^ex each, and their sum
+  // must fit an int32: 2^fbits * 64 * taps <= 2^30  (3x3: fbits = 20)
+  int fbits = 30;
+  for (int c = 64 * taps - 1; c > 0; c >>= 1) --fbits;
+  const float S = ldexpf(1.f, fbits - ex), invS = ldexpf(1.f, ex - fbits);
   if (dmax == 0.f) return;   // all-zero gradient tile (e.g. the regression branch away from the few positive locations): nothing to add
-  const bool finite_scale = dmax < 3.0e38f;   // inf: let the float path propagate it
+  const bool finite_scale = dmax < 3.0e38f;   // inf / NaN in the tile: the float atomic path propagates them
   for (int p = pl; p < 64; p += PPI) {
     const int ho = ho0 + (p >> 3), wo = wo0 + (p & 7);
     const bool live = ho < a.Ho && wo < a.Wo;

@@ -22,6 +22,11 @@ struct GnArgs {
   long long img_stride;                     // elements between images
   float eps;
   int pix_per_block;
+  // deterministic mode (caller passed a workspace): blocks store their partial sums, indexed by block, and the gn_det_* kernels add
+  // them up in a fixed order; null = float atomics
+  float* part_grp;   // [gridDim.x][N][C/8][2]   per channel-vector (sum, sumsq) or (s1, s2)
+  float* part_gb;    // [gridDim.x][N][2*C]      dgamma | dbeta
+  float* part_dx;    // [gridDim.x][N][C]        per-channel sum of dx
 };
 
 __device__ __forceinline__ void gn_stats_body(const GnArgs& a, const int bx) {
@@ -48,8 +53,13 @@ __device__ __forceinline__ void gn_stats_body(const GnArgs& a, const int bx) {
     float ts = 0.f, tss = 0.f;
     for (int r = 0; r < rows_per_iter; ++r) { ts += lsum[(r * c8n + threadIdx.x) * 2]; tss += lsum[(r * c8n + threadIdx.x) * 2 + 1]; }
     const int g = ((int)threadIdx.x * 8) / a.cpg;
-    atomicAdd(a.stats + ((long long)n * a.G + g) * 2, ts);
-    atomicAdd(a.stats + ((long long)n * a.G + g) * 2 + 1, tss);
+    if (a.part_grp) {
+      float* dst = a.part_grp + (((size_t)blockIdx.x * a.N + n) * c8n + threadIdx.x) * 2;
+      dst[0] = ts; dst[1] = tss;
+    } else {
+      atomicAdd(a.stats + ((long long)n * a.G + g) * 2, ts);
+      atomicAdd(a.stats + ((long long)n * a.G + g) * 2 + 1, tss);
+    }
   }
 }
 
@@ -57,13 +67,14 @@ __device__ __forceinline__ void gn_stats_body(const GnArgs& a, const int bx) {
 constexpr int GN_MAX_LEVELS = 6;
 struct GnLevel {
   const __bf16* x; const __bf16* dy; __bf16* y; __bf16* dx; float* stats; float* red;
-  long long img_stride; int HW, pix_per_block, blk0; float inv_m;
+  long long img_stride; int HW, pix_per_block, blk0, nblk; float inv_m;
 };
 struct GnML {
   GnLevel lev[GN_MAX_LEVELS];
   int nlev;
   const float* gamma; const float* beta; float* dgamma; float* dbeta; float* dxsum;
   int N, C, G, cpg, relu; float eps;
+  float* part_grp; float* part_gb; float* part_dx;
 };
 
 __device__ __forceinline__ int gn_pick(const GnML& m, GnArgs& a) {
@@ -74,6 +85,7 @@ __device__ __forceinline__ int gn_pick(const GnML& m, GnArgs& a) {
   a.pix_per_block = L.pix_per_block;
   a.gamma = m.gamma; a.beta = m.beta; a.dgamma = m.dgamma; a.dbeta = m.dbeta; a.dxsum = m.dxsum;
   a.N = m.N; a.C = m.C; a.G = m.G; a.cpg = m.cpg; a.relu = m.relu; a.eps = m.eps;
+  a.part_grp = m.part_grp; a.part_gb = m.part_gb; a.part_dx = m.part_dx;
   return l;
 }
 
@@ -157,15 +169,25 @@ __device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx
       const float* src = lsum + (r * c8n + (i >> 3)) * 18 + (i & 7);
       tg += src[0]; tb += src[8];
     }
-    atomicAdd(a.dgamma + i, tg);                   // fp32 accumulation into the grad arena
-    atomicAdd(a.dbeta + i, tb);
+    if (a.part_gb) {
+      float* dst = a.part_gb + ((size_t)blockIdx.x * a.N + n) * (2 * a.C);
+      dst[i] = tg; dst[a.C + i] = tb;
+    } else {
+      atomicAdd(a.dgamma + i, tg);                 // fp32 accumulation into the grad arena
+      atomicAdd(a.dbeta + i, tb);
+    }
   }
   if ((int)threadIdx.x < c8n) {
     float t1 = 0.f, t2 = 0.f;
     for (int r = 0; r < rows_per_iter; ++r) { t1 += lsum[(r * c8n + threadIdx.x) * 18 + 16]; t2 += lsum[(r * c8n + threadIdx.x) * 18 + 17]; }
     const int gg = ((int)threadIdx.x * 8) / a.cpg;
-    atomicAdd(a.red + ((long long)n * a.G + gg) * 2, t1);
-    atomicAdd(a.red + ((long long)n * a.G + gg) * 2 + 1, t2);
+    if (a.part_grp) {
+      float* dst = a.part_grp + (((size_t)blockIdx.x * a.N + n) * c8n + threadIdx.x) * 2;
+      dst[0] = t1; dst[1] = t2;
+    } else {
+      atomicAdd(a.red + ((long long)n * a.G + gg) * 2, t1);
+      atomicAdd(a.red + ((long long)n * a.G + gg) * 2 + 1, t2);
+    }
   }
 }
 
@@ -206,9 +228,46 @@ __device__ __forceinline__ void gn_bwd_apply_body(const GnArgs& a, const int bx,
     for (int i = threadIdx.x; i < a.C; i += 256) {
       float t = 0.f;
       for (int r = 0; r < rows_per_iter; ++r) t += lsum[(r * c8n + (i >> 3)) * 8 + (i & 7)];
-      atomicAdd(a.dxsum + i, t);
+      if (a.part_dx) a.part_dx[((size_t)blockIdx.x * a.N + n) * a.C + i] = t;
+      else atomicAdd(a.dxsum + i, t);
     }
   }
+}
+
+// ---- deterministic second stages (one thread per output; the loops fix the summation order) ----
+// out[(l, n, g)][w] = sum over the blocks of level l and the channel vectors of group g of part_grp[block][n][c8][w];
+// finalize != 0 turns (sum, sumsq) into (mean, rstd) as gn_finalize_stats_kernel does.
+__global__ void gn_det_group_kernel(const GnML m, int finalize) {
+  const GnLevel& L = m.lev[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m.N * m.G) return;
+  const int n = i / m.G, g = i - n * m.G;
+  const int c8n = m.C >> 3, vpg = m.cpg >> 3;
+  float s0 = 0.f, s1 = 0.f;
+  for (int b = L.blk0; b < L.blk0 + L.nblk; ++b) {
+    const float* src = m.part_grp + (((size_t)b * m.N + n) * c8n + (size_t)g * vpg) * 2;
+    for (int v = 0; v < vpg; ++v) { s0 += src[v * 2]; s1 += src[v * 2 + 1]; }
+  }
+  float* dst = (finalize ? L.stats : L.red) + (size_t)i * 2;
+  if (finalize) {
+    const float mean = s0 * L.inv_m;
+    const float var = fmaxf(s1 * L.inv_m - mean * mean, 0.f);
+    dst[0] = mean; dst[1] = rsqrtf(var + m.eps);
+  } else {
+    dst[0] = s0; dst[1] = s1;
+  }
+}
+
+// out[c] += sum_r part[r * ld + c]  for c < cols: 64 columns x 4 row lanes per block, lanes combined as (0+1)+(2+3)
+__global__ __launch_bounds__(256) void col_accumulate_kernel(const float* __restrict__ part, int rows, int cols, int ld, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < cols)
+    for (int r = rl; r < rows; r += 4) s += part[(size_t)r * ld + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) out[c] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnML m) {
@@ -289,7 +348,7 @@ __global__ __launch_bounds__(256) void add_up2_kernel(const __bf16* __restrict__
 
 // bias gradient: db[c] += sum over rows of dy[row][c]; dy rows may be strided per image
 __global__ __launch_bounds__(256) void channel_sum_kernel(const __bf16* __restrict__ dy, float* __restrict__ db,
-                                                          int HW, int C, long long img_stride, int pix_per_block) {
+                                                          int HW, int C, long long img_stride, int pix_per_block, float* __restrict__ part) {
   extern __shared__ float lsum[];   // [256][8] per-thread partials
   const int n = blockIdx.y;
   const int c8n = C >> 3;
@@ -312,7 +371,8 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const __bf16* __restri
   for (int i = threadIdx.x; i < C; i += 256) {
     float t = 0.f;
     for (int r = 0; r < rows_per_iter; ++r) t += lsum[(r * c8n + (i >> 3)) * 8 + (i & 7)];
-    atomicAdd(db + i, t);
+    if (part) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * C + i] = t;      // deterministic mode: col_accumulate_kernel adds the rows
+    else atomicAdd(db + i, t);
   }
 }
 
@@ -608,14 +668,22 @@ static int gn_fill(GnML& m, int nlev, const int* hw, int N, int C, int G, float 
     if (ppb < 64) ppb = 64;
     L.pix_per_block = ppb;
     L.blk0 = blk;
-    blk += (hw[l] + ppb - 1) / ppb;
+    L.nblk = (hw[l] + ppb - 1) / ppb;
+    blk += L.nblk;
     L.inv_m = 1.f / ((float)hw[l] * (float)m.cpg);
   }
   return blk;     // total blocks in x (positive) or a negative status
 }
 
+// Floats of deterministic-mode scratch a GroupNorm call over these levels needs (0 blocks -> 0).
+static long long gn_det_floats(int gx, int N, int C, bool bwd) {
+  const long long rows = (long long)gx * N;
+  return rows * (C / 8) * 2 + (bwd ? rows * 3 * C : 0);
+}
+
 extern "C" int sod_groupnorm_fwd_ml(int nlev, const void* const* x, const float* gamma, const float* beta, void* const* y, float* mean_rstd,
-                                    int N, const int* hw, int C, int G, float eps, int relu, void* stream) {
+                                    int N, const int* hw, int C, int G, float eps, int relu, float* det_ws, long long det_ws_bytes,
+                                    void* stream) {
   if (!x || !gamma || !beta || !y || !mean_rstd) return SOD_EARG;
   GnML m{};
   const int gx = gn_fill(m, nlev, hw, N, C, G, eps, relu, nullptr);
@@ -626,10 +694,17 @@ extern "C" int sod_groupnorm_fwd_ml(int nlev, const void* const* x, const float*
     m.lev[l].x = (const __bf16*)x[l]; m.lev[l].y = (__bf16*)y[l]; m.lev[l].stats = mean_rstd + (size_t)l * N * G * 2;
   }
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(mean_rstd, 0, sizeof(float) * 2 * N * G * nlev, st);
-  if (e != hipSuccess) return (int)e;
-  SOD_LAUNCH(gn_stats_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * 256, st, m);
-  SOD_LAUNCH(gn_finalize_stats_kernel, dim3((N * G + 255) / 256, nlev), dim3(256), 0, st, m);
+  if (det_ws) {
+    if (gn_det_floats(gx, N, C, false) * (long long)sizeof(float) > det_ws_bytes) return SOD_EARG;
+    m.part_grp = det_ws;
+    SOD_LAUNCH(gn_stats_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * 256, st, m);
+    SOD_LAUNCH(gn_det_group_kernel, dim3((N * G + 255) / 256, nlev), dim3(256), 0, st, m, 1);
+  } else {
+    hipError_t e = hipMemsetAsync(mean_rstd, 0, sizeof(float) * 2 * N * G * nlev, st);
+    if (e != hipSuccess) return (int)e;
+    SOD_LAUNCH(gn_stats_kernel, dim3(gx, N), dim3(256), sizeof(float) * 2 * 256, st, m);
+    SOD_LAUNCH(gn_finalize_stats_kernel, dim3((N * G + 255) / 256, nlev), dim3(256), 0, st, m);
+  }
   SOD_LAUNCH(gn_apply_kernel, dim3(gx, N), dim3(256), 0, st, m);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
@@ -637,7 +712,8 @@ extern "C" int sod_groupnorm_fwd_ml(int nlev, const void* const* x, const float*
 
 extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void* const* x, const float* gamma, const float* beta,
                                     const float* mean_rstd, void* const* dx, float* dgamma, float* dbeta, float* dxsum,
-                                    float* red_ws /* 2*N*G*nlev floats */, int N, const int* hw, int C, int G, int relu, void* stream) {
+                                    float* red_ws /* 2*N*G*nlev floats */, int N, const int* hw, int C, int G, int relu,
+                                    float* det_ws, long long det_ws_bytes, void* stream) {
   if (!dy || !x || !gamma || !beta || !mean_rstd || !dx || !dgamma || !dbeta || !red_ws) return SOD_EARG;
   GnML m{};
   const int gx = gn_fill(m, nlev, hw, N, C, G, 0.f, relu, nullptr);
@@ -649,6 +725,21 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
     m.lev[l].stats = const_cast<float*>(mean_rstd) + (size_t)l * N * G * 2; m.lev[l].red = red_ws + (size_t)l * N * G * 2;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (det_ws) {
+    if (gn_det_floats(gx, N, C, true) * (long long)sizeof(float) > det_ws_bytes) return SOD_EARG;
+    const long long rows = (long long)gx * N;
+    m.part_grp = det_ws;
+    m.part_gb = det_ws + rows * (C / 8) * 2;
+    m.part_dx = dxsum ? m.part_gb + rows * 2 * C : nullptr;
+    SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 18 * 256, st, m);
+    SOD_LAUNCH(gn_det_group_kernel, dim3((N * G + 255) / 256, nlev), dim3(256), 0, st, m, 0);
+    SOD_LAUNCH(col_accumulate_kernel, dim3((C + 63) / 64), dim3(256), 0, st, m.part_gb, (int)rows, C, 2 * C, dgamma);
+    SOD_LAUNCH(col_accumulate_kernel, dim3((C + 63) / 64), dim3(256), 0, st, m.part_gb + C, (int)rows, C, 2 * C, dbeta);
+    SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * 8 * 256 : 0, st, m);
+    if (dxsum) SOD_LAUNCH(col_accumulate_kernel, dim3((C + 63) / 64), dim3(256), 0, st, m.part_dx, (int)rows, C, C, dxsum);
+    SOD_CHECK_LAUNCH();
+    return SOD_OK;
+  }
   hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * N * G * nlev, st);
   if (e != hipSuccess) return (int)e;
   SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 18 * 256, st, m);
@@ -658,23 +749,24 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
 }
 
 extern "C" int sod_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd,
-                                 int N, int HW, int C, int G, long long img_stride, float eps, int relu, void* stream) {
+                                 int N, int HW, int C, int G, long long img_stride, float eps, int relu, float* det_ws, long long det_ws_bytes,
+                                 void* stream) {
   if (!x || !y) return SOD_EARG;
   if (img_stride > 0 && img_stride != (long long)HW * C) return SOD_EARG;     // dense images only
   const void* xs[1] = {x};
   void* ys[1] = {y};
-  return sod_groupnorm_fwd_ml(1, xs, gamma, beta, ys, mean_rstd, N, &HW, C, G, eps, relu, stream);
+  return sod_groupnorm_fwd_ml(1, xs, gamma, beta, ys, mean_rstd, N, &HW, C, G, eps, relu, det_ws, det_ws_bytes, stream);
 }
 
 extern "C" int sod_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean_rstd,
                                  void* dx, float* dgamma, float* dbeta, float* dxsum, float* red_ws /* 2*N*G floats */,
-                                 int N, int HW, int C, int G, long long img_stride, int relu, void* stream) {
+                                 int N, int HW, int C, int G, long long img_stride, int relu, float* det_ws, long long det_ws_bytes, void* stream) {
   if (!dy || !x || !dx) return SOD_EARG;
   if (img_stride > 0 && img_stride != (long long)HW * C) return SOD_EARG;
   const void* dys[1] = {dy};
   const void* xs[1] = {x};
   void* dxs[1] = {dx};
-  return sod_groupnorm_bwd_ml(1, dys, xs, gamma, beta, mean_rstd, dxs, dgamma, dbeta, dxsum, red_ws, N, &HW, C, G, relu, stream);
+  return sod_groupnorm_bwd_ml(1, dys, xs, gamma, beta, mean_rstd, dxs, dgamma, dbeta, dxsum, red_ws, N, &HW, C, G, relu, det_ws, det_ws_bytes, stream);
 }
 
 extern "C" int sod_relu_bwd(const void* dy, const void* y, void* dx, long long n, void* stream) {
@@ -706,14 +798,18 @@ extern "C" int sod_add_up2_bf16(const void* a, const void* b, void* out, int N, 
   return SOD_OK;
 }
 
-extern "C" int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C, long long img_stride, void* stream) {
+extern "C" int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C, long long img_stride, float* det_ws, long long det_ws_bytes,
+                             void* stream) {
   if (!dy || !dbias || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || C > 2048) return SOD_EARG;
   if (img_stride <= 0) img_stride = (long long)HW * C;
   const int c8n = C / 8;
   if (c8n > 256) return SOD_EARG;
   int ppb;
   const int gx = gn_grid(HW, N, ppb);
-  SOD_LAUNCH(channel_sum_kernel, dim3(gx, N), dim3(256), sizeof(float) * 8 * 256, (hipStream_t)stream, (const __bf16*)dy, dbias, HW, C, img_stride, ppb);
+  if (det_ws && (long long)gx * N * C * (long long)sizeof(float) > det_ws_bytes) return SOD_EARG;
+  SOD_LAUNCH(channel_sum_kernel, dim3(gx, N), dim3(256), sizeof(float) * 8 * 256, (hipStream_t)stream, (const __bf16*)dy, dbias, HW, C, img_stride, ppb,
+             det_ws);
+  if (det_ws) SOD_LAUNCH(col_accumulate_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, det_ws, gx * N, C, C, dbias);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -192,8 +192,10 @@ class BaseTrainer(DefaultTrainer):
 
 
 class _Checkpointer:
-    """Minimal DetectionCheckpointer stand-in (rank-0 torch.save of model/optimizer/scheduler state; checkpoint I/O itself is out
-    of scope, SURVEY.md §2.1 #5)."""
+    """DetectionCheckpointer stand-in (slender_det/checkpoint/detection_checkpoint.py): rank-0 torch.save of model / optimizer /
+    scheduler state; loads native checkpoints and - through slenderobjdet_amd.checkpoint - reference / detectron2 ``.pth`` / ``.pkl``
+    files (layout conversion, incompatible keys logged).  Remote paths (detectron2://, https://) need the reference's PathManager
+    and a network, neither of which this package has: they raise instead of silently training from random weights."""
 
     def __init__(self, model, save_dir="", **checkpointables):
         self.model, self.save_dir, self.checkpointables = model, save_dir, checkpointables
@@ -201,23 +203,46 @@ class _Checkpointer:
     def save(self, name, **extra):
         if not self.save_dir or not comm.is_main_process():
             return
+        from ..checkpoint import NATIVE_FORMAT
+
         os.makedirs(self.save_dir, exist_ok=True)
-        data = {"model": self.model.state_dict(), **{k: v.state_dict() for k, v in self.checkpointables.items() if hasattr(v, "state_dict")}, **extra}
+        data = {"model": self.model.state_dict(), "__format__": NATIVE_FORMAT,
+                **{k: v.state_dict() for k, v in self.checkpointables.items() if hasattr(v, "state_dict")}, **extra}
         torch.save(data, os.path.join(self.save_dir, name + ".pth"))
         with open(os.path.join(self.save_dir, "last_checkpoint"), "w") as f:
             f.write(name + ".pth")
 
+    def save_reference_format(self, name):
+        """Writes ``<name>.pth`` with the REFERENCE's key names / layouts, loadable by its DetectionCheckpointer."""
+        if not self.save_dir or not comm.is_main_process():
+            return
+        from ..checkpoint import native_to_reference
+
+        os.makedirs(self.save_dir, exist_ok=True)
+        torch.save({"model": native_to_reference(self.model)}, os.path.join(self.save_dir, name + ".pth"))
+
     def resume_or_load(self, path, resume=True):
+        import logging
+
+        from ..checkpoint import load_into
+
+        log = logging.getLogger(__name__)
         last = os.path.join(self.save_dir or ".", "last_checkpoint")
         if resume and os.path.exists(last):
             path = os.path.join(self.save_dir, open(last).read().strip())
-        if not path or not os.path.exists(path):
+        if not path:
+            log.info("no checkpoint given (MODEL.WEIGHTS is empty): training starts from the random initialisation")
             return 0
-        data = torch.load(path, map_location="cpu")
-        self.model.load_state_dict(data["model"], strict=False)
-        if getattr(self.model, "arena", None) is not None:
-            self.model.arena.bump()
-        for k, v in self.checkpointables.items():
-            if k in data and hasattr(v, "load_state_dict") and resume:
-                v.load_state_dict(data[k])
-        return int(data.get("iteration", -1)) + 1 if resume else 0
+        if "://" in path:
+            raise FileNotFoundError(f"MODEL.WEIGHTS = {path!r}: remote checkpoints are not supported (no network / PathManager); "
+                                    "download the file and pass its local path")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"MODEL.WEIGHTS = {path!r} does not exist")
+        report, meta = load_into(self.model, path)
+        data = meta["raw"]
+        if resume and meta["native"]:
+            for k, v in self.checkpointables.items():
+                if k in data and hasattr(v, "load_state_dict"):
+                    v.load_state_dict(data[k])
+            return int(data.get("iteration", -1)) + 1
+        return 0

@@ -275,13 +275,22 @@ def weight_prep(w_master, scale=None, want_krsc=True, want_crsk=True, cpad=None)
     return wk, wc
 
 
+def _det_ws(device, stream=None):
+    """(pointer, bytes) of the deterministic-mode scratch for GroupNorm / bias-gradient reductions: the stream's weight-gradient
+    workspace (used in stream order, one launch at a time), or (NULL, 0) when deterministic mode is off."""
+    if not DETERMINISTIC:
+        return None, 0
+    ws = wgrad_workspace(device, stream)
+    return ptr(ws), ws.numel()
+
+
 def groupnorm_fwd(x, gamma, beta, G, eps=1e-5, relu=False):
     _chk(x, torch.bfloat16, "x"); _chk(gamma, torch.float32, "gamma"); _chk(beta, torch.float32, "beta")
     N, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * C)
     y = torch.empty_like(x)
     stats = torch.empty((N, G, 2), dtype=torch.float32, device=x.device)
-    call("sod_groupnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stats), N, HW, C, G, 0, eps, 1 if relu else 0, stream_ptr())
+    call("sod_groupnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stats), N, HW, C, G, 0, eps, 1 if relu else 0, *_det_ws(x.device), stream_ptr())
     return y, stats
 
 
@@ -293,7 +302,7 @@ def groupnorm_bwd(dy, x, gamma, beta, stats, G, dgamma, dbeta, relu=False, dxsum
     dx = torch.empty_like(x)
     red = torch.empty((N, G, 2), dtype=torch.float32, device=x.device)
     call("sod_groupnorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(stats), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(red),
-         N, HW, C, G, 0, 1 if relu else 0, stream_ptr())
+         N, HW, C, G, 0, 1 if relu else 0, *_det_ws(x.device), stream_ptr())
     return dx
 
 
@@ -307,7 +316,7 @@ def groupnorm_fwd_ml(xs, gamma, beta, G, eps=1e-5, relu=False):
     ys = [torch.empty_like(x) for x in xs]
     stats = torch.empty((len(xs), N, G, 2), dtype=torch.float32, device=xs[0].device)
     call("sod_groupnorm_fwd_ml", len(xs), _ptr_arr(xs), ptr(gamma), ptr(beta), _ptr_arr(ys), ptr(stats), N, ctypes.cast(_int_arr(hw), ctypes.c_void_p),
-         C, G, eps, 1 if relu else 0, stream_ptr())
+         C, G, eps, 1 if relu else 0, *_det_ws(xs[0].device), stream_ptr())
     return ys, stats
 
 
@@ -321,7 +330,7 @@ def groupnorm_bwd_ml(dys, xs, gamma, beta, stats, G, dgamma, dbeta, relu=False, 
     dxs = [torch.empty_like(x) for x in xs]
     red = torch.empty((len(xs), N, G, 2), dtype=torch.float32, device=xs[0].device)
     call("sod_groupnorm_bwd_ml", len(xs), _ptr_arr(dys), _ptr_arr(xs), ptr(gamma), ptr(beta), ptr(stats), _ptr_arr(dxs), ptr(dgamma), ptr(dbeta),
-         ptr(dxsum), ptr(red), N, ctypes.cast(_int_arr(hw), ctypes.c_void_p), C, G, 1 if relu else 0, stream_ptr())
+         ptr(dxsum), ptr(red), N, ctypes.cast(_int_arr(hw), ctypes.c_void_p), C, G, 1 if relu else 0, *_det_ws(xs[0].device), stream_ptr())
     return dxs
 
 
@@ -349,7 +358,7 @@ def add_bf16(a, b):
 def bias_grad(dy, dbias, N, HW, C, img_stride=0):
     _chk(dy, torch.bfloat16, "dy"); _chk(dbias, torch.float32, "dbias")
     side = _wgrad_stream(dbias.device, (dy,))      # like the weight gradient: only the optimizer / all-reduce consumes it
-    call("sod_bias_grad", ptr(dy), ptr(dbias), N, HW, C, img_stride, stream_ptr(side))
+    call("sod_bias_grad", ptr(dy), ptr(dbias), N, HW, C, img_stride, *_det_ws(dbias.device, side), stream_ptr(side))
     return dbias
 
 

@@ -122,9 +122,12 @@ class FastRCNNConvFCHead(nn.Module):
         assert b.NUM_FC > 0
         dim = in_channels * height * width
         self.fcs = nn.ModuleList()
-        for _ in range(b.NUM_FC):
+        for i in range(b.NUM_FC):
             fc = HipConv2d(dim, b.FC_DIM, 1, 1, 0, bias=True, relu=True)     # Linear + ReLU as a 1x1 conv over (R,1,1,dim)
             fc.init_xavier()
+            fc.is_linear = True                  # checkpoint interchange (checkpoint.py): a reference file stores nn.Linear (out, in)
+            if i == 0:
+                fc.fc_input_chw = (in_channels, height, width)      # ... whose input is flattened CHW there, HWC here
             self.fcs.append(fc)
             dim = b.FC_DIM
         self.output_size = dim
@@ -174,6 +177,7 @@ class FastRCNNOutputLayers(nn.Module):
         self.cls_pad, self.box_out = _ceil8(self.num_classes + 1), _ceil8(self.num_classes * self.box_dim)
         self.cls_score = HipConv2d(input_size, self.cls_pad, 1, 1, 0, bias=True, out_f32=True)
         self.bbox_pred = HipConv2d(input_size, self.box_out, 1, 1, 0, bias=True, out_f32=True)
+        self.cls_score.is_linear = self.bbox_pred.is_linear = True
         with torch.no_grad():
             self.cls_score.init_normal(0.01, 0.0)
             self.bbox_pred.init_normal(0.001, 0.0)

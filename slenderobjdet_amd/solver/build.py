@@ -71,6 +71,31 @@ class FusedSGD(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
 
+    # The momentum lives in the arena, not in Optimizer.state: save / restore it explicitly so that ``--resume`` continues the run
+    # torch.optim.SGD's momentum_buffer round trip would (slender_det/engine: detectron2's checkpointer stores optimizer.state_dict()).
+    def state_dict(self):
+        sd = super().state_dict()
+        mom = self.arena.momentum
+        sd["fused_sgd"] = {"steps": self._steps, "momentum": None if mom is None else mom.detach().cpu().clone(),
+                           "arena_names": [(n, o, c) for n, o, c in self.arena.names]}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        fused = sd.pop("fused_sgd", None)
+        super().load_state_dict(sd)
+        if fused is None:
+            raise ValueError("FusedSGD.load_state_dict: the checkpoint holds no 'fused_sgd' entry (momentum buffer); it was not written by FusedSGD")
+        if [tuple(x) for x in fused["arena_names"]] != [tuple(x) for x in self.arena.names]:
+            raise ValueError("FusedSGD.load_state_dict: the checkpoint's parameter arena layout differs from this model's")
+        if fused["momentum"] is not None:
+            if self.arena.momentum is None:
+                self.arena.momentum = torch.zeros_like(self.arena.params)
+            self.arena.momentum.copy_(fused["momentum"])
+        self._steps = int(fused["steps"])      # > 0: the next step() must not re-initialise the buffer from the gradient
+        # the segment table (per-parameter lr multipliers / weight decay) is structural and stays as built; the loaded param_groups
+        # carry the schedule's current lr, which step() reads through the same reference group as before
+
     @torch.no_grad()
     def step(self, closure=None):
         # every group carries lr = base_lr(t) * its multiplier; read the schedule from the first group

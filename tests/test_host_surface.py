@@ -269,3 +269,71 @@ def test_bench_gpus_flag_fails_loudly_without_the_gpus():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=root)
     assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
+
+
+def test_checkpoint_conversion_round_trip(tmp_path):
+    """Reference-format state dict -> native -> reference is the identity, the native tensors have the HIP layouts, and a file
+    that matches nothing (or does not exist) is an error, not a silent random initialisation (round-1 finding)."""
+    import pickle
+
+    import numpy as np
+    import pytest
+    import torch
+
+    from bench import make_cfg
+    from slenderobjdet_amd import checkpoint as ck
+    from slenderobjdet_amd.engine.defaults import _Checkpointer
+    from slenderobjdet_amd.modeling import build_model
+
+    cfg = make_cfg(50)
+    cfg.MODEL.DEVICE = "cpu"
+    torch.manual_seed(3)
+    model = build_model(cfg)
+    with torch.no_grad():                                   # non-trivial FrozenBN statistics and scales
+        for n, b in model.named_buffers():
+            if "bn_" in n:
+                b.copy_(torch.rand_like(b) + 0.5)
+        model.head.scales.copy_(torch.arange(5.0) + 1)
+    ref = ck.native_to_reference(model)
+    # the reference's names and layouts (fcos.py:486-547; detectron2 ResNet / FPN)
+    assert ref["backbone.bottom_up.stem.conv1.weight"].shape == (64, 3, 7, 7)
+    assert "backbone.bottom_up.res2.0.conv1.norm.running_var" in ref and "backbone.bottom_up.res2.0.shortcut.norm.weight" in ref
+    assert ref["head.cls_logits.weight"].shape == (80, 256, 3, 3) and ref["head.bbox_pred.weight"].shape == (4, 256, 3, 3)
+    assert ref["head.centerness.weight"].shape == (1, 256, 3, 3) and ref["head.cls_tower.9.weight"].shape == (256, 256, 3, 3)
+    assert ref["head.cls_tower.10.weight"].shape == (256,) and float(ref["head.scales.3.scale"]) == 4.0
+    cfg2 = make_cfg(50)
+    cfg2.MODEL.DEVICE = "cpu"
+    torch.manual_seed(4)
+    other = build_model(cfg2)
+    native, report = ck.reference_to_native(ref, other)
+    assert not report["shape_mismatch"] and not report["unexpected"], report
+    assert set(report["missing"]) <= {"pixel_mean", "pixel_std"} or not report["missing"], report["missing"]
+    other.load_state_dict(native, strict=False)
+    a, b = model.state_dict(), other.state_dict()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # through files: torch .pth in reference format, native format, and a Caffe2-named detectron2 .pkl backbone
+    torch.save({"model": ref}, tmp_path / "ref.pth")
+    torch.manual_seed(5)
+    third = build_model(cfg2)
+    rep, meta = ck.load_into(third, str(tmp_path / "ref.pth"))
+    assert not meta["native"] and all(torch.equal(a[k], v) for k, v in third.state_dict().items())
+    c2 = {"conv1_w": np.full((64, 3, 7, 7), 0.5, np.float32), "res_conv1_bn_s": np.full(64, 2.0, np.float32), "res_conv1_bn_b": np.zeros(64, np.float32),
+          "res2_0_branch2a_w": np.ones((64, 64, 1, 1), np.float32), "res2_0_branch1_bn_s": np.full(256, 3.0, np.float32), "fc1000_w": np.zeros((1000, 2048), np.float32)}
+    with open(tmp_path / "R-50.pkl", "wb") as f:
+        pickle.dump({"blobs": c2}, f)
+    rep, _ = ck.load_into(third, str(tmp_path / "R-50.pkl"))
+    sd3 = third.state_dict()
+    assert float(sd3["backbone.bottom_up.stem.conv1.weight"].mean()) == 0.5 and sd3["backbone.bottom_up.stem.conv1.weight"].shape == (64, 7, 7, 3)
+    assert float(sd3["backbone.bottom_up.stem.conv1.bn_weight"][0]) == 2.0 and float(sd3["backbone.bottom_up.res2.0.shortcut.bn_weight"][0]) == 3.0
+    assert len(rep["missing"]) > 100            # the head / FPN are not in an ImageNet backbone file: reported, not hidden
+    # loud failures
+    cp = _Checkpointer(third, str(tmp_path / "out"))
+    with pytest.raises(FileNotFoundError):
+        cp.resume_or_load(str(tmp_path / "nope.pth"), resume=False)
+    with pytest.raises(FileNotFoundError):
+        cp.resume_or_load("detectron2://ImageNetPretrained/MSRA/R-50.pkl", resume=False)
+    torch.save({"model": {"something.else": torch.zeros(3)}}, tmp_path / "alien.pth")
+    with pytest.raises(RuntimeError):
+        cp.resume_or_load(str(tmp_path / "alien.pth"), resume=False)
+    assert cp.resume_or_load("", resume=False) == 0

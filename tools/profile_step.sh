@@ -1,0 +1,19 @@
+#!/bin/bash
+# Profiles the headline bench step on the GPU box and writes the tracked summaries under profiles/:
+#   tools/profile_step.sh <tag>     (run from the repo root through gpurun; raw outputs go to gpurun_out/<tag>_*)
+# Passes: kernel stats of the default two-stream run, kernel stats of a single-stream run (true per-kernel durations), and the two PMC
+# passes (FETCH_SIZE / WRITE_SIZE, each alone with --kernel-trace as the pool requires).
+set -u
+tag=$1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $B > gpurun_out/${tag}_stats.log 2>&1
+SOD_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_serial -- $B > gpurun_out/${tag}_serial.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- $B > gpurun_out/${tag}_fetch.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- $B > gpurun_out/${tag}_write.log 2>&1
+python3 tools/summarize_profile.py ${tag} gpurun_out/${tag}_stats gpurun_out/${tag}_fetch gpurun_out/${tag}_write 7
+python3 tools/summarize_profile.py ${tag}_serial gpurun_out/${tag}_serial "" "" 7
+mkdir -p gpurun_out/profiles_${tag} && cp profiles/${tag}* gpurun_out/profiles_${tag}/
+# keep the merged scratch small: the raw traces are not needed once summarised
+rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_serial gpurun_out/${tag}_fetch gpurun_out/${tag}_write
+ls -la gpurun_out/profiles_${tag}

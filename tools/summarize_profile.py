@@ -22,7 +22,10 @@ def main(tag, stats_dir, fetch_dir, write_dir, steps):
     rows = list(csv.DictReader(open(glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))[0])))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps %d --warmup 2 --no-cpu-baseline ; all %d steps incl. warm-up\n" % (steps - 2, steps))
+        pre = "SOD_WGRAD_STREAM=0 " if tag.endswith("_serial") else ""
+        post = " ; one stream, no kernel overlap: true per-kernel durations" if pre else " ; default two-stream run: backward kernels share the GPU"
+        f.write("# %srocprofv3 --kernel-trace --stats -- python bench.py --steps %d --warmup 2 --no-cpu-baseline --no-roofline ; all %d steps incl. warm-up%s\n"
+                % (pre, steps - 2, steps, post))
         f.write("kernel,calls,total_ms,avg_us,min_us,max_us,percent\n")
         for r in rows[:40]:
             f.write("%s,%s,%.3f,%.2f,%.2f,%.2f,%s\n" % (short(r["Name"]).replace(",", ";"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
