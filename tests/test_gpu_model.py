@@ -342,22 +342,20 @@ def test_fused_sgd_state_dict_round_trip(cuda):
         for _ in range(2):
             train_step(model, opt, data)
         saved_opt = opt.state_dict()
-        saved_params = model.arena.params.detach().clone()
+        saved_model = {k: v.detach().clone() for k, v in model.state_dict().items()}
         assert saved_opt["fused_sgd"]["steps"] == 2 and float(saved_opt["fused_sgd"]["momentum"].abs().sum()) > 0
         train_step(model, opt, data)
         want = model.arena.params.detach().clone()
         # "resume": a fresh model + optimizer restored from the checkpoint
         cfg2, model2, opt2 = _build(18, seed=99)
-        with torch.no_grad():
-            model2.arena.params.copy_(saved_params)
+        model2.load_state_dict(saved_model)
         model2.arena.bump()
         opt2.load_state_dict(saved_opt)
         train_step(model2, opt2, data)
         assert torch.equal(model2.arena.params, want)
         # without the momentum the resumed run would differ
         cfg3, model3, opt3 = _build(18, seed=99)
-        with torch.no_grad():
-            model3.arena.params.copy_(saved_params)
+        model3.load_state_dict(saved_model)
         model3.arena.bump()
         train_step(model3, opt3, data)
         assert not torch.equal(model3.arena.params, want)
