@@ -222,6 +222,28 @@ int sod_fcos_finalize_losses(const float* focal_sum, const float* regctr_sums, c
 long long sod_nms_workspace_bytes(int n);
 int sod_nms(const float* boxes, const long long* order, int n, float iou_threshold, long long* keep, int* num_keep,
             void* mask_ws, void* stream);
+/* Dense-detector post-processing on the device for the whole batch.
+ * sod_fcos_decode = the per-level part of FCOS(V2).inference_single_image (fcosv2.py:194-238, fcos.py:385-436), one launch:
+ *   keep = sigmoid(cls) > pre_nms_thresh;  score = sigmoid(cls) * sigmoid(centerness);  per (image, level) the pre_nms_top_n best
+ *   scores (all of them when fewer; ties at the cut resolved towards the lower (location, class) index);  boxes = location -+ the
+ *   regression decoded as in FCOSHead (exp(scale * x), or relu(scale * x) * stride with NORM_REG_TARGETS);  score = sqrt(score).
+ * cls_logits (N, L, ld_cls), box_raw (N, L, ld_box) fp32 = the head's prediction buffers (L = sum H[l]*W[l], level-major); the
+ * centerness logit is column ctr_col_box of box_raw (CENTERNESS_ON_REG) or column ctr_col_cls of cls_logits - exactly one >= 0.
+ * Outputs have pre_nms_top_n slots per (image, level), filled in torch.nonzero() order; unused slots carry score -1 / class -1;
+ * out_counts (N, nlev) = candidates per level.  No host synchronisation. */
+int sod_fcos_decode(const float* cls_logits, int ld_cls, const float* box_raw, int ld_box, const float* scales,
+                    int N, int nlev, const int* H, const int* W, const int* strides, int num_classes,
+                    int ctr_col_box, int ctr_col_cls, int norm_reg_targets, float pre_nms_thresh, int pre_nms_top_n,
+                    float* out_boxes, float* out_scores, int* out_classes, int* out_counts, void* stream);
+/* detectron2.layers.batched_nms (fcosv2.py:241) + keep[: max_keep] for B images of M candidate slots each (score < 0 = empty slot):
+ * prepare() writes boxes + class * (max coordinate of the image + 1) and the per-image candidate count into ws; the caller then
+ * sorts the scores of every image in stable descending order (order: (B, M) int64 local indices, empty slots last) and run()
+ * performs the greedy suppression (IoU > iou_threshold) per image, stopping after max_keep survivors: keep (B, max_keep) local
+ * indices in score order, num_keep (B).  The candidate counts never leave the device. */
+long long sod_batched_nms_workspace_bytes(int B, int M);
+int sod_batched_nms_prepare(const float* boxes, const float* scores, const int* classes, int B, int M, void* ws, void* stream);
+int sod_batched_nms_run(const long long* order, int B, int M, float iou_threshold, int max_keep, long long* keep, int* num_keep,
+                        void* ws, void* stream);
 /* detectron2 nms_rotated / box_iou_rotated (csrc/nms_rotated, csrc/box_iou_rotated; reached through RRPN / RROIHeads selected by
  * configs/rotated/Base-RRCNN-FPN.yaml:10-36 and pairwise_iou at retina_rotated.py:276): boxes (n,5) = (cx,cy,w,h,angle_deg). */
 int sod_nms_rotated(const float* boxes, const long long* order, int n, float iou_threshold, long long* keep, int* num_keep,

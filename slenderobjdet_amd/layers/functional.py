@@ -540,6 +540,45 @@ def nms(boxes, scores, iou_threshold):
     return keep[: int(nkeep.item())]
 
 
+def fcos_decode(cls_buf, box_buf, scales, level_hw, strides, num_classes, centerness_on_reg, norm_reg_targets, pre_nms_thresh, pre_nms_top_n):
+    """Per-level threshold / top-k / decode of FCOS inference for the whole batch in one launch (no host sync).
+    cls_buf (N, L, ld) / box_buf (N, L, ld) fp32 prediction buffers -> boxes (N, M, 4), scores (N, M) (-1 = empty slot),
+    classes (N, M) int32, counts (N, nlev) int32 with M = nlev * pre_nms_top_n."""
+    _chk(cls_buf, torch.float32, "cls_buf"); _chk(box_buf, torch.float32, "box_buf"); _chk(scales, torch.float32, "scales")
+    N, L, ld_cls = cls_buf.shape
+    ld_box = box_buf.shape[-1]
+    nlev = len(level_hw)
+    if L != sum(h * w for h, w in level_hw) or box_buf.shape[1] != L:
+        raise _C.SlenderHipError("fcos_decode: prediction buffers do not match the level geometry")
+    M = nlev * int(pre_nms_top_n)
+    dev = cls_buf.device
+    boxes = torch.empty((N, M, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((N, M), dtype=torch.float32, device=dev)
+    classes = torch.empty((N, M), dtype=torch.int32, device=dev)
+    counts = torch.empty((N, nlev), dtype=torch.int32, device=dev)
+    call("sod_fcos_decode", ptr(cls_buf), ld_cls, ptr(box_buf), ld_box, ptr(scales), N, nlev,
+         ctypes.cast(_int_arr([h for h, _ in level_hw]), ctypes.c_void_p), ctypes.cast(_int_arr([w for _, w in level_hw]), ctypes.c_void_p),
+         ctypes.cast(_int_arr(strides), ctypes.c_void_p), int(num_classes), 4 if centerness_on_reg else -1, -1 if centerness_on_reg else int(num_classes),
+         1 if norm_reg_targets else 0, float(pre_nms_thresh), int(pre_nms_top_n), ptr(boxes), ptr(scores), ptr(classes), ptr(counts), stream_ptr())
+    return boxes, scores, classes, counts
+
+
+def batched_nms_topk(boxes, scores, classes, iou_threshold, max_keep):
+    """Class-aware NMS + top-``max_keep`` of B images at once on padded candidate lists (score < 0 = empty slot).
+    Returns keep (B, max_keep) int64 local indices in score order (entries beyond num_keep are 0) and num_keep (B) int32, both on
+    the device.  The per-image sort is torch's stable sort (plumbing), everything else runs in the HIP kernels."""
+    _chk(boxes, torch.float32, "boxes"); _chk(scores, torch.float32, "scores"); _chk(classes, torch.int32, "classes")
+    B, M = scores.shape
+    dev = scores.device
+    ws = torch.empty(int(_C.load().sod_batched_nms_workspace_bytes(B, M)), dtype=torch.uint8, device=dev)
+    call("sod_batched_nms_prepare", ptr(boxes), ptr(scores), ptr(classes), B, M, ptr(ws), stream_ptr())
+    order = torch.sort(scores, dim=1, descending=True, stable=True).indices.contiguous()
+    keep = torch.zeros((B, int(max_keep)), dtype=torch.int64, device=dev)
+    nkeep = torch.zeros(B, dtype=torch.int32, device=dev)
+    call("sod_batched_nms_run", ptr(order), B, M, float(iou_threshold), int(max_keep), ptr(keep), ptr(nkeep), ptr(ws), stream_ptr())
+    return keep, nkeep
+
+
 def nms_rotated(boxes, scores, iou_threshold):
     """detectron2.layers.nms_rotated: boxes (n,5) = (cx,cy,w,h,angle_deg)."""
     _chk(boxes, torch.float32, "boxes"); _chk(scores, torch.float32, "scores")

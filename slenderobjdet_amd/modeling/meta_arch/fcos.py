@@ -308,58 +308,36 @@ class FCOSV2(nn.Module):
 
     # ------------------------------------------------------------------ inference (fcosv2.py:174-266)
     @torch.no_grad()
-    def inference(self, level_hw, cls_t, box_t, image_sizes):
+    def decode_candidates(self, cls_t, box_t):
+        """Per-level threshold -> top-k -> decode for the whole batch: ONE kernel, no host sync (replaces the per-image / per-level
+        boolean-indexing loop of inference_single_image, fcosv2.py:194-238).  -> boxes (N,M,4), scores (N,M), classes (N,M), counts."""
         head = self.head
         cls_buf, box_buf, hw = head.predict(cls_t, box_t)
-        K = self.num_classes
-        N, L = cls_buf.shape[:2]
-        dev = cls_buf.device
-        lvl = torch.cat([torch.full((h * w,), i, dtype=torch.long) for i, (h, w) in enumerate(hw)]).to(dev)
-        scale = head.scales.detach()[lvl][:, None]
-        strides = torch.tensor(self.fpn_strides, dtype=torch.float32, device=dev)[lvl]
-        z = box_buf[..., :4] * scale
-        box_reg = torch.relu(z) * strides[:, None] if head.norm_reg_targets else torch.exp(z)
-        ctr = box_buf[..., 4] if head.centerness_on_reg else cls_buf[..., K]
-        locs = []
-        for (h, w), s in zip(hw, self.fpn_strides):
-            ys = torch.arange(0, h * s, step=s, dtype=torch.float32, device=dev)
-            xs = torch.arange(0, w * s, step=s, dtype=torch.float32, device=dev)
-            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
-            locs.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), dim=1) + s // 2)
-        results = []
-        bounds = [0]
-        for h, w in hw:
-            bounds.append(bounds[-1] + h * w)
-        for i, image_size in enumerate(image_sizes):
-            boxes_all, scores_all, cls_all = [], [], []
-            for l in range(len(hw)):
-                sl = slice(bounds[l], bounds[l + 1])
-                p = cls_buf[i, sl, :K].sigmoid()
-                keep = p > self.pre_nms_thresh
-                p = p * ctr[i, sl].sigmoid()[:, None]
-                sc = p[keep]
-                idx = keep.nonzero()
-                loc_i, class_i = idx[:, 0], idx[:, 1]
-                reg_i, locs_i = box_reg[i, sl][loc_i], locs[l][loc_i]
-                n_keep = int(keep.sum())
-                top_n = min(n_keep, self.pre_nms_top_n)
-                if n_keep > top_n:
-                    sc, ti = sc.topk(top_n, sorted=False)
-                    class_i, reg_i, locs_i = class_i[ti], reg_i[ti], locs_i[ti]
-                boxes_all.append(torch.stack([locs_i[:, 0] - reg_i[:, 0], locs_i[:, 1] - reg_i[:, 1],
-                                              locs_i[:, 0] + reg_i[:, 2], locs_i[:, 1] + reg_i[:, 3]], dim=1))
-                scores_all.append(torch.sqrt(sc))
-                cls_all.append(class_i)
-            boxes_all, scores_all, cls_all = torch.cat(boxes_all), torch.cat(scores_all), torch.cat(cls_all)
-            from ...layers.nms import batched_nms
+        return HF.fcos_decode(cls_buf, box_buf, head.scales.detach().float().contiguous(), hw, self.fpn_strides, self.num_classes,
+                              head.centerness_on_reg, head.norm_reg_targets, self.pre_nms_thresh, self.pre_nms_top_n)
 
-            keep = batched_nms(boxes_all, scores_all, cls_all, self.nms_thresh)[: self.max_detections_per_image]
+    @torch.no_grad()
+    def nms_candidates(self, cand, image_sizes):
+        """batched_nms + top-``max_detections_per_image`` (fcosv2.py:240-249) for all images on the device; the only host
+        synchronisation of the whole post-processing is the final read of the per-image detection counts."""
+        boxes, scores, classes, _counts = cand
+        keep, nkeep = HF.batched_nms_topk(boxes, scores, classes, self.nms_thresh, self.max_detections_per_image)
+        kb = torch.gather(boxes, 1, keep[:, :, None].expand(-1, -1, 4))
+        ks = torch.gather(scores, 1, keep)
+        kc = torch.gather(classes, 1, keep)
+        nk = nkeep.cpu().tolist()
+        results = []
+        for i, image_size in enumerate(image_sizes):
             r = Instances(tuple(image_size))
-            r.pred_boxes = Boxes(boxes_all[keep])
-            r.scores = scores_all[keep]
-            r.pred_classes = cls_all[keep]
+            r.pred_boxes = Boxes(kb[i, : nk[i]])
+            r.scores = ks[i, : nk[i]]
+            r.pred_classes = kc[i, : nk[i]].long()
             results.append(r)
         return results
+
+    @torch.no_grad()
+    def inference(self, level_hw, cls_t, box_t, image_sizes):
+        return self.nms_candidates(self.decode_candidates(cls_t, box_t), image_sizes)
 
     def postprocess(self, instances, batched_inputs, image_sizes):
         from ..postprocessing import detector_postprocess
@@ -384,5 +362,51 @@ class FCOSV2(nn.Module):
 
 @META_ARCH_REGISTRY.register()
 class FCOS(FCOSV2):
-    """slender_det/modeling/meta_arch/fcos/fcos.py:174-473 — same head, targets and losses as FCOSV2 (it differs only in
-    how the reference transposes the targets, fcos.py:343-372, and in ``inference_single_image``'s threshold order)."""
+    """slender_det/modeling/meta_arch/fcos/fcos.py:174-473.  Same head, target assignment and losses as FCOSV2; the reference
+    class differs in two places, both of which are kept:
+
+    * ``get_ground_truth`` (fcos.py:326-372) returns the targets LEVEL-first (one tensor per level holding all images) where
+      FCOSV2 stacks them image-first; ``losses`` flattens either into the same multiset of (label, target) rows, so the three loss
+      sums are equal up to fp32 summation order.  Here both run on the one batched assignment kernel; ``targets_level_first``
+      exposes the reference's level-first view of it.
+    * inference (fcos.py:374-464): ``inference`` only selects and decodes the candidates per feature map
+      (``inference_single_feature_map``) and concatenates them per image; the class-aware NMS and the top-100 cut happen in
+      ``postprocess``.  FCOSV2 does both inside ``inference``.  The detections are the same."""
+
+    def targets_level_first(self, level_hw, gt_instances):
+        """fcos.py:343-372: ``labels_level_first`` / ``reg_targets_level_first`` - per level, (N * Hl * Wl,) and (N * Hl * Wl, 4)."""
+        labels, reg, _ctr, _stats = self.get_ground_truth(level_hw, gt_instances)
+        sizes = [h * w for h, w in level_hw]
+        return ([t.reshape(-1) for t in labels.split(sizes, dim=1)], [t.reshape(-1, 4) for t in reg.split(sizes, dim=1)])
+
+    @torch.no_grad()
+    def inference(self, level_hw, cls_t, box_t, image_sizes):
+        """fcos.py:374-383: candidates of every feature map, concatenated per image, NO suppression yet."""
+        cand = self.decode_candidates(cls_t, box_t)
+        self._pending = cand                 # padded device tensors for postprocess (one NMS launch for the batch)
+        boxes, scores, classes, counts = cand
+        cnt = counts.cpu()
+        top_n = self.pre_nms_top_n
+        results = []
+        for i, image_size in enumerate(image_sizes):
+            idx = torch.cat([torch.arange(l * top_n, l * top_n + int(cnt[i, l]), device=boxes.device) for l in range(cnt.shape[1])])
+            r = Instances(tuple(image_size))
+            r.pred_boxes = Boxes(boxes[i, idx])
+            r.scores = scores[i, idx]
+            r.pred_classes = classes[i, idx].long()
+            results.append(r)
+        return results
+
+    def postprocess(self, instances, batched_inputs, image_sizes):
+        """fcos.py:438-464: per-class NMS, top ``max_detections_per_image``, then rescale to the requested output size."""
+        cand, self._pending = getattr(self, "_pending", None), None
+        if cand is None:                     # called with Instances that did not come from inference(): per-image path
+            from ...layers.nms import batched_nms
+
+            kept = []
+            for r in instances:
+                keep = batched_nms(r.pred_boxes.tensor, r.scores, r.pred_classes, self.nms_thresh)[: self.max_detections_per_image]
+                kept.append(r[keep])
+        else:
+            kept = self.nms_candidates(cand, image_sizes)
+        return super().postprocess(kept, batched_inputs, image_sizes)

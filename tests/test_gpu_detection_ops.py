@@ -163,3 +163,30 @@ def test_nms_rotated_keep_indices(cuda):
     # class offsets shift the centres by thousands of pixels, which perturbs the clipped polygon in the last float digits:
     # allow a pair sitting exactly at the threshold to flip
     assert len(set(keep.tolist()) ^ set(ref)) <= 2
+
+
+def test_anchor_match_full_size_bit_exact(cuda):
+    """BASELINE configs[2] size: A = 201 600 anchors (800x1344, 9 per location), G up to 50: labels, matched indices and matched
+    IoUs bit-exact vs the oracle's explicit G x A matrix + detectron2 Matcher (retina_rotated.py:251-295), including the
+    low-quality pass.  Property on top: every gt whose best IoU is > 0 owns at least one positive anchor."""
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.modeling.anchor_generator import grid_anchors
+
+    hw = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    sizes = [[x, x * 2 ** (1.0 / 3), x * 2 ** (2.0 / 3)] for x in [32, 64, 128, 256, 512]]
+    anchors = torch.cat(grid_anchors(hw, [8, 16, 32, 64, 128], sizes, [[0.5, 1.0, 2.0]] * 5))
+    assert anchors.shape[0] == 201600
+    ad = anchors.to(cuda)
+    for G, seed in ((1, 3), (7, 4), (50, 5)):
+        g = _g(seed)
+        c = torch.rand(G, 2, generator=g) * torch.tensor([1333.0, 800.0])
+        wh = torch.pow(2.0, torch.rand(G, 2, generator=g) * 5.2 + 4.0)
+        gts = torch.cat([(c - wh / 2).clamp(min=0), torch.minimum(c + wh / 2, torch.tensor([1333.0, 800.0]))], 1)
+        q = od.pairwise_iou(gts, anchors)
+        m_ref, l_ref = od.matcher(q, [0.4, 0.5], [0, -1, 1], True)
+        vals, idx, lab = HF.anchor_match(gts.to(cuda), ad, [0.4, 0.5], [0, -1, 1], True)
+        assert torch.equal(lab.cpu(), l_ref) and torch.equal(idx.cpu().long(), m_ref) and torch.equal(vals.cpu(), q.max(dim=0).values), G
+        best = q.max(dim=1).values
+        for j in range(G):
+            if best[j] > 0:
+                assert ((l_ref == 1) & (q[j] == best[j])).any()

@@ -170,3 +170,43 @@ def test_retinanet_giou_regression_vs_oracle(cuda):
     l0 = float(train_step_retina(model, opt, data))
     l1 = float(train_step_retina(model, opt, data))
     assert l0 == l0 and l1 == l1 and model.head.bbox_pred.weight.grad[:36].abs().sum() > 0
+
+
+def test_retinanet_r50_full_size_step(cuda):
+    """BASELINE configs[2] at its real depth and resolution (R50-FPN, 800x1344, 201 600 anchors; batch reduced to 2): anchor labels
+    bit-exact, both losses within 1e-4 of the oracle loss on the product's own predictions, and one finite training step."""
+    from bench import damp_residual_branches, make_cfg
+    from oracle import retinanet as orn
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+
+    cfg = make_cfg(50, "retinanet")
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    damp_residual_branches(model)       # random-init R50 without a checkpoint overflows the un-normalised head (bench.py)
+    data = synthetic_batch(2, 800, 1333, 77, device="cuda")
+    hw = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    anchors = model.anchors_for(hw).cpu()
+    assert anchors.shape[0] == 201600
+    gtb = [d["instances"].gt_boxes.tensor.cpu() for d in data]
+    gtc = [d["instances"].gt_classes.cpu() for d in data]
+    ref_l, ref_b = orn.label_anchors(anchors, gtb, gtc, [0.4, 0.5], [0, -1, 1], 80)
+    lab, _ = model.label_anchors(model.anchors_for(hw), [d["instances"] for d in data])
+    assert torch.equal(lab.cpu().long(), ref_l)
+    with torch.no_grad():
+        imgs = model.preprocess_image(data)
+        feats = model.backbone(imgs.tensor)
+        ct, bt = model.head.run_towers([feats[f] for f in model.in_features])
+        cls_buf, box_buf, _, _ = model.head.predict(ct, bt)
+    N, P = cls_buf.shape[:2]
+    ref, _ = orn.losses(anchors, cls_buf.cpu().view(N, P * 9, 80), box_buf.cpu()[..., :36].reshape(N, P * 9, 4), ref_l, ref_b, 80, 0.25, 2.0,
+                        cfg.MODEL.RETINANET.SMOOTH_L1_LOSS_BETA, (1, 1, 1, 1), 100.0)
+    got = model(data)
+    for k in ref:
+        a, b = float(got[k].detach()), float(ref[k])
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-3), (k, a, b)
+    opt = build_optimizer(cfg, model)
+    l0 = float(train_step_retina(model, opt, data))
+    assert l0 == l0 and abs(l0) < 1e6
