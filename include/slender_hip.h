@@ -164,6 +164,17 @@ int sod_preprocess_image(const void* img, int is_uint8, int C, int H, int W, voi
  * one dtype); out is the (n, Hp, Wp, 8) batch buffer. */
 int sod_preprocess_batch(int n, const void* const* imgs, int is_uint8, int C, const int* H, const int* W, void* out, int Hp, int Wp,
                          int Cpad, const float* mean3, const float* std3, void* stream);
+/* The augmentation + batching stage in front of the model on the device: ResizeShortestEdge / ResizeLongestEdge and
+ * RandomFlip of build_augmentation (slender_det/data/utils.py:29-50; detectron2 ResizeTransform = PIL BILINEAR resize of the uint8
+ * image, HFlipTransform) fused with sod_preprocess_batch's normalise + zero-pad + NHWC(8) bf16, ONE launch for n (<= 64) images.
+ * imgs[i]: device (H[i], W[i], 3) uint8, channel-interleaved.  xbounds[i] / ybounds[i]: device int32 [new][2] = {first source
+ * index, number of taps}; xcoef[i] / ycoef[i]: device int32 [new][kx[i]] / [new][ky[i]] = Pillow's fixed-point (22-bit) filter
+ * coefficients (slenderobjdet_amd/data/transforms.py:pil_bilinear_coeffs restates Pillow's precompute_coeffs).  flip[i] != 0 mirrors
+ * the resized image horizontally.  All array arguments are HOST arrays of n entries.  Resized pixels equal PIL's bit for bit. */
+int sod_resize_flip_preprocess_batch(int n, const void* const* imgs, const int* H, const int* W, const int* newH, const int* newW,
+                                     const int* const* xbounds, const int* const* xcoef, const int* kx,
+                                     const int* const* ybounds, const int* const* ycoef, const int* ky, const int* flip,
+                                     void* out, int Hp, int Wp, int Cpad, const float* mean3, const float* std3, void* stream);
 int sod_nchw_f32_to_nhwc_bf16(const float* x, void* y, int N, int C, int HW, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -611,6 +611,55 @@ __global__ __launch_bounds__(256) void preprocess_batch_kernel(const PreBatch b,
   }
 }
 
+// ---- input pipeline on the device: ResizeShortestEdge + RandomFlip (slender_det/data/utils.py:29-50 ->
+// detectron2 ResizeTransform = PIL.Image.resize(BILINEAR) on the uint8 image, HFlipTransform) fused with preprocess_image's
+// normalise + pad + NHWC(8) bf16 (fcosv2.py:268-275).  PIL's bilinear resize is a separable triangle filter whose support grows with
+// the down-scaling factor, evaluated in fixed point (22 fractional bits) with a ROUNDED uint8 image between the horizontal and the
+// vertical pass; the per-axis tap ranges and integer coefficients are computed on the host exactly as Pillow's precompute_coeffs does
+// (data/transforms.py) and the kernel repeats Pillow's integer arithmetic, so resized pixels match PIL bit for bit.
+struct ResizeImg {
+  const uint8_t* src;      // (H, W, 3) uint8, interleaved channels (the decoded image as detectron2's mapper holds it)
+  const int* xb; const int* xk;   // [newW][2] (first tap, taps), [newW][kx] coefficients
+  const int* yb; const int* yk;   // [newH][2], [newH][ky]
+  int H, W, newH, newW, kx, ky, flip;
+};
+struct ResizeBatch { ResizeImg im[PRE_MAX_IMAGES]; };
+
+__device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+__global__ __launch_bounds__(256) void resize_flip_preprocess_kernel(const ResizeBatch b, __bf16* __restrict__ out, int Hp, int Wp,
+                                                                     float m0, float m1, float m2, float s0, float s1, float s2) {
+  const ResizeImg& im = b.im[blockIdx.y];
+  __bf16* __restrict__ o_n = out + (long long)blockIdx.y * Hp * Wp * 8;
+  const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
+  const int total = Hp * Wp;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int y = i / Wp, xo = i - y * Wp;
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)0.f;
+    if (y < im.newH && xo < im.newW) {
+      const int x = im.flip ? im.newW - 1 - xo : xo;            // HFlipTransform of the RESIZED image
+      const int x0 = im.xb[2 * x], nx = im.xb[2 * x + 1], y0 = im.yb[2 * y], ny = im.yb[2 * y + 1];
+      int acc[3] = {1 << 21, 1 << 21, 1 << 21};                 // vertical pass accumulators, 1 << (PRECISION_BITS - 1)
+      for (int r = 0; r < ny; ++r) {
+        const uint8_t* row = im.src + ((long long)(y0 + r) * im.W + x0) * 3;
+        int h[3] = {1 << 21, 1 << 21, 1 << 21};                 // horizontal pass of source row y0 + r at output column x
+        for (int t = 0; t < nx; ++t) {
+          const int k = im.xk[(long long)x * im.kx + t];
+          h[0] += (int)row[3 * t] * k; h[1] += (int)row[3 * t + 1] * k; h[2] += (int)row[3 * t + 2] * k;
+        }
+        const int kv = im.yk[(long long)y * im.ky + r];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] += clip8(h[c] >> 22) * kv;      // the intermediate image is uint8 in Pillow
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = (__bf16)(((float)clip8(acc[c] >> 22) - mean[c]) / stdv[c]);
+    }
+    *reinterpret_cast<bf16x8_t*>(o_n + (long long)i * 8) = o;
+  }
+}
+
 // NHWC bf16 <-> NCHW f32 layout conversion (API boundary only)
 __global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y,
                                                                     int N, int C, int HW) {
@@ -892,6 +941,26 @@ extern "C" int sod_preprocess_batch(int n, const void* const* imgs, int is_uint8
     SOD_LAUNCH(preprocess_batch_kernel<uint8_t>, grid, dim3(256), 0, (hipStream_t)stream, b, C, (__bf16*)out, Hp, Wp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
   else
     SOD_LAUNCH(preprocess_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, b, C, (__bf16*)out, Hp, Wp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_resize_flip_preprocess_batch(int n, const void* const* imgs, const int* H, const int* W, const int* newH, const int* newW,
+                                               const int* const* xbounds, const int* const* xcoef, const int* kx,
+                                               const int* const* ybounds, const int* const* ycoef, const int* ky, const int* flip,
+                                               void* out, int Hp, int Wp, int Cpad, const float* mean3, const float* std3, void* stream) {
+  if (!imgs || !H || !W || !newH || !newW || !xbounds || !xcoef || !kx || !ybounds || !ycoef || !ky || !flip || !out || !mean3 || !std3) return SOD_EARG;
+  if (n <= 0 || n > PRE_MAX_IMAGES || Cpad != 8 || Hp <= 0 || Wp <= 0 || (long long)Hp * Wp >= (1ll << 31)) return SOD_EARG;
+  ResizeBatch b;
+  for (int i = 0; i < n; ++i) {
+    if (!imgs[i] || !xbounds[i] || !xcoef[i] || !ybounds[i] || !ycoef[i]) return SOD_EARG;
+    if (H[i] <= 0 || W[i] <= 0 || newH[i] <= 0 || newW[i] <= 0 || newH[i] > Hp || newW[i] > Wp || kx[i] <= 0 || ky[i] <= 0) return SOD_EARG;
+    ResizeImg& im = b.im[i];
+    im.src = (const uint8_t*)imgs[i]; im.xb = xbounds[i]; im.xk = xcoef[i]; im.yb = ybounds[i]; im.yk = ycoef[i];
+    im.H = H[i]; im.W = W[i]; im.newH = newH[i]; im.newW = newW[i]; im.kx = kx[i]; im.ky = ky[i]; im.flip = flip[i] ? 1 : 0;
+  }
+  SOD_LAUNCH(resize_flip_preprocess_kernel, dim3(blocks_for((long long)Hp * Wp, 2048), n), dim3(256), 0, (hipStream_t)stream, b, (__bf16*)out, Hp, Wp,
+             mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

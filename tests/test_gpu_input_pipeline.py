@@ -1,0 +1,58 @@
+"""GPU parity of the on-device input pipeline: resize (PIL BILINEAR semantics) + flip + normalise + pad + NHWC(8)
+bf16 in one launch vs the numpy oracle (oracle/resize.py; reference slender_det/data/utils.py:29-50, fcosv2.py:268-275)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import resize as orz
+
+pytestmark = pytest.mark.gpu
+
+
+def test_resize_flip_preprocess_bit_exact(cuda):
+    from slenderobjdet_amd.data import DeviceInputPipeline
+
+    rng = np.random.RandomState(1)
+    imgs = [rng.randint(0, 256, s).astype(np.uint8) for s in ((48, 64, 3), (75, 50, 3), (33, 90, 3), (64, 64, 3))]
+    choices = [(80, 107, False), (96, 64, True), (30, 82, True), (64, 64, False)]      # up-scale, up + flip, down + flip, identity
+    mean, std = (103.53, 116.28, 123.675), (57.375, 57.12, 58.395)
+    pipe = DeviceInputPipeline(pixel_mean=mean, pixel_std=std, size_divisibility=32)
+    boxes = [torch.tensor([[4.0, 5.0, 40.0, 30.0]]), torch.tensor([[10.0, 10.0, 45.0, 70.0]]), torch.zeros((0, 4)), torch.tensor([[0.0, 0.0, 64.0, 64.0]])]
+    out, sizes, new_boxes, _ = pipe([torch.from_numpy(i).to(cuda) for i in imgs], [b.to(cuda) for b in boxes], choices=choices)
+    ref = orz.pipeline(imgs, choices, mean, std, 32)
+    assert tuple(out.shape) == (4, ref.shape[1], ref.shape[2], 8) and sizes == [(c[0], c[1]) for c in choices]
+    got = out.float().cpu()
+    assert (got[..., 3:] == 0).all()
+    want = torch.from_numpy(ref).to(torch.bfloat16).float()          # the kernel rounds (v - mean) / std to bf16 once
+    assert torch.equal(got[..., :3], want), float((got[..., :3] - want).abs().max())
+    for b, im, c, nb in zip(boxes, imgs, choices, new_boxes):
+        assert np.allclose(nb.cpu().numpy(), orz.transform_boxes(b.numpy(), im.shape[0], im.shape[1], c[0], c[1], c[2]).reshape(-1, 4), atol=1e-4)
+
+
+def test_resize_full_size_and_model_consumes_it(cuda):
+    """COCO-sized inputs (480x640 / 427x640 -> shortest edge 800, max 1333): bit-exact against the oracle on a strip of rows, and the
+    batch tensor has the layout FCOSV2.preprocess_image produces (the backbone consumes it unchanged)."""
+    from bench import make_cfg
+    from slenderobjdet_amd.data import DeviceInputPipeline
+    from slenderobjdet_amd.modeling import build_model
+
+    rng = np.random.RandomState(2)
+    imgs = [rng.randint(0, 256, s).astype(np.uint8) for s in ((480, 640, 3), (427, 640, 3))]
+    cfg = make_cfg(18)
+    pipe = DeviceInputPipeline(min_sizes=(800,), max_size=1333, flip_prob=0.5, pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD, seed=3)
+    out, sizes, _, choices = pipe([torch.from_numpy(i).to(cuda) for i in imgs])
+    assert sizes == [(800, 1067), (800, 1199)] and tuple(out.shape) == (2, 800, 1216, 8)
+    for i, (im, c) in enumerate(zip(imgs, choices)):
+        r = orz.pil_resize_bilinear(im, c[0], c[1])
+        if c[2]:
+            r = r[:, ::-1, :]
+        strip = slice(390, 410)
+        want = torch.from_numpy((r[strip].astype(np.float32) - np.asarray(cfg.MODEL.PIXEL_MEAN, np.float32)) / np.asarray(cfg.MODEL.PIXEL_STD, np.float32))
+        assert torch.equal(out[i, strip, : c[1], :3].float().cpu(), want.to(torch.bfloat16).float())
+        assert (out[i, :, c[1]:] == 0).all()
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.eval()
+    with torch.no_grad():
+        feats = model.backbone(out)
+    assert tuple(feats["p3"].shape) == (2, 100, 152, 256) and torch.isfinite(feats["p3"].float()).all()
