@@ -240,21 +240,28 @@ int sod_nms(const float* boxes, const long long* order, int n, float iou_thresho
  *   regression decoded as in FCOSHead (exp(scale * x), or relu(scale * x) * stride with NORM_REG_TARGETS);  score = sqrt(score).
  * cls_logits (N, L, ld_cls), box_raw (N, L, ld_box) fp32 = the head's prediction buffers (L = sum H[l]*W[l], level-major); the
  * centerness logit is column ctr_col_box of box_raw (CENTERNESS_ON_REG) or column ctr_col_cls of cls_logits - exactly one >= 0.
- * Outputs have pre_nms_top_n slots per (image, level), filled in torch.nonzero() order; unused slots carry score -1 / class -1;
+ * Outputs have pre_nms_top_n slots per (image, level), filled in torch.nonzero() order; unused slots carry score -inf / class -1;
  * out_counts (N, nlev) = candidates per level.  No host synchronisation. */
 int sod_fcos_decode(const float* cls_logits, int ld_cls, const float* box_raw, int ld_box, const float* scales,
                     int N, int nlev, const int* H, const int* W, const int* strides, int num_classes,
                     int ctr_col_box, int ctr_col_cls, int norm_reg_targets, float pre_nms_thresh, int pre_nms_top_n,
                     float* out_boxes, float* out_scores, int* out_classes, int* out_counts, void* stream);
-/* detectron2.layers.batched_nms (fcosv2.py:241) + keep[: max_keep] for B images of M candidate slots each (score < 0 = empty slot):
- * prepare() writes boxes + class * (max coordinate of the image + 1) and the per-image candidate count into ws; the caller then
- * sorts the scores of every image in stable descending order (order: (B, M) int64 local indices, empty slots last) and run()
- * performs the greedy suppression (IoU > iou_threshold) per image, stopping after max_keep survivors: keep (B, max_keep) local
- * indices in score order, num_keep (B).  The candidate counts never leave the device. */
-long long sod_batched_nms_workspace_bytes(int B, int M);
-int sod_batched_nms_prepare(const float* boxes, const float* scores, const int* classes, int B, int M, void* ws, void* stream);
-int sod_batched_nms_run(const long long* order, int B, int M, float iou_threshold, int max_keep, long long* keep, int* num_keep,
+/* detectron2.layers.batched_nms / batched_nms_rotated (fcosv2.py:241, proposal_utils.py:104) + keep[: max_keep] for B images of M
+ * candidate slots each (score -inf = empty slot), box_dim 4 (XYXY) or 5 (cx, cy, w, h, angle_deg):
+ * prepare() writes the class-shifted boxes and the per-image candidate count into ws; the caller then sorts the scores of every
+ * image in stable descending order (order: (B, M) int64 local indices, empty slots last) and run() performs the greedy suppression
+ * (IoU > iou_threshold) per image, stopping after max_keep survivors: keep (B, max_keep) local indices in score order, num_keep (B).
+ * The candidate counts never leave the device. */
+long long sod_batched_nms_workspace_bytes(int B, int M, int box_dim);
+int sod_batched_nms_prepare(const float* boxes, const float* scores, const int* classes, int B, int M, int box_dim, void* ws, void* stream);
+int sod_batched_nms_run(const long long* order, int B, int M, int box_dim, float iou_threshold, int max_keep, long long* keep, int* num_keep,
                         void* ws, void* stream);
+/* The per-image part of find_top_rpn_proposals (slender_det/modeling/proposal_generator/proposal_utils.py:45-120, = detectron2's)
+ * for the whole batch, in place: entries with a non-finite box or score are counted in *bad_count (zero it first) and emptied,
+ * boxes are clipped to their image (image_hw: device (B, 2) floats; rotated boxes as RotatedBoxes.clip: angles normalised, only
+ * |angle| <= 1 degree clipped), boxes with a side <= min_size are emptied (score = -inf). */
+int sod_rpn_clip_filter(float* boxes, float* scores, const float* image_hw, int B, int M, int box_dim, float min_size, int* bad_count,
+                        void* stream);
 /* detectron2 nms_rotated / box_iou_rotated (csrc/nms_rotated, csrc/box_iou_rotated; reached through RRPN / RROIHeads selected by
  * configs/rotated/Base-RRCNN-FPN.yaml:10-36 and pairwise_iou at retina_rotated.py:276): boxes (n,5) = (cx,cy,w,h,angle_deg). */
 int sod_nms_rotated(const float* boxes, const long long* order, int n, float iou_threshold, long long* keep, int* num_keep,

@@ -208,6 +208,175 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long
   if (w == 0) *nkeep = kept;
 }
 
+// ---------------------------------------------------------------------------------------------- batched class-aware NMS
+// detectron2.layers.batched_nms / batched_nms_rotated + keep[: max_keep] for B images of M candidate slots each, without a host round
+// trip: empty slots carry score -inf, the per-image candidate counts stay on the device, and the scan stops after max_keep survivors.
+// Class offsets: axis-aligned  boxes + class * (max coordinate of the image + 1)                       (torchvision batched_nms)
+//                rotated       centres + class * (max - min + 1), max = max(max(cx, cy) + max(w, h) / 2), min = min(min(cx, cy) - max(w, h) / 2)
+template <int BD>
+__global__ __launch_bounds__(1024) void nms_class_shift_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                               const int* __restrict__ classes, int M, float* __restrict__ shifted,
+                                                               int* __restrict__ nvalid) {
+  __shared__ float redmx[16], redmn[16];
+  __shared__ unsigned cntw[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* bx = boxes + (long long)b * M * BD;
+  const float* sc = scores + (long long)b * M;
+  float mx = -3.0e38f, mn = 3.0e38f;
+  unsigned cnt = 0;
+  for (int i = tid; i < M; i += 1024)
+    if (sc[i] > -3.0e38f) {
+      ++cnt;
+      if (BD == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx = fmaxf(mx, bx[i * 4 + k]);
+      } else {
+        const float half = fmaxf(bx[i * 5 + 2], bx[i * 5 + 3]) / 2.f;
+        mx = fmaxf(mx, fmaxf(bx[i * 5], bx[i * 5 + 1]) + half);
+        mn = fminf(mn, fminf(bx[i * 5], bx[i * 5 + 1]) - half);
+      }
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mn = fminf(mn, __shfl_xor(mn, o, 64)); cnt += __shfl_xor(cnt, o, 64); }
+  if ((tid & 63) == 0) { redmx[tid >> 6] = mx; redmn[tid >> 6] = mn; cntw[tid >> 6] = cnt; }
+  __syncthreads();
+  mx = redmx[0]; mn = redmn[0]; cnt = cntw[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) { mx = fmaxf(mx, redmx[w]); mn = fminf(mn, redmn[w]); cnt += cntw[w]; }
+  const float step = BD == 4 ? mx + 1.f : mx - mn + 1.f;
+  for (int i = tid; i < M; i += 1024) {
+    const float off = sc[i] > -3.0e38f ? (float)classes[(long long)b * M + i] * step : 0.f;
+#pragma unroll
+    for (int k = 0; k < BD; ++k) shifted[((long long)b * M + i) * BD + k] = bx[i * BD + k] + ((BD == 4 || k < 2) ? off : 0.f);
+  }
+  if (tid == 0) nvalid[b] = (int)cnt;
+}
+
+// mask[b][i][w] bit j = IoU(box order[i], box order[64 w + j]) > thr for j > i; grid (words, words, B); n read per image
+template <int BD>
+__global__ __launch_bounds__(64) void nms_mask_batched_kernel(const float* __restrict__ boxes, const long long* __restrict__ order,
+                                                              const int* __restrict__ nvalid, int M, float thr,
+                                                              unsigned long long* __restrict__ mask, int words) {
+  const int b = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+  const int n = min(nvalid[b], M);
+  if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+  boxes += (long long)b * M * BD; order += (long long)b * M; mask += (long long)b * M * words;
+  __shared__ float cbox[64 * BD];
+  __shared__ float crad[64];
+  const int lane = threadIdx.x;
+  const int cj = cb * 64 + lane;
+  if (cj < n) {
+    const long long o = order[cj];
+#pragma unroll
+    for (int e = 0; e < BD; ++e) cbox[lane * BD + e] = boxes[o * BD + e];
+    if (BD == 5) crad[lane] = 0.5f * sqrtf(cbox[lane * BD + 2] * cbox[lane * BD + 2] + cbox[lane * BD + 3] * cbox[lane * BD + 3]);
+  }
+  __syncthreads();
+  const int i = rb * 64 + lane;
+  if (i >= n) return;
+  float a[BD];
+  const long long oi = order[i];
+#pragma unroll
+  for (int e = 0; e < BD; ++e) a[e] = boxes[oi * BD + e];
+  const float ra = BD == 5 ? 0.5f * sqrtf(a[2] * a[2] + a[3] * a[3]) : 0.f;
+  unsigned long long bits = 0;
+  const int cnt = min(64, n - cb * 64);
+  for (int j = (rb == cb) ? lane + 1 : 0; j < cnt; ++j) {
+    bool hit;
+    if (BD == 4) hit = iou_gt(a, cbox + j * BD, thr);
+    else {
+      const float dx = a[0] - cbox[j * BD], dy = a[1] - cbox[j * BD + 1], rs = ra + crad[j];
+      hit = (dx * dx + dy * dy <= rs * rs * 1.0001f) && (iou_rotated(a, cbox + j * BD) > thr);
+    }
+    if (hit) bits |= 1ull << j;
+  }
+  mask[(long long)i * words + cb] = bits;
+}
+
+// one workgroup per image; nms_scan_kernel with the count read from device memory and an early stop at max_keep survivors
+__global__ __launch_bounds__(1024) void nms_scan_batched_kernel(const unsigned long long* __restrict__ mask, const long long* __restrict__ order,
+                                                                const int* __restrict__ nvalid, int M, int words, int max_keep,
+                                                                long long* __restrict__ keep, int* __restrict__ nkeep) {
+  __shared__ unsigned long long removed[1024];
+  __shared__ unsigned long long chunk_keep;
+  const int b = blockIdx.x, w = threadIdx.x;
+  const int n = min(nvalid[b], M);
+  mask += (long long)b * M * words; order += (long long)b * M; keep += (long long)b * max_keep;
+  const int nw = (n + 63) / 64;
+  if (w < words) removed[w] = 0;
+  __syncthreads();
+  int kept = 0;
+  for (int c = 0; c < nw && kept < max_keep; ++c) {
+    const int cnt = min(64, n - c * 64);
+    if (w < 64) {
+      const long long i = (long long)c * 64 + w;
+      const unsigned long long diag = (w < cnt) ? mask[i * words + c] : 0ull;
+      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+      unsigned long long rem = removed[c], kb = 0ull;
+      for (int j = 0; j < cnt; ++j) {
+        const unsigned long long dj = ((unsigned long long)__shfl(dhi, j, 64) << 32) | (unsigned long long)__shfl(dlo, j, 64);
+        if (!((rem >> j) & 1ull)) { kb |= 1ull << j; rem |= dj; }
+      }
+      if (w == 0) chunk_keep = kb;
+    }
+    __syncthreads();
+    const unsigned long long kb = chunk_keep;
+    {
+      const int slices = 1024 / words;
+      const int ww = w % words, sl = w / words;
+      if (sl < slices && ww > c && ww < nw) {
+        unsigned long long acc = 0ull;
+        for (int j = sl; j < cnt; j += slices)
+          if ((kb >> j) & 1ull) acc |= mask[((long long)c * 64 + j) * words + ww];
+        if (acc) atomicOr(&removed[ww], acc);
+      }
+    }
+    if (w < 64 && ((kb >> w) & 1ull)) {
+      const int pos = kept + __popcll(kb & ((1ull << w) - 1ull));
+      if (pos < max_keep) keep[pos] = order[(long long)c * 64 + w];
+    }
+    kept += __popcll(kb);
+    __syncthreads();
+  }
+  if (w == 0) nkeep[b] = kept < max_keep ? kept : max_keep;
+}
+
+// The per-image glue of find_top_rpn_proposals (detectron2 proposal_utils; reference copy slender_det/modeling/proposal_generator/
+// proposal_utils.py:45-120) for the whole batch: drop non-finite entries, clip to the image, drop boxes not larger than min_size.
+// Dropped slots get score -inf (= empty for the batched NMS); the number of non-finite entries is counted in *bad.
+template <int BD>
+__global__ __launch_bounds__(256) void rpn_clip_filter_kernel(float* __restrict__ boxes, float* __restrict__ scores, const float* __restrict__ image_hw,
+                                                              int B, int M, float min_size, int* __restrict__ bad) {
+  const long long total = (long long)B * M;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / M);
+    float* q = boxes + i * BD;
+    const float h = image_hw[2 * b], w = image_hw[2 * b + 1];
+    bool fin = isfinite(scores[i]);
+#pragma unroll
+    for (int k = 0; k < BD; ++k) fin = fin && isfinite(q[k]);
+    if (!fin) { atomicAdd(bad, 1); scores[i] = -__builtin_inff(); continue; }
+    bool keep;
+    if (BD == 4) {
+      q[0] = fminf(fmaxf(q[0], 0.f), w); q[1] = fminf(fmaxf(q[1], 0.f), h);
+      q[2] = fminf(fmaxf(q[2], 0.f), w); q[3] = fminf(fmaxf(q[3], 0.f), h);
+      keep = (q[2] - q[0] > min_size) && (q[3] - q[1] > min_size);
+    } else {
+      float ang = fmodf(q[4] + 180.0f, 360.0f);          // RotatedBoxes.normalize_angles: (a + 180) % 360 - 180, Python modulo
+      if (ang < 0.f) ang += 360.0f;
+      q[4] = ang - 180.0f;
+      if (fabsf(q[4]) <= 1.0f) {                          // RotatedBoxes.clip: only nearly horizontal boxes
+        float x1 = q[0] - q[2] / 2.0f, y1 = q[1] - q[3] / 2.0f, x2 = q[0] + q[2] / 2.0f, y2 = q[1] + q[3] / 2.0f;
+        x1 = fminf(fmaxf(x1, 0.f), w); y1 = fminf(fmaxf(y1, 0.f), h); x2 = fminf(fmaxf(x2, 0.f), w); y2 = fminf(fmaxf(y2, 0.f), h);
+        q[0] = (x1 + x2) / 2.0f; q[1] = (y1 + y2) / 2.0f;
+        q[2] = fminf(q[2], x2 - x1); q[3] = fminf(q[3], y2 - y1);
+      }
+      keep = (q[2] > min_size) && (q[3] > min_size);
+    }
+    if (!keep) scores[i] = -__builtin_inff();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- ROIAlign (aligned=True)
 struct RoiArgs {
   const __bf16* x;      // (N,H,W,C) NHWC bf16
@@ -904,6 +1073,52 @@ extern "C" int sod_retina_box_loss_bwd(const float* pred, int pitch, const int* 
   if (!pred || !gt_labels || !gt_deltas || !grad_num || !grad_den || !dpred_bf16 || N <= 0 || R <= 0 || A <= 0 || R % A || pitch < A * 4) return SOD_EARG;
   RetinaBoxArgs a{pred, gt_labels, gt_deltas, N, R, A, pitch, num_classes, beta};
   SOD_LAUNCH(retina_box_kernel<true>, dim3(nblk((long long)N * R, 4096)), dim3(256), 0, (hipStream_t)stream, a, nullptr, grad_num, grad_den, (__bf16*)dpred_bf16);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" long long sod_batched_nms_workspace_bytes(int B, int M, int box_dim) {
+  const long long words = (M + 63) / 64;
+  return (long long)B * M * words * 8 + (long long)B * M * box_dim * (long long)sizeof(float) + (long long)B * (long long)sizeof(int);
+}
+
+// shifted boxes + per-image candidate count (first half of batched NMS); the caller sorts the scores (any stable descending sort)
+// and then calls sod_batched_nms_run with the order.  ws layout: [mask][shifted boxes][nvalid].
+extern "C" int sod_batched_nms_prepare(const float* boxes, const float* scores, const int* classes, int B, int M, int box_dim, void* ws, void* stream) {
+  if (!boxes || !scores || !classes || !ws || B <= 0 || M <= 0 || M > 65536 || (box_dim != 4 && box_dim != 5)) return SOD_EARG;
+  const long long words = (M + 63) / 64;
+  float* shifted = (float*)((char*)ws + (long long)B * M * words * 8);
+  int* nvalid = (int*)(shifted + (long long)B * M * box_dim);
+  if (box_dim == 4) SOD_LAUNCH(nms_class_shift_kernel<4>, dim3(B), dim3(1024), 0, (hipStream_t)stream, boxes, scores, classes, M, shifted, nvalid);
+  else SOD_LAUNCH(nms_class_shift_kernel<5>, dim3(B), dim3(1024), 0, (hipStream_t)stream, boxes, scores, classes, M, shifted, nvalid);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_batched_nms_run(const long long* order, int B, int M, int box_dim, float iou_threshold, int max_keep, long long* keep,
+                                   int* num_keep, void* ws, void* stream) {
+  if (!order || !keep || !num_keep || !ws || B <= 0 || M <= 0 || M > 65536 || max_keep <= 0 || (box_dim != 4 && box_dim != 5)) return SOD_EARG;
+  const int words = (M + 63) / 64;
+  if (words > 1024) return SOD_ESIZE;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* mask = (unsigned long long*)ws;
+  const float* shifted = (const float*)((char*)ws + (long long)B * M * words * 8);
+  const int* nvalid = (const int*)(shifted + (long long)B * M * box_dim);
+  hipError_t e = hipMemsetAsync(mask, 0, (size_t)B * M * words * 8, st);
+  if (e != hipSuccess) return (int)e;
+  if (box_dim == 4) SOD_LAUNCH(nms_mask_batched_kernel<4>, dim3(words, words, B), dim3(64), 0, st, shifted, order, nvalid, M, iou_threshold, mask, words);
+  else SOD_LAUNCH(nms_mask_batched_kernel<5>, dim3(words, words, B), dim3(64), 0, st, shifted, order, nvalid, M, iou_threshold, mask, words);
+  SOD_LAUNCH(nms_scan_batched_kernel, dim3(B), dim3(1024), 0, st, (const unsigned long long*)mask, order, nvalid, M, words, max_keep, keep, num_keep);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_rpn_clip_filter(float* boxes, float* scores, const float* image_hw, int B, int M, int box_dim, float min_size, int* bad_count,
+                                   void* stream) {
+  if (!boxes || !scores || !image_hw || !bad_count || B <= 0 || M <= 0 || (box_dim != 4 && box_dim != 5)) return SOD_EARG;
+  const int g = nblk((long long)B * M, 4096);
+  if (box_dim == 4) SOD_LAUNCH(rpn_clip_filter_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, boxes, scores, image_hw, B, M, min_size, bad_count);
+  else SOD_LAUNCH(rpn_clip_filter_kernel<5>, dim3(g), dim3(256), 0, (hipStream_t)stream, boxes, scores, image_hw, B, M, min_size, bad_count);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -5,9 +5,7 @@
 //   fcos_decode_kernel      one workgroup per (image, level): sigmoid -> threshold -> x sigmoid(centerness) -> per-level top-k (exact
 //                           radix select over the score bits) -> decode l/t/r/b into boxes -> sqrt; candidates come out in the order
 //                           torch's nonzero() gives them (location-major, class-minor), padded to top_n slots per level.
-//   nms_class_shift_kernel  detectron2.layers.batched_nms' class-offset trick per image: boxes + class * (max coordinate + 1).
-//   nms_mask / nms_scan     the batched form of the kernels in detection_ops.hip: per-image candidate counts are read from device
-//                           memory, the scan stops after max_keep survivors (keep[: max_detections_per_image]).
+//   (the batched class-aware NMS that consumes these candidates lives in detection_ops.hip: sod_batched_nms_*)
 // The reference does all of this per image and per level with boolean indexing, .nonzero(), .item() and topk (one host sync each).
 #include "common.h"
 #include "../../include/slender_hip.h"
@@ -28,7 +26,7 @@ struct DecodeArgs {
   float thresh;
   int H[SOD_MAX_LEVELS], W[SOD_MAX_LEVELS], stride[SOD_MAX_LEVELS], loc0[SOD_MAX_LEVELS];
   float* out_boxes;       // (N, nlev*top_n, 4)
-  float* out_scores;      // (N, nlev*top_n), -1 in unused slots
+  float* out_scores;      // (N, nlev*top_n), -inf in unused slots
   int* out_classes;       // (N, nlev*top_n), -1 in unused slots
   int* out_counts;        // (N, nlev)
 };
@@ -178,136 +176,14 @@ __global__ __launch_bounds__(DEC_THREADS) void fcos_decode_kernel(const DecodeAr
     out_base += tot_gt + (tot_eq < q_rem ? tot_eq : q_rem);
     eq_seen += tot_eq;
   }
-  // unused slots: score -1 sorts behind every real candidate
+  // unused slots: score -inf sorts behind every real candidate and marks the slot empty for the batched NMS
   for (unsigned s = count + tid; s < (unsigned)a.top_n; s += DEC_THREADS) {
     float* ob = a.out_boxes + (slot0 + s) * 4;
     ob[0] = ob[1] = ob[2] = ob[3] = 0.f;
-    a.out_scores[slot0 + s] = -1.f;
+    a.out_scores[slot0 + s] = -__builtin_inff();
     a.out_classes[slot0 + s] = -1;
   }
   if (tid == 0) a.out_counts[n * a.nlev + l] = (int)count;
-}
-
-// batched_nms' class offsets (torchvision / detectron2.layers.batched_nms): shifted = boxes + class * (max over the image's boxes + 1)
-__global__ __launch_bounds__(1024) void nms_class_shift_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                               const int* __restrict__ classes, int M, float* __restrict__ shifted,
-                                                               int* __restrict__ nvalid) {
-  __shared__ float red[16];
-  __shared__ unsigned cntw[16];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float* bx = boxes + (long long)b * M * 4;
-  const float* sc = scores + (long long)b * M;
-  float mx = -3.0e38f;
-  unsigned cnt = 0;
-  for (int i = tid; i < M; i += 1024)
-    if (sc[i] >= 0.f) {
-      ++cnt;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) mx = fmaxf(mx, bx[i * 4 + k]);
-    }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); cnt += __shfl_xor(cnt, o, 64); }
-  if ((tid & 63) == 0) { red[tid >> 6] = mx; cntw[tid >> 6] = cnt; }
-  __syncthreads();
-  mx = red[0]; cnt = cntw[0];
-#pragma unroll
-  for (int w = 1; w < 16; ++w) { mx = fmaxf(mx, red[w]); cnt += cntw[w]; }
-  const float step = mx + 1.f;
-  for (int i = tid; i < M; i += 1024) {
-    const float off = sc[i] >= 0.f ? (float)classes[(long long)b * M + i] * step : 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) shifted[((long long)b * M + i) * 4 + k] = bx[i * 4 + k] + off;
-  }
-  if (tid == 0) nvalid[b] = (int)cnt;
-}
-
-__device__ __forceinline__ bool iou_gt4(const float* a, const float* b, float thr) {       // as detection_ops.hip:iou_gt
-  const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
-  const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
-  const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
-  const float inter = width * height;
-  const float sa = (a[2] - a[0]) * (a[3] - a[1]);
-  const float sb = (b[2] - b[0]) * (b[3] - b[1]);
-  return inter / (sa + sb - inter) > thr;
-}
-
-// mask[b][i][w] bit j = IoU(box order[i], box order[64 w + j]) > thr for j > i; grid (words, words, B); n read per image
-__global__ __launch_bounds__(64) void nms_mask_batched_kernel(const float* __restrict__ boxes, const long long* __restrict__ order,
-                                                              const int* __restrict__ nvalid, int M, float thr,
-                                                              unsigned long long* __restrict__ mask, int words) {
-  const int b = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
-  const int n = min(nvalid[b], M);
-  if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
-  boxes += (long long)b * M * 4; order += (long long)b * M; mask += (long long)b * M * words;
-  __shared__ float cbox[64 * 4];
-  const int lane = threadIdx.x;
-  const int cj = cb * 64 + lane;
-  if (cj < n) {
-    const long long o = order[cj];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) cbox[lane * 4 + e] = boxes[o * 4 + e];
-  }
-  __syncthreads();
-  const int i = rb * 64 + lane;
-  if (i >= n) return;
-  float a4[4];
-  const long long oi = order[i];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) a4[e] = boxes[oi * 4 + e];
-  unsigned long long bits = 0;
-  const int cnt = min(64, n - cb * 64);
-  for (int j = (rb == cb) ? lane + 1 : 0; j < cnt; ++j)
-    if (iou_gt4(a4, cbox + j * 4, thr)) bits |= 1ull << j;
-  mask[(long long)i * words + cb] = bits;
-}
-
-// one workgroup per image; as nms_scan_kernel (detection_ops.hip) with the count read from device memory and an early stop once
-// max_keep boxes survived (the reference slices keep[: max_detections_per_image])
-__global__ __launch_bounds__(1024) void nms_scan_batched_kernel(const unsigned long long* __restrict__ mask, const long long* __restrict__ order,
-                                                                const int* __restrict__ nvalid, int M, int words, int max_keep,
-                                                                long long* __restrict__ keep, int* __restrict__ nkeep) {
-  __shared__ unsigned long long removed[1024];
-  __shared__ unsigned long long chunk_keep;
-  const int b = blockIdx.x, w = threadIdx.x;
-  const int n = min(nvalid[b], M);
-  mask += (long long)b * M * words; order += (long long)b * M; keep += (long long)b * max_keep;
-  const int nw = (n + 63) / 64;
-  if (w < words) removed[w] = 0;
-  __syncthreads();
-  int kept = 0;
-  for (int c = 0; c < nw && kept < max_keep; ++c) {
-    const int cnt = min(64, n - c * 64);
-    if (w < 64) {
-      const long long i = (long long)c * 64 + w;
-      const unsigned long long diag = (w < cnt) ? mask[i * words + c] : 0ull;
-      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-      unsigned long long rem = removed[c], kb = 0ull;
-      for (int j = 0; j < cnt; ++j) {
-        const unsigned long long dj = ((unsigned long long)__shfl(dhi, j, 64) << 32) | (unsigned long long)__shfl(dlo, j, 64);
-        if (!((rem >> j) & 1ull)) { kb |= 1ull << j; rem |= dj; }
-      }
-      if (w == 0) chunk_keep = kb;
-    }
-    __syncthreads();
-    const unsigned long long kb = chunk_keep;
-    {
-      const int slices = 1024 / words;
-      const int ww = w % words, sl = w / words;
-      if (sl < slices && ww > c && ww < nw) {
-        unsigned long long acc = 0ull;
-        for (int j = sl; j < cnt; j += slices)
-          if ((kb >> j) & 1ull) acc |= mask[((long long)c * 64 + j) * words + ww];
-        if (acc) atomicOr(&removed[ww], acc);
-      }
-    }
-    if (w < 64 && ((kb >> w) & 1ull)) {
-      const int pos = kept + __popcll(kb & ((1ull << w) - 1ull));
-      if (pos < max_keep) keep[pos] = order[(long long)c * 64 + w];
-    }
-    kept += __popcll(kb);
-    __syncthreads();
-  }
-  if (w == 0) nkeep[b] = kept < max_keep ? kept : max_keep;
 }
 
 }  // namespace
@@ -339,36 +215,3 @@ extern "C" int sod_fcos_decode(const float* cls_logits, int ld_cls, const float*
   return SOD_OK;
 }
 
-extern "C" long long sod_batched_nms_workspace_bytes(int B, int M) {
-  const long long words = (M + 63) / 64;
-  return (long long)B * M * words * 8 + (long long)B * M * 4 * (long long)sizeof(float) + (long long)B * (long long)sizeof(int);
-}
-
-// shifted boxes + per-image candidate count (first half of batched NMS); the caller sorts the scores (any stable descending sort)
-// and then calls sod_batched_nms_run with the order.  ws layout: [mask][shifted boxes][nvalid].
-extern "C" int sod_batched_nms_prepare(const float* boxes, const float* scores, const int* classes, int B, int M, void* ws, void* stream) {
-  if (!boxes || !scores || !classes || !ws || B <= 0 || M <= 0 || M > 65536) return SOD_EARG;
-  const long long words = (M + 63) / 64;
-  float* shifted = (float*)((char*)ws + (long long)B * M * words * 8);
-  int* nvalid = (int*)(shifted + (long long)B * M * 4);
-  SOD_LAUNCH(nms_class_shift_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, boxes, scores, classes, M, shifted, nvalid);
-  SOD_CHECK_LAUNCH();
-  return SOD_OK;
-}
-
-extern "C" int sod_batched_nms_run(const long long* order, int B, int M, float iou_threshold, int max_keep, long long* keep, int* num_keep,
-                                   void* ws, void* stream) {
-  if (!order || !keep || !num_keep || !ws || B <= 0 || M <= 0 || M > 65536 || max_keep <= 0) return SOD_EARG;
-  const int words = (M + 63) / 64;
-  if (words > 1024) return SOD_ESIZE;
-  hipStream_t st = (hipStream_t)stream;
-  unsigned long long* mask = (unsigned long long*)ws;
-  const float* shifted = (const float*)((char*)ws + (long long)B * M * words * 8);
-  const int* nvalid = (const int*)(shifted + (long long)B * M * 4);
-  hipError_t e = hipMemsetAsync(mask, 0, (size_t)B * M * words * 8, st);
-  if (e != hipSuccess) return (int)e;
-  SOD_LAUNCH(nms_mask_batched_kernel, dim3(words, words, B), dim3(64), 0, st, shifted, order, nvalid, M, iou_threshold, mask, words);
-  SOD_LAUNCH(nms_scan_batched_kernel, dim3(B), dim3(1024), 0, st, (const unsigned long long*)mask, order, nvalid, M, words, max_keep, keep, num_keep);
-  SOD_CHECK_LAUNCH();
-  return SOD_OK;
-}

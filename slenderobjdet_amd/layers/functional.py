@@ -542,7 +542,7 @@ def nms(boxes, scores, iou_threshold):
 
 def fcos_decode(cls_buf, box_buf, scales, level_hw, strides, num_classes, centerness_on_reg, norm_reg_targets, pre_nms_thresh, pre_nms_top_n):
     """Per-level threshold / top-k / decode of FCOS inference for the whole batch in one launch (no host sync).
-    cls_buf (N, L, ld) / box_buf (N, L, ld) fp32 prediction buffers -> boxes (N, M, 4), scores (N, M) (-1 = empty slot),
+    cls_buf (N, L, ld) / box_buf (N, L, ld) fp32 prediction buffers -> boxes (N, M, 4), scores (N, M) (-inf = empty slot),
     classes (N, M) int32, counts (N, nlev) int32 with M = nlev * pre_nms_top_n."""
     _chk(cls_buf, torch.float32, "cls_buf"); _chk(box_buf, torch.float32, "box_buf"); _chk(scales, torch.float32, "scales")
     N, L, ld_cls = cls_buf.shape
@@ -564,19 +564,30 @@ def fcos_decode(cls_buf, box_buf, scales, level_hw, strides, num_classes, center
 
 
 def batched_nms_topk(boxes, scores, classes, iou_threshold, max_keep):
-    """Class-aware NMS + top-``max_keep`` of B images at once on padded candidate lists (score < 0 = empty slot).
-    Returns keep (B, max_keep) int64 local indices in score order (entries beyond num_keep are 0) and num_keep (B) int32, both on
-    the device.  The per-image sort is torch's stable sort (plumbing), everything else runs in the HIP kernels."""
+    """Class-aware NMS + top-``max_keep`` of B images at once on padded candidate lists (score -inf = empty slot); boxes (B, M, 4)
+    XYXY or (B, M, 5) rotated.  Returns keep (B, max_keep) int64 local indices in score order (entries beyond num_keep are 0) and
+    num_keep (B) int32, both on the device.  The per-image sort is torch's stable sort (plumbing), the rest runs in the HIP kernels."""
     _chk(boxes, torch.float32, "boxes"); _chk(scores, torch.float32, "scores"); _chk(classes, torch.int32, "classes")
     B, M = scores.shape
+    D = boxes.shape[-1]
     dev = scores.device
-    ws = torch.empty(int(_C.load().sod_batched_nms_workspace_bytes(B, M)), dtype=torch.uint8, device=dev)
-    call("sod_batched_nms_prepare", ptr(boxes), ptr(scores), ptr(classes), B, M, ptr(ws), stream_ptr())
+    ws = torch.empty(int(_C.load().sod_batched_nms_workspace_bytes(B, M, D)), dtype=torch.uint8, device=dev)
+    call("sod_batched_nms_prepare", ptr(boxes), ptr(scores), ptr(classes), B, M, D, ptr(ws), stream_ptr())
     order = torch.sort(scores, dim=1, descending=True, stable=True).indices.contiguous()
     keep = torch.zeros((B, int(max_keep)), dtype=torch.int64, device=dev)
     nkeep = torch.zeros(B, dtype=torch.int32, device=dev)
-    call("sod_batched_nms_run", ptr(order), B, M, float(iou_threshold), int(max_keep), ptr(keep), ptr(nkeep), ptr(ws), stream_ptr())
+    call("sod_batched_nms_run", ptr(order), B, M, D, float(iou_threshold), int(max_keep), ptr(keep), ptr(nkeep), ptr(ws), stream_ptr())
     return keep, nkeep
+
+
+def rpn_clip_filter(boxes, scores, image_hw, min_size):
+    """In place on (B, M, D) boxes / (B, M) scores: non-finite entries and boxes not larger than ``min_size`` become empty slots
+    (score -inf), boxes are clipped to their image.  Returns the device counter of non-finite entries (int32, 1 element)."""
+    _chk(boxes, torch.float32, "boxes"); _chk(scores, torch.float32, "scores"); _chk(image_hw, torch.float32, "image_hw")
+    B, M, D = boxes.shape
+    bad = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    call("sod_rpn_clip_filter", ptr(boxes), ptr(scores), ptr(image_hw), B, M, D, float(min_size), ptr(bad), stream_ptr())
+    return bad
 
 
 def nms_rotated(boxes, scores, iou_threshold):

@@ -185,25 +185,28 @@ class RPN(nn.Module):
             topk_props.append(props[batch_idx[:, None], idx])
             level_ids.append(torch.full((num,), lvl, dtype=torch.int64, device=lg.device))
         topk_scores, topk_props, level_ids = torch.cat(topk_scores, 1), torch.cat(topk_props, 1), torch.cat(level_ids, 0)
+        # find_top_rpn_proposals' per-image loop (proposal_utils.py:77-120: finite check, clip, min-size filter, batched NMS,
+        # post-NMS top-k) for the whole batch on the device: one filter launch, one sort, one NMS; the only host read is the
+        # final (counts, non-finite counter) tensor.
+        dev = topk_scores.device
+        boxes = topk_props.float().contiguous()
+        scores = topk_scores.float().contiguous()
+        hw = torch.tensor([[float(s[0]), float(s[1])] for s in image_sizes], dtype=torch.float32, device=dev)
+        bad = HF.rpn_clip_filter(boxes, scores, hw, self.min_box_size)
+        classes = level_ids.to(torch.int32)[None].expand(N, -1).contiguous()
+        post = self.post_nms_topk[training]
+        keep, nkeep = HF.batched_nms_topk(boxes, scores, classes, self.nms_thresh, post)
+        kb = torch.gather(boxes, 1, keep[:, :, None].expand(-1, -1, D))
+        ks = torch.gather(scores, 1, keep)
+        host = torch.cat([nkeep, bad]).cpu().tolist()
+        if host[-1] and training:
+            raise FloatingPointError(f"Predicted boxes or scores contain Inf/NaN. Training has diverged. ({host[-1]} proposal entries)")
         results = []
         BoxT = self._box_type()
         for n, image_size in enumerate(image_sizes):
-            boxes, scores, lvl = BoxT(topk_props[n].clone()), topk_scores[n], level_ids
-            valid = torch.isfinite(boxes.tensor).all(dim=1) & torch.isfinite(scores)
-            if not bool(valid.all()):
-                if training:
-                    raise FloatingPointError(f"Predicted boxes or scores contain Inf/NaN. Training has diverged. (image {n}: "
-                                             f"{int((~torch.isfinite(boxes.tensor)).sum())} box values, {int((~torch.isfinite(scores)).sum())} scores)")
-                boxes, scores, lvl = boxes[valid], scores[valid], lvl[valid]
-            boxes.clip(image_size)
-            keep = boxes.nonempty(threshold=self.min_box_size)
-            if int(keep.sum()) != len(boxes):
-                boxes, scores, lvl = boxes[keep], scores[keep], lvl[keep]
-            nms_fn = batched_nms_rotated if self.rotated else batched_nms
-            keep = nms_fn(boxes.tensor, scores, lvl, self.nms_thresh)[: self.post_nms_topk[training]]
             res = Instances(tuple(image_size))
-            res.proposal_boxes = boxes[keep]
-            res.objectness_logits = scores[keep]
+            res.proposal_boxes = BoxT(kb[n, : host[n]])
+            res.objectness_logits = ks[n, : host[n]]
             results.append(res)
         return results
 

@@ -18,7 +18,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, bucket_dtype="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -27,7 +27,7 @@ def _worker(rank, world, port, out):
 
         torch.manual_seed(0)
         model = torch.nn.Sequential(torch.nn.Linear(300, 200), torch.nn.Linear(200, 100), torch.nn.Linear(100, 50), torch.nn.Linear(50, 10))
-        arena = ParamArena(model, bucket_mb=0.01)   # several buckets
+        arena = ParamArena(model, bucket_mb=0.01, bucket_dtype=bucket_dtype)   # several buckets
         assert len(arena.buckets) >= 3
         params = [p for p in model.parameters()]
         # forward "uses": last layer used twice (like the head weights shared by FPN levels)
@@ -52,8 +52,18 @@ def _worker(rank, world, port, out):
         ok = True
         for p in params:
             e = expect[id(p)].clone()
-            dist.all_reduce(e)
-            ok = ok and torch.allclose(arena.grad_view(p), e, atol=1e-6)
+            if bucket_dtype == "bf16":      # the wire carries the per-rank gradient rounded to bf16; the reduced values are what every rank gets
+                e = e.to(torch.bfloat16)
+                dist.all_reduce(e)
+                ok = ok and torch.allclose(arena.grad_view(p), e.float(), rtol=2e-2, atol=2e-2)
+            else:
+                dist.all_reduce(e)
+                ok = ok and torch.allclose(arena.grad_view(p), e, atol=1e-6)
+        # replicas must hold bit-identical gradients (same reduced values on every rank), whatever the wire format
+        mine = arena.grads.clone()
+        other = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(other, mine)
+        ok = ok and all(torch.equal(o, other[0]) for o in other)
         # normaliser exchange: one 2-element all-reduce == two scalar reduce_sum calls
         stats = torch.tensor([3.0 + rank, 1.5 * (rank + 1)])
         folded = stats.clone()
@@ -69,11 +79,12 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_arena_bucketed_allreduce_world2():
+@pytest.mark.parametrize("bucket_dtype", ["fp32", "bf16"])
+def test_arena_bucketed_allreduce_world2(bucket_dtype):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, bucket_dtype)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

@@ -82,7 +82,7 @@ def test_fcos_decode_vs_oracle(cuda, ctr_on_reg, norm_reg, ld_cls):
             assert torch.equal(classes[i, sl].long(), rc), (i, l)                       # same candidates in the same order
             assert torch.allclose(scores[i, sl], rs, rtol=2e-6, atol=1e-7)
             assert torch.allclose(boxes[i, sl], rb, rtol=1e-5, atol=1e-3)
-            assert (scores[i, l * top_n + n:(l + 1) * top_n] == -1).all() and (classes[i, l * top_n + n:(l + 1) * top_n] == -1).all()
+            assert (scores[i, l * top_n + n:(l + 1) * top_n] == float("-inf")).all() and (classes[i, l * top_n + n:(l + 1) * top_n] == -1).all()
 
 
 def test_fcos_decode_full_size_properties(cuda):
@@ -107,7 +107,7 @@ def test_fcos_decode_full_size_properties(cuda):
         sl = scores[:, l * top_n:(l + 1) * top_n]
         for i in range(N):
             n = int(counts[i, l])
-            assert (sl[i, :n] > 0).all() and (sl[i, n:] == -1).all()
+            assert (sl[i, :n] > 0).all() and (sl[i, n:] == float("-inf")).all()
             if int(n_over[i]) > top_n:          # the emitted set is the top_n best: its minimum equals the top_n-th largest reference score
                 ref_sorted = torch.sort(s[i, off:off + h * w][keep[i, off:off + h * w]], descending=True).values
                 assert abs(float(sl[i, :n].min()) - float(ref_sorted[top_n - 1])) <= 1e-6 * float(ref_sorted[top_n - 1])
@@ -130,7 +130,7 @@ def test_batched_nms_topk_keep_indices_bit_exact(cuda):
     scores[:, ::7] = scores[:, 1::7][:, : scores[:, ::7].shape[1]]          # exact score ties: stable order decides
     classes = torch.randint(0, 5, (B, M), generator=g).int()
     valid = torch.rand(B, M, generator=g) < torch.tensor([0.9, 0.5, 0.02, 0.0])[:, None]      # image 3 has no candidate at all
-    scores = torch.where(valid, scores, torch.full_like(scores, -1.0))
+    scores = torch.where(valid, scores, torch.full_like(scores, float("-inf")))
     classes = torch.where(valid, classes, torch.full_like(classes, -1))
     keep, nkeep = HF.batched_nms_topk(boxes.to(cuda), scores.to(cuda), classes.to(cuda), 0.6, max_keep)
     keep, nkeep = keep.cpu(), nkeep.cpu()
