@@ -246,6 +246,13 @@ int sod_fcos_decode(const float* cls_logits, int ld_cls, const float* box_raw, i
                     int N, int nlev, const int* H, const int* W, const int* strides, int num_classes,
                     int ctr_col_box, int ctr_col_cls, int norm_reg_targets, float pre_nms_thresh, int pre_nms_top_n,
                     float* out_boxes, float* out_scores, int* out_classes, int* out_counts, void* stream);
+/* The same selection for heads without a centerness branch: rows of K class logits (RetinaNet: anchors, retina_rotated.py:296-340;
+ * RepPoints: points, rpd.py:717-765), logits (N, R, ld) with R = sum rows[l] (level-major).  by_row_max = 0: candidates are the
+ * (row, class) pairs with sigmoid(logit) > score_thresh, the top_n best per (image, level) are kept (= sort, take top_n, threshold);
+ * by_row_max = 1: candidates are rows scored by their best class (scores, classes = logits.sigmoid().max(1)).  out_rows = the row
+ * index inside its level of every kept slot (the caller gathers / decodes the boxes); scores without sqrt; rest as sod_fcos_decode. */
+int sod_dense_topk_select(const float* logits, int ld, int N, int nlev, const int* rows, int num_classes, int by_row_max,
+                          float score_thresh, int top_n, int* out_rows, float* out_scores, int* out_classes, int* out_counts, void* stream);
 /* detectron2.layers.batched_nms / batched_nms_rotated (fcosv2.py:241, proposal_utils.py:104) + keep[: max_keep] for B images of M
  * candidate slots each (score -inf = empty slot), box_dim 4 (XYXY) or 5 (cx, cy, w, h, angle_deg):
  * prepare() writes the class-shifted boxes and the per-image candidate count into ws; the caller then sorts the scores of every

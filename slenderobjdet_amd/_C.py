@@ -62,6 +62,7 @@ _SIGS = {
     "sod_fcos_finalize_losses": [_P, _P, _P, _F, _P, _P],
     "sod_nms_workspace_bytes": [_I],
     "sod_fcos_decode": [_P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
+    "sod_dense_topk_select": [_P, _I, _I, _I, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P],
     "sod_batched_nms_workspace_bytes": [_I, _I, _I],
     "sod_batched_nms_prepare": [_P, _P, _P, _I, _I, _I, _P, _P],
     "sod_batched_nms_run": [_P, _I, _I, _I, _F, _I, _P, _P, _P, _P],

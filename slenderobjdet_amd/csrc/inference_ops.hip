@@ -25,6 +25,10 @@ struct DecodeArgs {
   int norm_reg, top_n;
   float thresh;
   int H[SOD_MAX_LEVELS], W[SOD_MAX_LEVELS], stride[SOD_MAX_LEVELS], loc0[SOD_MAX_LEVELS];
+  int mode;               // 0: FCOS (rows = locations, score x centerness, boxes decoded, sqrt)
+                          // 1: generic (row, class) selection: rows of K logits, score = sigmoid(logit), emits row indices
+                          // 2: generic row selection: score = max over the K classes, class = first argmax, emits row indices
+  int* out_rows;          // modes 1 / 2: (N, nlev*top_n) row index inside the level
   float* out_boxes;       // (N, nlev*top_n, 4)
   float* out_scores;      // (N, nlev*top_n), -inf in unused slots
   int* out_classes;       // (N, nlev*top_n), -1 in unused slots
@@ -61,8 +65,8 @@ __global__ __launch_bounds__(DEC_THREADS) void fcos_decode_kernel(const DecodeAr
   __shared__ unsigned wv[32];
   __shared__ unsigned sel[4];            // [0] bucket, [1] remaining k, [2] block count
   const int l = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-  const int HW = a.H[l] * a.W[l], K = a.K;
-  const long long total = (long long)HW * K;
+  const int HW = a.H[l] * a.W[l], K = a.K;     // modes 1 / 2: H = rows of the level, W = 1
+  const long long total = a.mode == 2 ? (long long)HW : (long long)HW * K;
   const float* cls = a.cls + ((long long)n * a.L + a.loc0[l]) * a.ld_cls;
   const float* box = a.box + ((long long)n * a.L + a.loc0[l]) * a.ld_box;
   const bool dense = a.ld_cls == K;      // logits of consecutive (location, class) pairs are consecutive in memory
@@ -77,12 +81,23 @@ __global__ __launch_bounds__(DEC_THREADS) void fcos_decode_kernel(const DecodeAr
   };
   // candidate test and score key of element e (fcosv2.py:206-212: keep = sigmoid(cls) > thresh; score = sigmoid(cls) * sigmoid(ctr))
   auto key_of = [&](long long e, bool& cand) -> unsigned {
+    if (a.mode == 2) {                   // rpd.py:741-748: scores, classes = logits.sigmoid().max(1); keep = score > threshold
+      const float* row = cls + e * a.ld_cls;
+      float m = row[0];
+      for (int k = 1; k < K; ++k) m = fmaxf(m, row[k]);
+      const float p = sigmoidf_(m);
+      cand = p > a.thresh;
+      return cand ? __float_as_uint(p) : 0u;
+    }
     const float p = sigmoidf_(logit_at(e));
     cand = p > a.thresh;
     if (!cand) return 0u;
-    const float s = p * sigmoidf_(ctr_at((int)(e / K)));
+    const float s = a.mode == 0 ? p * sigmoidf_(ctr_at((int)(e / K))) : p;
     return __float_as_uint(s);           // s >= 0: the bit pattern orders like the value
   };
+
+  // RetinaNet takes k = min(topk_candidates, number of ANCHORS of the level) of the anchor x class scores (retina_rotated.py:318)
+  const int top_n = (a.mode == 1 && HW < a.top_n) ? HW : a.top_n;
 
   // ---- pass 1: number of candidates
   unsigned mine = 0;
@@ -96,8 +111,8 @@ __global__ __launch_bounds__(DEC_THREADS) void fcos_decode_kernel(const DecodeAr
 
   // ---- pass 2 (only when more than top_n candidates): the top_n-th largest score key T and how many elements equal to T are taken
   unsigned T = 0u, quota = 0xffffffffu;
-  if (cnt > (unsigned)a.top_n) {
-    unsigned prefix = 0u, krem = (unsigned)a.top_n;
+  if (cnt > (unsigned)top_n) {
+    unsigned prefix = 0u, krem = (unsigned)top_n;
     for (int shift = 24; shift >= 0; shift -= 8) {
       if (tid < 256) hist[tid] = 0u;
       __syncthreads();
@@ -123,11 +138,11 @@ __global__ __launch_bounds__(DEC_THREADS) void fcos_decode_kernel(const DecodeAr
     }
     T = prefix; quota = krem;
   }
-  const unsigned count = cnt > (unsigned)a.top_n ? (unsigned)a.top_n : cnt;
+  const unsigned count = cnt > (unsigned)top_n ? (unsigned)top_n : cnt;
 
   // ---- pass 3: ordered compaction + decode.  Selected = candidate with key > T, or key == T among the first `quota` such elements.
   const long long slot0 = ((long long)n * a.nlev + l) * a.top_n;
-  const float scale = a.scales[l];
+  const float scale = a.mode == 0 ? a.scales[l] : 1.f;      // the generic modes have no Scale / box inputs
   const int W = a.W[l], stride = a.stride[l];
   unsigned out_base = 0u, eq_seen = 0u;
   for (long long c0 = 0; c0 < total; c0 += DEC_CHUNK) {
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(DEC_THREADS) void fcos_decode_kernel(const DecodeAr
       bool c = false;
       keys[v] = (e0 + v < total) ? key_of(e0 + v, c) : 0u;
       if (c) {
-        if (cnt <= (unsigned)a.top_n || keys[v] > T) gt_bits |= 1u << v;
+        if (cnt <= (unsigned)top_n || keys[v] > T) gt_bits |= 1u << v;
         else if (keys[v] == T) eq_bits |= 1u << v;
       }
     }
@@ -154,7 +169,20 @@ __global__ __launch_bounds__(DEC_THREADS) void fcos_decode_kernel(const DecodeAr
     for (int v = 0; v < DEC_V; ++v) {
       bool take = (gt_bits >> v) & 1u;
       if ((eq_bits >> v) & 1u) { take = eq_rank < q_rem; ++eq_rank; }
-      if (take) {
+      if (take && a.mode != 0) {
+        const long long e = e0 + v;
+        int row = (int)e, c = 0;
+        if (a.mode == 1) { row = (int)(e / K); c = (int)(e - (long long)row * K); }
+        else {
+          const float* lr = cls + e * a.ld_cls;
+          float m = lr[0];
+          for (int k = 1; k < K; ++k) if (lr[k] > m) { m = lr[k]; c = k; }
+        }
+        a.out_rows[slot0 + pos] = row;
+        a.out_scores[slot0 + pos] = __uint_as_float(keys[v]);
+        a.out_classes[slot0 + pos] = c;
+        ++pos;
+      } else if (take) {
         const long long e = e0 + v;
         const int loc = (int)(e / K), c = (int)(e - (long long)loc * K);
         const int i = loc / W, j = loc - i * W;
@@ -178,8 +206,12 @@ __global__ __launch_bounds__(DEC_THREADS) void fcos_decode_kernel(const DecodeAr
   }
   // unused slots: score -inf sorts behind every real candidate and marks the slot empty for the batched NMS
   for (unsigned s = count + tid; s < (unsigned)a.top_n; s += DEC_THREADS) {
-    float* ob = a.out_boxes + (slot0 + s) * 4;
-    ob[0] = ob[1] = ob[2] = ob[3] = 0.f;
+    if (a.mode == 0) {
+      float* ob = a.out_boxes + (slot0 + s) * 4;
+      ob[0] = ob[1] = ob[2] = ob[3] = 0.f;
+    } else {
+      a.out_rows[slot0 + s] = 0;
+    }
     a.out_scores[slot0 + s] = -__builtin_inff();
     a.out_classes[slot0 + s] = -1;
   }
@@ -215,3 +247,29 @@ extern "C" int sod_fcos_decode(const float* cls_logits, int ld_cls, const float*
   return SOD_OK;
 }
 
+/* Generic per-level "threshold + top-k" selection on rows of K class logits (RetinaNet: retina_rotated.py:296-340 / d2
+ * inference_single_image; RepPoints: rpd.py:717-765), for the whole batch in one launch.  logits (N, R, ld) with R = sum rows[l]
+ * (level-major).  by_row_max = 0: candidates are (row, class) pairs with sigmoid(logit) > thresh, top_n best per (image, level);
+ * by_row_max = 1: candidates are rows, scored by their best class.  Outputs as sod_fcos_decode, with the selected row index inside
+ * its level instead of a decoded box. */
+extern "C" int sod_dense_topk_select(const float* logits, int ld, int N, int nlev, const int* rows, int num_classes, int by_row_max,
+                                     float score_thresh, int top_n, int* out_rows, float* out_scores, int* out_classes, int* out_counts,
+                                     void* stream) {
+  if (!logits || !rows || !out_rows || !out_scores || !out_classes || !out_counts) return SOD_EARG;
+  if (N <= 0 || nlev <= 0 || nlev > SOD_MAX_LEVELS || num_classes <= 0 || ld < num_classes || top_n <= 0 || top_n >= 65536) return SOD_EARG;
+  DecodeArgs a{};
+  a.cls = logits; a.N = N; a.nlev = nlev; a.K = num_classes; a.ld_cls = ld; a.ld_box = 0;
+  a.ctr_col_box = a.ctr_col_cls = -1; a.top_n = top_n; a.thresh = score_thresh; a.mode = by_row_max ? 2 : 1;
+  long long R = 0;
+  for (int l = 0; l < nlev; ++l) {
+    if (rows[l] <= 0 || (long long)rows[l] * num_classes >= (1ll << 31)) return SOD_EARG;
+    a.H[l] = rows[l]; a.W[l] = 1; a.stride[l] = 1; a.loc0[l] = (int)R;
+    R += rows[l];
+  }
+  if (R * N >= (1ll << 31)) return SOD_ESIZE;
+  a.L = (int)R;
+  a.out_rows = out_rows; a.out_scores = out_scores; a.out_classes = out_classes; a.out_counts = out_counts;
+  SOD_LAUNCH(fcos_decode_kernel, dim3(nlev, N), dim3(DEC_THREADS), 0, (hipStream_t)stream, a);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}

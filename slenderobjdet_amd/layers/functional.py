@@ -563,6 +563,26 @@ def fcos_decode(cls_buf, box_buf, scales, level_hw, strides, num_classes, center
     return boxes, scores, classes, counts
 
 
+def dense_topk_select(logits, rows_per_level, num_classes, score_thresh, top_n, by_row_max=False):
+    """Per-(image, level) threshold + top-k over rows of K class logits for the whole batch in one launch.  logits (N, R, ld) fp32;
+    returns rows (N, M) int32 (row index inside the level), scores (N, M) (-inf = empty slot), classes (N, M) int32, counts
+    (N, nlev) int32 with M = nlev * top_n."""
+    _chk(logits, torch.float32, "logits")
+    N, R, ld = logits.shape
+    nlev = len(rows_per_level)
+    if R != sum(rows_per_level):
+        raise _C.SlenderHipError("dense_topk_select: logits do not match the level geometry")
+    M = nlev * int(top_n)
+    dev = logits.device
+    rows = torch.empty((N, M), dtype=torch.int32, device=dev)
+    scores = torch.empty((N, M), dtype=torch.float32, device=dev)
+    classes = torch.empty((N, M), dtype=torch.int32, device=dev)
+    counts = torch.empty((N, nlev), dtype=torch.int32, device=dev)
+    call("sod_dense_topk_select", ptr(logits), ld, N, nlev, ctypes.cast(_int_arr(rows_per_level), ctypes.c_void_p), int(num_classes), 1 if by_row_max else 0,
+         float(score_thresh), int(top_n), ptr(rows), ptr(scores), ptr(classes), ptr(counts), stream_ptr())
+    return rows, scores, classes, counts
+
+
 def batched_nms_topk(boxes, scores, classes, iou_threshold, max_keep):
     """Class-aware NMS + top-``max_keep`` of B images at once on padded candidate lists (score -inf = empty slot); boxes (B, M, 4)
     XYXY or (B, M, 5) rotated.  Returns keep (B, max_keep) int64 local indices in score order (entries beyond num_keep are 0) and

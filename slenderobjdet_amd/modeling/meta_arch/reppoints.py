@@ -322,32 +322,31 @@ class RepPointsDetector(nn.Module):
 
     @torch.no_grad()
     def inference(self, logits, init_boxes, refine_boxes, geo, image_sizes):
-        """rpd.py:701-789: per level the best class of every point, top-k by score, threshold, then class-aware NMS."""
-        from ...layers.nms import batched_nms
-
+        """rpd.py:701-789 for the whole batch on the device: per level the best class of every point, top-k by score, threshold
+        (one selection launch), then class-aware NMS + top detections (batched NMS); one host read of the detection counts."""
         hw, offs, X = geo
-        bounds = list(offs) + [X]
+        N = logits.shape[0]
+        rows_per_level = [h * w for h, w in hw]
+        K = self.num_classes
+        rows, scores, classes, _counts = HF.dense_topk_select(logits.float().contiguous(), rows_per_level, K, self.score_threshold, self.topk_candidates,
+                                                              by_row_max=True)
+        top_n = self.topk_candidates
+        row0 = torch.tensor(list(offs), dtype=torch.int64, device=rows.device)
+        grow = rows.long() + row0.repeat_interleave(top_n)[None]
+        valid = torch.isfinite(scores)[:, :, None]
+        boxes = torch.where(valid, torch.gather(refine_boxes.float(), 1, grow[:, :, None].expand(-1, -1, 4)), torch.zeros((), device=rows.device)).contiguous()
+        init = torch.gather(init_boxes.float(), 1, grow[:, :, None].expand(-1, -1, 4))
+        keep, nkeep = HF.batched_nms_topk(boxes, scores, classes, self.nms_threshold, self.max_detections_per_image)
+        kb = torch.gather(boxes, 1, keep[:, :, None].expand(-1, -1, 4))
+        ki = torch.gather(init, 1, keep[:, :, None].expand(-1, -1, 4))
+        ks, kc = torch.gather(scores, 1, keep), torch.gather(classes, 1, keep)
+        nk = nkeep.cpu().tolist()
         results = []
         for i, image_size in enumerate(image_sizes):
-            boxes_all, init_all, cls_all, scores_all = [], [], [], []
-            for l in range(len(hw)):
-                sl = slice(bounds[l], bounds[l + 1])
-                scores, cls = logits[i, sl].sigmoid().max(1)
-                prob, idx = scores.sort(descending=True)
-                k = min(self.topk_candidates, cls.shape[0])
-                prob, idx = prob[:k], idx[:k]
-                keep = prob > self.score_threshold
-                idx = idx[keep]
-                boxes_all.append(refine_boxes[i, sl][idx])
-                init_all.append(init_boxes[i, sl][idx])
-                cls_all.append(cls[idx])
-                scores_all.append(scores[idx])
-            boxes_all, init_all, cls_all, scores_all = (torch.cat(t) for t in (boxes_all, init_all, cls_all, scores_all))
-            keep = batched_nms(boxes_all, scores_all, cls_all, self.nms_threshold)[: self.max_detections_per_image]
             r = Instances(tuple(image_size))
-            r.pred_boxes = Boxes(boxes_all[keep])
-            r.scores = scores_all[keep]
-            r.pred_classes = cls_all[keep]
-            r.init_boxes = init_all[keep]
+            r.pred_boxes = Boxes(kb[i, : nk[i]])
+            r.scores = ks[i, : nk[i]]
+            r.pred_classes = kc[i, : nk[i]].long()
+            r.init_boxes = ki[i, : nk[i]]
             results.append(r)
         return results

@@ -215,37 +215,35 @@ class RetinaNet(nn.Module):
 
     @torch.no_grad()
     def inference(self, level_hw, cls_buf, box_buf, offs, image_sizes):
-        """retina_rotated.py:296-377: per level sigmoid over (HWA x K), top-k, score threshold, decode the surviving anchors
-        (Box2BoxTransform.apply_deltas, one kernel), class-aware NMS, top detections."""
-        from ...layers.nms import batched_nms
+        """retina_rotated.py:296-377 for the whole batch on the device: per level sigmoid over (HWA x K), top-k, score threshold
+        (one selection launch), decode the surviving anchors (Box2BoxTransform.apply_deltas, one kernel), class-aware NMS and
+        the top detections (batched NMS); the only host read is the final per-image detection count."""
         from ...structures import Boxes, Instances
         from ..box_regression import Box2BoxTransform
 
         A, K = self.head.num_anchors, self.num_classes
+        N, P = cls_buf.shape[:2]
         transform = Box2BoxTransform(weights=self.bbox_reg_weights)
-        anchors_l = grid_anchors(level_hw, self.strides, self.anchor_sizes, self.anchor_ratios, self.anchor_offset, self.device)
-        P = cls_buf.shape[1]
-        bounds = list(offs) + [P]
+        anchors = torch.cat(grid_anchors(level_hw, self.strides, self.anchor_sizes, self.anchor_ratios, self.anchor_offset, self.device))   # (P*A, 4)
+        rows_per_level = [h * w * A for h, w in level_hw]
+        logits = cls_buf[..., : A * K].reshape(N, P * A, K) if cls_buf.shape[-1] != A * K else cls_buf.view(N, P * A, K)
+        rows, scores, classes, _counts = HF.dense_topk_select(logits.contiguous(), rows_per_level, K, self.score_threshold, self.topk_candidates)
+        top_n = self.topk_candidates
+        row0 = torch.tensor([sum(rows_per_level[:l]) for l in range(len(rows_per_level))], dtype=torch.int64, device=rows.device)
+        grow = rows.long() + row0.repeat_interleave(top_n)[None]                       # anchor index over all levels, (N, M)
+        deltas = box_buf[..., : A * 4].reshape(N, P * A, 4)
+        sel_d = torch.gather(deltas, 1, grow[:, :, None].expand(-1, -1, 4)).reshape(-1, 4).contiguous()
+        sel_a = anchors[grow.reshape(-1)].contiguous()
+        boxes = transform.apply_deltas(sel_d, sel_a).view(N, -1, 4)
+        boxes = torch.where(torch.isfinite(scores)[:, :, None], boxes, torch.zeros_like(boxes)).contiguous()       # empty slots
+        keep, nkeep = HF.batched_nms_topk(boxes, scores, classes, self.nms_threshold, self.max_detections_per_image)
+        kb = torch.gather(boxes, 1, keep[:, :, None].expand(-1, -1, 4))
+        ks, kc = torch.gather(scores, 1, keep), torch.gather(classes, 1, keep)
+        nk = nkeep.cpu().tolist()
         results = []
         for i, image_size in enumerate(image_sizes):
-            B, S, C = [], [], []
-            for l, anc in enumerate(anchors_l):
-                sl = slice(bounds[l], bounds[l + 1])
-                p = cls_buf[i, sl].reshape(-1).sigmoid()                       # (HW*A*K,), anchor-major then class
-                deltas = box_buf[i, sl, : A * 4].reshape(-1, 4)
-                k = min(self.topk_candidates, deltas.shape[0])
-                prob, idx = p.sort(descending=True)
-                prob, idx = prob[:k], idx[:k]
-                keep = prob > self.score_threshold
-                prob, idx = prob[keep], idx[keep]
-                a_idx, c_idx = idx // K, idx % K
-                B.append(transform.apply_deltas(deltas[a_idx].contiguous(), anc[a_idx].contiguous()))
-                S.append(prob)
-                C.append(c_idx)
-            B, S, C = torch.cat(B), torch.cat(S), torch.cat(C)
-            keep = batched_nms(B, S, C, self.nms_threshold)[: self.max_detections_per_image]
             r = Instances(tuple(image_size))
-            r.pred_boxes, r.scores, r.pred_classes = Boxes(B[keep]), S[keep], C[keep]
+            r.pred_boxes, r.scores, r.pred_classes = Boxes(kb[i, : nk[i]]), ks[i, : nk[i]], kc[i, : nk[i]].long()
             results.append(r)
         return results
 

@@ -183,3 +183,42 @@ def test_fcos_v1_and_v2_detect_the_same(cuda):
         assert len(ia) == len(ib) and len(ia) > 5 and len(r) > len(ia)
         assert torch.equal(ia.pred_classes, ib.pred_classes) and torch.equal(ia.scores, ib.scores) and torch.equal(ia.pred_boxes.tensor, ib.pred_boxes.tensor)
     assert len(lv[0]) == 5 and lv[0][0].shape == (2 * hw[0][0] * hw[0][1],) and lv[1][0].shape == (2 * hw[0][0] * hw[0][1], 4)
+
+
+@pytest.mark.parametrize("by_row_max", [False, True])
+def test_dense_topk_select_vs_torch(cuda, by_row_max):
+    """The head-agnostic selection (RetinaNet anchors x classes / RepPoints row maxima): same candidates, in index order, as
+    sort-descending -> take k = min(top_n, rows) -> threshold (retina_rotated.py:316-324, rpd.py:741-752) per image and level."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    g = torch.Generator().manual_seed(9)
+    N, K, top_n, thr = 2, 7, 20, 0.3
+    rows_per_level = [60, 24, 6]
+    R = sum(rows_per_level)
+    logits = _grid_logits((N, R, K), g, -4.0, 3.0)
+    logits[0, 3] = logits[0, 2]                      # exact ties
+    rows, scores, classes, counts = HF.dense_topk_select(logits.to(cuda), rows_per_level, K, thr, top_n, by_row_max=by_row_max)
+    rows, scores, classes, counts = rows.cpu(), scores.cpu(), classes.cpu(), counts.cpu()
+    off = 0
+    for l, nr in enumerate(rows_per_level):
+        for i in range(N):
+            p = logits[i, off:off + nr].sigmoid()
+            if by_row_max:
+                sc, cl = p.max(1)
+                flat_sc, flat_idx = sc, torch.arange(nr)
+            else:
+                flat_sc, flat_idx = p.reshape(-1), torch.arange(nr * K)
+            k = min(top_n, nr)
+            o = torch.sort(flat_sc, descending=True, stable=True).indices[:k]
+            o = o[flat_sc[o] > thr]
+            o = torch.sort(o).values                  # the kernel emits the selection in index order
+            n = int(counts[i, l])
+            assert n == len(o), (i, l, n, len(o))
+            sl = slice(l * top_n, l * top_n + n)
+            if by_row_max:
+                assert torch.equal(rows[i, sl].long(), o) and torch.equal(classes[i, sl].long(), cl[o])
+            else:
+                assert torch.equal(rows[i, sl].long(), o // K) and torch.equal(classes[i, sl].long(), o % K)
+            assert torch.allclose(scores[i, sl], flat_sc[o], rtol=2e-6, atol=1e-7)
+            assert (scores[i, l * top_n + n:(l + 1) * top_n] == float("-inf")).all()
+        off += nr
