@@ -75,3 +75,25 @@ def iou_loss(pred, target, weight=None, loss_type="iou"):
     if weight is None:
         assert pred.shape[0] != 0
     return _IouLossFn.apply(pred, target, weight, loss_type)
+
+
+class _BceSoftFn(torch.autograd.Function):
+    """F.binary_cross_entropy_with_logits(x[fg], t[fg], reduction="sum") with fg = rows whose label is a foreground class; the rows
+    are selected by the label inside the kernel (no boolean gather)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, labels, bg_label):
+        x, t, l = logits.contiguous().float(), targets.contiguous().float(), labels.contiguous().to(torch.int32)
+        ctx.save_for_backward(x, t, l)
+        ctx.bg = int(bg_label)
+        return HF.bce_logits_soft_fwd(x, t, l, ctx.bg)[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, t, l = ctx.saved_tensors
+        return HF.bce_logits_soft_bwd(x, t, l, ctx.bg, g.reshape(1).float().contiguous()), None, None, None
+
+
+def bce_with_logits_fg_sum(logits, targets, labels, bg_label):
+    return _BceSoftFn.apply(logits, targets, labels, bg_label)

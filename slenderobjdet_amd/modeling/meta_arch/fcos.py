@@ -288,8 +288,38 @@ class FCOSV2(nn.Module):
         results = self.inference(level_hw, cls_t, box_t, images.image_sizes)
         return self.postprocess(results, batched_inputs, images.image_sizes)
 
-    def losses_from_outputs(self, *a, **k):   # kept for symmetry with the reference's method name
-        raise NotImplementedError("losses are fused with the prediction convs in _FcosHeadLossFn")
+    def losses(self, gt_classes, reg_targets, pred_class_logits, pred_box_reg, pred_center_score):
+        """FCOSV2.losses with the reference's argument contract (fcosv2.py:104-148): per-level NCHW prediction lists, labels
+        (N, L) / (N*L,), regression targets (N, L, 4).  The training step does NOT come through here - forward() fuses the three
+        losses with the prediction convs (_FcosHeadLossFn) - but code written against the reference's method keeps working, on the
+        same HIP loss kernels and with the normalisers kept on the device (the reference reads them back with .item())."""
+        from ...layers.losses import bce_with_logits_fg_sum, iou_loss, sigmoid_focal_loss_jit
+        from ...utils import comm
+
+        K = self.num_classes
+
+        def cat(ts, c):       # permute_and_concat (fcos/utils.py:32-52): NCHW -> (N * sum(HW), c)
+            return torch.cat([t.permute(0, 2, 3, 1).reshape(t.shape[0], -1, c) for t in ts], 1).reshape(-1, c).float()
+
+        logits, reg, ctr = cat(pred_class_logits, K), cat(pred_box_reg, 4), cat(pred_center_score, 1).reshape(-1)
+        labels = gt_classes.flatten().to(torch.int32)
+        reg_t = reg_targets.reshape(-1, 4).float()
+        fg = (labels >= 0) & (labels != K)
+        world = float(comm.get_num_gpus())
+        num_pos_avg = (comm.reduce_sum(fg.sum().float().reshape(1)) / world).clamp(min=1.0)
+        cls_loss = sigmoid_focal_loss_jit(logits, labels, alpha=self.focal_loss_alpha, gamma=self.focal_loss_gamma, reduction="sum") / num_pos_avg[0]
+        lr, tb = reg_t[:, [0, 2]], reg_t[:, [1, 3]]           # compute_centerness_targets (fcos/utils.py:295-300) on every row
+        ctr_t = torch.sqrt((lr.min(-1)[0] / lr.max(-1)[0]).clamp(min=0) * (tb.min(-1)[0] / tb.max(-1)[0]).clamp(min=0))
+        ctr_t = torch.where(fg, ctr_t, torch.zeros_like(ctr_t))
+        if bool(fg.any()):
+            sum_ctr_avg = comm.reduce_sum(ctr_t.sum().reshape(1)) / world
+            reg_loss = iou_loss(reg[fg], reg_t[fg], ctr_t[fg], loss_type=self.iou_loss_type) / sum_ctr_avg[0]
+            centerness_loss = bce_with_logits_fg_sum(ctr, ctr_t, labels, K) / num_pos_avg[0]
+        else:                 # fcosv2.py:143-146: keep the graph and the collective alive
+            reg_loss = reg[fg].sum()
+            comm.reduce_sum(ctr.new_zeros(1))
+            centerness_loss = ctr[fg].sum()
+        return dict(cls_loss=cls_loss, reg_loss=reg_loss, centerness_loss=centerness_loss)
 
     @torch.no_grad()
     def get_ground_truth(self, level_hw, gt_instances):

@@ -370,3 +370,35 @@ def test_fused_sgd_state_dict_round_trip(cuda):
         assert not torch.equal(model3.arena.params, want)
     finally:
         HF.DETERMINISTIC = prev
+
+
+def test_losses_method_with_reference_contract(cuda):
+    """FCOSV2.losses(gt_classes, reg_targets, per-level NCHW predictions) - the reference's signature (fcosv2.py:104) - gives the
+    same three values as the fused training forward on the same predictions, and is differentiable."""
+    from slenderobjdet_amd.data import synthetic_batch
+
+    cfg, model, _ = _build(18, seed=5)
+    data = synthetic_batch(2, 256, 320, 13, device="cuda")
+    got = model(data)
+    with torch.no_grad():
+        imgs = model.preprocess_image(data)
+        feats = model.backbone(imgs.tensor)
+        ct, bt = model.head.run_towers([feats[f] for f in model.in_features])
+        cls_buf, box_buf, hw = model.head.predict(ct, bt)
+        labels, reg_t, _ctr_t, _stats = model.get_ground_truth(hw, [d["instances"].to("cuda") for d in data])
+    N, K = 2, model.num_classes
+    scales = model.head.scales.detach()
+    cls_l, reg_l, ctr_l, off = [], [], [], 0
+    for l, (h, w) in enumerate(hw):
+        sl = slice(off, off + h * w)
+        cls_l.append(cls_buf[:, sl, :K].reshape(N, h, w, K).permute(0, 3, 1, 2).contiguous().requires_grad_(True))
+        reg_l.append(torch.exp(box_buf[:, sl, :4] * scales[l]).reshape(N, h, w, 4).permute(0, 3, 1, 2).contiguous().requires_grad_(True))
+        ctr_l.append(box_buf[:, sl, 4:5].reshape(N, h, w, 1).permute(0, 3, 1, 2).contiguous().requires_grad_(True))
+        off += h * w
+    out = model.losses(labels.long(), reg_t, cls_l, reg_l, ctr_l)
+    for k in ("cls_loss", "reg_loss", "centerness_loss"):
+        a, b = float(out[k].detach()), float(got[k].detach())
+        assert abs(a - b) <= 1e-5 * max(abs(b), 1e-3), (k, a, b)
+    sum(out.values()).backward()
+    assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in cls_l + reg_l + ctr_l)
+    assert cls_l[0].grad.abs().sum() > 0 and reg_l[0].grad.abs().sum() > 0 and ctr_l[0].grad.abs().sum() > 0
