@@ -294,6 +294,21 @@ int sod_anchor_match(const float* gt_boxes, int G, const float* anchors, int A, 
                      int label_below, int label_between, int label_above, int allow_low_quality,
                      float* matched_vals, int* matches, signed char* labels, unsigned* gt_best_ws, void* stream);
 
+/* DeformConv / ModulatedDeformConv FORWARD as one implicit-GEMM kernel: the bilinear gather feeds the MFMA loop through LDS, no
+ * (N*Ho*Wo, KH*KW*C) column buffer in HBM (detectron2.layers.DeformConv.forward at df_conv.py:67-78, rpd.py:637-642).
+ * x (N,H,W,C) bf16, offset / mask fp32 rows as for sod_deform_im2col, w [K][KH*KW][C] bf16 (the GEMM view of the KRSC weights),
+ * bias [K] or NULL, y (N,Ho,Wo,K) bf16 = act(conv).  Needs C % 64 == 0, (C / deformable_groups) % 64 == 0, K % 8 == 0.
+ * The sampled values are computed exactly as sod_deform_im2col computes them (fp32, one rounding to bf16). */
+int sod_deform_conv_fwd_fused(const void* x, const float* offset, const float* mask, const void* w, const float* bias, void* y,
+                              int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
+                              int off_ld, int mask_ld, int mask_is_logit, int relu, void* stream);
+/* ... and its WEIGHT GRADIENT the same way: dw[k][tap][c] (fp32, [K][KH*KW][C], accumulated) += sum over pixels of dy * sample, the
+ * sampled rows gathered into LDS tiles inside the kernel (detectron2 deform_conv_backward_filter).  Pixel splits meet in fp32 slabs
+ * in ws (sod_conv2d_wgrad_workspace_bytes() suffices) summed in a fixed order: deterministic.  dy (N,Ho,Wo,K) bf16.  Needs
+ * C % 128 == 0 (or C == 64) and, with deformable_groups > 1, (C / deformable_groups) % 128 == 0. */
+int sod_deform_conv_wgrad_fused(const void* dy, const void* x, const float* offset, const float* mask, float* dw,
+                                int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
+                                int off_ld, int mask_ld, int mask_is_logit, void* ws, long long ws_bytes, void* stream);
 /* ---------------------------------------------------------------------------------------------------------
  * Deformable convolution v1/v2 — detectron2.layers.DeformConv / ModulatedDeformConv behind DFConv2d
  * (slender_det/layers/df_conv.py:6-78; rpd.py:147-154,637-642). NHWC; offset fp32 rows of pitch off_ld with channel

@@ -15,6 +15,11 @@ from .nn import HipConv2d, _arena_of
 import os
 
 SAVE_COLS = os.environ.get("SOD_DCN_SAVE_COLS", "1") != "0"
+# Fused kernels (csrc/dcn_fused.hip): forward and weight gradient gather the samples into LDS tiles inside the MFMA loop - no
+# (N*Ho*Wo, KH*KW*C) column buffer in HBM.  Measured per 256->256 DCN layer over the 5 RepPoints levels (batch 16): forward
+# 1.51 -> 0.95 ms, weight gradient 0.53 ms (on kept columns) -> 0.79 ms, i.e. 2.04 -> 1.74 ms and 1.65 GB less memory traffic and
+# footprint per layer.  SOD_DCN_FUSED=0 restores the column-buffer path (shapes the fused kernels do not take use it anyway).
+FUSED = os.environ.get("SOD_DCN_FUSED", "1") != "0"
 
 
 def _ceil8(v):
@@ -25,13 +30,19 @@ class _DeformConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, offset, mask, weight, mod, off_ld, mask_ld, mask_is_logit):
         k = mod.kernel_size
-        cols = HF.deform_im2col(x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, mod.deformable_groups, off_ld, mask_ld, mask_is_logit)
-        y = HF.conv2d_fwd(cols, mod.w_bf16, mod.bias_eff, None, 1, 0, 1, relu=mod.relu)
-        ctx.mod, ctx.cfg = mod, (off_ld, mask_ld, mask_is_logit)
-        # The sampled columns are needed again by the weight gradient.  They are KEPT across the step (2 DCN layers x 5 levels of
-        # RepPoints at batch 16: 3.3 GB of the 288 GB) instead of being re-gathered in backward (1.97 ms of a 44.7 ms step);
+        fused = FUSED and HF.deform_fused_supported(x.shape[3], mod.out_channels, mod.deformable_groups)
+        cols = None
+        if fused:
+            y = HF.deform_conv_fwd_fused(x, offset, mask, mod.w_bf16, mod.bias_eff, (k, k), mod.stride, mod.padding, mod.dilation,
+                                         mod.deformable_groups, off_ld, mask_ld, mask_is_logit, relu=mod.relu)
+        else:
+            cols = HF.deform_im2col(x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, mod.deformable_groups, off_ld, mask_ld, mask_is_logit)
+            y = HF.conv2d_fwd(cols, mod.w_bf16, mod.bias_eff, None, 1, 0, 1, relu=mod.relu)
+        ctx.mod, ctx.cfg, ctx.fused = mod, (off_ld, mask_ld, mask_is_logit), fused
+        # Column-buffer path only: the sampled columns are needed again by the weight gradient.  They are KEPT across the step
+        # (2 DCN layers x 5 levels of RepPoints at batch 16: 3.3 GB of the 288 GB) instead of being re-gathered in backward;
         # SOD_DCN_SAVE_COLS=0 restores the recomputation.
-        keep_cols = SAVE_COLS and mod.weight.requires_grad
+        keep_cols = SAVE_COLS and mod.weight.requires_grad and cols is not None
         ctx.save_for_backward(x, offset, mask, y if mod.relu else None, cols if keep_cols else None)
         arena = _arena_of(mod)
         if arena is not None and mod.weight.requires_grad:
@@ -54,10 +65,14 @@ class _DeformConvFn(torch.autograd.Function):
         N, Ho, Wo, K = dy.shape
         C = x.shape[3]
         if mod.weight.requires_grad:
-            if cols is None:
-                cols = HF.deform_im2col(x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, off_ld, mask_ld, mask_is_logit)
-            HF.conv2d_wgrad(dy, cols, arena.grad_view(mod.weight).view(K, 1, 1, k * k * C), 1, 1, 1, 0, 1)
-            del cols
+            if ctx.fused:
+                HF.deform_conv_wgrad_fused(dy, x, offset, mask, arena.grad_view(mod.weight).view(K, 1, 1, k * k * C), (k, k), mod.stride, mod.padding,
+                                           mod.dilation, dg, off_ld, mask_ld, mask_is_logit)
+            else:
+                if cols is None:
+                    cols = HF.deform_im2col(x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, off_ld, mask_ld, mask_is_logit)
+                HF.conv2d_wgrad(dy, cols, arena.grad_view(mod.weight).view(K, 1, 1, k * k * C), 1, 1, 1, 0, 1)
+                del cols
             arena.mark_ready(mod.weight)
             if mod.bias is not None:
                 HF.bias_grad(dy, arena.grad_view(mod.bias), N, Ho * Wo, K)

@@ -711,6 +711,41 @@ def deform_im2col(x, offset, mask, ksize, stride, pad, dil, dg=1, off_ld=0, mask
     return cols
 
 
+def deform_conv_fwd_fused(x, offset, mask, w_gemm, bias, ksize, stride, pad, dil, dg=1, off_ld=0, mask_ld=0, mask_is_logit=False, relu=False):
+    """DeformConv forward without the column buffer: x (N,H,W,C) bf16, w_gemm (K,1,1,KH*KW*C) bf16 -> y (N,Ho,Wo,K) bf16."""
+    _chk(x, torch.bfloat16, "x"); _chk(w_gemm, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias")
+    N, H, W, C = x.shape
+    KH, KW = ksize
+    K = w_gemm.shape[0]
+    if w_gemm.numel() != K * KH * KW * C:
+        raise _C.SlenderHipError("deform_conv_fwd_fused: weight shape does not match (K, KH*KW*C)")
+    Ho, Wo = conv_out_size(H, W, KH, KW, stride, pad, dil)
+    y = torch.empty((N, Ho, Wo, K), dtype=torch.bfloat16, device=x.device)
+    call("sod_deform_conv_fwd_fused", ptr(x), ptr(offset), ptr(mask), ptr(w_gemm), ptr(bias), ptr(y), N, H, W, C, K, KH, KW, stride, pad, dil, dg,
+         off_ld, mask_ld, 1 if mask_is_logit else 0, 1 if relu else 0, stream_ptr())
+    return y
+
+
+def deform_conv_wgrad_fused(dy, x, offset, mask, dw, ksize, stride, pad, dil, dg=1, off_ld=0, mask_ld=0, mask_is_logit=False):
+    """Accumulates the DeformConv weight gradient into dw (K, KH*KW*C elements, fp32) without a column buffer."""
+    _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(dw, torch.float32, "dw")
+    N, H, W, C = x.shape
+    KH, KW = ksize
+    K = dy.shape[-1]
+    if dw.numel() != K * KH * KW * C:
+        raise _C.SlenderHipError("deform_conv_wgrad_fused: dw does not hold K x KH*KW*C elements")
+    side = _wgrad_stream(dw.device, (dy, x, offset, mask))
+    ws = wgrad_workspace(dw.device, side)
+    call("sod_deform_conv_wgrad_fused", ptr(dy), ptr(x), ptr(offset), ptr(mask), ptr(dw), N, H, W, C, K, KH, KW, stride, pad, dil, dg, off_ld, mask_ld,
+         1 if mask_is_logit else 0, ptr(ws), ws.numel(), stream_ptr(side))
+    return dw
+
+
+def deform_fused_supported(C, K, dg):
+    """Shapes both fused DeformConv kernels (forward and weight gradient) accept."""
+    return C % 128 == 0 and K % 8 == 0 and C % dg == 0 and (dg == 1 or (C // dg) % 128 == 0)
+
+
 def deform_col2im(dcols, x, offset, mask, ksize, stride, pad, dil, dg, doffset, dmask, off_ld=0, mask_ld=0, mask_is_logit=False):
     """Returns dx fp32 (N,H,W,C); fills the (zero-initialised, pitched) doffset / dmask."""
     N, H, W, C = x.shape

@@ -98,3 +98,76 @@ def test_dfconv2d_module_trains(cuda, v2):
     for p in (m.conv.weight, m.offset.weight, m.offset.bias):
         assert torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
     assert (m.offset.weight.grad[m.n_off:] == 0).all()     # padding rows stay inert
+
+
+@pytest.mark.parametrize("modulated,dg,stride,C,K,relu", [(False, 1, 1, 64, 32, False), (True, 1, 1, 128, 256, True), (True, 2, 2, 128, 72, False),
+                                                        (False, 1, 1, 256, 256, False)])
+def test_deform_conv_fused_forward(cuda, modulated, dg, stride, C, K, relu):
+    """The fused gather -> LDS -> MFMA forward (no column buffer): equal to the column-buffer path up to the fp32 accumulation order
+    (both feed identical bf16 samples to the matrix cores), and within bf16 output tolerance of the fp32 oracle."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W = 2, 13, 19
+    x = onn.rb(torch.randn(N, C, H, W, generator=_g(0)))
+    w = onn.rb(torch.randn(K, C, 3, 3, generator=_g(1)) * 0.05)
+    bias = torch.randn(K, generator=_g(5)) if modulated else None
+    Ho, Wo = HF.conv_out_size(H, W, 3, 3, stride, 1, 1)
+    off = (torch.rand(N, 18 * dg, Ho, Wo, generator=_g(2)) - 0.5) * 4.3 + 0.017
+    off[0, :, 0, 0] = 9.0                            # far outside: zero contribution
+    off[1, :, 1, 2] = 0.0                            # integer positions
+    mask = torch.rand(N, 9 * dg, Ho, Wo, generator=_g(3)) if modulated else None
+    ref = odc.deform_conv2d(x, off, w, bias, stride, 1, 1, mask, dg)
+    if relu:
+        ref = torch.relu(ref)
+    xd, offd = _nhwc(x).to(cuda).bfloat16(), _nhwc(off).to(cuda)
+    maskd = _nhwc(mask).to(cuda) if modulated else None
+    wk, _ = HF.weight_prep(w.permute(0, 2, 3, 1).contiguous().reshape(K, 1, 1, 9 * C).to(cuda))
+    bd = bias.to(cuda) if bias is not None else None
+    y = HF.deform_conv_fwd_fused(xd, offd, maskd, wk, bd, (3, 3), stride, 1, 1, dg, relu=relu)
+    cols = HF.deform_im2col(xd, offd, maskd, (3, 3), stride, 1, 1, dg)
+    y_cols = HF.conv2d_fwd(cols, wk, bd, stride=1, pad=0, relu=relu)
+    assert tuple(y.shape) == (N, Ho, Wo, K)
+    scale = ref.abs().max().item()
+    assert (y.float() - y_cols.float()).abs().max().item() <= 2 ** -7 * scale                    # two bf16 roundings of nearly equal sums
+    assert (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 2 ** -6 * scale
+    # with fp32 accumulation exposed (bf16 samples, but no output rounding) the two device paths agree to accumulation-order noise
+    y32 = HF.conv2d_fwd(cols, wk, bd, stride=1, pad=0, relu=relu, out_f32=True)
+    assert (y.float() - y32).abs().max().item() <= 2 ** -8 * scale
+
+
+@pytest.mark.parametrize("modulated,dg,stride,C,K,hw", [(False, 1, 1, 128, 32, (13, 19)), (True, 1, 1, 128, 256, (13, 19)), (True, 2, 2, 256, 72, (21, 17)),
+                                                      (False, 1, 1, 256, 256, (40, 36))])
+def test_deform_conv_fused_wgrad(cuda, modulated, dg, stride, C, K, hw):
+    """The fused gather -> LDS -> MFMA weight gradient: equal to the 1x1 wgrad on the column buffer up to summation order, within
+    2e-4 of the fp32 oracle on bf16-rounded operands... the samples themselves are rounded to bf16 (as the column buffer is), so the
+    bar against the oracle is the bf16 one; accumulation semantics and run-to-run bit-identity are checked as well."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, (H, W) = 2, hw
+    x = onn.rb(torch.randn(N, C, H, W, generator=_g(0)))
+    w = torch.zeros(K, C, 3, 3)
+    Ho, Wo = HF.conv_out_size(H, W, 3, 3, stride, 1, 1)
+    off = (torch.rand(N, 18 * dg, Ho, Wo, generator=_g(2)) - 0.5) * 4.3 + 0.017
+    mask = torch.rand(N, 9 * dg, Ho, Wo, generator=_g(3)) if modulated else None
+    dy = onn.rb(torch.randn(N, K, Ho, Wo, generator=_g(4)))
+    ws_ = w.clone().requires_grad_(True)
+    ref = odc.deform_conv2d(x, off, ws_, None, stride, 1, 1, mask, dg)
+    (gw,) = torch.autograd.grad(ref, [ws_], dy)
+    dw_ref = gw.permute(0, 2, 3, 1).reshape(K, 1, 1, 9 * C)
+    xd, offd = _nhwc(x).to(cuda).bfloat16(), _nhwc(off).to(cuda)
+    maskd = _nhwc(mask).to(cuda) if modulated else None
+    dyd = _nhwc(dy).to(cuda).bfloat16()
+    dw = torch.zeros(K, 1, 1, 9 * C, device=cuda)
+    HF.deform_conv_wgrad_fused(dyd, xd, offd, maskd, dw, (3, 3), stride, 1, 1, dg)
+    cols = HF.deform_im2col(xd, offd, maskd, (3, 3), stride, 1, 1, dg)
+    dw_cols = torch.zeros_like(dw)
+    HF.conv2d_wgrad(dyd, cols, dw_cols, 1, 1, 1, 0, 1)
+    scale = dw_ref.abs().max().item()
+    assert (dw - dw_cols).abs().max().item() <= 2e-4 * scale                   # identical bf16 operands, different summation order
+    assert (dw.cpu() - dw_ref).abs().max().item() <= 2 ** -7 * scale
+    first = dw.clone()
+    HF.deform_conv_wgrad_fused(dyd, xd, offd, maskd, dw, (3, 3), stride, 1, 1, dg)
+    assert (dw - 2 * first).abs().max().item() <= 1e-5 * scale                 # accumulates
+    dw2 = torch.zeros_like(dw)
+    HF.deform_conv_wgrad_fused(dyd, xd, offd, maskd, dw2, (3, 3), stride, 1, 1, dg)
+    assert torch.equal(dw2, first)                                             # fixed summation order
