@@ -164,6 +164,13 @@ int sod_preprocess_image(const void* img, int is_uint8, int C, int H, int W, voi
  * one dtype); out is the (n, Hp, Wp, 8) batch buffer. */
 int sod_preprocess_batch(int n, const void* const* imgs, int is_uint8, int C, const int* H, const int* W, void* out, int Hp, int Wp,
                          int Cpad, const float* mean3, const float* std3, void* stream);
+/* preprocess_image + the frozen ResNet stem in ONE kernel: uint8 image -> (v - mean) / std -> conv 7x7 stride 2 pad 3 with the
+ * folded FrozenBatchNorm2d -> ReLU -> max-pool 3x3 stride 2 pad 1 (fcosv2.py:268-275 + detectron2 BasicStem).
+ * imgs / H / W: HOST arrays of n (<= 64) device pointers to (3, H, W) uint8 planes and their sizes; w_packed: [64][24][8] bf16 =
+ * w_eff[k][c*7 + r][s] (zero for s = 7 and chunks 21..23); bias: [64] folded BN shift; out: (n, Hp/4, Wp/4, 64) bf16 for the
+ * batch padded to (Hp, Wp) (multiples of 4; images are zero-padded bottom / right as ImageList.from_tensors does). */
+int sod_stem_fused(int n, const void* const* imgs, const int* H, const int* W, const void* w_packed, const float* bias,
+                   void* out, int Hp, int Wp, const float* mean3, const float* std3, void* stream);
 /* The augmentation + batching stage in front of the model on the device: ResizeShortestEdge / ResizeLongestEdge and
  * RandomFlip of build_augmentation (slender_det/data/utils.py:29-50; detectron2 ResizeTransform = PIL BILINEAR resize of the uint8
  * image, HFlipTransform) fused with sod_preprocess_batch's normalise + zero-pad + NHWC(8) bf16, ONE launch for n (<= 64) images.

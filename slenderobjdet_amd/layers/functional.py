@@ -413,6 +413,59 @@ def preprocess_batch(imgs, out, mean, std):
     return out
 
 
+class RawImageBatch:
+    """A batch of decoded uint8 (3, H, W) images that has NOT been normalised / padded yet.  ``preprocess_image`` hands this to the
+    backbone instead of the NHWC(8) tensor when the stem can consume the raw pixels (``stem_fused``); anything else calls
+    ``materialize()`` and gets exactly the tensor ``preprocess_batch`` builds."""
+
+    def __init__(self, imgs, sizes, padded_hw, mean, std):
+        self.imgs, self.sizes, self.padded_hw, self.mean, self.std = imgs, sizes, padded_hw, mean, std
+        self._tensor = None
+
+    @property
+    def shape(self):
+        return (len(self.imgs), self.padded_hw[0], self.padded_hw[1], 8)
+
+    @property
+    def device(self):
+        return self.imgs[0].device
+
+    def materialize(self):
+        if self._tensor is None:
+            Hp, Wp = self.padded_hw
+            batch = torch.empty((len(self.imgs), Hp, Wp, 8), dtype=torch.bfloat16, device=self.device)
+            self._tensor = preprocess_batch(self.imgs, batch, self.mean, self.std)
+        return self._tensor
+
+
+def stem_pack_weights(w_bf16):
+    """(64, 7, 7, Cpad) bf16 KRSC compute copy (FrozenBN scale folded) -> the [64][24][8] layout of sod_stem_fused."""
+    K = w_bf16.shape[0]
+    w = w_bf16[..., :3].permute(0, 3, 1, 2).contiguous()                     # (K, 3, 7, 7) = [k][c][r][s]
+    out = torch.zeros((K, 24, 8), dtype=torch.bfloat16, device=w_bf16.device)
+    out[:, :21, :7] = w.reshape(K, 21, 7)
+    return out.contiguous()
+
+
+def stem_fused(raw, w_packed, bias):
+    """raw: RawImageBatch of uint8 images -> (N, Hp/4, Wp/4, 64) bf16 = maxpool(relu(frozen_bn(conv7x7s2(normalise(images)))))."""
+    _chk(w_packed, torch.bfloat16, "w_packed"); _chk(bias, torch.float32, "bias")
+    n = len(raw.imgs)
+    Hp, Wp = raw.padded_hw
+    if n > 64 or Hp % 4 or Wp % 4 or tuple(w_packed.shape) != (64, 24, 8):
+        raise _C.SlenderHipError("stem_fused: unsupported batch / weight shape")
+    for im in raw.imgs:
+        _chk(im, torch.uint8, "image")
+        if im.dim() != 3 or im.shape[0] != 3:
+            raise _C.SlenderHipError("stem_fused: images must be (3, H, W) uint8")
+    out = torch.empty((n, Hp // 4, Wp // 4, 64), dtype=torch.bfloat16, device=raw.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in raw.mean])
+    s_ = (ctypes.c_float * 3)(*[float(v) for v in raw.std])
+    call("sod_stem_fused", n, _ptr_arr(raw.imgs), _int_arr([i.shape[1] for i in raw.imgs]), _int_arr([i.shape[2] for i in raw.imgs]), ptr(w_packed), ptr(bias),
+         ptr(out), Hp, Wp, ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s_, ctypes.c_void_p), stream_ptr())
+    return out
+
+
 def nchw_f32_to_nhwc_bf16(x):
     _chk(x, torch.float32, "x")
     N, C, H, W = x.shape

@@ -12,7 +12,11 @@ from torch.autograd.function import once_differentiable
 
 from ...layers import functional as HF
 from ...layers.nn import HipConv2d, _arena_of, max_pool_3x3_s2
+import os
+
 from ..shape_spec import ShapeSpec
+
+STEM_FUSED = os.environ.get("SOD_STEM_FUSED", "1") != "0"
 from .build import BACKBONE_REGISTRY, Backbone
 
 
@@ -24,6 +28,16 @@ class BasicStem(nn.Module):
         self.out_channels, self.stride = out_channels, 4
 
     def forward(self, x):
+        if isinstance(x, HF.RawImageBatch):
+            # frozen stem on raw uint8 pixels: normalise + conv + FrozenBN + ReLU + max-pool in one kernel (csrc/stem_fused.hip)
+            c = self.conv1
+            if STEM_FUSED and not c.weight.requires_grad and c.in_channels == 3 and c.out_channels == 64:
+                c.prepare()
+                key = (c._prep_key, c.w_bf16.data_ptr())
+                if getattr(self, "_packed_key", None) != key:
+                    self._packed, self._packed_key = HF.stem_pack_weights(c.w_bf16), key
+                return HF.stem_fused(x, self._packed, c.bias_eff)
+            x = x.materialize()
         return max_pool_3x3_s2(self.conv1(x))
 
 

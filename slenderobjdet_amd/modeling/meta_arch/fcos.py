@@ -384,6 +384,10 @@ class FCOSV2(nn.Module):
         imgs = [x["image"].to(self.device, non_blocking=True) for x in batched_inputs]
         sizes = [(int(i.shape[-2]), int(i.shape[-1])) for i in imgs]
         Hp, Wp = ImageList.padded_size(sizes, self.backbone.size_divisibility)
+        if all(im.dtype == torch.uint8 and im.dim() == 3 and im.shape[0] == 3 for im in imgs) and len(imgs) <= 64 and Hp % 4 == 0 and Wp % 4 == 0:
+            # decoded uint8 images: hand the raw pixels to the backbone - a frozen stem normalises, convolves and pools them in one
+            # kernel (csrc/stem_fused.hip); any other consumer materialises the NHWC(8) tensor below on demand
+            return ImageList(HF.RawImageBatch([im.contiguous() for im in imgs], sizes, (Hp, Wp), self._mean, self._std), sizes)
         batch = torch.empty((len(imgs), Hp, Wp, 8), dtype=torch.bfloat16, device=self.device)
         imgs = [im if im.dtype == torch.uint8 else im.float() for im in imgs]
         HF.preprocess_batch(imgs, batch, self._mean, self._std)       # one launch for the batch

@@ -56,3 +56,46 @@ def test_resize_full_size_and_model_consumes_it(cuda):
     with torch.no_grad():
         feats = model.backbone(out)
     assert tuple(feats["p3"].shape) == (2, 100, 152, 256) and torch.isfinite(feats["p3"].float()).all()
+
+
+def test_fused_stem_matches_unfused(cuda):
+    """normalise + conv7x7s2 + FrozenBN + ReLU + max-pool in one kernel on raw uint8 images (csrc/stem_fused.hip) vs the three
+    separate launches (preprocess_batch -> conv kernel -> maxpool): same values up to the fp32 summation order of the 147-term dot
+    products (one bf16 ulp where a sum sits on a rounding boundary), on images of different sizes incl. the zero padding."""
+    from bench import make_cfg
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.modeling import build_model
+
+    cfg = make_cfg(18)
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    stem = model.backbone.bottom_up.stem
+    with torch.no_grad():                  # non-trivial FrozenBN statistics
+        stem.conv1.bn_weight.copy_(torch.rand(64, device=cuda) + 0.5)
+        stem.conv1.bn_bias.copy_(torch.randn(64, device=cuda) * 50)
+        stem.conv1.bn_running_mean.copy_(torch.randn(64, device=cuda) * 10)
+    g = torch.Generator().manual_seed(1)
+    imgs = [torch.randint(0, 256, (3, h, w), dtype=torch.uint8, generator=g).to(cuda) for h, w in ((97, 130), (128, 61), (64, 64))]
+    Hp, Wp = 128, 160
+    raw = HF.RawImageBatch(imgs, [(i.shape[1], i.shape[2]) for i in imgs], (Hp, Wp), cfg.MODEL.PIXEL_MEAN, cfg.MODEL.PIXEL_STD)
+    with torch.no_grad():
+        fused = stem(raw)
+        assert tuple(fused.shape) == (3, Hp // 4, Wp // 4, 64)
+        ref = stem(raw.materialize())
+    d = (fused.float() - ref.float()).abs()
+    scale = ref.float().abs().max().item()
+    assert d.max().item() <= 2 ** -7 * scale, (d.max().item(), scale)
+    assert (d > 0).float().mean().item() < 0.02                       # almost every element is bit-identical
+    # and against the fp32 oracle of the same stem
+    from oracle import nn as onn
+
+    x = torch.zeros(3, 3, Hp, Wp)
+    for i, im in enumerate(imgs):
+        x[i, :, : im.shape[1], : im.shape[2]] = onn.rb((im.cpu().float() - torch.tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1)) / torch.tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1))
+    c = stem.conv1
+    scale_bn = (c.bn_weight * torch.rsqrt(c.bn_running_var + 1e-5)).cpu()
+    shift = (c.bn_bias - c.bn_running_mean * c.bn_weight * torch.rsqrt(c.bn_running_var + 1e-5)).cpu()
+    w = onn.rb(c.weight.detach().cpu() * scale_bn.view(-1, 1, 1, 1))
+    y = torch.relu(torch.nn.functional.conv2d(x, w.permute(0, 3, 1, 2), shift, stride=2, padding=3))
+    y = torch.nn.functional.max_pool2d(onn.rb(y), 3, 2, 1).permute(0, 2, 3, 1)
+    assert (fused.float().cpu() - y).abs().max().item() <= 2 ** -7 * y.abs().max().item()
