@@ -136,6 +136,8 @@ KIND_MODE = {"conv_fwd": 0, "conv_dgrad": 1, "conv_wgrad": 2}
 
 def kernel_name(kind, code):
     """(kind, sod_conv_prof_collect variant code) -> the kernel name rocprofv3 prints."""
+    if code == -7:
+        return "stem_fused_kernel"
     if kind == "conv_wgrad":
         if code == 256:
             return "sodconv::conv_wgrad256_kernel"
@@ -361,16 +363,24 @@ def main():
     if HF.PROFILE_LIB:
         import ctypes
         _C.call("sod_conv_prof_enable", 0)
-        n = len(prof)
+        lib_entries = [p_ for p_ in prof if p_[2] is None]      # entries timed by the library; the rest carry their own torch events
+        n = len(lib_entries)
         ms, var, frac, mode = (ctypes.c_float * max(n, 1))(), (ctypes.c_int * max(n, 1))(), (ctypes.c_float * max(n, 1))(), (ctypes.c_int * max(n, 1))()
         got = _C.load().sod_conv_prof_collect(ms, var, frac, mode, n)
         kinds = {"conv_fwd": 0, "conv_dgrad": 1, "conv_wgrad": 2}
-        if got != n or any(kinds[p_[0]] != mode[j] for j, p_ in enumerate(prof)):
+        if got != n or any(kinds[p_[0]] != mode[j] for j, p_ in enumerate(lib_entries)):
             # never fail the measurement over the instrumentation: drop the roofline instead
             print(f"# roofline skipped: library recorded {got} conv dispatches, host {n} (or their order differs)", file=sys.stderr)
             prof = []
         else:
-            prof = [(kind, flops * frac[j], ms[j] * 1e-3, desc, var[j]) for j, (kind, flops, _e0, _e1, desc, _v) in enumerate(prof)]
+            filled, j = [], 0
+            for kind, flops, e0, e1, desc, variant in prof:
+                if e0 is None:
+                    filled.append((kind, flops * frac[j], ms[j] * 1e-3, desc, var[j]))
+                    j += 1
+                else:
+                    filled.append((kind, flops, e0.elapsed_time(e1) * 1e-3, desc, variant))
+            prof = filled
         HF.PROFILE_LIB = False
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

@@ -459,10 +459,19 @@ def stem_fused(raw, w_packed, bias):
         if im.dim() != 3 or im.shape[0] != 3:
             raise _C.SlenderHipError("stem_fused: images must be (3, H, W) uint8")
     out = torch.empty((n, Hp // 4, Wp // 4, 64), dtype=torch.bfloat16, device=raw.device)
+    prof = PROFILE is not None and (PROFILE_KINDS is None or "conv_fwd" in PROFILE_KINDS)
+    if prof:        # not a library conv dispatch: timed with a torch event pair on the launch stream (bench.py roofline)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     m = (ctypes.c_float * 3)(*[float(v) for v in raw.mean])
     s_ = (ctypes.c_float * 3)(*[float(v) for v in raw.std])
     call("sod_stem_fused", n, _ptr_arr(raw.imgs), _int_arr([i.shape[1] for i in raw.imgs]), _int_arr([i.shape[2] for i in raw.imgs]), ptr(w_packed), ptr(bias),
          ptr(out), Hp, Wp, ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s_, ctypes.c_void_p), stream_ptr())
+    if prof:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        # algorithmic work of the stem conv: 2 * N * (Hp/2) * (Wp/2) * 64 * 7 * 7 * 3 (the pool halo recomputation is not counted)
+        PROFILE.append(("conv_fwd", 2.0 * n * (Hp // 2) * (Wp // 2) * 64 * 49 * 3, e0, e1, (n, Hp, Wp, 3, 64, 7, 2), -7))
     return out
 
 
