@@ -309,6 +309,12 @@ int sod_anchor_match(const float* gt_boxes, int G, const float* anchors, int A, 
 int sod_deform_conv_fwd_fused(const void* x, const float* offset, const float* mask, const void* w, const float* bias, void* y,
                               int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
                               int off_ld, int mask_ld, int mask_is_logit, int relu, void* stream);
+/* fp32 reference-precision forward of the same op (TEST MODE: one thread per output, no matrix cores): x (N,H,W,C), w [K][KH*KW][C],
+ * y (N,Ho,Wo,K) all fp32.  Lets the sampling / contraction semantics be checked on the device at fp32 tolerance (the reference's
+ * known-answer vectors, tests/test_deformable_conv.py:67-87) independently of the bf16 operand rounding of the fast paths. */
+int sod_deform_conv_fwd_f32(const float* x, const float* offset, const float* mask, const float* w, const float* bias, float* y,
+                            int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
+                            int off_ld, int mask_ld, int mask_is_logit, void* stream);
 /* ... and its WEIGHT GRADIENT the same way: dw[k][tap][c] (fp32, [K][KH*KW][C], accumulated) += sum over pixels of dy * sample, the
  * sampled rows gathered into LDS tiles inside the kernel (detectron2 deform_conv_backward_filter).  Pixel splits meet in fp32 slabs
  * in ws (sod_conv2d_wgrad_workspace_bytes() suffices) summed in a fixed order: deterministic.  dy (N,Ho,Wo,K) bf16.  Needs

@@ -82,6 +82,7 @@ _SIGS = {
     "sod_retina_giou_loss_bwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P],
     "sod_retina_box_loss_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "sod_deform_conv_fwd_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "sod_deform_conv_fwd_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sod_deform_conv_wgrad_fused": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "sod_deform_im2col": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sod_deform_col2im": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

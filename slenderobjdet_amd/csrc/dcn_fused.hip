@@ -501,6 +501,45 @@ __global__ __launch_bounds__(256) void dcn_wgrad_reduce_kernel(const DcnFArgs a)
   }
 }
 
+// fp32 reference-precision forward (test mode): one thread per output element, fp32 input / weights / accumulation, the sampling
+// rule of make_tap.  It exists so that the op's SEMANTICS can be checked on the device at fp32 tolerance (the reference's known-answer
+// vectors, tests/test_deformable_conv.py:67-87) independently of bf16 operand rounding; it is not a fast path.
+__global__ __launch_bounds__(256) void dcn_fwd_f32_kernel(const float* __restrict__ x, const float* __restrict__ off, const float* __restrict__ mask,
+                                                          const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+                                                          int N, int H, int W, int C, int Ho, int Wo, int K, int KH, int KW, int stride, int pad, int dil,
+                                                          int DG, int off_ld, int mask_ld, int mask_logit) {
+  const long long total = (long long)N * Ho * Wo * K;
+  const int taps = KH * KW, cpg = C / DG;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int k = (int)(i % K);
+    const long long pix = i / K;
+    const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), n = (int)(pix / ((long long)Wo * Ho));
+    float acc = bias ? bias[k] : 0.f;
+    for (int g = 0; g < DG; ++g)
+      for (int tap = 0; tap < taps; ++tap) {
+        const int kk = g * taps + tap, ki = tap / KW, kj = tap - ki * KW;
+        const float py = (float)(ho * stride - pad + ki * dil) + off[pix * off_ld + 2 * kk];
+        const float px = (float)(wo * stride - pad + kj * dil) + off[pix * off_ld + 2 * kk + 1];
+        if (!(py > -1.f && px > -1.f && py < (float)H && px < (float)W)) continue;
+        float m = mask ? mask[pix * mask_ld + kk] : 1.f;
+        if (mask && mask_logit) m = 1.f / (1.f + expf(-m));
+        const float fy = floorf(py), fx = floorf(px);
+        const int yl = (int)fy, xl = (int)fx, yh = yl + 1, xh = xl + 1;
+        const float ly = py - fy, lx = px - fx, hy = 1.f - ly, hx = 1.f - lx;
+        const float* xb = x + (long long)n * H * W * C;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+          float v = 0.f;
+          if (yl >= 0 && xl >= 0) v += hy * hx * xb[((long long)yl * W + xl) * C + c];
+          if (yl >= 0 && xh <= W - 1) v += hy * lx * xb[((long long)yl * W + xh) * C + c];
+          if (yh <= H - 1 && xl >= 0) v += ly * hx * xb[((long long)yh * W + xl) * C + c];
+          if (yh <= H - 1 && xh <= W - 1) v += ly * lx * xb[((long long)yh * W + xh) * C + c];
+          acc += w[((long long)k * taps + tap) * C + c] * (v * m);
+        }
+      }
+    y[i] = acc;
+  }
+}
+
 int dcn_fill(DcnFArgs& a, const void* x, const float* offset, const float* mask, int N, int H, int W, int C, int K, int KH, int KW,
              int stride, int pad, int dil, int DG, int off_ld, int mask_ld, int mask_is_logit) {
   if (!x || !offset || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || dil <= 0 || pad < 0 || DG <= 0) return SOD_EARG;
@@ -578,6 +617,24 @@ extern "C" int sod_deform_conv_wgrad_fused(const void* dy, const void* x, const 
   hipStream_t st = (hipStream_t)stream;
   SOD_LAUNCH(dcn_wgrad_fused_kernel, dim3(nz * tiles), dim3(512), G_LDS, st, a);
   SOD_LAUNCH(dcn_wgrad_reduce_kernel, dim3(tiles * 32), dim3(256), 0, st, a);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_deform_conv_fwd_f32(const float* x, const float* offset, const float* mask, const float* w, const float* bias, float* y,
+                                       int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
+                                       int off_ld, int mask_ld, int mask_is_logit, void* stream) {
+  if (!x || !offset || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || dil <= 0 || pad < 0) return SOD_EARG;
+  if (deformable_groups <= 0 || C % deformable_groups) return SOD_EARG;
+  const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return SOD_EARG;
+  if (off_ld <= 0) off_ld = 2 * KH * KW * deformable_groups;
+  if (mask_ld <= 0) mask_ld = KH * KW * deformable_groups;
+  const long long total = (long long)N * Ho * Wo * K;
+  long long g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  SOD_LAUNCH(dcn_fwd_f32_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, offset, mask, w, bias, y, N, H, W, C, Ho, Wo, K, KH, KW, stride, pad,
+             dil, deformable_groups, off_ld, mask_ld, mask_is_logit);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

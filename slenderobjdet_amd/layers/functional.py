@@ -788,6 +788,19 @@ def deform_conv_fwd_fused(x, offset, mask, w_gemm, bias, ksize, stride, pad, dil
     return y
 
 
+def deform_conv_fwd_f32(x, offset, mask, w, bias, ksize, stride, pad, dil, dg=1, mask_is_logit=False):
+    """fp32 test-mode forward: x (N,H,W,C) fp32, w (K, KH*KW*C) fp32 in (tap, channel) order -> y (N,Ho,Wo,K) fp32."""
+    _chk(x, torch.float32, "x"); _chk(w, torch.float32, "w"); _chk(offset, torch.float32, "offset"); _chk(mask, torch.float32, "mask"); _chk(bias, torch.float32, "bias")
+    N, H, W, C = x.shape
+    KH, KW = ksize
+    K = w.shape[0]
+    Ho, Wo = conv_out_size(H, W, KH, KW, stride, pad, dil)
+    y = torch.empty((N, Ho, Wo, K), dtype=torch.float32, device=x.device)
+    call("sod_deform_conv_fwd_f32", ptr(x), ptr(offset), ptr(mask), ptr(w), ptr(bias), ptr(y), N, H, W, C, K, KH, KW, stride, pad, dil, dg, 0, 0,
+         1 if mask_is_logit else 0, stream_ptr())
+    return y
+
+
 def deform_conv_wgrad_fused(dy, x, offset, mask, dw, ksize, stride, pad, dil, dg=1, off_ld=0, mask_ld=0, mask_is_logit=False):
     """Accumulates the DeformConv weight gradient into dw (K, KH*KW*C elements, fp32) without a column buffer."""
     _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(dw, torch.float32, "dw")

@@ -36,6 +36,11 @@ def test_reference_kat(cuda):
         cols = HF.deform_im2col(_nhwc(x).to(cuda).bfloat16(), offset, None, (3, 3), 1, 1, 1)
         y = HF.conv2d_fwd(cols, wk, None, stride=1, pad=0, out_f32=True)
         np.testing.assert_allclose(y[0, :, :, 0].cpu().numpy(), d[key][0, 0], atol=0.2, rtol=4e-3)   # bf16 inputs (0.1 is not exact)
+        # the same vectors through the fp32 test-mode kernel: the op's semantics at fp32 tolerance (1e-5 relative)
+        w32 = torch.tensor(d["weight"]).permute(0, 2, 3, 1).contiguous().reshape(1, 18).to(cuda)
+        x32 = _nhwc(torch.tensor(d["input"])).contiguous().to(cuda)
+        y32 = HF.deform_conv_fwd_f32(x32, offset, None, w32, None, (3, 3), 1, 1, 1)
+        np.testing.assert_allclose(y32[0, :, :, 0].cpu().numpy(), d[key][0, 0], rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("modulated,dg,stride", [(False, 1, 1), (True, 1, 1), (True, 2, 2), (False, 4, 1)])
@@ -171,3 +176,21 @@ def test_deform_conv_fused_wgrad(cuda, modulated, dg, stride, C, K, hw):
     dw2 = torch.zeros_like(dw)
     HF.deform_conv_wgrad_fused(dyd, xd, offd, maskd, dw2, (3, 3), stride, 1, 1, dg)
     assert torch.equal(dw2, first)                                             # fixed summation order
+
+
+@pytest.mark.parametrize("modulated,dg,stride", [(False, 1, 1), (True, 2, 2)])
+def test_deform_conv_f32_mode_vs_oracle(cuda, modulated, dg, stride):
+    """fp32 test-mode forward vs the fp32 oracle on fractional offsets: 1e-5 relative (north_star: 1e-3 rel fp32)."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, C, K, H, W = 2, 16, 12, 9, 11
+    x = torch.randn(N, C, H, W, generator=_g(0))
+    w = torch.randn(K, C, 3, 3, generator=_g(1)) * 0.1
+    bias = torch.randn(K, generator=_g(6))
+    Ho, Wo = HF.conv_out_size(H, W, 3, 3, stride, 1, 1)
+    off = (torch.rand(N, 18 * dg, Ho, Wo, generator=_g(2)) - 0.5) * 4.3 + 0.017
+    mask = torch.rand(N, 9 * dg, Ho, Wo, generator=_g(3)) if modulated else None
+    ref = odc.deform_conv2d(x, off, w, bias, stride, 1, 1, mask, dg)
+    y = HF.deform_conv_fwd_f32(_nhwc(x).to(cuda), _nhwc(off).to(cuda), _nhwc(mask).to(cuda) if modulated else None,
+                               w.permute(0, 2, 3, 1).contiguous().reshape(K, 9 * C).to(cuda), bias.to(cuda), (3, 3), stride, 1, 1, dg)
+    assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
