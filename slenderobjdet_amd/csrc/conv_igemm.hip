@@ -955,10 +955,13 @@ int device_cus() {
 }
 
 // Which kernel a weight gradient goes to.  SOD_WGRAD256: 0 = never, 1 (default) = shapes with K, C multiples of 256 whose blocks get
-// at least SOD_WGRAD256_MIN_KT K-tiles of work each, 2 = every supported shape (parity tests).
+// at least SOD_WGRAD256_MIN_KT (64) K-tiles of work each, 2 = every supported shape (parity tests).
 bool use_wgrad256(const WgradArgs& a, float* ws, long long ws_bytes) {
   static const int mode = getenv("SOD_WGRAD256") ? atoi(getenv("SOD_WGRAD256")) : 1;
-  static const int min_kt = getenv("SOD_WGRAD256_MIN_KT") ? atoi(getenv("SOD_WGRAD256_MIN_KT")) : 6;
+  // Blocks with few K-tiles are dominated by their 256-KB slab write, and the 48-KB workgroups of the 128x128 kernel share CUs with the
+  // data-gradient kernels on the other stream.  Swept on the FCOS R50 step (one box, two rounds): >= 6 K-tiles per block 572.1 / 573.5
+  // img/s, >= 40: 575.5 / 576.5, >= 70: 576.7 / 577.4, >= 120: 576.6 / 577.2, >= 250 (head towers off the 256 kernel): 565.6 / 566.1.
+  static const int min_kt = getenv("SOD_WGRAD256_MIN_KT") ? atoi(getenv("SOD_WGRAD256_MIN_KT")) : 64;
   if (!mode || !ws || !wgrad256_supported(a)) return false;
   const int cus = device_cus();
   if (wgrad256_workspace_bytes(a, cus) > ws_bytes) return false;
