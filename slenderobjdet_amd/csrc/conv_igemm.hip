@@ -1006,7 +1006,8 @@ int launch_wgrad(WgradArgs& a, int splits, int flags, hipStream_t st, float* ws 
     // (3.02 waves -> a nearly empty 4th round, 3x the atomic traffic) run at 585.  At least 256 pixels per block.
     const int cus = device_cus();
     static const int per_cu_env = getenv("SOD_WGRAD_PER_CU") ? atoi(getenv("SOD_WGRAD_PER_CU")) : 0;
-    static const int pc_big = getenv("SOD_WGRAD_PC_BIG") ? atoi(getenv("SOD_WGRAD_PC_BIG")) : 3;
+    // re-swept with the 256x256 kernel taking the large shapes (round 2, one box): 3 per CU 576.1 / 575.2, 2 per CU 581.2 / 581.0, 1: 564
+    static const int pc_big = getenv("SOD_WGRAD_PC_BIG") ? atoi(getenv("SOD_WGRAD_PC_BIG")) : 2;
     const int slots = (per_cu_env > 0 ? per_cu_env : (tiles >= 36 ? (kp == 32 ? pc_big : 2) : pc_small)) * cus;
     splits = slots / tiles;
     const int maxs = (int)((Ptot + 255) / 256);
