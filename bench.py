@@ -110,8 +110,18 @@ def damp_residual_branches(model, gamma=0.25):
     return n
 
 
-def train_step(model, optimizer, data):
+# SOD_PREFETCH=0: no software pipelining of the frozen backbone prefix (see train_step)
+PREFETCH = os.environ.get("SOD_PREFETCH", "1") != "0"
+
+
+def train_step(model, optimizer, data, next_data=None):
+    """One training step.  ``next_data`` (optional) is the batch of the FOLLOWING step: between this step's forward and backward the
+    model runs that batch's preprocess + frozen stem/res2 on a side stream (meta-arch ``prefetch``), where the HBM-bound frozen convs
+    share the GPU with the MFMA-bound head backward; the next step's forward picks the result up.  Every step still carries exactly one
+    frozen prefix (the next batch's instead of its own)."""
     losses = model(data)
+    if next_data is not None and PREFETCH and hasattr(model, "prefetch"):
+        model.prefetch(next_data)
     total = sum(losses.values())
     optimizer.zero_grad()
     model.arena.begin_backward()
@@ -173,7 +183,7 @@ def roofline_report(prof, prof_steps, args):
            "selection": "kernel with the largest share of conv GPU time in the sampled steps", "launches": cnt, "sampled_steps": prof_steps,
            "avg_launch_us": round(sec / cnt * 1e6, 2), "ms_per_step": round(sec / prof_steps * 1e3, 3),
            "flops": "algorithmic, un-padded channels",
-           "sampling": "every 8th timed step; sampled steps run the weight gradients on the main stream so that every interval is one kernel's duration",
+           "sampling": "one timed step in 32 (the first at K/2); sampled steps run the weight gradients and the box tower on the main stream so that every interval is one kernel's duration",
            "kernels": [row(v, kernel_name(*k)) for k, v in sorted(by_k.items(), key=lambda kv: -kv[1][1])],
            "by_pass": {k: row(v) for k, v in kinds.items()}}
     if args.arch == "fcos":
@@ -328,8 +338,13 @@ def main():
     optimizer.grad_scale = 1.0 / world
     loader = SyntheticCocoBatches(args.batch_per_gpu, args.height, args.width, rank=rank, device=dev, pool=2, rotated=args.arch == "rrcnn")
 
-    for _ in range(args.warmup):
-        train_step(model, optimizer, next(loader))
+    sample_at = set() if args.no_roofline else (set(range(args.steps)) if args.dump_prof else set(range(args.steps // 2, args.steps, 32)))
+    sample_at = set(sorted(sample_at)[:12])      # the library keeps 8192 event pairs
+    cur = next(loader)
+    for w in range(args.warmup):
+        nxt = next(loader)
+        train_step(model, optimizer, cur, None if (w == args.warmup - 1 and 0 in sample_at) else nxt)
+        cur = nxt
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -340,21 +355,29 @@ def main():
         # would then include the time it shares the chip with another kernel.  The SAMPLED steps therefore launch the weight
         # gradients on the main stream (what SOD_WGRAD_STREAM=0 does for a whole run; profiles/*_serial_kernel_stats.csv is the
         # rocprofv3 summary of such a run): intervals are per-kernel durations.  A sampled step is ~5 % slower and carries a few us
-        # of queue bubbles per event pair, so only every 8th timed step is sampled (all steps with --dump-prof); `value` includes them.
+        # of queue bubbles per event pair, so only one timed step in 32 is sampled, starting in the middle of the run (all steps with --dump-prof); `value` includes them.
         HF.PROFILE_KINDS = None
         HF.PROFILE_LIB = True
     prof_all, prof_steps = [], 0
     side_default = HF.WGRAD_SIDE_STREAM
+    from slenderobjdet_amd.modeling.meta_arch import fcos as fcos_mod
+    tower_default = fcos_mod.TOWER_STREAMS
     t0 = time.perf_counter()
     for i in range(args.steps):
-        sample = (not args.no_roofline) and bool(args.dump_prof or i % 8 == 0) and prof_steps < 12     # the library keeps 8192 event pairs
+        sample = i in sample_at       # one timed step in 32, the first in the middle of the run (all of them with --dump-prof)
         HF.PROFILE = prof_all if sample else None
         if HF.PROFILE_LIB:
             _C.call("sod_conv_prof_enable", 1 if sample else 0)
         prof_steps += int(sample)
         HF.WGRAD_SIDE_STREAM = side_default and not sample
-        last = train_step(model, optimizer, next(loader))
+        fcos_mod.TOWER_STREAMS = tower_default and not sample
+        # a sampled step computes its own frozen prefix on the main stream (so that its profile holds every conv of a step) and hands
+        # none to its successor
+        nxt = next(loader)
+        last = train_step(model, optimizer, cur, None if (sample or (i + 1) in sample_at) else nxt)
+        cur = nxt
     HF.WGRAD_SIDE_STREAM = side_default
+    fcos_mod.TOWER_STREAMS = tower_default
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

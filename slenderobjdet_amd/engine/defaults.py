@@ -151,8 +151,18 @@ class DefaultTrainer:
         self.iter = self.start_iter
 
     def run_step(self):
-        data = next(self._data_loader_iter)
+        # one batch of look-ahead: between this step's forward and backward the model runs the NEXT batch's preprocess + frozen
+        # backbone prefix on a side stream (meta-arch ``prefetch``; bench.py's train_step does the same)
+        data = self._next_data if getattr(self, "_next_data", None) is not None else next(self._data_loader_iter)
+        self._next_data = None
         loss_dict = self.model(data)
+        if hasattr(self.model, "prefetch") and self.iter + 1 < self.max_iter:
+            try:
+                self._next_data = next(self._data_loader_iter)
+            except StopIteration:
+                self._next_data = None
+            if self._next_data is not None:
+                self.model.prefetch(self._next_data)
         losses = sum(loss_dict.values())
         self.optimizer.zero_grad()
         arena = getattr(self.model, "arena", None)

@@ -191,6 +191,8 @@ class ParamArena:
                 self._comm_stream.wait_event(ev)
                 if side is not None:        # weight gradients of this bucket were enqueued on the wgrad side stream
                     self._comm_stream.wait_stream(side)
+                for aux in HF.aux_compute_streams(self.device):   # a bucket may mix parameters whose backward nodes ran on different
+                    self._comm_stream.wait_stream(aux)            # streams (the FCOS box tower has its own)
                 wire = view if self.bucket_dtype == torch.float32 else view.to(self.bucket_dtype)
                 h = dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True)
         else:

@@ -55,6 +55,21 @@ _side_keep = []
 _side_join_queued = False
 
 
+_aux_streams = {}
+
+
+def register_compute_stream(device, stream):
+    """Announce an extra stream that runs backward nodes (e.g. the FCOS box tower's).  Parameter gradients may be produced on it, so
+    the bucket reducer (arena._launch_bucket) waits for it in addition to the launching node's stream and the wgrad side stream."""
+    lst = _aux_streams.setdefault(device.index, [])
+    if all(s.cuda_stream != stream.cuda_stream for s in lst):
+        lst.append(stream)
+
+
+def aux_compute_streams(device):
+    return list(_aux_streams.get(device.index, ()))
+
+
 def wgrad_side_stream(device):
     """The side stream of ``device`` if wgrad work may be pending on it in this backward pass, else None."""
     return _side_streams.get(device.index) if _side_join_queued else None

@@ -183,6 +183,15 @@ class BasicBlock(nn.Module):
         return self.conv2(self.conv1(x), res=sc)
 
 
+class FrozenPrefix:
+    """What ``ResNet.forward_frozen_prefix`` hands to ``ResNet.forward``: the activation behind the last frozen stage, the number of
+    stages it covers and the named outputs produced on the way.  ``shape`` is the input batch's (N, Hp, Wp, C) so that callers that
+    only look at ``images.tensor.shape`` keep working."""
+
+    def __init__(self, tensor, n_stages, outputs, input_shape):
+        self.tensor, self.n_stages, self.outputs, self.shape = tensor, n_stages, outputs, tuple(input_shape)
+
+
 class ResNet(Backbone):
     def __init__(self, stem, stages, out_features):
         super().__init__()
@@ -202,15 +211,48 @@ class ResNet(Backbone):
         self._out_features = out_features
 
     def forward(self, x):
-        outputs = {}
-        x = self.stem(x)
-        if "stem" in self._out_features:
-            outputs["stem"] = x
-        for stage, name in self.stages_and_names:
+        outputs, start = {}, 0
+        if isinstance(x, FrozenPrefix):
+            outputs.update(x.outputs)
+            start, x = x.n_stages, x.tensor
+        else:
+            x = self.stem(x)
+            if "stem" in self._out_features:
+                outputs["stem"] = x
+        for stage, name in self.stages_and_names[start:]:
             x = stage(x)
             if name in self._out_features:
                 outputs[name] = x
         return outputs
+
+    def frozen_prefix_len(self):
+        """Number of leading stages (behind a frozen stem) without a trainable parameter; -1 if the stem itself trains."""
+        if any(p.requires_grad for p in self.stem.parameters()):
+            return -1
+        n = 0
+        for stage, _ in self.stages_and_names:
+            if any(p.requires_grad for p in stage.parameters()):
+                break
+            n += 1
+        return n
+
+    @torch.no_grad()
+    def forward_frozen_prefix(self, x):
+        """Stem + the frozen leading stages (FREEZE_AT) of ``x``.  They have no gradient and their weights never change, so a training
+        loop may run them for the NEXT batch while the current one is in backward (meta-arch ``prefetch``).  None if nothing is frozen."""
+        n = self.frozen_prefix_len()
+        if n < 0:
+            return None
+        shape = x.shape
+        outputs = {}
+        x = self.stem(x)
+        if "stem" in self._out_features:
+            outputs["stem"] = x
+        for stage, name in self.stages_and_names[:n]:
+            x = stage(x)
+            if name in self._out_features:
+                outputs[name] = x
+        return FrozenPrefix(x, n, outputs, shape)
 
     def freeze(self, freeze_at=0):
         """FREEZE_AT: 1 = stem, 2 = stem + res2, ..."""

@@ -39,9 +39,13 @@ def _ceil8(v):
     return (v + 7) // 8 * 8
 
 
-# SOD_TOWER_STREAMS=1: box tower on a second stream (experiment; measured neutral on the FCOS R50 step, 463.1 vs 463.5 img/s, so off)
-TOWER_STREAMS = os.environ.get("SOD_TOWER_STREAMS", "0") == "1"
+# The box tower runs on a second stream beside the classification tower (FCOSHead.run_towers).  Round 1 measured this neutral (463.1
+# vs 463.5 img/s); with the round-2 kernels the convs are short enough that the GroupNorm passes of one tower hide behind the other's
+# convs: 573.3-574.6 -> 583.1-584.1 img/s in a 4-round A/B, allocator pool 11.1 -> 14.9 GB and flat over 160 steps.
+# SOD_TOWER_STREAMS=0 keeps both towers on one stream.
+TOWER_STREAMS = os.environ.get("SOD_TOWER_STREAMS", "1") != "0"
 _tower_streams = {}
+_prefetch_streams = {}
 
 
 class DcnGnRelu(nn.Module):
@@ -119,6 +123,7 @@ class FCOSHead(nn.Module):
         s2 = _tower_streams.get(dev.index)
         if s2 is None:
             s2 = _tower_streams[dev.index] = torch.cuda.Stream(device=dev)
+            HF.register_compute_stream(dev, s2)
         s2.wait_stream(main)
         for f in feats:
             f.record_stream(s2)
@@ -256,8 +261,43 @@ class FCOSV2(nn.Module):
         return self.pixel_mean.device
 
     # ------------------------------------------------------------------ forward
+    def prefetch(self, batched_inputs):
+        """Software pipelining for training loops: run ``preprocess_image`` and the FROZEN bottom of the backbone (stem + the
+        FREEZE_AT stages: no gradient, weights that never change) for the NEXT batch on a side stream.  Called between forward and
+        backward of the current batch, the side stream starts when that forward has finished on the GPU, so the HBM-bound frozen
+        convolutions run beside the MFMA-bound head backward.  ``forward`` picks the result up when it is handed the same list
+        object; a batch that was not prefetched (or another list) takes the normal path.  Results are identical either way."""
+        bottom = getattr(self.backbone, "bottom_up", self.backbone)
+        if not (self.device.type == "cuda" and hasattr(bottom, "forward_frozen_prefix")) or bottom.frozen_prefix_len() < 0:
+            return False
+        dev = self.device
+        main = torch.cuda.current_stream(dev)
+        side = _prefetch_streams.get(dev.index)
+        if side is None:
+            side = _prefetch_streams[dev.index] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            images = self.preprocess_image(batched_inputs)
+            prefix = bottom.forward_frozen_prefix(images.tensor)
+        self._prefetched = (batched_inputs, images, prefix, side)
+        return True
+
+    def _take_prefetched(self, batched_inputs):
+        pre, self._prefetched = getattr(self, "_prefetched", None), None
+        if pre is None or pre[0] is not batched_inputs:
+            return None
+        _, images, prefix, side = pre
+        self.prefetch_hits = getattr(self, "prefetch_hits", 0) + 1
+        main = torch.cuda.current_stream(self.device)
+        main.wait_stream(side)
+        for t in [prefix.tensor] + list(prefix.outputs.values()):
+            t.record_stream(main)           # allocated on the side stream's pool, consumed (and kept for backward) on this one
+        return ImageList(prefix, images.image_sizes)
+
     def forward(self, batched_inputs):
-        images = self.preprocess_image(batched_inputs)
+        images = self._take_prefetched(batched_inputs) if self.training else None
+        if images is None:
+            images = self.preprocess_image(batched_inputs)
         if "instances" in batched_inputs[0]:
             gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         elif "targets" in batched_inputs[0]:

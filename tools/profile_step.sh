@@ -8,7 +8,7 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $B > gpurun_out/${tag}_stats.log 2>&1
-SOD_WGRAD_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_serial -- $B > gpurun_out/${tag}_serial.log 2>&1
+SOD_WGRAD_STREAM=0 SOD_TOWER_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_serial -- $B > gpurun_out/${tag}_serial.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- $B > gpurun_out/${tag}_fetch.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- $B > gpurun_out/${tag}_write.log 2>&1
 python3 tools/summarize_profile.py ${tag} gpurun_out/${tag}_stats gpurun_out/${tag}_fetch gpurun_out/${tag}_write 7
