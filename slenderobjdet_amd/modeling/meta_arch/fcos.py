@@ -276,6 +276,7 @@ class FCOSV2(nn.Module):
         if side is None:
             side = _prefetch_streams[dev.index] = torch.cuda.Stream(device=dev)
         side.wait_stream(main)
+        self._prefetched = None
         with torch.cuda.stream(side):
             images = self.preprocess_image(batched_inputs)
             prefix = bottom.forward_frozen_prefix(images.tensor)
@@ -295,9 +296,7 @@ class FCOSV2(nn.Module):
         return ImageList(prefix, images.image_sizes)
 
     def forward(self, batched_inputs):
-        images = self._take_prefetched(batched_inputs) if self.training else None
-        if images is None:
-            images = self.preprocess_image(batched_inputs)
+        images = self.preprocess_image(batched_inputs)
         if "instances" in batched_inputs[0]:
             gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         elif "targets" in batched_inputs[0]:
@@ -420,7 +419,12 @@ class FCOSV2(nn.Module):
 
     def preprocess_image(self, batched_inputs):
         """fcosv2.py:268-275: normalise, pad to size_divisibility, batch — one kernel per image straight into the
-        NHWC(8) bf16 batch buffer (the H2D copy of the uint8 image is the only other traffic)."""
+        NHWC(8) bf16 batch buffer (the H2D copy of the uint8 image is the only other traffic).  In training mode a batch that
+        ``prefetch`` has already been given comes back as an ImageList around its FrozenPrefix (which ``backbone`` resumes from)."""
+        if self.training and getattr(self, "_prefetched", None) is not None:
+            images = self._take_prefetched(batched_inputs)
+            if images is not None:
+                return images
         imgs = [x["image"].to(self.device, non_blocking=True) for x in batched_inputs]
         sizes = [(int(i.shape[-2]), int(i.shape[-1])) for i in imgs]
         Hp, Wp = ImageList.padded_size(sizes, self.backbone.size_divisibility)

@@ -222,6 +222,7 @@ class AblationMetaArch(nn.Module):
         return self.pixel_mean.device
 
     preprocess_image = FCOSV2.preprocess_image
+    prefetch, _take_prefetched = FCOSV2.prefetch, FCOSV2._take_prefetched
     postprocess = FCOSV2.postprocess
 
     def forward(self, batched_inputs):

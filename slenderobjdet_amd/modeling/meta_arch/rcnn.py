@@ -30,6 +30,7 @@ class GeneralizedRCNN(nn.Module):
         return self.pixel_mean.device
 
     preprocess_image = FCOSV2.preprocess_image
+    prefetch, _take_prefetched = FCOSV2.prefetch, FCOSV2._take_prefetched
     postprocess = FCOSV2.postprocess
 
     def forward(self, batched_inputs):
@@ -95,6 +96,7 @@ class ProposalNetwork(nn.Module):
         return self.pixel_mean.device
 
     preprocess_image = FCOSV2.preprocess_image
+    prefetch, _take_prefetched = FCOSV2.prefetch, FCOSV2._take_prefetched
 
     def forward(self, batched_inputs):
         images = self.preprocess_image(batched_inputs)

@@ -203,6 +203,7 @@ class RepPointsDetector(nn.Module):
         return self.pixel_mean.device
 
     preprocess_image = FCOSV2.preprocess_image
+    prefetch, _take_prefetched = FCOSV2.prefetch, FCOSV2._take_prefetched
     postprocess = FCOSV2.postprocess
     res_refine = True                       # offsets_refine(...) + offsets_init.detach()  (rpd.py:639-642)
 

@@ -173,6 +173,7 @@ class RetinaNet(nn.Module):
         return self.pixel_mean.device
 
     preprocess_image = FCOSV2.preprocess_image
+    prefetch, _take_prefetched = FCOSV2.prefetch, FCOSV2._take_prefetched
 
     def anchors_for(self, level_hw):
         key = tuple(level_hw)
