@@ -148,6 +148,8 @@ def kernel_name(kind, code):
     """(kind, sod_conv_prof_collect variant code) -> the kernel name rocprofv3 prints."""
     if code == -7:
         return "stem_fused_kernel"
+    if code == -8:
+        return "bottleneck_frozen_kernel"
     if kind == "conv_wgrad":
         if code == 256:
             return "sodconv::conv_wgrad256_kernel"

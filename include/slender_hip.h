@@ -171,6 +171,15 @@ int sod_preprocess_batch(int n, const void* const* imgs, int is_uint8, int C, co
  * batch padded to (Hp, Wp) (multiples of 4; images are zero-padded bottom / right as ImageList.from_tensors does). */
 int sod_stem_fused(int n, const void* const* imgs, const int* H, const int* W, const void* w_packed, const float* bias,
                    void* out, int Hp, int Wp, const float* mean3, const float* std3, void* stream);
+/* A FROZEN bottleneck block of the ResNet body in ONE kernel (detectron2 BottleneckBlock with FrozenBatchNorm2d folded, as
+ * build_resnet_backbone builds res2 under MODEL.BACKBONE.FREEZE_AT >= 2; reached from slender_det/modeling/backbone/fpn.py:103):
+ *   out = relu(conv3(relu(conv2_3x3(relu(conv1(x))))) + shortcut(x)),  64 bottleneck channels, 256 output channels, stride 1.
+ * x: (N, H, W, Cin) bf16 NHWC, Cin a multiple of 64 (<= 1024); w1: [64][Cin], w2: [64][3][3][64], w3: [256][64] bf16 with the BN scale
+ * folded; b1 / b2: [64], b3: [256] fp32 folded BN shifts (b3 INCLUDES the projection shortcut's shift when wsc is given);
+ * wsc: [256][Cin] bf16 projection-shortcut weights, or NULL for the identity shortcut (then Cin must be 256); out: (N, H, W, 256)
+ * bf16.  The two 64-channel intermediates stay in LDS (a frozen block has no backward pass). */
+int sod_bottleneck_frozen_fwd(const void* x, int N, int H, int W, int Cin, const void* w1, const float* b1, const void* w2,
+                              const float* b2, const void* w3, const float* b3, const void* wsc, void* out, void* stream);
 /* The augmentation + batching stage in front of the model on the device: ResizeShortestEdge / ResizeLongestEdge and
  * RandomFlip of build_augmentation (slender_det/data/utils.py:29-50; detectron2 ResizeTransform = PIL BILINEAR resize of the uint8
  * image, HFlipTransform) fused with sod_preprocess_batch's normalise + zero-pad + NHWC(8) bf16, ONE launch for n (<= 64) images.

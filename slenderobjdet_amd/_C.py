@@ -51,6 +51,7 @@ _SIGS = {
     "sod_preprocess_batch": [_I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "sod_nchw_f32_to_nhwc_bf16": [_P, _P, _I, _I, _I, _P],
     "sod_stem_fused": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "sod_bottleneck_frozen_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "sod_resize_flip_preprocess_batch": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "sod_sigmoid_focal_loss_fwd": [_P, _P, _P, _L, _I, _I, _F, _F, _P, _P, _P, _P],
     "sod_sigmoid_focal_loss_bwd": [_P, _P, _P, _L, _I, _I, _F, _F, _P, _P, _F, _F, _P, _I, _I, _P],

@@ -490,6 +490,32 @@ def stem_fused(raw, w_packed, bias):
     return out
 
 
+def bottleneck_frozen_fwd(x, w1, b1, w2, b2, w3, b3, wsc=None):
+    """One frozen ResNet bottleneck block (64 bottleneck / 256 output channels, stride 1) in one kernel (csrc/bottleneck_fused.hip):
+    x (N,H,W,Cin) bf16; w1 (64,1,1,Cin), w2 (64,3,3,64), w3 (256,1,1,64), wsc (256,1,1,Cin) | None bf16 KRSC with the FrozenBN scale
+    folded; b1 / b2 / b3 fp32 folded shifts (b3 includes the projection shortcut's).  Returns (N,H,W,256) bf16."""
+    for t, nm in ((x, "x"), (w1, "w1"), (w2, "w2"), (w3, "w3"), (wsc, "wsc")):
+        _chk(t, torch.bfloat16, nm)
+    for t, nm in ((b1, "b1"), (b2, "b2"), (b3, "b3")):
+        _chk(t, torch.float32, nm)
+    N, H, W, Cin = x.shape
+    if (tuple(w1.shape) != (64, 1, 1, Cin) or tuple(w2.shape) != (64, 3, 3, 64) or tuple(w3.shape) != (256, 1, 1, 64)
+            or (wsc is not None and tuple(wsc.shape) != (256, 1, 1, Cin)) or b1.numel() != 64 or b2.numel() != 64 or b3.numel() != 256):
+        raise _C.SlenderHipError("bottleneck_frozen_fwd: unsupported block shape")
+    out = torch.empty((N, H, W, 256), dtype=torch.bfloat16, device=x.device)
+    prof = PROFILE is not None and (PROFILE_KINDS is None or "conv_fwd" in PROFILE_KINDS)
+    if prof:        # not a library conv dispatch: timed with a torch event pair on the launch stream (bench.py roofline)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("sod_bottleneck_frozen_fwd", ptr(x), N, H, W, Cin, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(wsc), ptr(out), stream_ptr())
+    if prof:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        macs = Cin * 64 + 9 * 64 * 64 + 64 * 256 + (Cin * 256 if wsc is not None else 0)     # algorithmic: no halo recomputation
+        PROFILE.append(("conv_fwd", 2.0 * N * H * W * macs, e0, e1, (N, H, W, Cin, 256, "bneck", 1), -8))
+    return out
+
+
 def nchw_f32_to_nhwc_bf16(x):
     _chk(x, torch.float32, "x")
     N, C, H, W = x.shape

@@ -17,6 +17,8 @@ import os
 from ..shape_spec import ShapeSpec
 
 STEM_FUSED = os.environ.get("SOD_STEM_FUSED", "1") != "0"
+# frozen 64 -> 256 bottleneck blocks (res2 under FREEZE_AT >= 2) as one kernel each (csrc/bottleneck_fused.hip)
+BNECK_FUSED = os.environ.get("SOD_BNECK_FUSED", "1") != "0"
 from .build import BACKBONE_REGISTRY, Backbone
 
 
@@ -158,10 +160,55 @@ def _dgrad_pair_into_input(blk, g, da, xin):
     return _dgrad(sc, g, xin, accum=_dgrad(c1, da, xin))
 
 
+def _block_fusable(blk):
+    c1, c2, c3, sc = blk.conv1, blk.conv2, blk.conv3, blk.shortcut
+    if not (c1.kernel_size == 1 and c1.stride == 1 and c1.padding == 0 and c1.out_channels == 64 and c1.relu
+            and c2.kernel_size == 3 and c2.stride == 1 and c2.padding == 1 and c2.dilation == 1 and c2.out_channels == 64 and c2.relu
+            and c3.kernel_size == 1 and c3.stride == 1 and c3.padding == 0 and c3.out_channels == 256 and c3.relu):
+        return False
+    if c1.in_channels % 64 or c1.in_channels > 1024 or any(m.cin_pad for m in (c1, c2, c3)):
+        return False
+    if sc is None:
+        return c1.in_channels == 256
+    return sc.kernel_size == 1 and sc.stride == 1 and sc.padding == 0 and sc.out_channels == 256 and not sc.relu and not sc.cin_pad
+
+
+def _fused_frozen_block(blk, x):
+    """relu(conv3(conv2(conv1(x))) + shortcut(x)) of a block without a backward pass in one launch; None if an operand is unsuitable."""
+    convs = [m for m in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut) if m is not None]
+    for m in convs:
+        m.prepare()
+    if any(m.w_bf16.data_ptr() % 16 or not m.w_bf16.is_contiguous() for m in convs):
+        return None
+    key = tuple((m._prep_key, id(m.bias_eff)) for m in convs)
+    if getattr(blk, "_fused_key", None) != key:
+        def shift(m):
+            return m.bias_eff if m.bias_eff is not None else torch.zeros(m.out_channels, dtype=torch.float32, device=x.device)
+        b3 = shift(blk.conv3) + (shift(blk.shortcut) if blk.shortcut is not None else 0)
+        blk._fused_bias = (shift(blk.conv1).contiguous(), shift(blk.conv2).contiguous(), b3.contiguous())
+        blk._fused_key = key
+    b1, b2, b3 = blk._fused_bias
+    return HF.bottleneck_frozen_fwd(x, blk.conv1.w_bf16, b1, blk.conv2.w_bf16, b2, blk.conv3.w_bf16, b3,
+                                    blk.shortcut.w_bf16 if blk.shortcut is not None else None)
+
+
 class BottleneckStage(nn.Sequential):
-    """nn.Sequential of BottleneckBlocks (same parameter names as a plain Sequential) executed as one fused autograd node."""
+    """nn.Sequential of BottleneckBlocks (same parameter names as a plain Sequential) executed as one fused autograd node; a stage
+    that needs no backward pass (frozen under FREEZE_AT, or any stage under no_grad) whose blocks have the res2 shape runs one
+    kernel per block instead."""
 
     def forward(self, x):
+        no_bwd = not torch.is_grad_enabled() or not (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if (BNECK_FUSED and no_bwd and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()
+                and all(_block_fusable(b) for b in self) and self[0].conv1.in_channels == x.shape[-1]):
+            y = x
+            for blk in self:
+                nxt = _fused_frozen_block(blk, y)
+                if nxt is None:
+                    break
+                y = nxt
+            else:
+                return y
         return _BottleneckStageFn.apply(x, self[0].conv1.weight, self)
 
 
