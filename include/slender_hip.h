@@ -174,10 +174,10 @@ int sod_stem_fused(int n, const void* const* imgs, const int* H, const int* W, c
 /* A FROZEN bottleneck block of the ResNet body in ONE kernel (detectron2 BottleneckBlock with FrozenBatchNorm2d folded, as
  * build_resnet_backbone builds res2 under MODEL.BACKBONE.FREEZE_AT >= 2; reached from slender_det/modeling/backbone/fpn.py:103):
  *   out = relu(conv3(relu(conv2_3x3(relu(conv1(x))))) + shortcut(x)),  64 bottleneck channels, 256 output channels, stride 1.
- * x: (N, H, W, Cin) bf16 NHWC, Cin a multiple of 64 (<= 1024); w1: [64][Cin], w2: [64][3][3][64], w3: [256][64] bf16 with the BN scale
- * folded; b1 / b2: [64], b3: [256] fp32 folded BN shifts (b3 INCLUDES the projection shortcut's shift when wsc is given);
- * wsc: [256][Cin] bf16 projection-shortcut weights, or NULL for the identity shortcut (then Cin must be 256); out: (N, H, W, 256)
- * bf16.  The two 64-channel intermediates stay in LDS (a frozen block has no backward pass). */
+ * x: (N, H, W, Cin) bf16 NHWC; w1: [64][Cin], w2: [64][3][3][64], w3: [256][64] bf16 with the BN scale folded; b1 / b2: [64],
+ * b3: [256] fp32 folded BN shifts (b3 INCLUDES the projection shortcut's shift when wsc is given); wsc: [256][Cin] bf16
+ * projection-shortcut weights with Cin = 64 (first block of res2), or NULL for the identity shortcut with Cin = 256 (SOD_EARG for any
+ * other combination); out: (N, H, W, 256) bf16.  The two 64-channel intermediates stay in LDS (a frozen block has no backward pass). */
 int sod_bottleneck_frozen_fwd(const void* x, int N, int H, int W, int Cin, const void* w1, const float* b1, const void* w2,
                               const float* b2, const void* w3, const float* b3, const void* wsc, void* out, void* stream);
 /* The augmentation + batching stage in front of the model on the device: ResizeShortestEdge / ResizeLongestEdge and

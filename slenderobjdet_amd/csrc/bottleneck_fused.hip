@@ -6,17 +6,21 @@
 // the two 64-channel intermediates need not exist in HBM at all: per block of a 16 x 200x336 batch the un-fused path moves 2.2 GB
 // (x read twice, both intermediates written and read, out written) at the HBM roofline, this kernel 1.1 GB (x in, out out).
 //
-// One workgroup (4 waves, two workgroups per CU) = an 8 x 16 tile of output pixels of one image:
-//   stage 1  h1 = relu(W1 x + b1) on the 10 x 18 halo (180 pixels, 12 MFMA column tiles): implicit GEMM M = 64, K = Cin in chunks of
-//            64 channels, x and W1 chunks double-buffered in LDS by buffer_load ... lds; h1 of halo pixels OUTSIDE the image is
-//            zero (it is the zero padding of the 3x3 conv, not relu(b1)); written to LDS as bf16 rows of 128 B, XOR-swizzled;
-//   stage 2  h2 = relu(W2 * h1 + b2): M = 64, N = 128 pixels, K = 9 taps x 64; a tile row of 16 pixels is one MFMA column tile, so
-//            a tap is a row / column shift of the h1 row index; W2 streams tap by tap through a two-slot ring; h2 overwrites h1;
-//   stage 3  acc = W3 h2 (+ Wsc x_centre for a projection shortcut, as extra contraction chunks): M = 256, N = 128, W3 was
-//            requested at the end of stage 1;
-//   epilogue + b3 (+ identity x), ReLU, bf16, through per-wave LDS so that every lane stores 16 contiguous bytes.
+// One workgroup (4 waves, two workgroups per CU) = an 8 x 16 tile of output pixels of one image.  Every GEMM keeps its WEIGHTS IN
+// REGISTERS (MFMA A operand, loaded straight from global / L2 while the previous stage computes) and reads only the activations (B
+// operand) from LDS, so a stage has no weight staging and no barrier inside:
+//   stage 1  h1 = relu(W1 x + b1) on the 10 x 18 halo (180 pixels = 12 MFMA column tiles): wave w owns output channels 16w..16w+15;
+//            K = Cin in chunks of 64 channels, the x chunks go HBM -> LDS by buffer_load ... lds through a three-slot ring (two
+//            chunks in flight, counted vmcnt + raw s_barrier); h1 of halo pixels OUTSIDE the image is zero (the zero padding of the
+//            3x3 conv, not relu(b1)); h1 -> LDS as bf16 rows of 128 B, 16-B chunks XOR-swizzled by (row >> 1) & 7;
+//   stage 2  h2 = relu(W2 * h1 + b2): wave w owns channels 16w..; a tile row of 16 pixels is one MFMA column tile, so a tap is a row /
+//            column shift of the h1 row index; all 9 x 64 contraction elements of W2's 16 rows sit in 72 VGPRs;
+//   stage 3  acc = W3 h2 (+ Wsc x for the projection shortcut: the tile's own pixels of the x chunk still in ring slot 0): wave w owns
+//            output channels 64w..64w+63;
+//   epilogue + b3 (+ identity x, all 16 loads of a lane issued at once), ReLU, bf16, through per-wave LDS so that every lane stores 16
+//            contiguous bytes.
 // Intermediates are rounded to bf16 exactly where the un-fused path stores them; the projection shortcut is added in fp32 (the
-// un-fused path rounds it to bf16 first).
+// un-fused path rounds it to bf16 first).  Two shapes exist: <Cin = 64, projection> (first block of res2) and <Cin = 256, identity>.
 #include "common.h"
 #include "../../include/slender_hip.h"
 
@@ -26,28 +30,36 @@ constexpr int BT_TH = 8, BT_TW = 16;
 constexpr int BT_HW = BT_TW + 2;              // halo columns
 constexpr int BT_HP = (BT_TH + 2) * BT_HW;    // 180 halo pixels
 constexpr int BT_ROWB = 128;                  // LDS row: 64 bf16
-// LDS map (bytes)
-constexpr int L_XS0 = 0;                      // x chunk, slot 0: [192][128]      -> later h1 [192][128], then h2 [128][128]
-constexpr int L_XS1 = 24576;                  // x chunk, slot 1                  -> later W3 / Wsc chunk [256][128] (32 KB)
-constexpr int L_WS0 = 49152;                  // W1 chunk, slot 0: [64][128]         (inside the later W3 region)
-constexpr int L_WS1 = 57344;                  // W1 chunk, slot 1                 -> later W2 tap ring slot 0 / x-centre chunk [128][128]
-constexpr int L_WS2 = 65536;                  //                                     W2 tap ring slot 1
-constexpr int L_TOTAL = 73728;
-constexpr int L_H1 = 0, L_H2 = 0, L_W3 = L_XS1, L_XC = L_WS1;
-constexpr int EROWB = 128 * 4 + 16;           // epilogue: fp32 row of 128 channels + pad
+constexpr int SLOT = 192 * BT_ROWB;           // 24 KB: one x chunk [192 halo rows][64 ch]
+constexpr int L_TOTAL = 3 * SLOT;             // 72 KB: two workgroups per CU
+constexpr int L_H1 = SLOT, L_H2 = 2 * SLOT;   // h1 [192][128 B] in slot 1, h2 [128][128 B] in slot 2 (their x chunks are consumed by then)
+constexpr int L_EPI = SLOT;                   // epilogue staging (h1 is dead after stage 2)
+constexpr int EROWB = 64 * 4 + 16;            // epilogue: fp32 row of 64 channels + pad
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 struct BneckArgs {
   const void* x; void* out;
-  const void* w1; const void* w2; const void* w3; const void* wsc;
+  const __bf16* w1; const __bf16* w2; const __bf16* w3; const __bf16* wsc;
   const float* b1; const float* b2; const float* b3;
-  uint32_t x_bytes, w1_bytes, w2_bytes, w3_bytes, wsc_bytes;
-  int N, H, W, Cin;
+  uint32_t x_bytes, out_bytes;
+  int N, H, W;
   int tiles_x, tiles_y;
 };
 
 __device__ __forceinline__ uint32_t swz_off(int row, int chunk) { return (uint32_t)(row * BT_ROWB + ((chunk ^ ((row >> 1) & 7)) << 4)); }
 
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void lds_fence_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+template <int NK, bool PROJ>
 __global__ __launch_bounds__(256, 2) void bottleneck_frozen_kernel(const BneckArgs a) {
+  constexpr int Cin = NK * 64;
+  static_assert(!PROJ || NK == 1, "the projection shortcut reads the single x chunk kept in ring slot 0");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,16 +68,22 @@ __global__ __launch_bounds__(256, 2) void bottleneck_frozen_kernel(const BneckAr
   const int ty = (int)(bid % (uint32_t)a.tiles_y);
   const int n = (int)(bid / (uint32_t)a.tiles_y);
   const int y0 = ty * BT_TH, x0 = tx * BT_TW;
-  const int H = a.H, W = a.W, Cin = a.Cin;
-  const int nk = Cin >> 6;
+  const int H = a.H, W = a.W;
+  const int fr = lane & 15, fg = lane >> 4;
 
-  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
-  auto w1rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w1), 0, a.w1_bytes, 0x00020000);
-  auto w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w2), 0, a.w2_bytes, 0x00020000);
-  auto w3rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w3), 0, a.w3_bytes, 0x00020000);
+  // ---- weights of stage 1 and stage 2 -> registers (A operand: lane = output row 16*wave + fr, 8 consecutive k at fg*8)
+  bf16x8_t a1[NK][2], a2[9][2];
+  {
+    const __bf16* p1 = a.w1 + (size_t)(16 * wave + fr) * Cin + fg * 8;
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a1[kc][ks] = *reinterpret_cast<const bf16x8_t*>(p1 + kc * 64 + ks * 32);
+  }
 
-  // ---- staging geometry: one wave instruction = 8 LDS rows x 128 B; lane -> (row, 16-B slot); the lane fetches the LOGICAL chunk
+  // ---- x chunk staging: one wave instruction = 8 LDS rows x 128 B; lane -> (row, 16-B slot); the lane fetches the LOGICAL chunk
   // slot ^ ((row >> 1) & 7) (source-side swizzle), so that fragment reads (16 lanes = 16 consecutive rows, one chunk) are conflict-free
+  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
   const int srow = lane >> 3, spos = lane & 7;
   const int schunk = spos ^ ((lane >> 4) | ((wave & 1) << 2));
   const uint32_t img_base = (uint32_t)n * (uint32_t)H * (uint32_t)W;
@@ -78,237 +96,222 @@ __global__ __launch_bounds__(256, 2) void bottleneck_frozen_kernel(const BneckAr
     const bool ok = (row < BT_HP) & ((unsigned)y < (unsigned)H) & ((unsigned)xx < (unsigned)W);
     xrow[i] = ok ? ((img_base + (uint32_t)(y * W + xx)) * (uint32_t)Cin + (uint32_t)schunk * 8u) * 2u : SOD_OOB;
   }
-  const int wrow0 = wave * 8 + srow;                       // weight rows of this lane: wrow0 + 32 j
-  auto stage1 = [&](int kc, int slot) {
-    char* dx = smem + (slot ? L_XS1 : L_XS0) + wave * 1024;
-    char* dw = smem + (slot ? L_WS1 : L_WS0) + wave * 1024;
+  auto stage_x = [&](int kc) {     // 6 LDS-DMA loads per thread
+    char* dx = smem + (kc % 3) * SLOT + wave * 1024;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(dx + i * 4096), 16, xrow[i] + (uint32_t)kc * 128u, 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const uint32_t off = ((uint32_t)(wrow0 + 32 * j) * (uint32_t)Cin + (uint32_t)kc * 64u + (uint32_t)schunk * 8u) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w1rsrc, SOD_LDS(dw + j * 4096), 16, off, 0, 0, 0);
-    }
   };
-  auto stage_w2 = [&](int tap) {
-    char* dw = smem + ((tap & 1) ? L_WS2 : L_WS1) + wave * 1024;
+  // W2 rows of this wave: taps 0-4 are requested in front of stage 1 (older than every x chunk, so the first counted wait covers
+  // them), taps 5-8 during the first taps of stage 2 (register pressure: 40 instead of 72 VGPRs live through stage 1)
+  const __bf16* p2 = a.w2 + (size_t)(16 * wave + fr) * 576 + fg * 8;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const uint32_t off = ((uint32_t)(wrow0 + 32 * j) * 576u + (uint32_t)tap * 64u + (uint32_t)schunk * 8u) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rsrc, SOD_LDS(dw + j * 4096), 16, off, 0, 0, 0);
-    }
-  };
+  for (int tap = 0; tap < 5; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a2[tap][ks] = *reinterpret_cast<const bf16x8_t*>(p2 + tap * 64 + ks * 32);
+  stage_x(0);
+  if (NK > 1) stage_x(1);
+  if (NK > 2) stage_x(2);               // all three ring slots are free at the start of a tile
+  __builtin_amdgcn_sched_barrier(0);      // the scheduler must not sink the register loads towards their first use
+  const f32x4_t bv0 = *reinterpret_cast<const f32x4_t*>(a.b3 + wave * 64 + (lane & 7) * 8);       // epilogue bias: requested first, so that
+  const f32x4_t bv1 = *reinterpret_cast<const f32x4_t*>(a.b3 + wave * 64 + (lane & 7) * 8 + 4);   // no late wait on it drains the stores
+  const f32x4_t b1v = *reinterpret_cast<const f32x4_t*>(a.b1 + 16 * wave + fg * 4);
+  const f32x4_t b2v = *reinterpret_cast<const f32x4_t*>(a.b2 + 16 * wave + fg * 4);
 
-  const int fr = lane & 15, fg = lane >> 4;
-  // biases of the accumulator rows this lane holds (q = i*16 + fg*4 + e)
-  f32x4_t b1v[4], b2v[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    b1v[i] = *reinterpret_cast<const f32x4_t*>(a.b1 + i * 16 + fg * 4);
-    b2v[i] = *reinterpret_cast<const f32x4_t*>(a.b2 + i * 16 + fg * 4);
-  }
+  // fragment offset of row fr inside a [.][128 B] tile whose first row is a multiple of 16: the swizzle term depends on fr only
+  const uint32_t fo0 = swz_off(fr, fg), fo1 = fo0 ^ 64u;
 
-  // ================= stage 1: h1 = relu(W1 x + b1) on the halo =================
-  uint32_t aoff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) aoff[i] = swz_off(i * 16 + fr, fg);
+  // ================= stage 1: h1 = relu(W1 x + b1) on the halo; this wave: channels 16*wave .. +15, all 12 column tiles =============
   {
-    uint32_t boff[3];
+    f32x4_t acc[12];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) boff[j] = swz_off((wave * 3 + j) * 16 + fr, fg);
-    f32x4_t acc[4][3];
+    for (int j = 0; j < 12; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    stage1(0, 0);
-    for (int kc = 0; kc < nk; ++kc) {
-      __syncthreads();                                     // chunk kc has landed (vmcnt(0)); everybody is done with chunk kc-1
-      if (kc + 1 < nk) stage1(kc + 1, (kc + 1) & 1);
-      const char* cx = smem + ((kc & 1) ? L_XS1 : L_XS0);
-      const char* cw = smem + ((kc & 1) ? L_WS1 : L_WS0);
+    for (int kc = 0; kc < NK; ++kc) {
+      // chunks 0-2 are requested up front, chunk c >= 3 in iteration c-2: chunk kc has landed when at most the loads of the chunks
+      // requested after it (6 each) are outstanding (any other load issued later only makes the wait stricter)
+      const int issued = (kc == 0) ? (NK < 3 ? NK : 3) : (kc + 2 < NK ? kc + 2 : NK);
+      const int younger = issued - kc - 1;                 // folds to a constant: the loop is fully unrolled
+      if (younger <= 0) wait_vm<0>(); else if (younger == 1) wait_vm<6>(); else wait_vm<12>();
+      __builtin_amdgcn_s_barrier();                        // ... for every wave; and everybody is done reading chunk kc-1
+      if (kc >= 1 && kc + 2 < NK) stage_x(kc + 2);         // into the slot of chunk kc-1
+      const char* cx = smem + (kc % 3) * SLOT;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8_t af[4], bf[3];
+        const uint32_t fo = ks ? fo1 : fo0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(cw + (aoff[i] ^ (ks << 6)));
+        for (int h = 0; h < 2; ++h) {
+          bf16x8_t bf[6];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(cx + (boff[j] ^ (ks << 6)));
+          for (int j = 0; j < 6; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(cx + (h * 6 + j) * 2048 + fo);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 6; ++j) acc[h * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[kc][ks], bf[j], acc[h * 6 + j], 0, 0, 0);
+        }
       }
     }
-    __syncthreads();                                       // every wave has finished reading the x / W1 slots
-    // W3 (32 KB) and the first W2 tap are requested now and land while h1 is written
+    // h1 overwrites slot 1 (chunk 1): with NK >= 3 the barrier of iteration 2 already proves every wave has finished reading it
+    if (NK == 2) __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t off = ((uint32_t)(wrow0 + 32 * j) * 64u + (uint32_t)schunk * 8u) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w3rsrc, SOD_LDS(smem + L_W3 + wave * 1024 + j * 4096), 16, off, 0, 0, 0);
-    }
-    stage_w2(0);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int hp = (wave * 3 + j) * 16 + fr;
+    for (int j = 0; j < 12; ++j) {
+      const int hp = j * 16 + fr;
       const int hy = hp / BT_HW, hx = hp - hy * BT_HW;
       const int y = y0 - 1 + hy, xx = x0 - 1 + hx;
       const bool ok = (hp < BT_HP) & ((unsigned)y < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+      bf16x4_t o;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bf16x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(ok ? fmaxf(acc[i][j][e] + b1v[i][e], 0.f) : 0.f);
-        *reinterpret_cast<bf16x4_t*>(smem + L_H1 + swz_off(hp, i * 2 + (fg >> 1)) + (fg & 1) * 8) = o;
-      }
+      for (int e = 0; e < 4; ++e) o[e] = (__bf16)(ok ? fmaxf(acc[j][e] + b1v[e], 0.f) : 0.f);
+      *reinterpret_cast<bf16x4_t*>(smem + L_H1 + j * 2048 + swz_off(fr, 2 * wave + (fg >> 1)) + (fg & 1) * 8) = o;
     }
   }
+  lds_fence_barrier();                                     // h1 visible
 
-  // ================= stage 2: h2 = relu(W2 * h1 + b2) =================
+  // ================= stage 2: h2 = relu(W2 * h1 + b2); this wave: channels 16*wave .., the 8 tile rows =================
+  bf16x8_t a3[4][2], asc[PROJ ? 4 : 1][2];
   {
-    f32x4_t acc[4][2];
+    f32x4_t acc[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int base0 = (2 * wave) * BT_HW + fr;              // halo index of (tile row 2*wave, column fr) for tap (0, 0)
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      __syncthreads();                                     // tap's weights landed; h1 visible (tap 0); the other ring slot is free
-      if (tap + 1 < 9) stage_w2(tap + 1);
-      const char* cw = smem + ((tap & 1) ? L_WS2 : L_WS1);
       const int r = tap / 3, s = tap - r * 3;
-      uint32_t boff[2];
+      if (tap < 4) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) boff[j] = L_H1 + swz_off(base0 + (j + r) * BT_HW + s, fg);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8_t af[4], bf[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(cw + (aoff[i] ^ (ks << 6)));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(smem + (boff[j] ^ (ks << 6)));
+        for (int ks = 0; ks < 2; ++ks) a2[tap + 5][ks] = *reinterpret_cast<const bf16x8_t*>(p2 + (tap + 5) * 64 + ks * 32);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tap == 5) {
+        // weights of stage 3 (this wave: output rows 64*wave .. +63): requested once most of W2's registers are free again
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int ks = 0; ks < 2; ++ks) {
+            a3[i][ks] = *reinterpret_cast<const bf16x8_t*>(a.w3 + (size_t)((4 * wave + i) * 16 + fr) * 64 + ks * 32 + fg * 8);
+            if (PROJ) asc[i][ks] = *reinterpret_cast<const bf16x8_t*>(a.wsc + (size_t)((4 * wave + i) * 16 + fr) * Cin + ks * 32 + fg * 8);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t bf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(smem + L_H1 + (swz_off((j + r) * BT_HW + s + fr, fg) ^ (uint32_t)(ks << 6)));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[tap][ks], bf[j], acc[j], 0, 0, 0);
       }
     }
-    __syncthreads();                                       // every wave has finished reading h1 and the W2 ring
+    // h2 goes to slot 2, which nobody reads any more (its x chunk was consumed before the barrier in front of h1)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int p = (2 * wave + j) * 16 + fr;
+    for (int j = 0; j < 8; ++j) {
+      bf16x4_t o;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bf16x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(acc[i][j][e] + b2v[i][e], 0.f);
-        *reinterpret_cast<bf16x4_t*>(smem + L_H2 + swz_off(p, i * 2 + (fg >> 1)) + (fg & 1) * 8) = o;
-      }
+      for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(acc[j][e] + b2v[e], 0.f);
+      *reinterpret_cast<bf16x4_t*>(smem + L_H2 + j * 2048 + swz_off(fr, 2 * wave + (fg >> 1)) + (fg & 1) * 8) = o;
     }
   }
+  lds_fence_barrier();                                     // h2 visible; every wave is done with h1 (the epilogue reuses slot 1)
 
-  // ================= stage 3: acc = W3 h2 (+ Wsc x) =================
-  const int wq = wave >> 1, wp = wave & 1;
-  f32x4_t acc[8][4];
+  // ================= stage 3 + epilogue, in two halves of four tile rows (64 accumulator registers instead of 128) =================
+  // acc = W3 h2 (+ Wsc x); this wave: channels 64*wave .. +63.  acc[i][jj]: lane holds channels 64*wave + i*16 + fg*4 .. +3 of pixel
+  // (tile row 4*hh + jj, column fr).  Through per-wave LDS ([16 columns][64 channels] fp32) every lane gets 8 consecutive channels of one
+  // pixel: 16-B loads / stores, 128-B runs per pixel.
+  // Branch-free: residual loads and stores go through buffer resources, pixels outside the image use the out-of-range offset (the
+  // hardware returns zero / drops the store).  A lane-dependent branch around them made hipcc drain vmcnt(0) (stores included) per pass.
+  char* wl = smem + L_EPI + wave * (16 * EROWB);
+  const int erow = lane >> 3, eq = (lane & 7) * 8;
+  const int q = wave * 64 + eq;
+  auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+  uint32_t dcol[2];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int k = 0; k < 2; ++k) {
+    const int xx = x0 + k * 8 + erow;
+    dcol[k] = (xx < W) ? ((uint32_t)xx * 256u + (uint32_t)q) * 2u : SOD_OOB;
+  }
+  const uint32_t img_row0 = (img_base + (uint32_t)(y0 * W)) * 512u;      // byte offset of (n, y0, 0, 0) in a 256-channel tensor
+  u32x4_t resv[PROJ ? 1 : 8][2];
+  if (!PROJ) {
+    // identity shortcut: all 16 loads of the lane are requested in front of the GEMM (x was just read: L2 / MALL hits)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  uint32_t aoff3[8], boff3[4];
+    for (int j = 0; j < 8; ++j)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) aoff3[i] = L_W3 + swz_off((wq * 8 + i) * 16 + fr, fg);
+      for (int k = 0; k < 2; ++k) {
+        const uint32_t off = (y0 + j < H) ? img_row0 + (uint32_t)(j * W) * 512u + dcol[k] : SOD_OOB;
+        resv[j][k] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) boff3[j] = swz_off((wp * 4 + j) * 16 + fr, fg);
-  auto gemm3 = [&](int bbase) {
+  for (int hh = 0; hh < 2; ++hh) {
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[8], bf[4];
+      const uint32_t fo = ks ? fo1 : fo0;
+      bf16x8_t bf[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(smem + (aoff3[i] ^ (ks << 6)));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(smem + bbase + (boff3[j] ^ (ks << 6)));
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-  };
-  __syncthreads();                                         // h2 visible, W3 landed
-  gemm3(L_H2);
-  if (a.wsc != nullptr) {
-    // projection shortcut = more contraction chunks of the same GEMM: A = Wsc[:, chunk], B = x at the tile's own pixels
-    auto scrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wsc), 0, a.wsc_bytes, 0x00020000);
-    uint32_t crow[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (i * 4 + wave) * 8 + srow;           // tile pixel
-      const int y = y0 + (row >> 4), xx = x0 + (row & 15);
-      const bool ok = (y < H) & (xx < W);
-      crow[i] = ok ? ((img_base + (uint32_t)(y * W + xx)) * (uint32_t)Cin + (uint32_t)schunk * 8u) * 2u : SOD_OOB;
-    }
-    for (int kc = 0; kc < nk; ++kc) {
-      __syncthreads();                                     // the W3 region and the x-centre slot are free
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint32_t off = ((uint32_t)(wrow0 + 32 * j) * (uint32_t)Cin + (uint32_t)kc * 64u + (uint32_t)schunk * 8u) * 2u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(scrsrc, SOD_LDS(smem + L_W3 + wave * 1024 + j * 4096), 16, off, 0, 0, 0);
-      }
+      for (int jj = 0; jj < 4; ++jj) bf[jj] = *reinterpret_cast<const bf16x8_t*>(smem + L_H2 + (hh * 4 + jj) * 2048 + fo);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(smem + L_XC + wave * 1024 + i * 4096), 16, crow[i] + (uint32_t)kc * 128u, 0, 0, 0);
-      __syncthreads();
-      gemm3(L_XC);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[i][ks], bf[jj], acc[i][jj], 0, 0, 0);
     }
-  }
-  __syncthreads();                                         // all LDS reads of the GEMMs are done: the epilogue reuses the memory
-
-  // ================= epilogue =================
-  // acc[i][jj]: lane holds channels (wq*8 + i)*16 + fg*4 .. +3 of pixel (tile row wp*4 + jj, column fr).  Through per-wave LDS
-  // ([16 columns][128 channels] fp32) every lane gets 8 consecutive channels of one pixel: 16-B loads / stores, 256-B runs.
-  char* wl = smem + wave * (16 * EROWB);
-  const int erow = lane >> 4, eq = (lane & 15) * 8;
-  const int q = wq * 128 + eq;
-  float bv[8];
-  {
-    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(a.b3 + q), b1 = *reinterpret_cast<const f32x4_t*>(a.b3 + q + 4);
-    bv[0] = b0[0]; bv[1] = b0[1]; bv[2] = b0[2]; bv[3] = b0[3]; bv[4] = b1[0]; bv[5] = b1[1]; bv[6] = b1[2]; bv[7] = b1[3];
-  }
-  const bool identity = a.wsc == nullptr;
+    if (PROJ) {
+      // projection shortcut = one more contraction chunk of the same GEMM: B = x at the tile's own pixels = halo rows (j+1)*18 + fr + 1
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int y = y0 + wp * 4 + jj;
-    bf16x8_t resv[4];
-    size_t drow[4];
-    bool ok[4];
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t bf[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int xx = x0 + k * 4 + erow;
-      ok[k] = (y < H) & (xx < W);
-      drow[k] = ((size_t)img_base + (size_t)(ok[k] ? y * W + xx : 0)) * 256u + (size_t)q;
-      if (identity && ok[k]) resv[k] = *reinterpret_cast<const bf16x8_t*>((const __bf16*)a.x + drow[k]);
+        for (int jj = 0; jj < 4; ++jj)
+          bf[jj] = *reinterpret_cast<const bf16x8_t*>(smem + (swz_off((hh * 4 + jj + 1) * BT_HW + 1 + fr, fg) ^ (uint32_t)(ks << 6)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asc[i][ks], bf[jj], acc[i][jj], 0, 0, 0);
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4_t*>(wl + fr * EROWB + (i * 16 + fg * 4) * 4) = acc[i][jj];
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = hh * 4 + jj;
+      const uint32_t rowoff = (y0 + j < H) ? img_row0 + (uint32_t)(j * W) * 512u : SOD_OOB;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = k * 4 + erow;
-      const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(wl + row * EROWB + eq * 4);
-      const f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(wl + row * EROWB + eq * 4 + 16);
-      if (ok[k]) {
-        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_t*>(wl + fr * EROWB + (i * 16 + fg * 4) * 4) = acc[i][jj];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int row = k * 8 + erow;
+        const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(wl + row * EROWB + eq * 4);
+        const f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(wl + row * EROWB + eq * 4 + 16);
+        float v[8] = {t0[0] + bv0[0], t0[1] + bv0[1], t0[2] + bv0[2], t0[3] + bv0[3], t1[0] + bv1[0], t1[1] + bv1[1], t1[2] + bv1[2], t1[3] + bv1[3]};
+        if (!PROJ) {
+          const u32x4_t rv = resv[PROJ ? 0 : j][k];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {        // bf16 pair -> two floats
+            v[2 * e] += __uint_as_float(rv[e] << 16);
+            v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u);
+          }
+        }
         bf16x8_t o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float t = v[e] + bv[e];
-          if (identity) t += (float)resv[k][e];
-          o[e] = (__bf16)fmaxf(t, 0.f);
-        }
-        *reinterpret_cast<bf16x8_t*>((__bf16*)a.out + drow[k]) = o;
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e], 0.f);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), orsrc, (rowoff | dcol[k]) & SOD_OOB ? SOD_OOB : rowoff + dcol[k], 0, 0);
       }
     }
   }
+}
+
+template <int NK, bool PROJ>
+int launch_bneck(const BneckArgs& a, long long blocks, hipStream_t st) {
+  auto kern = bottleneck_frozen_kernel<NK, PROJ>;
+  static bool attr_done = false;                           // process-wide; idempotent
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  SOD_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), L_TOTAL, st, a);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
 }
 
 }  // namespace
@@ -316,32 +319,24 @@ __global__ __launch_bounds__(256, 2) void bottleneck_frozen_kernel(const BneckAr
 extern "C" int sod_bottleneck_frozen_fwd(const void* x, int N, int H, int W, int Cin, const void* w1, const float* b1, const void* w2,
                                          const float* b2, const void* w3, const float* b3, const void* wsc, void* out, void* stream) {
   if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out) return SOD_EARG;
-  if (N <= 0 || H <= 0 || W <= 0 || Cin < 64 || (Cin & 63) || Cin > 1024) return SOD_EARG;
-  if (!wsc && Cin != 256) return SOD_EARG;                 // identity shortcut: input and output channels agree
+  if (N <= 0 || H <= 0 || W <= 0) return SOD_EARG;
+  // the two block shapes of a ResNet res2 stage: projection shortcut on the 64-channel stem output, identity on 256 channels
+  if (!((wsc && Cin == 64) || (!wsc && Cin == 256))) return SOD_EARG;
   const long long px = (long long)N * H * W;
-  if (px * Cin * 2 >= (1ll << 31) || px * 256 * 2 >= (1ll << 31)) return SOD_ESIZE;
+  if (px * 256 * 2 >= (1ll << 31)) return SOD_ESIZE;
   const uintptr_t al = (uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)w3 | (uintptr_t)wsc | (uintptr_t)out | (uintptr_t)b1 | (uintptr_t)b2 |
                        (uintptr_t)b3;
   if (al & 15) return SOD_EALIGN;
   BneckArgs a;
-  a.x = x; a.out = out; a.w1 = w1; a.w2 = w2; a.w3 = w3; a.wsc = wsc; a.b1 = b1; a.b2 = b2; a.b3 = b3;
+  a.x = x; a.out = out;
+  a.w1 = (const __bf16*)w1; a.w2 = (const __bf16*)w2; a.w3 = (const __bf16*)w3; a.wsc = (const __bf16*)wsc;
+  a.b1 = b1; a.b2 = b2; a.b3 = b3;
   a.x_bytes = (uint32_t)(px * Cin * 2);
-  a.w1_bytes = (uint32_t)(64 * Cin * 2);
-  a.w2_bytes = 64u * 576u * 2u;
-  a.w3_bytes = 256u * 64u * 2u;
-  a.wsc_bytes = wsc ? (uint32_t)(256 * Cin * 2) : 0u;
-  a.N = N; a.H = H; a.W = W; a.Cin = Cin;
+  a.out_bytes = (uint32_t)(px * 256 * 2);
+  a.N = N; a.H = H; a.W = W;
   a.tiles_x = (W + BT_TW - 1) / BT_TW;
   a.tiles_y = (H + BT_TH - 1) / BT_TH;
-  static bool attr_done = false;                           // process-wide; idempotent
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)bottleneck_frozen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
   const long long blocks = (long long)N * a.tiles_x * a.tiles_y;
   if (blocks >= (1ll << 31)) return SOD_ESIZE;
-  SOD_LAUNCH(bottleneck_frozen_kernel, dim3((unsigned)blocks), dim3(256), L_TOTAL, (hipStream_t)stream, a);
-  SOD_CHECK_LAUNCH();
-  return SOD_OK;
+  return wsc ? launch_bneck<1, true>(a, blocks, (hipStream_t)stream) : launch_bneck<4, false>(a, blocks, (hipStream_t)stream);
 }

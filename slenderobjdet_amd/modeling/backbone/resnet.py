@@ -166,11 +166,12 @@ def _block_fusable(blk):
             and c2.kernel_size == 3 and c2.stride == 1 and c2.padding == 1 and c2.dilation == 1 and c2.out_channels == 64 and c2.relu
             and c3.kernel_size == 1 and c3.stride == 1 and c3.padding == 0 and c3.out_channels == 256 and c3.relu):
         return False
-    if c1.in_channels % 64 or c1.in_channels > 1024 or any(m.cin_pad for m in (c1, c2, c3)):
+    if any(m.cin_pad for m in (c1, c2, c3)):
         return False
-    if sc is None:
+    if sc is None:      # the two block shapes of res2: identity on 256 channels, projection on the 64-channel stem output
         return c1.in_channels == 256
-    return sc.kernel_size == 1 and sc.stride == 1 and sc.padding == 0 and sc.out_channels == 256 and not sc.relu and not sc.cin_pad
+    return (c1.in_channels == 64 and sc.kernel_size == 1 and sc.stride == 1 and sc.padding == 0 and sc.out_channels == 256
+            and not sc.relu and not sc.cin_pad)
 
 
 def _fused_frozen_block(blk, x):
