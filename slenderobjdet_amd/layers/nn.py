@@ -19,6 +19,42 @@ def _arena_of(mod):
     return getattr(mod, "_arena", None)
 
 
+class DeferSlot:
+    """Hand-over between a producer node that can fold a consumer's data gradient into its own first backward kernel and that consumer.
+
+    A ResNet stage output feeds the next stage AND an FPN lateral 1x1 conv; autograd would sum the two input gradients with an add
+    kernel and the stage would then apply its output ReLU mask in another pass (7 passes over the wide tensor incl. the lateral's own
+    dgrad store).  Instead the stage publishes a slot for its output (``offer``); the lateral conv that consumes exactly that tensor
+    takes it (``take``), and in backward leaves its output gradient here instead of running its dgrad; the stage's backward - which
+    autograd runs after every consumer - runs that dgrad itself with ``accum`` = the other consumers' gradient and ``relu_mask`` =
+    the stage output: read accum, read mask, write = 3 passes."""
+    _offers = {}
+
+    def __init__(self):
+        self.g = self.mod = None
+
+    @classmethod
+    def reset(cls):
+        """Start of a backbone forward: offers nobody took (outputs without a lateral conv) must not outlive their tensors."""
+        cls._offers.clear()
+
+    @classmethod
+    def offer(cls, tensor):
+        slot = cls()
+        cls._offers[(tensor.data_ptr(), tuple(tensor.shape))] = slot
+        return slot
+
+    @classmethod
+    def take(cls, tensor):
+        return cls._offers.pop((tensor.data_ptr(), tuple(tensor.shape)), None)
+
+
+import os as _os
+
+# SOD_DEFER_LATERAL=0: the FPN lateral convs run their own data gradient and autograd sums it with the next stage's (see DeferSlot)
+DEFER_LATERAL_DGRAD = _os.environ.get("SOD_DEFER_LATERAL", "1") != "0"
+
+
 class HipConv2d(nn.Module):
     """Conv2d with optional folded FrozenBatchNorm2d, fused bias / residual / ReLU epilogue.
 
@@ -150,6 +186,10 @@ class _ConvFn(torch.autograd.Function):
         y = HF.conv2d_fwd(x, mod.w_bf16, mod.bias_eff, res, mod.stride, mod.padding, mod.dilation, relu=mod.relu, res_up2=res_up2,
                           out_f32=mod.out_f32, c_real=mod.in_channels if mod.cin_pad else None)
         ctx.mod, ctx.res_up2, ctx.has_res = mod, res_up2, res is not None
+        # a 1x1 stride-1 conv on a stage output whose producer offered to run this conv's data gradient (DeferSlot)
+        ctx.slot = None
+        if DEFER_LATERAL_DGRAD and x.requires_grad and mod.kernel_size == 1 and mod.stride == 1 and not mod.mask_input and not mod.relu:
+            ctx.slot = DeferSlot.take(x)
         train_w = mod.weight.requires_grad
         if train_w or x.requires_grad or (res is not None and res.requires_grad):
             ctx.save_for_backward(x, y if mod.relu else None)
@@ -179,8 +219,11 @@ class _ConvFn(torch.autograd.Function):
                 arena.mark_ready(mod.bias)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = HF.conv2d_dgrad(g, mod.wt_bf16, (H, W), mod.stride, mod.padding, mod.dilation,
-                                 relu_mask=x if mod.mask_input else None)
+            if ctx.slot is not None:      # the producer of x runs this data gradient fused with its own mask / accumulate (DeferSlot)
+                ctx.slot.g, ctx.slot.mod = g, mod
+            else:
+                dx = HF.conv2d_dgrad(g, mod.wt_bf16, (H, W), mod.stride, mod.padding, mod.dilation,
+                                     relu_mask=x if mod.mask_input else None)
         dres = None
         if ctx.has_res and ctx.needs_input_grad[1]:
             dres = HF.upsample2x_bwd(g) if ctx.res_up2 else g

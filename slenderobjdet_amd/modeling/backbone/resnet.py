@@ -11,7 +11,7 @@ from torch import nn
 from torch.autograd.function import once_differentiable
 
 from ...layers import functional as HF
-from ...layers.nn import HipConv2d, _arena_of, max_pool_3x3_s2
+from ...layers.nn import DeferSlot, HipConv2d, _arena_of, max_pool_3x3_s2
 import os
 
 from ..shape_spec import ShapeSpec
@@ -87,9 +87,12 @@ class _BottleneckStageFn(torch.autograd.Function):
             out = _conv(blk.conv3, b, res=sc)
             saved += [a, b, out]
         ctx.stage = stage
+        ctx.slot = None
         train = blocks[0].conv1.weight.requires_grad
         if train or x.requires_grad:
             ctx.save_for_backward(*saved)
+            ctx.set_materialize_grads(False)
+            ctx.slot = DeferSlot.offer(saved[-1])      # an FPN lateral conv on this output may leave its data gradient to us
             arena = _arena_of(blocks[0].conv1)
             if train and arena is not None:
                 for blk in blocks:
@@ -104,7 +107,17 @@ class _BottleneckStageFn(torch.autograd.Function):
         blocks = list(ctx.stage)
         saved = ctx.saved_tensors
         arena = _arena_of(blocks[0].conv1)
-        g = HF.relu_bwd(dout.contiguous(), saved[-1])
+        slot, ctx.slot = ctx.slot, None
+        if slot is not None and slot.g is not None:
+            # d(out) = dgrad(lateral 1x1, its output gradient) + the other consumers' gradient, times the ReLU mask of out: one launch
+            lat = slot.mod
+            g = HF.conv2d_dgrad(slot.g, lat.wt_bf16, (saved[-1].shape[1], saved[-1].shape[2]), 1, 0, 1,
+                                accum=None if dout is None else dout.contiguous(), relu_mask=saved[-1])
+            slot.g = slot.mod = None
+        elif dout is None:
+            return None, None, None
+        else:
+            g = HF.relu_bwd(dout.contiguous(), saved[-1])
         dx = None
         for k in range(len(blocks) - 1, -1, -1):
             blk = blocks[k]
@@ -260,6 +273,7 @@ class ResNet(Backbone):
 
     def forward(self, x):
         outputs, start = {}, 0
+        DeferSlot.reset()
         if isinstance(x, FrozenPrefix):
             outputs.update(x.outputs)
             start, x = x.n_stages, x.tensor

@@ -448,3 +448,54 @@ def test_prefetched_frozen_prefix_is_bit_identical(cuda):
         assert not took and other_l == ref_l and torch.equal(other_g, ref_g)
     finally:
         HF.DETERMINISTIC = prev
+
+
+def test_deferred_lateral_dgrad_matches_separate_passes(cuda):
+    """The FPN lateral convs leave their data gradient to the ResNet stage that produced their input (layers/nn.py DeferSlot): the
+    stage runs dgrad(lateral) + other consumers' gradient + its output ReLU mask as ONE launch instead of dgrad -> autograd add ->
+    relu_bwd.  Same losses bit for bit (forward is untouched); gradients agree to bf16 rounding (the fused form rounds once instead
+    of three times), and the optimisation really is taken (the slots are consumed)."""
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.layers import nn as HN
+
+    cfg, model, opt = _build(50, seed=4)
+    data = synthetic_batch(2, 320, 384, 9, device="cuda")
+    prev, HF.DETERMINISTIC = HF.DETERMINISTIC, True
+    calls = {"fused": 0}
+    orig = HF.conv2d_dgrad
+
+    def counting(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=None, **kw):
+        if relu_mask is not None and wt.data_ptr() in lateral_ptrs:
+            calls["fused"] += 1
+        return orig(dy, wt, x_hw, stride, pad, dil, accum=accum, relu_mask=relu_mask, **kw)
+
+    try:
+        def step(defer):
+            HN.DEFER_LATERAL_DGRAD = defer
+            opt.zero_grad()
+            out = model(data)
+            total = sum(out.values())
+            model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+            return {k: float(v.detach()) for k, v in out.items()}, model.arena.grads.clone()
+
+        ref_l, ref_g = step(False)
+        lateral_ptrs = {m.wt_bf16.data_ptr() for m in model.backbone.lateral_convs}
+        HF.conv2d_dgrad = counting
+        got_l, got_g = step(True)
+        HF.conv2d_dgrad = orig
+        assert calls["fused"] == 3, calls            # res3, res4, res5 outputs
+        assert got_l == ref_l
+        assert torch.isfinite(got_g).all()
+        num = (got_g - ref_g).norm().item()
+        den = ref_g.norm().item()
+        assert num <= 2e-2 * den, (num, den)
+        # per-parameter: the backbone gradients (the only ones that can change) stay within bf16 noise of the three-pass form
+        for name, off, n in model.arena.names:
+            if "bottom_up" in name:
+                a, b = got_g[off:off + n], ref_g[off:off + n]
+                assert (a - b).norm().item() <= 5e-2 * max(b.norm().item(), 1e-12), name
+    finally:
+        HF.conv2d_dgrad = orig
+        HN.DEFER_LATERAL_DGRAD = True
+        HF.DETERMINISTIC = prev
