@@ -81,6 +81,14 @@ int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const float* qsca
 int sod_conv2d_fwd_ml(int nlev, const void* const* x, const void* w, const float* bias, void* const* y,
                       int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                       long long y_img_stride, int flags, int out_f32, void* stream);
+/* sod_conv2d_fwd_ml with bf16 output that ALSO gathers the GroupNorm statistics of what it stores: the FCOS / RetinaNet-GN tower unit is
+ * conv3x3 -> GroupNorm(32, 256) -> ReLU (fcosv2.py:300-336), and the statistics pass of the norm would re-read the tensor the conv
+ * epilogue just held in registers.  gn_sums: nlev consecutive [N][G][2] blocks, zeroed by this call, then accumulated (float atomics)
+ * with the per-(image, group) sum and sum of squares of the STORED bf16 values; K must equal 8 * G.  sod_groupnorm_apply_ml turns them
+ * into (mean, rstd) and applies the norm. */
+int sod_conv2d_fwd_ml_gnsum(int nlev, const void* const* x, const void* w, const float* bias, void* const* y,
+                            int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                            long long y_img_stride, int flags, float* gn_sums, int G, void* stream);
 int sod_conv2d_dgrad_ml(int nlev, const void* const* dy, const void* wt, void* const* dx,
                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                         long long dy_img_stride, void* stream);
@@ -122,6 +130,10 @@ int sod_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const f
  * level. x/y/dy/dx: arrays of nlev device pointers (dense (N,hw[l],C) bf16); mean_rstd / red_ws: nlev consecutive [N][G][2] blocks. */
 int sod_groupnorm_fwd_ml(int nlev, const void* const* x, const float* gamma, const float* beta, void* const* y, float* mean_rstd,
                          int N, const int* hw, int C, int G, float eps, int relu, float* det_ws, long long det_ws_bytes, void* stream);
+/* Second half of sod_groupnorm_fwd_ml for statistics that sod_conv2d_fwd_ml_gnsum gathered: sums_to_mean_rstd holds nlev [N][G][2]
+ * blocks of (sum, sum of squares) on entry and (mean, rstd) - what the backward pass takes - on return; y = [relu](norm(x)). */
+int sod_groupnorm_apply_ml(int nlev, const void* const* x, const float* gamma, const float* beta, void* const* y, float* sums_to_mean_rstd,
+                           int N, const int* hw, int C, int G, float eps, int relu, void* stream);
 int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void* const* x, const float* gamma, const float* beta,
                          const float* mean_rstd, void* const* dx, float* dgamma, float* dbeta, float* dxsum, float* red_ws,
                          int N, const int* hw, int C, int G, int relu, float* det_ws, long long det_ws_bytes, void* stream);

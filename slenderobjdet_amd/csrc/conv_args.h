@@ -9,6 +9,7 @@ namespace sodconv {
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 enum {
   F_BIAS = 1, F_RELU = 2, F_RES = 4, F_RES_UP2 = 8, F_MASK = 16,
+  F_GNSTATS = 32,      // bf16 forward output: per-(image, 8-channel group) sum / sum of squares of the stored values -> LevelGeo::gn_sum
 };
 constexpr int MAXLEV = SOD_CONV_MAX_LEVELS;
 
@@ -19,6 +20,7 @@ struct LevelGeo {
   void* dst;           // (N,Hp,Wp,Nout) rows at dst_img_stride
   const void* res;     // bf16, indexed like dst (or half-resolution with F_RES_UP2)
   const void* mask;    // bf16, indexed like dst: dst = mask>0 ? v : 0 (ReLU backward)
+  float* gn_sum;       // F_GNSTATS: [N][gn_G][2] running (sum, sum of squares), accumulated with float atomics
   uint32_t src_bytes;
   int Hs, Ws, Hp, Wp, P;
   int tile0;           // first pixel tile of this level
@@ -40,6 +42,7 @@ struct ConvArgs {
   int nq_tiles, np_tiles;
   FastDiv div_cpt /* Cred/64 (fast) or Cred/8 (generic) */, div_s, div_stride;
   FastDiv div_rs;      // R*S
+  int gn_G;            // F_GNSTATS: number of groups (Nout / gn_G == 8: the 8 channels a lane stores are one group)
   int tap_inner;       // linear path: K-step order (channel chunk outer, tap inner) - the taps of one chunk re-read the same cache lines
 };
 
@@ -52,6 +55,48 @@ inline int conv_tap_inner(int dflt) {
   static int v = -2;
   if (v == -2) { const char* e = getenv("SOD_CONV_TAP_INNER"); v = e ? atoi(e) : -1; }
   return v < 0 ? dflt : v;
+}
+
+// GroupNorm statistics gathered in the conv epilogue (F_GNSTATS): the FCOS tower unit is conv3x3 -> GroupNorm(32) -> ReLU
+// (slender_det/modeling/meta_arch/fcos/fcosv2.py:300-336) and the statistics pass would re-read the tensor the epilogue just held in
+// registers.  A lane owns 8 consecutive channels of a pixel = one group of GroupNorm(32, 256); it accumulates over its pixels (flushing
+// when the image index changes), then the lanes that own the same channels are summed with shuffles and one lane per group issues the
+// two atomics - unless the wave's 64 pixels straddle two images, in which case every lane flushes its own partial.
+struct GnAcc {
+  float s, ss;
+  int n;
+};
+__device__ __forceinline__ void gn_acc_flush(const GnAcc& g, float* sums, int G, int grp) {
+  if (g.n >= 0) {
+    atomicAdd(sums + ((size_t)g.n * G + grp) * 2, g.s);
+    atomicAdd(sums + ((size_t)g.n * G + grp) * 2 + 1, g.ss);
+  }
+}
+__device__ __forceinline__ void gn_acc_add(GnAcc& g, int n, const bf16x8_t& o, float* sums, int G, int grp) {
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { const float f = (float)o[e]; s += f; ss += f * f; }     // the STORED (rounded) values, as gn_stats reads them
+  if (n != g.n) { gn_acc_flush(g, sums, G, grp); g.n = n; g.s = 0.f; g.ss = 0.f; }
+  g.s += s; g.ss += ss;
+}
+// LPR = lanes per pixel row (lanes l, l + LPR, l + 2 LPR, ... own the same channels); pa .. pb = the wave's pixel range
+template <int LPR>
+__device__ __forceinline__ void gn_acc_finish(GnAcc& g, uint32_t pa, uint32_t pb, uint32_t P, const FastDiv& div_hw, float* sums, int G, int grp,
+                                              bool qok, int lane) {
+  if (pa >= P) return;                                   // wave-uniform
+  if (pb >= P) pb = P - 1;
+  const int na = (int)fd_div(pa, div_hw), nb = (int)fd_div(pb, div_hw);
+  if (na == nb) {                                        // wave-uniform: every partial belongs to image na (or is empty)
+    float s = (g.n >= 0) ? g.s : 0.f, ss = (g.n >= 0) ? g.ss : 0.f;
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+    if (lane < LPR && qok) {
+      atomicAdd(sums + ((size_t)na * G + grp) * 2, s);
+      atomicAdd(sums + ((size_t)na * G + grp) * 2 + 1, ss);
+    }
+  } else if (qok) {
+    gn_acc_flush(g, sums, G, grp);
+  }
 }
 
 // conv_igemm256.hip: 256x256x64 tile, 8 waves, 8-phase main loop.  Returns SOD_EARG when the shape is outside its fast path.

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
         bv[e] = b[0]; bv[e + 1] = b[1]; bv[e + 2] = b[2]; bv[e + 3] = b[3];
       }
     }
+    GnAcc ga{0.f, 0.f, -1};
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       // Residual / mask operands of ALL passes of this half are requested before the accumulators go through LDS: one exposed
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
       RV resv[NP], maskv[NP];
       size_t drow[NP];
       bool ok[NP];
+      int nimg[NP];
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         const int row = k * ERPP + erow;
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
         if (ok[k]) {
           const uint32_t n = fd_div(p, g.div_hw);
           const uint32_t rem = p - n * g.div_hw.d;
+          nimg[k] = (int)n;
           drow[k] = (size_t)n * g.dst_img_stride + (size_t)rem * Nout;
           if (a.flags & (F_RES | F_RES_UP2)) {
             size_t res_row;
@@ -400,9 +403,14 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
             *reinterpret_cast<bf16x8_t*>((__bf16*)g.dst + drow[k] + q) = o;
+            if constexpr (MODE == MODE_FWD) { if (a.flags & F_GNSTATS) gn_acc_add(ga, nimg[k], o, g.gn_sum, a.gn_G, q >> 3); }
           }
         }
       }
+    }
+    if constexpr (!OUT_F32 && MODE == MODE_FWD) {
+      if (a.flags & F_GNSTATS)
+        gn_acc_finish<LPR>(ga, p0 + wp * FP * 16, p0 + wp * FP * 16 + FP * 16 - 1, (uint32_t)gP, g.div_hw, g.gn_sum, a.gn_G, q >> 3, qok, lane);
     }
     return;
   }
@@ -1123,6 +1131,30 @@ extern "C" int sod_conv2d_fwd_ml(int nlev, const void* const* x, const void* w, 
   a.flags = (bias ? F_BIAS : 0) | ((flags & SOD_CONV_RELU) ? F_RELU : 0);
   hipStream_t st = (hipStream_t)stream;
   return out_f32 ? dispatch_conv<MODE_FWD, true>(a, st) : dispatch_conv<MODE_FWD, false>(a, st);
+}
+
+extern "C" int sod_conv2d_fwd_ml_gnsum(int nlev, const void* const* x, const void* w, const float* bias, void* const* y,
+                                       int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                       long long y_img_stride, int flags, float* gn_sums, int G, void* stream) {
+  if (!x || !w || !y || !H || !W || !gn_sums) return SOD_EARG;
+  if (G <= 0 || K != G * 8) return SOD_EARG;          // a lane's 8 output channels must be exactly one group
+  ConvArgs a{};
+  int rc = fill_common(a, nlev, N, C, K, R, S, stride, pad, dil);
+  if (rc) return rc;
+  for (int l = 0; l < nlev; ++l) {
+    const int Ho = out_size(H[l], pad, dil, R, stride), Wo = out_size(W[l], pad, dil, S, stride);
+    if (Ho <= 0 || Wo <= 0) return SOD_EARG;
+    rc = fill_level(a, l, x[l], y[l], H[l], W[l], Ho, Wo, 0, y_img_stride, 2);
+    if (rc) return rc;
+    a.lev[l].gn_sum = gn_sums + (size_t)l * N * G * 2;
+  }
+  a.w = w; a.bias = bias;
+  a.gn_G = G;
+  a.flags = (bias ? F_BIAS : 0) | ((flags & SOD_CONV_RELU) ? F_RELU : 0) | F_GNSTATS;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(gn_sums, 0, sizeof(float) * 2 * (size_t)N * G * nlev, st);
+  if (e != hipSuccess) return (int)e;
+  return dispatch_conv<MODE_FWD, false>(a, st);
 }
 
 extern "C" int sod_conv2d_dgrad(const void* dy, const void* wt, const void* accum, const void* relu_mask, void* dx,

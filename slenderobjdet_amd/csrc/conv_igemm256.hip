@@ -240,12 +240,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
       bv[e] = b[0]; bv[e + 1] = b[1]; bv[e + 2] = b[2]; bv[e + 3] = b[3];
     }
   }
+  GnAcc ga{0.f, 0.f, -1};
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) {
     // residual / mask operands of the 16 pixel rows are requested before the accumulators go through LDS (one exposed latency)
     RV resv[NP], maskv[NP];
     size_t drow[NP];
     bool ok[NP];
+    int nimg[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const uint32_t p = (uint32_t)(p0 + wc * 64 + jj * 16 + k * ERPP + erow);
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
       if (ok[k]) {
         const uint32_t n = fd_div(p, g.div_hw);
         const uint32_t rem = p - n * g.div_hw.d;
+        nimg[k] = (int)n;
         drow[k] = (size_t)n * g.dst_img_stride + (size_t)rem * Nout;
         if (a.flags & (F_RES | F_RES_UP2)) {
           size_t res_row;
@@ -305,9 +308,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
           *reinterpret_cast<bf16x8_t*>((__bf16*)g.dst + drow[k] + q) = o;
+          if constexpr (MODE == MODE_FWD) { if (a.flags & F_GNSTATS) gn_acc_add(ga, nimg[k], o, g.gn_sum, a.gn_G, q >> 3); }
         }
       }
     }
+  }
+  if constexpr (!OUT_F32 && MODE == MODE_FWD) {
+    if (a.flags & F_GNSTATS)
+      gn_acc_finish<LPR>(ga, (uint32_t)(p0 + wc * 64), (uint32_t)(p0 + wc * 64 + 63), (uint32_t)gP, g.div_hw, g.gn_sum, a.gn_G, q >> 3, qok, lane);
   }
 }
 

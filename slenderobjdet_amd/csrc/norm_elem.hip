@@ -759,6 +759,24 @@ extern "C" int sod_groupnorm_fwd_ml(int nlev, const void* const* x, const float*
   return SOD_OK;
 }
 
+extern "C" int sod_groupnorm_apply_ml(int nlev, const void* const* x, const float* gamma, const float* beta, void* const* y, float* sums_to_mean_rstd,
+                                      int N, const int* hw, int C, int G, float eps, int relu, void* stream) {
+  if (!x || !gamma || !beta || !y || !sums_to_mean_rstd) return SOD_EARG;
+  GnML m{};
+  const int gx = gn_fill(m, nlev, hw, N, C, G, eps, relu, nullptr);
+  if (gx <= 0) return gx ? gx : SOD_EARG;
+  m.gamma = gamma; m.beta = beta;
+  for (int l = 0; l < nlev; ++l) {
+    if (!x[l] || !y[l]) return SOD_EARG;
+    m.lev[l].x = (const __bf16*)x[l]; m.lev[l].y = (__bf16*)y[l]; m.lev[l].stats = sums_to_mean_rstd + (size_t)l * N * G * 2;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  SOD_LAUNCH(gn_finalize_stats_kernel, dim3((N * G + 255) / 256, nlev), dim3(256), 0, st, m);
+  SOD_LAUNCH(gn_apply_kernel, dim3(gx, N), dim3(256), 0, st, m);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
 extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void* const* x, const float* gamma, const float* beta,
                                     const float* mean_rstd, void* const* dx, float* dgamma, float* dbeta, float* dxsum,
                                     float* red_ws /* 2*N*G*nlev floats */, int N, const int* hw, int C, int G, int relu,

@@ -246,6 +246,32 @@ def conv2d_fwd_ml(xs, w, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=
     return outs
 
 
+def conv_gn_fwd_ml(xs, w, bias, gamma, beta, G, eps=1e-5, relu=True, pad=1):
+    """[conv (stride 1, bias) -> GroupNorm(G) -> ReLU] over several levels that share the weights, with the norm's statistics gathered
+    in the conv epilogue (sod_conv2d_fwd_ml_gnsum) instead of a separate pass over the conv output.  Returns (conv outputs, norm
+    outputs, stats (nl,N,G,2) = mean / rstd)."""
+    _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias"); _chk(gamma, torch.float32, "gamma"); _chk(beta, torch.float32, "beta")
+    for x in xs:
+        _chk(x, torch.bfloat16, "x")
+    N, C = xs[0].shape[0], xs[0].shape[3]
+    K, R, S, Cw = w.shape
+    if Cw != C or K != 8 * G:
+        raise _C.SlenderHipError("conv_gn_fwd_ml: needs matching channels and 8 channels per group")
+    hs, ws = [x.shape[1] for x in xs], [x.shape[2] for x in xs]
+    outs = [torch.empty((N,) + conv_out_size(h, wd, R, S, 1, pad, 1) + (K,), dtype=torch.bfloat16, device=xs[0].device) for h, wd in zip(hs, ws)]
+    stats = torch.empty((len(xs), N, G, 2), dtype=torch.float32, device=xs[0].device)
+    e0 = _prof_begin(None, "conv_fwd")
+    call("sod_conv2d_fwd_ml_gnsum", len(xs), _ptr_arr(xs), ptr(w), ptr(bias), _ptr_arr(outs), N, _int_arr(hs), _int_arr(ws), C, K, R, S,
+         1, pad, 1, 0, 0, ptr(stats), G, stream_ptr())
+    fl = sum(2.0 * N * o.shape[1] * o.shape[2] * K * R * S * C for o in outs)
+    _prof_end("conv_fwd", fl, e0, ("ml", N, tuple(hs), C, K, R, 1))
+    ys = [torch.empty_like(o) for o in outs]
+    hw = [o.shape[1] * o.shape[2] for o in outs]
+    call("sod_groupnorm_apply_ml", len(outs), _ptr_arr(outs), ptr(gamma), ptr(beta), _ptr_arr(ys), ptr(stats), N, ctypes.cast(_int_arr(hw), ctypes.c_void_p),
+         K, G, eps, 1 if relu else 0, stream_ptr())
+    return outs, ys, stats
+
+
 def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=None, k_real=None):
     """dys: per-level dY tensors (or 1-D views into a concatenated buffer with dy_img_stride); returns per-level dX."""
     _chk(wt, torch.bfloat16, "wt")

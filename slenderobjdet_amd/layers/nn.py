@@ -51,6 +51,8 @@ class DeferSlot:
 
 import os as _os
 
+# SOD_GN_EPILOGUE_STATS=0: the GroupNorm statistics of the tower units come from their own pass over the conv output
+GN_EPILOGUE_STATS = _os.environ.get("SOD_GN_EPILOGUE_STATS", "1") != "0"
 # SOD_DEFER_LATERAL=0: the FPN lateral convs run their own data gradient and autograd sums it with the next stage's (see DeferSlot)
 DEFER_LATERAL_DGRAD = _os.environ.get("SOD_DEFER_LATERAL", "1") != "0"
 
@@ -262,9 +264,14 @@ class _ConvGnReluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, unit, *xs):
         conv, gn = unit.conv, unit.gn
-        y1s = HF.conv2d_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, 1, 1, 1)
         gw, gb = gn.weight.detach(), gn.bias.detach()
-        y2s, stats = HF.groupnorm_fwd_ml(y1s, gw, gb, gn.num_groups, gn.eps, relu=True)      # all levels in one launch per pass
+        if (GN_EPILOGUE_STATS and not HF.DETERMINISTIC and conv.out_channels == 8 * gn.num_groups and conv.bias_eff is not None
+                and conv.kernel_size == 3 and conv.stride == 1 and conv.padding == 1 and conv.dilation == 1):
+            # the norm's statistics are gathered in the conv epilogue (float atomics: not for the deterministic mode)
+            y1s, y2s, stats = HF.conv_gn_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, gw, gb, gn.num_groups, gn.eps, relu=True)
+        else:
+            y1s = HF.conv2d_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, 1, 1, 1)
+            y2s, stats = HF.groupnorm_fwd_ml(y1s, gw, gb, gn.num_groups, gn.eps, relu=True)      # all levels in one launch per pass
         ctx.unit, ctx.nl = unit, len(xs)
         ctx.save_for_backward(*xs, *y1s, stats)
         arena = _arena_of(conv)

@@ -431,3 +431,40 @@ def test_conv_prof_event_pairs(cuda):
     assert all(0.0 < ms[i] < 50.0 for i in range(2)) and mode[0] == 0 and mode[1] == 0 and frac[0] == 1.0
     assert var[0] // 100000 == 128 and var[1] // 100000 == 16          # BQ of the two tile variants
     assert _C.load().sod_conv_prof_collect(ms, var, frac, mode, 8) == 0   # cleared
+
+
+def test_conv_epilogue_groupnorm_statistics(cuda):
+    """sod_conv2d_fwd_ml_gnsum + sod_groupnorm_apply_ml (GroupNorm statistics gathered in the conv epilogue, both the 256x256 and the
+    128x128 kernel, levels whose 64-pixel wave ranges straddle image boundaries) against conv -> separate GroupNorm passes: the same
+    conv output bit for bit, mean / rstd to fp32 summation-order accuracy, the normalised output to one bf16 ulp; and against the
+    oracle (F.conv2d + F.group_norm on the bf16-rounded conv output)."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, C, G = 3, 256, 32
+    hw = [(23, 37), (12, 19), (6, 10), (3, 5)]           # 851 / 228 / 60 / 15 pixels per image: none a multiple of 64
+    xs = [_rand((N, h, w, C), 20 + i) for i, (h, w) in enumerate(hw)]
+    w = _rand((C, 3, 3, C), 31, scale=(9 * C) ** -0.5)
+    bias = torch.randn(C, generator=torch.Generator().manual_seed(32)) * 0.5
+    gamma = torch.rand(C, generator=torch.Generator().manual_seed(33)) + 0.5
+    beta = torch.randn(C, generator=torch.Generator().manual_seed(34)) * 0.2
+    d = lambda t: t.to(cuda).to(torch.bfloat16).contiguous()
+    f = lambda t: t.to(cuda).contiguous()
+    xd, wd = [d(x) for x in xs], d(w)
+    for tile256 in (1, 0):
+        HF.call("sod_conv_set_tile256", 2 if tile256 else 0)
+        try:
+            y1, y2, st = HF.conv_gn_fwd_ml(xd, wd, f(bias), f(gamma), f(beta), G, relu=True)
+            r1 = HF.conv2d_fwd_ml(xd, wd, f(bias), 1, 1, 1)
+        finally:
+            HF.call("sod_conv_set_tile256", 1)
+        r2, rst = HF.groupnorm_fwd_ml(r1, f(gamma), f(beta), G, relu=True)
+        for l in range(len(hw)):
+            assert torch.equal(y1[l], r1[l]), (tile256, l)
+            # mean to 1e-5 of the value scale, rstd to 1e-5 relative (different summation order of the same rounded values)
+            scale = r1[l].float().abs().max().item()
+            assert (st[l, :, :, 0] - rst[l, :, :, 0]).abs().max().item() <= 1e-5 * scale + 1e-6, (tile256, l)
+            assert ((st[l, :, :, 1] - rst[l, :, :, 1]).abs() / rst[l, :, :, 1]).max().item() <= 2e-5, (tile256, l)
+            dd = (y2[l].float() - r2[l].float()).abs().max().item()
+            assert dd <= 2 ** -7 * max(r2[l].float().abs().max().item(), 1e-6), (tile256, l, dd)
+            ref = onn.group_norm(onn.rb(onn.conv2d(xs[l], w, bias, pad=1)), gamma, beta, G, relu=True)
+            _close(y2[l], ref, 2 ** -6, f"conv+gn level {l} tile256={tile256}")
