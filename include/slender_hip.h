@@ -74,6 +74,15 @@ int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const float* qsca
                      long long dy_img_stride, long long x_img_stride, int splits, int flags,
                      void* ws, long long ws_bytes, void* stream);
 
+/* 1-bit ReLU masks for the bottleneck backward (detectron2 BottleneckBlock: out = relu(conv3 + shortcut), whose mask the backward
+ * pass of the NEXT block's first conv applies to d(out)): sod_conv2d_fwd_bits is sod_conv2d_fwd with dense bf16 output that also
+ * writes bit i of relu_bits (uint8[N*Ho*Wo*K/8], bit e of byte j = element 8j+e) = "stored y[i] > 0"; sod_conv2d_dgrad_bits is
+ * sod_conv2d_dgrad whose mask operand is such a bit array of dx's shape (1/16 of the bytes of the bf16 tensor it replaces). */
+int sod_conv2d_fwd_bits(const void* x, const void* w, const float* bias, const void* res, void* y, void* relu_bits,
+                        int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int flags, void* stream);
+int sod_conv2d_dgrad_bits(const void* dy, const void* wt, const void* accum, const void* relu_bits, void* dx,
+                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, void* stream);
+
 /* Multi-level forms: ONE launch applies the same weights to `nlev` tensors (the FPN levels the FCOS towers and
  * prediction convs share, fcosv2.py:358-380 loops over them). x/y/dy/dx are HOST arrays of device pointers, H/W host
  * arrays of the per-level input sizes. y_img_stride / dy_img_stride (elements, <=0: dense per level) is common to all

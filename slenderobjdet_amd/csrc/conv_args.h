@@ -9,6 +9,8 @@ namespace sodconv {
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 enum {
   F_BIAS = 1, F_RELU = 2, F_RES = 4, F_RES_UP2 = 8, F_MASK = 16,
+  F_WBITS = 64,        // bf16 forward output: bit (dst element index) of LevelGeo::bits = stored value > 0 (1-bit ReLU mask for backward)
+  F_MASKBITS = 128,    // like F_MASK, but LevelGeo::mask is such a bit array (1/16 of the bytes of the bf16 tensor)
   F_GNSTATS = 32,      // bf16 forward output: per-(image, 8-channel group) sum / sum of squares of the stored values -> LevelGeo::gn_sum
 };
 constexpr int MAXLEV = SOD_CONV_MAX_LEVELS;
@@ -20,6 +22,7 @@ struct LevelGeo {
   void* dst;           // (N,Hp,Wp,Nout) rows at dst_img_stride
   const void* res;     // bf16, indexed like dst (or half-resolution with F_RES_UP2)
   const void* mask;    // bf16, indexed like dst: dst = mask>0 ? v : 0 (ReLU backward)
+  void* bits;          // F_WBITS: uint8 [N * dst_img_stride / 8]
   float* gn_sum;       // F_GNSTATS: [N][gn_G][2] running (sum, sum of squares), accumulated with float atomics
   uint32_t src_bytes;
   int Hs, Ws, Hp, Wp, P;

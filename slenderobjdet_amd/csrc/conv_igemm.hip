@@ -340,6 +340,7 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
       size_t drow[NP];
       bool ok[NP];
       int nimg[NP];
+      uint32_t mbits[NP];
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         const int row = k * ERPP + erow;
@@ -363,6 +364,9 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
             resv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.res + res_row + q);
           }
           if (a.flags & F_MASK) maskv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.mask + drow[k] + q);
+          if constexpr (MODE == MODE_DGRAD && !OUT_F32) {
+            if (a.flags & F_MASKBITS) mbits[k] = ((const uint8_t*)g.mask)[(drow[k] + q) >> 3];
+          }
         }
       }
 #pragma unroll
@@ -396,6 +400,12 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
 #pragma unroll
             for (int e = 0; e < EPL; ++e) v[e] = ((float)maskv[k][e] > 0.f) ? v[e] : 0.f;
           }
+          if constexpr (MODE == MODE_DGRAD && !OUT_F32) {
+            if (a.flags & F_MASKBITS) {
+#pragma unroll
+              for (int e = 0; e < EPL; ++e) v[e] = ((mbits[k] >> e) & 1u) ? v[e] : 0.f;
+            }
+          }
           if constexpr (OUT_F32) {
             *reinterpret_cast<f32x4_t*>((float*)g.dst + drow[k] + q) = f32x4_t{v[0], v[1], v[2], v[3]};
           } else {
@@ -403,6 +413,14 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
             *reinterpret_cast<bf16x8_t*>((__bf16*)g.dst + drow[k] + q) = o;
+            if constexpr (MODE == MODE_FWD) {
+              if (a.flags & F_WBITS) {
+                uint32_t b = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b |= ((float)o[e] > 0.f ? 1u : 0u) << e;
+                ((uint8_t*)g.bits)[(drow[k] + q) >> 3] = (uint8_t)b;
+              }
+            }
             if constexpr (MODE == MODE_FWD) { if (a.flags & F_GNSTATS) gn_acc_add(ga, nimg[k], o, g.gn_sum, a.gn_G, q >> 3); }
           }
         }
@@ -828,7 +846,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   // a CU (490 vs 487.5 img/s in favour of 128x128); with two ring workgroups per CU and the faster wgrad it wins 542.4 vs 536.0.
   static int c256_dgrad = -1;
   if (c256_dgrad < 0) { const char* e = getenv("SOD_CONV256_DGRAD"); c256_dgrad = e ? atoi(e) : 1; }
-  if (c256 && !any_start && conv256_supported(a, MODE) && (MODE == MODE_FWD || c256_dgrad || c256 == 2)) {
+  if (c256 && !any_start && !(a.flags & (F_WBITS | F_MASKBITS)) && conv256_supported(a, MODE) && (MODE == MODE_FWD || c256_dgrad || c256 == 2)) {
     const int nq = (a.Nout + 255) / 256;
     long long pt256 = 0;
     for (int l = 0; l < a.nlev; ++l) pt256 += (a.lev[l].P + 255) / 256;
@@ -1083,11 +1101,12 @@ int fill_wlevel(WgradArgs& a, int l, const void* dy, const void* x, int H, int W
 
 }  // namespace
 
-extern "C" int sod_conv2d_fwd(const void* x, const void* w, const float* bias, const void* res, void* y,
-                              int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
-                              long long x_img_stride, long long y_img_stride, long long res_img_stride,
-                              int flags, int out_f32, void* stream) {
+static int conv2d_fwd_impl(const void* x, const void* w, const float* bias, const void* res, void* y, void* relu_bits,
+                           int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                           long long x_img_stride, long long y_img_stride, long long res_img_stride,
+                           int flags, int out_f32, void* stream) {
   if (!x || !w || !y) return SOD_EARG;
+  if (relu_bits && (out_f32 || (K & 7) || y_img_stride > 0)) return SOD_EARG;      // bits follow the dense bf16 output
   const int Ho = out_size(H, pad, dil, R, stride), Wo = out_size(W, pad, dil, S, stride);
   if (Ho <= 0 || Wo <= 0) return SOD_EARG;
   ConvArgs a{};
@@ -1110,8 +1129,23 @@ extern "C" int sod_conv2d_fwd(const void* x, const void* w, const float* bias, c
       a.lev[0].res_img_stride = (int)(res_img_stride > 0 ? res_img_stride : a.lev[0].dst_img_stride);
     }
   }
+  if (relu_bits) { a.flags |= F_WBITS; a.lev[0].bits = relu_bits; }
   hipStream_t st = (hipStream_t)stream;
   return out_f32 ? dispatch_conv<MODE_FWD, true>(a, st) : dispatch_conv<MODE_FWD, false>(a, st);
+}
+
+extern "C" int sod_conv2d_fwd(const void* x, const void* w, const float* bias, const void* res, void* y,
+                              int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                              long long x_img_stride, long long y_img_stride, long long res_img_stride,
+                              int flags, int out_f32, void* stream) {
+  return conv2d_fwd_impl(x, w, bias, res, y, nullptr, N, H, W, C, K, R, S, stride, pad, dil, x_img_stride, y_img_stride, res_img_stride, flags,
+                         out_f32, stream);
+}
+
+extern "C" int sod_conv2d_fwd_bits(const void* x, const void* w, const float* bias, const void* res, void* y, void* relu_bits,
+                                   int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int flags, void* stream) {
+  if (!relu_bits) return SOD_EARG;
+  return conv2d_fwd_impl(x, w, bias, res, y, relu_bits, N, H, W, C, K, R, S, stride, pad, dil, 0, 0, 0, flags, 0, stream);
 }
 
 extern "C" int sod_conv2d_fwd_ml(int nlev, const void* const* x, const void* w, const float* bias, void* const* y,
@@ -1173,6 +1207,23 @@ extern "C" int sod_conv2d_dgrad(const void* dy, const void* wt, const void* accu
   a.flags = 0;
   if (accum) { a.flags |= F_RES; a.lev[0].res = accum; a.lev[0].res_img_stride = a.lev[0].dst_img_stride; }
   if (relu_mask) { a.flags |= F_MASK; a.lev[0].mask = relu_mask; }
+  return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
+}
+
+extern "C" int sod_conv2d_dgrad_bits(const void* dy, const void* wt, const void* accum, const void* relu_bits, void* dx,
+                                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, void* stream) {
+  if (!dy || !wt || !dx || !relu_bits || (C & 7)) return SOD_EARG;
+  const int Ho = out_size(H, pad, dil, R, stride), Wo = out_size(W, pad, dil, S, stride);
+  if (Ho <= 0 || Wo <= 0) return SOD_EARG;
+  ConvArgs a{};
+  int rc = fill_common(a, 1, N, K, C, R, S, stride, pad, dil);
+  if (rc) return rc;
+  rc = fill_level(a, 0, dy, dx, Ho, Wo, H, W, 0, 0, 2);
+  if (rc) return rc;
+  a.w = wt; a.bias = nullptr;
+  a.flags = F_MASKBITS;
+  a.lev[0].mask = relu_bits;
+  if (accum) { a.flags |= F_RES; a.lev[0].res = accum; a.lev[0].res_img_stride = a.lev[0].dst_img_stride; }
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 

@@ -150,7 +150,7 @@ def conv_out_size(H, W, R, S, stride, pad, dil):
 
 
 def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, res_up2=False, out_f32=False,
-               out=None, y_img_stride=0, x_img_stride=0, x_shape=None, c_real=None):
+               out=None, y_img_stride=0, x_img_stride=0, x_shape=None, c_real=None, relu_bits=None):
     """x (N,H,W,C) bf16, w (K,R,S,C) bf16 -> y (N,Ho,Wo,K). ``out``/``y_img_stride`` let the result land inside a
     larger (N, L, K) buffer; ``x_shape`` overrides (N,H,W,C) when x is such a view."""
     _chk(x, torch.bfloat16, "x"); _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias"); _chk(res, torch.bfloat16, "res")
@@ -163,14 +163,21 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
         out = torch.empty((N, Ho, Wo, K), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     flags = (CONV_RELU if relu else 0) | (CONV_RES_UP2 if res_up2 else 0)
     e0 = _prof_begin(None, "conv_fwd")
-    call("sod_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
-         x_img_stride, y_img_stride, 0, flags, 1 if out_f32 else 0, stream_ptr())
+    if relu_bits is not None:       # also records "stored output > 0" as one bit per element (uint8[numel / 8]) for the backward pass
+        _chk(relu_bits, torch.uint8, "relu_bits")
+        if out_f32 or res_up2 or x_img_stride or y_img_stride or relu_bits.numel() * 8 != out.numel():
+            raise _C.SlenderHipError("conv2d_fwd: relu_bits needs a dense bf16 output of 8 * relu_bits.numel() elements")
+        call("sod_conv2d_fwd_bits", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), ptr(relu_bits), N, H, W, C, K, R, S, stride, pad, dil, flags,
+             stream_ptr())
+    else:
+        call("sod_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
+             x_img_stride, y_img_stride, 0, flags, 1 if out_f32 else 0, stream_ptr())
     # c_real / k_real: un-padded channel counts, so that the profile counts ALGORITHMIC work (stem: 3 of its 8 input channels)
     _prof_end("conv_fwd", 2.0 * N * Ho * Wo * K * R * S * (c_real or C), e0, (N, H, W, C, K, R, stride))
     return out
 
 
-def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=None, dy_img_stride=0, dy_shape=None, out=None):
+def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=None, dy_img_stride=0, dy_shape=None, out=None, relu_bits=None):
     """dy (N,Ho,Wo,K) bf16, wt (C,R,S,K) bf16 (transposed weights) -> dx (N,H,W,C) bf16."""
     _chk(dy, torch.bfloat16, "dy"); _chk(wt, torch.bfloat16, "wt"); _chk(accum, torch.bfloat16, "accum"); _chk(relu_mask, torch.bfloat16, "relu_mask")
     N = dy_shape[0] if dy_shape is not None else dy.shape[0]
@@ -179,8 +186,14 @@ def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=Non
     if out is None:
         out = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=dy.device)
     e0 = _prof_begin(None, "conv_dgrad")
-    call("sod_conv2d_dgrad", ptr(dy), ptr(wt), ptr(accum), ptr(relu_mask), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
-         dy_img_stride, 0, stream_ptr())
+    if relu_bits is not None:       # the ReLU mask of dx's tensor as one bit per element (conv2d_fwd(..., relu_bits=...))
+        _chk(relu_bits, torch.uint8, "relu_bits")
+        if relu_mask is not None or dy_img_stride or relu_bits.numel() * 8 != out.numel():
+            raise _C.SlenderHipError("conv2d_dgrad: relu_bits replaces relu_mask and needs 8 * relu_bits.numel() == dx.numel()")
+        call("sod_conv2d_dgrad_bits", ptr(dy), ptr(wt), ptr(accum), ptr(relu_bits), ptr(out), N, H, W, C, K, R, S, stride, pad, dil, stream_ptr())
+    else:
+        call("sod_conv2d_dgrad", ptr(dy), ptr(wt), ptr(accum), ptr(relu_mask), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
+             dy_img_stride, 0, stream_ptr())
     Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
     _prof_end("conv_dgrad", 2.0 * N * Ho * Wo * K * R * S * C, e0, (N, H, W, C, K, R, stride))
     return out

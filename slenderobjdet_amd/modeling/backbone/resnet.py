@@ -19,6 +19,9 @@ from ..shape_spec import ShapeSpec
 STEM_FUSED = os.environ.get("SOD_STEM_FUSED", "1") != "0"
 # frozen 64 -> 256 bottleneck blocks (res2 under FREEZE_AT >= 2) as one kernel each (csrc/bottleneck_fused.hip)
 BNECK_FUSED = os.environ.get("SOD_BNECK_FUSED", "1") != "0"
+# ReLU masks of the block outputs of a trainable bottleneck stage as 1 bit per element, written by the conv3 epilogue and read by the
+# data gradient that folds the mask in (1/16 of the bytes of re-reading the bf16 block output); SOD_RELU_BITS=0 re-reads the tensor
+RELU_BITS = os.environ.get("SOD_RELU_BITS", "1") != "0"
 from .build import BACKBONE_REGISTRY, Backbone
 
 
@@ -75,7 +78,9 @@ class _BottleneckStageFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, stage):
         blocks = list(stage)
-        saved = [x]
+        saved, bits = [x], []
+        train = blocks[0].conv1.weight.requires_grad
+        need_bwd = train or x.requires_grad
         for blk in blocks:
             for m in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut):
                 if m is not None:
@@ -84,13 +89,21 @@ class _BottleneckStageFn(torch.autograd.Function):
             sc = _conv(blk.shortcut, xin) if blk.shortcut is not None else xin
             a = _conv(blk.conv1, xin)
             b = _conv(blk.conv2, a)
-            out = _conv(blk.conv3, b, res=sc)
+            c3 = blk.conv3
+            if need_bwd and RELU_BITS and c3.relu and c3.out_channels % 8 == 0:
+                N, Hb, Wb, _ = b.shape
+                Ho, Wo = HF.conv_out_size(Hb, Wb, c3.kernel_size, c3.kernel_size, c3.stride, c3.padding, c3.dilation)
+                bt = torch.empty(N * Ho * Wo * c3.out_channels // 8, dtype=torch.uint8, device=b.device)
+                out = HF.conv2d_fwd(b, c3.w_bf16, c3.bias_eff, sc, c3.stride, c3.padding, c3.dilation, relu=True, relu_bits=bt)
+                bits.append(bt)
+            else:
+                out = _conv(c3, b, res=sc)
             saved += [a, b, out]
         ctx.stage = stage
         ctx.slot = None
-        train = blocks[0].conv1.weight.requires_grad
-        if train or x.requires_grad:
-            ctx.save_for_backward(*saved)
+        ctx.nbits = len(bits) if len(bits) == len(blocks) else 0
+        if need_bwd:
+            ctx.save_for_backward(*saved, *(bits if ctx.nbits else []))
             ctx.set_materialize_grads(False)
             ctx.slot = DeferSlot.offer(saved[-1])      # an FPN lateral conv on this output may leave its data gradient to us
             arena = _arena_of(blocks[0].conv1)
@@ -106,13 +119,20 @@ class _BottleneckStageFn(torch.autograd.Function):
     def backward(ctx, dout):
         blocks = list(ctx.stage)
         saved = ctx.saved_tensors
+        bits = None
+        if ctx.nbits:
+            saved, bits = saved[:-ctx.nbits], saved[-ctx.nbits:]
+
+        def mask_of(k):      # ReLU mask of block k's output: its bit array if the forward pass recorded one, else the tensor itself
+            return dict(relu_bits=bits[k]) if bits is not None else dict(relu_mask=saved[3 * k + 3])
+
         arena = _arena_of(blocks[0].conv1)
         slot, ctx.slot = ctx.slot, None
         if slot is not None and slot.g is not None:
             # d(out) = dgrad(lateral 1x1, its output gradient) + the other consumers' gradient, times the ReLU mask of out: one launch
             lat = slot.mod
             g = HF.conv2d_dgrad(slot.g, lat.wt_bf16, (saved[-1].shape[1], saved[-1].shape[2]), 1, 0, 1,
-                                accum=None if dout is None else dout.contiguous(), relu_mask=saved[-1])
+                                accum=None if dout is None else dout.contiguous(), **mask_of(len(blocks) - 1))
             slot.g = slot.mod = None
         elif dout is None:
             return None, None, None
@@ -138,9 +158,9 @@ class _BottleneckStageFn(torch.autograd.Function):
                         dx = _dgrad(blk.conv1, da, xin, accum=g)
             else:   # previous block's output is post-ReLU: fold its mask and the identity-path gradient into the epilogue
                 if blk.shortcut is not None:
-                    g = _dgrad(blk.shortcut, g, xin, accum=_dgrad(blk.conv1, da, xin), relu_mask=xin)
+                    g = _dgrad(blk.shortcut, g, xin, accum=_dgrad(blk.conv1, da, xin), **mask_of(k - 1))
                 else:
-                    g = _dgrad(blk.conv1, da, xin, accum=g, relu_mask=xin)
+                    g = _dgrad(blk.conv1, da, xin, accum=g, **mask_of(k - 1))
         return dx, None, None
 
 
@@ -154,8 +174,9 @@ def _wgrad(m, g, x, arena):
         arena.mark_ready(m.weight)
 
 
-def _dgrad(m, g, x, accum=None, relu_mask=None):
-    return HF.conv2d_dgrad(g, m.wt_bf16, (x.shape[1], x.shape[2]), m.stride, m.padding, m.dilation, accum=accum, relu_mask=relu_mask)
+def _dgrad(m, g, x, accum=None, relu_mask=None, relu_bits=None):
+    return HF.conv2d_dgrad(g, m.wt_bf16, (x.shape[1], x.shape[2]), m.stride, m.padding, m.dilation, accum=accum, relu_mask=relu_mask,
+                           relu_bits=relu_bits)
 
 
 def _dgrad_pair_into_input(blk, g, da, xin):

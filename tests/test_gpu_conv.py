@@ -468,3 +468,31 @@ def test_conv_epilogue_groupnorm_statistics(cuda):
             assert dd <= 2 ** -7 * max(r2[l].float().abs().max().item(), 1e-6), (tile256, l, dd)
             ref = onn.group_norm(onn.rb(onn.conv2d(xs[l], w, bias, pad=1)), gamma, beta, G, relu=True)
             _close(y2[l], ref, 2 ** -6, f"conv+gn level {l} tile256={tile256}")
+
+
+def test_relu_bit_masks_match_tensor_masks(cuda):
+    """sod_conv2d_fwd_bits records "stored output > 0" as one bit per element; sod_conv2d_dgrad_bits applies it.  The forward output
+    is bit-identical to sod_conv2d_fwd's, the bits equal (y > 0) packed little-endian per 8 channels, and the data gradient with the
+    bit mask (+ accumulate) is bit-identical to the one that re-reads the bf16 tensor as its mask."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K = 2, 19, 27, 128, 512
+    x, w = _rand((N, H, W, C), 41), _rand((K, 1, 1, C), 42, scale=C ** -0.5)
+    res = _rand((N, H, W, K), 43)
+    bias = torch.randn(K, generator=torch.Generator().manual_seed(44)) * 0.1
+    d = lambda t: t.to(cuda).to(torch.bfloat16).contiguous()
+    bits = torch.zeros(N * H * W * K // 8, dtype=torch.uint8, device=cuda)
+    y = HF.conv2d_fwd(d(x), d(w), bias.to(cuda), d(res), relu=True, relu_bits=bits)
+    y0 = HF.conv2d_fwd(d(x), d(w), bias.to(cuda), d(res), relu=True)
+    assert torch.equal(y, y0)
+    want = ((y.reshape(-1, 8) > 0).to(torch.int32) << torch.arange(8, device=cuda, dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(bits, want)
+    assert 0.2 < (y > 0).float().mean().item() < 0.8
+    # data gradient of a 1x1 conv K -> C' whose input is y: dx = mask(y) * (dy W + accum)
+    Cp = 128
+    dy, wt = _rand((N, H, W, Cp), 45), _rand((K, 1, 1, Cp), 46, scale=Cp ** -0.5)
+    accum = _rand((N, H, W, K), 47)
+    a = HF.conv2d_dgrad(d(dy), d(wt), (H, W), accum=d(accum), relu_bits=bits)
+    b = HF.conv2d_dgrad(d(dy), d(wt), (H, W), accum=d(accum), relu_mask=y)
+    assert torch.equal(a, b)
+    assert (a != 0).any()

@@ -466,7 +466,7 @@ def test_deferred_lateral_dgrad_matches_separate_passes(cuda):
     orig = HF.conv2d_dgrad
 
     def counting(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=None, **kw):
-        if relu_mask is not None and wt.data_ptr() in lateral_ptrs:
+        if (relu_mask is not None or kw.get("relu_bits") is not None) and wt.data_ptr() in lateral_ptrs:
             calls["fused"] += 1
         return orig(dy, wt, x_hw, stride, pad, dil, accum=accum, relu_mask=relu_mask, **kw)
 
@@ -498,4 +498,32 @@ def test_deferred_lateral_dgrad_matches_separate_passes(cuda):
     finally:
         HF.conv2d_dgrad = orig
         HN.DEFER_LATERAL_DGRAD = True
+        HF.DETERMINISTIC = prev
+
+
+def test_relu_bit_masks_leave_the_step_bit_identical(cuda):
+    """Trainable bottleneck stages record their block-output ReLU masks as bit arrays (resnet.RELU_BITS) instead of re-reading the bf16
+    block outputs in backward: losses and every gradient are bit-identical (deterministic mode) with and without."""
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.modeling.backbone import resnet
+
+    cfg, model, opt = _build(50, seed=6)
+    data = synthetic_batch(2, 320, 384, 11, device="cuda")
+    prev, HF.DETERMINISTIC = HF.DETERMINISTIC, True
+    try:
+        def step(on):
+            resnet.RELU_BITS = on
+            opt.zero_grad()
+            out = model(data)
+            total = sum(out.values())
+            model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+            return {k: float(v.detach()) for k, v in out.items()}, model.arena.grads.clone()
+
+        ref_l, ref_g = step(False)
+        got_l, got_g = step(True)
+        assert got_l == ref_l
+        assert torch.equal(got_g, ref_g)
+    finally:
+        resnet.RELU_BITS = True
         HF.DETERMINISTIC = prev
