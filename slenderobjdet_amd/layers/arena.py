@@ -186,10 +186,10 @@ class ParamArena:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             from . import functional as HF
-            side = HF.wgrad_side_stream(self.device)
+            sides = HF.wgrad_side_streams(self.device)
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
-                if side is not None:        # weight gradients of this bucket were enqueued on the wgrad side stream
+                for side in sides:          # weight gradients of this bucket were enqueued on the wgrad side stream(s)
                     self._comm_stream.wait_stream(side)
                 for aux in HF.aux_compute_streams(self.device):   # a bucket may mix parameters whose backward nodes ran on different
                     self._comm_stream.wait_stream(aux)            # streams (the FCOS box tower has its own)

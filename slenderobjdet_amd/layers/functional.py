@@ -70,16 +70,23 @@ def aux_compute_streams(device):
     return list(_aux_streams.get(device.index, ()))
 
 
-def wgrad_side_stream(device):
-    """The side stream of ``device`` if wgrad work may be pending on it in this backward pass, else None."""
-    return _side_streams.get(device.index) if _side_join_queued else None
+# SOD_WGRAD_STREAMS=n: round-robin over n side streams (independent weight gradients may then overlap each other, which shortens the
+# tail of backward where only weight gradients are left); 1 = a single in-order side stream
+WGRAD_NSTREAMS = max(1, int(os.environ.get("SOD_WGRAD_STREAMS", "1")))
+_side_rr = 0
+
+
+def wgrad_side_streams(device):
+    """The side streams of ``device`` on which wgrad work may be pending in this backward pass (empty list if none)."""
+    return list(_side_streams.get(device.index, ())) if _side_join_queued else []
 
 
 def _wgrad_join():
     global _side_join_queued
     _side_join_queued = False
-    for idx, side in _side_streams.items():
-        torch.cuda.current_stream(idx).wait_stream(side)
+    for idx, sides in _side_streams.items():
+        for side in sides:
+            torch.cuda.current_stream(idx).wait_stream(side)
     _side_keep.clear()      # the main stream now waits for every side-stream reader: the operands may go back to its pool
 
 
@@ -91,9 +98,13 @@ def wgrad_join():
         _wgrad_join()
 
 
-def _wgrad_stream(device, tensors):
-    """Returns the stream to launch a wgrad on (None = current stream)."""
-    global _side_join_queued
+_side_of_key = {}
+
+
+def _wgrad_stream(device, tensors, key=None):
+    """Returns the stream to launch a wgrad on (None = current stream).  ``key`` identifies the gradient buffer: launches that add to
+    the same buffer always use the same stream (the slab / deterministic reductions update it with plain read-modify-writes)."""
+    global _side_join_queued, _side_rr
     if not WGRAD_SIDE_STREAM or device.type != "cuda":
         return None
     if not _side_join_queued:
@@ -102,12 +113,22 @@ def _wgrad_stream(device, tensors):
         except RuntimeError:     # not inside a backward pass (op-level calls): nobody would join, stay on the current stream
             return None
         _side_join_queued = True
-    side = _side_streams.get(device.index)
-    if side is None:
+    sides = _side_streams.get(device.index)
+    if sides is None:
         # lowest HIP stream priority (range on MI355X: 1 .. -1): the data-gradient chain is the critical path.  Measured 491.5-492.3
         # (low) / 491.8 (normal) / 483-484 (high) img/s
         prio = int(os.environ.get("SOD_WGRAD_PRIO", "1"))
-        side = _side_streams[device.index] = torch.cuda.Stream(device=device, priority=prio)
+        sides = _side_streams[device.index] = [torch.cuda.Stream(device=device, priority=prio) for _ in range(WGRAD_NSTREAMS)]
+    if len(sides) == 1:
+        side = sides[0]
+    else:
+        i = _side_of_key.get(key)
+        if i is None:
+            _side_rr = (_side_rr + 1) % len(sides)
+            i = _side_rr
+            if key is not None:
+                _side_of_key[key] = i
+        side = sides[i]
     side.wait_stream(torch.cuda.current_stream(device))
     # The operands (dY, X) must outlive the side-stream kernel.  They are kept referenced until the join instead of
     # Tensor.record_stream(): with record_stream the allocator cannot reuse a block until a GPU-side event has completed, and since the
@@ -224,7 +245,7 @@ def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img
     N, H, W, C = x_shape if x_shape is not None else x.shape
     if K is None:
         K = dy.shape[-1]
-    side = _wgrad_stream(dw.device, (dy, x))
+    side = _wgrad_stream(dw.device, (dy, x), dw.data_ptr())
     ws = wgrad_workspace(dw.device, side)
     e0 = _prof_begin(side, "conv_wgrad")
     call("sod_conv2d_wgrad", ptr(dy), ptr(x), ptr(dw), ptr(qscale), N, H, W, C, K, R, S, stride, pad, dil, dy_img_stride, x_img_stride,
@@ -308,7 +329,7 @@ def conv2d_wgrad_ml(dys, xs, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, 
     if K is None:
         K = dys[0].shape[-1]
     hs, ws_ = [x.shape[1] for x in xs], [x.shape[2] for x in xs]
-    side = _wgrad_stream(dw.device, list(dys) + list(xs))
+    side = _wgrad_stream(dw.device, list(dys) + list(xs), dw.data_ptr())
     ws = wgrad_workspace(dw.device, side)
     e0 = _prof_begin(side, "conv_wgrad")
     call("sod_conv2d_wgrad_ml", len(xs), _ptr_arr(dys), _ptr_arr(xs), ptr(dw), ptr(qscale), N, _int_arr(hs), _int_arr(ws_), C, K, R, S,
@@ -411,7 +432,7 @@ def add_bf16(a, b):
 
 def bias_grad(dy, dbias, N, HW, C, img_stride=0):
     _chk(dy, torch.bfloat16, "dy"); _chk(dbias, torch.float32, "dbias")
-    side = _wgrad_stream(dbias.device, (dy,))      # like the weight gradient: only the optimizer / all-reduce consumes it
+    side = _wgrad_stream(dbias.device, (dy,), dbias.data_ptr())      # like the weight gradient: only the optimizer / all-reduce consumes it
     call("sod_bias_grad", ptr(dy), ptr(dbias), N, HW, C, img_stride, *_det_ws(dbias.device, side), stream_ptr(side))
     return dbias
 
@@ -889,7 +910,7 @@ def deform_conv_wgrad_fused(dy, x, offset, mask, dw, ksize, stride, pad, dil, dg
     K = dy.shape[-1]
     if dw.numel() != K * KH * KW * C:
         raise _C.SlenderHipError("deform_conv_wgrad_fused: dw does not hold K x KH*KW*C elements")
-    side = _wgrad_stream(dw.device, (dy, x, offset, mask))
+    side = _wgrad_stream(dw.device, (dy, x, offset, mask), dw.data_ptr())
     ws = wgrad_workspace(dw.device, side)
     call("sod_deform_conv_wgrad_fused", ptr(dy), ptr(x), ptr(offset), ptr(mask), ptr(dw), N, H, W, C, K, KH, KW, stride, pad, dil, dg, off_ld, mask_ld,
          1 if mask_is_logit else 0, ptr(ws), ws.numel(), stream_ptr(side))
