@@ -253,6 +253,22 @@ def cpu_baseline(model, args):
                       f"fp32 CPU oracle, {dt:.1f} s timed ({time.time() - t0:.1f} s in all); host: {os.cpu_count()} logical CPUs, {cpu}"}
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; the contract of this script is ONE JSON line there.
+    While the process group is created (eager communicator: ``device_id``) and the first collectives run, file descriptor 1 points to
+    stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -297,6 +313,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-prof", type=int, default=0, help="print the N most expensive (kernel, shape) groups to stderr")
+    ap.add_argument("--rccl-rehearsal", action="store_true",
+                    help="--gpus 1 only: create a one-rank RCCL process group and issue every data-parallel collective anyway (parameter "
+                         "broadcast, normaliser all-reduce, bucketed gradient all-reduce) - exercises the real RCCL path on a one-GPU box")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -316,10 +335,22 @@ def main():
         if share:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            with _StdoutToStderr():
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+                dist.barrier()
     else:
         torch.cuda.set_device(0)
+        if args.rccl_rehearsal:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            with _StdoutToStderr():
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+                dist.barrier()
     dev = torch.device("cuda", torch.cuda.current_device())
+    rehearsal = args.rccl_rehearsal and world == 1
+    if rehearsal:
+        from slenderobjdet_amd.utils import comm as _comm
+        _comm.FORCE_COLLECTIVES = True
 
     from slenderobjdet_amd import _C
     from slenderobjdet_amd.data import SyntheticCocoBatches
@@ -333,7 +364,7 @@ def main():
     model.train()
     if args.arch in ("retinanet", "rrcnn") and args.depth >= 50:
         damp_residual_branches(model)
-    if world > 1:   # DDP semantics: identical initial parameters on every rank
+    if world > 1 or rehearsal:   # DDP semantics: identical initial parameters on every rank
         dist.broadcast(model.arena.params, src=0)
         model.arena.bump()
     optimizer = build_optimizer(cfg, model)
@@ -347,7 +378,7 @@ def main():
         nxt = next(loader)
         train_step(model, optimizer, cur, None if (w == args.warmup - 1 and 0 in sample_at) else nxt)
         cur = nxt
-    if world > 1:
+    if world > 1 or rehearsal:
         dist.barrier()
     torch.cuda.synchronize()
     if not args.no_roofline:
@@ -380,7 +411,7 @@ def main():
         cur = nxt
     HF.WGRAD_SIDE_STREAM = side_default
     fcos_mod.TOWER_STREAMS = tower_default
-    if world > 1:
+    if world > 1 or rehearsal:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -407,7 +438,7 @@ def main():
                     filled.append((kind, flops, e0.elapsed_time(e1) * 1e-3, desc, variant))
             prof = filled
         HF.PROFILE_LIB = False
-    if world > 1:
+    if world > 1 or rehearsal:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -426,6 +457,8 @@ def main():
             "config": {"workload": WORKLOADS[args.arch], "global_batch": args.batch_per_gpu * world, "parallelism": f"dp{world}",
                        "final_loss": round(loss_val, 5)},
         }
+        if rehearsal:
+            out["config"]["rccl_rehearsal"] = "one-rank RCCL group, every data-parallel collective issued"
         if args.arch == "fcos" and args.depth == 50:
             out["model_tflops"] = round(imgs * TRAIN_FLOP_PER_IMAGE / dt / 1e12, 2)
         if prof:
@@ -440,7 +473,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.arch == "fcos":
             out["cpu_baseline"] = cpu_baseline(model, args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or rehearsal:
         dist.barrier()
         dist.destroy_process_group()
 

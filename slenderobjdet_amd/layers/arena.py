@@ -156,7 +156,8 @@ class ParamArena:
     def begin_backward(self):
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self._world = world
-        if world <= 1:
+        from ..utils import comm as _comm
+        if world <= 1 and not _comm.collectives_active():
             self._uses.clear()
             self._pending = None
             return

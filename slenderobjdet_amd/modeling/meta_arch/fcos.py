@@ -311,7 +311,7 @@ class FCOSV2(nn.Module):
             labels, reg_t, ctr_t, stats = self.get_ground_truth(level_hw, gt_instances)
             world = comm.get_world_size()
             stats_work = None
-            if world > 1:       # asynchronous: the compute stream only waits for it in front of the loss node, a whole forward pass later
+            if comm.collectives_active():       # asynchronous: the compute stream only waits for it in front of the loss node, a whole forward pass later
                 stats_work = dist.all_reduce(stats, op=dist.ReduceOp.SUM, async_op=True)
 
         features = self.backbone(images.tensor)

@@ -27,6 +27,17 @@ def is_main_process() -> bool:
     return get_rank() == 0
 
 
+# A process group of ONE rank normally takes the single-process shortcuts (no collective is issued).  ``FORCE_COLLECTIVES`` (bench.py
+# --rccl-rehearsal, tests) makes the data-parallel code issue them anyway: on a one-GPU box that runs the real RCCL calls - the
+# asynchronous normaliser all-reduce, the bucketed gradient all-reduce from the autograd thread, their stream hand-overs - which a
+# two-ranks-on-one-GPU gloo test cannot.
+FORCE_COLLECTIVES = False
+
+
+def collectives_active() -> bool:
+    return get_world_size() > 1 or (FORCE_COLLECTIVES and is_dist())
+
+
 def synchronize():
     if get_world_size() > 1:
         dist.barrier()

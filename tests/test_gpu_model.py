@@ -270,6 +270,35 @@ def test_bench_two_ranks_data_parallel(cuda, tmp_path):
     assert torch.equal(p0, p1), "replicas diverged: gradient all-reduce / broadcast is broken"
 
 
+def test_bench_rccl_rehearsal_single_rank(cuda):
+    """``python bench.py --rccl-rehearsal``: a ONE-rank RCCL ("nccl") process group on the real GPU with every data-parallel
+    collective issued anyway - parameter broadcast, the asynchronous normaliser all-reduce waited for in front of the loss node, the
+    bucketed gradient all-reduce launched from the autograd thread on its own stream (fp32 and bf16 wire formats), barriers.  With
+    one rank every reduction is the identity, so the run must reproduce the plain single-process run's loss; what it proves is that
+    the RCCL calls, handles and stream hand-overs of the N-GPU path execute (the two-rank test of this box runs them over gloo)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--depth", "18", "--batch-per-gpu", "2",
+            "--height", "256", "--width", "320", "--no-roofline", "--no-cpu-baseline"]
+
+    def run(extra, env_extra=None):
+        env = dict(os.environ, SOD_DETERMINISTIC="1", **(env_extra or {}))
+        out = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+    plain = run([])
+    reh = run(["--rccl-rehearsal"])
+    assert reh["config"].get("rccl_rehearsal") and reh["n_gpus"] == 1
+    assert reh["config"]["final_loss"] == plain["config"]["final_loss"], (reh["config"], plain["config"])
+    reh16 = run(["--rccl-rehearsal"], {"SOD_GRAD_BUCKET_DTYPE": "bf16"})
+    assert abs(reh16["config"]["final_loss"] - plain["config"]["final_loss"]) <= 2e-2 * abs(plain["config"]["final_loss"])
+
+
 def test_side_streams_gradients_match_single_stream(cuda):
     """The weight gradients enqueued on the side stream (layers/functional.py:_wgrad_stream) and the box tower's nodes on the tower
     stream (FCOSHead.run_towers) must be complete when backward() returns.  In deterministic mode no float atomics are left, so
