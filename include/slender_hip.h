@@ -101,6 +101,16 @@ int sod_conv2d_fwd_ml_gnsum(int nlev, const void* const* x, const void* w, const
 int sod_conv2d_dgrad_ml(int nlev, const void* const* dy, const void* wt, void* const* dx,
                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                         long long dy_img_stride, void* stream);
+/* sod_conv2d_dgrad_ml whose output dx IS dL/d(relu(GroupNorm(gn_x))) - the data gradient of the conv that follows a tower unit
+ * conv -> GroupNorm(32) -> ReLU (fcosv2.py:300-336) - with the reduction pass of that norm's backward gathered in the epilogue:
+ * gn_x[l] = the norm's input (bf16, dx[l]'s shape), gn_mean_rstd = its saved statistics (nlev [N][G][2] blocks); on return
+ * gn_red (nlev [N][G][2] blocks, zeroed by this call) holds (sum gm*gamma, sum gm*gamma*xhat) per (image, group) and dgamma / dbeta have
+ * been incremented by sum gm*xhat / sum gm per channel (gm = dx masked by gamma*xhat+beta > 0).  C (dx channels) must equal 8 * G.
+ * sod_groupnorm_bwd_apply_ml then needs one pass instead of two. */
+int sod_conv2d_dgrad_ml_gnbwd(int nlev, const void* const* dy, const void* wt, void* const* dx,
+                              int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                              long long dy_img_stride, const void* const* gn_x, const float* gn_mean_rstd, const float* gamma,
+                              const float* beta, float* gn_red, float* dgamma, float* dbeta, int G, void* stream);
 int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, float* dw, const float* qscale,
                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                         long long dy_img_stride, int splits, int flags, void* ws, long long ws_bytes, void* stream);
@@ -146,6 +156,12 @@ int sod_groupnorm_apply_ml(int nlev, const void* const* x, const float* gamma, c
 int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void* const* x, const float* gamma, const float* beta,
                          const float* mean_rstd, void* const* dx, float* dgamma, float* dbeta, float* dxsum, float* red_ws,
                          int N, const int* hw, int C, int G, int relu, float* det_ws, long long det_ws_bytes, void* stream);
+
+/* Second half of sod_groupnorm_bwd_ml for reductions that sod_conv2d_dgrad_ml_gnbwd gathered (red = its gn_red; dgamma / dbeta are
+ * complete already): dx = rstd * (gm*gamma - (s1 + xhat*s2)/m), dxsum (optional) += per-channel sum of dx. */
+int sod_groupnorm_bwd_apply_ml(int nlev, const void* const* dy, const void* const* x, const float* gamma, const float* beta,
+                               const float* mean_rstd, void* const* dx, float* dxsum, const float* red, int N, const int* hw, int C,
+                               int G, int relu, void* stream);
 
 /* elementwise helpers on bf16 tensors of n elements (n % 8 == 0) */
 int sod_relu_fwd(const void* x, void* y, long long n, void* stream);

@@ -55,7 +55,7 @@ inline void prof_end(int i, hipStream_t st, int variant, float frac, int mode) {
   p.variant[i] = variant; p.frac[i] = frac; p.mode[i] = mode;
 }
 
-template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK, int NSTAGE>
+template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK, int NSTAGE, bool GNB = false>
 __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int NW = WQ * WP;                  // waves per workgroup (4 or 8)
   constexpr int BQ = WQ * FQ * 16, BP = WP * FP * 16;
@@ -331,6 +331,8 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
       }
     }
     GnAcc ga{0.f, 0.f, -1};
+    GnBwdAcc gb;
+    if constexpr (GNB) gnb_init(gb, a.gnb_gamma, a.gnb_beta, q, qok);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       // Residual / mask operands of ALL passes of this half are requested before the accumulators go through LDS: one exposed
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
           if constexpr (MODE == MODE_DGRAD && !OUT_F32) {
             if (a.flags & F_MASKBITS) mbits[k] = ((const uint8_t*)g.mask)[(drow[k] + q) >> 3];
           }
+          if constexpr (GNB) maskv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.mask + drow[k] + q);      // the norm's input x
         }
       }
 #pragma unroll
@@ -422,6 +425,7 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
               }
             }
             if constexpr (MODE == MODE_FWD) { if (a.flags & F_GNSTATS) gn_acc_add(ga, nimg[k], o, g.gn_sum, a.gn_G, q >> 3); }
+            if constexpr (GNB) gnb_add(gb, nimg[k], maskv[k], o, g.gnb_stats, g.gnb_red, a.gn_G, q >> 3);
           }
         }
       }
@@ -429,6 +433,14 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
     if constexpr (!OUT_F32 && MODE == MODE_FWD) {
       if (a.flags & F_GNSTATS)
         gn_acc_finish<LPR>(ga, p0 + wp * FP * 16, p0 + wp * FP * 16 + FP * 16 - 1, (uint32_t)gP, g.div_hw, g.gn_sum, a.gn_G, q >> 3, qok, lane);
+    }
+    if constexpr (GNB) {
+      gnb_finish_groups<LPR>(gb, p0 + wp * FP * 16, p0 + wp * FP * 16 + FP * 16 - 1, (uint32_t)gP, g.div_hw, g.gnb_red, a.gn_G, q >> 3, qok, lane);
+      gnb_reduce_channels<LPR>(gb);          // this kernel only covers the tail of a launch (< half a round of 256-pixel tiles)
+      if (lane < LPR && qok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { atomicAdd(a.gnb_dgamma + q + e, gb.dg[e]); atomicAdd(a.gnb_dbeta + q + e, gb.db[e]); }
+      }
     }
     return;
   }
@@ -788,7 +800,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
   }
 }
 
-template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK = 64, int NSTAGE = 2>
+template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK = 64, int NSTAGE = 2, bool GNB = false>
 int launch_conv(const ConvArgs& a0, hipStream_t st) {
   constexpr int BQ = WQ * FQ * 16, BP = WP * FP * 16;
   ConvArgs a = a0;
@@ -811,7 +823,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   size_t lds = a.T == 1 ? (size_t)(BQ + BP) * BK * 2 : lds_full;
   if (lds < epi) lds = epi;
   g_last_variant = BQ * 100000 + BP * 100 + BK + (GENERIC ? 1 : 0);
-  auto kern = conv_igemm_kernel<MODE, GENERIC, WQ, WP, FQ, FP, OUT_F32, BK, NSTAGE>;
+  auto kern = conv_igemm_kernel<MODE, GENERIC, WQ, WP, FQ, FP, OUT_F32, BK, NSTAGE, GNB>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_full > epi ? lds_full : epi));
@@ -827,7 +839,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
 
 int g_conv256_mode = -1;   // -1: read SOD_CONV256 (default 1); 0 off; 1 heuristic; 2 every supported shape
 
-template <int MODE, bool OUT_F32>
+template <int MODE, bool OUT_F32, bool GNB = false>
 int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   const bool generic = (a.Cred & 63) != 0 || a.R * a.S > 64;      // the linear path keeps one validity bit per tap in 64-bit masks
   // 256x256 8-phase kernel (conv_igemm256.hip) for the large compute-bound shapes.  SOD_CONV256=0 disables it, =2 forces it for
@@ -854,7 +866,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     if (c256 == 2) {
       g_last_variant = 256;
       const int pi = prof_begin(st);
-      const int rc = launch_conv256(a, MODE, OUT_F32, 0, st);
+      const int rc = launch_conv256(a, MODE, OUT_F32, 0, st, GNB);
       prof_end(pi, st, 256, 1.f, MODE);
       return rc;
     }
@@ -871,7 +883,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
       if (rem == 0 || rem * 2 >= (long long)cus || (full / nq) * nq != full) {
         g_last_variant = 256;
         const int pi = prof_begin(st);
-        const int rc = launch_conv256(a, MODE, OUT_F32, 0, st);
+        const int rc = launch_conv256(a, MODE, OUT_F32, 0, st, GNB);
         prof_end(pi, st, 256, 1.f, MODE);
         return rc;
       }
@@ -879,7 +891,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
       long long ptot = 0;
       for (int l = 0; l < a.nlev; ++l) ptot += a.lev[l].P;
       const int pi = prof_begin(st);
-      int rc = launch_conv256(a, MODE, OUT_F32, main_pt, st);
+      int rc = launch_conv256(a, MODE, OUT_F32, main_pt, st, GNB);
       prof_end(pi, st, 256, (float)((double)main_pt * 256.0 / (double)ptot), MODE);     // main tiles are full 256-pixel tiles
       if (rc) return rc;
       ConvArgs tail = a;
@@ -889,11 +901,15 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
         else { tail.lev[l].pstart = main_pt * 256; main_pt = 0; }
       }
       ++g_prof_depth;            // the tail launch belongs to this dispatch: no event pair of its own
-      rc = dispatch_conv<MODE, OUT_F32>(tail, st);
+      rc = dispatch_conv<MODE, OUT_F32, GNB>(tail, st);
       --g_prof_depth;
       g_last_variant = 256;      // whole rounds on the 256 kernel (+ a short 128x128 tail launch)
       return rc;
     }
+  }
+  if constexpr (GNB) {       // the one 128x128 instantiation that carries the GroupNorm-backward epilogue (256-channel tower tensors)
+    if (generic) return SOD_EARG;
+    return launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32, 64, 2, true>(a, st);
   }
   if (a.Nout <= 16) {
     return generic ? launch_conv<MODE, true, 1, 4, 1, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 1, 4, 1, 4, OUT_F32>(a, st);
@@ -1301,6 +1317,33 @@ extern "C" int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const 
 // Workspace that lets every shape of one launch take the slab path: one 256x256 fp32 partial tile per CU plus the rounding of the
 // split count, doubled for grids of more than one round (tiles > CUs).
 extern "C" long long sod_conv2d_wgrad_workspace_bytes(void) { return 160ll << 20; }
+
+extern "C" int sod_conv2d_dgrad_ml_gnbwd(int nlev, const void* const* dy, const void* wt, void* const* dx,
+                                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                         long long dy_img_stride, const void* const* gn_x, const float* gn_mean_rstd, const float* gamma,
+                                         const float* beta, float* gn_red, float* dgamma, float* dbeta, int G, void* stream) {
+  if (!dy || !wt || !dx || !H || !W || !gn_x || !gn_mean_rstd || !gamma || !beta || !gn_red || !dgamma || !dbeta) return SOD_EARG;
+  if (G <= 0 || C != 8 * G || (K & 63)) return SOD_EARG;      // a lane's 8 output channels = one group; linear (non-generic) contraction
+  ConvArgs a{};
+  int rc = fill_common(a, nlev, N, K, C, R, S, stride, pad, dil);
+  if (rc) return rc;
+  for (int l = 0; l < nlev; ++l) {
+    const int Ho = out_size(H[l], pad, dil, R, stride), Wo = out_size(W[l], pad, dil, S, stride);
+    if (Ho <= 0 || Wo <= 0 || !gn_x[l]) return SOD_EARG;
+    rc = fill_level(a, l, dy[l], dx[l], Ho, Wo, H[l], W[l], dy_img_stride, 0, 2);
+    if (rc) return rc;
+    a.lev[l].mask = gn_x[l];
+    a.lev[l].gnb_stats = gn_mean_rstd + (size_t)l * N * G * 2;
+    a.lev[l].gnb_red = gn_red + (size_t)l * N * G * 2;
+  }
+  a.w = wt; a.bias = nullptr;
+  a.flags = F_GNBWD;
+  a.gn_G = G; a.gnb_gamma = gamma; a.gnb_beta = beta; a.gnb_dgamma = dgamma; a.gnb_dbeta = dbeta;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(gn_red, 0, sizeof(float) * 2 * (size_t)N * G * nlev, st);
+  if (e != hipSuccess) return (int)e;
+  return dispatch_conv<MODE_DGRAD, false, true>(a, st);
+}
 
 extern "C" int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, float* dw, const float* qscale,
                                    int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,

@@ -815,6 +815,25 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
   return SOD_OK;
 }
 
+extern "C" int sod_groupnorm_bwd_apply_ml(int nlev, const void* const* dy, const void* const* x, const float* gamma, const float* beta,
+                                          const float* mean_rstd, void* const* dx, float* dxsum, const float* red, int N, const int* hw, int C,
+                                          int G, int relu, void* stream) {
+  if (!dy || !x || !gamma || !beta || !mean_rstd || !dx || !red) return SOD_EARG;
+  GnML m{};
+  const int gx = gn_fill(m, nlev, hw, N, C, G, 0.f, relu, nullptr);
+  if (gx <= 0) return gx ? gx : SOD_EARG;
+  m.gamma = gamma; m.beta = beta; m.dxsum = dxsum;
+  for (int l = 0; l < nlev; ++l) {
+    if (!x[l] || !dy[l] || !dx[l]) return SOD_EARG;
+    m.lev[l].x = (const __bf16*)x[l]; m.lev[l].dy = (const __bf16*)dy[l]; m.lev[l].dx = (__bf16*)dx[l];
+    m.lev[l].stats = const_cast<float*>(mean_rstd) + (size_t)l * N * G * 2; m.lev[l].red = const_cast<float*>(red) + (size_t)l * N * G * 2;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * 8 * 256 : 0, st, m);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
 extern "C" int sod_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd,
                                  int N, int HW, int C, int G, long long img_stride, float eps, int relu, float* det_ws, long long det_ws_bytes,
                                  void* stream) {

@@ -322,6 +322,43 @@ def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=N
     return outs
 
 
+def conv2d_dgrad_ml_gnbwd(dys, wt, x_hws, gn_xs, gn_stats, gamma, beta, dgamma, dbeta, G, stride=1, pad=0, dil=1, N=None):
+    """conv2d_dgrad_ml whose outputs are the gradients w.r.t. relu(GroupNorm(gn_xs)): the epilogue also gathers the reduction pass of that
+    norm's backward.  Returns (dxs, red) with red (nl, N, G, 2); dgamma / dbeta (fp32, [C]) are incremented in place."""
+    _chk(wt, torch.bfloat16, "wt"); _chk(gn_stats, torch.float32, "gn_stats")
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _chk(t, torch.float32, nm)
+    for t in list(dys) + list(gn_xs):
+        _chk(t, torch.bfloat16, "dy/x")
+    C, R, S, K = wt.shape
+    if N is None:
+        N = dys[0].shape[0]
+    dev = dys[0].device
+    if C != 8 * G or len(gn_xs) != len(dys) or any(tuple(x.shape) != (N, h, w, C) for x, (h, w) in zip(gn_xs, x_hws)):
+        raise _C.SlenderHipError("conv2d_dgrad_ml_gnbwd: the norm's inputs must have the data gradient's shape, 8 channels per group")
+    outs = [torch.empty((N, h, w, C), dtype=torch.bfloat16, device=dev) for h, w in x_hws]
+    red = torch.empty((len(dys), N, G, 2), dtype=torch.float32, device=dev)
+    e0 = _prof_begin(None, "conv_dgrad")
+    call("sod_conv2d_dgrad_ml_gnbwd", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]), _int_arr([w for _, w in x_hws]),
+         C, K, R, S, stride, pad, dil, 0, _ptr_arr(gn_xs), ptr(gn_stats), ptr(gamma), ptr(beta), ptr(red), ptr(dgamma), ptr(dbeta), G, stream_ptr())
+    fl = sum(2.0 * N * ho * wo * K * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in x_hws))
+    _prof_end("conv_dgrad", fl, e0, ("ml", N, tuple(h for h, _ in x_hws), C, K, R, stride))
+    return outs, red
+
+
+def groupnorm_bwd_apply_ml(dys, xs, gamma, beta, stats, red, G, relu=False, dxsum=None):
+    """The apply pass of groupnorm_bwd_ml alone, for reductions gathered by conv2d_dgrad_ml_gnbwd: returns the list of dx."""
+    _chk(stats, torch.float32, "stats"); _chk(red, torch.float32, "red")
+    for t in list(dys) + list(xs):
+        _chk(t, torch.bfloat16, "dy/x")
+    N, C = xs[0].shape[0], xs[0].shape[-1]
+    hw = [x.numel() // (N * C) for x in xs]
+    dxs = [torch.empty_like(x) for x in xs]
+    call("sod_groupnorm_bwd_apply_ml", len(xs), _ptr_arr(dys), _ptr_arr(xs), ptr(gamma), ptr(beta), ptr(stats), _ptr_arr(dxs), ptr(dxsum), ptr(red),
+         N, ctypes.cast(_int_arr(hw), ctypes.c_void_p), C, G, 1 if relu else 0, stream_ptr())
+    return dxs
+
+
 def conv2d_wgrad_ml(dys, xs, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, K=None, splits=0, qscale=None, k_real=None):
     """Accumulates the weight gradient over all levels in one launch."""
     _chk(dw, torch.float32, "dw")

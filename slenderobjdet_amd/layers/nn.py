@@ -53,6 +53,12 @@ import os as _os
 
 # SOD_GN_EPILOGUE_STATS=0: the GroupNorm statistics of the tower units come from their own pass over the conv output
 GN_EPILOGUE_STATS = _os.environ.get("SOD_GN_EPILOGUE_STATS", "1") != "0"
+# SOD_GN_BWD_FUSED=1 (EXPERIMENT, off by default): a tower unit's data gradient gathers the reduction pass of the previous unit's GroupNorm
+# backward in its epilogue (GnBwdSlot).  Correct (tests/test_gpu_conv.py, test_gpu_model.py) but measured SLOWER on the FCOS R50 step:
+# 610.0 / 612.5 vs 618.4 / 616.4 img/s.  The pass it removes (0.79 ms of HBM-bound kernel time per step) already runs beside the other
+# tower's MFMA-bound convolutions, while its ~12 VALU operations per element land in the un-overlapped epilogue of the 256x256 kernel
+# (one workgroup per CU: two waves per SIMD x 128 elements x 12 instructions x 4 cycles = 5.8 us on a 17.5 us tile).
+GN_BWD_FUSED = _os.environ.get("SOD_GN_BWD_FUSED", "0") == "1"
 # SOD_DEFER_LATERAL=0: the FPN lateral convs run their own data gradient and autograd sums it with the next stage's (see DeferSlot)
 DEFER_LATERAL_DGRAD = _os.environ.get("SOD_DEFER_LATERAL", "1") != "0"
 
@@ -242,6 +248,20 @@ class HipGroupNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(num_channels))
 
 
+class GnBwdSlot:
+    """What a ConvGnRelu unit publishes for the unit that consumes its output (and is its ONLY consumer): the norm's input, statistics
+    and module.  The consumer's data gradient (sod_conv2d_dgrad_ml_gnbwd) gathers the reduction pass of this unit's GroupNorm backward
+    in its epilogue and leaves the group sums in ``red``; this unit's backward then runs the apply pass alone."""
+
+    def __init__(self, y1s, stats, gn, outs):
+        self.y1s, self.stats, self.gn = y1s, stats, gn
+        self.out_ptrs = [(t.data_ptr(), tuple(t.shape)) for t in outs]
+        self.red = None
+
+    def matches(self, xs):
+        return len(xs) == len(self.out_ptrs) and all((x.data_ptr(), tuple(x.shape)) == k for x, k in zip(xs, self.out_ptrs))
+
+
 class ConvGnRelu(nn.Module):
     """[Conv3x3(bias) -> GroupNorm(32) -> ReLU] unit of the FCOS towers (fcosv2.py:300-336), applied to ALL FPN levels at
     once: the levels share the weights, so the convolution forward / dgrad / wgrad are one multi-level launch each."""
@@ -250,19 +270,25 @@ class ConvGnRelu(nn.Module):
         super().__init__()
         self.conv = HipConv2d(channels, channels, 3, 1, 1, bias=True)
         self.gn = HipGroupNorm(num_groups, channels)
+        self._last_slot = None
 
-    def forward(self, xs):
+    def forward(self, xs, chained=None):
+        """``chained``: the ConvGnRelu unit whose latest forward produced ``xs`` and that has no other consumer (the previous unit of a
+        tower): this unit's backward then gathers the reduction pass of that unit's GroupNorm backward in its data gradient."""
         single = isinstance(xs, torch.Tensor)
         if single:
             xs = [xs]
         self.conv.prepare()
-        out = _ConvGnReluFn.apply(self.conv.weight, self, *xs)
+        prev = None
+        if GN_BWD_FUSED and chained is not None and chained._last_slot is not None and chained._last_slot.matches(xs):
+            prev = chained._last_slot
+        out = _ConvGnReluFn.apply(self.conv.weight, self, prev, *xs)
         return out[0] if single else list(out)
 
 
 class _ConvGnReluFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, weight, unit, *xs):
+    def forward(ctx, weight, unit, prev_slot, *xs):
         conv, gn = unit.conv, unit.gn
         gw, gb = gn.weight.detach(), gn.bias.detach()
         if (GN_EPILOGUE_STATS and not HF.DETERMINISTIC and conv.out_channels == 8 * gn.num_groups and conv.bias_eff is not None
@@ -274,10 +300,14 @@ class _ConvGnReluFn(torch.autograd.Function):
             y2s, stats = HF.groupnorm_fwd_ml(y1s, gw, gb, gn.num_groups, gn.eps, relu=True)      # all levels in one launch per pass
         ctx.unit, ctx.nl = unit, len(xs)
         ctx.save_for_backward(*xs, *y1s, stats)
+        ctx.prev_slot = prev_slot
+        ctx.slot = unit._last_slot = None
         arena = _arena_of(conv)
         if arena is not None and conv.weight.requires_grad:
             for p in (conv.weight, conv.bias, gn.weight, gn.bias):
                 arena.note_use(p)
+            if conv.out_channels == 8 * gn.num_groups:
+                ctx.slot = unit._last_slot = GnBwdSlot(list(y1s), stats, gn, y2s)
         return tuple(y2s)
 
     @staticmethod
@@ -291,16 +321,29 @@ class _ConvGnReluFn(torch.autograd.Function):
         gw, gb = gn.weight.detach(), gn.bias.detach()
         dgw, dgb = arena.grad_view(gn.weight), arena.grad_view(gn.bias)
         dbias = arena.grad_view(conv.bias)      # the conv bias gradient (sum of dy1 over pixels) falls out of the GN backward pass
-        dy1s = HF.groupnorm_bwd_ml([d.contiguous() for d in dy2s], list(y1s), gw, gb, stats, gn.num_groups, dgw, dgb, relu=True, dxsum=dbias)
+        slot, ctx.slot = ctx.slot, None
+        if slot is not None and slot.red is not None:
+            # the consumer's data gradient already gathered the group sums and dgamma / dbeta (sod_conv2d_dgrad_ml_gnbwd): apply pass only
+            dy1s = HF.groupnorm_bwd_apply_ml([d.contiguous() for d in dy2s], list(y1s), gw, gb, stats, slot.red, gn.num_groups, relu=True, dxsum=dbias)
+            slot.red = None
+        else:
+            dy1s = HF.groupnorm_bwd_ml([d.contiguous() for d in dy2s], list(y1s), gw, gb, stats, gn.num_groups, dgw, dgb, relu=True, dxsum=dbias)
         arena.mark_ready(gn.weight)
         arena.mark_ready(gn.bias)
         arena.mark_ready(conv.bias)
         HF.conv2d_wgrad_ml(dy1s, list(xs), arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
         arena.mark_ready(conv.weight)
         dxs = [None] * nl
-        if any(ctx.needs_input_grad[2:]):
-            dxs = HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, [(x.shape[1], x.shape[2]) for x in xs], 1, 1, 1)
-        return (None, None, *dxs)
+        if any(ctx.needs_input_grad[3:]):
+            prev, ctx.prev_slot = ctx.prev_slot, None
+            hw = [(x.shape[1], x.shape[2]) for x in xs]
+            if prev is not None and not HF.DETERMINISTIC and all(ctx.needs_input_grad[3:]):
+                pg = prev.gn
+                dxs, prev.red = HF.conv2d_dgrad_ml_gnbwd(dy1s, conv.wt_bf16, hw, prev.y1s, prev.stats, pg.weight.detach(), pg.bias.detach(),
+                                                         arena.grad_view(pg.weight), arena.grad_view(pg.bias), pg.num_groups, 1, 1, 1)
+            else:
+                dxs = HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, hw, 1, 1, 1)
+        return (None, None, None, *dxs)
 
 
 class ConvReluML(nn.Module):

@@ -109,11 +109,18 @@ class FCOSHead(nn.Module):
     def run_towers(self, feats):
         """Every tower unit runs over all FPN levels in one multi-level launch (the levels share the weights)."""
         cls_t, box_t = list(feats), list(feats)
+        def run(unit, xs, prev):     # consecutive ConvGnRelu units share the GroupNorm backward reduction (layers/nn.py GnBwdSlot)
+            if isinstance(unit, ConvGnRelu):
+                return unit(xs, chained=prev if isinstance(prev, ConvGnRelu) else None)
+            return unit(xs)
+
         if not (TOWER_STREAMS and feats[0].is_cuda):
+            prev = None
             for unit in self.cls_tower:
-                cls_t = unit(cls_t)
+                cls_t, prev = run(unit, cls_t, prev), unit
+            prev = None
             for unit in self.bbox_tower:
-                box_t = unit(box_t)
+                box_t, prev = run(unit, box_t, prev), unit
             return cls_t, box_t
         # The two towers are independent chains of (MFMA-bound conv, HBM-bound GroupNorm) launches: the box tower runs on a second
         # stream, enqueued unit by unit alongside the classification tower, so that one tower's GroupNorm passes overlap the other's
@@ -127,10 +134,11 @@ class FCOSHead(nn.Module):
         s2.wait_stream(main)
         for f in feats:
             f.record_stream(s2)
+        pc = pb = None
         for cu, bu in zip(self.cls_tower, self.bbox_tower):
             with torch.cuda.stream(s2):
-                box_t = bu(box_t)
-            cls_t = cu(cls_t)
+                box_t, pb = run(bu, box_t, pb), bu
+            cls_t, pc = run(cu, cls_t, pc), cu
         main.wait_stream(s2)
         for t in box_t:
             t.record_stream(main)

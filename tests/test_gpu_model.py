@@ -45,7 +45,19 @@ def test_fcos_r18_losses_and_gradients_vs_oracle(cuda, depth):
             ref_emu = {k: float(v) for k, v in ref.items()}
         else:
             ref_f32 = {k: float(v) for k, v in ref.items()}
-    got = model(data)
+    # Deterministic mode (fixed summation order everywhere, no float atomics): the deep-layer gradient bar below sits at 0.99 of its
+    # bound for one res3 weight (measured 0.988 .. 0.997 over the atomic paths, tools/gradcheck_r50.py), so run-to-run noise of the
+    # default paths must not decide it.  The atomic paths are compared with the deterministic ones by the A/B tests of this file and
+    # of test_gpu_conv.py.
+    from slenderobjdet_amd.layers import functional as HF
+    prev_det, HF.DETERMINISTIC = HF.DETERMINISTIC, True
+    try:
+        got = model(data)
+        total = sum(got.values())
+        opt.zero_grad()
+        model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    finally:
+        HF.DETERMINISTIC = prev_det
     for k, b in ref_emu.items():
         a = float(got[k].detach())
         assert abs(a - b) <= 1e-3 * max(abs(b), 1e-3), (k, a, b)
@@ -56,9 +68,6 @@ def test_fcos_r18_losses_and_gradients_vs_oracle(cuda, depth):
         a, e = float(got[k].detach()), ref_emu[k]
         assert abs(a - f) <= 2e-3 * max(abs(f), 1e-3), (k, a, f)
         assert abs(a - f) <= 3.0 * abs(e - f) + 1e-3 * max(abs(f), 1e-3), (k, a, e, f)
-    total = sum(got.values())
-    opt.zero_grad()
-    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
     checked = 0
     for name, p in model.named_parameters():
         if not p.requires_grad:
@@ -556,3 +565,55 @@ def test_relu_bit_masks_leave_the_step_bit_identical(cuda):
     finally:
         resnet.RELU_BITS = True
         HF.DETERMINISTIC = prev
+
+
+def test_groupnorm_backward_reduction_in_the_consumer_dgrad(cuda):
+    """Inside the FCOS towers a unit's data gradient gathers the reduction pass of the PREVIOUS unit's GroupNorm backward (layers/nn.py
+    GnBwdSlot).  Same losses bit for bit (forward untouched); gradients agree with the two-pass form to the accuracy float atomics
+    in a different order allow; and the fused path really runs (3 of the 4 units of each tower)."""
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.layers import nn as HN
+
+    cfg, model, opt = _build(50, seed=8)
+    data = synthetic_batch(2, 320, 384, 13, device="cuda")
+    calls = {"fused": 0}
+    orig = HF.conv2d_dgrad_ml_gnbwd
+
+    def counting(*a, **k):
+        calls["fused"] += 1
+        return orig(*a, **k)
+
+    prev_flag = HN.GN_BWD_FUSED
+
+    def step(on):
+        HN.GN_BWD_FUSED = on
+        opt.zero_grad()
+        out = model(data)
+        total = sum(out.values())
+        model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+        return {k: float(v.detach()) for k, v in out.items()}, model.arena.grads.clone()
+
+    try:
+        ref_l, ref_g = step(False)
+        ref2_l, ref2_g = step(False)         # the run-to-run noise of the two-pass form itself (float atomics)
+        HF.conv2d_dgrad_ml_gnbwd = counting
+        got_l, got_g = step(True)
+        assert calls["fused"] == 6, calls
+        # the forward pass is the same code in all steps; its GroupNorm statistics come from float atomics (not bit-reproducible)
+        for k in ref_l:
+            assert abs(got_l[k] - ref_l[k]) <= 2e-4 * abs(ref_l[k]), (k, got_l[k], ref_l[k])
+        # Every gradient may differ from the two-pass form by no more than that form differs from itself between two runs (x4, + 0.3 %):
+        # a last-bit change in one norm's sums moves bf16 roundings downstream, and sums with cancellation (dgamma) show it at the
+        # per-cent level either way.  A wrong reduction (missing mask, wrong group, lost pixels) is off by tens of per cent.
+        worst = 0.0
+        for name, off, n in model.arena.names:
+            a, b, b2 = got_g[off:off + n], ref_g[off:off + n], ref2_g[off:off + n]
+            nb = max(b.norm().item(), 1e-12)
+            d, noise = (a - b).norm().item() / nb, (b2 - b).norm().item() / nb
+            worst = max(worst, d)
+            assert d <= 4.0 * noise + 3e-3, (name, d, noise)
+        assert worst < 0.3
+    finally:
+        HF.conv2d_dgrad_ml_gnbwd = orig
+        HN.GN_BWD_FUSED = prev_flag
