@@ -6,21 +6,31 @@
 // the two 64-channel intermediates need not exist in HBM at all: per block of a 16 x 200x336 batch the un-fused path moves 2.2 GB
 // (x read twice, both intermediates written and read, out written) at the HBM roofline, this kernel 1.1 GB (x in, out out).
 //
-// One workgroup (4 waves, two workgroups per CU) = an 8 x 16 tile of output pixels of one image.  Every GEMM keeps its WEIGHTS IN
-// REGISTERS (MFMA A operand, loaded straight from global / L2 while the previous stage computes) and reads only the activations (B
-// operand) from LDS, so a stage has no weight staging and no barrier inside:
+// One PERSISTENT workgroup per CU (4 waves, one per SIMD, 512 registers each) walks over 8 x 16 tiles of output pixels.  All weights
+// are loaded ONCE per workgroup and stay in registers as MFMA A operands (W1 32 + W2 72 + W3 32 (+ Wsc 32) VGPRs / AGPRs): the per-tile
+// L2 -> CU traffic is the x halo and the residual, nothing else.  The GEMMs read only activations (B operands) from LDS:
 //   stage 1  h1 = relu(W1 x + b1) on the 10 x 18 halo (180 pixels = 12 MFMA column tiles): wave w owns output channels 16w..16w+15;
-//            K = Cin in chunks of 64 channels, the x chunks go HBM -> LDS by buffer_load ... lds through a three-slot ring (two
-//            chunks in flight, counted vmcnt + raw s_barrier); h1 of halo pixels OUTSIDE the image is zero (the zero padding of the
-//            3x3 conv, not relu(b1)); h1 -> LDS as bf16 rows of 128 B, 16-B chunks XOR-swizzled by (row >> 1) & 7;
+//            K = Cin in chunks of 64 channels; h1 of halo pixels OUTSIDE the image is zero (the zero padding of the 3x3 conv, not
+//            relu(b1)); h1 -> LDS as bf16 rows of 128 B, 16-B chunks XOR-swizzled by (row >> 1) & 7;
 //   stage 2  h2 = relu(W2 * h1 + b2): wave w owns channels 16w..; a tile row of 16 pixels is one MFMA column tile, so a tap is a row /
-//            column shift of the h1 row index; all 9 x 64 contraction elements of W2's 16 rows sit in 72 VGPRs;
-//   stage 3  acc = W3 h2 (+ Wsc x for the projection shortcut: the tile's own pixels of the x chunk still in ring slot 0): wave w owns
-//            output channels 64w..64w+63;
-//   epilogue + b3 (+ identity x, all 16 loads of a lane issued at once), ReLU, bf16, through per-wave LDS so that every lane stores 16
-//            contiguous bytes.
+//            column shift of the h1 row index; the fragment reads of tap t+1 are in flight while the MFMAs of tap t issue;
+//   stage 3  acc = W3 h2 (+ Wsc x for the projection shortcut: the tile's own pixels of its x chunk, still in the ring): wave w owns
+//            output channels 64w..64w+63; in two halves of four tile rows (64 accumulator registers);
+//   epilogue + b3 (+ identity x, all 16 loads of a lane requested in front of stage 3), ReLU, bf16, through per-wave LDS so that every
+//            lane stores 16 contiguous bytes; branch-free through buffer resources (out-of-range offsets for pixels outside the image).
+// x chunks go HBM -> LDS by buffer_load ... lds; the chunks of tile i+1 are requested while tile i computes: chunk c of the next tile
+// goes into ring slot c as soon as every wave has consumed chunk c of this tile, so the prefetch distance is a whole tile and stage 1
+// normally finds its operands in LDS.  LDS: ring (Cin/64 slots; 2 for the projection block, whose single chunk must survive until
+// its shortcut GEMM) + h1 + h2 + epilogue staging, no overlays (153 KB for Cin = 256).
+// Counted waits: `s_waitcnt vmcnt(N)` retires all but the N youngest vector-memory operations, which complete in issue order (loads,
+// stores and LDS-DMA alike).  The chunk stage 1 waits for is OLDER than the previous tile's 16 residual loads and 16 stores (exactly
+// one instruction per builtin call; the waits are compiler barriers for memory operations, so the set between two waits is fixed):
+// N = 6 * (chunks requested after it) + 32 (16 for the projection block, which has no residual loads).  The kernel must not spill:
+// scratch accesses would join that count (tests/test_cabi_surface.py checks the compiled code object).
 // Intermediates are rounded to bf16 exactly where the un-fused path stores them; the projection shortcut is added in fp32 (the
 // un-fused path rounds it to bf16 first).  Two shapes exist: <Cin = 64, projection> (first block of res2) and <Cin = 256, identity>.
+// History: a per-tile variant (two workgroups per CU, weights re-read per tile, 3-slot ring) ran the identity block in 344 us, this
+// one in 317 us (16 x 200x336; un-fused 517 us); with the weights staged through LDS per tap 368 us.
 #include "common.h"
 #include "../../include/slender_hip.h"
 
@@ -31,9 +41,6 @@ constexpr int BT_HW = BT_TW + 2;              // halo columns
 constexpr int BT_HP = (BT_TH + 2) * BT_HW;    // 180 halo pixels
 constexpr int BT_ROWB = 128;                  // LDS row: 64 bf16
 constexpr int SLOT = 192 * BT_ROWB;           // 24 KB: one x chunk [192 halo rows][64 ch]
-constexpr int L_TOTAL = 3 * SLOT;             // 72 KB: two workgroups per CU
-constexpr int L_H1 = SLOT, L_H2 = 2 * SLOT;   // h1 [192][128 B] in slot 1, h2 [128][128 B] in slot 2 (their x chunks are consumed by then)
-constexpr int L_EPI = SLOT;                   // epilogue staging (h1 is dead after stage 2)
 constexpr int EROWB = 64 * 4 + 16;            // epilogue: fp32 row of 64 channels + pad
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -57,259 +64,286 @@ __device__ __forceinline__ void lds_fence_barrier() {
 }
 
 template <int NK, bool PROJ>
-__global__ __launch_bounds__(256, 2) void bottleneck_frozen_kernel(const BneckArgs a) {
+__global__ __launch_bounds__(256, 1) void bottleneck_frozen_kernel(const BneckArgs a) {
   constexpr int Cin = NK * 64;
-  static_assert(!PROJ || NK == 1, "the projection shortcut reads the single x chunk kept in ring slot 0");
+  constexpr int NR = (NK == 1) ? 2 : NK;                 // ring slots
+  constexpr int P_H1 = NR * SLOT, P_H2 = P_H1 + SLOT, P_EPI = P_H2 + 128 * BT_ROWB;
+  constexpr int EPI_OPS = PROJ ? 16 : 32;                // vector-memory instructions of one tile's epilogue (stores + residual loads)
+  static_assert(!PROJ || NK == 1, "projection shortcut: single-chunk input");
+  static_assert(NK == 1 || NK == 4, "ring bookkeeping below is written for the two res2 shapes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tx = (int)(bid % (uint32_t)a.tiles_x); bid /= (uint32_t)a.tiles_x;
-  const int ty = (int)(bid % (uint32_t)a.tiles_y);
-  const int n = (int)(bid / (uint32_t)a.tiles_y);
-  const int y0 = ty * BT_TH, x0 = tx * BT_TW;
   const int H = a.H, W = a.W;
   const int fr = lane & 15, fg = lane >> 4;
+  const uint32_t tiles_per_img = (uint32_t)(a.tiles_x * a.tiles_y);
+  const uint32_t ntiles = tiles_per_img * (uint32_t)a.N;
+  // workgroup b works on tiles perm(b), perm(b) + G, ...: within a round every XCD (b % 8) owns a contiguous run of G/8 tiles
+  const uint32_t G = gridDim.x;
+  const uint32_t first = (G & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3);
 
-  // ---- weights of stage 1 and stage 2 -> registers (A operand: lane = output row 16*wave + fr, 8 consecutive k at fg*8)
-  bf16x8_t a1[NK][2], a2[9][2];
+  // ---- all weights -> registers, once
+  bf16x8_t a1[NK][2], a2[9][2], a3[4][2], asc[PROJ ? 4 : 1][2];
   {
     const __bf16* p1 = a.w1 + (size_t)(16 * wave + fr) * Cin + fg * 8;
 #pragma unroll
     for (int kc = 0; kc < NK; ++kc)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) a1[kc][ks] = *reinterpret_cast<const bf16x8_t*>(p1 + kc * 64 + ks * 32);
-  }
-
-  // ---- x chunk staging: one wave instruction = 8 LDS rows x 128 B; lane -> (row, 16-B slot); the lane fetches the LOGICAL chunk
-  // slot ^ ((row >> 1) & 7) (source-side swizzle), so that fragment reads (16 lanes = 16 consecutive rows, one chunk) are conflict-free
-  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
-  const int srow = lane >> 3, spos = lane & 7;
-  const int schunk = spos ^ ((lane >> 4) | ((wave & 1) << 2));
-  const uint32_t img_base = (uint32_t)n * (uint32_t)H * (uint32_t)W;
-  uint32_t xrow[6];
+    const __bf16* p2 = a.w2 + (size_t)(16 * wave + fr) * 576 + fg * 8;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int row = (i * 4 + wave) * 8 + srow;            // halo pixel
-    const int hy = row / BT_HW, hx = row - hy * BT_HW;
-    const int y = y0 - 1 + hy, xx = x0 - 1 + hx;
-    const bool ok = (row < BT_HP) & ((unsigned)y < (unsigned)H) & ((unsigned)xx < (unsigned)W);
-    xrow[i] = ok ? ((img_base + (uint32_t)(y * W + xx)) * (uint32_t)Cin + (uint32_t)schunk * 8u) * 2u : SOD_OOB;
-  }
-  auto stage_x = [&](int kc) {     // 6 LDS-DMA loads per thread
-    char* dx = smem + (kc % 3) * SLOT + wave * 1024;
+    for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(dx + i * 4096), 16, xrow[i] + (uint32_t)kc * 128u, 0, 0, 0);
-  };
-  // W2 rows of this wave: taps 0-4 are requested in front of stage 1 (older than every x chunk, so the first counted wait covers
-  // them), taps 5-8 during the first taps of stage 2 (register pressure: 40 instead of 72 VGPRs live through stage 1)
-  const __bf16* p2 = a.w2 + (size_t)(16 * wave + fr) * 576 + fg * 8;
-#pragma unroll
-  for (int tap = 0; tap < 5; ++tap)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) a2[tap][ks] = *reinterpret_cast<const bf16x8_t*>(p2 + tap * 64 + ks * 32);
-  stage_x(0);
-  if (NK > 1) stage_x(1);
-  if (NK > 2) stage_x(2);               // all three ring slots are free at the start of a tile
-  __builtin_amdgcn_sched_barrier(0);      // the scheduler must not sink the register loads towards their first use
-  const f32x4_t bv0 = *reinterpret_cast<const f32x4_t*>(a.b3 + wave * 64 + (lane & 7) * 8);       // epilogue bias: requested first, so that
-  const f32x4_t bv1 = *reinterpret_cast<const f32x4_t*>(a.b3 + wave * 64 + (lane & 7) * 8 + 4);   // no late wait on it drains the stores
-  const f32x4_t b1v = *reinterpret_cast<const f32x4_t*>(a.b1 + 16 * wave + fg * 4);
-  const f32x4_t b2v = *reinterpret_cast<const f32x4_t*>(a.b2 + 16 * wave + fg * 4);
-
-  // fragment offset of row fr inside a [.][128 B] tile whose first row is a multiple of 16: the swizzle term depends on fr only
-  const uint32_t fo0 = swz_off(fr, fg), fo1 = fo0 ^ 64u;
-
-  // ================= stage 1: h1 = relu(W1 x + b1) on the halo; this wave: channels 16*wave .. +15, all 12 column tiles =============
-  {
-    f32x4_t acc[12];
-#pragma unroll
-    for (int j = 0; j < 12; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kc = 0; kc < NK; ++kc) {
-      // chunks 0-2 are requested up front, chunk c >= 3 in iteration c-2: chunk kc has landed when at most the loads of the chunks
-      // requested after it (6 each) are outstanding (any other load issued later only makes the wait stricter)
-      const int issued = (kc == 0) ? (NK < 3 ? NK : 3) : (kc + 2 < NK ? kc + 2 : NK);
-      const int younger = issued - kc - 1;                 // folds to a constant: the loop is fully unrolled
-      if (younger <= 0) wait_vm<0>(); else if (younger == 1) wait_vm<6>(); else wait_vm<12>();
-      __builtin_amdgcn_s_barrier();                        // ... for every wave; and everybody is done reading chunk kc-1
-      if (kc >= 1 && kc + 2 < NK) stage_x(kc + 2);         // into the slot of chunk kc-1
-      const char* cx = smem + (kc % 3) * SLOT;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const uint32_t fo = ks ? fo1 : fo0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          bf16x8_t bf[6];
-#pragma unroll
-          for (int j = 0; j < 6; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(cx + (h * 6 + j) * 2048 + fo);
-#pragma unroll
-          for (int j = 0; j < 6; ++j) acc[h * 6 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[kc][ks], bf[j], acc[h * 6 + j], 0, 0, 0);
-        }
-      }
-    }
-    // h1 overwrites slot 1 (chunk 1): with NK >= 3 the barrier of iteration 2 already proves every wave has finished reading it
-    if (NK == 2) __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      const int hp = j * 16 + fr;
-      const int hy = hp / BT_HW, hx = hp - hy * BT_HW;
-      const int y = y0 - 1 + hy, xx = x0 - 1 + hx;
-      const bool ok = (hp < BT_HP) & ((unsigned)y < (unsigned)H) & ((unsigned)xx < (unsigned)W);
-      bf16x4_t o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (__bf16)(ok ? fmaxf(acc[j][e] + b1v[e], 0.f) : 0.f);
-      *reinterpret_cast<bf16x4_t*>(smem + L_H1 + j * 2048 + swz_off(fr, 2 * wave + (fg >> 1)) + (fg & 1) * 8) = o;
-    }
-  }
-  lds_fence_barrier();                                     // h1 visible
-
-  // ================= stage 2: h2 = relu(W2 * h1 + b2); this wave: channels 16*wave .., the 8 tile rows =================
-  bf16x8_t a3[4][2], asc[PROJ ? 4 : 1][2];
-  {
-    f32x4_t acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int r = tap / 3, s = tap - r * 3;
-      if (tap < 4) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) a2[tap + 5][ks] = *reinterpret_cast<const bf16x8_t*>(p2 + (tap + 5) * 64 + ks * 32);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (tap == 5) {
-        // weights of stage 3 (this wave: output rows 64*wave .. +63): requested once most of W2's registers are free again
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            a3[i][ks] = *reinterpret_cast<const bf16x8_t*>(a.w3 + (size_t)((4 * wave + i) * 16 + fr) * 64 + ks * 32 + fg * 8);
-            if (PROJ) asc[i][ks] = *reinterpret_cast<const bf16x8_t*>(a.wsc + (size_t)((4 * wave + i) * 16 + fr) * Cin + ks * 32 + fg * 8);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8_t bf[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(smem + L_H1 + (swz_off((j + r) * BT_HW + s + fr, fg) ^ (uint32_t)(ks << 6)));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[tap][ks], bf[j], acc[j], 0, 0, 0);
-      }
-    }
-    // h2 goes to slot 2, which nobody reads any more (its x chunk was consumed before the barrier in front of h1)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      bf16x4_t o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(acc[j][e] + b2v[e], 0.f);
-      *reinterpret_cast<bf16x4_t*>(smem + L_H2 + j * 2048 + swz_off(fr, 2 * wave + (fg >> 1)) + (fg & 1) * 8) = o;
-    }
-  }
-  lds_fence_barrier();                                     // h2 visible; every wave is done with h1 (the epilogue reuses slot 1)
-
-  // ================= stage 3 + epilogue, in two halves of four tile rows (64 accumulator registers instead of 128) =================
-  // acc = W3 h2 (+ Wsc x); this wave: channels 64*wave .. +63.  acc[i][jj]: lane holds channels 64*wave + i*16 + fg*4 .. +3 of pixel
-  // (tile row 4*hh + jj, column fr).  Through per-wave LDS ([16 columns][64 channels] fp32) every lane gets 8 consecutive channels of one
-  // pixel: 16-B loads / stores, 128-B runs per pixel.
-  // Branch-free: residual loads and stores go through buffer resources, pixels outside the image use the out-of-range offset (the
-  // hardware returns zero / drops the store).  A lane-dependent branch around them made hipcc drain vmcnt(0) (stores included) per pass.
-  char* wl = smem + L_EPI + wave * (16 * EROWB);
-  const int erow = lane >> 3, eq = (lane & 7) * 8;
-  const int q = wave * 64 + eq;
-  auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
-  uint32_t dcol[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int xx = x0 + k * 8 + erow;
-    dcol[k] = (xx < W) ? ((uint32_t)xx * 256u + (uint32_t)q) * 2u : SOD_OOB;
-  }
-  const uint32_t img_row0 = (img_base + (uint32_t)(y0 * W)) * 512u;      // byte offset of (n, y0, 0, 0) in a 256-channel tensor
-  u32x4_t resv[PROJ ? 1 : 8][2];
-  if (!PROJ) {
-    // identity shortcut: all 16 loads of the lane are requested in front of the GEMM (x was just read: L2 / MALL hits)
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const uint32_t off = (y0 + j < H) ? img_row0 + (uint32_t)(j * W) * 512u + dcol[k] : SOD_OOB;
-        resv[j][k] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    f32x4_t acc[4][4];
+      for (int ks = 0; ks < 2; ++ks) a2[tap][ks] = *reinterpret_cast<const bf16x8_t*>(p2 + tap * 64 + ks * 32);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int ks = 0; ks < 2; ++ks) {
+        a3[i][ks] = *reinterpret_cast<const bf16x8_t*>(a.w3 + (size_t)((4 * wave + i) * 16 + fr) * 64 + ks * 32 + fg * 8);
+        if (PROJ) asc[i][ks] = *reinterpret_cast<const bf16x8_t*>(a.wsc + (size_t)((4 * wave + i) * 16 + fr) * Cin + ks * 32 + fg * 8);
+      }
+  }
+  const f32x4_t bv0 = *reinterpret_cast<const f32x4_t*>(a.b3 + wave * 64 + (lane & 7) * 8);
+  const f32x4_t bv1 = *reinterpret_cast<const f32x4_t*>(a.b3 + wave * 64 + (lane & 7) * 8 + 4);
+  const f32x4_t b1v = *reinterpret_cast<const f32x4_t*>(a.b1 + 16 * wave + fg * 4);
+  const f32x4_t b2v = *reinterpret_cast<const f32x4_t*>(a.b2 + 16 * wave + fg * 4);
+
+  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, a.x_bytes, 0x00020000);
+  auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+  const int srow = lane >> 3, spos = lane & 7;
+  const int schunk = spos ^ ((lane >> 4) | ((wave & 1) << 2));
+  const uint32_t fo0 = swz_off(fr, fg), fo1 = fo0 ^ 64u;
+  const int erow = lane >> 3, eq = (lane & 7) * 8;
+  const int q = wave * 64 + eq;
+  char* wl = smem + P_EPI + wave * (16 * EROWB);
+
+  // geometry of a tile; xrow = the six staging offsets of this thread (out-of-range for halo pixels outside the image / dead tiles)
+  struct Tile { int n, y0, x0; };
+  auto tile_of = [&](uint32_t t) {
+    Tile r;
+    r.n = (int)(t / tiles_per_img);
+    const uint32_t rem = t - (uint32_t)r.n * tiles_per_img;
+    const int ty = (int)(rem / (uint32_t)a.tiles_x);
+    r.y0 = ty * BT_TH; r.x0 = (int)(rem - (uint32_t)ty * (uint32_t)a.tiles_x) * BT_TW;
+    return r;
+  };
+  auto rows_of = [&](const Tile& tl, bool live, uint32_t (&xr)[6]) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const uint32_t fo = ks ? fo1 : fo0;
-      bf16x8_t bf[4];
+    for (int i = 0; i < 6; ++i) {
+      const int row = (i * 4 + wave) * 8 + srow;
+      const int hy = row / BT_HW, hx = row - hy * BT_HW;
+      const int y = tl.y0 - 1 + hy, xx = tl.x0 - 1 + hx;
+      const bool ok = live & (row < BT_HP) & ((unsigned)y < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+      xr[i] = ok ? (((uint32_t)tl.n * (uint32_t)H * (uint32_t)W + (uint32_t)(y * W + xx)) * (uint32_t)Cin + (uint32_t)schunk * 8u) * 2u : SOD_OOB;
+    }
+  };
+  auto stage_x = [&](const uint32_t (&xr)[6], int kc, int slot) {     // always exactly 6 LDS-DMA loads per thread
+    char* dx = smem + slot * SLOT + wave * 1024;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) bf[jj] = *reinterpret_cast<const bf16x8_t*>(smem + L_H2 + (hh * 4 + jj) * 2048 + fo);
+    for (int i = 0; i < 6; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(dx + i * 4096), 16, xr[i] + (uint32_t)kc * 128u, 0, 0, 0);
+  };
+
+  uint32_t xnext[6];
+  Tile cur = tile_of(first < ntiles ? first : 0);
+  rows_of(cur, first < ntiles, xnext);
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc) stage_x(xnext, kc, kc);            // first tile: all chunks in flight at once
+  // The counted waits below assume that everything older than a tile's chunks has completed; for the first tile that is the weight
+  // loads above (wherever the compiler scheduled them): drain once.
+  wait_vm<0>();
+  int it = 0;
+  for (uint32_t t = first; t < ntiles; t += G, ++it) {
+    const uint32_t tn = t + G;
+    const Tile nxt = tile_of(tn < ntiles ? tn : 0);
+    rows_of(nxt, tn < ntiles, xnext);                                 // a dead next tile stages zeros: the load counts stay uniform
+    const int y0 = cur.y0, x0 = cur.x0;
+    const uint32_t img_base = (uint32_t)cur.n * (uint32_t)H * (uint32_t)W;
+    const int pslot = PROJ ? (it & 1) : 0;                            // projection: the tile's single chunk lives in slot it & 1
+
+    // ================= stage 1 =================
+    {
+      f32x4_t acc[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < NK; ++kc) {
+        // younger than chunk kc of this tile: its later chunks, the previous tile's epilogue, the next tile's chunks 0 .. kc-2
+        const int younger = (NK - 1 - kc) + (kc >= 1 ? kc - 1 : 0);
+        if (younger == 0) wait_vm<EPI_OPS>(); else if (younger == 2) wait_vm<12 + EPI_OPS>(); else wait_vm<18 + EPI_OPS>();
+        __builtin_amdgcn_s_barrier();                      // chunk kc visible to every wave; every wave is done with chunk kc-1
+        if (NK > 1 && kc >= 1) stage_x(xnext, kc - 1, kc - 1);       // next tile's chunk kc-1 into the slot just released
+        const char* cx = smem + (PROJ ? pslot : kc) * SLOT;
+        // One wave per SIMD: nobody else hides an LDS round trip, so all 24 fragment reads of the chunk are issued before the first
+        // MFMA (hipcc otherwise emits read -> wait -> MFMA one by one); the MFMAs then start as the fragments arrive, in order.
+        bf16x8_t bf[2][12];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int j = 0; j < 12; ++j) bf[ks][j] = *reinterpret_cast<const bf16x8_t*>(cx + j * 2048 + (ks ? fo1 : fo0));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int j = 0; j < 12; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[kc][ks], bf[ks][j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const int hp = j * 16 + fr;
+        const int hy = hp / BT_HW, hx = hp - hy * BT_HW;
+        const int y = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool ok = (hp < BT_HP) & ((unsigned)y < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+        bf16x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(ok ? fmaxf(acc[j][e] + b1v[e], 0.f) : 0.f);
+        *reinterpret_cast<bf16x4_t*>(smem + P_H1 + j * 2048 + swz_off(fr, 2 * wave + (fg >> 1)) + (fg & 1) * 8) = o;
+      }
+    }
+    lds_fence_barrier();                                   // h1 visible; every wave is done with the last x chunk
+    if (PROJ) stage_x(xnext, 0, pslot ^ 1);                // the OTHER slot: this tile's chunk is still the shortcut's operand
+    else stage_x(xnext, NK - 1, NK - 1);
+
+    // ================= stage 2 =================
+    {
+      f32x4_t acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      // software pipeline over the taps: the 16 fragment reads of tap t+1 are in flight while the 16 MFMAs of tap t issue
+      bf16x8_t bf[2][2][8];
+      auto read_tap = [&](int tap, bf16x8_t (&dst)[2][8]) {
+        const int r = tap / 3, s = tap - r * 3;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dst[ks][j] = *reinterpret_cast<const bf16x8_t*>(smem + P_H1 + (swz_off((j + r) * BT_HW + s + fr, fg) ^ (uint32_t)(ks << 6)));
+      };
+      // (the projection variant also holds Wsc: one fragment buffer there, or the register file overflows into scratch)
+      constexpr bool PIPE = !PROJ;
+      if (PIPE) read_tap(0, bf[0]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (PIPE) { if (tap + 1 < 9) read_tap(tap + 1, bf[(tap + 1) & 1]); }
+        else read_tap(tap, bf[tap & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[tap][ks], bf[tap & 1][ks][j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bf16x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(acc[j][e] + b2v[e], 0.f);
+        *reinterpret_cast<bf16x4_t*>(smem + P_H2 + j * 2048 + swz_off(fr, 2 * wave + (fg >> 1)) + (fg & 1) * 8) = o;
+      }
+    }
+    lds_fence_barrier();                                   // h2 visible; every wave is done with h1
+
+    // ================= stage 3 + epilogue (two halves of four tile rows) =================
+    uint32_t dcol[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int xx = x0 + k * 8 + erow;
+      dcol[k] = (xx < W) ? ((uint32_t)xx * 256u + (uint32_t)q) * 2u : SOD_OOB;
+    }
+    const uint32_t img_row0 = (img_base + (uint32_t)(y0 * W)) * 512u;
+    u32x4_t resv[PROJ ? 1 : 8][2];
+    if (!PROJ) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const uint32_t off = (y0 + j < H) ? img_row0 + (uint32_t)(j * W) * 512u + dcol[k] : SOD_OOB;
+          resv[j][k] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      f32x4_t acc[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[i][ks], bf[jj], acc[i][jj], 0, 0, 0);
-    }
-    if (PROJ) {
-      // projection shortcut = one more contraction chunk of the same GEMM: B = x at the tile's own pixels = halo rows (j+1)*18 + fr + 1
+        for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      {
+        bf16x8_t bf[2][4];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8_t bf[4];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          bf[jj] = *reinterpret_cast<const bf16x8_t*>(smem + (swz_off((hh * 4 + jj + 1) * BT_HW + 1 + fr, fg) ^ (uint32_t)(ks << 6)));
+          for (int jj = 0; jj < 4; ++jj) bf[ks][jj] = *reinterpret_cast<const bf16x8_t*>(smem + P_H2 + (hh * 4 + jj) * 2048 + (ks ? fo1 : fo0));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asc[i][ks], bf[jj], acc[i][jj], 0, 0, 0);
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[i][ks], bf[ks][jj], acc[i][jj], 0, 0, 0);
       }
-    }
+      if (PROJ) {
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int j = hh * 4 + jj;
-      const uint32_t rowoff = (y0 + j < H) ? img_row0 + (uint32_t)(j * W) * 512u : SOD_OOB;
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8_t bf[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_t*>(wl + fr * EROWB + (i * 16 + fg * 4) * 4) = acc[i][jj];
+          for (int jj = 0; jj < 4; ++jj)
+            bf[jj] = *reinterpret_cast<const bf16x8_t*>(smem + pslot * SLOT + (swz_off((hh * 4 + jj + 1) * BT_HW + 1 + fr, fg) ^ (uint32_t)(ks << 6)));
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int row = k * 8 + erow;
-        const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(wl + row * EROWB + eq * 4);
-        const f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(wl + row * EROWB + eq * 4 + 16);
-        float v[8] = {t0[0] + bv0[0], t0[1] + bv0[1], t0[2] + bv0[2], t0[3] + bv0[3], t1[0] + bv1[0], t1[1] + bv1[1], t1[2] + bv1[2], t1[3] + bv1[3]};
-        if (!PROJ) {
-          const u32x4_t rv = resv[PROJ ? 0 : j][k];
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {        // bf16 pair -> two floats
-            v[2 * e] += __uint_as_float(rv[e] << 16);
-            v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u);
-          }
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(asc[i][ks], bf[jj], acc[i][jj], 0, 0, 0);
         }
-        bf16x8_t o;
+      }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e], 0.f);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), orsrc, (rowoff | dcol[k]) & SOD_OOB ? SOD_OOB : rowoff + dcol[k], 0, 0);
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = hh * 4 + jj;
+        const uint32_t rowoff = (y0 + j < H) ? img_row0 + (uint32_t)(j * W) * 512u : SOD_OOB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4_t*>(wl + fr * EROWB + (i * 16 + fg * 4) * 4) = acc[i][jj];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int row = k * 8 + erow;
+          const f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(wl + row * EROWB + eq * 4);
+          const f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(wl + row * EROWB + eq * 4 + 16);
+          float v[8] = {t0[0] + bv0[0], t0[1] + bv0[1], t0[2] + bv0[2], t0[3] + bv0[3], t1[0] + bv1[0], t1[1] + bv1[1], t1[2] + bv1[2], t1[3] + bv1[3]};
+          if (!PROJ) {
+            const u32x4_t rv = resv[PROJ ? 0 : j][k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] += __uint_as_float(rv[e] << 16);
+              v[2 * e + 1] += __uint_as_float(rv[e] & 0xffff0000u);
+            }
+          }
+          bf16x8_t o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (__bf16)fmaxf(v[e], 0.f);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), orsrc, (rowoff | dcol[k]) & SOD_OOB ? SOD_OOB : rowoff + dcol[k], 0, 0);
+        }
       }
     }
+    cur = nxt;
   }
+  wait_vm<0>();      // the dead next tile's zero-fill loads must have landed before the LDS allocation goes back
 }
 
 template <int NK, bool PROJ>
-int launch_bneck(const BneckArgs& a, long long blocks, hipStream_t st) {
+int launch_bneck(const BneckArgs& a, hipStream_t st) {
+  constexpr int NR = (NK == 1) ? 2 : NK;
+  constexpr int lds = NR * SLOT + SLOT + 128 * BT_ROWB + 4 * 16 * EROWB;
   auto kern = bottleneck_frozen_kernel<NK, PROJ>;
-  static bool attr_done = false;                           // process-wide; idempotent
+  static bool attr_done = false;
+  static int cus = 0;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     attr_done = true;
   }
-  SOD_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), L_TOTAL, st, a);
+  const long long ntiles = (long long)a.N * a.tiles_x * a.tiles_y;
+  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+  SOD_LAUNCH(kern, dim3(grid), dim3(256), lds, st, a);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -336,7 +370,6 @@ extern "C" int sod_bottleneck_frozen_fwd(const void* x, int N, int H, int W, int
   a.N = N; a.H = H; a.W = W;
   a.tiles_x = (W + BT_TW - 1) / BT_TW;
   a.tiles_y = (H + BT_TH - 1) / BT_TH;
-  const long long blocks = (long long)N * a.tiles_x * a.tiles_y;
-  if (blocks >= (1ll << 31)) return SOD_ESIZE;
-  return wsc ? launch_bneck<1, true>(a, blocks, (hipStream_t)stream) : launch_bneck<4, false>(a, blocks, (hipStream_t)stream);
+  if ((long long)N * a.tiles_x * a.tiles_y >= (1ll << 31)) return SOD_ESIZE;
+  return wsc ? launch_bneck<1, true>(a, (hipStream_t)stream) : launch_bneck<4, false>(a, (hipStream_t)stream);
 }

@@ -85,3 +85,35 @@ def test_fastdiv_host_model():
         for n in [0, 1, d - 1, d, d + 1, 2 * d - 1, (1 << 31) - 1] + [random.randrange(1 << 31) for _ in range(200)]:
             got = n if d == 1 else (((n * mul) >> 32) + n) >> shr
             assert got == n // d, (n, d)
+
+
+def test_counted_wait_kernels_do_not_spill(tmp_path):
+    """The kernels that pace their LDS-DMA pipelines with counted ``s_waitcnt vmcnt(N)`` (bottleneck_fused.hip, conv_igemm256.hip,
+    conv_wgrad256.hip) derive N from the vector-memory instructions they issue themselves; scratch (spill) accesses would join that
+    count.  hipcc cross-compiles for gfx950 without a GPU: no kernel of these files may report a spilled register."""
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "slenderobjdet_amd", "csrc")
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    files = ["bottleneck_fused", "conv_igemm256", "conv_wgrad256"]
+    procs = []
+    for f in files:
+        d = tmp_path / f
+        d.mkdir()
+        procs.append((f, d, subprocess.Popen([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-ffp-contract=off",
+                                              "-save-temps=obj", "-c", os.path.join(src, f + ".hip"), "-o", str(d / (f + ".o"))],
+                                             cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for f, d, p in procs:
+        out, _ = p.communicate(timeout=900)
+        assert p.returncode == 0, out.decode()[-2000:]
+        asm = [x for x in os.listdir(d) if x.endswith("gfx950.s")]
+        assert asm, os.listdir(d)
+        text = open(d / asm[0]).read()
+        spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]      # (SGPR spills go to VGPR lanes, not to memory)
+        assert spills and max(spills) == 0, (f, spills)
+        assert "scratch_" not in text, f
