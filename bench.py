@@ -219,8 +219,8 @@ def pmc_traffic(kind, kernel_name_):
 
 def cpu_baseline(model, args):
     """Time the CPU oracle (oracle/model.py) on a bounded sample of the same workload, host cores of this box.  SURVEY.md §8(d) asks
-    for 3 warm-up + 10 timed iterations; a 16-image CPU step takes ~20 s, so the sample is bounded to ``--cpu-images`` images per step
-    and ``--cpu-warmup`` + ``--cpu-steps`` steps (stated in `sample`)."""
+    for 3 warm-up + 10 timed iterations: that is the default (``--cpu-warmup`` / ``--cpu-steps``); a 16-image CPU step takes ~20 s, so the
+    sample is bounded to ``--cpu-images`` (2) images per step - about 35 s in all - and says so in `sample`."""
     from oracle.model import OracleFCOS
     from slenderobjdet_amd.data import synthetic_batch
 
@@ -303,8 +303,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=16)
     ap.add_argument("--cpu-images", type=int, default=2)
-    ap.add_argument("--cpu-warmup", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-warmup", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--depth", type=int, default=50, help="ResNet depth (tests use 18; the benchmark is R50)")
     ap.add_argument("--height", type=int, default=800)
