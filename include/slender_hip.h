@@ -77,10 +77,12 @@ int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const float* qsca
 /* 1-bit ReLU masks for the bottleneck backward (detectron2 BottleneckBlock: out = relu(conv3 + shortcut), whose mask the backward
  * pass of the NEXT block's first conv applies to d(out)): sod_conv2d_fwd_bits is sod_conv2d_fwd with dense bf16 output that also
  * writes bit i of relu_bits (uint8[N*Ho*Wo*K/8], bit e of byte j = element 8j+e) = "stored y[i] > 0"; sod_conv2d_dgrad_bits is
- * sod_conv2d_dgrad whose mask operand is such a bit array of dx's shape (1/16 of the bytes of the bf16 tensor it replaces). */
+ * sod_conv2d_dgrad whose mask operand is such a bit array of dx's shape (1/16 of the bytes of the bf16 tensor it replaces).
+ * accum_even != 0: accum is (N, H/2, W/2, C) and is added at EVEN (h, w) only - the compact data gradient of the next stage's
+ * stride-2 1x1 convolutions (STRIDE_IN_1X1), which the un-fused path scatters into a zero tensor of dx's shape first. */
 int sod_conv2d_fwd_bits(const void* x, const void* w, const float* bias, const void* res, void* y, void* relu_bits,
                         int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int flags, void* stream);
-int sod_conv2d_dgrad_bits(const void* dy, const void* wt, const void* accum, const void* relu_bits, void* dx,
+int sod_conv2d_dgrad_bits(const void* dy, const void* wt, const void* accum, int accum_even, const void* relu_bits, void* dx,
                           int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, void* stream);
 
 /* Multi-level forms: ONE launch applies the same weights to `nlev` tensors (the FPN levels the FCOS towers and

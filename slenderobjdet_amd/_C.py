@@ -24,7 +24,7 @@ _SIGS = {
     "sod_conv2d_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _I, _P],
     "sod_conv2d_dgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _P],
     "sod_conv2d_fwd_bits": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "sod_conv2d_dgrad_bits": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "sod_conv2d_dgrad_bits": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sod_conv2d_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _I, _P, _L, _P],
     "sod_conv2d_wgrad_workspace_bytes": [],
     "sod_conv2d_fwd_ml": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P],

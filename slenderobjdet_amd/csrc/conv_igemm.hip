@@ -343,6 +343,7 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
       bool ok[NP];
       int nimg[NP];
       uint32_t mbits[NP];
+      bool odd[NP];
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         const int row = k * ERPP + erow;
@@ -360,8 +361,10 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
               const uint32_t ph = fd_div(rem, g.div_w);
               const uint32_t pw = rem - ph * g.div_w.d;
               res_row = (size_t)n * g.res_img_stride + (size_t)((ph >> 1) * (g.Wp >> 1) + (pw >> 1)) * Nout;
-            } else {
+              if constexpr (MODE == MODE_DGRAD && !OUT_F32) odd[k] = (a.flags & F_RES_EVEN) && ((ph | pw) & 1u);   // loaded anyway (no lane-
+            } else {                                                                                                // dependent branch), not added
               res_row = (size_t)n * g.res_img_stride + (size_t)rem * Nout;
+              if constexpr (MODE == MODE_DGRAD && !OUT_F32) odd[k] = false;
             }
             resv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.res + res_row + q);
           }
@@ -392,8 +395,13 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
             for (int e = 0; e < EPL; ++e) v[e] += bv[e];
           }
           if (a.flags & (F_RES | F_RES_UP2)) {
+            if constexpr (MODE == MODE_DGRAD && !OUT_F32) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) v[e] += (float)resv[k][e];
+              for (int e = 0; e < EPL; ++e) v[e] += odd[k] ? 0.f : (float)resv[k][e];
+            } else {
+#pragma unroll
+              for (int e = 0; e < EPL; ++e) v[e] += (float)resv[k][e];
+            }
           }
           if (a.flags & F_RELU) {
 #pragma unroll
@@ -1226,9 +1234,10 @@ extern "C" int sod_conv2d_dgrad(const void* dy, const void* wt, const void* accu
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 
-extern "C" int sod_conv2d_dgrad_bits(const void* dy, const void* wt, const void* accum, const void* relu_bits, void* dx,
+extern "C" int sod_conv2d_dgrad_bits(const void* dy, const void* wt, const void* accum, int accum_even, const void* relu_bits, void* dx,
                                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, void* stream) {
   if (!dy || !wt || !dx || !relu_bits || (C & 7)) return SOD_EARG;
+  if (accum_even && (!accum || (H & 1) || (W & 1))) return SOD_EARG;
   const int Ho = out_size(H, pad, dil, R, stride), Wo = out_size(W, pad, dil, S, stride);
   if (Ho <= 0 || Wo <= 0) return SOD_EARG;
   ConvArgs a{};
@@ -1239,7 +1248,11 @@ extern "C" int sod_conv2d_dgrad_bits(const void* dy, const void* wt, const void*
   a.w = wt; a.bias = nullptr;
   a.flags = F_MASKBITS;
   a.lev[0].mask = relu_bits;
-  if (accum) { a.flags |= F_RES; a.lev[0].res = accum; a.lev[0].res_img_stride = a.lev[0].dst_img_stride; }
+  if (accum && accum_even) {       // accum is (N, H/2, W/2, C): the compact data gradient of a stride-2 1x1 consumer
+    a.flags |= F_RES_UP2 | F_RES_EVEN; a.lev[0].res = accum; a.lev[0].res_img_stride = (H / 2) * (W / 2) * C;
+  } else if (accum) {
+    a.flags |= F_RES; a.lev[0].res = accum; a.lev[0].res_img_stride = a.lev[0].dst_img_stride;
+  }
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 

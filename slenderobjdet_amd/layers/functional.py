@@ -198,7 +198,8 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
     return out
 
 
-def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=None, dy_img_stride=0, dy_shape=None, out=None, relu_bits=None):
+def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=None, dy_img_stride=0, dy_shape=None, out=None, relu_bits=None,
+                 accum_even=False):
     """dy (N,Ho,Wo,K) bf16, wt (C,R,S,K) bf16 (transposed weights) -> dx (N,H,W,C) bf16."""
     _chk(dy, torch.bfloat16, "dy"); _chk(wt, torch.bfloat16, "wt"); _chk(accum, torch.bfloat16, "accum"); _chk(relu_mask, torch.bfloat16, "relu_mask")
     N = dy_shape[0] if dy_shape is not None else dy.shape[0]
@@ -211,8 +212,13 @@ def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=Non
         _chk(relu_bits, torch.uint8, "relu_bits")
         if relu_mask is not None or dy_img_stride or relu_bits.numel() * 8 != out.numel():
             raise _C.SlenderHipError("conv2d_dgrad: relu_bits replaces relu_mask and needs 8 * relu_bits.numel() == dx.numel()")
-        call("sod_conv2d_dgrad_bits", ptr(dy), ptr(wt), ptr(accum), ptr(relu_bits), ptr(out), N, H, W, C, K, R, S, stride, pad, dil, stream_ptr())
+        if accum_even and (accum is None or tuple(accum.shape) != (N, H // 2, W // 2, C) or H % 2 or W % 2):
+            raise _C.SlenderHipError("conv2d_dgrad: accum_even needs accum of shape (N, H/2, W/2, C) with even H, W")
+        call("sod_conv2d_dgrad_bits", ptr(dy), ptr(wt), ptr(accum), 1 if accum_even else 0, ptr(relu_bits), ptr(out), N, H, W, C, K, R, S, stride,
+             pad, dil, stream_ptr())
     else:
+        if accum_even:
+            raise _C.SlenderHipError("conv2d_dgrad: accum_even is available with relu_bits only")
         call("sod_conv2d_dgrad", ptr(dy), ptr(wt), ptr(accum), ptr(relu_mask), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
              dy_img_stride, 0, stream_ptr())
     Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)

@@ -27,11 +27,15 @@ class DeferSlot:
     dgrad store).  Instead the stage publishes a slot for its output (``offer``); the lateral conv that consumes exactly that tensor
     takes it (``take``), and in backward leaves its output gradient here instead of running its dgrad; the stage's backward - which
     autograd runs after every consumer - runs that dgrad itself with ``accum`` = the other consumers' gradient and ``relu_mask`` =
-    the stage output: read accum, read mask, write = 3 passes."""
+    the stage output: read accum, read mask, write = 3 passes.  The NEXT stage defers as well when its first block opens with stride-2
+    1x1 convolutions (STRIDE_IN_1X1): only the even (h, w) positions of its input receive gradient, so it leaves the COMPACT
+    (N, H/2, W/2, C) gradient in ``comp`` instead of scattering it into a zero tensor of the full shape, and the producer's fused
+    launch adds it at the even positions (``accum_even``)."""
     _offers = {}
 
     def __init__(self):
         self.g = self.mod = None
+        self.comp = None          # compact (N, H/2, W/2, C) data gradient of the next stage's stride-2 1x1 convs (see resnet.py)
 
     @classmethod
     def reset(cls):
@@ -46,7 +50,9 @@ class DeferSlot:
 
     @classmethod
     def take(cls, tensor):
-        return cls._offers.pop((tensor.data_ptr(), tuple(tensor.shape)), None)
+        """The slot offered for ``tensor`` (None if its producer made no offer).  Offers stay registered until the next backbone forward:
+        a stage output has up to two deferring consumers, the FPN lateral conv and the next stage."""
+        return cls._offers.get((tensor.data_ptr(), tuple(tensor.shape)))
 
 
 import os as _os

@@ -22,6 +22,9 @@ BNECK_FUSED = os.environ.get("SOD_BNECK_FUSED", "1") != "0"
 # ReLU masks of the block outputs of a trainable bottleneck stage as 1 bit per element, written by the conv3 epilogue and read by the
 # data gradient that folds the mask in (1/16 of the bytes of re-reading the bf16 block output); SOD_RELU_BITS=0 re-reads the tensor
 RELU_BITS = os.environ.get("SOD_RELU_BITS", "1") != "0"
+# A stage whose first block opens with stride-2 1x1 convolutions hands its input gradient to the producing stage in compact form
+# (layers/nn.py DeferSlot.comp) instead of a zero-stuffed full-resolution tensor; SOD_COMPACT_S2_GRAD=0 scatters it as before
+COMPACT_S2_GRAD = os.environ.get("SOD_COMPACT_S2_GRAD", "1") != "0"
 from .build import BACKBONE_REGISTRY, Backbone
 
 
@@ -101,6 +104,12 @@ class _BottleneckStageFn(torch.autograd.Function):
             saved += [a, b, out]
         ctx.stage = stage
         ctx.slot = None
+        # the producer of x may take this stage's input gradient in compact form (DeferSlot.comp): first block = stride-2 1x1 convs
+        b0 = blocks[0]
+        ctx.in_slot = None
+        if (x.requires_grad and COMPACT_S2_GRAD and b0.shortcut is not None and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+                and all(m.kernel_size == 1 and m.stride == 2 and m.padding == 0 for m in (b0.shortcut, b0.conv1))):
+            ctx.in_slot = DeferSlot.take(x)
         ctx.nbits = len(bits) if len(bits) == len(blocks) else 0
         if need_bwd:
             ctx.save_for_backward(*saved, *(bits if ctx.nbits else []))
@@ -128,11 +137,21 @@ class _BottleneckStageFn(torch.autograd.Function):
 
         arena = _arena_of(blocks[0].conv1)
         slot, ctx.slot = ctx.slot, None
+        comp = None
+        if slot is not None and slot.comp is not None:      # the next stage left its input gradient in compact (even-pixel) form
+            comp, slot.comp = slot.comp, None
+            if not (slot.g is not None and dout is None and bits is not None):
+                dense = _scatter_even(comp, saved[-1].shape)
+                dout, comp = dense if dout is None else HF.add_bf16(dout.contiguous(), dense), None
         if slot is not None and slot.g is not None:
             # d(out) = dgrad(lateral 1x1, its output gradient) + the other consumers' gradient, times the ReLU mask of out: one launch
             lat = slot.mod
-            g = HF.conv2d_dgrad(slot.g, lat.wt_bf16, (saved[-1].shape[1], saved[-1].shape[2]), 1, 0, 1,
-                                accum=None if dout is None else dout.contiguous(), **mask_of(len(blocks) - 1))
+            if comp is not None:
+                g = HF.conv2d_dgrad(slot.g, lat.wt_bf16, (saved[-1].shape[1], saved[-1].shape[2]), 1, 0, 1, accum=comp, accum_even=True,
+                                    relu_bits=bits[len(blocks) - 1])
+            else:
+                g = HF.conv2d_dgrad(slot.g, lat.wt_bf16, (saved[-1].shape[1], saved[-1].shape[2]), 1, 0, 1,
+                                    accum=None if dout is None else dout.contiguous(), **mask_of(len(blocks) - 1))
             slot.g = slot.mod = None
         elif dout is None:
             return None, None, None
@@ -152,7 +171,12 @@ class _BottleneckStageFn(torch.autograd.Function):
                 _wgrad(blk.shortcut, g, xin, arena)
             if k == 0:
                 if ctx.needs_input_grad[0]:
-                    if blk.shortcut is not None:
+                    if ctx.in_slot is not None:      # compact gradient for the producer's fused launch; autograd sees no gradient here
+                        Ho, Wo = g.shape[1], g.shape[2]
+                        part = HF.conv2d_dgrad(da, blk.conv1.wt_bf16, (Ho, Wo), 1, 0, 1)
+                        ctx.in_slot.comp = HF.conv2d_dgrad(g, blk.shortcut.wt_bf16, (Ho, Wo), 1, 0, 1, accum=part)
+                        ctx.in_slot = None
+                    elif blk.shortcut is not None:
                         dx = _dgrad_pair_into_input(blk, g, da, xin)
                     else:
                         dx = _dgrad(blk.conv1, da, xin, accum=g)
@@ -177,6 +201,13 @@ def _wgrad(m, g, x, arena):
 def _dgrad(m, g, x, accum=None, relu_mask=None, relu_bits=None):
     return HF.conv2d_dgrad(g, m.wt_bf16, (x.shape[1], x.shape[2]), m.stride, m.padding, m.dilation, accum=accum, relu_mask=relu_mask,
                            relu_bits=relu_bits)
+
+
+def _scatter_even(comp, shape):
+    """(N, H/2, W/2, C) gradient of the even (h, w) positions -> zero-stuffed (N, H, W, C)."""
+    dx = torch.zeros(shape, dtype=comp.dtype, device=comp.device)
+    dx[:, ::2, ::2, :] = comp
+    return dx
 
 
 def _dgrad_pair_into_input(blk, g, da, xin):

@@ -617,3 +617,43 @@ def test_groupnorm_backward_reduction_in_the_consumer_dgrad(cuda):
     finally:
         HF.conv2d_dgrad_ml_gnbwd = orig
         HN.GN_BWD_FUSED = prev_flag
+
+
+def test_compact_stride2_input_gradient_is_bit_identical(cuda):
+    """A bottleneck stage that opens with stride-2 1x1 convolutions leaves its input gradient in compact (N, H/2, W/2, C) form to the
+    producing stage, whose fused launch adds it at the even positions (resnet.COMPACT_S2_GRAD, layers/nn.py DeferSlot.comp) instead of
+    scattering it into a zero tensor first: losses and every gradient are bit-identical (deterministic mode) with and without."""
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.modeling.backbone import resnet
+
+    cfg, model, opt = _build(50, seed=10)
+    data = synthetic_batch(2, 320, 384, 15, device="cuda")
+    prev, HF.DETERMINISTIC = HF.DETERMINISTIC, True
+    calls = {"even": 0}
+    orig = HF.conv2d_dgrad
+
+    def counting(*a, **k):
+        calls["even"] += int(bool(k.get("accum_even")))
+        return orig(*a, **k)
+
+    try:
+        def step(on):
+            resnet.COMPACT_S2_GRAD = on
+            opt.zero_grad()
+            out = model(data)
+            total = sum(out.values())
+            model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+            return {k: float(v.detach()) for k, v in out.items()}, model.arena.grads.clone()
+
+        ref_l, ref_g = step(False)
+        HF.conv2d_dgrad = counting
+        got_l, got_g = step(True)
+        HF.conv2d_dgrad = orig
+        assert calls["even"] == 2, calls          # res3 <- res4 and res4 <- res5
+        assert got_l == ref_l
+        assert torch.equal(got_g, ref_g)
+    finally:
+        HF.conv2d_dgrad = orig
+        resnet.COMPACT_S2_GRAD = True
+        HF.DETERMINISTIC = prev
