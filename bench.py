@@ -299,8 +299,8 @@ def spawn_ranks(args, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch-per-gpu", type=int, default=16)
     ap.add_argument("--cpu-images", type=int, default=2)
     ap.add_argument("--cpu-warmup", type=int, default=3)
