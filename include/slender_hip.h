@@ -113,6 +113,12 @@ int sod_conv2d_dgrad_ml_gnbwd(int nlev, const void* const* dy, const void* wt, v
                               int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                               long long dy_img_stride, const void* const* gn_x, const float* gn_mean_rstd, const float* gamma,
                               const float* beta, float* gn_red, float* dgamma, float* dbeta, int G, void* stream);
+/* sod_conv2d_dgrad_ml with the ReLU backward of the tensors dx is the gradient of folded into the epilogue: dx[l] = relu_mask[l] > 0 ?
+ * (data gradient) : 0, relu_mask[l] = the post-ReLU tensor (bf16, dx[l]'s shape).  Consecutive [conv3x3 -> ReLU] tower units
+ * (RetinaNetHead, retina_rotated.py:418-430): the consumer's data gradient applies the producer's mask, one launch per level less. */
+int sod_conv2d_dgrad_ml_mask(int nlev, const void* const* dy, const void* wt, const void* const* relu_mask, void* const* dx,
+                             int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                             long long dy_img_stride, void* stream);
 int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, float* dw, const float* qscale,
                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                         long long dy_img_stride, int splits, int flags, void* ws, long long ws_bytes, void* stream);

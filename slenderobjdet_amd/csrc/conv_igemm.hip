@@ -1273,6 +1273,24 @@ extern "C" int sod_conv2d_dgrad_ml(int nlev, const void* const* dy, const void* 
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 
+extern "C" int sod_conv2d_dgrad_ml_mask(int nlev, const void* const* dy, const void* wt, const void* const* relu_mask, void* const* dx,
+                                        int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                        long long dy_img_stride, void* stream) {
+  if (!dy || !wt || !dx || !relu_mask || !H || !W) return SOD_EARG;
+  ConvArgs a{};
+  int rc = fill_common(a, nlev, N, K, C, R, S, stride, pad, dil);
+  if (rc) return rc;
+  for (int l = 0; l < nlev; ++l) {
+    const int Ho = out_size(H[l], pad, dil, R, stride), Wo = out_size(W[l], pad, dil, S, stride);
+    if (Ho <= 0 || Wo <= 0 || !relu_mask[l]) return SOD_EARG;
+    rc = fill_level(a, l, dy[l], dx[l], Ho, Wo, H[l], W[l], dy_img_stride, 0, 2);
+    if (rc) return rc;
+    a.lev[l].mask = relu_mask[l];
+  }
+  a.w = wt; a.bias = nullptr; a.flags = F_MASK;
+  return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
+}
+
 extern "C" int sod_conv_last_variant(void) { return g_last_variant; }
 
 extern "C" int sod_conv_prof_enable(int on) {

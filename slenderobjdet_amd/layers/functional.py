@@ -312,8 +312,9 @@ def conv_gn_fwd_ml(xs, w, bias, gamma, beta, G, eps=1e-5, relu=True, pad=1):
     return outs, ys, stats
 
 
-def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=None, k_real=None):
-    """dys: per-level dY tensors (or 1-D views into a concatenated buffer with dy_img_stride); returns per-level dX."""
+def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=None, k_real=None, relu_masks=None):
+    """dys: per-level dY tensors (or 1-D views into a concatenated buffer with dy_img_stride); returns per-level dX.  ``relu_masks``:
+    the post-ReLU tensors dX is the gradient of - the ReLU backward is then applied in the epilogue (dX = mask > 0 ? dX : 0)."""
     _chk(wt, torch.bfloat16, "wt")
     C, R, S, K = wt.shape
     if N is None:
@@ -321,8 +322,16 @@ def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=N
     dev = dys[0].device
     outs = [torch.empty((N, h, w, C), dtype=torch.bfloat16, device=dev) for h, w in x_hws]
     e0 = _prof_begin(None, "conv_dgrad")
-    call("sod_conv2d_dgrad_ml", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]), _int_arr([w for _, w in x_hws]),
-         C, K, R, S, stride, pad, dil, dy_img_stride, stream_ptr())
+    if relu_masks is not None:
+        for t, o in zip(relu_masks, outs):
+            _chk(t, torch.bfloat16, "relu_mask")
+            if tuple(t.shape) != tuple(o.shape):
+                raise _C.SlenderHipError("conv2d_dgrad_ml: relu_masks must have the data gradients' shapes")
+        call("sod_conv2d_dgrad_ml_mask", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(relu_masks), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]),
+             _int_arr([w for _, w in x_hws]), C, K, R, S, stride, pad, dil, dy_img_stride, stream_ptr())
+    else:
+        call("sod_conv2d_dgrad_ml", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]), _int_arr([w for _, w in x_hws]),
+             C, K, R, S, stride, pad, dil, dy_img_stride, stream_ptr())
     fl = sum(2.0 * N * ho * wo * (k_real or K) * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in x_hws))
     _prof_end("conv_dgrad", fl, e0, ("ml", N, tuple(h for h, _ in x_hws), C, K, R, stride))
     return outs

@@ -352,29 +352,58 @@ class _ConvGnReluFn(torch.autograd.Function):
         return (None, None, None, *dxs)
 
 
+class _ReluToken:
+    """Shared by a ConvReluML unit and the unit that consumes its outputs as their ONLY consumer: the consumer's data gradient applies
+    this unit's ReLU mask in its epilogue (sod_conv2d_dgrad_ml_mask), so this unit's backward skips its relu_bwd launches."""
+
+    def __init__(self, outs):
+        self.out_ptrs = [(t.data_ptr(), tuple(t.shape)) for t in outs]
+        self.premasked = False
+
+    def matches(self, xs):
+        return len(xs) == len(self.out_ptrs) and all((x.data_ptr(), tuple(x.shape)) == k for x, k in zip(xs, self.out_ptrs))
+
+
+# SOD_RELU_CHAIN=0: every ConvReluML unit masks its own incoming gradient (one relu_bwd launch per level)
+RELU_CHAIN = _os.environ.get("SOD_RELU_CHAIN", "1") != "0"
+
+
 class ConvReluML(nn.Module):
     """[Conv3x3(bias) -> ReLU] tower unit of RetinaNetHead (retina_rotated.py:418-430) over all FPN levels in one launch."""
 
     def __init__(self, channels):
         super().__init__()
         self.conv = HipConv2d(channels, channels, 3, 1, 1, bias=True)
+        self._last_token = None
 
-    def forward(self, xs):
+    def forward(self, xs, chained=None):
+        """``chained``: the ConvReluML unit whose latest forward produced ``xs`` and that has no other consumer (the previous unit of
+        a tower): this unit's data gradient then applies that unit's ReLU mask in its epilogue."""
         self.conv.prepare()
-        return list(_ConvReluMLFn.apply(self.conv.weight, self, *xs))
+        tok = None
+        if RELU_CHAIN and chained is not None and chained._last_token is not None and chained._last_token.matches(xs):
+            tok = chained._last_token
+        return list(_ConvReluMLFn.apply(self.conv.weight, self, tok, *xs))
 
 
 class _ConvReluMLFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, weight, unit, *xs):
+    def forward(ctx, weight, unit, in_token, *xs):
         conv = unit.conv
         ys = HF.conv2d_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, 1, 1, 1, relu=True)
         ctx.unit, ctx.nl = unit, len(xs)
         ctx.save_for_backward(*xs, *ys)
+        ctx.in_token = in_token
+        ctx.token = unit._last_token = None
         arena = _arena_of(conv)
         if arena is not None and conv.weight.requires_grad:
             arena.note_use(conv.weight)
             arena.note_use(conv.bias)
+            ctx.token = unit._last_token = _ReluToken(ys)
+        if in_token is not None and all(x.requires_grad for x in xs):
+            in_token.premasked = True          # decided in forward: the producer's backward runs after ours and relies on it
+        else:
+            ctx.in_token = None
         return tuple(ys)
 
     @staticmethod
@@ -384,7 +413,10 @@ class _ConvReluMLFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         xs, ys = saved[:nl], saved[nl:]
         arena = _arena_of(conv)
-        gs = [HF.relu_bwd(dy.contiguous(), y) for dy, y in zip(dys, ys)]
+        if ctx.token is not None and ctx.token.premasked:      # the consumer's data gradient already applied this unit's ReLU mask
+            gs = [dy.contiguous() for dy in dys]
+        else:
+            gs = [HF.relu_bwd(dy.contiguous(), y) for dy, y in zip(dys, ys)]
         HF.conv2d_wgrad_ml(gs, list(xs), arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
         arena.mark_ready(conv.weight)
         dbias = arena.grad_view(conv.bias)
@@ -393,9 +425,10 @@ class _ConvReluMLFn(torch.autograd.Function):
             HF.bias_grad(g, dbias, N, H * W, C)
         arena.mark_ready(conv.bias)
         dxs = [None] * nl
-        if any(ctx.needs_input_grad[2:]):
-            dxs = HF.conv2d_dgrad_ml(gs, conv.wt_bf16, [(x.shape[1], x.shape[2]) for x in xs], 1, 1, 1)
-        return (None, None, *dxs)
+        if any(ctx.needs_input_grad[3:]):
+            hw = [(x.shape[1], x.shape[2]) for x in xs]
+            dxs = HF.conv2d_dgrad_ml(gs, conv.wt_bf16, hw, 1, 1, 1, relu_masks=list(xs) if ctx.in_token is not None else None)
+        return (None, None, None, *dxs)
 
 
 class ConvML(nn.Module):

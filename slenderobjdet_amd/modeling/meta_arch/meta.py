@@ -23,6 +23,15 @@ from torch import nn
 from ...layers import functional as HF
 from ...layers.deform_conv import DeformConv
 from ...layers.nn import ConvGnRelu, ConvML, ConvReluML, HipConv2d
+
+
+def _run_tower(units, xs):
+    """A tower of [conv -> (GroupNorm) -> ReLU] units: every unit is told which unit produced its input (that unit's ONLY consumer), so
+    that its data gradient can take over the producer's ReLU backward (layers/nn.py _ReluToken / GnBwdSlot)."""
+    prev = None
+    for u in units:
+        xs, prev = u(xs, chained=prev), u
+    return xs
 from ...structures import Boxes, Instances
 from ...utils.registry import Registry
 from ..backbone import build_backbone
@@ -117,10 +126,7 @@ class PointSetHead(nn.Module):
 
     def run_head(self, features):
         cls_f, loc_f = list(features), list(features)
-        for u in self.cls_subnet:
-            cls_f = u(cls_f)
-        for u in self.loc_subnet:
-            loc_f = u(loc_f)
+        cls_f, loc_f = _run_tower(self.cls_subnet, cls_f), _run_tower(self.loc_subnet, loc_f)
         oi = self.loc_init_out(self.loc_init_conv(loc_f))
         if self.feat_adaption == "Empty":
             return oi, self.cls_conv(cls_f), self.loc_refine_conv(loc_f)
@@ -383,10 +389,7 @@ class LRTBHead(nn.Module):
         """-> per level: cls logits (N,H,W,K), centerness logits (N,H,W), init / refine distances (N,H,W,4), all fp32."""
         nl, K = len(features), self.num_classes
         cls_f, loc_f = list(features), list(features)
-        for u in self.cls_subnet:
-            cls_f = u(cls_f)
-        for u in self.loc_subnet:
-            loc_f = u(loc_f)
+        cls_f, loc_f = _run_tower(self.cls_subnet, cls_f), _run_tower(self.loc_subnet, loc_f)
         raw_init = self.loc_init_out(self.loc_init_conv(loc_f))
         init = [self._decode(raw_init[l][..., :4], self.scales_init, l) for l in range(nl)]
         if self.feat_adaption == "Empty":
@@ -685,10 +688,7 @@ class AnchorHead(nn.Module):
         """-> cls towers, box towers (inputs of the 3x3 prediction convs), raw init offsets per level (N,H,W,8)."""
         nl = len(features)
         cls_f, loc_f = list(features), list(features)
-        for u in self.cls_subnet:
-            cls_f = u(cls_f)
-        for u in self.loc_subnet:
-            loc_f = u(loc_f)
+        cls_f, loc_f = _run_tower(self.cls_subnet, cls_f), _run_tower(self.loc_subnet, loc_f)
         raw = self.loc_init_out(self.loc_init_conv(loc_f))
         fa = self.feat_adaption
         if fa in (None, "none"):

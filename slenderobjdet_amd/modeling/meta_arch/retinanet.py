@@ -52,10 +52,12 @@ class RetinaNetHead(nn.Module):
 
     def run_towers(self, feats):
         c, b = list(feats), list(feats)
-        for u in self.cls_subnet:
-            c = u(c)
+        prev = None
+        for u in self.cls_subnet:          # consecutive units: the consumer's data gradient applies the producer's ReLU mask
+            c, prev = u(c, chained=prev), u
+        prev = None
         for u in self.bbox_subnet:
-            b = u(b)
+            b, prev = u(b, chained=prev), u
         return c, b
 
     def predict(self, cls_t, box_t):
