@@ -181,6 +181,9 @@ int sod_add_up2_bf16(const void* a, const void* b, void* out, int N, int H, int 
 /* dbias[c] += sum over (n, pixel) of dy — bias gradient of nn.Conv2d(bias=True) */
 int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C, long long img_stride, float* det_ws, long long det_ws_bytes, void* stream);
 /* d2 BasicStem: F.max_pool2d(x, kernel_size=3, stride=2, padding=1) */
+/* sod_bias_grad over several dense (N, hw[l], C) bf16 tensors that share the bias (a conv applied to all FPN levels): one launch,
+ * dbias[c] += sum over levels, images and pixels (float atomics). */
+int sod_bias_grad_ml(int nlev, const void* const* dy, float* dbias, int N, const int* hw, int C, void* stream);
 int sod_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, void* stream);
 /* backward of F.interpolate(scale_factor=2, mode="nearest") in d2 FPN */
 int sod_upsample2x_bwd(const void* g, void* dprev, int N, int Hc, int Wc, int C, void* stream);

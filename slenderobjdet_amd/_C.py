@@ -44,6 +44,7 @@ _SIGS = {
     "sod_add_bf16": [_P, _P, _P, _L, _P],
     "sod_add_up2_bf16": [_P, _P, _P, _I, _I, _I, _I, _P],
     "sod_bias_grad": [_P, _P, _I, _I, _I, _L, _P, _L, _P],
+    "sod_bias_grad_ml": [_I, _P, _P, _I, _P, _I, _P],
     "sod_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
     "sod_upsample2x_bwd": [_P, _P, _I, _I, _I, _I, _P],
     "sod_conv_set_tile256": [_I],

@@ -376,6 +376,41 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const __bf16* __restri
   }
 }
 
+// channel_sum over several dense (N, HW_l, C) tensors in ONE launch (bias gradient of a conv shared by all FPN levels)
+struct ChanSumML {
+  const __bf16* dy[GN_MAX_LEVELS];
+  int HW[GN_MAX_LEVELS], blk0[GN_MAX_LEVELS], ppb[GN_MAX_LEVELS];
+  int nlev, C;
+};
+__global__ __launch_bounds__(256) void channel_sum_ml_kernel(const ChanSumML m, float* __restrict__ db) {
+  extern __shared__ float lsum[];   // [256][8] per-thread partials
+  int l = 0;
+  while (l + 1 < m.nlev && (int)blockIdx.x >= m.blk0[l + 1]) ++l;
+  const int n = blockIdx.y, C = m.C, HW = m.HW[l];
+  const int c8n = C >> 3;
+  const int rows_per_iter = 256 / c8n;
+  const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int p0 = ((int)blockIdx.x - m.blk0[l]) * m.ppb[l];
+  int p1 = p0 + m.ppb[l]; if (p1 > HW) p1 = HW;
+  if (threadIdx.x < rows_per_iter * c8n) {
+    const __bf16* __restrict__ dy = m.dy[l] + (long long)n * HW * C + c8 * 8;
+    for (int p = p0 + prow; p < p1; p += rows_per_iter) {
+      const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(dy + (long long)p * C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lsum[threadIdx.x * 8 + e] = s[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    float t = 0.f;
+    for (int r = 0; r < rows_per_iter; ++r) t += lsum[(r * c8n + (i >> 3)) * 8 + (i & 7)];
+    atomicAdd(db + i, t);
+  }
+}
+
 // 3x3 stride-2 pad-1 max pool, NHWC bf16 (detectron2 BasicStem)
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y,
                                                            int N, int H, int W, int C, int Ho, int Wo) {
@@ -896,6 +931,23 @@ extern "C" int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C,
   SOD_LAUNCH(channel_sum_kernel, dim3(gx, N), dim3(256), sizeof(float) * 8 * 256, (hipStream_t)stream, (const __bf16*)dy, dbias, HW, C, img_stride, ppb,
              det_ws);
   if (det_ws) SOD_LAUNCH(col_accumulate_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, det_ws, gx * N, C, C, dbias);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_bias_grad_ml(int nlev, const void* const* dy, float* dbias, int N, const int* hw, int C, void* stream) {
+  if (!dy || !dbias || !hw || nlev <= 0 || nlev > GN_MAX_LEVELS || N <= 0 || C <= 0 || (C & 7) || C > 2048) return SOD_EARG;
+  ChanSumML m{};
+  m.nlev = nlev; m.C = C;
+  int blk = 0;
+  for (int l = 0; l < nlev; ++l) {
+    if (!dy[l] || hw[l] <= 0) return SOD_EARG;
+    int ppb;
+    const int gx = gn_grid(hw[l], N, ppb);
+    m.dy[l] = (const __bf16*)dy[l]; m.HW[l] = hw[l]; m.ppb[l] = ppb; m.blk0[l] = blk;
+    blk += gx;
+  }
+  SOD_LAUNCH(channel_sum_ml_kernel, dim3(blk, N), dim3(256), sizeof(float) * 8 * 256, (hipStream_t)stream, m, dbias);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

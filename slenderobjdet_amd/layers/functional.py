@@ -489,6 +489,23 @@ def bias_grad(dy, dbias, N, HW, C, img_stride=0):
     return dbias
 
 
+def bias_grad_ml(dys, dbias):
+    """Bias gradient of a conv shared by several levels: dbias += per-channel sum of every dense (N, H_l, W_l, C) tensor in ``dys``, one
+    launch (deterministic mode: one fixed-order launch per level)."""
+    _chk(dbias, torch.float32, "dbias")
+    for t in dys:
+        _chk(t, torch.bfloat16, "dy")
+    N, C = dys[0].shape[0], dys[0].shape[-1]
+    if DETERMINISTIC or len(dys) > 6:
+        for g in dys:
+            bias_grad(g, dbias, N, g.numel() // (N * C), C)
+        return dbias
+    side = _wgrad_stream(dbias.device, list(dys), dbias.data_ptr())
+    hw = [g.numel() // (N * C) for g in dys]
+    call("sod_bias_grad_ml", len(dys), _ptr_arr(dys), ptr(dbias), N, ctypes.cast(_int_arr(hw), ctypes.c_void_p), C, stream_ptr(side))
+    return dbias
+
+
 def maxpool3x3s2(x):
     _chk(x, torch.bfloat16, "x")
     N, H, W, C = x.shape

@@ -419,10 +419,7 @@ class _ConvReluMLFn(torch.autograd.Function):
             gs = [HF.relu_bwd(dy.contiguous(), y) for dy, y in zip(dys, ys)]
         HF.conv2d_wgrad_ml(gs, list(xs), arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
         arena.mark_ready(conv.weight)
-        dbias = arena.grad_view(conv.bias)
-        for g in gs:
-            N, H, W, C = g.shape
-            HF.bias_grad(g, dbias, N, H * W, C)
+        HF.bias_grad_ml(gs, arena.grad_view(conv.bias))
         arena.mark_ready(conv.bias)
         dxs = [None] * nl
         if any(ctx.needs_input_grad[3:]):
@@ -476,10 +473,7 @@ class _ConvMLFn(torch.autograd.Function):
         k = conv.kernel_size
         HF.conv2d_wgrad_ml(gs, list(xs), arena.grad_view(conv.weight), k, k, 1, conv.padding, 1)
         arena.mark_ready(conv.weight)
-        dbias = arena.grad_view(conv.bias)
-        for g in gs:
-            N, H, W, C = g.shape
-            HF.bias_grad(g, dbias, N, H * W, C)
+        HF.bias_grad_ml(gs, arena.grad_view(conv.bias))
         arena.mark_ready(conv.bias)
         dxs = [None] * nl
         if any(ctx.needs_input_grad[2:]):

@@ -288,3 +288,17 @@ def test_reference_signature_wrappers(cuda):
     _rel(pd.grad, gref, 2e-5, "iou wrapper grad")
     with pytest.raises(NotImplementedError):
         iou_loss(pd, tgt.to(cuda), None, loss_type="diou")
+
+
+def test_bias_grad_multi_level(cuda):
+    """sod_bias_grad_ml (one launch over all levels of a shared conv) against per-level torch sums."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    g = torch.Generator().manual_seed(5)
+    N, C = 3, 256
+    dys = [(torch.randn(N, h, w, C, generator=g)).to(torch.bfloat16).to(cuda) for h, w in ((23, 37), (12, 19), (6, 10), (3, 5), (2, 3))]
+    db = torch.zeros(C, device=cuda)
+    HF.bias_grad_ml(dys, db)
+    torch.cuda.synchronize()
+    ref = sum(t.float().sum(dim=(0, 1, 2)) for t in dys)
+    assert (db - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-4
