@@ -157,6 +157,25 @@ def kernel_name(kind, code):
     return variant_kernel_name(code, KIND_MODE[kind])
 
 
+def algo_bytes(kind, desc):
+    """ALGORITHMIC HBM bytes of one conv dispatch: every operand of the convolution read or written exactly once (bf16 activations and
+    weights, the fp32 weight gradient written once); fused epilogue operands (residual, ReLU mask, accumulate) are not counted."""
+    if not desc:
+        return 0.0
+    if desc[0] == "ml":
+        _, N, hs, C, K, R, stride, ws = desc[:8]
+        hw = list(zip(hs, ws))
+    else:
+        N, H, W, C, K, R, stride = desc[:7]
+        if R == "bneck":      # fused frozen bottleneck block: x in, 256-channel block output out, four weight matrices
+            return N * H * W * (C + K) * 2.0 + (C * 64 + 64 * 64 * 9 + 64 * K + (C * K if C != K else 0)) * 2.0
+        if R == 7 and C == 3:      # fused stem: uint8 RGB in, pooled 64-channel bf16 out
+            return N * H * W * 3.0 + N * (H // 4) * (W // 4) * K * 2.0 + K * 49 * 8 * 2.0
+        hw = [(H, W)]
+    act = sum(N * h * w * C + N * -(-h // stride) * -(-w // stride) * K for h, w in hw) * 2.0
+    return act + K * R * R * C * (4.0 if kind == "conv_wgrad" else 2.0)
+
+
 def roofline_report(prof, prof_steps, args):
     """`roofline` = the conv kernel with the most GPU time in the sampled steps (duration = hipEvent interval on its launch
     stream, algorithmic FLOPs = 2*N*Ho*Wo*K*R*S*C with UN-padded channel counts); every other kernel in `kernels`;
@@ -164,11 +183,11 @@ def roofline_report(prof, prof_steps, args):
     by_k, groups, kinds = {}, {}, {}
     for kind, flops, sec, desc, variant in prof:
         for tab, key in ((by_k, (kind, variant)), (kinds, kind), (groups, "head_convs" if desc and desc[0] == "ml" else "backbone_convs")):
-            a = tab.setdefault(key, [0.0, 0.0, 0])
-            a[0] += flops; a[1] += sec; a[2] += 1
+            a = tab.setdefault(key, [0.0, 0.0, 0, 0.0])
+            a[0] += flops; a[1] += sec; a[2] += 1; a[3] += algo_bytes(kind, desc)
 
     def row(v, name=None):
-        fl, sec, cnt = v
+        fl, sec, cnt = v[:3]
         r = {"TFLOP/s": round(fl / sec / 1e12, 2), "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4), "ms_per_step": round(sec / prof_steps * 1e3, 3),
              "launches_per_step": round(cnt / prof_steps, 1), "tflop_per_step": round(fl / prof_steps / 1e12, 3)}
         if name:
@@ -176,16 +195,19 @@ def roofline_report(prof, prof_steps, args):
         return r
 
     dom = max(by_k, key=lambda k: by_k[k][1])
-    fl, sec, cnt = by_k[dom]
+    fl, sec, cnt, nbytes = by_k[dom]
     kname = kernel_name(*dom)
     tr = pmc_traffic(dom[0], kname)
     rep = {"bound": "mfma", "kernel": kname, "achieved": round(fl / sec / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4), "traffic": (tr or {}).get("hbm_bytes_per_launch"),
            "traffic_source": (tr or {}).get("source"),
+           "algorithmic_bytes": round(nbytes / cnt), "algorithmic_bytes_note": "per launch, conv operands read / written once (no fused epilogue operands)",
+           "traffic_over_algorithmic": round(tr["hbm_bytes_per_launch"] / (nbytes / cnt), 3) if tr and nbytes else None,
+           "hbm_GBps_algorithmic": round(nbytes / sec / 1e9, 1),
            "selection": "kernel with the largest share of conv GPU time in the sampled steps", "launches": cnt, "sampled_steps": prof_steps,
            "avg_launch_us": round(sec / cnt * 1e6, 2), "ms_per_step": round(sec / prof_steps * 1e3, 3),
            "flops": "algorithmic, un-padded channels",
-           "sampling": "one timed step in 32 (the first at K/2); sampled steps run the weight gradients and the box tower on the main stream so that every interval is one kernel's duration",
+           "sampling": f"{prof_steps} of the {args.steps} timed steps (every 32nd from step K/2; all with --dump-prof); sampled steps run the weight gradients and the box tower on the main stream so that every interval is one kernel's duration",
            "kernels": [row(v, kernel_name(*k)) for k, v in sorted(by_k.items(), key=lambda kv: -kv[1][1])],
            "by_pass": {k: row(v) for k, v in kinds.items()}}
     if args.arch == "fcos":
@@ -202,7 +224,8 @@ def pmc_traffic(kind, kernel_name_):
     def norm(x):
         return x.replace(";", ",").replace(" ", "").replace("void", "")
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.getmtime)
+    # by NAME (tags are ordered: r1b < r2a < ... < r3a): modification times are all equal in a fresh checkout
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.basename)
     if not files:
         return None
     try:
@@ -392,6 +415,8 @@ def main():
         HF.PROFILE_KINDS = None
         HF.PROFILE_LIB = True
     prof_all, prof_steps = [], 0
+    if world > 1 or rehearsal:
+        model.arena.comm_probe = []
     side_default = HF.WGRAD_SIDE_STREAM
     from slenderobjdet_amd.modeling.meta_arch import fcos as fcos_mod
     tower_default = fcos_mod.TOWER_STREAMS
@@ -457,12 +482,28 @@ def main():
             "config": {"workload": WORKLOADS[args.arch], "global_batch": args.batch_per_gpu * world, "parallelism": f"dp{world}",
                        "final_loss": round(loss_val, 5)},
         }
+        if world > 1 or rehearsal:
+            # what the collective layer saw, so that a reader of this line can check that the run was the N-rank data-parallel job it
+            # claims (reference: train_net.py:185-195 -> detectron2 launch -> one process per GPU, NCCL all-reduce of every gradient)
+            ar = model.arena
+            pairs = getattr(ar, "comm_probe", None) or []
+            exposed = [a.elapsed_time(b) for a, b in pairs]
+            out["config"].update({
+                "backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "bucket_mb": round(ar.bucket_elems * 4 / (1 << 20), 1),
+                "n_buckets": len(ar.buckets), "grad_bytes_per_step": int(ar.total * (4 if ar.bucket_dtype == torch.float32 else 2)),
+                "wire_dtype": str(ar.bucket_dtype).replace("torch.", ""),
+                "exposed_comm_ms_per_step": round(sum(exposed) / len(exposed), 3) if exposed else None,
+                "exposed_comm_note": "rank 0, mean over the timed steps: compute-stream idle time between the end of backward and the end of the last bucket's all-reduce"})
         if rehearsal:
             out["config"]["rccl_rehearsal"] = "one-rank RCCL group, every data-parallel collective issued"
         if args.arch == "fcos" and args.depth == 50:
-            out["model_tflops"] = round(imgs * TRAIN_FLOP_PER_IMAGE / dt / 1e12, 2)
+            # SURVEY.md 8(d)'s 1.1913 TFLOP per image is an UPPER bound (it counts a data gradient for the first trainable layer);
+            # roofline.by_pass sums the FLOPs of the launches actually timed
+            out["model_tflops_upper_bound"] = round(imgs * TRAIN_FLOP_PER_IMAGE / dt / 1e12, 2)
         if prof:
             out["roofline"] = roofline_report(prof, prof_steps, args)
+            if prof_steps:
+                out["timed_conv_tflop_per_step"] = round(sum(p_[1] for p_ in prof) / prof_steps / 1e12, 3)
         if prof and args.dump_prof:
             per = {}
             for kind, flops, sec_, desc, _variant in prof:

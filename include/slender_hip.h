@@ -204,6 +204,14 @@ int sod_scale_rows(float* g, const float* scale, int K, long long row, void* str
 int sod_sgd_step(float* params, const float* grads, float* momentum_buf, const void* segments_dev, int nseg,
                  const float* lr_dev, float lr, float momentum, int nesterov, int first_step, float grad_scale, void* stream);
 
+/* torch.optim.Adam / AdamW / Adagrad over the flat arena: SOLVER.OPTIM "ADAM" / "ADAMW" / "ADAGRAD"
+ * (slender_det/solver/build.py:26-31), one launch for all parameters, per-segment lr multiplier and weight decay as sod_sgd_step.
+ * mode 0 Adam (L2 decay in the gradient), 1 AdamW (decoupled decay), 2 Adagrad (exp_avg unused, exp_avg_sq = running sum of squares;
+ * lr = the caller's clr = lr / (1 + (t-1) * lr_decay)).  bias_correction1 = 1 - beta1^t, bias_correction2_sqrt = sqrt(1 - beta2^t). */
+int sod_adaptive_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const void* segments_dev, int nseg,
+                      int mode, float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt,
+                      float grad_scale, void* stream);
+
 /* FCOSV2.preprocess_image (fcosv2.py:268-275) + ImageList.from_tensors: (x-mean)/std, zero pad, CHW -> NHWC(8) bf16.
  * mean3/std3 are HOST pointers. */
 int sod_preprocess_image(const void* img, int is_uint8, int C, int H, int W, void* out, int Hp, int Wp, int Cpad,

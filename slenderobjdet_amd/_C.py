@@ -55,6 +55,7 @@ _SIGS = {
     "sod_weight_prep": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sod_scale_rows": [_P, _P, _I, _L, _P],
     "sod_sgd_step": [_P, _P, _P, _P, _I, _P, _F, _F, _I, _I, _F, _P],
+    "sod_adaptive_step": [_P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _F, _P],
     "sod_preprocess_image": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P],
     "sod_preprocess_batch": [_I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "sod_nchw_f32_to_nhwc_bf16": [_P, _P, _I, _I, _I, _P],

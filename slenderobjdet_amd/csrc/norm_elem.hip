@@ -599,6 +599,36 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
 }
 
+// ------------------------------------------------------------------ fused Adam / AdamW / Adagrad over the flat arena
+// torch.optim.Adam / AdamW / Adagrad semantics (slender_det/solver/build.py:26-31), one launch over all parameters, per-segment
+// learning-rate multiplier and weight decay exactly as sgd_kernel.  mode 0 = Adam (L2 decay added to the gradient), 1 = AdamW
+// (decoupled: p *= 1 - lr*wd), 2 = Adagrad (L2 decay added to the gradient; `m` unused, `v` = the running sum of squares).
+// bc1 / bc2 = 1 - beta^t, computed in double on the host as torch does; `clr` (Adagrad) = lr / (1 + (t-1) * lr_decay).
+__global__ __launch_bounds__(256) void adaptive_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, const SgdSeg* __restrict__ segs, int mode, float lr,
+                                                       float beta1, float beta2, float eps, float bc1, float bc2_sqrt, float grad_scale) {
+  const SgdSeg sg = segs[blockIdx.y];
+  const float step = lr * sg.lr_mult;
+  for (long long i = sg.begin + (long long)blockIdx.x * 256 + threadIdx.x; i < sg.end; i += (long long)gridDim.x * 256) {
+    float pv = p[i];
+    float d = g[i] * grad_scale;
+    if (mode == 1) pv *= 1.f - step * sg.wd;
+    else d += sg.wd * pv;
+    if (mode == 2) {
+      const float s = v[i] + d * d;
+      v[i] = s;
+      pv -= step * (d / (sqrtf(s) + eps));
+    } else {
+      const float mi = m[i] + (d - m[i]) * (1.f - beta1);          // torch: exp_avg.lerp_(grad, 1 - beta1)
+      const float vi = beta2 * v[i] + (1.f - beta2) * d * d;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+      m[i] = mi; v[i] = vi;
+      const float denom = sqrtf(vi) / bc2_sqrt + eps;
+      pv -= (step / bc1) * (mi / denom);
+    }
+    p[i] = pv;
+  }
+}
+
 // ------------------------------------------------------------------ image batching
 // uint8/float CHW image -> (x - mean)/std -> NHWC bf16 with Cpad channels, zero padded to (Hp, Wp)
 template <typename T>
@@ -998,6 +1028,17 @@ extern "C" int sod_sgd_step(float* params, const float* grads, float* momentum_b
   if (!params || !grads || !segments_dev || nseg <= 0 || (momentum != 0.f && !momentum_buf)) return SOD_EARG;
   SOD_LAUNCH(sgd_kernel, dim3(512, nseg), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf,
                      (const SgdSeg*)segments_dev, nseg, lr_dev, lr, momentum, nesterov, first_step, grad_scale);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_adaptive_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const void* segments_dev, int nseg,
+                                 int mode, float lr, float beta1, float beta2, float eps, float bias_correction1, float bias_correction2_sqrt,
+                                 float grad_scale, void* stream) {
+  if (!params || !grads || !exp_avg_sq || !segments_dev || nseg <= 0 || mode < 0 || mode > 2 || (mode != 2 && !exp_avg)) return SOD_EARG;
+  if (mode != 2 && !(bias_correction1 > 0.f && bias_correction2_sqrt > 0.f)) return SOD_EARG;
+  SOD_LAUNCH(adaptive_kernel, dim3(512, nseg), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+                     (const SgdSeg*)segments_dev, mode, lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt, grad_scale);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

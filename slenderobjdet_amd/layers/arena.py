@@ -167,8 +167,12 @@ class ParamArena:
         self._pending = counts
         self._launched = [False] * len(self.buckets)
         self._handles = []
-        if self._comm_stream is None and self.device.type == "cuda":
-            self._comm_stream = torch.cuda.Stream(device=self.device)
+        if self.device.type == "cuda":
+            # the stream backward() is called on: nodes without a stream of their own (the classification tower, the prediction
+            # convs, the backbone) produce their parameter gradients there, whichever node's mark_ready ends up launching the bucket
+            self._main_stream = torch.cuda.current_stream(self.device)
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=self.device)
 
     def mark_ready(self, p):
         """Called in backward after the last kernel that adds to ``p.grad`` for this use has been enqueued."""
@@ -190,6 +194,13 @@ class ParamArena:
             sides = HF.wgrad_side_streams(self.device)
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
+                # A 32 MB bucket mixes gradients produced on different streams (GroupNorm dgamma / dbeta and bias gradients on the main
+                # stream, the box tower's on its own stream, weight gradients on the side stream): the launching node's event covers
+                # only ITS stream, so the reduction always waits for the main compute stream too, not only when a weight gradient
+                # happened to be ordered behind it through side.wait_stream(main) (SOD_WGRAD_STREAM=0 + SOD_TOWER_STREAMS=1).
+                main = getattr(self, "_main_stream", None)
+                if main is not None:
+                    self._comm_stream.wait_stream(main)
                 for side in sides:          # weight gradients of this bucket were enqueued on the wgrad side stream(s)
                     self._comm_stream.wait_stream(side)
                 for aux in HF.aux_compute_streams(self.device):   # a bucket may mix parameters whose backward nodes ran on different
@@ -212,10 +223,20 @@ class ParamArena:
         for bi in range(len(self.buckets)):
             if not self._launched[bi]:
                 self._launch_bucket(bi)
+        probe = getattr(self, "comm_probe", None)      # bench.py: a list that receives (event, event) around the wait for the reducer
+        if probe is not None and self.device.type == "cuda":
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h, wire, view in self._handles:
             h.wait()
         if self.device.type == "cuda":
             torch.cuda.current_stream().wait_stream(self._comm_stream)
+            if probe is not None:
+                # the compute stream's own work ends at e0; it resumes at e1, when the last bucket's reduction is done: e1 - e0 is the
+                # communication time NOT hidden behind backward ("exposed")
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                probe.append((e0, e1))
         for h, wire, view in self._handles:
             if wire is not view:            # reduced bf16 values back into the fp32 gradient arena (current stream, after the wait)
                 view.copy_(wire)

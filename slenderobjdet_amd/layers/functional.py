@@ -282,7 +282,7 @@ def conv2d_fwd_ml(xs, w, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=
     call("sod_conv2d_fwd_ml", len(xs), _ptr_arr(xs), ptr(w), ptr(bias), _ptr_arr(outs), N, _int_arr(hs), _int_arr(ws), C, K, R, S,
          stride, pad, dil, y_img_stride, CONV_RELU if relu else 0, 1 if out_f32 else 0, stream_ptr())
     fl = sum(2.0 * N * ho * wo * (k_real or K) * R * S * C for ho, wo in (conv_out_size(h, wd, R, S, stride, pad, dil) for h, wd in zip(hs, ws)))
-    _prof_end("conv_fwd", fl, e0, ("ml", N, tuple(hs), C, K, R, stride))
+    _prof_end("conv_fwd", fl, e0, ("ml", N, tuple(hs), C, K, R, stride, tuple(ws)))
     return outs
 
 
@@ -304,7 +304,7 @@ def conv_gn_fwd_ml(xs, w, bias, gamma, beta, G, eps=1e-5, relu=True, pad=1):
     call("sod_conv2d_fwd_ml_gnsum", len(xs), _ptr_arr(xs), ptr(w), ptr(bias), _ptr_arr(outs), N, _int_arr(hs), _int_arr(ws), C, K, R, S,
          1, pad, 1, 0, 0, ptr(stats), G, stream_ptr())
     fl = sum(2.0 * N * o.shape[1] * o.shape[2] * K * R * S * C for o in outs)
-    _prof_end("conv_fwd", fl, e0, ("ml", N, tuple(hs), C, K, R, 1))
+    _prof_end("conv_fwd", fl, e0, ("ml", N, tuple(hs), C, K, R, 1, tuple(ws)))
     ys = [torch.empty_like(o) for o in outs]
     hw = [o.shape[1] * o.shape[2] for o in outs]
     call("sod_groupnorm_apply_ml", len(outs), _ptr_arr(outs), ptr(gamma), ptr(beta), _ptr_arr(ys), ptr(stats), N, ctypes.cast(_int_arr(hw), ctypes.c_void_p),
@@ -333,7 +333,7 @@ def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=N
         call("sod_conv2d_dgrad_ml", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]), _int_arr([w for _, w in x_hws]),
              C, K, R, S, stride, pad, dil, dy_img_stride, stream_ptr())
     fl = sum(2.0 * N * ho * wo * (k_real or K) * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in x_hws))
-    _prof_end("conv_dgrad", fl, e0, ("ml", N, tuple(h for h, _ in x_hws), C, K, R, stride))
+    _prof_end("conv_dgrad", fl, e0, ("ml", N, tuple(h for h, _ in x_hws), C, K, R, stride, tuple(w for _, w in x_hws)))
     return outs
 
 
@@ -357,7 +357,7 @@ def conv2d_dgrad_ml_gnbwd(dys, wt, x_hws, gn_xs, gn_stats, gamma, beta, dgamma, 
     call("sod_conv2d_dgrad_ml_gnbwd", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]), _int_arr([w for _, w in x_hws]),
          C, K, R, S, stride, pad, dil, 0, _ptr_arr(gn_xs), ptr(gn_stats), ptr(gamma), ptr(beta), ptr(red), ptr(dgamma), ptr(dbeta), G, stream_ptr())
     fl = sum(2.0 * N * ho * wo * K * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in x_hws))
-    _prof_end("conv_dgrad", fl, e0, ("ml", N, tuple(h for h, _ in x_hws), C, K, R, stride))
+    _prof_end("conv_dgrad", fl, e0, ("ml", N, tuple(h for h, _ in x_hws), C, K, R, stride, tuple(w for _, w in x_hws)))
     return outs, red
 
 
@@ -387,7 +387,7 @@ def conv2d_wgrad_ml(dys, xs, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, 
     call("sod_conv2d_wgrad_ml", len(xs), _ptr_arr(dys), _ptr_arr(xs), ptr(dw), ptr(qscale), N, _int_arr(hs), _int_arr(ws_), C, K, R, S,
          stride, pad, dil, dy_img_stride, splits, WGRAD_DETERMINISTIC if DETERMINISTIC else 0, ptr(ws), ws.numel(), stream_ptr(side))
     fl = sum(2.0 * N * ho * wo * (k_real or K) * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in zip(hs, ws_)))
-    _prof_end("conv_wgrad", fl, e0, ("ml", N, tuple(hs), C, K, R, stride), side)
+    _prof_end("conv_wgrad", fl, e0, ("ml", N, tuple(hs), C, K, R, stride, tuple(ws_)), side)
     return dw
 
 

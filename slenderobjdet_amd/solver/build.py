@@ -109,7 +109,76 @@ class FusedSGD(torch.optim.Optimizer):
         a.bump()
 
 
+class FusedAdaptive(torch.optim.Optimizer):
+    """torch.optim.Adam / AdamW / Adagrad semantics (default hyper-parameters of the reference's calls, slender_det/solver/build.py:26-31:
+    betas (0.9, 0.999), eps 1e-8 / 1e-10, no amsgrad, lr_decay 0) over the flat arena: ONE launch of ``sod_adaptive_step`` per step
+    instead of a chain of ATen kernels per parameter.  The first / second moment buffers are two more flat fp32 arenas."""
+
+    MODES = {"ADAM": 0, "ADAMW": 1, "ADAGRAD": 2}
+
+    def __init__(self, params, lr, kind, arena=None, betas=(0.9, 0.999), eps=None, lr_decay=0.0):
+        if arena is None:
+            raise ValueError("FusedAdaptive needs the model's ParamArena")
+        if kind not in self.MODES:
+            raise ValueError(kind)
+        eps = (1e-10 if kind == "ADAGRAD" else 1e-8) if eps is None else eps
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0.0, lr_decay=lr_decay))
+        self.arena, self.kind = arena, kind
+        self._segs, self._nseg = arena.build_segments(self.param_groups, lr)
+        self._ref_group, self._ref_mult = 0, 1.0
+        for i, g in enumerate(self.param_groups):
+            if lr and g["lr"] != 0:
+                self._ref_group, self._ref_mult = i, g["lr"] / lr
+                break
+        self._steps = 0
+        self.grad_scale = 1.0
+        self.exp_avg = torch.zeros_like(arena.params) if kind != "ADAGRAD" else None
+        self.exp_avg_sq = torch.zeros_like(arena.params)      # Adagrad: the running sum of squared gradients (initial value 0)
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["fused_adaptive"] = {"kind": self.kind, "steps": self._steps, "exp_avg": None if self.exp_avg is None else self.exp_avg.detach().cpu().clone(),
+                                "exp_avg_sq": self.exp_avg_sq.detach().cpu().clone(), "arena_names": [(n, o, c) for n, o, c in self.arena.names]}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        fused = sd.pop("fused_adaptive", None)
+        super().load_state_dict(sd)
+        if fused is None or fused.get("kind") != self.kind:
+            raise ValueError(f"FusedAdaptive.load_state_dict: the checkpoint holds no '{self.kind}' moment buffers")
+        if [tuple(x) for x in fused["arena_names"]] != [tuple(x) for x in self.arena.names]:
+            raise ValueError("FusedAdaptive.load_state_dict: the checkpoint's parameter arena layout differs from this model's")
+        if self.exp_avg is not None:
+            self.exp_avg.copy_(fused["exp_avg"])
+        self.exp_avg_sq.copy_(fused["exp_avg_sq"])
+        self._steps = int(fused["steps"])
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g0 = self.param_groups[0]
+        lr_now = self.param_groups[self._ref_group]["lr"] / self._ref_mult
+        self._steps += 1
+        t = self._steps
+        b1, b2 = g0["betas"]
+        if self.kind == "ADAGRAD":
+            lr_now = lr_now / (1.0 + (t - 1) * g0["lr_decay"])
+            bc1 = bc2s = 1.0
+        else:
+            bc1, bc2s = 1.0 - b1 ** t, (1.0 - b2 ** t) ** 0.5
+        a = self.arena
+        HF.wgrad_join()
+        call("sod_adaptive_step", ptr(a.params), ptr(a.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self._segs), self._nseg,
+             self.MODES[self.kind], float(lr_now), float(b1), float(b2), float(g0["eps"]), float(bc1), float(bc2s), float(self.grad_scale), stream_ptr())
+        a.bump()
+
+
 def build_optimizer(cfg, model):
+    """slender_det/solver/build.py:8-33.  On a model that owns a flat arena every SOLVER.OPTIM value is one fused launch over the arena
+    (FusedSGD / FusedAdaptive); without an arena (CPU models) the torch.optim classes the reference constructs."""
     params = get_default_optimizer_params(model, base_lr=cfg.SOLVER.BASE_LR, weight_decay=cfg.SOLVER.WEIGHT_DECAY,
                                           weight_decay_norm=cfg.SOLVER.WEIGHT_DECAY_NORM, bias_lr_factor=cfg.SOLVER.BIAS_LR_FACTOR,
                                           weight_decay_bias=cfg.SOLVER.WEIGHT_DECAY_BIAS)
@@ -119,6 +188,9 @@ def build_optimizer(cfg, model):
         if arena is not None:
             return FusedSGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, nesterov=cfg.SOLVER.NESTEROV, arena=arena)
         return torch.optim.SGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, nesterov=cfg.SOLVER.NESTEROV)
+    if optim in FusedAdaptive.MODES and arena is not None and arena.device.type == "cuda":
+        # (ADAGRAD: the reference passes an undefined name as the default weight_decay, solver/build.py:31; every group carries its own)
+        return FusedAdaptive(params, cfg.SOLVER.BASE_LR, optim, arena=arena)
     if optim == "ADAM":
         return torch.optim.Adam(params, cfg.SOLVER.BASE_LR)
     if optim == "ADAMW":

@@ -61,12 +61,12 @@ def test_fcos_r18_losses_and_gradients_vs_oracle(cuda, depth):
     for k, b in ref_emu.items():
         a = float(got[k].detach())
         assert abs(a - b) <= 1e-3 * max(abs(b), 1e-3), (k, a, b)
-    # distance to the plain fp32 oracle (= the reference's CPU path restated): bounded by what bf16 storage of weights and
-    # activations costs in ONE forward pass - 2e-3 relative per loss (measured 1e-4 .. 6e-4) - and never more than 3x the distance
+    # distance to the plain fp32 oracle (= the reference's CPU path restated): north_star's 1e-3 relative per loss (measured
+    # 1e-4 .. 6e-4: what bf16 storage of weights and activations costs in ONE forward pass) - and never more than 3x the distance
     # of the bf16-emulating oracle from fp32 plus the 1e-3 kernel tolerance above
     for k, f in ref_f32.items():
         a, e = float(got[k].detach()), ref_emu[k]
-        assert abs(a - f) <= 2e-3 * max(abs(f), 1e-3), (k, a, f)
+        assert abs(a - f) <= 1e-3 * max(abs(f), 1e-3), (k, a, f)
         assert abs(a - f) <= 3.0 * abs(e - f) + 1e-3 * max(abs(f), 1e-3), (k, a, e, f)
     checked = 0
     for name, p in model.named_parameters():
@@ -274,6 +274,9 @@ def test_bench_two_ranks_data_parallel(cuda, tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    c = d["config"]       # the line says what the collective layer saw
+    assert c["ranks_seen"] == 2 and c["backend"] == "gloo" and c["n_buckets"] >= 1 and c["wire_dtype"] == "float32"
+    assert c["exposed_comm_ms_per_step"] is not None and c["exposed_comm_ms_per_step"] >= 0 and c["grad_bytes_per_step"] > 0
     p0 = torch.load(os.path.join(tmp_path, "params_rank0.pt"))
     p1 = torch.load(os.path.join(tmp_path, "params_rank1.pt"))
     assert torch.equal(p0, p1), "replicas diverged: gradient all-reduce / broadcast is broken"
@@ -303,9 +306,17 @@ def test_bench_rccl_rehearsal_single_rank(cuda):
     plain = run([])
     reh = run(["--rccl-rehearsal"])
     assert reh["config"].get("rccl_rehearsal") and reh["n_gpus"] == 1
+    assert reh["config"]["backend"] == "nccl" and reh["config"]["ranks_seen"] == 1 and reh["config"]["n_buckets"] >= 1
     assert reh["config"]["final_loss"] == plain["config"]["final_loss"], (reh["config"], plain["config"])
     reh16 = run(["--rccl-rehearsal"], {"SOD_GRAD_BUCKET_DTYPE": "bf16"})
     assert abs(reh16["config"]["final_loss"] - plain["config"]["final_loss"]) <= 2e-2 * abs(plain["config"]["final_loss"])
+    # Stream hand-over of the bucket reducer: without a weight-gradient side stream nothing orders the comm stream behind the MAIN
+    # compute stream except the reducer's own wait (arena._launch_bucket) when the launching node ran on the tower stream.  On the bf16
+    # wire the bucket is COPIED (rounded) on the comm stream and written back after the reduction, so a bucket read before the main
+    # stream's gradients were complete would overwrite them with stale values: the deterministic run must not change.
+    for env_extra in ({"SOD_WGRAD_STREAM": "0", "SOD_TOWER_STREAMS": "1"}, {"SOD_WGRAD_STREAM": "0", "SOD_TOWER_STREAMS": "0"}):
+        other = run(["--rccl-rehearsal"], dict(env_extra, SOD_GRAD_BUCKET_DTYPE="bf16"))
+        assert other["config"]["final_loss"] == reh16["config"]["final_loss"], (env_extra, other["config"], reh16["config"])
 
 
 def test_side_streams_gradients_match_single_stream(cuda):
@@ -373,6 +384,71 @@ def test_sgd_kernel_matches_oracle(cuda):
                 rp, rb_ = onn.sgd_step(p[b:e], grad[b:e] * 0.5, buf[b:e], 0.05 * lr_mult, 0.9, wd, nesterov=nesterov, first=first)
                 assert torch.allclose(pd[b:e].cpu(), rp, rtol=1e-6, atol=1e-7), (nesterov, first, b)
                 assert torch.allclose(bd[b:e].cpu(), rb_, rtol=1e-6, atol=1e-7), (nesterov, first, b)
+
+
+@pytest.mark.parametrize("kind", ["ADAM", "ADAMW", "ADAGRAD"])
+def test_adaptive_optimizer_kernel_matches_torch_optim(cuda, kind):
+    """SOLVER.OPTIM ADAM / ADAMW / ADAGRAD (slender_det/solver/build.py:26-31): the fused arena kernel (sod_adaptive_step) against the
+    torch.optim class the reference constructs, run on the CPU in fp32 on the same parameters / gradients: five steps with changing
+    gradients, two segments with different lr multiplier and weight decay, gradient scale 1/world.  1e-6 relative."""
+    import numpy as np
+
+    from slenderobjdet_amd._C import call, ptr, stream_ptr
+
+    g = torch.Generator().manual_seed(5)
+    n0p, n1 = 1024, 64 * 29
+    total = n0p + n1
+    p0 = torch.randn(total, generator=g)
+    grads = [torch.randn(total, generator=g) * (0.5 + i) for i in range(5)]
+    spec = ((0, n0p, 1.0, 1e-2), (n0p, total, 2.0, 0.0))
+    segs = np.zeros(2, dtype=np.dtype([("b", "<i8"), ("e", "<i8"), ("lr", "<f4"), ("wd", "<f4")]))
+    for i, sp in enumerate(spec):
+        segs[i] = sp
+    segs_dev = torch.from_numpy(segs.view(np.uint8).copy()).to(cuda)
+    lr, scale = 3e-3, 0.5
+    ref_p = [torch.nn.Parameter(p0[b:e].clone()) for b, e, _, _ in spec]
+    groups = [{"params": [rp], "lr": lr * m, "weight_decay": wd} for rp, (_, _, m, wd) in zip(ref_p, spec)]
+    ref = {"ADAM": torch.optim.Adam, "ADAMW": torch.optim.AdamW, "ADAGRAD": torch.optim.Adagrad}[kind](groups, lr)
+    pd = p0.clone().to(cuda)
+    m = torch.zeros(total, device=cuda) if kind != "ADAGRAD" else None
+    v = torch.zeros(total, device=cuda)
+    mode = {"ADAM": 0, "ADAMW": 1, "ADAGRAD": 2}[kind]
+    eps = 1e-10 if kind == "ADAGRAD" else 1e-8
+    for t, gr in enumerate(grads, start=1):
+        for rp, (b, e, _, _) in zip(ref_p, spec):
+            rp.grad = gr[b:e] * scale
+        ref.step()
+        bc1, bc2s = (1.0, 1.0) if kind == "ADAGRAD" else (1 - 0.9 ** t, (1 - 0.999 ** t) ** 0.5)
+        call("sod_adaptive_step", ptr(pd), ptr(gr.to(cuda)), ptr(m), ptr(v), ptr(segs_dev), 2, mode, lr, 0.9, 0.999, eps, bc1, bc2s, scale, stream_ptr())
+        for rp, (b, e, _, _) in zip(ref_p, spec):
+            assert torch.allclose(pd[b:e].cpu(), rp.detach(), rtol=2e-6, atol=2e-7), (kind, t, b, float((pd[b:e].cpu() - rp.detach()).abs().max()))
+
+
+def test_build_optimizer_returns_fused_classes_on_the_arena(cuda):
+    """No SOLVER.OPTIM value leaves the HIP path on a GPU model: SGD -> FusedSGD, ADAM / ADAMW / ADAGRAD -> FusedAdaptive; a training
+    step with each runs, changes every trainable parameter and keeps the loss finite; state_dict round-trips the moment buffers."""
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.solver import build_optimizer
+    from slenderobjdet_amd.solver.build import FusedAdaptive, FusedSGD
+
+    from bench import make_cfg, train_step
+
+    data = synthetic_batch(2, 256, 256, 5, device="cuda")
+    for optim in ("SGD", "ADAM", "ADAMW", "ADAGRAD"):
+        cfg, model, _ = _build(18, seed=4)
+        cfg.SOLVER.OPTIM = optim
+        cfg.SOLVER.BASE_LR = 1e-4
+        opt = build_optimizer(cfg, model)
+        assert isinstance(opt, FusedSGD if optim == "SGD" else FusedAdaptive), (optim, type(opt))
+        before = model.arena.params.detach().clone()
+        l0 = float(train_step(model, opt, data))
+        l1 = float(train_step(model, opt, data))
+        assert l0 == l0 and l1 == l1 and not torch.equal(before, model.arena.params)
+        if optim != "SGD":
+            sd = opt.state_dict()
+            assert sd["fused_adaptive"]["steps"] == 2 and float(sd["fused_adaptive"]["exp_avg_sq"].abs().sum()) > 0
+            opt.load_state_dict(sd)
+            assert opt._steps == 2
 
 
 def test_fused_sgd_state_dict_round_trip(cuda):
