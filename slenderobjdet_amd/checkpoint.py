@@ -139,6 +139,46 @@ def _fcos_head_rules(model):
     return rules
 
 
+# module attributes named differently here and in detectron2 (native prefix, reference prefix)
+_PREFIX_ALIASES = (("proposal_generator.head.", "proposal_generator.rpn_head."),)
+
+
+def _ref_name(name):
+    for nat, ref in _PREFIX_ALIASES:
+        if name.startswith(nat):
+            return ref + name[len(nat):]
+    # detectron2's FastRCNNConvFCHead registers its layers as fc1, fc2, ... (add_module("fc{k+1}")); natively ``fcs`` is a ModuleList
+    m = re.match(r"^(.*\.box_head)\.fcs\.(\d+)\.(.*)$", name)
+    if m:
+        return f"{m.group(1)}.fc{int(m.group(2)) + 1}.{m.group(3)}"
+    return name
+
+
+def _unit_tower_map(model):
+    """native key prefix -> reference key prefix for towers built from [conv (+ GroupNorm) + ReLU] UNITS.  The reference keeps such a
+    tower as a flat ``nn.Sequential`` (RetinaNetHead: ``cls_subnet.{2i}`` = conv, ``{2i+1}`` = ReLU, retina_rotated.py:418-430; the
+    ablation heads with GN: ``{3i}`` conv, ``{3i+1}`` GroupNorm) or as a Sequential of per-layer Sequentials (RepPointsDetector:
+    ``cls_conv.{i}.0`` conv, ``cls_conv.{i}.1`` GroupNorm, rpd.py:191-204); natively unit i is ``<tower>.{i}.conv`` / ``<tower>.{i}.gn``."""
+    from torch import nn
+
+    from .layers.nn import ConvGnRelu, ConvML, ConvReluML
+
+    out = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, ConvML):          # a plain shared conv: the reference has the nn.Conv2d itself under this name
+            out[f"{name}.conv"] = name
+            continue
+        if not isinstance(mod, nn.ModuleList) or len(mod) == 0 or not all(isinstance(u, (ConvGnRelu, ConvReluML)) for u in mod):
+            continue
+        nested = getattr(mod, "ckpt_nested", False) or name.rsplit(".", 1)[-1] in ("cls_conv", "reg_conv")
+        for i, u in enumerate(mod):
+            stride = 3 if isinstance(u, ConvGnRelu) else 2
+            out[f"{name}.{i}.conv"] = f"{name}.{i}.0" if nested else f"{name}.{stride * i}"
+            if isinstance(u, ConvGnRelu):
+                out[f"{name}.{i}.gn"] = f"{name}.{i}.1" if nested else f"{name}.{stride * i + 1}"
+    return out
+
+
 def reference_to_native(ref_sd, model):
     """Maps a reference / detectron2 state dict onto ``model``'s native keys.
     Returns (native state dict, report) with report = {"missing": native keys nothing was found for, "unexpected": reference keys
@@ -146,6 +186,7 @@ def reference_to_native(ref_sd, model):
     native = model.state_dict()
     convs = _conv_modules(model)
     rules = _fcos_head_rules(model)
+    towers = {} if rules else _unit_tower_map(model)
     out, used, mismatch = {}, set(), []
     for key, cur in native.items():
         if key in rules:
@@ -162,6 +203,9 @@ def reference_to_native(ref_sd, model):
         src = key
         if mod in convs and leaf in _BN.values():
             src = mod + ".norm." + {v: k for k, v in _BN.items()}[leaf]
+        elif mod in towers:
+            src = towers[mod] + "." + leaf
+        src = _ref_name(src)
         if src not in ref_sd:
             continue
         t = ref_sd[src]
@@ -192,10 +236,17 @@ def native_to_reference(model):
     convs = _conv_modules(model)
     head = getattr(model, "head", None)
     fcos = head is not None and hasattr(head, "cls_pred") and hasattr(head, "box_pred") and hasattr(head, "scales")
+    towers = {} if fcos else _unit_tower_map(model)
     out = {}
     for key, t in sd.items():
         t = t.detach().cpu()
         mod, _, leaf = key.rpartition(".")
+        rows = getattr(convs.get(mod), "ckpt_rows", None)
+        if rows is not None and leaf in ("weight", "bias"):      # prediction convs padded to a multiple of 8 output channels: drop the pad
+            t = t[:rows]
+        if mod in towers:
+            out[_ref_name(towers[mod] + "." + leaf)] = _kcrs(t) if (leaf == "weight" and t.dim() == 4) else t.clone()
+            continue
         if fcos and key.startswith("head."):
             if key == "head.scales":
                 for i in range(t.numel()):
@@ -235,12 +286,14 @@ def native_to_reference(model):
                     out[key] = _kcrs(t)
                 continue
         out[key] = t.clone()
-    return out
+    return {_ref_name(k): v for k, v in out.items()}
 
 
-def load_into(model, path, strict=False):
+def load_into(model, path, strict=False, allow_missing=()):
     """Loads ``path`` (native or reference format) into ``model``.  Returns the report dict; raises if NOTHING of the file matched
-    (a silently random-initialised model is the failure this guards against) or, with ``strict``, on any incompatibility."""
+    (a silently random-initialised model is the failure this guards against), if the file is a whole-model checkpoint (it holds tensors
+    outside ``backbone.``) and leaves a trainable tensor outside the backbone without a value - unless its name starts with one of the
+    ``allow_missing`` prefixes -, or, with ``strict``, on any incompatibility."""
     sd, meta = load_file(path)
     if meta["native"]:
         res = model.load_state_dict(sd, strict=False)
@@ -252,6 +305,15 @@ def load_into(model, path, strict=False):
         matched = len(native)
     if matched == 0:
         raise RuntimeError(f"checkpoint {path}: no tensor matches this model ({len(sd)} tensors in the file)")
+    if any(not k.startswith("backbone.") for k in sd):
+        # a detector checkpoint, not an ImageNet backbone file: a head parameter nothing was found for would train from its random
+        # initialisation behind a log line (the padded / re-laid-out heads are exactly where a name or shape rule can be missing)
+        params = {n for n, _ in model.named_parameters()}
+        lost = [k for k in list(report["missing"]) + [m[0] for m in report["shape_mismatch"]]
+                if k in params and not k.startswith("backbone.") and not any(k.startswith(a) for a in allow_missing)]
+        if lost:
+            raise RuntimeError(f"checkpoint {path}: {len(lost)} head parameter(s) of the model have no counterpart in the file "
+                               f"(pass allow_missing=(prefix, ...) to accept): {lost[:12]}{' ...' if len(lost) > 12 else ''}")
     for kind in ("shape_mismatch", "missing", "unexpected"):
         if report[kind]:
             logger.warning("checkpoint %s: %d %s key(s): %s%s", path, len(report[kind]), kind.replace("_", " "),

@@ -9,6 +9,7 @@ NHWC(8) bf16 for the whole batch in ONE kernel (sod_resize_flip_preprocess_batch
 ``pil_bilinear_coeffs`` restates Pillow's ``precompute_coeffs`` + ``normalize_coeffs_8bpc`` (src/libImaging/Resample.c [upstream
 knowledge; Pillow is not installed in this image]) - the triangle filter whose support widens with the down-scaling factor.
 """
+import collections
 import ctypes
 import math
 
@@ -78,7 +79,11 @@ class DeviceInputPipeline:
         self.min_sizes, self.max_size, self.flip_prob = tuple(min_sizes), max_size, flip_prob
         self.mean, self.std, self.div = [float(v) for v in pixel_mean], [float(v) for v in pixel_std], size_divisibility
         self.rng = np.random.RandomState(seed)
-        self._tables = {}
+        self._tables = collections.OrderedDict()
+
+    # COCO has thousands of distinct (source size, target size) pairs: the coefficient tables are an LRU of bounded size (one call
+    # uses at most 2 x 64 of them; an evicted table is freed in stream order, behind the launch that read it)
+    MAX_TABLES = 1024
 
     def _coeffs(self, in_size, out_size, device):
         key = (in_size, out_size, device)
@@ -86,6 +91,10 @@ class DeviceInputPipeline:
         if t is None:
             b, k = pil_bilinear_coeffs(in_size, out_size)
             t = self._tables[key] = (torch.from_numpy(b).to(device), torch.from_numpy(k).to(device), k.shape[1])
+            while len(self._tables) > self.MAX_TABLES:
+                self._tables.popitem(last=False)
+        else:
+            self._tables.move_to_end(key)
         return t
 
     def draw(self, h, w):

@@ -265,7 +265,10 @@ class BottleneckStage(nn.Sequential):
 
     def forward(self, x):
         no_bwd = not torch.is_grad_enabled() or not (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        # the fused kernel addresses its 256-channel output with 32-bit byte offsets (SOD_ESIZE above 2 GiB, e.g. >= 63 images of
+        # 800x1333 per GPU); the generic per-conv path accepts destinations up to 8 GiB (sources stay below 2 GiB model-wide)
         if (BNECK_FUSED and no_bwd and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()
+                and x.shape[0] * x.shape[1] * x.shape[2] * 256 * 2 < 2 ** 31
                 and all(_block_fusable(b) for b in self) and self[0].conv1.in_channels == x.shape[-1]):
             y = x
             for blk in self:
@@ -349,6 +352,20 @@ class ResNet(Backbone):
                 break
             n += 1
         return n
+
+    @torch.no_grad()
+    def prepare_frozen_prefix(self):
+        """Refresh the folded bf16 compute copies of the stem and of the frozen leading stages on the CURRENT stream (a no-op unless a
+        weight or FrozenBN buffer changed): ``forward_frozen_prefix`` may then run on any stream without allocating or writing them."""
+        n = self.frozen_prefix_len()
+        if n < 0:
+            return
+        mods = list(self.stem.modules())
+        for stage, _ in self.stages_and_names[:n]:
+            mods += list(stage.modules())
+        for m in mods:
+            if isinstance(m, HipConv2d):
+                m.prepare()
 
     @torch.no_grad()
     def forward_frozen_prefix(self, x):

@@ -280,6 +280,11 @@ class FCOSV2(nn.Module):
             return False
         dev = self.device
         main = torch.cuda.current_stream(dev)
+        # (re)build the frozen prefix's folded weights on the MAIN stream first: if a checkpoint load changed a buffer, the refolded
+        # copies must not be allocated and written on the side stream, where a forward that does not come through _take_prefetched
+        # (an evaluation hook, another batch) would read them without any ordering
+        if hasattr(bottom, "prepare_frozen_prefix"):
+            bottom.prepare_frozen_prefix()
         side = _prefetch_streams.get(dev.index)
         if side is None:
             side = _prefetch_streams[dev.index] = torch.cuda.Stream(device=dev)
@@ -469,7 +474,6 @@ class FCOS(FCOSV2):
     def inference(self, level_hw, cls_t, box_t, image_sizes):
         """fcos.py:374-383: candidates of every feature map, concatenated per image, NO suppression yet."""
         cand = self.decode_candidates(cls_t, box_t)
-        self._pending = cand                 # padded device tensors for postprocess (one NMS launch for the batch)
         boxes, scores, classes, counts = cand
         cnt = counts.cpu()
         top_n = self.pre_nms_top_n
@@ -481,12 +485,19 @@ class FCOS(FCOSV2):
             r.scores = scores[i, idx]
             r.pred_classes = classes[i, idx].long()
             results.append(r)
+        # padded device tensors for postprocess (one NMS launch for the batch), valid only for THIS list of THESE Instances objects
+        self._pending = (cand, results, [id(r) for r in results])
         return results
 
     def postprocess(self, instances, batched_inputs, image_sizes):
         """fcos.py:438-464: per-class NMS, top ``max_detections_per_image``, then rescale to the requested output size."""
-        cand, self._pending = getattr(self, "_pending", None), None
-        if cand is None:                     # called with Instances that did not come from inference(): per-image path
+        pend, self._pending = getattr(self, "_pending", None), None
+        cand = None
+        # the batched path only when the caller hands back exactly what inference() returned; a filtered / augmented / re-ordered
+        # list (or other Instances) goes through the per-image path on the tensors it carries
+        if pend is not None and instances is pend[1] and [id(r) for r in instances] == pend[2]:
+            cand = pend[0]
+        if cand is None:
             from ...layers.nms import batched_nms
 
             kept = []

@@ -42,6 +42,8 @@ class RetinaNetHead(nn.Module):
         self.box_pitch = _ceil8(num_anchors * 4)            # 36 -> 40
         self.cls_score = HipConv2d(in_channels, self.kc, 3, 1, 1, bias=True)
         self.bbox_pred = HipConv2d(in_channels, self.box_pitch, 3, 1, 1, bias=True)
+        # rows a reference checkpoint holds (checkpoint.py drops / restores the pad): A*K scores, A*4 deltas (retina_rotated.py:432-437)
+        self.cls_score.ckpt_rows, self.bbox_pred.ckpt_rows = num_anchors * self.num_classes, num_anchors * 4
         for u in list(self.cls_subnet) + list(self.bbox_subnet):
             u.conv.init_normal(0.01, 0.0)
         prior = cfg.MODEL.RETINANET.PRIOR_PROB

@@ -54,6 +54,7 @@ class StandardRPNHead(nn.Module):
         self.conv = ConvML(C, C, 3, 1, relu=True)
         self.objectness_logits = ConvML(C, self.obj_pad, 1, 0, out_f32=True)
         self.anchor_deltas = ConvML(C, self.delta_pad, 1, 0, out_f32=True)
+        self.objectness_logits.conv.ckpt_rows, self.anchor_deltas.conv.ckpt_rows = num_anchors, num_anchors * box_dim     # without the pad
         with torch.no_grad():
             for m in (self.conv, self.objectness_logits, self.anchor_deltas):
                 m.conv.init_normal(0.01, 0.0)

@@ -178,6 +178,7 @@ class FastRCNNOutputLayers(nn.Module):
         self.cls_score = HipConv2d(input_size, self.cls_pad, 1, 1, 0, bias=True, out_f32=True)
         self.bbox_pred = HipConv2d(input_size, self.box_out, 1, 1, 0, bias=True, out_f32=True)
         self.cls_score.is_linear = self.bbox_pred.is_linear = True
+        self.cls_score.ckpt_rows, self.bbox_pred.ckpt_rows = self.num_classes + 1, self.num_classes * self.box_dim     # without the pad
         with torch.no_grad():
             self.cls_score.init_normal(0.01, 0.0)
             self.bbox_pred.init_normal(0.001, 0.0)
