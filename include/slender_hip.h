@@ -383,8 +383,9 @@ int sod_deform_conv_fwd_f32(const float* x, const float* offset, const float* ma
 /* ... and its WEIGHT GRADIENT the same way: dw[k][tap][c] (fp32, [K][KH*KW][C], accumulated) += sum over pixels of dy * sample, the
  * sampled rows gathered into LDS tiles inside the kernel (detectron2 deform_conv_backward_filter).  Pixel splits meet in fp32 slabs
  * in ws (sod_conv2d_wgrad_workspace_bytes() suffices) summed in a fixed order: deterministic.  dy (N,Ho,Wo,K) bf16.  Needs
- * C % 128 == 0 (or C == 64) and, with deformable_groups > 1, (C / deformable_groups) % 128 == 0. */
-int sod_deform_conv_wgrad_fused(const void* dy, const void* x, const float* offset, const float* mask, float* dw,
+ * C % 128 == 0 (or C == 64) and, with deformable_groups > 1, (C / deformable_groups) % 128 == 0.  qscale (optional, [K]): each row k
+ * of the sum is multiplied by qscale[k] before it is added (detectron2 DeformBottleneckBlock: FrozenBN folded into conv2's weights). */
+int sod_deform_conv_wgrad_fused(const void* dy, const void* x, const float* offset, const float* mask, float* dw, const float* qscale,
                                 int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
                                 int off_ld, int mask_ld, int mask_is_logit, void* ws, long long ws_bytes, void* stream);
 /* ---------------------------------------------------------------------------------------------------------
@@ -531,6 +532,47 @@ int sod_border_align_bwd(const float* dout, const float* feature, const float* b
 int sod_corner_pool_fwd(const float* x, float* y, long long planes, int H, int W, int mode, void* stream);
 int sod_corner_pool_bwd(const float* x, const float* dy, float* dx, long long planes, int H, int W, int mode, int tie_latest,
                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * fp32-STORAGE validation path (csrc/f32_path.hip; Python: SOD_PRECISION=fp32 / layers.functional.set_precision("fp32")).
+ * The operators of the training step with fp32 activations, weight copies and gradients and fp32 FMA accumulation, untuned: the
+ * configuration in which north_star's "total-loss delta < 1e-3 vs the reference's CPU path after 100 iterations" is asserted
+ * (tests/test_gpu_parity100.py).  Same operand conventions as the bf16 entry points they shadow (NHWC, KRSC weights, image strides
+ * in elements, flags SOD_CONV_RELU | SOD_CONV_RES_UP2); every reduction has a fixed order.
+ *   conv fwd / dgrad / wgrad: ATen conv2d of detectron2 ResNet / FPN and of FCOSHead (slender_det/modeling/meta_arch/fcos/fcosv2.py:277-381).
+ *   dgrad reads the KRSC weights (no transposed copy); `accum` is added (at the even pixels only with accum_even, shape (N,H/2,W/2,C))
+ *   before `relu_mask` (> 0 keeps) is applied; wgrad ADDS qscale[k] * sum into dw. */
+int sod_conv2d_fwd_f32(const float* x, const float* w_krsc, const float* bias, const float* res, float* y, int N, int H, int W, int C, int K,
+                       int R, int S, int stride, int pad, int dil, long long x_img_stride, long long y_img_stride, int flags, void* stream);
+int sod_conv2d_dgrad_f32(const float* dy, const float* w_krsc, const float* accum, const float* relu_mask, float* dx, int N, int H, int W, int C,
+                         int K, int R, int S, int stride, int pad, int dil, long long dy_img_stride, int accum_even, void* stream);
+int sod_conv2d_wgrad_f32(const float* dy, const float* x, float* dw, const float* qscale, int N, int H, int W, int C, int K, int R, int S,
+                         int stride, int pad, int dil, long long dy_img_stride, long long x_img_stride, void* stream);
+/* nn.GroupNorm(G, C) (+ ReLU) of the towers (fcosv2.py:315-336): two-pass statistics; backward also adds dgamma / dbeta and (optional)
+ * the per-channel sum of dx (the bias gradient of the preceding conv) in place.  256 % (C / G) == 0. */
+int sod_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean_rstd, int N, int HW, int C, int G,
+                          float eps, int relu, void* stream);
+int sod_groupnorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta, const float* mean_rstd, float* dx,
+                          float* dgamma, float* dbeta, float* dxsum, int N, int HW, int C, int G, int relu, void* stream);
+/* op 0: out = relu(a); 1: out = b > 0 ? a : 0 (ReLU backward, a = dy, b = y); 2: out = a + b */
+int sod_eltwise_f32(int op, const float* a, const float* b, float* out, long long n, void* stream);
+/* FPN top-down sum a + nearest2x(b) and the gradient of the up-sampling; BasicStem max-pool (C.9) */
+int sod_add_up2_f32(const float* a, const float* b, float* out, int N, int H, int W, int C, void* stream);
+int sod_upsample2x_bwd_f32(const float* g, float* dprev, int N, int Hc, int Wc, int C, void* stream);
+int sod_maxpool3x3s2_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* dbias[c] += sum over images and pixels of dy (image stride in elements, 0 = dense) */
+int sod_bias_grad_f32(const float* dy, float* dbias, int N, int HW, int C, long long img_stride, void* stream);
+/* FCOSV2.preprocess_image (fcosv2.py:268-275) into an fp32 NHWC(Cpad) image; mean3 / std3 are HOST pointers */
+int sod_preprocess_image_f32(const void* img, int is_uint8, int C, int H, int W, float* out, int Hp, int Wp, int Cpad, const float* mean3,
+                             const float* std3, void* stream);
+/* fp32 compute copies of a master weight: KRSC times scale[k] (FrozenBN fold), input channels zero-padded to Cpad; optional CRSK */
+int sod_weight_prep_f32(const float* w, const float* scale, float* w_krsc, float* w_crsk, int K, int RS, int C, int Cpad, void* stream);
+/* sod_fcos_regctr_loss_bwd with fp32 gradient rows */
+int sod_fcos_regctr_loss_bwd_f32(const float* box_raw, int ld_box, const float* ctr_logit, int ld_ctr, const int* labels,
+                                 const float* reg_targets, const float* ctr_targets, const float* scales, int N, int nlevels, const int* lvl_h,
+                                 const int* lvl_w, const int* lvl_stride, int num_classes, int loss_type, int norm_reg_targets,
+                                 const float* grad_reg, const float* grad_ctr, const float* norm, float inv_world, void* dbox, int ld_out,
+                                 int ctr_col, void* dctr, int ld_dctr, int dctr_col, float* dscales, float* ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -45,11 +45,20 @@ class OracleFCOS:
     @classmethod
     def from_hip_model(cls, model, emulate_bf16=False):
         """Copy weights out of a slenderobjdet_amd FCOSV2 (any device) into torch-layout CPU tensors."""
+        from slenderobjdet_amd.layers.deform_conv import DeformConv
         from slenderobjdet_amd.layers.nn import HipConv2d, HipGroupNorm
 
-        params, buffers = {}, {}
+        params, buffers, dcn = {}, {}, {}
         for name, m in model.named_modules():
-            if isinstance(m, HipConv2d):
+            if isinstance(m, DeformConv):      # DeformConv / ModulatedDeformConv (detectron2, SURVEY.md C.11): KRSC -> KCRS, optional FrozenBN
+                params[name + ".weight"] = m.weight.detach().float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(m.weight.requires_grad)
+                if m.bias is not None:
+                    params[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(m.bias.requires_grad)
+                if m.frozen_bn:
+                    scale = m.bn_weight.float().cpu() * torch.rsqrt(m.bn_running_var.float().cpu() + 1e-5)
+                    buffers[name + ".scale"], buffers[name + ".shift"] = scale, m.bn_bias.float().cpu() - m.bn_running_mean.float().cpu() * scale
+                dcn[name] = dict(modulated=m.modulated, dg=m.deformable_groups, stride=m.stride, pad=m.padding, dil=m.dilation)
+            elif isinstance(m, HipConv2d):
                 w = m.weight.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
                 params[name + ".weight"] = w.requires_grad_(m.weight.requires_grad)
                 if m.bias is not None:
@@ -73,14 +82,40 @@ class OracleFCOS:
             num_convs=len(model.head.cls_tower), size_div=model.backbone.size_divisibility,
             stride_in_1x1={n: [blk.conv1.stride for blk in getattr(model.backbone.bottom_up, n)] for n in res_names},
             block_stride={n: [blk.stride for blk in getattr(model.backbone.bottom_up, n)] for n in res_names},
+            dcn=dcn,
         )
         return cls(params, buffers, cfg_like, emulate_bf16)
+
+    def double(self):
+        """The same model in float64 (an arbiter between two fp32 implementations: tests/test_gpu_f32_mode.py).  In place; returns self."""
+        self.p = {k: v.detach().double().requires_grad_(v.requires_grad) for k, v in self.p.items()}
+        self.b = {k: v.double() for k, v in self.b.items()}
+        return self
 
     # ------------------------------------------------------------------ layers
     def _act(self, x):
         return _RoundSTE.apply(x) if self.emu else x
 
-    def _conv(self, name, x, stride=1, pad=0, relu=False, res=None):
+    def _dcn(self, name, x, om, relu=False):
+        """DeformConv / ModulatedDeformConv ``name`` on x with the offset conv's output ``om`` (first 18*G channels offsets, next 9*G mask
+        logits; df_conv.py:67-78, detectron2 DeformBottleneckBlock), optional folded FrozenBN, ReLU."""
+        from . import deform_conv as odc
+
+        d = self.c["dcn"][name]
+        w, bias = self.p[name + ".weight"], self.p.get(name + ".bias")
+        if name + ".scale" in self.b:
+            w = w * self.b[name + ".scale"].view(-1, 1, 1, 1)
+            bias = self.b[name + ".shift"] + (bias * self.b[name + ".scale"] if bias is not None else 0)
+        if self.emu:
+            w = _RoundSTE.apply(w)
+        g = d["dg"]
+        mask = om[:, 18 * g:27 * g].sigmoid() if d["modulated"] else None
+        y = odc.deform_conv2d(x, om[:, :18 * g], w, bias, d["stride"], d["pad"], d["dil"], mask, g, sample_hook=self._act if self.emu else None)
+        if relu:
+            y = torch.relu(y)
+        return self._act(y)
+
+    def _conv(self, name, x, stride=1, pad=0, relu=False, res=None, out_f32=False):
         w = self.p[name + ".weight"]
         bias = self.p.get(name + ".bias")
         if name + ".scale" in self.b:      # FrozenBN folded the way the product path folds it
@@ -93,7 +128,7 @@ class OracleFCOS:
             y = y + res
         if relu:
             y = torch.relu(y)
-        return self._act(y)
+        return y if out_f32 else self._act(y)      # offset / prediction convs keep fp32 rows on the product path
 
     def _bottom_up(self, x):
         c = self.c
@@ -108,7 +143,11 @@ class OracleFCOS:
                 if c["bottleneck"]:
                     s1 = c["stride_in_1x1"][stage][b]
                     y = self._conv(pre + ".conv1", x, s1, 0, relu=True)
-                    y = self._conv(pre + ".conv2", y, bs // s1, 1, relu=True)
+                    if (pre + ".conv2_offset.weight") in self.p:       # DeformBottleneckBlock (MODEL.RESNETS.DEFORM_ON_PER_STAGE)
+                        om = self._conv(pre + ".conv2_offset", y, bs // s1, 1, out_f32=True)
+                        y = self._dcn(pre + ".conv2", y, om, relu=True)
+                    else:
+                        y = self._conv(pre + ".conv2", y, bs // s1, 1, relu=True)
                     x = self._conv(pre + ".conv3", y, 1, 0, relu=True, res=sc)
                 else:
                     y = self._conv(pre + ".conv1", x, bs, 1, relu=True)
@@ -132,7 +171,11 @@ class OracleFCOS:
 
     def _tower(self, prefix, x):
         for i in range(self.c["num_convs"]):
-            y = self._conv(f"{prefix}.{i}.conv", x, 1, 1)
+            if f"{prefix}.{i}.conv.offset.weight" in self.p:       # DFConv2d as the last tower conv (USE_DCN_IN_TOWER, fcosv2.py:300-336)
+                om = self._conv(f"{prefix}.{i}.conv.offset", x, 1, 1, out_f32=True)
+                y = self._dcn(f"{prefix}.{i}.conv.conv", x, om)
+            else:
+                y = self._conv(f"{prefix}.{i}.conv", x, 1, 1)
             y = F.group_norm(y, 32, self.p[f"{prefix}.{i}.gn.weight"], self.p[f"{prefix}.{i}.gn.bias"], 1e-5)
             x = self._act(torch.relu(y))
         return x
@@ -171,7 +214,7 @@ class OracleFCOS:
         batch = torch.zeros(len(imgs), 3, mh, mw)
         for i, im in enumerate(imgs):
             batch[i, :, : im.shape[1], : im.shape[2]] = im
-        return _rb(batch, self.emu)
+        return _rb(batch, self.emu).to(next(iter(self.p.values())).dtype)
 
     def losses(self, batched_inputs, world=1):
         c = self.c

@@ -93,7 +93,7 @@ _SIGS = {
     "sod_retina_box_loss_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "sod_deform_conv_fwd_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sod_deform_conv_fwd_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "sod_deform_conv_wgrad_fused": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P],
+    "sod_deform_conv_wgrad_fused": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P],
     "sod_deform_im2col": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sod_deform_col2im": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sod_f32_to_bf16": [_P, _P, _L, _P],
@@ -124,6 +124,20 @@ _SIGS = {
     "sod_reppoints_box_loss_fwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
     "sod_reppoints_box_loss_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _F, _F, _P, _P],
     "sod_reppoints_finalize": [_P, _P, _P, _P, _F, _I, _F, _P, _P],
+    "sod_conv2d_fwd_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _I, _P],
+    "sod_conv2d_dgrad_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P],
+    "sod_conv2d_wgrad_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _P],
+    "sod_groupnorm_fwd_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "sod_groupnorm_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sod_eltwise_f32": [_I, _P, _P, _P, _L, _P],
+    "sod_add_up2_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "sod_upsample2x_bwd_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "sod_maxpool3x3s2_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "sod_bias_grad_f32": [_P, _P, _I, _I, _I, _L, _P],
+    "sod_preprocess_image_f32": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P],
+    "sod_weight_prep_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "sod_fcos_regctr_loss_bwd_f32": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F,
+                                     _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "sod_reduce_workspace_bytes": [],
     "sod_version": [],
 }

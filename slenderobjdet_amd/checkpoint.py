@@ -69,9 +69,10 @@ def load_file(path):
 
 # ------------------------------------------------------------------------------------------------ conversion
 def _conv_modules(model):
+    from .layers.deform_conv import DeformConv
     from .layers.nn import HipConv2d
 
-    return {name: m for name, m in model.named_modules() if isinstance(m, HipConv2d)}
+    return {name: m for name, m in model.named_modules() if isinstance(m, (HipConv2d, DeformConv))}
 
 
 def _fit(t, shape):

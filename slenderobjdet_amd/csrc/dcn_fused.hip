@@ -41,6 +41,7 @@ struct DcnFArgs {
   const __bf16* dy;       // wgrad: (N,Ho,Wo,K)
   float* partial;         // wgrad: slabs
   float* dw;              // wgrad: [K][KH*KW][C] fp32, accumulated
+  const float* qscale;    // wgrad: optional per-output-channel factor (chain rule through a folded FrozenBN scale)
   uint32_t x_bytes, w_bytes, dy_bytes;
   int N, H, W, C, Ho, Wo, K, KH, KW, stride, pad, dil, DG;
   int off_ld, mask_ld, mask_logit, relu;
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(256) void dcn_wgrad_reduce_kernel(const DcnFArgs a)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int q = qt * 256 + wr * 64 + i * 16 + fg * 4 + e;
-    if (q < a.K) a.dw[((size_t)q * taps + tap) * a.C + c] += sum[e];
+    if (q < a.K) a.dw[((size_t)q * taps + tap) * a.C + c] += a.qscale ? sum[e] * a.qscale[q] : sum[e];
   }
 }
 
@@ -586,7 +587,7 @@ extern "C" int sod_deform_conv_fwd_fused(const void* x, const float* offset, con
   return SOD_OK;
 }
 
-extern "C" int sod_deform_conv_wgrad_fused(const void* dy, const void* x, const float* offset, const float* mask, float* dw,
+extern "C" int sod_deform_conv_wgrad_fused(const void* dy, const void* x, const float* offset, const float* mask, float* dw, const float* qscale,
                                            int N, int H, int W, int C, int K, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
                                            int off_ld, int mask_ld, int mask_is_logit, void* ws, long long ws_bytes, void* stream) {
   if (!dy || !dw || !ws || ws_bytes <= 0 || ((uintptr_t)ws & 15)) return SOD_EARG;
@@ -595,7 +596,7 @@ extern "C" int sod_deform_conv_wgrad_fused(const void* dy, const void* x, const 
   if (rc) return rc;
   if ((C & 127) && C != 64) return SOD_EARG;          // 128-channel tiles (a lone 64-channel input runs as one half-empty tile)
   if (((C / deformable_groups) & 127) && deformable_groups != 1) return SOD_EARG;    // a tile must not straddle deformable groups
-  a.dy = (const __bf16*)dy; a.dw = dw; a.partial = (float*)ws;
+  a.dy = (const __bf16*)dy; a.dw = dw; a.qscale = qscale; a.partial = (float*)ws;
   a.QT = (K + 255) / 256; a.CT = (C + 127) / 128;
   const int tiles = a.QT * a.CT * KH * KW;
   const int KT = (a.P + 63) / 64;

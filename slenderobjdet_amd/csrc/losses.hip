@@ -383,10 +383,11 @@ __global__ __launch_bounds__(256) void regctr_fwd_kernel(const RegCtrArgs a, flo
 
 // writes d(box_raw) and d(ctr_logit) as bf16 into a padded [M, ld_out] buffer (columns 0..3 box, ctr_col ctr,
 // remaining columns zero) and per-level d(scale) partials.
+template <typename T>      // T = __bf16 (product path) or float (fp32-storage validation path, f32_path.hip)
 __global__ __launch_bounds__(256) void regctr_bwd_kernel(const RegCtrArgs a, const float* __restrict__ greg,
                                                          const float* __restrict__ gctr, const float* __restrict__ norm, float inv_world,
-                                                         __bf16* __restrict__ dbox, int ld_out, int ctr_col,
-                                                         __bf16* __restrict__ dctr, int ld_dctr, int dctr_col,
+                                                         T* __restrict__ dbox, int ld_out, int ctr_col,
+                                                         T* __restrict__ dctr, int ld_dctr, int dctr_col,
                                                          float* __restrict__ part) {
   // norm[0] = sum over ranks of num_pos, norm[1] = sum over ranks of sum(ctr targets); inv_world = 1/world
   __shared__ float red[4];
@@ -430,11 +431,11 @@ __global__ __launch_bounds__(256) void regctr_bwd_kernel(const RegCtrArgs a, con
       for (int e = 0; e < ld_out; ++e) {
         float v = 0.f;
         if (e < 4) v = gb[e]; else if (e == ctr_col) v = gc;
-        dbox[(long long)i * ld_out + e] = (__bf16)v;
+        dbox[(long long)i * ld_out + e] = (T)v;
       }
     } else {
-      for (int e = 0; e < ld_out; ++e) dbox[(long long)i * ld_out + e] = (__bf16)(e < 4 ? gb[e] : 0.f);
-      dctr[(long long)i * ld_dctr + dctr_col] = (__bf16)gc;   // caller pre-fills the rest of that row
+      for (int e = 0; e < ld_out; ++e) dbox[(long long)i * ld_out + e] = (T)(e < 4 ? gb[e] : 0.f);
+      dctr[(long long)i * ld_dctr + dctr_col] = (T)gc;   // caller pre-fills the rest of that row
     }
   }
 #pragma unroll
@@ -589,7 +590,7 @@ extern "C" int sod_fcos_regctr_loss_fwd(const float* box_raw, int ld_box, const 
   return SOD_OK;
 }
 
-extern "C" int sod_fcos_regctr_loss_bwd(const float* box_raw, int ld_box, const float* ctr_logit, int ld_ctr,
+static int regctr_bwd_impl(int out_f32, const float* box_raw, int ld_box, const float* ctr_logit, int ld_ctr,
                                         const int* labels, const float* reg_targets, const float* ctr_targets,
                                         const float* scales, int N, int nlevels, const int* lvl_h, const int* lvl_w,
                                         const int* lvl_stride, int num_classes, int loss_type, int norm_reg_targets,
@@ -607,11 +608,37 @@ extern "C" int sod_fcos_regctr_loss_bwd(const float* box_raw, int ld_box, const 
   a.type = loss_type; a.norm_reg = norm_reg_targets;
   hipStream_t st = (hipStream_t)stream;
   const int g = grid_for(a.M);
-  SOD_LAUNCH(regctr_bwd_kernel, dim3(g), dim3(256), 0, st, a, grad_reg, grad_ctr, norm, inv_world, (__bf16*)dbox, ld_out, ctr_col,
-                     (__bf16*)dctr, ld_dctr, dctr_col, ws);
+  if (out_f32)
+    SOD_LAUNCH(regctr_bwd_kernel<float>, dim3(g), dim3(256), 0, st, a, grad_reg, grad_ctr, norm, inv_world, (float*)dbox, ld_out, ctr_col,
+               (float*)dctr, ld_dctr, dctr_col, ws);
+  else
+    SOD_LAUNCH(regctr_bwd_kernel<__bf16>, dim3(g), dim3(256), 0, st, a, grad_reg, grad_ctr, norm, inv_world, (__bf16*)dbox, ld_out, ctr_col,
+               (__bf16*)dctr, ld_dctr, dctr_col, ws);
   SOD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, g, nlevels, dscales, 1);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
+}
+
+extern "C" int sod_fcos_regctr_loss_bwd(const float* box_raw, int ld_box, const float* ctr_logit, int ld_ctr,
+                                        const int* labels, const float* reg_targets, const float* ctr_targets,
+                                        const float* scales, int N, int nlevels, const int* lvl_h, const int* lvl_w,
+                                        const int* lvl_stride, int num_classes, int loss_type, int norm_reg_targets,
+                                        const float* grad_reg, const float* grad_ctr, const float* norm /*[2]*/, float inv_world,
+                                        void* dbox, int ld_out, int ctr_col, void* dctr, int ld_dctr, int dctr_col,
+                                        float* dscales, float* ws, void* stream) {
+  return regctr_bwd_impl(0, box_raw, ld_box, ctr_logit, ld_ctr, labels, reg_targets, ctr_targets, scales, N, nlevels, lvl_h, lvl_w, lvl_stride, num_classes,
+                         loss_type, norm_reg_targets, grad_reg, grad_ctr, norm, inv_world, dbox, ld_out, ctr_col, dctr, ld_dctr, dctr_col, dscales, ws, stream);
+}
+
+extern "C" int sod_fcos_regctr_loss_bwd_f32(const float* box_raw, int ld_box, const float* ctr_logit, int ld_ctr,
+                                        const int* labels, const float* reg_targets, const float* ctr_targets,
+                                        const float* scales, int N, int nlevels, const int* lvl_h, const int* lvl_w,
+                                        const int* lvl_stride, int num_classes, int loss_type, int norm_reg_targets,
+                                        const float* grad_reg, const float* grad_ctr, const float* norm /*[2]*/, float inv_world,
+                                        void* dbox, int ld_out, int ctr_col, void* dctr, int ld_dctr, int dctr_col,
+                                        float* dscales, float* ws, void* stream) {
+  return regctr_bwd_impl(1, box_raw, ld_box, ctr_logit, ld_ctr, labels, reg_targets, ctr_targets, scales, N, nlevels, lvl_h, lvl_w, lvl_stride, num_classes,
+                         loss_type, norm_reg_targets, grad_reg, grad_ctr, norm, inv_world, dbox, ld_out, ctr_col, dctr, ld_dctr, dctr_col, dscales, ws, stream);
 }
 
 extern "C" int sod_fcos_finalize_losses(const float* focal_sum, const float* regctr_sums, const float* stats,

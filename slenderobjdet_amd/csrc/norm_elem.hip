@@ -5,6 +5,8 @@
 // Reference call sites: nn.GroupNorm(32,C)+ReLU in FCOSHead (fcosv2.py:315-336), detectron2 FrozenBatchNorm2d /
 // BasicStem max_pool2d / FPN top-down path, torch.optim.SGD built by
 // slender_det/solver/build.py:8-33, preprocess_image (fcosv2.py:268-275).
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/slender_hip.h"
 
@@ -19,6 +21,7 @@ struct GnArgs {
   float* dgamma; float* dbeta;
   float* dxsum;                             // optional: per-channel sum of dx (= bias gradient of the producing conv)
   int N, HW, C, G, cpg, relu;
+  int n0;                                   // first image of this launch (blockIdx.y counts from it): image-chunked backward
   long long img_stride;                     // elements between images
   float eps;
   int pix_per_block;
@@ -33,7 +36,7 @@ __device__ __forceinline__ void gn_stats_body(const GnArgs& a, const int bx) {
   // Block reduction through plain LDS stores: ds_add_f32 runs at 0.33 lanes/clk/CU on gfx950 (tools/micro/lds_atomic.hip), 40x
   // below ds_write/ds_read, and these kernels ended every block with 2-18 of them per thread.
   extern __shared__ float lsum[];   // [256][2] per-thread partials
-  const int n = blockIdx.y;
+  const int n = blockIdx.y + a.n0;
   const int c8n = a.C >> 3;                 // vectors per pixel
   const int rows_per_iter = 256 / c8n;      // host guarantees c8n divides 256
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
@@ -75,6 +78,7 @@ struct GnML {
   const float* gamma; const float* beta; float* dgamma; float* dbeta; float* dxsum;
   int N, C, G, cpg, relu; float eps;
   float* part_grp; float* part_gb; float* part_dx;
+  int n0;
 };
 
 __device__ __forceinline__ int gn_pick(const GnML& m, GnArgs& a) {
@@ -84,7 +88,7 @@ __device__ __forceinline__ int gn_pick(const GnML& m, GnArgs& a) {
   a.x = L.x; a.dy = L.dy; a.y = L.y; a.dx = L.dx; a.stats = L.stats; a.red = L.red; a.img_stride = L.img_stride; a.HW = L.HW;
   a.pix_per_block = L.pix_per_block;
   a.gamma = m.gamma; a.beta = m.beta; a.dgamma = m.dgamma; a.dbeta = m.dbeta; a.dxsum = m.dxsum;
-  a.N = m.N; a.C = m.C; a.G = m.G; a.cpg = m.cpg; a.relu = m.relu; a.eps = m.eps;
+  a.N = m.N; a.C = m.C; a.G = m.G; a.cpg = m.cpg; a.relu = m.relu; a.eps = m.eps; a.n0 = m.n0;
   a.part_grp = m.part_grp; a.part_gb = m.part_gb; a.part_dx = m.part_dx;
   return l;
 }
@@ -102,7 +106,7 @@ __global__ void gn_finalize_stats_kernel(const GnML m) {
 }
 
 __device__ __forceinline__ void gn_apply_body(const GnArgs& a, const int bx) {
-  const int n = blockIdx.y;
+  const int n = blockIdx.y + a.n0;
   const int c8n = a.C >> 3;
   const int rows_per_iter = 256 / c8n;
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
@@ -132,7 +136,7 @@ __device__ __forceinline__ void gn_apply_body(const GnArgs& a, const int bx) {
 
 __device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx) {
   extern __shared__ float lsum[];   // [256][18] per-thread partials: dgamma[8], dbeta[8], s1, s2
-  const int n = blockIdx.y;
+  const int n = blockIdx.y + a.n0;
   const int c8n = a.C >> 3;
   const int rows_per_iter = 256 / c8n;
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
@@ -194,7 +198,7 @@ __device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx
 
 __device__ __forceinline__ void gn_bwd_apply_body(const GnArgs& a, const int bx, const float inv_m) {
   extern __shared__ float lsum[];   // [256][8] per-thread sums of dx when a.dxsum
-  const int n = blockIdx.y;
+  const int n = blockIdx.y + a.n0;
   const int c8n = a.C >> 3;
   const int rows_per_iter = 256 / c8n;
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
@@ -765,7 +769,7 @@ int gn_grid(int HW, int N, int& ppb) {
 
 }  // namespace
 
-static int gn_fill(GnML& m, int nlev, const int* hw, int N, int C, int G, float eps, int relu, const long long* img_strides) {
+static int gn_fill(GnML& m, int nlev, const int* hw, int N, int C, int G, float eps, int relu, const long long* img_strides, int grid_n = 0) {
   if (nlev <= 0 || nlev > GN_MAX_LEVELS || !hw) return SOD_EARG;
   m.nlev = nlev; m.N = N; m.C = C; m.G = G; m.cpg = C / G; m.relu = relu; m.eps = eps;
   int blk = 0;
@@ -776,7 +780,8 @@ static int gn_fill(GnML& m, int nlev, const int* hw, int N, int C, int G, float 
     L.HW = hw[l];
     L.img_stride = (img_strides && img_strides[l] > 0) ? img_strides[l] : (long long)hw[l] * C;
     // ~1024 / N blocks per level for the largest level, proportionally fewer for the small ones (>= 64 pixels per block)
-    int gx = 1024 / (N > 0 ? N : 1);
+    // (grid_n: the number of images one launch covers when that is fewer than N - the image-chunked backward)
+    int gx = 1024 / (grid_n > 0 ? grid_n : (N > 0 ? N : 1));
     if (gx < 1) gx = 1;
     int ppb = (hw[0] + gx - 1) / gx;
     if (ppb < 64) ppb = 64;
@@ -847,8 +852,33 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
                                     float* red_ws /* 2*N*G*nlev floats */, int N, const int* hw, int C, int G, int relu,
                                     float* det_ws, long long det_ws_bytes, void* stream) {
   if (!dy || !x || !gamma || !beta || !mean_rstd || !dx || !dgamma || !dbeta || !red_ws) return SOD_EARG;
+  if (!hw || N <= 0 || nlev <= 0 || nlev > GN_MAX_LEVELS) return SOD_EARG;
+  // EXPERIMENT, off by default (SOD_GN_BWD_CHUNK_MB=0): the apply pass re-reads dy and x; over the whole batch they are 367 MB per FCOS
+  // tower unit - more than the 256 MB Infinity Cache - so the two passes can walk over the batch in chunks of images whose dy + x fit the
+  // cache (the statistics are per image: a chunk's reduction is complete when its apply pass starts).  Measured on the FCOS R50 step
+  // (one gpurun call, 60 timed steps each): no chunks 619.6 / 621.9 img/s, 184 MB chunks 617.4 / 620.0, 128 MB 612.3 / 618.4, 96 MB
+  // 609.9 / 617.7 (blocks per image scaled up / kept) - slower every time: the other tower's convolutions and the weight-gradient
+  // stream run beside these kernels and stream ~1 GB through the same cache between a chunk's two passes, and four dependent kernel
+  // pairs expose four grid tails instead of one.  Deterministic mode always keeps one chunk.
+  static const long long chunk_bytes = [] {
+    const char* v = getenv("SOD_GN_BWD_CHUNK_MB");
+    return (long long)(v ? atoi(v) : 0) << 20;
+  }();
+  static const int grid_scale = [] {       // blocks per image grow as the chunk shrinks (1) or stay as for the whole batch (0)
+    const char* v = getenv("SOD_GN_BWD_CHUNK_GRID");
+    return v ? atoi(v) : 1;
+  }();
+  long long per_img = 0;
+  for (int l = 0; l < nlev; ++l) per_img += (long long)hw[l] * C * 2 * 2;
+  int cn = N;
+  if (!det_ws && chunk_bytes > 0 && per_img * N > chunk_bytes) {
+    cn = (int)(chunk_bytes / per_img);
+    if (cn < 1) cn = 1;
+    const int nchunks = (N + cn - 1) / cn;
+    cn = (N + nchunks - 1) / nchunks;          // equal chunks
+  }
   GnML m{};
-  const int gx = gn_fill(m, nlev, hw, N, C, G, 0.f, relu, nullptr);
+  const int gx = gn_fill(m, nlev, hw, N, C, G, 0.f, relu, nullptr, (cn < N && grid_scale) ? cn : 0);
   if (gx <= 0) return gx ? gx : SOD_EARG;
   m.gamma = gamma; m.beta = beta; m.dgamma = dgamma; m.dbeta = dbeta; m.dxsum = dxsum;
   for (int l = 0; l < nlev; ++l) {
@@ -874,8 +904,12 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
   }
   hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * N * G * nlev, st);
   if (e != hipSuccess) return (int)e;
-  SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 18 * 256, st, m);
-  SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * 8 * 256 : 0, st, m);
+  for (int n0 = 0; n0 < N; n0 += cn) {
+    const int nn = (N - n0 < cn) ? N - n0 : cn;
+    m.n0 = n0;
+    SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, nn), dim3(256), sizeof(float) * 18 * 256, st, m);
+    SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, nn), dim3(256), dxsum ? sizeof(float) * 8 * 256 : 0, st, m);
+  }
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -67,11 +67,11 @@ class _DeformConvFn(torch.autograd.Function):
         if mod.weight.requires_grad:
             if ctx.fused:
                 HF.deform_conv_wgrad_fused(dy, x, offset, mask, arena.grad_view(mod.weight).view(K, 1, 1, k * k * C), (k, k), mod.stride, mod.padding,
-                                           mod.dilation, dg, off_ld, mask_ld, mask_is_logit)
+                                           mod.dilation, dg, off_ld, mask_ld, mask_is_logit, qscale=mod.bn_scale)
             else:
                 if cols is None:
                     cols = HF.deform_im2col(x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, off_ld, mask_ld, mask_is_logit)
-                HF.conv2d_wgrad(dy, cols, arena.grad_view(mod.weight).view(K, 1, 1, k * k * C), 1, 1, 1, 0, 1)
+                HF.conv2d_wgrad(dy, cols, arena.grad_view(mod.weight).view(K, 1, 1, k * k * C), 1, 1, 1, 0, 1, qscale=mod.bn_scale)
                 del cols
             arena.mark_ready(mod.weight)
             if mod.bias is not None:
@@ -80,13 +80,17 @@ class _DeformConvFn(torch.autograd.Function):
         dcols = HF.conv2d_dgrad(dy, mod.wt_bf16, (Ho, Wo), 1, 0, 1)
         doff = torch.zeros_like(offset)          # pitched like the offset tensor (mask columns live in the same rows for v2)
         dmask = None
+        aliased = mask is not None and mask.untyped_storage().data_ptr() == offset.untyped_storage().data_ptr()
         if mask is not None:
-            dmask = doff.view(-1)[mask.storage_offset() - offset.storage_offset():] if mask.untyped_storage().data_ptr() == offset.untyped_storage().data_ptr() else torch.zeros_like(mask)
+            dmask = doff.view(-1)[mask.storage_offset() - offset.storage_offset():] if aliased else torch.zeros_like(mask)
         dx32 = HF.deform_col2im(dcols, x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, doff, dmask, off_ld, mask_ld, mask_is_logit)
         dx = HF.f32_to_bf16(dx32) if ctx.needs_input_grad[0] else None
         gmask = None
-        if mask is not None and ctx.needs_input_grad[2]:
+        if mask is not None and ctx.needs_input_grad[2] and not aliased:
             gmask = dmask if dmask.shape == mask.shape else None
+        # (a mask that is a VIEW into the offset tensor's rows - DFConv2d, DeformBottleneckBlock - got its gradient written into ``doff``'s
+        # mask columns above; returning it a second time through the view would make autograd add those columns - and, the view being
+        # one-dimensional, everything behind them - to the offset tensor's gradient twice)
         return dx, doff, gmask, None, None, None, None, None
 
 
@@ -96,11 +100,13 @@ class DeformConv(nn.Module):
     modulated = False
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, bias=False,
-                 relu=False):
+                 relu=False, frozen_bn=False):
         super().__init__()
         self.relu = relu
         if groups != 1:
-            raise NotImplementedError("grouped deformable convolution is not built")
+            # detectron2's ``groups`` splits the GEMM into independent channel groups (ResNeXt + DCN); no config of the reference sets it
+            # (DeformBottleneckBlock passes RESNETS.NUM_GROUPS, 1 in every DCN YAML): refused loudly rather than computed wrongly
+            raise NotImplementedError(f"deformable convolution with groups={groups} is not built (deformable_groups is)")
         if bias and not self.modulated:
             raise AssertionError("DeformConv has no bias (detectron2)")
         if isinstance(kernel_size, (tuple, list)):
@@ -111,40 +117,71 @@ class DeformConv(nn.Module):
         self.weight = nn.Parameter(torch.empty(out_channels, kernel_size, kernel_size, in_channels))   # KRSC
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         nn.init.kaiming_uniform_(self.weight.permute(0, 3, 1, 2), nonlinearity="relu")
+        # detectron2 wraps a norm around the op inside DeformBottleneckBlock (conv2 = DeformConv(..., norm=FrozenBN)): the frozen affine
+        # is folded into the compute copy of the weights (scale) and the epilogue bias (shift), as HipConv2d does
+        self.frozen_bn = frozen_bn
+        if frozen_bn:
+            self.register_buffer("bn_weight", torch.ones(out_channels))
+            self.register_buffer("bn_bias", torch.zeros(out_channels))
+            self.register_buffer("bn_running_mean", torch.zeros(out_channels))
+            self.register_buffer("bn_running_var", torch.ones(out_channels) - 1e-5)
         self._prep_key = None
-        self.w_bf16 = self.wt_bf16 = self.bias_eff = None
+        self.w_bf16 = self.wt_bf16 = self.bias_eff = self.bn_scale = None
 
     # batched weight preparation (layers/arena.py): the GEMM view is (K, 1, 1, k*k*C)
-    frozen_bn = False
-
     def batched_prep_shape(self):
         return self.out_channels, 1, self.kernel_size * self.kernel_size * self.in_channels
 
     def frozen_bn_scale(self):
-        return False
+        return self.frozen_bn
 
     def bind_batched_prep(self, krsc, crsk, scale_view):
         K, n = self.out_channels, self.kernel_size * self.kernel_size * self.in_channels
-        self._b_krsc, self._b_crsk = krsc.view(K, 1, 1, n), crsk.view(n, 1, 1, K)
+        self._b_krsc, self._b_crsk, self._b_scale = krsc.view(K, 1, 1, n), crsk.view(n, 1, 1, K), scale_view
         self._prep_ver = None
+        if self.frozen_bn:
+            self._fold_bn(self._b_scale)
+
+    def _bn_state(self):
+        return (self.bn_weight._version, self.bn_bias._version, self.bn_running_mean._version, self.bn_running_var._version,
+                self.bn_weight.data_ptr(), self.bias._version if self.bias is not None else 0)
+
+    @torch.no_grad()
+    def _fold_bn(self, scale_out=None):
+        scale = self.bn_weight * torch.rsqrt(self.bn_running_var + 1e-5)
+        shift = self.bn_bias - self.bn_running_mean * scale
+        if scale_out is not None:
+            scale_out.copy_(scale)
+            scale = scale_out
+        self.bn_scale = scale.contiguous()
+        self.bias_eff = (shift + (self.bias.detach() * scale if self.bias is not None else 0)).contiguous()
+        self._bn_key = self._bn_state()
 
     def prepare(self):
         arena = _arena_of(self)
-        key = (self.weight._version, arena.generation if (arena is not None and self.weight.requires_grad) else -1, self.weight.data_ptr())
+        key = (self.weight._version, arena.generation if (arena is not None and self.weight.requires_grad) else -1, self.weight.data_ptr(),
+               self._bn_state() if self.frozen_bn else None)
         if key == self._prep_key:
             return
-        if arena is not None and getattr(self, "_b_krsc", None) is not None and self.weight.requires_grad:
+        batched = arena is not None and getattr(self, "_b_krsc", None) is not None and self.weight.requires_grad
+        if self.frozen_bn:
+            if self._bn_state() != getattr(self, "_bn_key", None):      # buffers changed (checkpoint load): re-fold, re-prepare
+                self._fold_bn(self._b_scale if batched else None)
+                if batched:
+                    arena._prep_gen = -1
+        else:
+            self.bn_scale = None
+            self.bias_eff = self.bias.detach() if self.bias is not None else None
+        if batched:
             ver = (self.weight._version, self.weight.data_ptr())
             if arena._prep_gen != arena.generation or ver != self._prep_ver:
                 arena.prep_all()
             self.w_bf16, self.wt_bf16 = self._b_krsc, self._b_crsk
-            self.bias_eff = self.bias.detach() if self.bias is not None else None
             self._prep_ver, self._prep_key = ver, key
             return
         K, k, C = self.out_channels, self.kernel_size, self.in_channels
         # the GEMM sees a 1x1 convolution over k*k*C "channels" (tap-major, the layout deform_im2col writes)
-        self.w_bf16, self.wt_bf16 = HF.weight_prep(self.weight.detach().contiguous().view(K, 1, 1, k * k * C))
-        self.bias_eff = self.bias.detach() if self.bias is not None else None
+        self.w_bf16, self.wt_bf16 = HF.weight_prep(self.weight.detach().contiguous().view(K, 1, 1, k * k * C), self.bn_scale)
         self._prep_key = key
 
     def forward(self, x, offset, mask=None, off_ld=0, mask_ld=0, mask_is_logit=False):

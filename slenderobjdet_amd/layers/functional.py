@@ -13,6 +13,44 @@ from .._C import call, ptr, stream_ptr
 
 IOU_TYPES = {"iou": 0, "linear_iou": 1, "giou": 2}
 
+# ---- storage precision of activations / compute weights / gradients.  "bf16" is the product (what bench.py times); "fp32" is the
+# validation mode (layers/functional_f32.py, csrc/f32_path.hip): the same layer code with fp32 tensors and untuned fp32 kernels, in which
+# tests/test_gpu_parity100.py asserts north_star's 100-iteration loss bound.  SOD_PRECISION=fp32 or set_precision("fp32").
+PRECISION = "bf16"
+ACT_DTYPE = torch.bfloat16
+
+
+def set_precision(p):
+    """-> the previous precision.  Switch BEFORE building a model: the compute copies of the weights follow the mode they were
+    prepared in (HipConv2d.prepare re-derives them when the mode changes)."""
+    global PRECISION, ACT_DTYPE
+    if p not in ("bf16", "fp32"):
+        raise ValueError(f"precision must be 'bf16' or 'fp32', got {p!r}")
+    prev, PRECISION = PRECISION, p
+    ACT_DTYPE = torch.float32 if p == "fp32" else torch.bfloat16
+    return prev
+
+
+def is_f32():
+    return PRECISION == "fp32"
+
+
+def _precision_dispatch(fn):
+    """In the fp32 validation mode, route ``fn`` to its namesake in functional_f32 (same signature)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        if PRECISION == "fp32":
+            from . import functional_f32 as F32
+
+            impl = getattr(F32, fn.__name__, None)
+            if impl is None:
+                raise _C.SlenderHipError(f"{fn.__name__} has no fp32 validation variant")
+            return impl(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return wrapper
+
 # Optional per-launch timing of the convolution kernels (bench.py roofline): a list that receives
 # (kind, algorithmic_flops, start_event, end_event); events are recorded on the stream the kernel is launched on.
 PROFILE = None
@@ -742,7 +780,8 @@ def fcos_regctr_loss_bwd(box_raw, ld_box, ctr_logit, ld_ctr, labels, reg_t, ctr_
                          dscales):
     dev = labels.device
     nl = len(lvl_hw)
-    call("sod_fcos_regctr_loss_bwd", ptr(box_raw), ld_box, ptr(ctr_logit), ld_ctr, ptr(labels), ptr(reg_t), ptr(ctr_t), ptr(scales), N, nl,
+    # gradient rows in the storage precision: bf16 for the MFMA kernels, fp32 in the validation mode
+    call("sod_fcos_regctr_loss_bwd_f32" if is_f32() else "sod_fcos_regctr_loss_bwd", ptr(box_raw), ld_box, ptr(ctr_logit), ld_ctr, ptr(labels), ptr(reg_t), ptr(ctr_t), ptr(scales), N, nl,
          ctypes.cast(_int_arr([h for h, _ in lvl_hw]), ctypes.c_void_p), ctypes.cast(_int_arr([w for _, w in lvl_hw]), ctypes.c_void_p),
          ctypes.cast(_int_arr(strides), ctypes.c_void_p), num_classes, IOU_TYPES[loss_type], 1 if norm_reg else 0,
          ptr(grad_reg), ptr(grad_ctr), ptr(stats), float(inv_world), ptr(dbox), ld_out, ctr_col, ptr(dctr), ld_dctr, dctr_col,
@@ -971,7 +1010,7 @@ def deform_conv_fwd_f32(x, offset, mask, w, bias, ksize, stride, pad, dil, dg=1,
     return y
 
 
-def deform_conv_wgrad_fused(dy, x, offset, mask, dw, ksize, stride, pad, dil, dg=1, off_ld=0, mask_ld=0, mask_is_logit=False):
+def deform_conv_wgrad_fused(dy, x, offset, mask, dw, ksize, stride, pad, dil, dg=1, off_ld=0, mask_ld=0, mask_is_logit=False, qscale=None):
     """Accumulates the DeformConv weight gradient into dw (K, KH*KW*C elements, fp32) without a column buffer."""
     _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(dw, torch.float32, "dw")
     N, H, W, C = x.shape
@@ -981,7 +1020,8 @@ def deform_conv_wgrad_fused(dy, x, offset, mask, dw, ksize, stride, pad, dil, dg
         raise _C.SlenderHipError("deform_conv_wgrad_fused: dw does not hold K x KH*KW*C elements")
     side = _wgrad_stream(dw.device, (dy, x, offset, mask), dw.data_ptr())
     ws = wgrad_workspace(dw.device, side)
-    call("sod_deform_conv_wgrad_fused", ptr(dy), ptr(x), ptr(offset), ptr(mask), ptr(dw), N, H, W, C, K, KH, KW, stride, pad, dil, dg, off_ld, mask_ld,
+    _chk(qscale, torch.float32, "qscale")
+    call("sod_deform_conv_wgrad_fused", ptr(dy), ptr(x), ptr(offset), ptr(mask), ptr(dw), ptr(qscale), N, H, W, C, K, KH, KW, stride, pad, dil, dg, off_ld, mask_ld,
          1 if mask_is_logit else 0, ptr(ws), ws.numel(), stream_ptr(side))
     return dw
 
@@ -1249,3 +1289,16 @@ def retina_giou_loss_bwd(pred, pitch, gt_labels, anchors, matched_boxes, N, R, A
     w = _float_arr(weights)
     call("sod_retina_giou_loss_bwd", ptr(pred), pitch, ptr(gt_labels), ptr(anchors), ptr(matched_boxes), N, R, A, num_classes,
          ctypes.cast(w, ctypes.c_void_p), float(scale_clamp), ptr(grad_num), ptr(grad_den), ptr(dpred), stream_ptr())
+
+
+# ---- fp32 validation mode: the wrappers of the training step dispatch to functional_f32 when it is on; everything that only the bf16
+# product path offers (fused stem / bottleneck, 1-bit masks, statistics epilogues, DeformConv, ...) is switched off by its callers or refuses
+for _name in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "conv2d_fwd_ml", "conv2d_dgrad_ml", "conv2d_wgrad_ml", "weight_prep",
+              "groupnorm_fwd", "groupnorm_bwd", "groupnorm_fwd_ml", "groupnorm_bwd_ml", "relu_fwd", "relu_bwd", "add_bf16", "f32_to_bf16",
+              "add_up2", "upsample2x_bwd", "maxpool3x3s2", "bias_grad", "bias_grad_ml", "preprocess_image", "preprocess_batch"):
+    globals()[_name] = _precision_dispatch(globals()[_name])
+for _name in ("conv_gn_fwd_ml", "conv2d_dgrad_ml_gnbwd", "groupnorm_bwd_apply_ml", "stem_fused", "bottleneck_frozen_fwd", "deform_im2col"):
+    if _name in globals():
+        globals()[_name] = _precision_dispatch(globals()[_name])     # no fp32 variant: raises instead of mixing precisions
+if os.environ.get("SOD_PRECISION", "bf16") != "bf16":
+    set_precision(os.environ["SOD_PRECISION"])

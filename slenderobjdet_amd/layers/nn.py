@@ -165,15 +165,16 @@ class HipConv2d(nn.Module):
         """(Re)build the bf16 compute copies when the master weights changed."""
         arena = _arena_of(self)
         key = (self.weight._version, self.bias._version if self.bias is not None else 0,
-               arena.generation if (arena is not None and self.weight.requires_grad) else -1, self.weight.data_ptr())
+               arena.generation if (arena is not None and self.weight.requires_grad) else -1, self.weight.data_ptr(), HF.PRECISION)
         if not force and key == self._prep_key:
             return
-        if arena is not None and getattr(self, "_b_krsc", None) is not None and self.weight.requires_grad:
+        # (the batched preparation writes the bf16 arenas; the fp32 validation mode derives its copies per convolution)
+        if arena is not None and getattr(self, "_b_krsc", None) is not None and self.weight.requires_grad and not HF.is_f32():
             return self._prepare_batched(arena, key)
         w = self.weight.detach()
         if self.frozen_bn:
             bn_key = (self.bn_weight._version, self.bn_bias._version, self.bn_running_mean._version, self.bn_running_var._version,
-                      self.bn_weight.data_ptr(), self.bias._version if self.bias is not None else 0)
+                      self.bn_weight.data_ptr(), self.bias._version if self.bias is not None else 0, "own")
             if bn_key != getattr(self, "_bn_key", None):   # the folded affine is constant: recompute only when buffers change
                 scale = self.bn_weight * torch.rsqrt(self.bn_running_var + 1e-5)
                 shift = self.bn_bias - self.bn_running_mean * scale
@@ -286,7 +287,7 @@ class ConvGnRelu(nn.Module):
             xs = [xs]
         self.conv.prepare()
         prev = None
-        if GN_BWD_FUSED and chained is not None and chained._last_slot is not None and chained._last_slot.matches(xs):
+        if GN_BWD_FUSED and not HF.is_f32() and chained is not None and chained._last_slot is not None and chained._last_slot.matches(xs):
             prev = chained._last_slot
         out = _ConvGnReluFn.apply(self.conv.weight, self, prev, *xs)
         return out[0] if single else list(out)
@@ -297,7 +298,7 @@ class _ConvGnReluFn(torch.autograd.Function):
     def forward(ctx, weight, unit, prev_slot, *xs):
         conv, gn = unit.conv, unit.gn
         gw, gb = gn.weight.detach(), gn.bias.detach()
-        if (GN_EPILOGUE_STATS and not HF.DETERMINISTIC and conv.out_channels == 8 * gn.num_groups and conv.bias_eff is not None
+        if (GN_EPILOGUE_STATS and not HF.DETERMINISTIC and not HF.is_f32() and conv.out_channels == 8 * gn.num_groups and conv.bias_eff is not None
                 and conv.kernel_size == 3 and conv.stride == 1 and conv.padding == 1 and conv.dilation == 1):
             # the norm's statistics are gathered in the conv epilogue (float atomics: not for the deterministic mode)
             y1s, y2s, stats = HF.conv_gn_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, gw, gb, gn.num_groups, gn.eps, relu=True)

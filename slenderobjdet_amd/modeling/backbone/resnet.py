@@ -39,7 +39,7 @@ class BasicStem(nn.Module):
         if isinstance(x, HF.RawImageBatch):
             # frozen stem on raw uint8 pixels: normalise + conv + FrozenBN + ReLU + max-pool in one kernel (csrc/stem_fused.hip)
             c = self.conv1
-            if STEM_FUSED and not c.weight.requires_grad and c.in_channels == 3 and c.out_channels == 64:
+            if STEM_FUSED and not HF.is_f32() and not c.weight.requires_grad and c.in_channels == 3 and c.out_channels == 64:
                 c.prepare()
                 key = (c._prep_key, c.w_bf16.data_ptr())
                 if getattr(self, "_packed_key", None) != key:
@@ -72,6 +72,54 @@ class BottleneckBlock(nn.Module):
         return self.conv3(out, res=sc)     # relu(conv3 + shortcut) fused in the conv epilogue
 
 
+class DeformBottleneckBlock(nn.Module):
+    """detectron2's DeformBottleneckBlock (MODEL.RESNETS.DEFORM_ON_PER_STAGE; source absent): the bottleneck with its 3x3
+    replaced by ``conv2_offset`` (a plain 3x3 conv with bias, zero-initialised, 18 * G offsets - or 27 * G with DEFORM_MODULATED: the
+    first 18 * G channels are the offsets, the last 9 * G the mask logits) followed by DeformConv / ModulatedDeformConv with FrozenBN +
+    ReLU.  The reference reaches it through configs/fcos/fcos_R_50_FPN_2x_dcnv2.yaml:6-7.  conv1's ReLU output has two consumers here
+    (the offset conv and the sampled conv), so it masks its own gradient and autograd sums the two input gradients."""
+
+    def __init__(self, in_channels, out_channels, bottleneck_channels, stride=1, stride_in_1x1=True, dilation=1, deform_modulated=False,
+                 deform_num_groups=1, num_groups=1):
+        super().__init__()
+        from ...layers.deform_conv import DeformConv, ModulatedDeformConv, _ceil8
+
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        self.deform_modulated, self.deform_num_groups = deform_modulated, deform_num_groups
+        s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        self.shortcut = None
+        if in_channels != out_channels:
+            self.shortcut = HipConv2d(in_channels, out_channels, 1, stride, 0, bias=False, frozen_bn=True)
+        self.conv1 = HipConv2d(in_channels, bottleneck_channels, 1, s1, 0, bias=False, frozen_bn=True, relu=True)
+        self.n_off = (27 if deform_modulated else 18) * deform_num_groups
+        self.n_off_pad = _ceil8(self.n_off)        # padded so that the offset gradient can feed the MFMA kernels; pad rows stay zero
+        self.conv2_offset = HipConv2d(bottleneck_channels, self.n_off_pad, 3, s3, dilation, dilation, bias=True, out_f32=True)
+        op = ModulatedDeformConv if deform_modulated else DeformConv
+        self.conv2 = op(bottleneck_channels, bottleneck_channels, 3, s3, dilation, dilation, groups=num_groups, deformable_groups=deform_num_groups,
+                        bias=False, relu=True, frozen_bn=True)
+        self.conv3 = HipConv2d(bottleneck_channels, out_channels, 1, 1, 0, bias=False, frozen_bn=True, relu=True)
+        for m in (self.conv1, self.conv3, self.shortcut):
+            if m is not None:
+                m.init_msra()
+        with torch.no_grad():
+            fan_out = bottleneck_channels * 9
+            self.conv2.weight.normal_(0.0, (2.0 / fan_out) ** 0.5)       # c2_msra_fill
+            self.conv2_offset.weight.zero_()
+            self.conv2_offset.bias.zero_()
+        self.conv2_offset.ckpt_rows = self.n_off
+
+    def forward(self, x):
+        sc = self.shortcut(x) if self.shortcut is not None else x
+        out = self.conv1(x)
+        om = self.conv2_offset(out)                       # (N, Ho, Wo, n_off_pad) fp32 rows: offsets, then mask logits
+        if self.deform_modulated:
+            mask = om.view(-1)[18 * self.deform_num_groups:]
+            out = self.conv2(out, om, mask, off_ld=self.n_off_pad, mask_ld=self.n_off_pad, mask_is_logit=True)
+        else:
+            out = self.conv2(out, om, None, off_ld=self.n_off_pad)
+        return self.conv3(out, res=sc)
+
+
 class _BottleneckStageFn(torch.autograd.Function):
     """A whole stage of bottleneck blocks as ONE autograd node.  Forward is the plain sequence of fused conv launches; the
     hand-written backward chains the blocks so that the ReLU mask of a block output and the residual-gradient sum are applied
@@ -93,7 +141,7 @@ class _BottleneckStageFn(torch.autograd.Function):
             a = _conv(blk.conv1, xin)
             b = _conv(blk.conv2, a)
             c3 = blk.conv3
-            if need_bwd and RELU_BITS and c3.relu and c3.out_channels % 8 == 0:
+            if need_bwd and RELU_BITS and not HF.is_f32() and c3.relu and c3.out_channels % 8 == 0:
                 N, Hb, Wb, _ = b.shape
                 Ho, Wo = HF.conv_out_size(Hb, Wb, c3.kernel_size, c3.kernel_size, c3.stride, c3.padding, c3.dilation)
                 bt = torch.empty(N * Ho * Wo * c3.out_channels // 8, dtype=torch.uint8, device=b.device)
@@ -107,7 +155,7 @@ class _BottleneckStageFn(torch.autograd.Function):
         # the producer of x may take this stage's input gradient in compact form (DeferSlot.comp): first block = stride-2 1x1 convs
         b0 = blocks[0]
         ctx.in_slot = None
-        if (x.requires_grad and COMPACT_S2_GRAD and b0.shortcut is not None and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+        if (x.requires_grad and COMPACT_S2_GRAD and not HF.is_f32() and b0.shortcut is not None and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
                 and all(m.kernel_size == 1 and m.stride == 2 and m.padding == 0 for m in (b0.shortcut, b0.conv1))):
             ctx.in_slot = DeferSlot.take(x)
         ctx.nbits = len(bits) if len(bits) == len(blocks) else 0
@@ -406,8 +454,9 @@ def build_resnet_backbone(cfg, input_shape):
         raise NotImplementedError(f"MODEL.RESNETS.NORM={norm}: only FrozenBN (the default the FCOS/RetinaNet configs use) is built")
     if cfg.MODEL.RESNETS.NUM_GROUPS != 1:
         raise NotImplementedError("grouped (ResNeXt) convolutions are not built")
-    if any(cfg.MODEL.RESNETS.DEFORM_ON_PER_STAGE):
-        raise NotImplementedError("DEFORM_ON_PER_STAGE backbones are not wired yet")
+    deform_on = list(cfg.MODEL.RESNETS.DEFORM_ON_PER_STAGE)
+    if any(deform_on) and depth in (18, 34):
+        raise NotImplementedError("DEFORM_ON_PER_STAGE needs bottleneck blocks (detectron2 asserts the same for R18 / R34)")
     stem = BasicStem(input_shape.channels, cfg.MODEL.RESNETS.STEM_OUT_CHANNELS)
     blocks_per_stage = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}[depth]
     in_ch = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
@@ -426,6 +475,10 @@ def build_resnet_backbone(cfg, input_shape):
             stride = first_stride if b == 0 else 1
             if depth in (18, 34):
                 blocks.append(BasicBlock(in_ch, out_ch, stride))
+            elif idx < len(deform_on) and deform_on[idx]:
+                blocks.append(DeformBottleneckBlock(in_ch, out_ch, bott, stride, cfg.MODEL.RESNETS.STRIDE_IN_1X1, dilation,
+                                                    deform_modulated=cfg.MODEL.RESNETS.DEFORM_MODULATED,
+                                                    deform_num_groups=cfg.MODEL.RESNETS.DEFORM_NUM_GROUPS, num_groups=cfg.MODEL.RESNETS.NUM_GROUPS))
             else:
                 blocks.append(BottleneckBlock(in_ch, out_ch, bott, stride, cfg.MODEL.RESNETS.STRIDE_IN_1X1, dilation))
             in_ch = out_ch

@@ -206,10 +206,10 @@ class _FcosHeadLossFn(torch.autograd.Function):
         arena = _arena_of(head)
         dev = cls_buf.device
         # d(cls logits): focal gradient * g[0] / max(num_pos/world, 1), bf16 rows padded to kc_pad
-        dcls = torch.empty((N, L, kcp), dtype=torch.bfloat16, device=dev)
+        dcls = torch.empty((N, L, kcp), dtype=HF.ACT_DTYPE, device=dev)
         HF.focal_loss_bwd(cls_buf, labels, None, model.focal_loss_alpha, model.focal_loss_gamma, K=K, scale_num=g3[0:1],
-                          scale_den=stats[0:1], den_mul=inv_world, den_min=1.0, ld_out=kcp, out_bf16=True, out=dcls)
-        dbox = torch.empty((N, L, 8), dtype=torch.bfloat16, device=dev)
+                          scale_den=stats[0:1], den_mul=inv_world, den_min=1.0, ld_out=kcp, out_bf16=not HF.is_f32(), out=dcls)
+        dbox = torch.empty((N, L, 8), dtype=HF.ACT_DTYPE, device=dev)
         if head.centerness_on_reg:
             ctr_ptr, ld_ctr = box_buf.view(-1)[4:], 8
             dctr, ld_dctr, dctr_col, ctr_col = dbox, 8, 4, 4
@@ -441,11 +441,12 @@ class FCOSV2(nn.Module):
         imgs = [x["image"].to(self.device, non_blocking=True) for x in batched_inputs]
         sizes = [(int(i.shape[-2]), int(i.shape[-1])) for i in imgs]
         Hp, Wp = ImageList.padded_size(sizes, self.backbone.size_divisibility)
-        if all(im.dtype == torch.uint8 and im.dim() == 3 and im.shape[0] == 3 for im in imgs) and len(imgs) <= 64 and Hp % 4 == 0 and Wp % 4 == 0:
+        if (not HF.is_f32() and all(im.dtype == torch.uint8 and im.dim() == 3 and im.shape[0] == 3 for im in imgs) and len(imgs) <= 64
+                and Hp % 4 == 0 and Wp % 4 == 0):
             # decoded uint8 images: hand the raw pixels to the backbone - a frozen stem normalises, convolves and pools them in one
             # kernel (csrc/stem_fused.hip); any other consumer materialises the NHWC(8) tensor below on demand
             return ImageList(HF.RawImageBatch([im.contiguous() for im in imgs], sizes, (Hp, Wp), self._mean, self._std), sizes)
-        batch = torch.empty((len(imgs), Hp, Wp, 8), dtype=torch.bfloat16, device=self.device)
+        batch = torch.empty((len(imgs), Hp, Wp, 8), dtype=HF.ACT_DTYPE, device=self.device)
         imgs = [im if im.dtype == torch.uint8 else im.float() for im in imgs]
         HF.preprocess_batch(imgs, batch, self._mean, self._std)       # one launch for the batch
         return ImageList(batch, sizes)

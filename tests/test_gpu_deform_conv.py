@@ -105,6 +105,53 @@ def test_dfconv2d_module_trains(cuda, v2):
     assert (m.offset.weight.grad[m.n_off:] == 0).all()     # padding rows stay inert
 
 
+@pytest.mark.parametrize("v2", [False, True])
+def test_dfconv2d_gradients_vs_oracle(cuda, v2):
+    """DFConv2d (slender_det/layers/df_conv.py:67-78) end to end as an autograd module against the CPU oracle: the gradient that reaches
+    the offset conv (weights and bias) and x.  With DCNv2 the mask is a VIEW into the offset conv's output rows: its gradient must be
+    counted once (it used to flow back both through the offset tensor's own gradient and through the view - a factor of two on
+    everything behind the first row's offsets)."""
+    import torch.nn.functional as F
+
+    from slenderobjdet_amd.layers.arena import ParamArena
+    from slenderobjdet_amd.layers.deform_conv import DFConv2d
+    from slenderobjdet_amd.layers.nn import attach_arena
+
+    torch.manual_seed(1)
+    C = 64
+    m = DFConv2d(C, C, with_modulated_dcn=v2).to(cuda)
+    with torch.no_grad():
+        m.offset.weight.mul_(0.05)       # offsets of a fraction of a pixel
+        m.offset.weight.copy_(onn.rb(m.offset.weight))
+        m.conv.weight.copy_(onn.rb(m.conv.weight))
+    arena = ParamArena(m)
+    attach_arena(m, arena)
+    x = onn.rb(torch.randn(2, 9, 11, C, generator=_g(7)) * 0.5)
+    xd = x.to(cuda).bfloat16().requires_grad_(True)
+    dy = onn.rb(torch.randn(2, 9, 11, C, generator=_g(8)))
+    arena.zero_grad()
+    y = m(xd)
+    y.backward(dy.to(cuda).bfloat16())
+    torch.cuda.synchronize()
+    # oracle: the same module in fp32 NCHW
+    n = m.n_off
+    w_off = m.offset.weight.detach().cpu()[:n].permute(0, 3, 1, 2).clone().requires_grad_(True)
+    b_off = m.offset.bias.detach().cpu()[:n].clone().requires_grad_(True)
+    w = m.conv.weight.detach().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    om = F.conv2d(xr, w_off, b_off, padding=1)
+    if v2:
+        ref = odc.deform_conv2d(xr, om[:, :18], w, None, 1, 1, 1, om[:, 18:27].sigmoid(), 1)
+    else:
+        ref = odc.deform_conv2d(xr, om, w, None, 1, 1, 1, None, 1)
+    gx, gwo, gbo, gw = torch.autograd.grad(ref, (xr, w_off, b_off, w), dy.permute(0, 3, 1, 2))
+    assert (y.detach().float().cpu() - ref.detach().permute(0, 2, 3, 1)).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
+    for got, want, name in ((m.offset.weight.grad.cpu()[:n].permute(0, 3, 1, 2), gwo, "d offset.weight"), (m.offset.bias.grad.cpu()[:n], gbo, "d offset.bias"),
+                            (m.conv.weight.grad.cpu().permute(0, 3, 1, 2), gw, "d conv.weight"), (xd.grad.float().cpu().permute(0, 3, 1, 2), gx, "dx")):
+        err = (got - want).norm().item() / max(want.norm().item(), 1e-12)
+        assert err <= 3e-2, (name, err)
+
+
 @pytest.mark.parametrize("modulated,dg,stride,C,K,relu", [(False, 1, 1, 64, 32, False), (True, 1, 1, 128, 256, True), (True, 2, 2, 128, 72, False),
                                                         (False, 1, 1, 256, 256, False)])
 def test_deform_conv_fused_forward(cuda, modulated, dg, stride, C, K, relu):

@@ -1,0 +1,239 @@
+"""The fp32-STORAGE validation mode (SOD_PRECISION=fp32; csrc/f32_path.hip, layers/functional_f32.py): op-level parity of every
+``sod_*_f32`` kernel with the CPU oracle (oracle/nn.py = F.conv2d / F.group_norm in fp32) at 1e-5, and the whole FCOS training step -
+losses AND every parameter gradient - against the plain fp32 oracle (= the reference's CPU path restated,
+slender_det/modeling/meta_arch/fcos/fcosv2.py:63-148) far inside north_star's 1e-3: with storage rounding out of the picture the layer
+code, the fused epilogue semantics (residual, up-sampled residual, accumulate, masks), the target assignment, the loss kernels and the
+optimizer are what is left to compare.  The 100-iteration statement lives in tests/test_gpu_parity100.py."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def f32mode():
+    from slenderobjdet_amd.layers import functional as HF
+
+    prev = HF.set_precision("fp32")
+    yield HF
+    HF.set_precision(prev)
+
+
+def _close(a, b, tol=1e-5):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    scale = max(float(b.abs().max()), 1e-6)
+    err = float((a - b).abs().max()) / scale
+    assert err <= tol, (err, tuple(a.shape))
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad,dil", [
+    (2, 13, 17, 8, 24, 3, 1, 1, 1),       # ragged tile edges in every dimension
+    (2, 14, 18, 16, 8, 1, 1, 0, 1),
+    (1, 16, 20, 8, 72, 7, 2, 3, 1),       # the stem shape family (input channels padded to 8)
+    (2, 12, 16, 40, 32, 3, 2, 1, 1),
+    (2, 12, 16, 24, 24, 1, 2, 0, 1),      # stride-2 1x1 (STRIDE_IN_1X1 shortcuts)
+    (1, 11, 13, 8, 16, 3, 1, 2, 2),       # dilation 2
+])
+def test_conv_f32_fwd_dgrad_wgrad_vs_oracle(cuda, f32mode, N, H, W, C, K, R, stride, pad, dil):
+    from oracle import nn as onn
+
+    HF = f32mode
+    g = torch.Generator().manual_seed(H * 100 + K)
+    x = torch.randn(N, H, W, C, generator=g)
+    w = torch.randn(K, R, R, C, generator=g) * 0.2
+    bias = torch.randn(K, generator=g)
+    ref = onn.conv2d(x, w, bias, stride, pad, dil)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    res = torch.randn(N, Ho, Wo, K, generator=g)
+    xd, wd, bd = x.to(cuda), w.to(cuda), bias.to(cuda)
+    wk, wt = HF.weight_prep(wd)
+    assert wk.dtype == torch.float32 and wt is wk
+    _close(HF.conv2d_fwd(xd, wk, bd, None, stride, pad, dil), ref)
+    _close(HF.conv2d_fwd(xd, wk, bd, res.to(cuda), stride, pad, dil, relu=True), onn.conv2d(x, w, bias, stride, pad, dil, res=res, relu=True))
+    if Ho % 2 == 0 and Wo % 2 == 0:
+        small = torch.randn(N, Ho // 2, Wo // 2, K, generator=g)
+        _close(HF.conv2d_fwd(xd, wk, bd, small.to(cuda), stride, pad, dil, res_up2=True), onn.conv2d(x, w, bias, stride, pad, dil, res=small, res_up2=True))
+    # FrozenBN scale folded into the compute copy
+    sc = torch.rand(K, generator=g) + 0.5
+    wks, _ = HF.weight_prep(wd, sc.to(cuda))
+    _close(HF.conv2d_fwd(xd, wks, None, None, stride, pad, dil), onn.conv2d(x, w * sc.view(-1, 1, 1, 1), None, stride, pad, dil))
+    # backward
+    dy = torch.randn(N, Ho, Wo, K, generator=g)
+    dx_ref, dw_ref = onn.conv2d_backward(x, w, dy, stride, pad, dil)
+    dyd = dy.to(cuda)
+    _close(HF.conv2d_dgrad(dyd, wt, (H, W), stride, pad, dil), dx_ref)
+    acc = torch.randn(N, H, W, C, generator=g)
+    mask = torch.randn(N, H, W, C, generator=g)
+    _close(HF.conv2d_dgrad(dyd, wt, (H, W), stride, pad, dil, accum=acc.to(cuda), relu_mask=mask.to(cuda)), (dx_ref + acc) * (mask > 0))
+    if H % 2 == 0 and W % 2 == 0:
+        comp = torch.randn(N, H // 2, W // 2, C, generator=g)
+        dense = torch.zeros(N, H, W, C)
+        dense[:, ::2, ::2] = comp
+        _close(HF.conv2d_dgrad(dyd, wt, (H, W), stride, pad, dil, accum=comp.to(cuda), accum_even=True), dx_ref + dense)
+    dw = torch.full((K, R, R, C), 0.25, device=cuda)      # the kernel ACCUMULATES into the gradient arena
+    HF.conv2d_wgrad(dyd, xd, dw, R, R, stride, pad, dil)
+    _close(dw - 0.25, dw_ref, 2e-5)
+    dw2 = torch.zeros((K, R, R, C), device=cuda)
+    HF.conv2d_wgrad(dyd, xd, dw2, R, R, stride, pad, dil, qscale=sc.to(cuda))
+    _close(dw2, dw_ref * sc.view(-1, 1, 1, 1), 2e-5)
+
+
+def test_conv_f32_image_strides_into_concatenated_buffers(cuda, f32mode):
+    """The prediction convs write all levels into one (N, L, K) buffer and read their gradients from one (fcos.py predict / loss)."""
+    from oracle import nn as onn
+
+    HF = f32mode
+    g = torch.Generator().manual_seed(3)
+    N, C, K = 2, 16, 8
+    hws = [(6, 8), (3, 4)]
+    L = sum(h * w for h, w in hws)
+    w = torch.randn(K, 3, 3, C, generator=g) * 0.2
+    xs = [torch.randn(N, h, wd, C, generator=g) for h, wd in hws]
+    buf = torch.zeros(N, L, K, device=cuda)
+    wk, wt = HF.weight_prep(w.to(cuda))
+    offs = [0, hws[0][0] * hws[0][1]]
+    HF.conv2d_fwd_ml([x.to(cuda) for x in xs], wk, None, 1, 1, 1, outs=[buf.view(-1)[o * K:] for o in offs], y_img_stride=L * K)
+    ref = torch.cat([onn.conv2d(x, w, None, 1, 1, 1).reshape(N, -1, K) for x in xs], 1)
+    _close(buf, ref)
+    dbuf = torch.randn(N, L, K, generator=g)
+    dys = [dbuf.to(cuda).view(-1)[o * K:] for o in offs]
+    dxs = HF.conv2d_dgrad_ml(dys, wt, hws, 1, 1, 1, dy_img_stride=L * K, N=N)
+    dw = torch.zeros(K, 3, 3, C, device=cuda)
+    HF.conv2d_wgrad_ml(dys, [x.to(cuda) for x in xs], dw, 3, 3, 1, 1, 1, dy_img_stride=L * K, K=K)
+    dw_ref = torch.zeros(K, 3, 3, C)
+    for (h, wd), o, x, dx in zip(hws, offs, xs, dxs):
+        dy = dbuf[:, o:o + h * wd].reshape(N, h, wd, K)
+        dx_ref, dwl = onn.conv2d_backward(x, w, dy, 1, 1, 1)
+        _close(dx, dx_ref)
+        dw_ref += dwl
+    _close(dw, dw_ref, 2e-5)
+    db = torch.zeros(K, device=cuda)
+    HF.bias_grad(dbuf.to(cuda), db, N, L, K)
+    _close(db, dbuf.sum((0, 1)), 2e-5)
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_groupnorm_f32_vs_oracle(cuda, f32mode, relu):
+    from oracle import nn as onn
+
+    HF = f32mode
+    g = torch.Generator().manual_seed(5)
+    N, C, G = 2, 64, 8
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    xs = [torch.randn(N, h, w, C, generator=g) * 2 + 0.5 for h, w in ((9, 7), (4, 5))]
+    ys, stats = HF.groupnorm_fwd_ml([x.to(cuda) for x in xs], gamma.to(cuda), beta.to(cuda), G, 1e-5, relu=relu)
+    assert tuple(stats.shape) == (2, N, G, 2)
+    dys = [torch.randn(x.shape, generator=g) for x in xs]
+    dgam, dbet, dxs_sum = torch.zeros(C, device=cuda), torch.zeros(C, device=cuda), torch.zeros(C, device=cuda)
+    dxs = HF.groupnorm_bwd_ml([d.to(cuda) for d in dys], [x.to(cuda) for x in xs], gamma.to(cuda), beta.to(cuda), stats, G, dgam, dbet, relu=relu,
+                              dxsum=dxs_sum)
+    rg, rb_, rs = torch.zeros(C), torch.zeros(C), torch.zeros(C)
+    for x, y, dy, dx in zip(xs, ys, dys, dxs):
+        _close(y, onn.group_norm(x, gamma, beta, G, relu=relu))
+        xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        out = onn.group_norm(xr, gr, br, G, relu=relu)
+        a, b, c = torch.autograd.grad(out, (xr, gr, br), dy)
+        _close(dx, a, 2e-5)
+        rg += b; rb_ += c; rs += a.sum((0, 1, 2))
+    _close(dgam, rg, 2e-5)
+    _close(dbet, rb_, 2e-5)
+    assert float((dxs_sum.cpu() - rs).abs().max()) <= 2e-4        # sums of signed terms that nearly cancel: absolute bar
+
+
+def test_elementwise_f32_kernels(cuda, f32mode):
+    import torch.nn.functional as F
+
+    HF = f32mode
+    g = torch.Generator().manual_seed(9)
+    a, b = torch.randn(2, 6, 8, 16, generator=g), torch.randn(2, 6, 8, 16, generator=g)
+    ad, bd = a.to(cuda), b.to(cuda)
+    assert torch.equal(HF.relu_fwd(ad).cpu(), torch.relu(a))
+    assert torch.equal(HF.relu_bwd(ad, bd).cpu(), a * (b > 0))
+    assert torch.equal(HF.add_bf16(ad, bd).cpu(), a + b)
+    small = torch.randn(2, 3, 4, 16, generator=g)
+    up = F.interpolate(small.permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(HF.add_up2(ad, small.to(cuda)).cpu(), a + up)
+    _close(HF.upsample2x_bwd(ad), a.reshape(2, 3, 2, 4, 2, 16).sum((2, 4)), 1e-6)
+    x = torch.randn(2, 9, 11, 8, generator=g)
+    ref = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(HF.maxpool3x3s2(x.to(cuda)).cpu(), ref)
+    img = torch.randint(0, 256, (3, 10, 13), dtype=torch.uint8, generator=g)
+    out = torch.empty(12, 16, 8, device=cuda)
+    HF.preprocess_image(img.to(cuda), out, (103.53, 116.28, 123.675), (1.0, 2.0, 0.5))
+    want = torch.zeros(12, 16, 8)
+    want[:10, :13, :3] = ((img.float() - torch.tensor([103.53, 116.28, 123.675]).view(3, 1, 1)) / torch.tensor([1.0, 2.0, 0.5]).view(3, 1, 1)).permute(1, 2, 0)
+    _close(out, want, 1e-6)
+
+
+@pytest.mark.parametrize("depth", [18, 50])
+def test_fcos_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, depth):
+    """One FCOS training step (BASELINE configs[0] shape family) in the validation mode against the plain fp32 oracle (= the reference's
+    CPU path restated): the three losses to 2e-5 relative - 50x inside north_star's 1e-3 - and EVERY parameter gradient.  Two fp32
+    implementations differ by summation order only, which on a random-init ResNet (identity FrozenBN: activations grow 256x in std) is
+    NOT small for the deep weight gradients: the CPU fp32 oracle itself sits up to 1.1e-2 (R50) from the same model evaluated in float64.
+    The float64 oracle therefore arbitrates: the HIP gradient may be no further from it than 1.5x the CPU fp32 oracle is (+1e-4), and
+    for R18, where fp32 noise is small, it must also agree with the CPU fp32 oracle to 1e-3 of the gradient's norm outright (measured
+    9e-5).  R50 gets a floor of 5e-3 instead of 1e-4: there a second family of tensors (fpn_output4, res4.2 / res4.3, the biases behind
+    them) sits at 2-3e-3 from BOTH CPU oracles while the CPU fp32 / float64 pair agrees to 1e-4 on them, and the deep res3 / res4 weights
+    sit at 1e-2 from float64 in the HIP and the CPU fp32 run alike (tools/f32_grad_table.py): single ReLU decisions on pre-activations
+    that cancel to ~1e-7 of their terms fall differently under different summation orders - discrete events, not rounding growth."""
+    from bench import make_cfg
+    from oracle.model import OracleFCOS
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+
+    cfg = make_cfg(depth)
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    data = synthetic_batch(2, 256, 320, 3, device="cuda")
+    cpu = [{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data]
+    refs = {}
+    for tag in ("f32", "f64"):
+        oracle = OracleFCOS.from_hip_model(model, emulate_bf16=False)
+        if tag == "f64":
+            oracle.double()
+        losses = oracle.losses(cpu)
+        names = list(oracle.trainable().keys())
+        refs[tag] = ({k: float(v.detach()) for k, v in losses.items()},
+                     dict(zip(names, torch.autograd.grad(sum(losses.values()), list(oracle.trainable().values())))))
+    got = model(data)
+    total = sum(got.values())
+    opt.zero_grad()
+    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    for k, b in refs["f32"][0].items():
+        a = float(got[k].detach())
+        assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
+        assert abs(a - refs["f64"][0][k]) <= 2e-5 * max(abs(b), 1e-3), (k, a, refs["f64"][0][k])
+    worst = [0.0, 0.0, 0.0]
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        gq = p.grad.detach().double().cpu()
+        if gq.dim() == 4:
+            gq = gq.permute(0, 3, 1, 2)
+        r32, r64 = refs["f32"][1][name].double(), refs["f64"][1][name]
+        n = max(r64.norm().item(), 1e-30)
+        d_hip, d_cpu, d_pair = (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, (gq - r32).norm().item() / n
+        worst = [max(worst[0], d_hip), max(worst[1], d_cpu), max(worst[2], d_pair)]
+        assert d_hip <= 1.5 * d_cpu + (1e-4 if depth == 18 else 5e-3), (name, d_hip, d_cpu)
+        if depth == 18:
+            assert d_pair <= 1e-3, (name, d_pair)
+    print(f"\nf32 mode R{depth}: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
+
+
+def test_bf16_only_devices_refuse_in_f32_mode(cuda, f32mode):
+    """No silent precision mixing: what exists only on the bf16 product path raises in the validation mode."""
+    from slenderobjdet_amd._C import SlenderHipError
+
+    HF = f32mode
+    x = torch.zeros(1, 8, 8, 8, device=cuda)
+    w = torch.zeros(8, 1, 1, 8, device=cuda)
+    with pytest.raises(SlenderHipError):
+        HF.conv2d_fwd(x, w, relu_bits=torch.zeros(64, dtype=torch.uint8, device=cuda))
+    with pytest.raises(SlenderHipError):
+        HF.conv2d_fwd(x.bfloat16(), w)
+    with pytest.raises(SlenderHipError):
+        HF.conv_gn_fwd_ml([x], w, None, None, None, 1)

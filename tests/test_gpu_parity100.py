@@ -7,6 +7,11 @@ Three trajectories of the total loss (reference: slender_det/modeling/meta_arch/
   hip   the product (bf16 activations / weights, fp32 accumulation and master weights), deterministic reductions switched on
   emu   oracle/model.py with bf16 STORAGE emulation (the same arithmetic contract, CPU fp32 kernels)
   f32   oracle/model.py in plain fp32 (= the reference's CPU path restated)
+  hip32 the same product code in the fp32-STORAGE validation mode (SOD_PRECISION=fp32: csrc/f32_path.hip, layers/functional_f32.py)
+Asserted, north_star's bound itself: |hip32 - f32| < 1e-3 ABSOLUTE on the total loss at iteration 100 and at every one of the 100
+iterations, and hip32 is bit-identical across two runs - with storage rounding out of the picture the HIP layer code, target assignment,
+loss kernels and optimizer track the reference's CPU path through 100 SGD steps.  For the bf16 product the same bound is evaluated and
+reported but cannot be asserted (see below), so it is held to what bf16 storage itself allows:
 Asserted: hip is bit-identical across two runs; all three agree to 5e-4 relative over iterations 1-20; over all 100 iterations hip
 stays within the distance from f32 that bf16 storage itself causes (1.5 x the emu-vs-f32 distance + 2e-3 relative).  The measured
 curve is printed and written to gpurun_out/parity100.json.  north_star's "< 1e-3 total-loss delta after 100 iterations" is
@@ -97,6 +102,14 @@ def test_100_iteration_loss_parity(cuda):
         fast, _, _ = _hip_run(pool)
     finally:
         HF.DETERMINISTIC = prev
+    # the fp32-storage validation mode: same model code, fp32 tensors, sod_*_f32 kernels
+    prev_p = HF.set_precision("fp32")
+    try:
+        hip32, _, p32a = _hip_run(pool)
+        hip32b, _, p32b = _hip_run(pool)
+    finally:
+        HF.set_precision(prev_p)
+    assert hip32 == hip32b and torch.equal(p32a, p32b), "fp32 validation mode is not reproducible"
     assert all(l == l for l in fast), "NaN loss (default paths)"
     assert all(l == l for l in hip), "NaN loss"
     # deterministic reductions (fixed-order weight-gradient slabs, GroupNorm / bias-gradient partials): two runs are the same run
@@ -108,26 +121,34 @@ def test_100_iteration_loss_parity(cuda):
     f32 = _oracle_run(pool, lrs, False)
 
     rel = lambda a, b: abs(a - b) / max(abs(b), 1e-6)
-    rows = [{"iter": i + 1, "lr": lrs[i], "hip": hip[i], "hip_default_paths": fast[i], "emu": emu[i], "f32": f32[i]} for i in range(ITERS)]
+    rows = [{"iter": i + 1, "lr": lrs[i], "hip": hip[i], "hip_default_paths": fast[i], "hip_fp32_storage": hip32[i], "emu": emu[i], "f32": f32[i]}
+            for i in range(ITERS)]
+    d32 = [abs(a - b) for a, b in zip(hip32, f32)]
     worst_emu = max(rel(h, e) for h, e in zip(hip, emu))
     worst_f32 = max(rel(h, f) for h, f in zip(hip, f32))
     worst_store = max(rel(e, f) for e, f in zip(emu, f32))
     summary = {"iters": ITERS, "max_rel_hip_vs_emu": worst_emu, "max_rel_hip_vs_f32": worst_f32, "max_rel_emu_vs_f32": worst_store,
                "abs_delta_iter100_hip_vs_f32": abs(hip[-1] - f32[-1]), "abs_delta_iter100_hip_vs_emu": abs(hip[-1] - emu[-1]),
                "abs_delta_iter100_emu_vs_f32": abs(emu[-1] - f32[-1]), "north_star_abs_1e-3_vs_f32": abs(hip[-1] - f32[-1]) < 1e-3,
+               "fp32_storage_mode": {"abs_delta_iter100_vs_f32": d32[-1], "max_abs_delta_all_iters_vs_f32": max(d32),
+                                     "median_abs_delta_iters_81_100": sorted(d32[80:])[10], "north_star_abs_1e-3_vs_f32": d32[-1] < 1e-3},
                "default_paths": {"max_rel_vs_f32": max(rel(h, f) for h, f in zip(fast, f32)), "max_rel_vs_emu": max(rel(h, e) for h, e in zip(fast, emu)),
                                  "max_rel_vs_deterministic": max(rel(a, b) for a, b in zip(fast, hip)),
                                  "abs_delta_iter100_vs_f32": abs(fast[-1] - f32[-1])}}
     print("\nparity100:", json.dumps(summary))
     for r in rows[::10] + [rows[-1]]:
-        print("  it %3d lr %.2e  hip %.6f  emu %.6f  f32 %.6f  |hip-emu| %.2e  |hip-f32| %.2e  |emu-f32| %.2e"
-              % (r["iter"], r["lr"], r["hip"], r["emu"], r["f32"], abs(r["hip"] - r["emu"]), abs(r["hip"] - r["f32"]), abs(r["emu"] - r["f32"])))
+        print("  it %3d lr %.2e  hip %.6f  emu %.6f  f32 %.6f  hip32 %.6f  |hip-emu| %.2e  |hip-f32| %.2e  |emu-f32| %.2e  |hip32-f32| %.2e"
+              % (r["iter"], r["lr"], r["hip"], r["emu"], r["f32"], r["hip_fp32_storage"], abs(r["hip"] - r["emu"]), abs(r["hip"] - r["f32"]),
+                 abs(r["emu"] - r["f32"]), abs(r["hip_fp32_storage"] - r["f32"])))
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         json.dump({"summary": summary, "curve": rows}, open(os.path.join(root, "gpurun_out", "parity100.json"), "w"), indent=1)
     except OSError:
         pass
+    # (0) north_star: total-loss delta < 1e-3 vs the reference's CPU path after 100 iterations - asserted where it is a property of the
+    # implementation and not of bf16 rounding luck: the fp32-storage mode, at iteration 100 AND at every iteration on the way
+    assert d32[-1] < 1e-3 and max(d32) < 1e-3, summary["fp32_storage_mode"]
     # (1) while the learning rate is tiny (warm-up iterations 1-20) the three runs are the same computation up to rounding
     early = max(max(rel(h, e), rel(h, f)) for h, e, f in zip(hip[:20], emu[:20], f32[:20]))
     assert early <= 5e-4, (early, summary)
@@ -141,3 +162,88 @@ def test_100_iteration_loss_parity(cuda):
     assert early_fast <= 5e-4, (early_fast, summary)
     assert summary["default_paths"]["max_rel_vs_f32"] <= 1.5 * worst_store + 2e-3, summary
     assert summary["default_paths"]["max_rel_vs_emu"] <= 3.0 * worst_store + 2e-3, summary
+
+
+# iterations (1-based) at which the one-step check below runs: the first steps, every tenth, and the last five of the 100
+CHECK_AT = sorted(set(list(range(1, 6)) + list(range(10, 100, 10)) + list(range(96, 101))))
+
+
+def _momentum_state(model, opt):
+    """The fused optimizer's momentum arena as the oracle's per-parameter state dict (conv weights KRSC -> KCRS)."""
+    mom = model.arena.momentum
+    if mom is None or opt._steps == 0:
+        return {}
+    state = {}
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        off, n = model.arena.index[id(p)]
+        b = mom[off:off + n].view(p.shape).detach().float().cpu()
+        state[name] = (b.permute(0, 3, 1, 2) if b.dim() == 4 else b).contiguous().clone()
+    return state
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_one_step_parity_along_the_100_iteration_trajectory(cuda, precision):
+    """What CAN be asserted at iteration 100.  Two correct fp32 implementations of this run drift apart by themselves (tests/golden/
+    chaos100.json: the CPU oracle against itself in another summation order, and against float64), so a free-running comparison measures
+    the run's sensitivity, not the implementation.  Here the product trains freely for 100 iterations (reference schedule, momentum,
+    weight decay), and at 19 of them - the first five, every tenth, the last five - the CPU fp32 oracle is handed the product's
+    CURRENT state (parameters and momentum), takes the same step on the same batch, and must reproduce
+      * the total loss of that iteration: 2e-5 relative in the fp32-storage mode, 1e-3 relative (north_star's number) for the bf16 product,
+      * the parameter update of that iteration (fp32-storage mode): 2e-3 of its norm over the whole parameter vector, 5e-2 per tensor,
+    i.e. the loss error of the implementation does not grow with training: at iteration 100 it is what it is at iteration 1."""
+    from bench import train_step
+    from oracle.model import OracleFCOS
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.layers import functional as HF
+
+    pool = [synthetic_batch(2, 512, 512, 100 + i, device="cuda") for i in range(4)]
+    cpu_pool = [_cpu(d) for d in pool]
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    prev_p, prev_d = HF.set_precision(precision), HF.DETERMINISTIC
+    HF.DETERMINISTIC = True
+    worst_loss, worst_upd = 0.0, 0.0
+    try:
+        cfg, model, opt, sched = _build(7)
+        for it in range(ITERS):
+            lr = opt.param_groups[0]["lr"]
+            check = (it + 1) in CHECK_AT
+            if check:
+                oracle = OracleFCOS.from_hip_model(model)
+                state = _momentum_state(model, opt)
+                before = {k: v.detach().clone() for k, v in oracle.trainable().items()}
+            loss = float(train_step(model, opt, pool[it % len(pool)]))
+            sched.step()
+            if not check:
+                continue
+            ref = oracle.losses(cpu_pool[it % len(cpu_pool)])
+            total = sum(ref.values())
+            grads = dict(zip(oracle.trainable().keys(), torch.autograd.grad(total, list(oracle.trainable().values()))))
+            oracle.sgd_step(grads, state, lr, cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY, cfg.SOLVER.WEIGHT_DECAY_NORM)
+            rel = abs(loss - float(total)) / abs(float(total))
+            worst_loss = max(worst_loss, rel)
+            assert rel <= (2e-5 if precision == "fp32" else 1e-3), (it + 1, loss, float(total), rel)
+            if precision == "fp32":
+                after = oracle.trainable()
+                num = den = 0.0
+                for name, p in model.named_parameters():
+                    if not p.requires_grad:
+                        continue
+                    q = p.detach().float().cpu()
+                    q = q.permute(0, 3, 1, 2) if q.dim() == 4 else q
+                    upd_ref = (after[name].detach() - before[name]).double()
+                    upd_hip = (q - before[name]).double()
+                    n2, d2 = float(upd_ref.pow(2).sum()), float((upd_hip - upd_ref).pow(2).sum())
+                    num, den = num + d2, den + n2
+                    # per tensor: a gross error (a missing factor, a lost term) is 1e-1 .. 1; single ReLU decisions falling differently
+                    # under another summation order move small tensors (biases: sums of signed terms) by up to ~1e-2
+                    floor = 4e-7 * before[name].double().norm().item() / max(n2 ** 0.5, 1e-30)
+                    assert (d2 / max(n2, 1e-60)) ** 0.5 <= 5e-2 + floor, (it + 1, name, (d2 / max(n2, 1e-60)) ** 0.5, floor)
+                glob = (num / den) ** 0.5
+                worst_upd = max(worst_upd, glob)
+                assert glob <= 2e-3, (it + 1, glob)           # the update of the whole parameter vector
+    finally:
+        HF.set_precision(prev_p)
+        HF.DETERMINISTIC = prev_d
+    print(f"\none-step parity along the trajectory ({precision}): worst loss delta {worst_loss:.2e} relative, worst update distance {worst_upd:.2e}")

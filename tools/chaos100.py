@@ -1,0 +1,65 @@
+"""How far do two correct fp32 implementations of the SAME 100-iteration FCOS R18 run drift apart?  CPU only: the fp32 oracle
+(oracle/model.py = the reference's CPU path restated) against the same oracle in float64 and against itself with another summation
+order (one thread instead of all, which changes oneDNN's blocking / reduction order).  Same initial weights, data and schedule as
+tests/test_gpu_parity100.py.  Writes tests/golden/chaos100.json."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main(iters=100):
+    from bench import make_cfg
+    from oracle.model import OracleFCOS
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_lr_scheduler, build_optimizer
+
+    cfg = make_cfg(18)
+    cfg.SOLVER.IMS_PER_BATCH = 2
+    cfg.MODEL.DEVICE = "cpu"
+    pool = [synthetic_batch(2, 512, 512, 100 + i, device="cpu") for i in range(4)]
+
+    def build():
+        torch.manual_seed(7)
+        model = build_model(cfg)
+        return model
+
+    model = build()
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], cfg.SOLVER.BASE_LR)
+    sched = build_lr_scheduler(cfg, opt)
+    lrs = []
+    for _ in range(iters):
+        lrs.append(opt.param_groups[0]["lr"])
+        sched.step()
+
+    def run(tag, threads, double):
+        torch.set_num_threads(threads)
+        oracle = OracleFCOS.from_hip_model(build())
+        if double:
+            oracle.double()
+        state, out = {}, []
+        for it in range(iters):
+            ref = oracle.losses(pool[it % len(pool)])
+            total = sum(ref.values())
+            grads = dict(zip(oracle.trainable().keys(), torch.autograd.grad(total, list(oracle.trainable().values()))))
+            oracle.sgd_step(grads, state, lrs[it], cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY, cfg.SOLVER.WEIGHT_DECAY_NORM)
+            out.append(float(total))
+            if it % 10 == 9:
+                print(tag, it + 1, out[-1], flush=True)
+        return out
+
+    ncpu = os.cpu_count() or 1
+    res = {"lrs": lrs, "f32_all_threads": run("f32/all", ncpu, False), "f32_one_thread": run("f32/1", 1, False), "f64": run("f64", ncpu, True)}
+    json.dump(res, open(os.path.join(ROOT, "tests", "golden", "chaos100.json"), "w"))
+    a, b, c = res["f32_all_threads"], res["f32_one_thread"], res["f64"]
+    for i in list(range(9, iters, 10)) + [iters - 1]:
+        print(f"it {i + 1:3d}  |f32 - f32'| {abs(a[i] - b[i]):.2e}  |f32 - f64| {abs(a[i] - c[i]):.2e}  |f32' - f64| {abs(b[i] - c[i]):.2e}")
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 100)
