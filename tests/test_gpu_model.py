@@ -204,17 +204,40 @@ def test_fcos_r50_dcn_backbone_step_vs_oracle(cuda, modulated):
     torch.manual_seed(0)
     model = build_model(cfg)
     model.train()
+    data = synthetic_batch(2, 256, 320, 3, device="cuda")
+    # random offset weights, calibrated block by block to offsets of ~0.5 px: without a checkpoint the ResNet activations grow by orders
+    # of magnitude from stage to stage, a fixed weight scale gives offsets of tens of pixels in res4 / res5, and sampling that far away
+    # turns bf16 rounding of the offset conv's input into O(1) feature differences (measured: 10 % in res4, 36 % in res5) - a property
+    # of that input, not of either implementation
     g = torch.Generator(device="cuda").manual_seed(5)
+    hooks = []
+
+    def calibrate(mod, inp, out):
+        s = 0.5 / float(out[..., :mod.ckpt_rows].float().std())
+        mod.weight.mul_(s)
+        return out * s
+
     with torch.no_grad():
         for name, mod in model.named_modules():
             if name.endswith("conv2_offset"):
-                mod.weight[:mod.ckpt_rows].copy_(torch.randn(mod.weight[:mod.ckpt_rows].shape, device="cuda", generator=g) * (0.3 / (9 * mod.in_channels) ** 0.5))
+                mod.weight[:mod.ckpt_rows].copy_(torch.randn(mod.weight[:mod.ckpt_rows].shape, device="cuda", generator=g) * (9 * mod.in_channels) ** -0.5)
+                hooks.append(mod.register_forward_hook(calibrate))
+        model.arena.bump()
+        model.backbone.bottom_up(model.preprocess_image(data).tensor)
+        for h in hooks:
+            h.remove()
         model.arena.bump()
     opt = build_optimizer(cfg, model)
-    data = synthetic_batch(2, 256, 320, 3, device="cuda")
     refs = {}
     for emu in (True, False):
         oracle = OracleFCOS.from_hip_model(model, emulate_bf16=emu)
+        if emu:      # the backbone features themselves: within bf16 storage noise of the emulating oracle
+            with torch.no_grad():
+                bu = oracle._bottom_up(oracle.preprocess(_cpu(data)))
+                feats = model.backbone.bottom_up(model.preprocess_image(data).tensor)
+            for k in ("res3", "res4", "res5"):
+                a, b = feats[k].float().cpu().permute(0, 3, 1, 2), bu[k]
+                assert float((a - b).norm() / b.norm()) <= 3e-2, (k, float((a - b).norm() / b.norm()))
         losses = oracle.losses(_cpu(data))
         names = list(oracle.trainable().keys())
         refs[emu] = ({k: float(v.detach()) for k, v in losses.items()},

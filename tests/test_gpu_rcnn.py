@@ -355,8 +355,8 @@ def test_reference_rcnn_variants(cuda):
 
 def test_rotated_rcnn_r101_step(cuda):
     """BASELINE configs[4] at its real depth (rotated Faster R-CNN R101-FPN: RRPN + RROIHeads + ROIAlignRotated + rotated NMS;
-    batch reduced to 2 at 512x640): the four losses are finite, the RPN / ROI targets obey the sampling contract and three steps
-    at the benchmark's learning rate stay finite."""
+    batch reduced to 2 at 512x640): the four losses agree with the oracle on the sampled targets of the same forward (3e-3, the bound of
+    the small-model test), the RPN / ROI targets obey the sampling contract and three steps at the benchmark's learning rate stay finite."""
     from bench import damp_residual_branches, make_cfg
     from slenderobjdet_amd.modeling import build_model
     from slenderobjdet_amd.solver import build_optimizer
@@ -376,5 +376,20 @@ def test_rotated_rcnn_r101_step(cuda):
     assert ((gt_labels >= -1) & (gt_labels <= 1)).all() and all(int((gt_labels[i] >= 0).sum()) == cfg.MODEL.RPN.BATCH_SIZE_PER_IMAGE for i in range(2))
     for p in model.roi_heads.last_proposals:
         assert len(p) <= cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE and p.proposal_boxes.tensor.shape[1] == 5
+    # the four losses against the oracle (oracle/rcnn.py: detectron2 RRPN / RROIHeads restated) with the sampled targets of THIS forward
+    # pinned (anchor / proposal subsampling is random): R101 body, 5-parameter boxes, ROIAlignRotated over 2 x 512 proposals
+    from oracle import rcnn as orc
+
+    rpn_labels, _matched, rpn_deltas = (t.cpu() for t in model.proposal_generator.last_targets)
+    props = model.roi_heads.last_proposals
+    rois = torch.cat([torch.cat((torch.full((len(p), 1), float(i)), p.proposal_boxes.tensor.cpu()), 1) for i, p in enumerate(props)])
+    roi_cls = torch.cat([p.gt_classes.cpu() for p in props])
+    roi_gtb = torch.cat([p.gt_boxes.tensor.cpu() for p in props])
+    oracle = orc.OracleRCNN.from_hip_model(model, emulate_bf16=True)
+    with torch.no_grad():
+        ref = oracle.losses(_cpu(data), rpn_labels, rpn_deltas, rois, roi_cls, roi_gtb)
+    for k, v in ref.items():
+        a, b = float(got[k].detach()), float(v)
+        assert abs(a - b) <= 3e-3 * max(abs(b), 1e-3), (k, a, b)
     ls = [float(_step(model, opt, data)) for _ in range(3)]
     assert all(v == v and abs(v) < 1e6 for v in ls), ls

@@ -247,6 +247,50 @@ def test_reppoints_detector_vs_oracle(cuda):
     assert l1 == l1 and l1 < l0, (l0, l1)
 
 
+def test_reppoints_r50_full_size_step(cuda):
+    """BASELINE configs[3] at its real depth and resolution (RepPointsDetector, R50 + GN-FPN over res2..res5, 800x1344: 22 400 points
+    per image; batch reduced to 2, configs/rep-points/rep_points_detector_R_50_FPN_1x.yaml semantics): the targets of
+    get_ground_truth (rpd.py:276-333: nearest-point assignment for the init stage, IoU matcher on the predicted init boxes for the
+    refine stage) bit-exact against oracle/reppoints.py on the product's own init boxes, the three losses (rpd.py:335-402) within 1e-4
+    of the oracle losses on the product's own predictions, and one finite training step through both DeformConv layers."""
+    from bench import make_cfg
+    from oracle import reppoints as orp
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+
+    cfg = make_cfg(50, "reppoints")
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    data = synthetic_batch(2, 800, 1333, 77, device="cuda")
+    got = model(data)
+    tg_hip = model.last_targets
+    with torch.no_grad():
+        imgs = model.preprocess_image(data)
+        feats = model.backbone(imgs.tensor)
+        oi, cf, rf = model.run_head([feats[f] for f in model.in_features])
+        logits_buf, _, init_boxes, _, refine_boxes, _, (hw, offs, X) = model.predict(oi, cf, rf)
+    assert [tuple(x) for x in hw] == [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)] and X == 22400
+    centers, st = orp.center_grid(hw, model.strides)
+    gtb = [d["instances"].gt_boxes.tensor.cpu() for d in data]
+    gtc = [d["instances"].gt_classes.cpu() for d in data]
+    sizes = [tuple(d["image"].shape[-2:]) for d in data]
+    tg = orp.get_ground_truth(centers, st, init_boxes.cpu(), gtb, gtc, sizes, 80, "points")
+    assert torch.equal(tg_hip[0].cpu().float(), tg[0]) and torch.equal(tg_hip[1].cpu(), tg[1])
+    assert torch.equal(tg_hip[2].cpu().long(), tg[2]) and torch.equal(tg_hip[3].cpu(), tg[3])
+    assert (tg[0] > 0).sum() > 0 and ((tg[2] >= 0) & (tg[2] != 80)).sum() >= 0
+    ref, _ = orp.losses(logits_buf.cpu(), init_boxes.cpu(), refine_boxes.cpu(), *tg, st, 80, 0.25, 2.0, 20.0)
+    for k in ref:
+        a, b = float(got[k].detach()), float(ref[k])
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-3), (k, a, b)
+    l0 = float(_step(model, opt, data))
+    assert l0 == l0 and abs(l0) < 1e6
+    for m in (model.deform_cls_conv, model.deform_reg_conv):
+        assert torch.isfinite(m.weight.grad).all() and float(m.weight.grad.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("mode", ["nearest_points", "inside"])
 def test_reppoints_other_sample_modes_train(cuda, mode):
     from slenderobjdet_amd.data import synthetic_batch
