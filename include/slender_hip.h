@@ -399,6 +399,16 @@ int sod_deform_conv_wgrad_fused(const void* dy, const void* x, const float* offs
 int sod_deform_im2col(const void* x, const float* offset, const float* mask, void* cols,
                       int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
                       int off_ld, int mask_ld, int mask_is_logit, void* stream);
+/* Backward of DeformConv / ModulatedDeformConv w.r.t. input, offsets and mask in ONE pass, without the column-gradient tensor
+ * (detectron2 deform_conv_backward_input + deform_conv_backward_parameters; call sites rpd.py:637-642, df_conv.py:67-78): the workgroup
+ * of an 8x8 output-pixel tile x 32 input channels computes its slice of dcols = dY x W^T tap by tap on the matrix cores (dY rows as
+ * register fragments, W^T rows staged through LDS) and scatters it straight into the LDS fixed-point window / the offset and mask
+ * gradients.  dy (N,Ho,Wo,K) bf16; wt = the CRSK copy of the weights viewed as [(KH*KW*C)][K] bf16 (row = tap*C + c); dx_f32, doffset,
+ * dmask as for sod_deform_col2im (zero them); wnorm_ws: KH*KW*C floats of scratch (column norms of W for the fixed-point scale).
+ * K in {128, 256, 512}, C % 32 == 0 and (C / deformable_groups) % 32 == 0; other shapes: sod_conv2d_dgrad + sod_deform_col2im. */
+int sod_deform_conv_bwd_fused(const void* dy, const void* wt, const void* x, const float* offset, const float* mask, float* dx_f32,
+                              float* doffset, float* dmask, float* wnorm_ws, int N, int H, int W, int C, int K, int KH, int KW, int stride,
+                              int pad, int dil, int deformable_groups, int off_ld, int mask_ld, int mask_is_logit, void* stream);
 int sod_deform_col2im(const void* dcols, const void* x, const float* offset, const float* mask,
                       float* dx_f32, float* doffset, float* dmask,
                       int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,

@@ -48,7 +48,7 @@ class OracleFCOS:
         from slenderobjdet_amd.layers.deform_conv import DeformConv
         from slenderobjdet_amd.layers.nn import HipConv2d, HipGroupNorm
 
-        params, buffers, dcn = {}, {}, {}
+        params, buffers, dcn, groups = {}, {}, {}, {}
         for name, m in model.named_modules():
             if isinstance(m, DeformConv):      # DeformConv / ModulatedDeformConv (detectron2): KRSC -> KCRS, optional FrozenBN
                 params[name + ".weight"] = m.weight.detach().float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(m.weight.requires_grad)
@@ -59,6 +59,8 @@ class OracleFCOS:
                     buffers[name + ".scale"], buffers[name + ".shift"] = scale, m.bn_bias.float().cpu() - m.bn_running_mean.float().cpu() * scale
                 dcn[name] = dict(modulated=m.modulated, dg=m.deformable_groups, stride=m.stride, pad=m.padding, dil=m.dilation)
             elif isinstance(m, HipConv2d):
+                if getattr(m, "groups", 1) > 1:
+                    groups[name] = m.groups
                 w = m.weight.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
                 params[name + ".weight"] = w.requires_grad_(m.weight.requires_grad)
                 if m.bias is not None:
@@ -82,7 +84,7 @@ class OracleFCOS:
             num_convs=len(model.head.cls_tower), size_div=model.backbone.size_divisibility,
             stride_in_1x1={n: [blk.conv1.stride for blk in getattr(model.backbone.bottom_up, n)] for n in res_names},
             block_stride={n: [blk.stride for blk in getattr(model.backbone.bottom_up, n)] for n in res_names},
-            dcn=dcn,
+            dcn=dcn, groups=groups,
         )
         return cls(params, buffers, cfg_like, emulate_bf16)
 
@@ -123,7 +125,7 @@ class OracleFCOS:
             bias = self.b[name + ".shift"] + (bias * self.b[name + ".scale"] if bias is not None else 0)
         if self.emu:
             w = _RoundSTE.apply(w)
-        y = F.conv2d(x, w, bias, stride=stride, padding=pad)
+        y = F.conv2d(x, w, bias, stride=stride, padding=pad, groups=self.c.get("groups", {}).get(name, 1))      # ResNeXt 3x3: grouped
         if res is not None:
             y = y + res
         if relu:

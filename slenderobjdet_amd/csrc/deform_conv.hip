@@ -306,6 +306,231 @@ __global__ __launch_bounds__(256) void dcn_col2im_tile_kernel(const DcnArgs a, i
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Fused backward w.r.t. input / offsets / mask WITHOUT the column-gradient buffer.  dcols = dY x W^T was a 1x1 data gradient writing a
+// (N*Ho*Wo, KH*KW*C) bf16 tensor to HBM (1.24 GB for the P3 level of RepPoints at batch 16) that dcn_col2im_tile_kernel read back.
+// Here the workgroup that owns an 8x8 tile of output pixels x CC = 32 input channels computes its slice of dcols itself, tap by tap,
+// on the matrix cores: A = the tile's dY rows (64 px x K, held in registers as MFMA fragments for all taps), B = W^T[(tap, c0..c0+31)]
+// (32 rows of K contiguous bf16 in the CRSK copy: 16 KB at K = 256, staged through LDS, the next tap's rows prefetched into registers
+// during the scatter), D = 64 px x 32 ch fp32 -> rounded to bf16 into an LDS tile (the value the column buffer used to hold) ->
+// the scatter of dcn_col2im_tile_kernel (bilinear weights, LDS fixed-point window for dX, offset / mask gradients reduced over the
+// channel lanes) runs on that tile.  The fixed-point scale needs max|dcols * mask| BEFORE the first tap is scattered; it is bounded by
+// Cauchy-Schwarz: |dcols[p, tap, c]| <= ||dY[p, :]|| * ||W[:, tap, c]|| (column norms from dcn_wnorm_kernel), typically a few times the
+// true maximum, i.e. the quantum is 2^-17 .. 2^-20 of the tile maximum instead of 2^-20: still far below the bf16 rounding of dX.
+__global__ __launch_bounds__(256) void dcn_wnorm_kernel(const __bf16* __restrict__ wt, int rows, int K, float* __restrict__ out) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int k = 0; k < K; k += 8) {
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(wt + (long long)r * K + k);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)v[e] * (float)v[e];
+  }
+  out[r] = sqrtf(s);
+}
+
+template <int KS>      // K = 32 * KS output channels of the convolution = contraction length of the dcols GEMM
+__global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, const __bf16* __restrict__ dy, const __bf16* __restrict__ wt,
+                                                            const float* __restrict__ wnorm, int tiles_x, int WH, int WW, int R) {
+  constexpr int CC = 32, PS = CC + 1, L = CC / 8, K = 32 * KS;
+  constexpr int WROW = K * 2 + 16;        // bytes per staged weight row (16 B pad: the 16 rows of a fragment read start on different banks)
+  constexpr int NPIECE = KS / 2;          // 16-B pieces of the weight chunk per thread (32 rows x K bf16 / 256 threads)
+  extern __shared__ int win[];            // [WH][WW][PS] fixed-point window, then the weight chunk, then the dcols tile
+  __shared__ float smax[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int c0 = blockIdx.y * CC, n = blockIdx.z;
+  const int taps = a.KH * a.KW, cpg = a.C / a.DG;
+  const int ho0 = ty * 8, wo0 = tx * 8;
+  const int wy0 = ho0 * a.stride - a.pad - R, wx0 = wo0 * a.stride - a.pad - R;
+  const int wsize = WH * WW * CC;
+  const int win_bytes = (WH * WW * PS * 4 + 15) & ~15;
+  char* wl = reinterpret_cast<char*>(win) + win_bytes;
+  __bf16* dcl = reinterpret_cast<__bf16*>(wl + 32 * WROW);
+  for (int i = tid; i < WH * WW * PS; i += 256) win[i] = 0;
+
+  // ---- A fragments: dY rows of this wave's 16 pixels, all K channels (lane: pixel = lane % 16, channels (lane / 16) * 8 .. + 8 of a step)
+  const int pa = wave * 16 + (lane & 15);
+  const int hoa = ho0 + (pa >> 3), woa = wo0 + (pa & 7);
+  const bool alive = hoa < a.Ho && woa < a.Wo;
+  const long long pixa = ((long long)n * a.Ho + hoa) * a.Wo + woa;
+  bf16x8_t af[KS];
+  float ss = 0.f;
+  bool bad = false;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8_t v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+    if (alive) v = *reinterpret_cast<const bf16x8_t*>(dy + pixa * K + ks * 32 + (lane >> 4) * 8);
+    af[ks] = v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = (float)v[e];
+      ss += f * f;
+      bad = bad || (f != f) || (fabsf(f) > 3.0e38f);
+    }
+  }
+  // the weight rows of tap 0 start to arrive while the scale is worked out
+  bf16x8_t wreg[NPIECE];
+  auto w_issue = [&](int tap) {
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int q = i * 256 + tid, row = q / (K / 8), col = q % (K / 8);
+      wreg[i] = *reinterpret_cast<const bf16x8_t*>(wt + ((long long)(tap * a.C + c0 + row)) * K + col * 8);
+    }
+  };
+  auto w_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+      const int q = i * 256 + tid, row = q / (K / 8), col = q % (K / 8);
+      *reinterpret_cast<bf16x8_t*>(wl + row * WROW + col * 16) = wreg[i];
+    }
+  };
+  w_issue(0);
+  // max over the tile of ||dY[p]||, of the column norms of this channel chunk, and of |mask|
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  float nmax = bad ? __builtin_inff() : sqrtf(ss);
+  float wmax = 0.f, mmax = a.mask ? 0.f : 1.f;
+  for (int i = tid; i < taps * CC; i += 256) wmax = fmaxf(wmax, wnorm[(i / CC) * a.C + c0 + (i % CC)]);
+  if (a.mask) {
+    const int g0 = c0 / cpg;
+    for (int i = tid; i < 64 * taps; i += 256) {
+      const int p = i / taps, tap = i - p * taps;
+      const int ho = ho0 + (p >> 3), wo = wo0 + (p & 7);
+      if (ho < a.Ho && wo < a.Wo) {
+        float m = a.mask[(((long long)n * a.Ho + ho) * a.Wo + wo) * a.mask_ld + g0 * taps + tap];
+        if (a.mask_logit) m = 1.f / (1.f + expf(-m));
+        mmax = fmaxf(mmax, fabsf(m));
+        if (m != m) mmax = __builtin_inff();
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    nmax = fmaxf(nmax, __shfl_xor(nmax, o, 64));
+    wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+    mmax = fmaxf(mmax, __shfl_xor(mmax, o, 64));
+  }
+  if (lane == 0) { smax[wave] = nmax; smax[4 + wave] = wmax * mmax; }
+  __syncthreads();
+  nmax = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+  const float wm = fmaxf(fmaxf(smax[4], smax[5]), fmaxf(smax[6], smax[7]));
+  if (nmax == 0.f) return;     // all-zero gradient tile (the regression branch away from the few positive locations): nothing to add
+  const float dmax = nmax * wm;
+  int ex = 0;
+  (void)frexpf(dmax, &ex);
+  int fbits = 30;
+  for (int c = 64 * taps - 1; c > 0; c >>= 1) --fbits;
+  const float S = ldexpf(1.f, fbits - ex), invS = ldexpf(1.f, ex - fbits);
+  const bool finite_scale = dmax < 3.0e38f && dmax > 0.f;   // inf / NaN in the tile: the float atomic path propagates them
+  w_store();
+  __syncthreads();
+
+  const int cl = tid % L, pl = tid / L;           // scatter phase: 4 lanes x 8 channels per pixel, the 64 pixels of the tile at once
+  const int cch = c0 + cl * 8;
+  const int g = cch / cpg;
+  const long long base = (long long)n * a.H * a.W;
+  const int ho = ho0 + (pl >> 3), wo = wo0 + (pl & 7);
+  const bool live = ho < a.Ho && wo < a.Wo;
+  const long long pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
+  for (int tap = 0; tap < taps; ++tap) {
+    // ---- dcols tile of this tap on the matrix cores: 16 px (this wave) x 32 ch
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(wl + (lane & 15) * WROW + (ks * 32 + (lane >> 4) * 8) * 2);
+      const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(wl + (16 + (lane & 15)) * WROW + (ks * 32 + (lane >> 4) * 8) * 2);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], b1, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                  // D[m = (lane / 16) * 4 + i][n = lane % 16]
+      __bf16* row = dcl + (wave * 16 + (lane >> 4) * 4 + i) * CC;
+      row[lane & 15] = (__bf16)acc0[i];
+      row[16 + (lane & 15)] = (__bf16)acc1[i];
+    }
+    if (tap + 1 < taps) w_issue(tap + 1);
+    __syncthreads();                               // the tile is complete; every wave is done with this tap's weight rows
+    // ---- scatter (dcn_col2im_tile_kernel's body, with the column gradients read from the LDS tile)
+    const int k = g * taps + tap;
+    float g_dy = 0.f, g_dx = 0.f, g_m = 0.f;
+    if (live) {
+      const float dyo = a.off[pix * a.off_ld + 2 * k], dxo = a.off[pix * a.off_ld + 2 * k + 1];
+      const int ki = tap / a.KW, kj = tap - ki * a.KW;
+      const Samp s = make_samp((float)(ho * a.stride - a.pad + ki * a.dil) + dyo, (float)(wo * a.stride - a.pad + kj * a.dil) + dxo, a.H, a.W);
+      float m = a.mask ? a.mask[pix * a.mask_ld + k] : 1.f;
+      if (a.mask && a.mask_logit) m = 1.f / (1.f + expf(-m));
+      const bf16x8_t dcv = *reinterpret_cast<const bf16x8_t*>(dcl + pl * CC + cl * 8);
+      const s16x8_t dbits = __builtin_bit_cast(s16x8_t, dcv);
+      bool any = false;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) any = any || ((dbits[e] & 0x7fff) != 0);
+      if (s.valid && any) {
+        float v00[8], v01[8], v10[8], v11[8];
+        auto ld = [&](bool ok, int yy, int xx, float* dst) {
+          if (ok) {
+            const bf16x8_t q = *reinterpret_cast<const bf16x8_t*>(a.x + ((base + (long long)yy * a.W + xx) * a.C) + cch);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[e] = (float)q[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[e] = 0.f;
+          }
+        };
+        ld(s.ok00, s.yl, s.xl, v00); ld(s.ok01, s.yl, s.xh, v01); ld(s.ok10, s.yh, s.xl, v10); ld(s.ok11, s.yh, s.xh, v11);
+        const float hy = 1.f - s.ly, hx = 1.f - s.lx;
+        const int wy = s.yl - wy0, wx = s.xl - wx0;
+        const bool inwin = wy >= 0 && wx >= 0 && wy + 1 < WH && wx + 1 < WW && finite_scale;
+        int* w00p = win + ((wy * WW + wx) * PS) + cl * 8;
+        float* g00p = a.dx + ((base + (long long)s.yl * a.W + s.xl) * a.C) + cch;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (float)dcv[e];
+          const float dm = d * m;
+          if (inwin) {
+            const float ds = dm * S;
+            if (s.ok00) atomicAdd(w00p + e, __float2int_rn(ds * s.w00));
+            if (s.ok01) atomicAdd(w00p + PS + e, __float2int_rn(ds * s.w01));
+            if (s.ok10) atomicAdd(w00p + WW * PS + e, __float2int_rn(ds * s.w10));
+            if (s.ok11) atomicAdd(w00p + WW * PS + PS + e, __float2int_rn(ds * s.w11));
+          } else {
+            if (s.ok00) atomicAdd(g00p + e, dm * s.w00);
+            if (s.ok01) atomicAdd(g00p + a.C + e, dm * s.w01);
+            if (s.ok10) atomicAdd(g00p + (long long)a.W * a.C + e, dm * s.w10);
+            if (s.ok11) atomicAdd(g00p + (long long)a.W * a.C + a.C + e, dm * s.w11);
+          }
+          g_dy += dm * (hx * (v10[e] - v00[e]) + s.lx * (v11[e] - v01[e]));
+          g_dx += dm * (hy * (v01[e] - v00[e]) + s.ly * (v11[e] - v10[e]));
+          g_m += d * (s.w00 * v00[e] + s.w01 * v01[e] + s.w10 * v10[e] + s.w11 * v11[e]);
+        }
+        if (a.mask && a.mask_logit) g_m *= m * (1.f - m);
+      }
+    }
+#pragma unroll
+    for (int o = L >> 1; o > 0; o >>= 1) {
+      g_dy += __shfl_xor(g_dy, o, 64); g_dx += __shfl_xor(g_dx, o, 64); g_m += __shfl_xor(g_m, o, 64);
+    }
+    if (live && cl == 0) {
+      atomicAdd(a.doff + pix * a.off_ld + 2 * k, g_dy);
+      atomicAdd(a.doff + pix * a.off_ld + 2 * k + 1, g_dx);
+      if (a.dmask) atomicAdd(a.dmask + pix * a.mask_ld + k, g_m);
+    }
+    if (tap + 1 < taps) w_store();                 // (this wave's own reads of the old rows finished before the barrier above)
+    __syncthreads();                               // next tap's weight rows visible; the dcols tile may be overwritten
+  }
+  for (int i = tid; i < wsize; i += 256) {
+    const int c = i % CC, r = i / CC;
+    const int q = win[r * PS + c];
+    if (q != 0) {
+      const float v = (float)q * invS;
+      const int wx = r % WW, wy = r / WW;
+      atomicAdd(a.dx + ((base + (long long)(wy0 + wy) * a.W + (wx0 + wx)) * a.C) + c0 + c, v);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, long long n8) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
     const f32x4_t a = reinterpret_cast<const f32x4_t*>(x)[i * 2], b = reinterpret_cast<const f32x4_t*>(x)[i * 2 + 1];
@@ -383,6 +608,40 @@ extern "C" int sod_deform_col2im(const void* dcols, const void* x, const float* 
   // the atomic fallback (red == 0) accumulates: the caller passes zero-initialised doffset / dmask in every case (they are
   // pitched buffers whose padding columns must be zero anyway)
   SOD_LAUNCH(dcn_col2im_kernel, dim3(grid_for((long long)N * a.Ho * a.Wo * KH * KW * (C / 8))), dim3(256), 0, st, a, red);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_deform_conv_bwd_fused(const void* dy, const void* wt, const void* x, const float* offset, const float* mask, float* dx_f32,
+                                         float* doffset, float* dmask, float* wnorm_ws, int N, int H, int W, int C, int K, int KH, int KW, int stride,
+                                         int pad, int dil, int deformable_groups, int off_ld, int mask_ld, int mask_is_logit, void* stream) {
+  if (!dy || !wt || !x || !offset || !dx_f32 || !doffset || !wnorm_ws || (mask && !dmask)) return SOD_EARG;
+  DcnArgs a{};
+  int rc = dcn_fill(a, N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, off_ld, mask_ld, mask_is_logit);
+  if (rc) return rc;
+  const int cpg = C / deformable_groups;
+  if ((K != 128 && K != 256 && K != 512) || (C & 31) || (cpg & 31) || N > 65535 || C / 32 > 65535) return SOD_EARG;
+  static const int r_env = getenv("SOD_DCN_FUSED_R") ? atoi(getenv("SOD_DCN_FUSED_R")) : 2;
+  const int WH = 7 * stride + (KH - 1) * dil + 2 + 2 * r_env, WW = 7 * stride + (KW - 1) * dil + 2 + 2 * r_env;
+  const size_t lds = (((size_t)WH * WW * 33 * 4 + 15) & ~(size_t)15) + (size_t)32 * (K * 2 + 16) + (size_t)64 * 32 * 2;
+  if (lds > 96 * 1024 || (unsigned long long)N * a.Ho * a.Wo * K * 2ull >= 0x80000000ull * 4ull) return SOD_EARG;
+  a.x = (const __bf16*)x; a.off = offset; a.mask = mask; a.dx = dx_f32; a.doff = doffset; a.dmask = dmask;
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = KH * KW * C;
+  SOD_LAUNCH(dcn_wnorm_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const __bf16*)wt, rows, K, wnorm_ws);
+  const int tiles_x = (a.Wo + 7) / 8, tiles_y = (a.Ho + 7) / 8;
+  const dim3 grid(tiles_x * tiles_y, C / 32, N);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  if (K == 128) SOD_LAUNCH(dcn_bwd_fused_kernel<4>, grid, dim3(256), lds, st, a, (const __bf16*)dy, (const __bf16*)wt, wnorm_ws, tiles_x, WH, WW, r_env);
+  else if (K == 256) SOD_LAUNCH(dcn_bwd_fused_kernel<8>, grid, dim3(256), lds, st, a, (const __bf16*)dy, (const __bf16*)wt, wnorm_ws, tiles_x, WH, WW, r_env);
+  else SOD_LAUNCH(dcn_bwd_fused_kernel<16>, grid, dim3(256), lds, st, a, (const __bf16*)dy, (const __bf16*)wt, wnorm_ws, tiles_x, WH, WW, r_env);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -20,6 +20,9 @@ SAVE_COLS = os.environ.get("SOD_DCN_SAVE_COLS", "1") != "0"
 # 1.51 -> 0.95 ms, weight gradient 0.53 ms (on kept columns) -> 0.79 ms, i.e. 2.04 -> 1.74 ms and 1.65 GB less memory traffic and
 # footprint per layer.  SOD_DCN_FUSED=0 restores the column-buffer path (shapes the fused kernels do not take use it anyway).
 FUSED = os.environ.get("SOD_DCN_FUSED", "1") != "0"
+# The gradient w.r.t. input / offsets / mask: sod_deform_conv_bwd_fused computes each tile's column gradients on the matrix cores inside
+# the scatter kernel; SOD_DCN_BWD_FUSED=0 restores 1x1 dgrad -> bf16 dcols (N*Ho*Wo, 9C) in HBM -> dcn_col2im_tile.
+BWD_FUSED = os.environ.get("SOD_DCN_BWD_FUSED", "1") != "0"
 
 
 def _ceil8(v):
@@ -77,13 +80,18 @@ class _DeformConvFn(torch.autograd.Function):
             if mod.bias is not None:
                 HF.bias_grad(dy, arena.grad_view(mod.bias), N, Ho * Wo, K)
                 arena.mark_ready(mod.bias)
-        dcols = HF.conv2d_dgrad(dy, mod.wt_bf16, (Ho, Wo), 1, 0, 1)
         doff = torch.zeros_like(offset)          # pitched like the offset tensor (mask columns live in the same rows for v2)
         dmask = None
         aliased = mask is not None and mask.untyped_storage().data_ptr() == offset.untyped_storage().data_ptr()
         if mask is not None:
             dmask = doff.view(-1)[mask.storage_offset() - offset.storage_offset():] if aliased else torch.zeros_like(mask)
-        dx32 = HF.deform_col2im(dcols, x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, doff, dmask, off_ld, mask_ld, mask_is_logit)
+        if BWD_FUSED and HF.deform_bwd_fused_supported(C, K, dg):
+            # one pass: the tile's slice of dcols = dY x W^T is computed inside the scatter kernel (no column-gradient tensor)
+            dx32 = HF.deform_conv_bwd_fused(dy, mod.wt_bf16, x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, doff, dmask,
+                                            off_ld, mask_ld, mask_is_logit)
+        else:
+            dcols = HF.conv2d_dgrad(dy, mod.wt_bf16, (Ho, Wo), 1, 0, 1)
+            dx32 = HF.deform_col2im(dcols, x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, doff, dmask, off_ld, mask_ld, mask_is_logit)
         dx = HF.f32_to_bf16(dx32) if ctx.needs_input_grad[0] else None
         gmask = None
         if mask is not None and ctx.needs_input_grad[2] and not aliased:

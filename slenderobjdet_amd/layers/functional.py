@@ -1031,6 +1031,27 @@ def deform_fused_supported(C, K, dg):
     return C % 128 == 0 and K % 8 == 0 and C % dg == 0 and (dg == 1 or (C // dg) % 128 == 0)
 
 
+def deform_bwd_fused_supported(C, K, dg):
+    """Shapes the fused input / offset / mask gradient (sod_deform_conv_bwd_fused) accepts."""
+    return K in (128, 256, 512) and C % 32 == 0 and C % dg == 0 and (C // dg) % 32 == 0
+
+
+def deform_conv_bwd_fused(dy, wt, x, offset, mask, ksize, stride, pad, dil, dg, doffset, dmask, off_ld=0, mask_ld=0, mask_is_logit=False):
+    """dx fp32 (N,H,W,C) + the (zero-initialised, pitched) doffset / dmask from dy (N,Ho,Wo,K) bf16 and wt = the CRSK weight copy
+    ((KH*KW*C, 1, 1, K) bf16), with no column-gradient tensor in between."""
+    _chk(dy, torch.bfloat16, "dy"); _chk(wt, torch.bfloat16, "wt"); _chk(x, torch.bfloat16, "x")
+    N, H, W, C = x.shape
+    KH, KW = ksize
+    K = dy.shape[-1]
+    if wt.numel() != KH * KW * C * K:
+        raise _C.SlenderHipError("deform_conv_bwd_fused: wt does not hold KH*KW*C x K elements")
+    dx = torch.zeros((N, H, W, C), dtype=torch.float32, device=x.device)
+    wn = torch.empty(KH * KW * C, dtype=torch.float32, device=x.device)
+    call("sod_deform_conv_bwd_fused", ptr(dy), ptr(wt), ptr(x), ptr(offset), ptr(mask), ptr(dx), ptr(doffset), ptr(dmask), ptr(wn), N, H, W, C, K, KH, KW,
+         stride, pad, dil, dg, off_ld, mask_ld, 1 if mask_is_logit else 0, stream_ptr())
+    return dx
+
+
 def deform_col2im(dcols, x, offset, mask, ksize, stride, pad, dil, dg, doffset, dmask, off_ld=0, mask_ld=0, mask_is_logit=False):
     """Returns dx fp32 (N,H,W,C); fills the (zero-initialised, pitched) doffset / dmask."""
     N, H, W, C = x.shape

@@ -195,6 +195,77 @@ class HipConv2d(nn.Module):
         return _ConvFn.apply(x, res, self.weight, self, res_up2)
 
 
+class HipGroupedConv2d(HipConv2d):
+    """Conv2d with ``groups`` > 1 (ResNeXt bottlenecks: MODEL.RESNETS.NUM_GROUPS / WIDTH_PER_GROUP, e.g.
+    configs/ablation_studies/pointset/base_X101.yaml:9-11).  The master weight has the reference's shape (K, R, S, C / groups); the
+    compute copies are its block-diagonal embedding into a dense (K, R, S, C) weight, so forward and data gradient run on the same
+    implicit-GEMM kernels as every other convolution and are exact (the off-diagonal blocks are zeros).  The weight gradient is taken
+    densely into a scratch tensor and its diagonal blocks are added to the arena.  Cost: groups x the FLOPs of a true grouped kernel on
+    this one layer type - correctness first; a channel-window variant of the implicit GEMM is the follow-up."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, **kw):
+        if in_channels % groups or out_channels % groups:
+            raise ValueError(f"groups={groups} must divide in_channels={in_channels} and out_channels={out_channels}")
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, **kw)
+        self.groups = groups
+        self.weight = nn.Parameter(torch.empty(out_channels, kernel_size, kernel_size, in_channels // groups))
+
+    batched_prep_shape = None          # not part of the arena's batched bf16 preparation: prepare() embeds the blocks first
+
+    def init_msra(self):               # fan_out of the grouped layer as torch computes it: out_channels * k * k / groups ... of weight (K, C/g, k, k)
+        fan_out = self.out_channels * self.kernel_size * self.kernel_size
+        nn.init.normal_(self.weight, 0.0, math.sqrt(2.0 / fan_out))
+
+    def dense_weight(self, w):
+        """(K, R, S, C/g) -> block-diagonal (K, R, S, C)."""
+        K, R, S, Cg = w.shape
+        g = self.groups
+        d = w.new_zeros(K, R, S, Cg * g)
+        idx = torch.arange(g, device=w.device)
+        d.view(g, K // g, R, S, g, Cg)[idx, :, :, :, idx, :] = w.reshape(g, K // g, R, S, Cg)
+        return d
+
+    def blocks_of(self, dense):
+        """Diagonal blocks of a dense (K, R, S, C) tensor -> (K, R, S, C/g)."""
+        K, R, S, C = dense.shape
+        g = self.groups
+        idx = torch.arange(g, device=dense.device)
+        return dense.view(g, K // g, R, S, g, C // g)[idx, :, :, :, idx, :].reshape(K, R, S, C // g)
+
+    def weight_kcrs(self):
+        return self.weight.detach().permute(0, 3, 1, 2).contiguous()
+
+    def prepare(self, force=False):
+        arena = _arena_of(self)
+        key = (self.weight._version, arena.generation if (arena is not None and self.weight.requires_grad) else -1, self.weight.data_ptr(),
+               self._bn_state() if self.frozen_bn else None, HF.PRECISION)
+        if not force and key == self._prep_key:
+            return
+        if self.frozen_bn:
+            scale = self.bn_weight * torch.rsqrt(self.bn_running_var + 1e-5)
+            self.bn_scale = scale.contiguous()
+            self.bias_eff = (self.bn_bias - self.bn_running_mean * scale + (self.bias.detach() * scale if self.bias is not None else 0)).contiguous()
+        else:
+            self.bn_scale = None
+            self.bias_eff = self.bias.detach() if self.bias is not None else None
+        with torch.no_grad():
+            dense = self.dense_weight(self.weight.detach())
+        self.w_bf16, self.wt_bf16 = HF.weight_prep(dense.contiguous(), self.bn_scale, True, True, None)
+        self._prep_key = key
+
+    def wgrad_into(self, arena, g, x):
+        """dW of the dense embedding into a scratch tensor on the CURRENT stream, diagonal blocks added to the arena gradient."""
+        K, k, C = self.out_channels, self.kernel_size, self.in_channels
+        dense = torch.zeros((K, k, k, C), dtype=torch.float32, device=g.device)
+        prev, HF.WGRAD_SIDE_STREAM = HF.WGRAD_SIDE_STREAM, False
+        try:
+            HF.conv2d_wgrad(g, x, dense, k, k, self.stride, self.padding, self.dilation, qscale=self.bn_scale)
+        finally:
+            HF.WGRAD_SIDE_STREAM = prev
+        arena.grad_view(self.weight).add_(self.blocks_of(dense))
+        arena.mark_ready(self.weight)
+
+
 class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, weight, mod, res_up2):
@@ -226,9 +297,12 @@ class _ConvFn(torch.autograd.Function):
         arena = _arena_of(mod)
         N, H, W, C = x.shape
         if mod.weight.requires_grad:
-            dw = arena.grad_view(mod.weight)
-            HF.conv2d_wgrad(g, x, dw, mod.kernel_size, mod.kernel_size, mod.stride, mod.padding, mod.dilation, qscale=mod.bn_scale)
-            arena.mark_ready(mod.weight)
+            if getattr(mod, "groups", 1) > 1:
+                mod.wgrad_into(arena, g, x)
+            else:
+                dw = arena.grad_view(mod.weight)
+                HF.conv2d_wgrad(g, x, dw, mod.kernel_size, mod.kernel_size, mod.stride, mod.padding, mod.dilation, qscale=mod.bn_scale)
+                arena.mark_ready(mod.weight)
             if mod.bias is not None:
                 HF.bias_grad(g, arena.grad_view(mod.bias), N, g.shape[1] * g.shape[2], mod.out_channels)
                 arena.mark_ready(mod.bias)

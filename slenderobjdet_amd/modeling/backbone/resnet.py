@@ -11,7 +11,7 @@ from torch import nn
 from torch.autograd.function import once_differentiable
 
 from ...layers import functional as HF
-from ...layers.nn import DeferSlot, HipConv2d, _arena_of, max_pool_3x3_s2
+from ...layers.nn import DeferSlot, HipConv2d, HipGroupedConv2d, _arena_of, max_pool_3x3_s2
 import os
 
 from ..shape_spec import ShapeSpec
@@ -50,7 +50,7 @@ class BasicStem(nn.Module):
 
 
 class BottleneckBlock(nn.Module):
-    def __init__(self, in_channels, out_channels, bottleneck_channels, stride=1, stride_in_1x1=True, dilation=1):
+    def __init__(self, in_channels, out_channels, bottleneck_channels, stride=1, stride_in_1x1=True, dilation=1, num_groups=1):
         super().__init__()
         self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
         s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
@@ -59,8 +59,12 @@ class BottleneckBlock(nn.Module):
             self.shortcut = HipConv2d(in_channels, out_channels, 1, stride, 0, bias=False, frozen_bn=True)
         # conv1's / conv2's ReLU outputs have a single consumer, so the consumer's dgrad applies their masks
         self.conv1 = HipConv2d(in_channels, bottleneck_channels, 1, s1, 0, bias=False, frozen_bn=True, relu=True, grad_premasked=True)
-        self.conv2 = HipConv2d(bottleneck_channels, bottleneck_channels, 3, s3, dilation, dilation, bias=False, frozen_bn=True,
-                               relu=True, mask_input=True, grad_premasked=True)
+        if num_groups > 1:     # ResNeXt: the 3x3 is grouped (detectron2 BottleneckBlock(num_groups=...))
+            self.conv2 = HipGroupedConv2d(bottleneck_channels, bottleneck_channels, 3, s3, dilation, dilation, groups=num_groups, bias=False,
+                                          frozen_bn=True, relu=True, mask_input=True, grad_premasked=True)
+        else:
+            self.conv2 = HipConv2d(bottleneck_channels, bottleneck_channels, 3, s3, dilation, dilation, bias=False, frozen_bn=True,
+                                   relu=True, mask_input=True, grad_premasked=True)
         self.conv3 = HipConv2d(bottleneck_channels, out_channels, 1, 1, 0, bias=False, frozen_bn=True, relu=True, mask_input=True)
         for m in (self.conv1, self.conv2, self.conv3, self.shortcut):
             if m is not None:
@@ -241,7 +245,9 @@ def _conv(m, x, res=None):
 
 
 def _wgrad(m, g, x, arena):
-    if m.weight.requires_grad:
+    if m.weight.requires_grad and getattr(m, "groups", 1) > 1:
+        m.wgrad_into(arena, g, x)
+    elif m.weight.requires_grad:
         HF.conv2d_wgrad(g, x, arena.grad_view(m.weight), m.kernel_size, m.kernel_size, m.stride, m.padding, m.dilation, qscale=m.bn_scale)
         arena.mark_ready(m.weight)
 
@@ -452,8 +458,9 @@ def build_resnet_backbone(cfg, input_shape):
     norm = cfg.MODEL.RESNETS.NORM
     if norm != "FrozenBN":
         raise NotImplementedError(f"MODEL.RESNETS.NORM={norm}: only FrozenBN (the default the FCOS/RetinaNet configs use) is built")
-    if cfg.MODEL.RESNETS.NUM_GROUPS != 1:
-        raise NotImplementedError("grouped (ResNeXt) convolutions are not built")
+    num_groups = cfg.MODEL.RESNETS.NUM_GROUPS
+    if num_groups != 1 and depth in (18, 34):
+        raise NotImplementedError("NUM_GROUPS > 1 needs bottleneck blocks (detectron2 asserts the same for R18 / R34)")
     deform_on = list(cfg.MODEL.RESNETS.DEFORM_ON_PER_STAGE)
     if any(deform_on) and depth in (18, 34):
         raise NotImplementedError("DEFORM_ON_PER_STAGE needs bottleneck blocks (detectron2 asserts the same for R18 / R34)")
@@ -480,7 +487,7 @@ def build_resnet_backbone(cfg, input_shape):
                                                     deform_modulated=cfg.MODEL.RESNETS.DEFORM_MODULATED,
                                                     deform_num_groups=cfg.MODEL.RESNETS.DEFORM_NUM_GROUPS, num_groups=cfg.MODEL.RESNETS.NUM_GROUPS))
             else:
-                blocks.append(BottleneckBlock(in_ch, out_ch, bott, stride, cfg.MODEL.RESNETS.STRIDE_IN_1X1, dilation))
+                blocks.append(BottleneckBlock(in_ch, out_ch, bott, stride, cfg.MODEL.RESNETS.STRIDE_IN_1X1, dilation, num_groups=num_groups))
             in_ch = out_ch
         out_ch *= 2
         bott *= 2

@@ -105,6 +105,54 @@ def test_dfconv2d_module_trains(cuda, v2):
     assert (m.offset.weight.grad[m.n_off:] == 0).all()     # padding rows stay inert
 
 
+@pytest.mark.parametrize("modulated,dg,stride,C,K,hw", [(False, 1, 1, 64, 128, (9, 11)), (True, 1, 1, 128, 256, (13, 19)), (True, 2, 2, 64, 128, (12, 14)),
+                                                         (False, 1, 1, 256, 256, (17, 9)), (True, 4, 1, 128, 512, (8, 8))])
+def test_deform_conv_fused_backward(cuda, modulated, dg, stride, C, K, hw):
+    """sod_deform_conv_bwd_fused - the gradient w.r.t. input, offsets and mask with the tile's column gradients computed on the matrix
+    cores INSIDE the scatter kernel (no (N*Ho*Wo, 9C) tensor) - against the oracle's autograd (2e-2 of the maximum: the column gradients
+    are rounded to bf16 exactly as the column buffer was) and against the two-kernel path it replaces (1x1 data gradient -> dcols in HBM
+    -> dcn_col2im_tile), which must agree to the fixed-point quantum of the LDS window.  Includes an all-zero dY image (the tile is
+    skipped), offsets far outside the image and a tile edge that is not a multiple of 8."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, (H, W) = 2, hw
+    x = onn.rb(torch.randn(N, C, H, W, generator=_g(0)))
+    w = onn.rb(torch.randn(K, C, 3, 3, generator=_g(1)) * 0.05)
+    Ho, Wo = HF.conv_out_size(H, W, 3, 3, stride, 1, 1)
+    off = (torch.rand(N, 18 * dg, Ho, Wo, generator=_g(2)) - 0.5) * 4.3 + 0.017
+    off[0, :, 0, 0] = 9.0
+    off[0, :, 1, 1] = -3.0
+    mask = torch.rand(N, 9 * dg, Ho, Wo, generator=_g(3)) if modulated else None
+    dy = onn.rb(torch.randn(N, K, Ho, Wo, generator=_g(4)))
+    dy[1, :, : Ho // 2] = 0                          # whole tiles without gradient
+    xs, os_, ws = x.clone().requires_grad_(True), off.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ms = mask.clone().requires_grad_(True) if modulated else None
+    ref = odc.deform_conv2d(xs, os_, ws, None, stride, 1, 1, ms, dg)
+    grads = torch.autograd.grad(ref, [xs, os_] + ([ms] if modulated else []), dy)
+
+    xd = _nhwc(x).to(cuda).bfloat16()
+    offd = _nhwc(off).to(cuda)
+    maskd = _nhwc(mask).to(cuda) if modulated else None
+    dyd = _nhwc(dy).to(cuda).bfloat16()
+    w_flat = w.permute(0, 2, 3, 1).contiguous().reshape(K, 1, 1, 9 * C).to(cuda)
+    _, wt = HF.weight_prep(w_flat)
+    assert HF.deform_bwd_fused_supported(C, K, dg)
+    doff = torch.zeros_like(offd)
+    dmask = torch.zeros_like(maskd) if modulated else None
+    dx = HF.deform_conv_bwd_fused(dyd, wt, xd, offd, maskd, (3, 3), stride, 1, 1, dg, doff, dmask)
+    # the path it replaces
+    dcols = HF.conv2d_dgrad(dyd, wt, (Ho, Wo), 1, 0, 1)
+    doff2 = torch.zeros_like(offd)
+    dmask2 = torch.zeros_like(maskd) if modulated else None
+    dx2 = HF.deform_col2im(dcols, xd, offd, maskd, (3, 3), stride, 1, 1, dg, doff2, dmask2)
+    for got, old, want, name in ((dx, dx2, grads[0], "dx"), (doff, doff2, grads[1], "doffset")) + (((dmask, dmask2, grads[2], "dmask"),) if modulated else ()):
+        want = _nhwc(want)
+        scale = want.abs().max().item()
+        assert (got.cpu() - want).abs().max().item() <= 2e-2 * scale, name
+        assert (got - old).abs().max().item() <= 2e-4 * scale, name          # same bf16 column gradients, another fixed-point scale / order
+    assert float(dx[1, : max((Ho // 2 - 2) * stride - 3, 0)].abs().max()) == 0 if Ho // 2 > 4 else True
+
+
 @pytest.mark.parametrize("v2", [False, True])
 def test_dfconv2d_gradients_vs_oracle(cuda, v2):
     """DFConv2d (slender_det/layers/df_conv.py:67-78) end to end as an autograd module against the CPU oracle: the gradient that reaches

@@ -272,6 +272,59 @@ def test_fcos_r50_dcn_backbone_step_vs_oracle(cuda, modulated):
     assert checked >= 3 * (4 + 6 + 3) + 4          # offset weight / bias + sampled conv of 13 blocks, two tower units
 
 
+def test_fcos_resnext_step_vs_oracle(cuda):
+    """ResNeXt bottlenecks (MODEL.RESNETS.NUM_GROUPS 32 / WIDTH_PER_GROUP 8 / STRIDE_IN_1X1 false: the X101 ablation configs' backbone
+    family, here at depth 50): one FCOS training step against the oracle (oracle/model.py with F.conv2d(groups=32)).  Losses 1e-3 of the
+    bf16-emulating oracle; the grouped 3x3 weight gradients (the diagonal blocks of the dense scratch gradient, in the reference's
+    (K, C / 32, 3, 3) shape) no further from fp32 than 1.5x the bf16 emulation + 1 %."""
+    from bench import make_cfg
+    from oracle.model import OracleFCOS
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.layers.nn import HipGroupedConv2d
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+
+    cfg = make_cfg(50)
+    cfg.MODEL.RESNETS.NUM_GROUPS, cfg.MODEL.RESNETS.WIDTH_PER_GROUP, cfg.MODEL.RESNETS.STRIDE_IN_1X1 = 32, 8, False
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    assert isinstance(model.backbone.bottom_up.res4[2].conv2, HipGroupedConv2d)
+    opt = build_optimizer(cfg, model)
+    data = synthetic_batch(2, 256, 320, 3, device="cuda")
+    refs = {}
+    for emu in (True, False):
+        oracle = OracleFCOS.from_hip_model(model, emulate_bf16=emu)
+        losses = oracle.losses(_cpu(data))
+        names = list(oracle.trainable().keys())
+        refs[emu] = ({k: float(v.detach()) for k, v in losses.items()},
+                     dict(zip(names, torch.autograd.grad(sum(losses.values()), list(oracle.trainable().values())))))
+    prev_det, HF.DETERMINISTIC = HF.DETERMINISTIC, True
+    try:
+        got = model(data)
+        total = sum(got.values())
+        opt.zero_grad()
+        model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    finally:
+        HF.DETERMINISTIC = prev_det
+    for k, e in refs[True][0].items():
+        a = float(got[k].detach())
+        assert abs(a - e) <= 1e-3 * max(abs(e), 1e-3), (k, a, e)
+    checked = 0
+    for name, p in model.named_parameters():
+        if not p.requires_grad or not name.endswith("conv2.weight"):
+            continue
+        gq = p.grad.detach().float().cpu().permute(0, 3, 1, 2)
+        r32, remu = refs[False][1][name], refs[True][1][name]
+        assert gq.shape == r32.shape and gq.shape[1] * 32 == gq.shape[0]
+        n = max(r32.norm().item(), 1e-12)
+        d_hip, d_emu = (gq - r32).norm().item() / n, (remu - r32).norm().item() / n
+        assert d_hip <= 1.5 * d_emu + 0.01, (name, d_hip, d_emu)
+        checked += 1
+    assert checked == 4 + 6 + 3
+
+
 def test_train_net_cli_runs(cuda, tmp_path):
     """train_net.py with the reference's CLI: config file + overrides, 3 iterations on synthetic batches."""
     import subprocess

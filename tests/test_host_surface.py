@@ -434,3 +434,40 @@ def test_dcnv2_backbone_config_builds_deform_bottleneck_blocks():
     cfg2.MODEL.BACKBONE.NAME = "build_retinanet_resnet_fpn_backbone_use_p5"
     with pytest.raises(NotImplementedError, match="bottleneck"):
         build_model(cfg2)
+
+
+def test_resnext_config_builds_grouped_bottlenecks():
+    """configs/ablation_studies/pointset/base_X101.yaml (the reference file's keys: NUM_GROUPS 32, WIDTH_PER_GROUP 8, STRIDE_IN_1X1 false,
+    DEPTH 101): the 3x3 of every bottleneck is a grouped convolution with detectron2's parameter shapes; its dense block-diagonal
+    embedding (what the implicit-GEMM kernels run) is the same linear map as F.conv2d(groups=32), and the diagonal blocks of a dense
+    gradient are the grouped gradient."""
+    import torch
+    import torch.nn.functional as F
+
+    from slenderobjdet_amd.layers.nn import HipGroupedConv2d
+    from slenderobjdet_amd.modeling import build_model
+
+    cfg = fresh_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(__file__), "..", "configs", "ablation_studies", "pointset", "base_X101.yaml"))
+    cfg.MODEL.DEVICE = "cpu"
+    m = build_model(cfg)
+    b = m.backbone.bottom_up
+    assert len(b.res4) == 23
+    for stage, width in ((b.res2, 256), (b.res3, 512), (b.res4, 1024), (b.res5, 2048)):
+        c = stage[0].conv2
+        assert isinstance(c, HipGroupedConv2d) and c.groups == 32 and tuple(c.weight.shape) == (width, 3, 3, width // 32)
+    assert b.res3[0].conv1.stride == 1 and b.res3[0].conv2.stride == 2 and b.res3[0].shortcut.stride == 2      # STRIDE_IN_1X1 false
+    c = b.res3[1].conv2
+    w = c.weight.detach()
+    dense = c.dense_weight(w)
+    assert tuple(dense.shape) == (512, 3, 3, 512) and torch.equal(c.blocks_of(dense), w) and float(dense.abs().sum()) == pytest.approx(float(w.abs().sum()), rel=1e-5)
+    x = torch.randn(1, 512, 6, 7)
+    y_grouped = F.conv2d(x, w.permute(0, 3, 1, 2), padding=1, groups=32)
+    y_dense = F.conv2d(x, dense.permute(0, 3, 1, 2), padding=1)
+    assert float((y_grouped - y_dense).abs().max()) <= 1e-5 * float(y_grouped.abs().max())
+    dy = torch.randn_like(y_grouped)
+    wg = w.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wd = dense.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    (gg,) = torch.autograd.grad(F.conv2d(x, wg, padding=1, groups=32), wg, dy)
+    (gd,) = torch.autograd.grad(F.conv2d(x, wd, padding=1), wd, dy)
+    assert torch.allclose(c.blocks_of(gd.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2), gg, rtol=1e-4, atol=1e-5)
