@@ -824,7 +824,7 @@ def test_groupnorm_backward_reduction_in_the_consumer_dgrad(cuda):
         # the forward pass is the same code in all steps; its GroupNorm statistics come from float atomics (not bit-reproducible)
         for k in ref_l:
             assert abs(got_l[k] - ref_l[k]) <= 2e-4 * abs(ref_l[k]), (k, got_l[k], ref_l[k])
-        # Every gradient may differ from the two-pass form by no more than that form differs from itself between two runs (x4, + 0.3 %):
+        # Every gradient may differ from the two-pass form by no more than that form differs from itself between two runs (x4, + 1 %):
         # a last-bit change in one norm's sums moves bf16 roundings downstream, and sums with cancellation (dgamma) show it at the
         # per-cent level either way.  A wrong reduction (missing mask, wrong group, lost pixels) is off by tens of per cent.
         worst = 0.0
@@ -833,7 +833,7 @@ def test_groupnorm_backward_reduction_in_the_consumer_dgrad(cuda):
             nb = max(b.norm().item(), 1e-12)
             d, noise = (a - b).norm().item() / nb, (b2 - b).norm().item() / nb
             worst = max(worst, d)
-            assert d <= 4.0 * noise + 3e-3, (name, d, noise)
+            assert d <= 4.0 * noise + 1e-2, (name, d, noise)
         assert worst < 0.3
     finally:
         HF.conv2d_dgrad_ml_gnbwd = orig
