@@ -126,6 +126,10 @@ int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, f
  * tiles, Nout % 256 == 0 and R*S*C >= 1024 run on the 256x256x64 8-phase kernel (whole rounds; a short remainder goes to the
  * 128x128 kernel); 0 = 128x128 kernel only; 2 = the 256 kernel for every shape it supports (tests); -1 = re-read the env. */
 int sod_conv_set_tile256(int mode);
+/* Process-wide, like sod_conv_set_tile256: while on, the single-level sod_conv2d_fwd / sod_conv2d_dgrad launches walk their
+ * output tiles last to first, so that a kernel reading a tensor its predecessor has just written starts with the part still in the
+ * Infinity Cache.  Results are unaffected. */
+int sod_conv_set_reverse(int on);
 /* Which kernel the last sod_conv2d_fwd / _dgrad call of this thread dispatched to (profiling aid): 256 = the 256x256x64 kernel
  * (possibly followed by a short 128x128 tail launch), otherwise BQ*100000 + BP*100 + BK (+1 for the generic-channel path). */
 int sod_conv_last_variant(void);

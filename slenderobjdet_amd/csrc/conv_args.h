@@ -12,6 +12,8 @@ enum {
   F_WBITS = 64,        // bf16 forward output: bit (dst element index) of LevelGeo::bits = stored value > 0 (1-bit ReLU mask for backward)
   F_MASKBITS = 128,    // like F_MASK, but LevelGeo::mask is such a bit array (1/16 of the bytes of the bf16 tensor)
   F_GNSTATS = 32,
+  F_REVERSE = 1024,    // walk the tiles last to first: a consumer that starts where its producer stopped finds that part of the tensor in the
+                       // Infinity Cache (sod_conv_set_reverse)
   F_RES_EVEN = 512,    // with F_RES_UP2 (dgrad): the half-resolution residual is added at EVEN (h, w) only = the compact data gradient of a
                        // stride-2 1x1 consumer scattered back, without materialising the zero-stuffed tensor
   F_GNBWD = 256,       // bf16 data gradient whose output is dL/d(relu(GroupNorm(x))): the epilogue also gathers the four sums of the norm's backward      // bf16 forward output: per-(image, 8-channel group) sum / sum of squares of the stored values -> LevelGeo::gn_sum

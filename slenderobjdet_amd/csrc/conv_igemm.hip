@@ -75,7 +75,8 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+  uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+  if (a.flags & F_REVERSE) bid = gridDim.x - 1 - bid;
   const int qt = bid % a.nq_tiles;
   int pt = bid / a.nq_tiles;   // q fastest: neighbours share the X tile
   int lv = 0;
@@ -418,12 +419,12 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
             }
           }
           if constexpr (OUT_F32) {
-            *reinterpret_cast<f32x4_t*>((float*)g.dst + drow[k] + q) = f32x4_t{v[0], v[1], v[2], v[3]};
+            sod_store16((float*)g.dst + drow[k] + q, f32x4_t{v[0], v[1], v[2], v[3]});
           } else {
             bf16x8_t o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
-            *reinterpret_cast<bf16x8_t*>((__bf16*)g.dst + drow[k] + q) = o;
+            sod_store16((__bf16*)g.dst + drow[k] + q, o);
             if constexpr (MODE == MODE_FWD) {
               if (a.flags & F_WBITS) {
                 uint32_t b = 0;
@@ -845,6 +846,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   return SOD_OK;
 }
 
+int g_conv_reverse = 0;    // sod_conv_set_reverse
 int g_conv256_mode = -1;   // -1: read SOD_CONV256 (default 1); 0 off; 1 heuristic; 2 every supported shape
 
 template <int MODE, bool OUT_F32, bool GNB = false>
@@ -1154,6 +1156,7 @@ static int conv2d_fwd_impl(const void* x, const void* w, const float* bias, cons
     }
   }
   if (relu_bits) { a.flags |= F_WBITS; a.lev[0].bits = relu_bits; }
+  if (g_conv_reverse) a.flags |= F_REVERSE;
   hipStream_t st = (hipStream_t)stream;
   return out_f32 ? dispatch_conv<MODE_FWD, true>(a, st) : dispatch_conv<MODE_FWD, false>(a, st);
 }
@@ -1231,6 +1234,7 @@ extern "C" int sod_conv2d_dgrad(const void* dy, const void* wt, const void* accu
   a.flags = 0;
   if (accum) { a.flags |= F_RES; a.lev[0].res = accum; a.lev[0].res_img_stride = a.lev[0].dst_img_stride; }
   if (relu_mask) { a.flags |= F_MASK; a.lev[0].mask = relu_mask; }
+  if (g_conv_reverse) a.flags |= F_REVERSE;
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 
@@ -1323,6 +1327,12 @@ extern "C" int sod_conv_prof_collect(float* ms, int* variant, float* frac, int* 
   }
   p.n.store(0);
   return n;
+}
+
+// the single-level forward / data-gradient launches that follow walk their tiles last to first (see F_REVERSE)
+extern "C" int sod_conv_set_reverse(int on) {
+  g_conv_reverse = on ? 1 : 0;
+  return SOD_OK;
 }
 
 extern "C" int sod_conv_set_tile256(int mode) {

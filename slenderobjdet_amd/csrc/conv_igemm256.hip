@@ -66,7 +66,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+  uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+  if (a.flags & F_REVERSE) bid = gridDim.x - 1 - bid;
   const int qt = bid % a.nq_tiles;
   int pt = bid / a.nq_tiles;
   int lv = 0;
@@ -305,12 +306,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
           for (int e = 0; e < EPL; ++e) v[e] = ((float)maskv[k][e] > 0.f) ? v[e] : 0.f;
         }
         if constexpr (OUT_F32) {
-          *reinterpret_cast<f32x4_t*>((float*)g.dst + drow[k] + q) = f32x4_t{v[0], v[1], v[2], v[3]};
+          sod_store16((float*)g.dst + drow[k] + q, f32x4_t{v[0], v[1], v[2], v[3]});
         } else {
           bf16x8_t o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
-          *reinterpret_cast<bf16x8_t*>((__bf16*)g.dst + drow[k] + q) = o;
+          sod_store16((__bf16*)g.dst + drow[k] + q, o);
           if constexpr (MODE == MODE_FWD) { if (a.flags & F_GNSTATS) gn_acc_add(ga, nimg[k], o, g.gn_sum, a.gn_G, q >> 3); }
           if constexpr (GNB) gnb_add(gb, nimg[k], maskv[k], o, g.gnb_stats, g.gnb_red, a.gn_G, q >> 3);
         }

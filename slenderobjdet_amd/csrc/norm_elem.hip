@@ -79,16 +79,21 @@ struct GnML {
   int N, C, G, cpg, relu; float eps;
   float* part_grp; float* part_gb; float* part_dx;
   int n0;
+  int rev;     // walk blocks / images last to first (a pass that re-reads what the previous pass just read starts where that one ended)
 };
+
+__device__ __forceinline__ int gn_bx(const GnML& m) { return m.rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x; }
 
 __device__ __forceinline__ int gn_pick(const GnML& m, GnArgs& a) {
   int l = 0;
-  while (l + 1 < m.nlev && (int)blockIdx.x >= m.lev[l + 1].blk0) ++l;
+  const int bxx = gn_bx(m);
+  while (l + 1 < m.nlev && bxx >= m.lev[l + 1].blk0) ++l;
   const GnLevel& L = m.lev[l];
   a.x = L.x; a.dy = L.dy; a.y = L.y; a.dx = L.dx; a.stats = L.stats; a.red = L.red; a.img_stride = L.img_stride; a.HW = L.HW;
   a.pix_per_block = L.pix_per_block;
   a.gamma = m.gamma; a.beta = m.beta; a.dgamma = m.dgamma; a.dbeta = m.dbeta; a.dxsum = m.dxsum;
-  a.N = m.N; a.C = m.C; a.G = m.G; a.cpg = m.cpg; a.relu = m.relu; a.eps = m.eps; a.n0 = m.n0;
+  a.N = m.N; a.C = m.C; a.G = m.G; a.cpg = m.cpg; a.relu = m.relu; a.eps = m.eps;
+  a.n0 = m.rev ? m.n0 + (int)gridDim.y - 1 - 2 * (int)blockIdx.y : m.n0;      // n = blockIdx.y + a.n0  ->  n0 + gridDim.y - 1 - blockIdx.y
   a.part_grp = m.part_grp; a.part_gb = m.part_gb; a.part_dx = m.part_dx;
   return l;
 }
@@ -130,7 +135,7 @@ __device__ __forceinline__ void gn_apply_body(const GnArgs& a, const int bx) {
       if (a.relu) f = fmaxf(f, 0.f);
       o[e] = (__bf16)f;
     }
-    *reinterpret_cast<bf16x8_t*>(a.y + base + (long long)p * a.C) = o;
+    sod_store16(a.y + base + (long long)p * a.C, o);
   }
 }
 
@@ -223,7 +228,7 @@ __device__ __forceinline__ void gn_bwd_apply_body(const GnArgs& a, const int bx,
       o[e] = (__bf16)(rstd * (d * gm[e] - m1 - xh * m2));
       sx[e] += (float)o[e];       // the bias gradient is the sum of what the conv's wgrad/dgrad see (the stored bf16 values)
     }
-    *reinterpret_cast<bf16x8_t*>(a.dx + base + (long long)p * a.C) = o;
+    sod_store16(a.dx + base + (long long)p * a.C, o);
   }
   if (a.dxsum) {
 #pragma unroll
@@ -277,22 +282,22 @@ __global__ __launch_bounds__(256) void col_accumulate_kernel(const float* __rest
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnML m) {
   GnArgs a;
   const int l = gn_pick(m, a);
-  gn_stats_body(a, (int)blockIdx.x - m.lev[l].blk0);
+  gn_stats_body(a, gn_bx(m) - m.lev[l].blk0);
 }
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnML m) {
   GnArgs a;
   const int l = gn_pick(m, a);
-  gn_apply_body(a, (int)blockIdx.x - m.lev[l].blk0);
+  gn_apply_body(a, gn_bx(m) - m.lev[l].blk0);
 }
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnML m) {
   GnArgs a;
   const int l = gn_pick(m, a);
-  gn_bwd_reduce_body(a, (int)blockIdx.x - m.lev[l].blk0);
+  gn_bwd_reduce_body(a, gn_bx(m) - m.lev[l].blk0);
 }
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnML m) {
   GnArgs a;
   const int l = gn_pick(m, a);
-  gn_bwd_apply_body(a, (int)blockIdx.x - m.lev[l].blk0, m.lev[l].inv_m);
+  gn_bwd_apply_body(a, gn_bx(m) - m.lev[l].blk0, m.lev[l].inv_m);
 }
 
 // ------------------------------------------------------------------ elementwise (8 x bf16 per lane)
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const __bf16* __restrict_
     bf16x8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = ((float)v[e] > 0.f) ? g[e] : (__bf16)0.f;
-    reinterpret_cast<bf16x8_t*>(dx)[i] = o;
+    sod_store16(reinterpret_cast<bf16x8_t*>(dx) + i, o);
   }
 }
 
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(256) void relu_fwd_kernel(const __bf16* __restrict_
     bf16x8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = ((float)v[e] > 0.f) ? v[e] : (__bf16)0.f;
-    reinterpret_cast<bf16x8_t*>(y)[i] = o;
+    sod_store16(reinterpret_cast<bf16x8_t*>(y) + i, o);
   }
 }
 
@@ -769,6 +774,16 @@ int gn_grid(int HW, int N, int& ppb) {
 
 }  // namespace
 
+// SOD_GN_REVERSE bit mask: 1 = the forward apply pass, 2 = the backward reduce pass, 4 = the backward apply pass walk their blocks and
+// images last to first.  The pass then starts on the part of the tensor its predecessor touched last (what the 256 MB Infinity Cache
+// still holds): the backward reduce follows the data gradient that wrote dy, the backward apply follows the reduce pass over the same two
+// tensors.  Measured on the FCOS R50 step (one gpurun call, 60 timed steps): mask 0 629.6 / 630.2 img/s, 4: 631.7, 6: 632.3, 5: 631.0,
+// 7: 631.7 - default 6.  Results do not depend on the order (float atomics aside; deterministic mode keeps its own fixed order).
+static int gn_reverse_mask() {
+  static const int v = getenv("SOD_GN_REVERSE") ? atoi(getenv("SOD_GN_REVERSE")) : 6;
+  return v;
+}
+
 static int gn_fill(GnML& m, int nlev, const int* hw, int N, int C, int G, float eps, int relu, const long long* img_strides, int grid_n = 0) {
   if (nlev <= 0 || nlev > GN_MAX_LEVELS || !hw) return SOD_EARG;
   m.nlev = nlev; m.N = N; m.C = C; m.G = G; m.cpg = C / G; m.relu = relu; m.eps = eps;
@@ -842,6 +857,7 @@ extern "C" int sod_groupnorm_apply_ml(int nlev, const void* const* x, const floa
   }
   hipStream_t st = (hipStream_t)stream;
   SOD_LAUNCH(gn_finalize_stats_kernel, dim3((N * G + 255) / 256, nlev), dim3(256), 0, st, m);
+  m.rev = gn_reverse_mask() & 1;
   SOD_LAUNCH(gn_apply_kernel, dim3(gx, N), dim3(256), 0, st, m);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
@@ -907,7 +923,9 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
   for (int n0 = 0; n0 < N; n0 += cn) {
     const int nn = (N - n0 < cn) ? N - n0 : cn;
     m.n0 = n0;
+    m.rev = (gn_reverse_mask() >> 1) & 1;
     SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, nn), dim3(256), sizeof(float) * 18 * 256, st, m);
+    m.rev = (gn_reverse_mask() >> 2) & 1;
     SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, nn), dim3(256), dxsum ? sizeof(float) * 8 * 256 : 0, st, m);
   }
   SOD_CHECK_LAUNCH();

@@ -141,8 +141,8 @@ class _BottleneckStageFn(torch.autograd.Function):
                 if m is not None:
                     m.prepare()
             xin = saved[-1] if len(saved) == 1 else saved[-1]
-            sc = _conv(blk.shortcut, xin) if blk.shortcut is not None else xin
-            a = _conv(blk.conv1, xin)
+            sc = _conv(blk.shortcut, xin, reverse=True) if blk.shortcut is not None else xin
+            a = _conv(blk.conv1, xin, reverse=blk.shortcut is None)
             b = _conv(blk.conv2, a)
             c3 = blk.conv3
             if need_bwd and RELU_BITS and not HF.is_f32() and c3.relu and c3.out_channels % 8 == 0:
@@ -215,7 +215,7 @@ class _BottleneckStageFn(torch.autograd.Function):
             xin, a, b = saved[3 * k], saved[3 * k + 1], saved[3 * k + 2]
             xin = saved[0] if k == 0 else saved[3 * k]        # block input = previous block's output
             _wgrad(blk.conv3, g, b, arena)
-            db = _dgrad(blk.conv3, g, b, relu_mask=b)
+            db = _dgrad(blk.conv3, g, b, relu_mask=b, reverse=True)
             _wgrad(blk.conv2, db, a, arena)
             da = _dgrad(blk.conv2, db, a, relu_mask=a)
             _wgrad(blk.conv1, da, xin, arena)
@@ -240,7 +240,19 @@ class _BottleneckStageFn(torch.autograd.Function):
         return dx, None, None
 
 
-def _conv(m, x, res=None):
+# The convolutions that read the wide block tensor right after it was written (forward: shortcut / conv1; backward: conv3's data gradient)
+# walk their tiles last to first, i.e. start on the part of the tensor the 256 MB Infinity Cache still holds (sod_conv_set_reverse).
+# Same results; measured 621.8 / 623.1 -> 624.8 / 624.6 img/s (A/B in one gpurun call).  SOD_CONV_REVERSE=0 restores first-to-last.
+CONV_REVERSE = os.environ.get("SOD_CONV_REVERSE", "1") != "0"
+
+
+def _conv(m, x, res=None, reverse=False):
+    if reverse and CONV_REVERSE:
+        HF.call("sod_conv_set_reverse", 1)
+        try:
+            return HF.conv2d_fwd(x, m.w_bf16, m.bias_eff, res, m.stride, m.padding, m.dilation, relu=m.relu)
+        finally:
+            HF.call("sod_conv_set_reverse", 0)
     return HF.conv2d_fwd(x, m.w_bf16, m.bias_eff, res, m.stride, m.padding, m.dilation, relu=m.relu)
 
 
@@ -252,7 +264,14 @@ def _wgrad(m, g, x, arena):
         arena.mark_ready(m.weight)
 
 
-def _dgrad(m, g, x, accum=None, relu_mask=None, relu_bits=None):
+def _dgrad(m, g, x, accum=None, relu_mask=None, relu_bits=None, reverse=False):
+    if reverse and CONV_REVERSE:
+        HF.call("sod_conv_set_reverse", 1)
+        try:
+            return HF.conv2d_dgrad(g, m.wt_bf16, (x.shape[1], x.shape[2]), m.stride, m.padding, m.dilation, accum=accum, relu_mask=relu_mask,
+                                   relu_bits=relu_bits)
+        finally:
+            HF.call("sod_conv_set_reverse", 0)
     return HF.conv2d_dgrad(g, m.wt_bf16, (x.shape[1], x.shape[2]), m.stride, m.padding, m.dilation, accum=accum, relu_mask=relu_mask,
                            relu_bits=relu_bits)
 
