@@ -547,6 +547,17 @@ int sod_corner_pool_fwd(const float* x, float* y, long long planes, int H, int W
 int sod_corner_pool_bwd(const float* x, const float* dy, float* dx, long long planes, int H, int W, int mode, int tie_latest,
                         void* stream);
 
+/* detectron2.modeling.sampling.subsample_labels for a whole batch on the device (RPN.label_and_sample_anchors,
+ * slender_det/modeling/proposal_generator/rpn.py:137-191; ROIHeads.label_and_sample_proposals behind roi_heads/roi_heads.py:30-66): per
+ * image, up to int(num_samples * positive_fraction) positives (label != -1 and != bg_label) and the remaining quota of negatives
+ * (label == bg_label), each a uniform random subset (keys from splitmix64(seed, image, kind, index); radix select of the k-th smallest).
+ * labels / out: (N, R) int8; out = 1 sampled positive, 0 sampled negative, -1 otherwise; counts: (N, 2) int32 = drawn positives /
+ * negatives.  No host synchronisation (the reference: two nonzero() + two randperm() per image). */
+int sod_sample_labels(const signed char* labels, int N, int R, int num_samples, float positive_fraction, int bg_label,
+                      unsigned long long seed, signed char* out, int* counts, void* stream);
+/* indices of the sampled elements (mask == 1 first, then mask == 0, each in index order) into S slots per image, -1 padded; num (N) */
+int sod_compact_samples(const signed char* mask, int N, int R, int S, int* idx, int* num, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------------------
  * fp32-STORAGE validation path (csrc/f32_path.hip; Python: SOD_PRECISION=fp32 / layers.functional.set_precision("fp32")).
  * The operators of the training step with fp32 activations, weight copies and gradients and fp32 FMA accumulation, untuned: the

@@ -140,6 +140,8 @@ _SIGS = {
     "sod_weight_prep_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "sod_fcos_regctr_loss_bwd_f32": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F,
                                      _P, _I, _I, _P, _I, _I, _P, _P, _P],
+    "sod_sample_labels": [_P, _I, _I, _I, _F, _I, ctypes.c_ulonglong, _P, _P, _P],
+    "sod_compact_samples": [_P, _I, _I, _I, _P, _P, _P],
     "sod_reduce_workspace_bytes": [],
     "sod_version": [],
 }

@@ -240,6 +240,123 @@ inline bool fill_w(W5& w, const float* weights, int D) {
 
 }  // namespace
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// detectron2.modeling.sampling.subsample_labels for a whole batch, on the device (the reference reaches it through RPN
+// label_and_sample_anchors, proposal_generator/rpn.py:137-191, and ROIHeads.label_and_sample_proposals): per image, up to
+// int(num_samples * positive_fraction) POSITIVES (label != -1 and != bg) and the remaining quota of NEGATIVES (label == bg), each drawn
+// uniformly without replacement.  The reference does this with two nonzero() + two randperm() per image (four host syncs per image);
+// here one workgroup per (image, kind) gives every candidate a 64-bit key = (splitmix64(seed, image, kind, index) high word, index) -
+// unique, so "the k smallest keys" is a uniform k-subset - and finds the k-th smallest key by an 8-pass radix select over LDS histograms.
+// out[i] = 1 sampled positive, 0 sampled negative, -1 everything else; counts[n] = {positives, negatives} drawn.
+__device__ __forceinline__ unsigned long long sample_key(unsigned long long seed, int n, int kind, uint32_t i) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * n + kind + 1) + (unsigned long long)i * 0xD6E8FEB86659FD93ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (z & 0xFFFFFFFF00000000ull) | i;
+}
+
+__global__ __launch_bounds__(1024) void sample_labels_kernel(const signed char* __restrict__ lab, int R, int num_samples, int max_pos, int bg,
+                                                            unsigned long long seed, signed char* __restrict__ out, int* __restrict__ counts) {
+  __shared__ int hist[256];
+  __shared__ int red[32];
+  __shared__ int s_bin, s_k;
+  const int n = blockIdx.x, kind = blockIdx.y, tid = threadIdx.x;
+  const signed char* L = lab + (long long)n * R;
+  signed char* O = out + (long long)n * R;
+  // members of both kinds (the negatives' quota depends on how many positives exist)
+  int cp = 0, cn = 0;
+  for (int i = tid; i < R; i += 1024) {
+    const int v = L[i];
+    cp += (v != -1 && v != bg);
+    cn += (v == bg);
+  }
+  for (int o = 32; o > 0; o >>= 1) { cp += __shfl_xor(cp, o, 64); cn += __shfl_xor(cn, o, 64); }
+  if ((tid & 63) == 0) { red[tid >> 6] = cp; red[16 + (tid >> 6)] = cn; }
+  __syncthreads();
+  cp = 0; cn = 0;
+  for (int w = 0; w < 16; ++w) { cp += red[w]; cn += red[16 + w]; }
+  const int num_pos = cp < max_pos ? cp : max_pos;
+  int num_neg = num_samples - num_pos;
+  if (num_neg > cn) num_neg = cn;
+  const int members = kind == 0 ? cp : cn;
+  const int k = kind == 0 ? num_pos : num_neg;
+  if (tid == 0) counts[2 * n + kind] = k;
+  // radix select of the k-th smallest key among this kind's members (k < members; otherwise every member is taken)
+  unsigned long long prefix = 0, T = ~0ull;
+  if (k < members && k > 0) {
+    int kk = k;      // rank (1-based) still to find inside the current prefix
+    for (int pass = 7; pass >= 0; --pass) {
+      for (int b = tid; b < 256; b += 1024) hist[b] = 0;
+      __syncthreads();
+      const int shift = pass * 8;
+      for (int i = tid; i < R; i += 1024) {
+        const int v = L[i];
+        const bool mem = kind == 0 ? (v != -1 && v != bg) : (v == bg);
+        if (!mem) continue;
+        const unsigned long long key = sample_key(seed, n, kind, (uint32_t)i);
+        if (pass == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int acc = 0, b = 0;
+        for (; b < 256; ++b) {
+          if (acc + hist[b] >= kk) break;
+          acc += hist[b];
+        }
+        s_bin = b; s_k = kk - acc;
+      }
+      __syncthreads();
+      prefix |= (unsigned long long)s_bin << shift;
+      kk = s_k;
+      __syncthreads();
+    }
+    T = prefix;        // the k-th smallest key itself (keys are unique)
+  }
+  for (int i = tid; i < R; i += 1024) {
+    const int v = L[i];
+    const bool pos = (v != -1 && v != bg), neg = (v == bg);
+    if (kind == 0) {
+      if (!neg) O[i] = (pos && k > 0 && sample_key(seed, n, 0, (uint32_t)i) <= T) ? 1 : -1;     // positives and "other" elements
+    } else if (neg) {
+      O[i] = (k > 0 && sample_key(seed, n, 1, (uint32_t)i) <= T) ? 0 : -1;
+    }
+  }
+}
+
+// Indices of the sampled elements of every image, positives (mask == 1) first, then negatives (mask == 0), each in index order, into S
+// slots per image (-1 padded); num[n] = how many.  One workgroup per image, ordered compaction by a block-wide scan over contiguous chunks.
+__global__ __launch_bounds__(1024) void compact_samples_kernel(const signed char* __restrict__ mask, int R, int S, int* __restrict__ idx,
+                                                              int* __restrict__ num) {
+  __shared__ int sc[1024];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const signed char* M = mask + (long long)n * R;
+  int* I = idx + (long long)n * S;
+  for (int i = tid; i < S; i += 1024) I[i] = -1;
+  const int chunk = (R + 1023) / 1024, lo = tid * chunk, hi = (lo + chunk < R) ? lo + chunk : R;
+  int base = 0;
+  for (int want = 1; want >= 0; --want) {
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += (M[i] == want);
+    sc[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {            // inclusive Hillis-Steele scan
+      const int v = tid >= o ? sc[tid - o] : 0;
+      __syncthreads();
+      sc[tid] += v;
+      __syncthreads();
+    }
+    int pos = base + sc[tid] - c;
+    const int total = sc[1023];
+    __syncthreads();
+    for (int i = lo; i < hi; ++i)
+      if (M[i] == want) { if (pos < S) I[pos] = i; ++pos; }
+    base += total;
+  }
+  if (tid == 0) num[n] = base < S ? base : S;
+}
+
 extern "C" int sod_box2box_get_deltas(const float* src, const float* tgt, long long n, int box_dim, const float* weights, float* deltas,
                                       void* stream) {
   W5 w{};
@@ -357,6 +474,23 @@ extern "C" int sod_fastrcnn_box_loss_bwd(const float* pred, const int* gt_classe
   if (R == 0) return SOD_OK;
   SOD_LAUNCH(frcnn_box_kernel<true>, dim3(rc_nblk((long long)R * ld, 4096)), dim3(256), 0, (hipStream_t)stream, pred, gt_classes, gt_deltas, R, K,
              box_dim, ld, beta, nullptr, grad_scale, scale_mul, dpred);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_sample_labels(const signed char* labels, int N, int R, int num_samples, float positive_fraction, int bg_label,
+                                 unsigned long long seed, signed char* out, int* counts, void* stream) {
+  if (!labels || !out || !counts || N <= 0 || R <= 0 || num_samples <= 0 || !(positive_fraction >= 0.f && positive_fraction <= 1.f)) return SOD_EARG;
+  if (N > 65535) return SOD_ESIZE;
+  const int max_pos = (int)(num_samples * positive_fraction);
+  SOD_LAUNCH(sample_labels_kernel, dim3(N, 2), dim3(1024), 0, (hipStream_t)stream, labels, R, num_samples, max_pos, bg_label, seed, out, counts);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_compact_samples(const signed char* mask, int N, int R, int S, int* idx, int* num, void* stream) {
+  if (!mask || !idx || !num || N <= 0 || R <= 0 || S <= 0) return SOD_EARG;
+  SOD_LAUNCH(compact_samples_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, mask, R, S, idx, num);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -1095,6 +1095,32 @@ def add_up2(a, b):
     return o
 
 
+def sample_labels(labels, num_samples, positive_fraction, bg_label, seed=None):
+    """detectron2 subsample_labels for a batch: labels (N, R) int8 (-1 ignore, bg_label background, anything else positive) ->
+    (out (N, R) int8: 1 sampled positive / 0 sampled negative / -1 rest, counts (N, 2) int32).  ``seed``: drawn from torch's CPU generator
+    when None (so torch.manual_seed reproduces the draw); nothing is read back from the device."""
+    _chk(labels, torch.int8, "labels")
+    N, R = labels.shape
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    out = torch.empty_like(labels)
+    counts = torch.empty((N, 2), dtype=torch.int32, device=labels.device)
+    call("sod_sample_labels", ptr(labels), N, R, int(num_samples), float(positive_fraction), int(bg_label), ctypes.c_ulonglong(seed), ptr(out), ptr(counts),
+         stream_ptr())
+    return out, counts
+
+
+def compact_samples(mask, slots):
+    """Indices of the sampled elements of each row of ``mask`` (N, R) int8 - 1s first, then 0s, index order - as (N, slots) int32 padded
+    with -1, and their number (N,) int32."""
+    _chk(mask, torch.int8, "mask")
+    N, R = mask.shape
+    idx = torch.empty((N, slots), dtype=torch.int32, device=mask.device)
+    num = torch.empty(N, dtype=torch.int32, device=mask.device)
+    call("sod_compact_samples", ptr(mask), N, R, int(slots), ptr(idx), ptr(num), stream_ptr())
+    return idx, num
+
+
 # ----------------------------------------------------------------------------------------------- RepPoints
 def reppoints_dcn_offset(pts, num_points, scale=1.0, subtract_base=True, flip_xy=True):
     """pts (..., ld) fp32 point rows (x, y interleaved) -> deformable-conv offsets (dy, dx interleaved) minus the kernel grid."""

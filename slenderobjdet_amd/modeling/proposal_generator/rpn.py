@@ -151,18 +151,16 @@ class RPN(nn.Module):
         R = anchors.shape[0]
         N = len(gt_instances)
         dev = anchors.device
-        labels = torch.empty((N, R), dtype=torch.int8, device=dev)
+        mlabs = torch.empty((N, R), dtype=torch.int8, device=dev)
         matched = torch.zeros((N, R, self.box_dim), dtype=torch.float32, device=dev)
         for i, g in enumerate(gt_instances):
             boxes = g.gt_boxes.tensor.float().contiguous()
             _, matches, mlab = HF.anchor_match(boxes, anchors, self.iou_thresholds, self.iou_labels, True)
-            pos, neg = subsample_labels(mlab, self.batch_size_per_image, self.positive_fraction, 0)
-            lab = labels[i]
-            lab.fill_(-1)
-            lab[pos] = 1
-            lab[neg] = 0
+            mlabs[i] = mlab
             if len(boxes):
                 matched[i] = boxes[matches.long()]
+        # the random subsample of the whole batch in one launch, nothing read back (detectron2: nonzero + randperm per image)
+        labels, _ = HF.sample_labels(mlabs, self.batch_size_per_image, self.positive_fraction, 0)
         return labels, matched
 
     @torch.no_grad()
@@ -258,7 +256,7 @@ class RPNWNM(RPN):
         from ...structures import pairwise_iou
 
         R, N, dev = anchors.shape[0], len(gt_instances), anchors.device
-        labels = torch.empty((N, R), dtype=torch.int8, device=dev)
+        mlabs = torch.empty((N, R), dtype=torch.int8, device=dev)
         matched = torch.zeros((N, R, self.box_dim), dtype=torch.float32, device=dev)
         for i, g in enumerate(gt_instances):
             boxes = g.gt_boxes.tensor.float().contiguous()
@@ -266,13 +264,10 @@ class RPNWNM(RPN):
             if len(boxes):      # top-k anchors of every gt (rows of the G x R IoU matrix; G is small)
                 q = pairwise_iou(Boxes(boxes), Boxes(anchors))
                 mlab[q.topk(k=self.matcher_topk, dim=1)[1].reshape(-1)] = 1
-            pos, neg = subsample_labels(mlab, self.batch_size_per_image, self.positive_fraction, 0)
-            lab = labels[i]
-            lab.fill_(-1)
-            lab[pos] = 1
-            lab[neg] = 0
+            mlabs[i] = mlab
             if len(boxes):
                 matched[i] = boxes[matches.long()]
+        labels, _ = HF.sample_labels(mlabs, self.batch_size_per_image, self.positive_fraction, 0)
         return labels, matched
 
 

@@ -22,7 +22,6 @@ from ...layers.nn import HipConv2d
 from ...structures import Boxes, Instances, RotatedBoxes
 from ...utils.registry import Registry
 from ..box_regression import Box2BoxTransform, Box2BoxTransformRotated
-from ..proposal_generator.rpn import subsample_labels
 
 ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
 ROI_BOX_HEAD_REGISTRY = Registry("ROI_BOX_HEAD")
@@ -273,9 +272,13 @@ class StandardROIHeads(nn.Module):
 
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals, targets):
+        """detectron2 ROIHeads.label_and_sample_proposals: append the ground truth, match, label, draw batch_size_per_image samples with
+        positive_fraction foreground.  Matching runs per image (its size differs); the random draw of the WHOLE batch is one launch
+        (sod_sample_labels + sod_compact_samples) and ONE host read (how many samples every image got) instead of two nonzero() and two
+        randperm() per image."""
         BoxT = self._box_type()
-        out, sampled_rec = [], []
         gt_logit = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
+        per_image = []
         for prop, tgt in zip(proposals, targets):
             boxes, logits = prop.proposal_boxes.tensor, prop.objectness_logits
             gtb = tgt.gt_boxes.tensor.float()
@@ -292,8 +295,21 @@ class StandardROIHeads(nn.Module):
                 gt_classes[mlab == -1] = -1
             else:
                 gt_classes = torch.zeros_like(matches) + self.num_classes
-            fg, bg = subsample_labels(gt_classes, self.batch_size_per_image, self.positive_fraction, self.num_classes)
-            idx = torch.cat([fg, bg], dim=0)
+            per_image.append((prop, boxes, logits, gtb, matches, gt_classes))
+        N = len(per_image)
+        dev = per_image[0][1].device
+        if self.num_classes > 126:
+            raise NotImplementedError("label sampling packs class indices into int8")
+        R = max(1, max(len(p[1]) for p in per_image))
+        cls8 = torch.full((N, R), -1, dtype=torch.int8, device=dev)
+        for i, p in enumerate(per_image):
+            cls8[i, : len(p[1])] = p[5].to(torch.int8)
+        mask, _ = HF.sample_labels(cls8, self.batch_size_per_image, self.positive_fraction, self.num_classes)
+        idx_all, num = HF.compact_samples(mask, self.batch_size_per_image)
+        num = num.cpu()                      # the one host read: Instances have a host-side length
+        out, sampled_rec = [], []
+        for i, (prop, boxes, logits, gtb, matches, gt_classes) in enumerate(per_image):
+            idx = idx_all[i, : int(num[i])].long()
             res = Instances(prop.image_size)
             res.proposal_boxes = BoxT(boxes[idx])
             res.objectness_logits = logits[idx]

@@ -147,6 +147,54 @@ def _step(model, opt, data):
     return total.detach()
 
 
+def test_device_label_sampling_contract(cuda):
+    """sod_sample_labels / sod_compact_samples against the contract of detectron2's subsample_labels (RPN.label_and_sample_anchors,
+    proposal_generator/rpn.py:137-191; ROIHeads.label_and_sample_proposals): per image min(#pos, int(S * f)) positives and
+    min(#neg, S - that) negatives, drawn from the right pools, reproducible for a seed, different for another, uniform over the pool
+    (every positive of a pool of 40 drawn 10 at a time is picked 25 % +- 8 % of 600 draws; sigma = 1.8 %), and compacted positives-first in index order."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    g = torch.Generator().manual_seed(4)
+    N, R, S, f, bg = 3, 5000, 256, 0.5, 0
+    lab = torch.full((N, R), -1, dtype=torch.int8)
+    lab[0, torch.randperm(R, generator=g)[:900]] = 1              # plenty of both
+    lab[0, (lab[0] == -1).nonzero().squeeze(1)[:3000]] = 0
+    lab[1, torch.randperm(R, generator=g)[:17]] = 1                # few positives: negatives fill up
+    lab[1, (lab[1] == -1).nonzero().squeeze(1)[:4000]] = 0
+    lab[2, :60] = 1                                                # few negatives: fewer than S samples in all
+    lab[2, 100:130] = 0
+    d = lab.to(cuda)
+    out, counts = HF.sample_labels(d, S, f, bg, seed=123)
+    out2, _ = HF.sample_labels(d, S, f, bg, seed=123)
+    out3, _ = HF.sample_labels(d, S, f, bg, seed=124)
+    assert torch.equal(out, out2) and not torch.equal(out, out3)
+    o, c = out.cpu(), counts.cpu()
+    for n in range(N):
+        P, Q = int((lab[n] == 1).sum()), int((lab[n] == 0).sum())
+        npos = min(P, int(S * f)); nneg = min(Q, S - npos)
+        assert c[n].tolist() == [npos, nneg], (n, c[n], npos, nneg)
+        assert int((o[n] == 1).sum()) == npos and int((o[n] == 0).sum()) == nneg
+        assert (lab[n][o[n] == 1] == 1).all() and (lab[n][o[n] == 0] == 0).all()
+    idx, num = HF.compact_samples(out, S)
+    idx, num = idx.cpu(), num.cpu()
+    for n in range(N):
+        k = int(num[n])
+        want = torch.cat(((o[n] == 1).nonzero().squeeze(1), (o[n] == 0).nonzero().squeeze(1)))
+        assert k == len(want) and torch.equal(idx[n, :k].long(), want) and (idx[n, k:] == -1).all()
+    # uniformity
+    small = torch.full((1, 300), -1, dtype=torch.int8)
+    small[0, 7:47] = 5                                             # any label but -1 / bg is a positive (ROI heads pass class indices)
+    small[0, 100:300] = 80
+    hits = torch.zeros(300)
+    sd = small.to(cuda)
+    for seed in range(600):
+        m, cc = HF.sample_labels(sd, 20, 0.5, 80, seed=1000 + seed)
+        hits += (m.cpu()[0] == 1).float()
+    assert float(hits[7:47].sum()) == 600 * 10 and float(hits[:7].sum() + hits[47:].sum()) == 0
+    freq = hits[7:47] / 600
+    assert float((freq - 0.25).abs().max()) < 0.08, freq
+
+
 @pytest.mark.parametrize("rotated", [True, False])
 def test_rcnn_training_step_vs_oracle(cuda, rotated):
     from oracle import rcnn as orc
