@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
   static_assert(BP % RPP == 0, "tile rows");
   constexpr bool WFULL = (BQ % RPP == 0);     // every wave stages weight rows in every pass: no wave-dependent branch in the K loop
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  static_assert(NSTAGE == 2 || NSTAGE == 3, "LDS ring depth");
+  static_assert(NSTAGE >= 2 && NSTAGE <= 6, "LDS ring depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -280,22 +280,33 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
       compute(smem + (t & 1) * STAGE);
     }
   } else {
-    // 3-deep LDS ring: the tile for step t+2 is requested while step t is computed, so a load has two full steps (~2 k
-    // cycles) to land instead of one.  Counted vmcnt keeps the youngest stage in flight across the (raw) barrier; every
-    // thread issues exactly LPS LDS-DMA loads per stage.
+    // NSTAGE-deep LDS ring: the tiles for steps t+1 .. t+NSTAGE-1 are in flight while step t is computed, so a load has NSTAGE-1 full
+    // steps to land instead of one (a 32-deep K-step is 256 cycles of MFMA per wave against ~2 k cycles of memory latency: with one
+    // step of prefetch every K-step of a short-K 1x1 convolution waited for its operands).  Counted vmcnt keeps the younger stages in
+    // flight across the (raw) barrier; every thread issues exactly LPS LDS-DMA loads per stage.
     constexpr int LPS = BQ / RPP + XI;
+    constexpr int AHEAD = NSTAGE - 1;
     static_assert(WFULL, "counted vmcnt needs a fixed number of loads per stage");
-    stage(0, smem);
-    if (a.T > 1) stage(1, smem + STAGE);
+    static_assert((AHEAD - 1) * LPS <= 63, "vmcnt range");
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s)
+      if (s < a.T) stage(s, smem + s * STAGE);
     int slot = 0;
     for (int t = 0; t < a.T; ++t) {
-      if (t + 1 < a.T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int younger = a.T - 1 - t;                 // stages requested after tile t: they may stay in flight
+      if (younger > AHEAD - 1) younger = AHEAD - 1;
+      switch (younger) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPS) : "memory"); break;
+      }
       __builtin_amdgcn_s_barrier();   // tile t has landed for every wave; every wave has finished computing tile t-1
-      int nslot = slot + 2; if (nslot >= 3) nslot -= 3;
-      if (t + 2 < a.T) stage(t + 2, smem + nslot * STAGE);   // overwrites the buffer of tile t-1
+      int nslot = slot + AHEAD; if (nslot >= NSTAGE) nslot -= NSTAGE;
+      if (t + AHEAD < a.T) stage(t + AHEAD, smem + nslot * STAGE);   // overwrites the buffer of tile t-1
       compute(smem + slot * STAGE);
-      slot = (slot == 2) ? 0 : slot + 1;
+      slot = (slot == NSTAGE - 1) ? 0 : slot + 1;
     }
   }
 
@@ -947,6 +958,16 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   if (MODE == MODE_DGRAD && dgrad_bk == 32) use32 = !generic && (a.Cred & 31) == 0;
   if (force_bk == 32) use32 = !generic && (a.Cred & 31) == 0;
   if (force_bk == 64) use32 = false;
+  // SOD_CONV_RING=3|4|5 (EXPERIMENT): deeper LDS ring for the 32-deep K-steps of the short-K convolutions (bf16 outputs only)
+  static int ring = -1;
+  if (ring < 0) { const char* e = getenv("SOD_CONV_RING"); ring = e ? atoi(e) : 0; }
+  if constexpr (!OUT_F32) {
+    if (use32 && ring >= 3 && a.T >= 3) {
+      if (ring == 3) return launch_conv<MODE, false, 2, 2, 4, 4, false, 32, 3>(a, st);
+      if (ring == 4) return launch_conv<MODE, false, 2, 2, 4, 4, false, 32, 4>(a, st);
+      return launch_conv<MODE, false, 2, 2, 4, 4, false, 32, 5>(a, st);
+    }
+  }
   if (use32) return launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32, 32>(a, st);
   // EXPERIMENT (off by default, SOD_CONV_T256=1): 128(q) x 256(p) tile, 8 waves, 3-deep LDS ring with counted vmcnt, one
   // workgroup per CU.  Measured SLOWER than two independent 4-wave workgroups per CU with a 2-deep ring on the head shape
