@@ -592,6 +592,12 @@ int sod_preprocess_image_f32(const void* img, int is_uint8, int C, int H, int W,
                              const float* std3, void* stream);
 /* fp32 compute copies of a master weight: KRSC times scale[k] (FrozenBN fold), input channels zero-padded to Cpad; optional CRSK */
 int sod_weight_prep_f32(const float* w, const float* scale, float* w_krsc, float* w_crsk, int K, int RS, int C, int Cpad, void* stream);
+/* sod_retina_box_loss_bwd / sod_retina_giou_loss_bwd with fp32 gradient rows (fp32 validation mode of RetinaNet, retina_rotated.py:185-249) */
+int sod_retina_box_loss_bwd_f32(const float* pred, int pitch, const int* gt_labels, const float* gt_deltas, int N, int R, int A,
+                                int num_classes, float beta, const float* grad_num, const float* grad_den, float* dpred, void* stream);
+int sod_retina_giou_loss_bwd_f32(const float* pred, int pitch, const int* gt_labels, const float* anchors, const float* matched_boxes,
+                                 int N, int R, int A, int num_classes, const float* weights4, float scale_clamp,
+                                 const float* grad_num, const float* grad_den, float* dpred, void* stream);
 /* sod_fcos_regctr_loss_bwd with fp32 gradient rows */
 int sod_fcos_regctr_loss_bwd_f32(const float* box_raw, int ld_box, const float* ctr_logit, int ld_ctr, const int* labels,
                                  const float* reg_targets, const float* ctr_targets, const float* scales, int N, int nlevels, const int* lvl_h,

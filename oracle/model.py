@@ -32,6 +32,18 @@ class _RoundSTE(torch.autograd.Function):
         return g.to(torch.bfloat16).to(torch.float32)
 
 
+class _RoundGrad(torch.autograd.Function):
+    """Identity whose gradient is rounded to bf16: fp32 prediction rows whose GRADIENT rows the product path stores in bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
 class OracleFCOS:
     """Functional model over a dict of fp32 tensors in torch layouts (conv weights KCRS)."""
 
@@ -45,6 +57,18 @@ class OracleFCOS:
     @classmethod
     def from_hip_model(cls, model, emulate_bf16=False):
         """Copy weights out of a slenderobjdet_amd FCOSV2 (any device) into torch-layout CPU tensors."""
+        params, buffers, dcn, groups = cls._collect(model)
+        params["head.scales"] = model.head.scales.detach().float().cpu().clone().requires_grad_(True)
+        cfg_like = cls._backbone_cfg(model, params, dcn, groups)
+        cfg_like.update(
+            num_classes=model.num_classes, strides=list(model.fpn_strides),
+            radius=model.center_sampling_radius, alpha=model.focal_loss_alpha, gamma=model.focal_loss_gamma,
+            iou_type=model.iou_loss_type, norm_reg=model.head.norm_reg_targets, ctr_on_reg=model.head.centerness_on_reg,
+            kc=model.head.kc, num_convs=len(model.head.cls_tower))
+        return cls(params, buffers, cfg_like, emulate_bf16)
+
+    @staticmethod
+    def _collect(model):
         from slenderobjdet_amd.layers.deform_conv import DeformConv
         from slenderobjdet_amd.layers.nn import HipConv2d, HipGroupNorm
 
@@ -72,21 +96,22 @@ class OracleFCOS:
             elif isinstance(m, HipGroupNorm):
                 params[name + ".weight"] = m.weight.detach().float().cpu().clone().requires_grad_(True)
                 params[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(True)
-        params["head.scales"] = model.head.scales.detach().float().cpu().clone().requires_grad_(True)
+        return params, buffers, dcn, groups
+
+    @staticmethod
+    def _backbone_cfg(model, params, dcn, groups):
         res_names = [name for _, name in model.backbone.bottom_up.stages_and_names]
         blocks = {n: len(getattr(model.backbone.bottom_up, n)) for n in res_names}
         bottleneck = any(k.endswith("conv3.weight") for k in params)
-        cfg_like = dict(
-            blocks=blocks, bottleneck=bottleneck, num_classes=model.num_classes, strides=list(model.fpn_strides),
-            radius=model.center_sampling_radius, alpha=model.focal_loss_alpha, gamma=model.focal_loss_gamma,
-            iou_type=model.iou_loss_type, norm_reg=model.head.norm_reg_targets, ctr_on_reg=model.head.centerness_on_reg,
-            kc=model.head.kc, mean=[float(v) for v in model.pixel_mean.flatten()], std=[float(v) for v in model.pixel_std.flatten()],
-            num_convs=len(model.head.cls_tower), size_div=model.backbone.size_divisibility,
+        top = getattr(model.backbone, "top_block", None)
+        return dict(
+            blocks=blocks, bottleneck=bottleneck,
+            mean=[float(v) for v in model.pixel_mean.flatten()], std=[float(v) for v in model.pixel_std.flatten()],
+            size_div=model.backbone.size_divisibility,
             stride_in_1x1={n: [blk.conv1.stride for blk in getattr(model.backbone.bottom_up, n)] for n in res_names},
             block_stride={n: [blk.stride for blk in getattr(model.backbone.bottom_up, n)] for n in res_names},
-            dcn=dcn, groups=groups,
+            dcn=dcn, groups=groups, p6_from=getattr(top, "in_feature", "p5"),
         )
-        return cls(params, buffers, cfg_like, emulate_bf16)
 
     def double(self):
         """The same model in float64 (an arbiter between two fp32 implementations: tests/test_gpu_f32_mode.py).  In place; returns self."""
@@ -166,7 +191,8 @@ class OracleFCOS:
             up = F.interpolate(prev, scale_factor=2, mode="nearest") if prev is not None else None
             prev = self._conv(f"backbone.fpn_lateral{s}", feats[n], 1, 0, res=up)
             outs[f"p{s}"] = self._conv(f"backbone.fpn_output{s}", prev, 1, 1)
-        p6 = self._conv("backbone.top_block.p6", outs["p5"], 2, 1)
+        # LastLevelP6P7 reads P5 (fpn.py:94-115, the FCOS builder) or res5 (detectron2's RetinaNet builder)
+        p6 = self._conv("backbone.top_block.p6", feats["res5"] if self.c.get("p6_from", "p5") == "res5" else outs["p5"], 2, 1)
         p7 = self._conv("backbone.top_block.p7", self._act(torch.relu(p6)), 2, 1)
         outs["p6"], outs["p7"] = p6, p7
         return [outs[k] for k in ("p3", "p4", "p5", "p6", "p7")]
@@ -246,6 +272,66 @@ class OracleFCOS:
                     state[k] = buf
                     d = buf
                 p -= lr * d
+
+
+class OracleRetinaNet(OracleFCOS):
+    """The RetinaNet training step (BASELINE configs[2]; retina_rotated.py:129-295 for axis-aligned boxes, head :390-474) over the same
+    backbone restatement: conv+ReLU subnets without a norm, A*K logits / A*4 deltas per location, anchor labels by IoU matching, focal +
+    smooth-L1 / GIoU loss over the EMA loss normaliser."""
+
+    @classmethod
+    def from_hip_model(cls, model, emulate_bf16=False):
+        params, buffers, dcn, groups = cls._collect(model)
+        cfg_like = cls._backbone_cfg(model, params, dcn, groups)
+        cfg_like.update(
+            num_classes=model.num_classes, strides=list(model.strides), alpha=model.focal_loss_alpha, gamma=model.focal_loss_gamma,
+            beta=model.smooth_l1_loss_beta, box_reg=model.box_reg_loss_type, weights=tuple(model.bbox_reg_weights),
+            thresholds=list(model.iou_thresholds), labels=list(model.iou_labels), sizes=model.anchor_sizes, ratios=model.anchor_ratios,
+            offset=model.anchor_offset, num_anchors=model.head.num_anchors, num_convs=len(model.head.cls_subnet),
+            normalizer=float(model.loss_normalizer), momentum=model.loss_normalizer_momentum)
+        return cls(params, buffers, cfg_like, emulate_bf16)
+
+    def _subnet(self, prefix, x):
+        for i in range(self.c["num_convs"]):
+            x = self._conv(f"{prefix}.{i}.conv", x, 1, 1, relu=True)
+        return x
+
+    def predictions(self, feats):
+        """(N, R, K) logits and (N, R, 4) deltas in detectron2's (level, h, w, anchor) row order (permute_to_N_HWA_K, :150-153)."""
+        c = self.c
+        A, K = c["num_anchors"], c["num_classes"]
+        wc, bc = self.p["head.cls_score.weight"][:A * K], self.p["head.cls_score.bias"][:A * K]
+        wb, bb = self.p["head.bbox_pred.weight"][:A * 4], self.p["head.bbox_pred.bias"][:A * 4]       # the product path pads 36 -> 40 rows
+        if self.emu:
+            wc, wb = _RoundSTE.apply(wc), _RoundSTE.apply(wb)
+        logits, deltas = [], []
+        for f in feats:
+            N = f.shape[0]
+            co = F.conv2d(self._subnet("head.cls_subnet", f), wc, bc, padding=1)
+            bo = F.conv2d(self._subnet("head.bbox_subnet", f), wb, bb, padding=1)
+            if self.emu:        # the focal / box gradient rows are bf16 on the product path (retinanet.py _RetinaLossFn.backward)
+                co, bo = _RoundGrad.apply(co), _RoundGrad.apply(bo)
+            logits.append(co.permute(0, 2, 3, 1).reshape(N, -1, K))
+            deltas.append(bo.permute(0, 2, 3, 1).reshape(N, -1, 4))
+        return torch.cat(logits, 1), torch.cat(deltas, 1)
+
+    def losses(self, batched_inputs, world=1):
+        from . import rcnn as orc
+        from . import retinanet as orn
+
+        c = self.c
+        feats = self._fpn(self._bottom_up(self.preprocess(batched_inputs)))
+        level_hw = [tuple(f.shape[2:]) for f in feats]
+        anchors = torch.cat(orc.anchors(level_hw, c["strides"], c["sizes"], c["ratios"], None, c["offset"]))
+        boxes = [b["instances"].gt_boxes.tensor.float().cpu() for b in batched_inputs]
+        classes = [b["instances"].gt_classes.cpu() for b in batched_inputs]
+        gt_labels, matched = orn.label_anchors(anchors, boxes, classes, c["thresholds"], c["labels"], c["num_classes"])
+        logits, deltas = self.predictions(feats)
+        dt = logits.dtype
+        out, norm = orn.losses(anchors.to(dt), logits, deltas, gt_labels, matched.to(dt), c["num_classes"], c["alpha"], c["gamma"], c["beta"],
+                               c["weights"], c["normalizer"], c["momentum"], box_reg_loss_type=c["box_reg"])
+        self.new_normalizer = norm
+        return out
 
 
 def random_batch_cpu(n, h, w, seed):

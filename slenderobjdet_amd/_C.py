@@ -142,6 +142,8 @@ _SIGS = {
                                      _P, _I, _I, _P, _I, _I, _P, _P, _P],
     "sod_sample_labels": [_P, _I, _I, _I, _F, _I, ctypes.c_ulonglong, _P, _P, _P],
     "sod_compact_samples": [_P, _I, _I, _I, _P, _P, _P],
+    "sod_retina_box_loss_bwd_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
+    "sod_retina_giou_loss_bwd_f32": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P],
     "sod_reduce_workspace_bytes": [],
     "sod_version": [],
 }

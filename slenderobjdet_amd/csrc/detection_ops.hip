@@ -730,9 +730,9 @@ struct RetinaBoxArgs {
   float beta;
 };
 
-template <bool BWD>
+template <bool BWD, typename T = __bf16>      // T: storage type of the delta gradient (bf16 product path, float in the fp32 validation mode)
 __global__ __launch_bounds__(256) void retina_box_kernel(const RetinaBoxArgs a, float* __restrict__ part, const float* __restrict__ gnum,
-                                                         const float* __restrict__ gden, __bf16* __restrict__ dpred) {
+                                                         const float* __restrict__ gden, T* __restrict__ dpred) {
   __shared__ float red[4];
   float acc = 0.f, npos = 0.f;
   const float sc = BWD ? gnum[0] / gden[0] : 0.f;
@@ -758,8 +758,8 @@ __global__ __launch_bounds__(256) void retina_box_kernel(const RetinaBoxArgs a, 
       }
     }
     if (BWD) {
-      bf16x4_t o = {(__bf16)(g[0] * sc), (__bf16)(g[1] * sc), (__bf16)(g[2] * sc), (__bf16)(g[3] * sc)};
-      *reinterpret_cast<bf16x4_t*>(dpred + po) = o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dpred[po + e] = (T)(g[e] * sc);
     }
   }
   if (!BWD) {
@@ -805,9 +805,9 @@ struct RetinaGiouArgs {
   int N, R, A, pitch, num_classes;
   float wx, wy, ww, wh, clampv;
 };
-template <bool BWD>
+template <bool BWD, typename T = __bf16>
 __global__ __launch_bounds__(256) void retina_giou_kernel(const RetinaGiouArgs a, float* __restrict__ part, const float* __restrict__ gnum,
-                                                          const float* __restrict__ gden, __bf16* __restrict__ dpred) {
+                                                          const float* __restrict__ gden, T* __restrict__ dpred) {
   __shared__ float red[4];
   float acc = 0.f, npos = 0.f;
   const float sc = BWD ? gnum[0] / gden[0] : 0.f;
@@ -840,8 +840,8 @@ __global__ __launch_bounds__(256) void retina_giou_kernel(const RetinaGiouArgs a
       }
     }
     if (BWD) {
-      bf16x4_t o = {(__bf16)(gd[0] * sc), (__bf16)(gd[1] * sc), (__bf16)(gd[2] * sc), (__bf16)(gd[3] * sc)};
-      *reinterpret_cast<bf16x4_t*>(dpred + po) = o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dpred[po + e] = (T)(gd[e] * sc);
     }
   }
   if (!BWD) {
@@ -1028,7 +1028,7 @@ extern "C" int sod_retina_box_loss_fwd(const float* pred, int pitch, const int* 
   RetinaBoxArgs a{pred, gt_labels, gt_deltas, N, R, A, pitch, num_classes, beta};
   hipStream_t st = (hipStream_t)stream;
   const int g = nblk((long long)N * R);
-  SOD_LAUNCH(retina_box_kernel<false>, dim3(g), dim3(256), 0, st, a, ws, nullptr, nullptr, nullptr);
+  SOD_LAUNCH((retina_box_kernel<false, __bf16>), dim3(g), dim3(256), 0, st, a, ws, nullptr, nullptr, nullptr);
   SOD_LAUNCH(retina_finish_kernel, dim3(1), dim3(256), 0, st, ws, g, sums2, normalizer, momentum);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
@@ -1050,7 +1050,7 @@ extern "C" int sod_retina_giou_loss_fwd(const float* pred, int pitch, const int*
   if (rc || !sums2 || !ws) return rc ? rc : SOD_EARG;
   hipStream_t st = (hipStream_t)stream;
   const int g = nblk((long long)N * R);
-  SOD_LAUNCH(retina_giou_kernel<false>, dim3(g), dim3(256), 0, st, a, ws, nullptr, nullptr, nullptr);
+  SOD_LAUNCH((retina_giou_kernel<false, __bf16>), dim3(g), dim3(256), 0, st, a, ws, nullptr, nullptr, nullptr);
   SOD_LAUNCH(retina_finish_kernel, dim3(1), dim3(256), 0, st, ws, g, sums2, normalizer, momentum);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
@@ -1062,7 +1062,7 @@ extern "C" int sod_retina_giou_loss_bwd(const float* pred, int pitch, const int*
   RetinaGiouArgs a{};
   int rc = retina_giou_fill(a, pred, pitch, gt_labels, anchors, matched_boxes, N, R, A, num_classes, weights4, scale_clamp);
   if (rc || !grad_num || !grad_den || !dpred_bf16) return rc ? rc : SOD_EARG;
-  SOD_LAUNCH(retina_giou_kernel<true>, dim3(nblk((long long)N * R, 4096)), dim3(256), 0, (hipStream_t)stream, a, nullptr, grad_num, grad_den,
+  SOD_LAUNCH((retina_giou_kernel<true, __bf16>), dim3(nblk((long long)N * R, 4096)), dim3(256), 0, (hipStream_t)stream, a, nullptr, grad_num, grad_den,
              (__bf16*)dpred_bf16);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
@@ -1072,7 +1072,27 @@ extern "C" int sod_retina_box_loss_bwd(const float* pred, int pitch, const int* 
                                        int num_classes, float beta, const float* grad_num, const float* grad_den, void* dpred_bf16, void* stream) {
   if (!pred || !gt_labels || !gt_deltas || !grad_num || !grad_den || !dpred_bf16 || N <= 0 || R <= 0 || A <= 0 || R % A || pitch < A * 4) return SOD_EARG;
   RetinaBoxArgs a{pred, gt_labels, gt_deltas, N, R, A, pitch, num_classes, beta};
-  SOD_LAUNCH(retina_box_kernel<true>, dim3(nblk((long long)N * R, 4096)), dim3(256), 0, (hipStream_t)stream, a, nullptr, grad_num, grad_den, (__bf16*)dpred_bf16);
+  SOD_LAUNCH((retina_box_kernel<true, __bf16>), dim3(nblk((long long)N * R, 4096)), dim3(256), 0, (hipStream_t)stream, a, nullptr, grad_num, grad_den, (__bf16*)dpred_bf16);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_retina_giou_loss_bwd_f32(const float* pred, int pitch, const int* gt_labels, const float* anchors, const float* matched_boxes,
+                                            int N, int R, int A, int num_classes, const float* weights4, float scale_clamp,
+                                            const float* grad_num, const float* grad_den, float* dpred, void* stream) {
+  RetinaGiouArgs a{};
+  int rc = retina_giou_fill(a, pred, pitch, gt_labels, anchors, matched_boxes, N, R, A, num_classes, weights4, scale_clamp);
+  if (rc || !grad_num || !grad_den || !dpred) return rc ? rc : SOD_EARG;
+  SOD_LAUNCH((retina_giou_kernel<true, float>), dim3(nblk((long long)N * R, 4096)), dim3(256), 0, (hipStream_t)stream, a, nullptr, grad_num, grad_den, dpred);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_retina_box_loss_bwd_f32(const float* pred, int pitch, const int* gt_labels, const float* gt_deltas, int N, int R, int A,
+                                           int num_classes, float beta, const float* grad_num, const float* grad_den, float* dpred, void* stream) {
+  if (!pred || !gt_labels || !gt_deltas || !grad_num || !grad_den || !dpred || N <= 0 || R <= 0 || A <= 0 || R % A || pitch < A * 4) return SOD_EARG;
+  RetinaBoxArgs a{pred, gt_labels, gt_deltas, N, R, A, pitch, num_classes, beta};
+  SOD_LAUNCH((retina_box_kernel<true, float>), dim3(nblk((long long)N * R, 4096)), dim3(256), 0, (hipStream_t)stream, a, nullptr, grad_num, grad_den, dpred);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -1079,7 +1079,7 @@ def retina_box_loss_fwd(pred, pitch, gt_labels, gt_deltas, N, R, A, num_classes,
 
 
 def retina_box_loss_bwd(pred, pitch, gt_labels, gt_deltas, N, R, A, num_classes, beta, grad_num, grad_den, dpred):
-    call("sod_retina_box_loss_bwd", ptr(pred), pitch, ptr(gt_labels), ptr(gt_deltas), N, R, A, num_classes, float(beta), ptr(grad_num),
+    call("sod_retina_box_loss_bwd_f32" if is_f32() else "sod_retina_box_loss_bwd", ptr(pred), pitch, ptr(gt_labels), ptr(gt_deltas), N, R, A, num_classes, float(beta), ptr(grad_num),
          ptr(grad_den), ptr(dpred), stream_ptr())
 
 
@@ -1334,7 +1334,7 @@ def retina_giou_loss_fwd(pred, pitch, gt_labels, anchors, matched_boxes, N, R, A
 
 def retina_giou_loss_bwd(pred, pitch, gt_labels, anchors, matched_boxes, N, R, A, num_classes, weights, scale_clamp, grad_num, grad_den, dpred):
     w = _float_arr(weights)
-    call("sod_retina_giou_loss_bwd", ptr(pred), pitch, ptr(gt_labels), ptr(anchors), ptr(matched_boxes), N, R, A, num_classes,
+    call("sod_retina_giou_loss_bwd_f32" if is_f32() else "sod_retina_giou_loss_bwd", ptr(pred), pitch, ptr(gt_labels), ptr(anchors), ptr(matched_boxes), N, R, A, num_classes,
          ctypes.cast(w, ctypes.c_void_p), float(scale_clamp), ptr(grad_num), ptr(grad_den), ptr(dpred), stream_ptr())
 
 

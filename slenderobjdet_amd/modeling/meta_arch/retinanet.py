@@ -122,8 +122,8 @@ class _RetinaLossFn(torch.autograd.Function):
         arena = _arena_of(head)
         dev = cls_buf.device
         dcls = HF.focal_loss_bwd(cls_buf.view(N * R, K), gt_labels.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma,
-                                 scale_num=g2[0:1], scale_den=norm, den_mul=1.0, den_min=1e-12, out_bf16=True).view(N, P, head.kc)
-        dbox = torch.zeros((N, P, head.box_pitch), dtype=torch.bfloat16, device=dev)
+                                 scale_num=g2[0:1], scale_den=norm, den_mul=1.0, den_min=1e-12, out_bf16=not HF.is_f32()).view(N, P, head.kc)
+        dbox = torch.zeros((N, P, head.box_pitch), dtype=HF.ACT_DTYPE, device=dev)
         if model.box_reg_loss_type == "giou":
             HF.retina_giou_loss_bwd(box_buf, head.box_pitch, gt_labels, model.anchors_for(hw), gt_deltas, N, R, A, K, model.bbox_reg_weights,
                                     model.scale_clamp, g2[1:2], norm, dbox)

@@ -224,6 +224,60 @@ def test_fcos_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, depth):
     print(f"\nf32 mode R{depth}: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
 
 
+@pytest.mark.parametrize("box_reg", ["smooth_l1", "giou"])
+def test_retinanet_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, box_reg):
+    """BASELINE configs[2]'s step (RetinaNet, R18 stand-in for the depth) in the validation mode against oracle.model.OracleRetinaNet in
+    fp32 and float64: both losses to 2e-5 relative, the EMA loss normaliser, and every parameter gradient no further from the float64
+    arbiter than 1.5x the CPU fp32 oracle is (+1e-4) and within 1e-3 of the CPU fp32 oracle outright (the R18 bars of the FCOS test)."""
+    from bench import make_cfg
+    from oracle.model import OracleRetinaNet
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+
+    cfg = make_cfg(18, "retinanet")
+    cfg.MODEL.RETINANET.BBOX_REG_LOSS_TYPE = box_reg
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    data = synthetic_batch(2, 256, 320, 3, device="cuda")
+    cpu = [{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data]
+    refs = {}
+    for tag in ("f32", "f64"):
+        oracle = OracleRetinaNet.from_hip_model(model, emulate_bf16=False)
+        if tag == "f64":
+            oracle.double()
+        losses = oracle.losses(cpu)
+        names = list(oracle.trainable().keys())
+        refs[tag] = ({k: float(v.detach()) for k, v in losses.items()},
+                     dict(zip(names, torch.autograd.grad(sum(losses.values()), list(oracle.trainable().values())))))
+        norm = oracle.new_normalizer
+    got = model(data)
+    total = sum(got.values())
+    opt.zero_grad()
+    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    assert abs(float(model.loss_normalizer) - norm) < 1e-4
+    for k, b in refs["f32"][0].items():
+        a = float(got[k].detach())
+        assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
+        assert abs(a - refs["f64"][0][k]) <= 2e-5 * max(abs(b), 1e-3), (k, a, refs["f64"][0][k])
+    worst = [0.0, 0.0, 0.0]
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        gq = p.grad.detach().double().cpu()
+        if gq.dim() == 4:
+            gq = gq.permute(0, 3, 1, 2)
+        r32, r64 = refs["f32"][1][name].double(), refs["f64"][1][name]
+        n = max(r64.norm().item(), 1e-30)
+        d_hip, d_cpu, d_pair = (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, (gq - r32).norm().item() / n
+        worst = [max(worst[0], d_hip), max(worst[1], d_cpu), max(worst[2], d_pair)]
+        assert d_hip <= 1.5 * d_cpu + 1e-4, (name, d_hip, d_cpu)
+        assert d_pair <= 1e-3, (name, d_pair)
+    print(f"\nf32 mode RetinaNet {box_reg}: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
+
+
 def test_bf16_only_devices_refuse_in_f32_mode(cuda, f32mode):
     """No silent precision mixing: what exists only on the bf16 product path raises in the validation mode."""
     from slenderobjdet_amd._C import SlenderHipError
