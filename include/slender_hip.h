@@ -417,6 +417,16 @@ int sod_deform_col2im(const void* dcols, const void* x, const float* offset, con
                       float* dx_f32, float* doffset, float* dmask,
                       int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
                       int off_ld, int mask_ld, int mask_is_logit, void* stream);
+
+/* fp32 validation mode of the two (SOD_PRECISION=fp32): fp32 activations, columns and column gradients; the GEMMs in between run on
+   sod_conv2d_*_f32 over the column tensor.  Same sampling rule (detectron2 deform_conv; df_conv.py:67-78). */
+int sod_deform_im2col_f32(const float* x, const float* offset, const float* mask, float* cols,
+                          int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
+                          int off_ld, int mask_ld, int mask_is_logit, void* stream);
+int sod_deform_col2im_f32(const float* dcols, const float* x, const float* offset, const float* mask,
+                          float* dx_f32, float* doffset, float* dmask,
+                          int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
+                          int off_ld, int mask_ld, int mask_is_logit, void* stream);
 int sod_f32_to_bf16(const float* x, void* y, long long n, void* stream);
 
 /* RetinaNet (detectron2 RetinaNet; in-tree mirror slender_det/modeling/meta_arch/retina/retina_rotated.py):

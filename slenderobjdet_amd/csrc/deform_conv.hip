@@ -17,7 +17,7 @@
 namespace {
 
 struct DcnArgs {
-  const __bf16* x;        // (N,H,W,C)
+  const __bf16* x;        // (N,H,W,C)   (x / cols / dcols hold fp32 for the <float> instantiations of the plain kernels: validation mode)
   const float* off;       // (N,Ho,Wo,2*KH*KW*DG)
   const float* mask;      // (N,Ho,Wo,KH*KW*DG) or null
   __bf16* cols;           // (N,Ho,Wo,KH*KW*C)  channel index = tap*C + c   (tap = i*KW + j; deformable group = c / (C/DG))
@@ -52,7 +52,35 @@ __device__ __forceinline__ Samp make_samp(float py, float px, int H, int W) {
   return s;
 }
 
+// 8 consecutive channels of element type T (bf16: the product path; float: the fp32 validation mode, SOD_PRECISION=fp32) as floats
+template <typename T>
+__device__ __forceinline__ void load8(const void* base, long long idx, float (&v)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    const bf16x8_t q = *reinterpret_cast<const bf16x8_t*>((const __bf16*)base + idx);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)q[e];
+  } else {
+    const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>((const float*)base + idx), q1 = *reinterpret_cast<const f32x4_t*>((const float*)base + idx + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = q0[e]; v[4 + e] = q1[e]; }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void store8(void* base, long long idx, const float (&v)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x8_t*>((__bf16*)base + idx) = o;
+  } else {
+    *reinterpret_cast<f32x4_t*>((float*)base + idx) = f32x4_t{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4_t*>((float*)base + idx + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+  }
+}
+
 // work item = (pixel, tap, 8-channel vector); the 8-channel vectors of one (pixel, tap) are consecutive threads
+template <typename T>
 __global__ __launch_bounds__(256) void dcn_im2col_kernel(const DcnArgs a) {
   const int c8n = a.C >> 3, taps = a.KH * a.KW, cpg = a.C / a.DG;
   const long long total = (long long)a.N * a.Ho * a.Wo * taps * c8n;
@@ -73,22 +101,23 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const DcnArgs a) {
     const long long base = (long long)n * a.H * a.W;
     auto add = [&](bool ok, int yy, int xx, float w) {
       if (!ok) return;
-      const bf16x8_t q = *reinterpret_cast<const bf16x8_t*>(a.x + ((base + (long long)yy * a.W + xx) * a.C) + c8 * 8);
+      float q[8];
+      load8<T>(a.x, ((base + (long long)yy * a.W + xx) * a.C) + c8 * 8, q);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += w * (float)q[e];
+      for (int e = 0; e < 8; ++e) v[e] += w * q[e];
     };
     add(s.ok00, s.yl, s.xl, s.w00); add(s.ok01, s.yl, s.xh, s.w01); add(s.ok10, s.yh, s.xl, s.w10); add(s.ok11, s.yh, s.xh, s.w11);
     float m = a.mask ? a.mask[pix * a.mask_ld + k] : 1.f;
     if (a.mask && a.mask_logit) m = 1.f / (1.f + expf(-m));
-    bf16x8_t o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (__bf16)(v[e] * m);
-    *reinterpret_cast<bf16x8_t*>(a.cols + (pix * taps + tap) * a.C + c8 * 8) = o;
+    for (int e = 0; e < 8; ++e) v[e] *= m;
+    store8<T>(a.cols, (pix * taps + tap) * a.C + c8 * 8, v);
   }
 }
 
 // backward of the gather: dX (atomic, fp32), dOffset, dMask.  Reduction over channels of one (pixel, tap, group) runs over
 // `red` consecutive lanes with shuffles (red = (C/DG)/8, a power of two <= 64), else falls back to atomics.
+template <typename T>
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(const DcnArgs a, int red) {
   const int c8n = a.C >> 3, taps = a.KH * a.KW, cpg = a.C / a.DG;
   const long long total = (long long)a.N * a.Ho * a.Wo * taps * c8n;
@@ -112,14 +141,13 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(const DcnArgs a, int re
       const Samp s = make_samp((float)(ho * a.stride - a.pad + ki * a.dil) + dy, (float)(wo * a.stride - a.pad + kj * a.dil) + dxo, a.H, a.W);
       float m = a.mask ? a.mask[pix * a.mask_ld + k] : 1.f;
       if (a.mask && a.mask_logit) m = 1.f / (1.f + expf(-m));
-      const bf16x8_t dcv = *reinterpret_cast<const bf16x8_t*>(a.dcols + (pix * taps + tap) * a.C + c8 * 8);
+      float dcv[8];
+      load8<T>(a.dcols, (pix * taps + tap) * a.C + c8 * 8, dcv);
       const long long base = (long long)n * a.H * a.W;
       float v00[8], v01[8], v10[8], v11[8];
-      auto ld = [&](bool ok, int yy, int xx, float* dst) {
+      auto ld = [&](bool ok, int yy, int xx, float (&dst)[8]) {
         if (ok) {
-          const bf16x8_t q = *reinterpret_cast<const bf16x8_t*>(a.x + ((base + (long long)yy * a.W + xx) * a.C) + c8 * 8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) dst[e] = (float)q[e];
+          load8<T>(a.x, ((base + (long long)yy * a.W + xx) * a.C) + c8 * 8, dst);
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) dst[e] = 0.f;
@@ -129,7 +157,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(const DcnArgs a, int re
       const float hy = 1.f - s.ly, hx = 1.f - s.lx;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float d = (float)dcv[e];
+        const float d = dcv[e];
         const float dm = d * m;     // gradient w.r.t. the un-masked sample
         if (s.ok00) atomicAdd(a.dx + ((base + (long long)s.yl * a.W + s.xl) * a.C) + c8 * 8 + e, dm * s.w00);
         if (s.ok01) atomicAdd(a.dx + ((base + (long long)s.yl * a.W + s.xh) * a.C) + c8 * 8 + e, dm * s.w01);
@@ -570,7 +598,41 @@ extern "C" int sod_deform_im2col(const void* x, const float* offset, const float
   int rc = dcn_fill(a, N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, off_ld, mask_ld, mask_is_logit);
   if (rc) return rc;
   a.x = (const __bf16*)x; a.off = offset; a.mask = mask; a.cols = (__bf16*)cols;
-  SOD_LAUNCH(dcn_im2col_kernel, dim3(grid_for((long long)N * a.Ho * a.Wo * KH * KW * (C / 8))), dim3(256), 0, (hipStream_t)stream, a);
+  SOD_LAUNCH(dcn_im2col_kernel<__bf16>, dim3(grid_for((long long)N * a.Ho * a.Wo * KH * KW * (C / 8))), dim3(256), 0, (hipStream_t)stream, a);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+// fp32 validation mode (SOD_PRECISION=fp32): the same gather with fp32 activations and columns; the contraction with the weights and
+// both of its gradients then run on the fp32 convolution kernels (f32_path.hip) over the column tensor.
+extern "C" int sod_deform_im2col_f32(const float* x, const float* offset, const float* mask, float* cols,
+                                     int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
+                                     int off_ld, int mask_ld, int mask_is_logit, void* stream) {
+  if (!x || !offset || !cols) return SOD_EARG;
+  DcnArgs a{};
+  int rc = dcn_fill(a, N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, off_ld, mask_ld, mask_is_logit);
+  if (rc) return rc;
+  a.x = (const __bf16*)x; a.off = offset; a.mask = mask; a.cols = (__bf16*)cols;
+  SOD_LAUNCH(dcn_im2col_kernel<float>, dim3(grid_for((long long)N * a.Ho * a.Wo * KH * KW * (C / 8))), dim3(256), 0, (hipStream_t)stream, a);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+// dX (fp32 atomics), dOffset, dMask from fp32 column gradients: the plain scatter kernel (summation order of dX varies run to run in
+// the last bit; everything else of the validation mode is order-fixed).
+extern "C" int sod_deform_col2im_f32(const float* dcols, const float* x, const float* offset, const float* mask,
+                                     float* dx_f32, float* doffset, float* dmask,
+                                     int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,
+                                     int off_ld, int mask_ld, int mask_is_logit, void* stream) {
+  if (!dcols || !x || !offset || !dx_f32 || !doffset || (mask && !dmask)) return SOD_EARG;
+  DcnArgs a{};
+  int rc = dcn_fill(a, N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, off_ld, mask_ld, mask_is_logit);
+  if (rc) return rc;
+  a.x = (const __bf16*)x; a.off = offset; a.mask = mask; a.dcols = (const __bf16*)dcols; a.dx = dx_f32; a.doff = doffset; a.dmask = dmask;
+  const int per = (C / deformable_groups) / 8;
+  int red = 0;
+  if (per <= 64 && (per & (per - 1)) == 0 && (C / 8) % per == 0) red = per;
+  SOD_LAUNCH(dcn_col2im_kernel<float>, dim3(grid_for((long long)N * a.Ho * a.Wo * KH * KW * (C / 8))), dim3(256), 0, (hipStream_t)stream, a, red);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -607,7 +669,7 @@ extern "C" int sod_deform_col2im(const void* dcols, const void* x, const float* 
   if (per <= 64 && (per & (per - 1)) == 0 && (C / 8) % per == 0) red = per;
   // the atomic fallback (red == 0) accumulates: the caller passes zero-initialised doffset / dmask in every case (they are
   // pitched buffers whose padding columns must be zero anyway)
-  SOD_LAUNCH(dcn_col2im_kernel, dim3(grid_for((long long)N * a.Ho * a.Wo * KH * KW * (C / 8))), dim3(256), 0, st, a, red);
+  SOD_LAUNCH(dcn_col2im_kernel<__bf16>, dim3(grid_for((long long)N * a.Ho * a.Wo * KH * KW * (C / 8))), dim3(256), 0, st, a, red);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -168,10 +168,11 @@ class DeformConv(nn.Module):
     def prepare(self):
         arena = _arena_of(self)
         key = (self.weight._version, arena.generation if (arena is not None and self.weight.requires_grad) else -1, self.weight.data_ptr(),
-               self._bn_state() if self.frozen_bn else None)
+               self._bn_state() if self.frozen_bn else None, HF.PRECISION)
         if key == self._prep_key:
             return
-        batched = arena is not None and getattr(self, "_b_krsc", None) is not None and self.weight.requires_grad
+        # (the batched preparation writes the bf16 arenas; the fp32 validation mode derives its copies per layer, as HipConv2d does)
+        batched = arena is not None and getattr(self, "_b_krsc", None) is not None and self.weight.requires_grad and not HF.is_f32()
         if self.frozen_bn:
             if self._bn_state() != getattr(self, "_bn_key", None):      # buffers changed (checkpoint load): re-fold, re-prepare
                 self._fold_bn(self._b_scale if batched else None)

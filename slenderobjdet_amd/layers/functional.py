@@ -971,13 +971,13 @@ def f32_to_bf16(x):
 
 
 def deform_im2col(x, offset, mask, ksize, stride, pad, dil, dg=1, off_ld=0, mask_ld=0, mask_is_logit=False):
-    """x (N,H,W,C) bf16; offset/mask fp32 (pitched rows); returns cols (N,Ho,Wo,KH*KW*C) bf16."""
-    _chk(x, torch.bfloat16, "x")
+    """x (N,H,W,C) bf16; offset/mask fp32 (pitched rows); returns cols (N,Ho,Wo,KH*KW*C) bf16 (both fp32 in the validation mode)."""
+    _chk(x, ACT_DTYPE, "x"); _chk(offset, torch.float32, "offset"); _chk(mask, torch.float32, "mask")
     N, H, W, C = x.shape
     KH, KW = ksize
     Ho, Wo = conv_out_size(H, W, KH, KW, stride, pad, dil)
-    cols = torch.empty((N, Ho, Wo, KH * KW * C), dtype=torch.bfloat16, device=x.device)
-    call("sod_deform_im2col", ptr(x), ptr(offset), ptr(mask), ptr(cols), N, H, W, C, KH, KW, stride, pad, dil, dg, off_ld, mask_ld,
+    cols = torch.empty((N, Ho, Wo, KH * KW * C), dtype=ACT_DTYPE, device=x.device)
+    call("sod_deform_im2col_f32" if is_f32() else "sod_deform_im2col", ptr(x), ptr(offset), ptr(mask), ptr(cols), N, H, W, C, KH, KW, stride, pad, dil, dg, off_ld, mask_ld,
          1 if mask_is_logit else 0, stream_ptr())
     return cols
 
@@ -1027,13 +1027,13 @@ def deform_conv_wgrad_fused(dy, x, offset, mask, dw, ksize, stride, pad, dil, dg
 
 
 def deform_fused_supported(C, K, dg):
-    """Shapes both fused DeformConv kernels (forward and weight gradient) accept."""
-    return C % 128 == 0 and K % 8 == 0 and C % dg == 0 and (dg == 1 or (C // dg) % 128 == 0)
+    """Shapes both fused DeformConv kernels (forward and weight gradient) accept (bf16 product path only)."""
+    return not is_f32() and C % 128 == 0 and K % 8 == 0 and C % dg == 0 and (dg == 1 or (C // dg) % 128 == 0)
 
 
 def deform_bwd_fused_supported(C, K, dg):
-    """Shapes the fused input / offset / mask gradient (sod_deform_conv_bwd_fused) accepts."""
-    return K in (128, 256, 512) and C % 32 == 0 and C % dg == 0 and (C // dg) % 32 == 0
+    """Shapes the fused input / offset / mask gradient (sod_deform_conv_bwd_fused) accepts (bf16 product path only)."""
+    return not is_f32() and K in (128, 256, 512) and C % 32 == 0 and C % dg == 0 and (C // dg) % 32 == 0
 
 
 def deform_conv_bwd_fused(dy, wt, x, offset, mask, ksize, stride, pad, dil, dg, doffset, dmask, off_ld=0, mask_ld=0, mask_is_logit=False):
@@ -1054,10 +1054,11 @@ def deform_conv_bwd_fused(dy, wt, x, offset, mask, ksize, stride, pad, dil, dg, 
 
 def deform_col2im(dcols, x, offset, mask, ksize, stride, pad, dil, dg, doffset, dmask, off_ld=0, mask_ld=0, mask_is_logit=False):
     """Returns dx fp32 (N,H,W,C); fills the (zero-initialised, pitched) doffset / dmask."""
+    _chk(dcols, ACT_DTYPE, "dcols"); _chk(x, ACT_DTYPE, "x"); _chk(doffset, torch.float32, "doffset"); _chk(dmask, torch.float32, "dmask")
     N, H, W, C = x.shape
     KH, KW = ksize
     dx = torch.zeros((N, H, W, C), dtype=torch.float32, device=x.device)
-    call("sod_deform_col2im", ptr(dcols), ptr(x), ptr(offset), ptr(mask), ptr(dx), ptr(doffset), ptr(dmask), N, H, W, C, KH, KW, stride, pad, dil,
+    call("sod_deform_col2im_f32" if is_f32() else "sod_deform_col2im", ptr(dcols), ptr(x), ptr(offset), ptr(mask), ptr(dx), ptr(doffset), ptr(dmask), N, H, W, C, KH, KW, stride, pad, dil,
          dg, off_ld, mask_ld, 1 if mask_is_logit else 0, stream_ptr())
     return dx
 
@@ -1339,12 +1340,12 @@ def retina_giou_loss_bwd(pred, pitch, gt_labels, anchors, matched_boxes, N, R, A
 
 
 # ---- fp32 validation mode: the wrappers of the training step dispatch to functional_f32 when it is on; everything that only the bf16
-# product path offers (fused stem / bottleneck, 1-bit masks, statistics epilogues, DeformConv, ...) is switched off by its callers or refuses
+# product path offers (fused stem / bottleneck, 1-bit masks, statistics epilogues, the fused DeformConv kernels, ...) is switched off by its callers or refuses
 for _name in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "conv2d_fwd_ml", "conv2d_dgrad_ml", "conv2d_wgrad_ml", "weight_prep",
               "groupnorm_fwd", "groupnorm_bwd", "groupnorm_fwd_ml", "groupnorm_bwd_ml", "relu_fwd", "relu_bwd", "add_bf16", "f32_to_bf16",
               "add_up2", "upsample2x_bwd", "maxpool3x3s2", "bias_grad", "bias_grad_ml", "preprocess_image", "preprocess_batch"):
     globals()[_name] = _precision_dispatch(globals()[_name])
-for _name in ("conv_gn_fwd_ml", "conv2d_dgrad_ml_gnbwd", "groupnorm_bwd_apply_ml", "stem_fused", "bottleneck_frozen_fwd", "deform_im2col"):
+for _name in ("conv_gn_fwd_ml", "conv2d_dgrad_ml_gnbwd", "groupnorm_bwd_apply_ml", "stem_fused", "bottleneck_frozen_fwd"):
     if _name in globals():
         globals()[_name] = _precision_dispatch(globals()[_name])     # no fp32 variant: raises instead of mixing precisions
 if os.environ.get("SOD_PRECISION", "bf16") != "bf16":

@@ -87,7 +87,7 @@ class _RepPointsLossFn(torch.autograd.Function):
         arena = _arena_of(model.logits)
         # classification branch
         dlogits = HF.focal_loss_bwd(logits_buf.view(N * X, K), cls.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma,
-                                    scale_num=g3[0:1], scale_den=norm, den_mul=1.0, den_min=1.0, out_bf16=True)
+                                    scale_num=g3[0:1], scale_den=norm, den_mul=1.0, den_min=1.0, out_bf16=not HF.is_f32())
         dys = [dlogits.view(-1)[o * K:] for o in offs]
         HF.conv2d_wgrad_ml(dys, list(cf), arena.grad_view(model.logits.weight), 1, 1, 1, 0, 1, dy_img_stride=X * K, K=K)
         arena.mark_ready(model.logits.weight)
@@ -99,22 +99,23 @@ class _RepPointsLossFn(torch.autograd.Function):
         d_init = HF.reppoints_box_loss_bwd(init_boxes, init_lab, obj, strides, -1, model.smooth_l1_beta, g3[1:2], init_sums[1:2], 1.0,
                                            model.loss_init_weight)
         doi, drd = [], []
+        f32 = HF.is_f32()          # validation mode: the gradient rows of offsets_refine stay fp32
         for l, (h, w) in enumerate(hw):
             o, ps = offs[l], model.point_scales[l]
             shape = (N, h, w, ld)
             if ctx.moment:
                 mt, dmt = model.moment_transfer.detach(), arena.grad_view(model.moment_transfer)
                 add = oi[l] if model.res_refine else None
-                _, d16 = HF.points2bbox_moment_bwd(d_refine.view(-1)[o * 4:], X * 4, rdelta[l], add, model.strides[l], ps, model.num_points, mt,
-                                                   model.moment_mul, dmt, want_f32=False, want_bf16=True)
+                r32, d16 = HF.points2bbox_moment_bwd(d_refine.view(-1)[o * 4:], X * 4, rdelta[l], add, model.strides[l], ps, model.num_points, mt,
+                                                     model.moment_mul, dmt, want_f32=f32, want_bf16=not f32)
                 d32, _ = HF.points2bbox_moment_bwd(d_init.view(-1)[o * 4:], X * 4, oi[l], None, model.strides[l], ps, model.num_points, mt,
                                                    model.moment_mul, dmt)
-                drd.append(d16)
+                drd.append(r32 if f32 else d16)
                 doi.append(d32)
                 continue
-            _, d16 = HF.points2bbox_bwd(d_refine.view(-1)[o * 4:], X * 4, refine_arg.view(-1)[o:], X, shape, ps, P, want_f32=False, want_bf16=True)
+            r32, d16 = HF.points2bbox_bwd(d_refine.view(-1)[o * 4:], X * 4, refine_arg.view(-1)[o:], X, shape, ps, P, want_f32=f32, want_bf16=not f32)
             d32, _ = HF.points2bbox_bwd(d_init.view(-1)[o * 4:], X * 4, init_arg.view(-1)[o:], X, shape, ps, P)
-            drd.append(d16)
+            drd.append(r32 if f32 else d16)
             doi.append(d32)
         if ctx.moment:
             arena.mark_ready(model.moment_transfer)

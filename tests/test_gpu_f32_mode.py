@@ -278,6 +278,119 @@ def test_retinanet_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, box_r
     print(f"\nf32 mode RetinaNet {box_reg}: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
 
 
+@pytest.mark.parametrize("v2", [False, True])
+def test_dfconv2d_module_in_f32_mode_vs_oracle(cuda, f32mode, v2):
+    """DFConv2d (slender_det/layers/df_conv.py:67-78: offset conv -> DeformConv / ModulatedDeformConv) as an autograd module with fp32
+    storage against the CPU oracle: output and the gradients w.r.t. x, the offset conv (through dOffset AND dMask) and the DCN weight to
+    2e-5 of their norm - the bf16 product path holds 2^-6 / 3e-2 on the same module (test_gpu_deform_conv.py), i.e. those bars are storage
+    precision, not kernel error.  Offsets of up to ~3 px so that samples cross pixel boundaries and the image border."""
+    import torch.nn.functional as F
+
+    from oracle import deform_conv as odc
+    from slenderobjdet_amd.layers.arena import ParamArena
+    from slenderobjdet_amd.layers.deform_conv import DFConv2d
+    from slenderobjdet_amd.layers.nn import attach_arena
+
+    torch.manual_seed(1)
+    C = 64
+    m = DFConv2d(C, C, with_modulated_dcn=v2).to(cuda)
+    with torch.no_grad():
+        m.offset.weight.mul_(2.0)
+    arena = ParamArena(m)
+    attach_arena(m, arena)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 9, 11, C, generator=g) * 0.5
+    dy = torch.randn(2, 9, 11, C, generator=g)
+    xd = x.to(cuda).requires_grad_(True)
+    arena.zero_grad()
+    y = m(xd)
+    assert y.dtype == torch.float32
+    y.backward(dy.to(cuda))
+    torch.cuda.synchronize()
+    n = m.n_off
+    w_off = m.offset.weight.detach().cpu()[:n].permute(0, 3, 1, 2).double().requires_grad_(True)
+    b_off = m.offset.bias.detach().cpu()[:n].double().requires_grad_(True)
+    w = m.conv.weight.detach().cpu().permute(0, 3, 1, 2).double().requires_grad_(True)
+    xr = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    om = F.conv2d(xr, w_off, b_off, padding=1)
+    assert om[:, :18].abs().max() > 1.0, "offsets must leave the sampling cell"
+    if v2:
+        ref = odc.deform_conv2d(xr, om[:, :18], w, None, 1, 1, 1, om[:, 18:27].sigmoid(), 1)
+    else:
+        ref = odc.deform_conv2d(xr, om, w, None, 1, 1, 1, None, 1)
+    gx, gwo, gbo, gw = torch.autograd.grad(ref, (xr, w_off, b_off, w), dy.permute(0, 3, 1, 2).double())
+    _close(y, ref.detach().permute(0, 2, 3, 1), 2e-5)
+    for got, want, name in ((m.offset.weight.grad.cpu()[:n].permute(0, 3, 1, 2), gwo, "d offset.weight"), (m.offset.bias.grad.cpu()[:n], gbo, "d offset.bias"),
+                            (m.conv.weight.grad.cpu().permute(0, 3, 1, 2), gw, "d conv.weight"), (xd.grad.cpu().permute(0, 3, 1, 2), gx, "dx")):
+        err = (got.double() - want).norm().item() / max(want.norm().item(), 1e-12)
+        assert err <= 2e-5, (name, err)
+    assert (m.offset.weight.grad[n:] == 0).all()
+
+
+def test_reppoints_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode):
+    """BASELINE configs[3]'s step (RepPointsDetector: ResNet + GN-FPN + two DeformConv layers fed by the learned point offsets,
+    rpd.py:621-671; R18 stand-in for the depth) in the validation mode against oracle.reppoints.OracleRepPoints in fp32 and float64.
+    The point-to-box assignment depends on the PREDICTED init boxes, so the oracle is given the labels of the run under test after they
+    were checked bit-exact against the oracle's own assignment on the same boxes.  Losses to 2e-5; every parameter gradient no further
+    from the float64 arbiter than 1.5x the CPU fp32 oracle is (+1e-4) and within 1e-3 of the CPU fp32 oracle outright."""
+    from oracle import reppoints as orp
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+    from test_gpu_reppoints import _cfg
+
+    cfg = _cfg()
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    data = synthetic_batch(2, 256, 320, 5, device="cuda")
+    cpu = [{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data]
+    got = model(data)
+    tg_hip = model.last_targets
+    total = sum(got.values())
+    opt.zero_grad()
+    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    refs = {}
+    for tag in ("f32", "f64"):
+        oracle = orp.OracleRepPoints.from_hip_model(model, emulate_bf16=False)
+        oracle.normalizer = 20.0
+        if tag == "f64":
+            oracle.double()
+            losses = oracle.losses(cpu, targets=tg)
+        else:
+            losses = oracle.losses(cpu)              # the CPU fp32 oracle's own assignment on its own init boxes
+            tg = oracle.last_targets
+            assert torch.equal(tg_hip[0].cpu().float(), tg[0].float()) and torch.equal(tg_hip[2].cpu().long(), tg[2].long()), "labels differ"
+            assert torch.equal(tg_hip[1].cpu(), tg[1]) and torch.equal(tg_hip[3].cpu(), tg[3])
+        tr = oracle.trainable()
+        refs[tag] = ({k: float(v.detach()) for k, v in losses.items()},
+                     dict(zip(tr.keys(), torch.autograd.grad(sum(losses.values()), list(tr.values()), allow_unused=True))))
+    for k, b in refs["f32"][0].items():
+        a = float(got[k].detach())
+        assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
+        assert abs(a - refs["f64"][0][k]) <= 2e-5 * max(abs(b), 1e-3), (k, a, refs["f64"][0][k])
+    worst, checked = [0.0, 0.0, 0.0], 0
+    for name, p in model.named_parameters():
+        if not p.requires_grad or refs["f64"][1].get(name) is None:
+            continue
+        gq = p.grad.detach().double().cpu()
+        if gq.dim() == 4:
+            gq = gq.permute(0, 3, 1, 2)
+        r32, r64 = refs["f32"][1][name].double(), refs["f64"][1][name]
+        if name.startswith(("offsets_init.1", "offsets_refine")):        # 18 point coordinates padded to 24 rows
+            assert (gq[18:] == 0).all(), name
+            gq, r32, r64 = gq[:18], r32[:18], r64[:18]
+        n = max(r64.norm().item(), 1e-30)
+        d_hip, d_cpu, d_pair = (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, (gq - r32).norm().item() / n
+        worst = [max(worst[0], d_hip), max(worst[1], d_cpu), max(worst[2], d_pair)]
+        assert d_hip <= 1.5 * d_cpu + 1e-4, (name, d_hip, d_cpu)
+        assert d_pair <= 1e-3, (name, d_pair)
+        checked += 1
+    assert checked > 40
+    print(f"\nf32 mode RepPoints: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
+
+
 def test_bf16_only_devices_refuse_in_f32_mode(cuda, f32mode):
     """No silent precision mixing: what exists only on the bf16 product path raises in the validation mode."""
     from slenderobjdet_amd._C import SlenderHipError
