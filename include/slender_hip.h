@@ -355,6 +355,9 @@ int sod_box_iou_rotated(const float* boxes1, int n1, const float* boxes2, int n2
  * bwd accumulates atomically into dx (N,H,W,C) fp32 (zero it first). */
 int sod_roi_align_fwd(const void* x, const float* rois, float* out, int R, int N, int H, int W, int C, int PH, int PW,
                       float spatial_scale, int sampling_ratio, int rotated, void* stream);
+/* the same with fp32 features (fp32 validation mode of the two-stage path; the backward already works on fp32 rows) */
+int sod_roi_align_fwd_f32(const float* x, const float* rois, float* out, int R, int N, int H, int W, int C, int PH, int PW,
+                          float spatial_scale, int sampling_ratio, int rotated, void* stream);
 int sod_roi_align_bwd(const float* dout, const float* rois, float* dx, int R, int N, int H, int W, int C, int PH, int PW,
                       float spatial_scale, int sampling_ratio, int rotated, void* stream);
 /* fvcore.nn.giou_loss(boxes1, boxes2, eps) on XYXY (retina_rotated.py:240): per-row loss, optional sum, optional gradient

@@ -83,6 +83,7 @@ _SIGS = {
     "sod_nms_rotated": [_P, _P, _I, _F, _P, _P, _P, _P],
     "sod_box_iou_rotated": [_P, _I, _P, _I, _P, _P],
     "sod_roi_align_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
+    "sod_roi_align_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "sod_roi_align_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "sod_giou_loss_xyxy": [_P, _P, _L, _F, _P, _P, _P, _P, _P, _P],
     "sod_smooth_l1_loss": [_P, _P, _L, _F, _P, _P, _P, _P, _P, _P],

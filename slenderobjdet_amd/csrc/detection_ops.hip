@@ -397,8 +397,8 @@ __device__ __forceinline__ void bilinear_setup(float y, float x, int H, int W, i
   w[0] = hy * hx; w[1] = hy * lx; w[2] = ly * hx; w[3] = ly * lx;
 }
 
-// one thread = one (roi, ph, pw, 8-channel vector)
-template <bool BWD>
+// one thread = one (roi, ph, pw, 8-channel vector); XF32: the features are fp32 (validation mode, SOD_PRECISION=fp32)
+template <bool BWD, bool XF32 = false>
 __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a, float* __restrict__ out /* fwd (R,PH,PW,C) f32 */,
                                                         const float* __restrict__ dout, float* __restrict__ dx /* (N,H,W,C) f32 */) {
   const int c8n = a.C >> 3;
@@ -444,7 +444,11 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a, float* 
         const long long base = ((long long)b * a.H) * a.W;
         const long long o00 = ((base + (long long)yl * a.W + xl) * a.C) + c8 * 8, o01 = ((base + (long long)yl * a.W + xh) * a.C) + c8 * 8;
         const long long o10 = ((base + (long long)yh * a.W + xl) * a.C) + c8 * 8, o11 = ((base + (long long)yh * a.W + xh) * a.C) + c8 * 8;
-        if (!BWD) {
+        if (!BWD && XF32) {
+          const float* xf = reinterpret_cast<const float*>(a.x);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += w[0] * xf[o00 + e] + w[1] * xf[o01 + e] + w[2] * xf[o10 + e] + w[3] * xf[o11 + e];
+        } else if (!BWD) {
           const bf16x8_t v00 = *reinterpret_cast<const bf16x8_t*>(a.x + o00), v01 = *reinterpret_cast<const bf16x8_t*>(a.x + o01);
           const bf16x8_t v10 = *reinterpret_cast<const bf16x8_t*>(a.x + o10), v11 = *reinterpret_cast<const bf16x8_t*>(a.x + o11);
 #pragma unroll
@@ -931,7 +935,18 @@ extern "C" int sod_roi_align_fwd(const void* x, const float* rois, float* out, i
   int rc = roi_fill(a, x, rois, R, N, H, W, C, PH, PW, spatial_scale, sampling_ratio, rotated);
   if (rc || !out) return rc ? rc : SOD_EARG;
   if (R == 0) return SOD_OK;
-  SOD_LAUNCH(roi_align_kernel<false>, dim3(nblk((long long)R * PH * PW * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream, a, out, nullptr, nullptr);
+  SOD_LAUNCH((roi_align_kernel<false, false>), dim3(nblk((long long)R * PH * PW * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream, a, out, nullptr, nullptr);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_roi_align_fwd_f32(const float* x, const float* rois, float* out, int R, int N, int H, int W, int C, int PH, int PW,
+                                     float spatial_scale, int sampling_ratio, int rotated, void* stream) {
+  RoiArgs a{};
+  int rc = roi_fill(a, x, rois, R, N, H, W, C, PH, PW, spatial_scale, sampling_ratio, rotated);
+  if (rc || !out) return rc ? rc : SOD_EARG;
+  if (R == 0) return SOD_OK;
+  SOD_LAUNCH((roi_align_kernel<false, true>), dim3(nblk((long long)R * PH * PW * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream, a, out, nullptr, nullptr);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -948,7 +963,7 @@ extern "C" int sod_roi_align_bwd(const float* dout, const float* rois, float* dx
     SOD_CHECK_LAUNCH();
     return SOD_OK;
   }
-  SOD_LAUNCH(roi_align_kernel<true>, dim3(nblk((long long)R * PH * PW * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream, a, nullptr, dout, dx);
+  SOD_LAUNCH((roi_align_kernel<true, false>), dim3(nblk((long long)R * PH * PW * (C / 8), 8192)), dim3(256), 0, (hipStream_t)stream, a, nullptr, dout, dx);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -903,13 +903,13 @@ def box_iou_rotated(b1, b2):
 
 
 def roi_align_fwd(x, rois, output_size, spatial_scale, sampling_ratio=0, rotated=False):
-    """x (N,H,W,C) bf16, rois (R,5|6) f32 -> (R,PH,PW,C) f32 (aligned=True semantics)."""
-    _chk(x, torch.bfloat16, "x"); _chk(rois, torch.float32, "rois")
+    """x (N,H,W,C) bf16 (fp32 in the validation mode), rois (R,5|6) f32 -> (R,PH,PW,C) f32 (aligned=True semantics)."""
+    _chk(x, ACT_DTYPE, "x"); _chk(rois, torch.float32, "rois")
     N, H, W, C = x.shape
     PH, PW = output_size
     R = rois.shape[0]
     out = torch.empty((R, PH, PW, C), dtype=torch.float32, device=x.device)
-    call("sod_roi_align_fwd", ptr(x), ptr(rois), ptr(out), R, N, H, W, C, PH, PW, float(spatial_scale), int(sampling_ratio), 1 if rotated else 0, stream_ptr())
+    call("sod_roi_align_fwd_f32" if is_f32() else "sod_roi_align_fwd", ptr(x), ptr(rois), ptr(out), R, N, H, W, C, PH, PW, float(spatial_scale), int(sampling_ratio), 1 if rotated else 0, stream_ptr())
     return out
 
 

@@ -63,7 +63,7 @@ class _RoiPoolFn(torch.autograd.Function):
                     g = HF.f32_to_bf16(HF.roi_align_bwd(dout[idx].contiguous(), rois[idx].contiguous(), ctx.shapes[l], pooler.scales[l],
                                                         pooler.sampling_ratio, pooler.rotated))
                 else:
-                    g = torch.zeros(ctx.shapes[l], dtype=torch.bfloat16, device=dout.device)
+                    g = torch.zeros(ctx.shapes[l], dtype=HF.ACT_DTYPE, device=dout.device)
             grads.append(g)
             start += cnt
         return (None, None, None, None, *grads)

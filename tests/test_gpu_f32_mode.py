@@ -391,6 +391,73 @@ def test_reppoints_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode):
     print(f"\nf32 mode RepPoints: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
 
 
+@pytest.mark.parametrize("rotated", [True, False])
+def test_rcnn_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, rotated):
+    """BASELINE configs[4]'s step family (GeneralizedRCNN: RPN / RRPN + StandardROIHeads / RROIHeads over ROIAlign / ROIAlignRotated) in
+    the validation mode against oracle.rcnn.OracleRCNN in fp32 and float64, with the random anchor / proposal samples and the proposals
+    taken from the run under test (they are checked against the oracle's matchers in test_gpu_rcnn.py).  The four losses to 2e-5; every
+    parameter gradient no further from the float64 arbiter than 1.5x the CPU fp32 oracle is (+1e-4) and within 1e-3 of it outright."""
+    from oracle import rcnn as orc
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+    from test_gpu_rcnn import _cfg, _cpu, _data
+
+    cfg = _cfg(rotated)
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    data = _data(2, 96, 128, 21, rotated)
+    got = model(data)
+    total = sum(got.values())
+    opt.zero_grad()
+    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    rpn, roi = model.proposal_generator, model.roi_heads
+    D = 5 if rotated else 4
+    gt_labels, _, gt_deltas = (t.cpu() for t in rpn.last_targets)
+    props = roi.last_proposals
+    rois = torch.cat([torch.cat((torch.full((len(p), 1), float(i)), p.proposal_boxes.tensor.cpu()), 1) for i, p in enumerate(props)])
+    roi_cls = torch.cat([p.gt_classes.cpu() for p in props])
+    roi_gtb = torch.cat([p.gt_boxes.tensor.cpu() for p in props])
+    refs = {}
+    for tag in ("f32", "f64"):
+        oracle = orc.OracleRCNN.from_hip_model(model, emulate_bf16=False)
+        args = (gt_labels, gt_deltas, rois, roi_cls, roi_gtb)
+        if tag == "f64":
+            oracle.double()
+            args = (gt_labels, gt_deltas.double(), rois.double(), roi_cls, roi_gtb.double())
+        r = oracle.losses(_cpu(data), *args)
+        tr = oracle.trainable()
+        refs[tag] = ({k: float(v.detach()) for k, v in r.items()},
+                     dict(zip(tr.keys(), torch.autograd.grad(sum(r.values()), list(tr.values()), allow_unused=True))))
+    for k, b in refs["f32"][0].items():
+        a = float(got[k].detach())
+        assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
+        assert abs(a - refs["f64"][0][k]) <= 2e-5 * max(abs(b), 1e-3), (k, a, refs["f64"][0][k])
+    K, A = 80, rpn.head.num_anchors
+    rows = {"objectness_logits": A, "anchor_deltas": A * D, "cls_score": K + 1, "bbox_pred": K * D}
+    worst, checked = [0.0, 0.0, 0.0], 0
+    for name, p in model.named_parameters():
+        if not p.requires_grad or refs["f64"][1].get(name) is None:
+            continue
+        gq = p.grad.detach().double().cpu()
+        if gq.dim() == 4:
+            gq = gq.permute(0, 3, 1, 2)
+        r32, r64 = refs["f32"][1][name].double(), refs["f64"][1][name]
+        for key, nrow in rows.items():
+            if key in name:
+                assert (gq[nrow:] == 0).all(), name
+                gq, r32, r64 = gq[:nrow], r32[:nrow], r64[:nrow]
+        n = max(r64.norm().item(), 1e-30)
+        d_hip, d_cpu, d_pair = (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, (gq - r32).norm().item() / n
+        worst = [max(worst[0], d_hip), max(worst[1], d_cpu), max(worst[2], d_pair)]
+        assert d_hip <= 1.5 * d_cpu + 1e-4, (name, d_hip, d_cpu)
+        assert d_pair <= 1e-3, (name, d_pair)
+        checked += 1
+    assert checked > 30
+    print(f"\nf32 mode R-CNN rotated={rotated}: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
+
+
 def test_bf16_only_devices_refuse_in_f32_mode(cuda, f32mode):
     """No silent precision mixing: what exists only on the bf16 product path raises in the validation mode."""
     from slenderobjdet_amd._C import SlenderHipError
