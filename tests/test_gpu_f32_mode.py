@@ -458,6 +458,88 @@ def test_rcnn_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, rotated):
     print(f"\nf32 mode R-CNN rotated={rotated}: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
 
 
+@pytest.mark.parametrize("which", ["pointset", "lrtb", "anchor"])
+def test_ablation_heads_in_f32_mode_vs_oracle(cuda, f32mode, which):
+    """AblationMetaArch with PointSetHead / LRTBHead / AnchorHead ("Supervised Offset" feature adaption: the
+    DeformConv fed by the head's own init prediction) in the validation mode.  The oracle heads (oracle/{pointset,lrtb,anchor_head}.py,
+    pinned to the reference's own heads run on CPU by tests/test_oracle_*.py) get the product's FPN features and must reproduce the
+    losses to 2e-5 and the gradient of every head parameter to 1e-4 of its norm (measured 2.5e-6 / 4.3e-6 / 7.7e-6; the bf16 product path
+    holds 3e-2 on the forward alone)."""
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+
+    if which == "pointset":
+        from oracle import pointset as om
+        from test_gpu_pointset import _cfg
+
+        cfg, seed, dseed, Oracle = _cfg("Supervised Offset"), 4, 12, om.OraclePointSetHead
+    elif which == "lrtb":
+        from oracle import lrtb as om
+        from test_gpu_lrtb import _cfg
+
+        cfg, seed, dseed, Oracle = _cfg("Supervised Offset", False, True, True, "giou", True, 1.5), 9, 14, om.OracleLRTBHead
+    else:
+        from oracle import anchor_head as om
+        from test_gpu_anchor_head import _cfg
+
+        cfg, seed, dseed, Oracle = _cfg("supervised", "smooth_l1"), 14, 17, om.OracleAnchorHead
+    torch.manual_seed(seed)
+    model = build_model(cfg)
+    model.train()
+    head = model.head
+    with torch.no_grad():      # the same away-from-degenerate-init tweaks as the bf16 tests of each head
+        if which == "pointset":
+            for m in (head.loc_init_out.conv, head.offsets_refine):
+                m.weight.mul_(6.0)
+        elif which == "lrtb":
+            head.loc_init_out.conv.bias[:4].fill_(0.75)
+            head.box_pred.conv.bias[:4].fill_(0.75)
+            head.scales_init.add_(torch.linspace(-0.2, 0.2, 5, device=head.scales_init.device))
+        else:
+            head.loc_init_out.conv.weight.mul_(5.0)
+            head.bbox_pred.weight.mul_(5.0)
+    model.arena.bump()
+    opt = build_optimizer(cfg, model)
+    data = synthetic_batch(2, 192, 256, dseed, device="cuda")
+    got = model(data)
+    total = sum(got.values())
+    opt.zero_grad()
+    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    with torch.no_grad():
+        imgs = model.preprocess_image(data)
+        feats = model.backbone(imgs.tensor)
+        feats = [feats[f].float().cpu().permute(0, 3, 1, 2).contiguous() for f in head.in_features]
+    gtb = [d["instances"].gt_boxes.tensor.cpu() for d in data]
+    gtc = [d["instances"].gt_classes.cpu() for d in data]
+    o = Oracle.from_hip_head(head, emulate_bf16=False)
+    if which == "anchor":
+        ref, _ = o.losses(feats, gtb, gtc, [tuple(d["image"].shape[-2:]) for d in data])
+    else:
+        ref = o.losses(feats, gtb, gtc)
+    assert set(ref) == set(got)
+    for k, v in ref.items():
+        a, b = float(got[k].detach()), float(v.detach())
+        assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
+    names = [k for k, v in o.p.items() if v.requires_grad]
+    grads = dict(zip(names, torch.autograd.grad(sum(ref.values()), [o.p[k] for k in names], allow_unused=True)))
+    mine = dict(head.named_parameters())
+    worst, checked = 0.0, 0
+    for k, r in grads.items():
+        if r is None or k not in mine or mine[k].grad is None:
+            continue
+        g = mine[k].grad.detach().float().cpu()
+        if g.dim() == 4:
+            g = g.permute(0, 3, 1, 2)
+        assert g.shape == r.shape, (k, g.shape, r.shape)
+        d = (g - r).norm().item() / max(r.norm().item(), 1e-12)
+        worst = max(worst, d)
+        assert d <= 1e-4, (k, d)
+        checked += 1
+    assert checked >= 20, checked
+    print(f"\nf32 mode AblationMetaArch {which}: {checked} head parameter gradients, worst relative distance to the fp32 oracle head {worst:.2e}")
+
+
 def test_bf16_only_devices_refuse_in_f32_mode(cuda, f32mode):
     """No silent precision mixing: what exists only on the bf16 product path raises in the validation mode."""
     from slenderobjdet_amd._C import SlenderHipError
