@@ -285,7 +285,64 @@ __global__ __launch_bounds__(1024) void sample_labels_kernel(const signed char* 
   if (tid == 0) counts[2 * n + kind] = k;
   // radix select of the k-th smallest key among this kind's members (k < members; otherwise every member is taken)
   unsigned long long prefix = 0, T = ~0ull;
+  bool done = false;
   if (k < members && k > 0) {
+    // k is tiny against the member count (256 of 1.6 M RPN anchors): ONE pass collects the members whose key falls under a threshold
+    // that ~8k of them are expected to pass, and the k-th smallest is selected among those in LDS.  The keys are uniform 64-bit hashes,
+    // so the count is Poisson(8k); should it come out below k or above the buffer, the full 8-pass select below runs instead - the
+    // threshold changes only the work, never T.
+    constexpr int CAP = 4096;
+    __shared__ unsigned long long cand[CAP];
+    __shared__ int ncand;
+    const double frac = 8.0 * (double)k / (double)members;
+    if (frac < 0.5 && 8 * k + 64 <= CAP) {
+      const unsigned long long thr = (unsigned long long)(frac * 18446744073709551616.0);
+      if (tid == 0) ncand = 0;
+      __syncthreads();
+      for (int i = tid; i < R; i += 1024) {
+        const int v = L[i];
+        const bool mem = kind == 0 ? (v != -1 && v != bg) : (v == bg);
+        if (!mem) continue;
+        const unsigned long long key = sample_key(seed, n, kind, (uint32_t)i);
+        if (key < thr) {
+          const int p = atomicAdd(&ncand, 1);
+          if (p < CAP) cand[p] = key;
+        }
+      }
+      __syncthreads();
+      const int m = ncand;
+      if (m >= k && m <= CAP) {
+        int kk = k;
+        for (int pass = 7; pass >= 0; --pass) {
+          for (int b = tid; b < 256; b += 1024) hist[b] = 0;
+          __syncthreads();
+          const int shift = pass * 8;
+          for (int i = tid; i < m; i += 1024) {
+            const unsigned long long key = cand[i];
+            if (pass == 7 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+          }
+          __syncthreads();
+          if (tid == 0) {
+            int acc = 0, b = 0;
+            for (; b < 256; ++b) {
+              if (acc + hist[b] >= kk) break;
+              acc += hist[b];
+            }
+            s_bin = b; s_k = kk - acc;
+          }
+          __syncthreads();
+          prefix |= (unsigned long long)s_bin << shift;
+          kk = s_k;
+          __syncthreads();
+        }
+        T = prefix;
+        done = true;
+      } else {
+        prefix = 0;
+      }
+    }
+  }
+  if (k < members && k > 0 && !done) {
     int kk = k;      // rank (1-based) still to find inside the current prefix
     for (int pass = 7; pass >= 0; --pass) {
       for (int b = tid; b < 256; b += 1024) hist[b] = 0;
