@@ -31,78 +31,120 @@ __device__ __forceinline__ P2 psub(P2 a, P2 b) { return P2{a.x - b.x, a.y - b.y}
 __device__ __forceinline__ float pcross(P2 a, P2 b) { return a.x * b.y - b.x * a.y; }
 __device__ __forceinline__ float pdot(P2 a, P2 b) { return a.x * b.x + a.y * b.y; }
 
-__device__ __forceinline__ void rot_vertices(float cx, float cy, float w, float h, float ang, P2* pts) {
-  const float theta = ang * 0.01745329251994329577f;
-  const float c2 = cosf(theta) * 0.5f, s2 = sinf(theta) * 0.5f;
+__device__ __forceinline__ void rot_vertices(float cx, float cy, float w, float h, float cs, float sn, P2* pts) {
+  const float c2 = cs * 0.5f, s2 = sn * 0.5f;      // cs / sn = cosf / sinf of the angle in radians (computed once by the caller)
   pts[0] = P2{cx + s2 * h + c2 * w, cy + c2 * h - s2 * w};
   pts[1] = P2{cx - s2 * h + c2 * w, cy - c2 * h - s2 * w};
   pts[2] = P2{2.f * cx - pts[0].x, 2.f * cy - pts[0].y};
   pts[3] = P2{2.f * cx - pts[1].x, 2.f * cy - pts[1].y};
 }
 
-__device__ float rot_intersection_area(const P2* p1, const P2* p2) {
-  P2 inter[24];
+// Where the up-to-24 candidate points of the clipping live.  A private array is indexed dynamically and therefore sits in SCRATCH memory
+// (400 B per lane): the bubble sort and the Graham scan below then make a few hundred trips to memory per box pair - measured ~50 000 cycles
+// per pair and lane.  The hot kernels hand in a slice of LDS instead (point k of thread t at [k * stride + t]).
+struct RotPtsPrivate {
+  P2 v[24];
+  __device__ __forceinline__ P2 get(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, P2 p) { v[i] = p; }
+};
+struct RotPtsLds {
+  P2* base; int stride;
+  __device__ __forceinline__ P2 get(int i) const { return base[i * stride]; }
+  __device__ __forceinline__ void set(int i, P2 p) { base[i * stride] = p; }
+};
+
+// detectron2's rotated-box intersection (box_iou_rotated_utils.h), the same candidate points, the same bubble sort by polar angle and the
+// same Graham scan in the same order - the result must match the reference's to the bit wherever a threshold decides a label or a keep.
+template <class PTS>
+__device__ __forceinline__ float rot_intersection_area(const P2* p1, const P2* p2, PTS& q) {
   int num = 0;
   P2 v1[4], v2[4];
+#pragma unroll
   for (int i = 0; i < 4; ++i) { v1[i] = psub(p1[(i + 1) & 3], p1[i]); v2[i] = psub(p2[(i + 1) & 3], p2[i]); }
+#pragma unroll
   for (int i = 0; i < 4; ++i)
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float det = pcross(v2[j], v1[i]);
       if (fabsf(det) <= 1e-14f) continue;
       const P2 v12 = psub(p2[j], p1[i]);
       const float t1 = pcross(v2[j], v12) / det, t2 = pcross(v1[i], v12) / det;
-      if (t1 >= 0.f && t1 <= 1.f && t2 >= 0.f && t2 <= 1.f) inter[num++] = P2{p1[i].x + v1[i].x * t1, p1[i].y + v1[i].y * t1};
+      if (t1 >= 0.f && t1 <= 1.f && t2 >= 0.f && t2 <= 1.f) q.set(num++, P2{p1[i].x + v1[i].x * t1, p1[i].y + v1[i].y * t1});
     }
   {
     const P2 AB = v2[0], DA = v2[3];
     const float ABAB = pdot(AB, AB), ADAD = pdot(DA, DA);
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
       const P2 AP = psub(p1[i], p2[0]);
       const float apab = pdot(AP, AB), apad = -pdot(AP, DA);
-      if (apab >= 0.f && apad >= 0.f && apab <= ABAB && apad <= ADAD) inter[num++] = p1[i];
+      if (apab >= 0.f && apad >= 0.f && apab <= ABAB && apad <= ADAD) q.set(num++, p1[i]);
     }
   }
   {
     const P2 AB = v1[0], DA = v1[3];
     const float ABAB = pdot(AB, AB), ADAD = pdot(DA, DA);
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
       const P2 AP = psub(p2[i], p1[0]);
       const float apab = pdot(AP, AB), apad = -pdot(AP, DA);
-      if (apab >= 0.f && apad >= 0.f && apab <= ABAB && apad <= ADAD) inter[num++] = p2[i];
+      if (apab >= 0.f && apad >= 0.f && apab <= ABAB && apad <= ADAD) q.set(num++, p2[i]);
     }
   }
   if (num <= 2) return 0.f;
   // Graham scan
   int t = 0;
-  for (int i = 1; i < num; ++i)
-    if (inter[i].y < inter[t].y || (inter[i].y == inter[t].y && inter[i].x < inter[t].x)) t = i;
-  const P2 start = inter[t];
-  P2 q[24];
-  for (int i = 0; i < num; ++i) q[i] = psub(inter[i], start);
-  { const P2 tmp = q[0]; q[0] = q[t]; q[t] = tmp; }
-  for (int i = 1; i < num - 1; ++i)          // bubble sort by polar angle around q[0] (as the CUDA path of detectron2)
-    for (int j = 1; j < num - i; ++j) {
-      const float c = pcross(q[j], q[j + 1]);
-      const bool swap = (c < -1e-6f) || (fabsf(c) < 1e-6f && pdot(q[j], q[j]) > pdot(q[j + 1], q[j + 1]));
-      if (swap) { const P2 tmp = q[j]; q[j] = q[j + 1]; q[j + 1] = tmp; }
+  {
+    P2 best = q.get(0);
+    for (int i = 1; i < num; ++i) {
+      const P2 c = q.get(i);
+      if (c.y < best.y || (c.y == best.y && c.x < best.x)) { t = i; best = c; }
     }
+    // q[i] = inter[i] - start, in place, then q[0] <-> q[t]
+    for (int i = 0; i < num; ++i) q.set(i, psub(q.get(i), best));
+    const P2 tmp = q.get(0); q.set(0, q.get(t)); q.set(t, tmp);
+  }
+  for (int i = 1; i < num - 1; ++i) {        // bubble sort by polar angle around q[0] (as the CUDA path of detectron2)
+    P2 cur = q.get(1);
+    for (int j = 1; j < num - i; ++j) {
+      const P2 nxt = q.get(j + 1);
+      const float c = pcross(cur, nxt);
+      const bool swap = (c < -1e-6f) || (fabsf(c) < 1e-6f && pdot(cur, cur) > pdot(nxt, nxt));
+      if (swap) { q.set(j, nxt); }            // cur moves up to j + 1
+      else { q.set(j, cur); cur = nxt; }
+    }
+    q.set(num - i, cur);
+  }
   int k = 1;
-  for (; k < num; ++k)
-    if (pdot(q[k], q[k]) > 1e-8f) break;
+  for (; k < num; ++k) {
+    const P2 c = q.get(k);
+    if (pdot(c, c) > 1e-8f) break;
+  }
   if (k == num) return 0.f;
-  q[1] = q[k];
+  q.set(1, q.get(k));
   int m = 2;
   for (int i = k + 1; i < num; ++i) {
-    while (m > 1 && pcross(psub(q[i], q[m - 2]), psub(q[m - 1], q[m - 2])) >= 0.f) --m;
-    q[m++] = q[i];
+    const P2 qi = q.get(i);
+    while (m > 1) {
+      const P2 b2 = q.get(m - 2);
+      if (pcross(psub(qi, b2), psub(q.get(m - 1), b2)) >= 0.f) --m; else break;
+    }
+    q.set(m++, qi);
   }
   if (m <= 2) return 0.f;
   float area = 0.f;
-  for (int i = 1; i < m - 1; ++i) area += fabsf(pcross(psub(q[i], q[0]), psub(q[i + 1], q[0])));
+  const P2 q0 = q.get(0);
+  P2 prev = q.get(1);
+  for (int i = 1; i < m - 1; ++i) {
+    const P2 nx = q.get(i + 1);
+    area += fabsf(pcross(psub(prev, q0), psub(nx, q0)));
+    prev = nx;
+  }
   return area / 2.f;
 }
 
-__device__ float iou_rotated(const float* a, const float* b) {
+template <class PTS>
+__device__ __forceinline__ float iou_rotated_impl(const float* a, const float* b, PTS& pts) {
   const float area1 = a[2] * a[3], area2 = b[2] * b[3];
   if (area1 < 1e-14f || area2 < 1e-14f) return 0.f;
   {   // disjoint circumscribed circles => empty intersection => IoU exactly 0 (skips the polygon clipping for almost every pair)
@@ -111,12 +153,42 @@ __device__ float iou_rotated(const float* a, const float* b) {
     const float rs = ra + rb;
     if (dx * dx + dy * dy > rs * rs * 1.0001f) return 0.f;
   }
+  const float tha = a[4] * 0.01745329251994329577f, thb = b[4] * 0.01745329251994329577f;
+  const float ca = cosf(tha), sa = sinf(tha), cb = cosf(thb), sb = sinf(thb);
+  {   // Separating-axis test on the four face normals (w axis (cos, -sin), h axis (sin, cos) as in rot_vertices): rectangles separated by a
+      // margin have no edge crossing and no contained vertex, so the clipping below returns EXACTLY 0 - provided its own arithmetic cannot
+      // invent a crossing: a computed crossing point is off by ~eps * |p2 - p1| / sin(angle between the edges), which stays below the
+      // margin unless the edges are within ~1 degree of parallel.  Hence only for boxes at least a pixel thick whose axes are more than
+      // ~3 degrees from parallel / perpendicular; everything else takes the full computation as before.
+    const float c = ca * cb + sa * sb, s2 = sa * cb - ca * sb;        // cos / sin of (angle a - angle b)
+    const float ac = fabsf(c), as = fabsf(s2);
+    if (ac > 0.05f && as > 0.05f && fminf(fminf(a[2], a[3]), fminf(b[2], b[3])) >= 1.f) {
+      const float dx = b[0] - a[0], dy = b[1] - a[1];
+      const float m = 0.05f + 1e-4f * (a[2] + a[3] + b[2] + b[3]);
+      const float hwa = 0.5f * a[2], hha = 0.5f * a[3], hwb = 0.5f * b[2], hhb = 0.5f * b[3];
+      if (fabsf(dx * ca - dy * sa) > hwa + hwb * ac + hhb * as + m) return 0.f;
+      if (fabsf(dx * sa + dy * ca) > hha + hwb * as + hhb * ac + m) return 0.f;
+      if (fabsf(dx * cb - dy * sb) > hwb + hwa * ac + hha * as + m) return 0.f;
+      if (fabsf(dx * sb + dy * cb) > hhb + hwa * as + hha * ac + m) return 0.f;
+    }
+  }
   const float sx = (a[0] + b[0]) / 2.f, sy = (a[1] + b[1]) / 2.f;   // centre shift for precision
   P2 p1[4], p2[4];
-  rot_vertices(a[0] - sx, a[1] - sy, a[2], a[3], a[4], p1);
-  rot_vertices(b[0] - sx, b[1] - sy, b[2], b[3], b[4], p2);
-  const float inter = rot_intersection_area(p1, p2);
+  rot_vertices(a[0] - sx, a[1] - sy, a[2], a[3], ca, sa, p1);
+  rot_vertices(b[0] - sx, b[1] - sy, b[2], b[3], cb, sb, p2);
+  const float inter = rot_intersection_area(p1, p2, pts);
   return inter / (area1 + area2 - inter);
+}
+
+__device__ float iou_rotated(const float* a, const float* b) {          // candidate points in a private (scratch) array
+  RotPtsPrivate pts;
+  return iou_rotated_impl(a, b, pts);
+}
+
+// candidate points in LDS: ``lds`` = this thread's first slot of a [24][stride] P2 array shared by the ``stride`` threads of the workgroup
+__device__ float iou_rotated_lds(const float* a, const float* b, P2* lds, int stride) {
+  RotPtsLds pts{lds, stride};
+  return iou_rotated_impl(a, b, pts);
 }
 
 // Cheap NECESSARY conditions for IoU(a, b) > thr between two rotated boxes (cx, cy, w, h, angle) - the NMS kernels run the polygon clipping
@@ -312,6 +384,7 @@ __global__ __launch_bounds__(64) void nms_mask_batched_kernel(const float* __res
     // heavily: nearly all 64 columns, 9.1 ms per step for 16 x 10 000 candidates).  Instead: circle test for all 64 x 64 pairs (no
     // divergence), the surviving pairs compacted through LDS and dealt out evenly over the lanes, results OR-ed into the rows' words.
     __shared__ float rbox[64 * BD];
+    __shared__ P2 rot_pts[24 * 64];
     __shared__ float ccs[64 * 2];
     __shared__ unsigned short pairs[64 * 64];
     __shared__ unsigned long long rbits[64];
@@ -355,7 +428,7 @@ __global__ __launch_bounds__(64) void nms_mask_batched_kernel(const float* __res
       float ar[BD];
 #pragma unroll
       for (int e = 0; e < BD; ++e) ar[e] = rbox[r * BD + e];
-      if (iou_rotated(ar, cbox + j * BD) > thr) atomicOr(&rbits[r], 1ull << j);
+      if (iou_rotated_lds(ar, cbox + j * BD, rot_pts + lane, 64) > thr) atomicOr(&rbits[r], 1ull << j);
     }
     __syncthreads();
     if (i < n) mask[(long long)i * words + cb] = rbits[lane];
@@ -598,14 +671,26 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(const RoiArgs a
     for (int tx = wx0; tx <= wx1; tx += ROI_T) {
       for (int i = tid; i < ROI_T * ROI_T * PS; i += 256) win[i] = 0;
       __syncthreads();
-      for (int bin = bl; bin < nb; bin += 256 / L) {
+      // work item = one ROW of a bin's sample grid (bin, iy), dealt out over the 256 / L lane groups.  A row whose bounding box (+2 px: the
+      // bilinear neighbour and the clamp into the map) misses this tile is skipped before anything is loaded: with the adaptive sampling
+      // ratio (ceil(roi / 7) samples per bin side) a large ROI has ~1 sample per feature pixel, and visiting every sample for every
+      // 16x16 tile of its footprint made the work quadratic in the ROI's area (3.4 ms per step for the rotated R-CNN's 8192 ROIs).
+      for (int item = bl; item < nb * gh; item += 256 / L) {
+        const int bin = item / gh, iy = item - bin * gh;
         const int ph = bin / a.PW, pw = bin - ph * a.PW;
+        const float yy = start_h + ph * bin_h + (iy + 0.5f) * bin_h / (float)gh;
+        {
+          const float xa = start_w + pw * bin_w + 0.5f * bin_w / (float)gw, xb = start_w + pw * bin_w + ((float)gw - 0.5f) * bin_w / (float)gw;
+          float ya0 = yy, xa0 = xa, yb0 = yy, xb0 = xb;
+          if (a.rotated) { ya0 = yy * cth - xa * sth + ctr_h; xa0 = yy * sth + xa * cth + ctr_w; yb0 = yy * cth - xb * sth + ctr_h; xb0 = yy * sth + xb * cth + ctr_w; }
+          if (fmaxf(xa0, xb0) + 2.f < (float)tx || fminf(xa0, xb0) - 2.f > (float)(tx + ROI_T - 1) ||
+              fmaxf(ya0, yb0) + 2.f < (float)ty || fminf(ya0, yb0) - 2.f > (float)(ty + ROI_T - 1)) continue;
+        }
         const float* gp = dout + ((long long)r * nb + bin) * a.C + c0 + cl * 8;
         float g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] = gp[e] * S;
-        for (int iy = 0; iy < gh; ++iy) {
-          const float yy = start_h + ph * bin_h + (iy + 0.5f) * bin_h / (float)gh;
+        {
           for (int ix = 0; ix < gw; ++ix) {
             const float xx = start_w + pw * bin_w + (ix + 0.5f) * bin_w / (float)gw;
             float y = yy, x = xx;
@@ -744,7 +829,8 @@ __global__ __launch_bounds__(256) void anchor_match1_kernel(const float* __restr
     for (int g = 0; g < G; ++g) {
       const float v = match_iou<D>(gts + g * D, a);
       if (v > bv) { bv = v; bi = g; }            // first maximum wins (torch.max(dim=0))
-      atomicMax(&lbest[g], __float_as_uint(v));  // v >= 0: uint order == float order
+      if (v > 0.f) atomicMax(&lbest[g], __float_as_uint(v));  // v >= 0: uint order == float order; lbest starts at 0, so a zero changes nothing
+                                                             // (and almost every pair is a zero: 256 threads on one LDS word serialise)
     }
     best_val[i] = bv; best_idx[i] = bi;
   }
@@ -752,11 +838,77 @@ __global__ __launch_bounds__(256) void anchor_match1_kernel(const float* __restr
   for (int g = threadIdx.x; g < G; g += 256) atomicMax(&gt_best_bits[g], lbest[g]);
 }
 
+// Rotated boxes: anchor_match1_kernel<5> above pays the polygon clipping per WAVE for every box some lane is near (64 consecutive anchors =
+// 3.5 locations x 18 shapes: near a box that is every wave, 150 of its 200 us for the 1.6 M RRPN anchors).  This variant tests all (anchor,
+// box) pairs of a 256-anchor chunk with the circle test only, compacts the survivors through LDS and deals them out evenly over the
+// threads; per-anchor maximum with "first maximum wins" = 64-bit LDS atomicMax of (IoU bits, ~box index).  Same values, same argmax.
+__global__ __launch_bounds__(256) void anchor_match1_rot_kernel(const float* __restrict__ gts, int G, const float* __restrict__ anchors, int A,
+                                                                float* __restrict__ best_val, int* __restrict__ best_idx,
+                                                                unsigned* __restrict__ gt_best_bits) {
+  extern __shared__ unsigned lbest[];   // [G]
+  constexpr int GS = 8;                 // boxes per round: at most 256 * GS pairs
+  __shared__ unsigned pairs[256 * GS];
+  __shared__ P2 rot_pts[24 * 256];      // 48 KB: the clipping's candidate points (see RotPtsLds)
+  __shared__ unsigned long long abest[256];
+  __shared__ int npairs;
+  const int tid = threadIdx.x;
+  for (int g = tid; g < G; g += 256) lbest[g] = 0u;
+  const int chunks = (A + 255) / 256;
+  for (int ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+    const int i = ch * 256 + tid;
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i < A) {
+#pragma unroll
+      for (int e = 0; e < 5; ++e) a[e] = anchors[(long long)i * 5 + e];
+    }
+    const float ra = 0.5f * sqrtf(a[2] * a[2] + a[3] * a[3]);
+    const bool live = i < A && a[2] * a[3] >= 1e-14f;
+    abest[tid] = 0x00000000FFFFFFFFull;          // IoU 0 with box 0: what "v > bv" from bv = -1 leaves when every IoU is 0
+    for (int g0 = 0; g0 < G; g0 += GS) {
+      if (tid == 0) npairs = 0;
+      __syncthreads();
+      if (live) {
+        const int g1 = min(G, g0 + GS);
+        for (int g = g0; g < g1; ++g) {
+          const float* b = gts + g * 5;
+          // the two early returns of iou_rotated: a pair dropped here has IoU exactly 0 there
+          const float dx = b[0] - a[0], dy = b[1] - a[1], rs = ra + 0.5f * sqrtf(b[2] * b[2] + b[3] * b[3]);
+          if (b[2] * b[3] >= 1e-14f && dx * dx + dy * dy <= rs * rs * 1.0001f) pairs[atomicAdd(&npairs, 1)] = ((unsigned)tid << 16) | (unsigned)(g - g0);
+        }
+      }
+      __syncthreads();
+      const int np = npairs;
+      for (int t = tid; t < np; t += 256) {
+        const unsigned pr = pairs[t];
+        const int la = (int)(pr >> 16), g = g0 + (int)(pr & 0xffffu);
+        float aa[5];
+#pragma unroll
+        for (int e = 0; e < 5; ++e) aa[e] = anchors[((long long)ch * 256 + la) * 5 + e];
+        const float v = fmaxf(iou_rotated_lds(gts + g * 5, aa, rot_pts + tid, 256), 0.f);
+        if (v > 0.f) {
+          atomicMax(&abest[la], ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)g));
+          atomicMax(&lbest[g], __float_as_uint(v));
+        }
+      }
+      __syncthreads();
+    }
+    if (i < A) {
+      const unsigned long long bb = abest[tid];
+      best_val[i] = __uint_as_float((unsigned)(bb >> 32));
+      best_idx[i] = (int)(0xFFFFFFFFu - (unsigned)(bb & 0xFFFFFFFFull));
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int g = tid; g < G; g += 256) atomicMax(&gt_best_bits[g], lbest[g]);
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void anchor_match2_kernel(const float* __restrict__ gts, int G, const float* __restrict__ anchors, int A,
                                                             const float* __restrict__ best_val, const unsigned* __restrict__ gt_best_bits,
                                                             float lo, float hi, int l0, int l1, int l2, int low_quality,
                                                             signed char* __restrict__ labels) {
+  __shared__ P2 rot_pts[D == 5 ? 24 * 256 : 1];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < A; i += gridDim.x * 256) {
     const float v = best_val[i];
     int lab = (v < lo) ? l0 : ((v < hi) ? l1 : l2);
@@ -764,8 +916,12 @@ __global__ __launch_bounds__(256) void anchor_match2_kernel(const float* __restr
       float a[D];
 #pragma unroll
       for (int e = 0; e < D; ++e) a[e] = anchors[(long long)i * D + e];
-      for (int g = 0; g < G; ++g)
-        if (match_iou<D>(gts + g * D, a) == __uint_as_float(gt_best_bits[g])) { lab = 1; break; }
+      for (int g = 0; g < G; ++g) {
+        float v;
+        if constexpr (D == 5) v = fmaxf(iou_rotated_lds(gts + g * D, a, rot_pts + threadIdx.x, 256), 0.f);
+        else v = match_iou<D>(gts + g * D, a);
+        if (v == __uint_as_float(gt_best_bits[g])) { lab = 1; break; }
+      }
     }
     labels[i] = (signed char)lab;
   }
@@ -1075,7 +1231,9 @@ static int anchor_match_impl(const float* gt_boxes, int G, const float* anchors,
   hipError_t e = hipMemsetAsync(gt_best_ws, 0, sizeof(unsigned) * G, st);
   if (e != hipSuccess) return (int)e;
   const int g = nblk(A, 2048);
-  SOD_LAUNCH(anchor_match1_kernel<D>, dim3(g), dim3(256), sizeof(unsigned) * G, st, gt_boxes, G, anchors, A, matched_vals, matches, gt_best_ws);
+  static const int rot_plain = getenv("SOD_ANCHOR_MATCH_PLAIN") ? atoi(getenv("SOD_ANCHOR_MATCH_PLAIN")) : 0;      // A/B switch
+  if (D == 5 && !rot_plain) SOD_LAUNCH(anchor_match1_rot_kernel, dim3(g), dim3(256), sizeof(unsigned) * G, st, gt_boxes, G, anchors, A, matched_vals, matches, gt_best_ws);
+  else SOD_LAUNCH(anchor_match1_kernel<D>, dim3(g), dim3(256), sizeof(unsigned) * G, st, gt_boxes, G, anchors, A, matched_vals, matches, gt_best_ws);
   SOD_LAUNCH(anchor_match2_kernel<D>, dim3(g), dim3(256), 0, st, gt_boxes, G, anchors, A, matched_vals, gt_best_ws, thr_lo, thr_hi,
              label_below, label_between, label_above, allow_low_quality, labels);
   SOD_CHECK_LAUNCH();
