@@ -220,6 +220,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   if (cb < rb) return;   // only the upper triangle is ever read
   __shared__ float cbox[64 * BD];
   __shared__ float crad[64];      // rotated: circumscribed-circle radius of each column box
+  __shared__ P2 rot_pts[BD == 5 ? 24 * 64 : 1];
   const int lane = threadIdx.x;
   const int cj = cb * 64 + lane;
   if (cj < n) {
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     if (BD == 4) hit = iou_gt(a, cbox + j * BD, thr);
     else {
       const float dx = a[0] - cbox[j * BD], dy = a[1] - cbox[j * BD + 1], rs = ra + crad[j];
-      hit = (dx * dx + dy * dy <= rs * rs * 1.0001f) && (iou_rotated(a, cbox + j * BD) > thr);   // disjoint circles: IoU is exactly 0
+      hit = (dx * dx + dy * dy <= rs * rs * 1.0001f) && (iou_rotated_lds(a, cbox + j * BD, rot_pts + lane, 64) > thr);   // disjoint circles: IoU is exactly 0
     }
     if (hit) bits |= 1ull << j;
   }
@@ -253,9 +254,10 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void pairwise_iou_rotated_kernel(const float* __restrict__ b1, int n1, const float* __restrict__ b2, int n2,
                                                                    float* __restrict__ out) {
+  __shared__ P2 rot_pts[24 * 256];
   const long long total = (long long)n1 * n2;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
-    out[i] = iou_rotated(b1 + (i / n2) * 5, b2 + (i % n2) * 5);
+    out[i] = iou_rotated_lds(b1 + (i / n2) * 5, b2 + (i % n2) * 5, rot_pts + threadIdx.x, 256);
 }
 
 // single workgroup, boxes visited in score order in chunks of 64: wave 0 resolves a chunk against the chunk's own 64x64 diagonal
