@@ -68,3 +68,58 @@ def test_sgd_matches_torch_optim():
         opt.step()
         q, buf = onn.sgd_step(q, g, buf, 0.1, 0.9, 1e-2, first=(i == 0))
     assert torch.allclose(p.detach(), q, atol=1e-6)
+
+
+def test_oracle_retinanet_whole_step_is_consistent():
+    """oracle.model.OracleRetinaNet (the whole-step oracle of BASELINE configs[2]): its losses equal oracle.retinanet.losses on its own
+    predictions and labels, the float64 copy agrees with fp32 to 1e-5, and a directional finite difference in float64 matches autograd -
+    for both places detectron2 / the reference's FPN builder take P6 from (res5, P5)."""
+    from bench import make_cfg
+    from oracle import rcnn as orc
+    from oracle import retinanet as orn
+    from oracle.model import OracleRetinaNet
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+
+    for backbone in ("build_retinanet_resnet_fpn_backbone", "build_retinanet_resnet_fpn_backbone_use_p5"):
+        cfg = make_cfg(18, "retinanet")
+        cfg.MODEL.DEVICE = "cpu"
+        cfg.MODEL.BACKBONE.NAME = backbone
+        torch.manual_seed(0)
+        model = build_model(cfg)
+        data = synthetic_batch(1, 96, 128, 3, device="cpu")
+        o = OracleRetinaNet.from_hip_model(model)
+        assert o.c["p6_from"] == ("p5" if backbone.endswith("use_p5") else "res5")
+        got = o.losses(data)
+        with torch.no_grad():
+            feats = o._fpn(o._bottom_up(o.preprocess(data)))
+            logits, deltas = o.predictions(feats)
+            hw = [tuple(f.shape[2:]) for f in feats]
+            anchors = torch.cat(orc.anchors(hw, o.c["strides"], o.c["sizes"], o.c["ratios"], None, o.c["offset"]))
+            gl, gb = orn.label_anchors(anchors, [d["instances"].gt_boxes.tensor for d in data], [d["instances"].gt_classes for d in data],
+                                       o.c["thresholds"], o.c["labels"], 80)
+            ref, norm = orn.losses(anchors, logits, deltas, gl, gb, 80, 0.25, 2.0, o.c["beta"], o.c["weights"], 100.0)
+        assert abs(norm - o.new_normalizer) < 1e-9
+        for k in ref:
+            assert abs(float(got[k]) - float(ref[k])) <= 1e-6 * abs(float(ref[k])), k
+        o64 = OracleRetinaNet.from_hip_model(model).double()
+        l64 = o64.losses(data)
+        for k in ref:
+            assert abs(float(l64[k]) - float(got[k])) <= 1e-5 * abs(float(got[k])), k
+        # directional derivative of the total loss along a random direction of two tensors (one head, one backbone)
+        names = ["head.cls_subnet.0.conv.weight", "backbone.fpn_lateral4.weight"]
+        g = torch.autograd.grad(sum(l64.values()), [o64.p[n] for n in names])
+        gen = torch.Generator().manual_seed(1)
+        dirs = [torch.randn(o64.p[n].shape, generator=gen, dtype=torch.float64) for n in names]
+        analytic = sum(float((a * d).sum()) for a, d in zip(g, dirs))
+        eps, vals = 1e-9, []      # small against the distance to the nearest ReLU kink along the direction
+        for sign in (1.0, -1.0):
+            with torch.no_grad():
+                for n, d in zip(names, dirs):
+                    o64.p[n].add_(sign * eps * d)
+            vals.append(float(sum(o64.losses(data).values())))
+            with torch.no_grad():
+                for n, d in zip(names, dirs):
+                    o64.p[n].sub_(sign * eps * d)
+        numeric = (vals[0] - vals[1]) / (2 * eps)
+        assert abs(numeric - analytic) <= 1e-3 * max(abs(analytic), 1e-6), (numeric, analytic)
