@@ -324,7 +324,7 @@ def conv2d_fwd_ml(xs, w, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=
     return outs
 
 
-def conv_gn_fwd_ml(xs, w, bias, gamma, beta, G, eps=1e-5, relu=True, pad=1):
+def conv_gn_fwd_ml(xs, w, bias, gamma, beta, G, eps=1e-5, relu=True, pad=1, after_conv=None):
     """[conv (stride 1, bias) -> GroupNorm(G) -> ReLU] over several levels that share the weights, with the norm's statistics gathered
     in the conv epilogue (sod_conv2d_fwd_ml_gnsum) instead of a separate pass over the conv output.  Returns (conv outputs, norm
     outputs, stats (nl,N,G,2) = mean / rstd)."""
@@ -343,6 +343,8 @@ def conv_gn_fwd_ml(xs, w, bias, gamma, beta, G, eps=1e-5, relu=True, pad=1):
          1, pad, 1, 0, 0, ptr(stats), G, stream_ptr())
     fl = sum(2.0 * N * o.shape[1] * o.shape[2] * K * R * S * C for o in outs)
     _prof_end("conv_fwd", fl, e0, ("ml", N, tuple(hs), C, K, R, 1, tuple(ws)))
+    if after_conv is not None:      # called between the convolution and the normalisation launch (stream events of the caller)
+        after_conv()
     ys = [torch.empty_like(o) for o in outs]
     hw = [o.shape[1] * o.shape[2] for o in outs]
     call("sod_groupnorm_apply_ml", len(outs), _ptr_arr(outs), ptr(gamma), ptr(beta), _ptr_arr(ys), ptr(stats), N, ctypes.cast(_int_arr(hw), ctypes.c_void_p),

@@ -367,17 +367,41 @@ class ConvGnRelu(nn.Module):
         return out[0] if single else list(out)
 
 
+class ConvGate:
+    """EXPERIMENT (SOD_TOWER_GATE=1, modeling/meta_arch/fcos.py): serialises the CONVOLUTION launches of the two head towers across their
+    streams (each conv waits for the previous conv of the other tower), so that a tower's HBM-bound GroupNorm passes always run beside
+    the other tower's MFMA-bound convolution instead of beside its GroupNorm passes."""
+    current = None
+
+    def __init__(self):
+        self.last = None
+
+    def before_conv(self):
+        if self.last is not None:
+            torch.cuda.current_stream().wait_event(self.last)
+
+    def after_conv(self):
+        self.last = torch.cuda.Event()
+        self.last.record(torch.cuda.current_stream())
+
+
 class _ConvGnReluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, unit, prev_slot, *xs):
         conv, gn = unit.conv, unit.gn
         gw, gb = gn.weight.detach(), gn.bias.detach()
+        gate = ConvGate.current
+        if gate is not None:
+            gate.before_conv()
         if (GN_EPILOGUE_STATS and not HF.DETERMINISTIC and not HF.is_f32() and conv.out_channels == 8 * gn.num_groups and conv.bias_eff is not None
                 and conv.kernel_size == 3 and conv.stride == 1 and conv.padding == 1 and conv.dilation == 1):
             # the norm's statistics are gathered in the conv epilogue (float atomics: not for the deterministic mode)
-            y1s, y2s, stats = HF.conv_gn_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, gw, gb, gn.num_groups, gn.eps, relu=True)
+            y1s, y2s, stats = HF.conv_gn_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, gw, gb, gn.num_groups, gn.eps, relu=True,
+                                                after_conv=gate.after_conv if gate is not None else None)
         else:
             y1s = HF.conv2d_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, 1, 1, 1)
+            if gate is not None:
+                gate.after_conv()
             y2s, stats = HF.groupnorm_fwd_ml(y1s, gw, gb, gn.num_groups, gn.eps, relu=True)      # all levels in one launch per pass
         ctx.unit, ctx.nl = unit, len(xs)
         ctx.save_for_backward(*xs, *y1s, stats)

@@ -44,6 +44,10 @@ def _ceil8(v):
 # convs: 573.3-574.6 -> 583.1-584.1 img/s in a 4-round A/B, allocator pool 11.1 -> 14.9 GB and flat over 160 steps.
 # SOD_TOWER_STREAMS=0 keeps both towers on one stream.
 TOWER_STREAMS = os.environ.get("SOD_TOWER_STREAMS", "1") != "0"
+# EXPERIMENT (off): the convolutions of the two towers take turns (layers/nn.py ConvGate) so that a GroupNorm pass always runs beside a
+# convolution.  Measured SLOWER, 620.1 / 622.3 vs 625.8 / 625.4 img/s in one call: the hardware's own interleaving of the two queues
+# already does better than a forced alternation (which also idles one queue while it waits for the other's event).
+TOWER_GATE = os.environ.get("SOD_TOWER_GATE", "0") != "0"
 _tower_streams = {}
 _prefetch_streams = {}
 
@@ -135,10 +139,15 @@ class FCOSHead(nn.Module):
         for f in feats:
             f.record_stream(s2)
         pc = pb = None
-        for cu, bu in zip(self.cls_tower, self.bbox_tower):
-            with torch.cuda.stream(s2):
-                box_t, pb = run(bu, box_t, pb), bu
-            cls_t, pc = run(cu, cls_t, pc), cu
+        from ...layers import nn as _nn
+        _nn.ConvGate.current = _nn.ConvGate() if TOWER_GATE else None
+        try:
+            for cu, bu in zip(self.cls_tower, self.bbox_tower):
+                with torch.cuda.stream(s2):
+                    box_t, pb = run(bu, box_t, pb), bu
+                cls_t, pc = run(cu, cls_t, pc), cu
+        finally:
+            _nn.ConvGate.current = None
         main.wait_stream(s2)
         for t in box_t:
             t.record_stream(main)
