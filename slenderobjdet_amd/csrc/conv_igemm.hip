@@ -148,13 +148,16 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       rowbase[i] = (xoff[i] + ((uint32_t)xh[i] * (uint32_t)gWs + (uint32_t)xw[i]) * (uint32_t)a.Cred + (uint32_t)schunk * 8u) * 2u;
-      unsigned long long m = 0;
-      for (int r = 0; r < a.R; ++r)
-        for (int s2 = 0; s2 < a.S; ++s2) {
-          int h, w;
-          const uint32_t ok = src_coord(xh[i], r, gHs, h) & src_coord(xw[i], s2, gWs, w);
-          m |= (unsigned long long)(ok & 1u) << (r * a.S + s2);
-        }
+      // a tap is valid iff its row and its column are: R + S tests and an outer product of the two bit rows instead of R * S tests
+      unsigned long long m = 0, colbits = 0;
+      for (int s2 = 0; s2 < a.S; ++s2) {
+        int w;
+        colbits |= (unsigned long long)(src_coord(xw[i], s2, gWs, w) & 1u) << s2;
+      }
+      for (int r = 0; r < a.R; ++r) {
+        int h;
+        if (src_coord(xh[i], r, gHs, h) & 1u) m |= colbits << (r * a.S);
+      }
       tapmask[i] = m;
     }
 #pragma unroll

@@ -66,6 +66,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  // (One workgroup per tile.  A persistent variant - one workgroup per CU looping over tiles - measured equal, 344.3 vs 345.6 us per
+  // P3-sized launch: of the 12 us a tower-conv tile spends outside its 54-us K loop [s_memtime stamps: address set-up + first LDS-DMA
+  // requests 2.4 us, waiting for them 0.7 us, epilogue 6.9 us] none is workgroup dispatch.  tools/bench_tower_tile.py.)
   uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
   if (a.flags & F_REVERSE) bid = gridDim.x - 1 - bid;
   const int qt = bid % a.nq_tiles;
@@ -95,36 +98,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
       const int L = (j * 8 + wave) * 8 + srow;
       const int q = q0 + (L >> 6) * 128 + u * 64 + (L & 63);
       wbase[u][j] = (q < a.Nout) ? ((uint32_t)q * (uint32_t)a.Kred + (uint32_t)schunk * 8u) * 2u : SOD_OOB;
-      const uint32_t p = (uint32_t)(p0 + (L >> 5) * 64 + u * 32 + (L & 31));
-      uint32_t m = 0, rb = 0;
-      if (p < (uint32_t)gP) {
-        const uint32_t n = fd_div(p, g.div_hw);
-        const uint32_t rem = p - n * g.div_hw.d;
-        const uint32_t ph = fd_div(rem, g.div_w);
-        const uint32_t pw = rem - ph * g.div_w.d;
-        int xh, xw;
-        if (MODE == MODE_FWD) { xh = (int)ph * a.stride - a.pad; xw = (int)pw * a.stride - a.pad; }
-        else                  { xh = (int)ph + a.pad;            xw = (int)pw + a.pad; }
-        rb = (n * (uint32_t)g.src_img_stride + ((uint32_t)xh * (uint32_t)gWs + (uint32_t)xw) * (uint32_t)a.Cred + (uint32_t)schunk * 8u) * 2u;
-        for (int r = 0; r < a.R; ++r)
-          for (int s2 = 0; s2 < a.S; ++s2) {
-            const int h = (MODE == MODE_FWD) ? xh + r * a.dil : xh - r * a.dil;
-            const int w = (MODE == MODE_FWD) ? xw + s2 * a.dil : xw - s2 * a.dil;
-            const uint32_t ok = ((unsigned)h < (unsigned)gHs) & ((unsigned)w < (unsigned)gWs);
-            m |= ok << (r * a.S + s2);
-          }
-      }
-      rowbase[u][j] = rb; tapmask[u][j] = m;
     }
-  const int tap_sign = (MODE == MODE_FWD) ? 1 : -1;
-
-  // Loop-invariant scalars in registers (no kernarg reloads, i.e. no lgkmcnt waits, inside the K loop); branch-free staging:
-  // a dead K-tile (kt >= T) ORs the out-of-range bit into the weight offset and selects tap 31, whose mask bit is never set.
-  const uint32_t s_mul = a.div_s.mul, s_shr = a.div_s.shr;
+  // The weight units of K-tile 0 need nothing but wbase: they are requested BEFORE the pixel geometry below is worked out (two divisions
+  // and the tap masks for four rows per thread: ~2 us with nothing else on the CU), so their latency runs beside that arithmetic.
   const uint32_t rs_mul = a.div_rs.mul, rs_shr = a.div_rs.shr, rs_d = a.div_rs.d;
   const int aCred = a.Cred;
-  const int aS = a.S, row_step = a.dil * gWs * a.Cred * 2 * tap_sign, col_step = a.dil * a.Cred * 2 * tap_sign;
-
   auto stage_a = [&](int u, int kt) {     // weight rows of sub-block u (a0 / a1) of K-tile kt
     char* dst = smem + (kt & 1) * BUF + u * UNIT + wave * 1024;
     const bool live = kt < T;
@@ -139,6 +117,44 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, SOD_LDS(dst + j * 8192), 16, voff, 0, 0, 0);
     }
   };
+  stage_a(0, 0); stage_a(1, 0);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int L = (j * 8 + wave) * 8 + srow;
+      const uint32_t p = (uint32_t)(p0 + (L >> 5) * 64 + u * 32 + (L & 31));
+      uint32_t m = 0, rb = 0;
+      if (p < (uint32_t)gP) {
+        const uint32_t n = fd_div(p, g.div_hw);
+        const uint32_t rem = p - n * g.div_hw.d;
+        const uint32_t ph = fd_div(rem, g.div_w);
+        const uint32_t pw = rem - ph * g.div_w.d;
+        int xh, xw;
+        if (MODE == MODE_FWD) { xh = (int)ph * a.stride - a.pad; xw = (int)pw * a.stride - a.pad; }
+        else                  { xh = (int)ph + a.pad;            xw = (int)pw + a.pad; }
+        rb = (n * (uint32_t)g.src_img_stride + ((uint32_t)xh * (uint32_t)gWs + (uint32_t)xw) * (uint32_t)a.Cred + (uint32_t)schunk * 8u) * 2u;
+        // tap (r, s) is valid iff its row AND its column lie inside the source: R + S comparisons and an outer product of the two bit
+        // rows instead of R * S (this runs once per tile, with nothing else on the CU to hide it)
+        uint32_t colbits = 0;
+        for (int s2 = 0; s2 < a.S; ++s2) {
+          const int w = (MODE == MODE_FWD) ? xw + s2 * a.dil : xw - s2 * a.dil;
+          colbits |= (uint32_t)((unsigned)w < (unsigned)gWs) << s2;
+        }
+        for (int r = 0; r < a.R; ++r) {
+          const int h = (MODE == MODE_FWD) ? xh + r * a.dil : xh - r * a.dil;
+          if ((unsigned)h < (unsigned)gHs) m |= colbits << (r * a.S);
+        }
+      }
+      rowbase[u][j] = rb; tapmask[u][j] = m;
+    }
+  const int tap_sign = (MODE == MODE_FWD) ? 1 : -1;
+
+  // Loop-invariant scalars in registers (no kernarg reloads, i.e. no lgkmcnt waits, inside the K loop); branch-free staging:
+  // a dead K-tile (kt >= T) ORs the out-of-range bit into the weight offset and selects tap 31, whose mask bit is never set.
+  const uint32_t s_mul = a.div_s.mul, s_shr = a.div_s.shr;
+  const int aS = a.S, row_step = a.dil * gWs * a.Cred * 2 * tap_sign, col_step = a.dil * a.Cred * 2 * tap_sign;
+
   auto stage_b = [&](int u, int kt) {     // pixel rows of sub-block u (b0 / b1) of K-tile kt
     char* dst = smem + (kt & 1) * BUF + (2 + u) * UNIT + wave * 1024;
     const bool live = kt < T;
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
   };
 
   // ---- prologue: K-tile 0 complete, first two units of K-tile 1
-  stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
+  stage_b(0, 0); stage_b(1, 0);          // (both weight units of K-tile 0 are on their way since the top of the tile)
   stage_a(0, 1); stage_b(0, 1);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -251,14 +267,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
     size_t drow[NP];
     bool ok[NP];
     int nimg[NP];
+    // (image, pixel-in-image) of this lane's first row by one division, the following rows (ERPP pixels further each) by carry
+    const uint32_t pfirst = (uint32_t)(p0 + wc * 64 + jj * 16 + erow);
+    const uint32_t pc0 = pfirst < (uint32_t)gP ? pfirst : 0u;
+    uint32_t n_run = fd_div(pc0, g.div_hw);
+    uint32_t rem_run = pc0 - n_run * g.div_hw.d;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      const uint32_t p = (uint32_t)(p0 + wc * 64 + jj * 16 + k * ERPP + erow);
+      const uint32_t p = pfirst + (uint32_t)(k * ERPP);
       ok[k] = (p < (uint32_t)gP) && qok;
       drow[k] = 0;
+      const uint32_t n = n_run, rem = rem_run;
+      rem_run += (uint32_t)ERPP;
+      if (rem_run >= g.div_hw.d) { rem_run -= g.div_hw.d; ++n_run; }
       if (ok[k]) {
-        const uint32_t n = fd_div(p, g.div_hw);
-        const uint32_t rem = p - n * g.div_hw.d;
         nimg[k] = (int)n;
         drow[k] = (size_t)n * g.dst_img_stride + (size_t)rem * Nout;
         if (a.flags & (F_RES | F_RES_UP2)) {
