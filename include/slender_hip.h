@@ -568,8 +568,23 @@ int sod_corner_pool_bwd(const float* x, const float* dy, float* dx, long long pl
  * negatives.  No host synchronisation (the reference: two nonzero() + two randperm() per image). */
 int sod_sample_labels(const signed char* labels, int N, int R, int num_samples, float positive_fraction, int bg_label,
                       unsigned long long seed, signed char* out, int* counts, void* stream);
+/* the same draw + the drawn indices per image as an unordered list idx (N, num_samples) int32 (-1 padded); list_n: (N,) int32 scratch */
+int sod_sample_labels_list(const signed char* labels, int N, int R, int num_samples, float positive_fraction, int bg_label,
+                           unsigned long long seed, signed char* out, int* counts, int* idx, int* list_n, void* stream);
 /* indices of the sampled elements (mask == 1 first, then mask == 0, each in index order) into S slots per image, -1 padded; num (N) */
 int sod_compact_samples(const signed char* mask, int N, int R, int S, int* idx, int* num, void* stream);
+
+/* RPN.losses on the sampled anchors only (detectron2 rpn.py losses(): the sums run over the <= BATCH_SIZE_PER_IMAGE sampled anchors of an
+   image).  idx (N, S) int32 = sod_compact_samples' output over the sampled labels (anchor index in the concatenated (level, h, w, a)
+   order, -1 = empty slot).  gather: rows of the per-level padded NHWC head outputs (level l: hw[l] pixels per image, logit_pitch[l] >= A
+   and delta_pitch[l] >= A*D floats per pixel) -> row_logits (N, S), row_deltas (N, S, D).  scatter: the gradients of those rows back into
+   zero-initialised per-level tensors of the same shapes. */
+int sod_rpn_gather_sampled(int nlev, const void* const* logits, const void* const* deltas, const int* hw, const int* logit_pitch,
+                           const int* delta_pitch, const int* idx, int N, int S, int A, int D, float* row_logits, float* row_deltas,
+                           void* stream);
+int sod_rpn_scatter_sampled(int nlev, void* const* dlogits, void* const* ddeltas, const int* hw, const int* logit_pitch,
+                            const int* delta_pitch, const int* idx, int N, int S, int A, int D, const float* row_dlogits,
+                            const float* row_ddeltas, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------------------
  * fp32-STORAGE validation path (csrc/f32_path.hip; Python: SOD_PRECISION=fp32 / layers.functional.set_precision("fp32")).

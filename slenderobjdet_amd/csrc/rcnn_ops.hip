@@ -257,8 +257,11 @@ __device__ __forceinline__ unsigned long long sample_key(unsigned long long seed
   return (z & 0xFFFFFFFF00000000ull) | i;
 }
 
+// ``list`` (optional, (N, S) int32 filled with -1 by the caller) + ``list_n`` ((N,) int32, zeroed): the indices of the sampled elements
+// as they are found (unordered: positives and negatives are drawn by different workgroups); S = num_samples.
 __global__ __launch_bounds__(1024) void sample_labels_kernel(const signed char* __restrict__ lab, int R, int num_samples, int max_pos, int bg,
-                                                            unsigned long long seed, signed char* __restrict__ out, int* __restrict__ counts) {
+                                                            unsigned long long seed, signed char* __restrict__ out, int* __restrict__ counts,
+                                                            int* __restrict__ list, int* __restrict__ list_n) {
   __shared__ int hist[256];
   __shared__ int red[32];
   __shared__ int s_bin, s_k;
@@ -374,10 +377,16 @@ __global__ __launch_bounds__(1024) void sample_labels_kernel(const signed char* 
   for (int i = tid; i < R; i += 1024) {
     const int v = L[i];
     const bool pos = (v != -1 && v != bg), neg = (v == bg);
+    bool taken = false;
     if (kind == 0) {
-      if (!neg) O[i] = (pos && k > 0 && sample_key(seed, n, 0, (uint32_t)i) <= T) ? 1 : -1;     // positives and "other" elements
+      if (!neg) { taken = pos && k > 0 && sample_key(seed, n, 0, (uint32_t)i) <= T; O[i] = taken ? 1 : -1; }     // positives and "other" elements
     } else if (neg) {
-      O[i] = (k > 0 && sample_key(seed, n, 1, (uint32_t)i) <= T) ? 0 : -1;
+      taken = k > 0 && sample_key(seed, n, 1, (uint32_t)i) <= T;
+      O[i] = taken ? 0 : -1;
+    }
+    if (taken && list) {
+      const int p = atomicAdd(list_n + n, 1);
+      if (p < num_samples) list[(long long)n * num_samples + p] = i;
     }
   }
 }
@@ -540,7 +549,101 @@ extern "C" int sod_sample_labels(const signed char* labels, int N, int R, int nu
   if (!labels || !out || !counts || N <= 0 || R <= 0 || num_samples <= 0 || !(positive_fraction >= 0.f && positive_fraction <= 1.f)) return SOD_EARG;
   if (N > 65535) return SOD_ESIZE;
   const int max_pos = (int)(num_samples * positive_fraction);
-  SOD_LAUNCH(sample_labels_kernel, dim3(N, 2), dim3(1024), 0, (hipStream_t)stream, labels, R, num_samples, max_pos, bg_label, seed, out, counts);
+  SOD_LAUNCH(sample_labels_kernel, dim3(N, 2), dim3(1024), 0, (hipStream_t)stream, labels, R, num_samples, max_pos, bg_label, seed, out, counts,
+             (int*)nullptr, (int*)nullptr);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+// The same draw, and the indices of the drawn elements of every image as a list: idx (N, num_samples) int32, -1 padded, UNORDERED (sort the
+// rows for a run-to-run stable order); list_n (N,) int32 scratch.  For row counts where sod_compact_samples' scan over every element costs
+// more than the draw itself (RPN: 1.6 M anchors per image for 256 samples).
+extern "C" int sod_sample_labels_list(const signed char* labels, int N, int R, int num_samples, float positive_fraction, int bg_label,
+                                      unsigned long long seed, signed char* out, int* counts, int* idx, int* list_n, void* stream) {
+  if (!labels || !out || !counts || !idx || !list_n || N <= 0 || R <= 0 || num_samples <= 0 || !(positive_fraction >= 0.f && positive_fraction <= 1.f)) return SOD_EARG;
+  if (N > 65535) return SOD_ESIZE;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(idx, 0xff, sizeof(int) * (size_t)N * num_samples, st);
+  if (e == hipSuccess) e = hipMemsetAsync(list_n, 0, sizeof(int) * (size_t)N, st);
+  if (e != hipSuccess) return (int)e;
+  const int max_pos = (int)(num_samples * positive_fraction);
+  SOD_LAUNCH(sample_labels_kernel, dim3(N, 2), dim3(1024), 0, st, labels, R, num_samples, max_pos, bg_label, seed, out, counts, idx, list_n);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+// RPN losses on the SAMPLED anchors only (detectron2 RPN.losses sums over the <= BATCH_SIZE_PER_IMAGE sampled anchors of an image; the
+// other ~1.6 M rows of the dense (N, R) formulation are label -1).  Anchor r of the concatenated (level, h, w, a) order lives in level l
+// with start[l] <= r < start[l + 1], at pixel (r - start[l]) / A, anchor (r - start[l]) % A of that level's padded NHWC head output.
+constexpr int RPN_MAXLEV = 8;
+struct RpnLevelPtrs {
+  const float* logit[RPN_MAXLEV]; const float* delta[RPN_MAXLEV];     // gather sources (forward)
+  float* dlogit[RPN_MAXLEV]; float* ddelta[RPN_MAXLEV];               // scatter destinations (backward), zero-initialised by the caller
+  int start[RPN_MAXLEV + 1], hw[RPN_MAXLEV], pl[RPN_MAXLEV], pd[RPN_MAXLEV];
+  int nlev;
+};
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void rpn_sampled_rows_kernel(const RpnLevelPtrs L, const int* __restrict__ idx, int N, int S, int A, int D,
+                                                               float* __restrict__ row_logit, float* __restrict__ row_delta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * S) return;
+  const int n = i / S, r = idx[i];
+  if (r < 0) {                       // padding slot of an image with fewer samples
+    if (!SCATTER) { row_logit[i] = 0.f; for (int d = 0; d < D; ++d) row_delta[(long long)i * D + d] = 0.f; }
+    return;
+  }
+  int l = 0;
+  for (int k = 1; k < L.nlev; ++k)
+    if (r >= L.start[k]) l = k;
+  const int local = r - L.start[l], pix = local / A, a = local - pix * A;
+  const long long row = (long long)n * L.hw[l] + pix;
+  if (SCATTER) {
+    L.dlogit[l][row * L.pl[l] + a] = row_logit[i];
+    for (int d = 0; d < D; ++d) L.ddelta[l][row * L.pd[l] + a * D + d] = row_delta[(long long)i * D + d];
+  } else {
+    row_logit[i] = L.logit[l][row * L.pl[l] + a];
+    for (int d = 0; d < D; ++d) row_delta[(long long)i * D + d] = L.delta[l][row * L.pd[l] + a * D + d];
+  }
+}
+
+static int rpn_levels_fill(RpnLevelPtrs& L, int nlev, const void* const* logits, const void* const* deltas, const int* hw, const int* pl, const int* pd,
+                           int A, bool scatter) {
+  if (nlev <= 0 || nlev > RPN_MAXLEV || !logits || !deltas || !hw || !pl || !pd || A <= 0) return SOD_EARG;
+  L.nlev = nlev;
+  int start = 0;
+  for (int l = 0; l < nlev; ++l) {
+    if (!logits[l] || !deltas[l] || hw[l] <= 0 || pl[l] < A || pd[l] <= 0) return SOD_EARG;
+    if (scatter) { L.dlogit[l] = (float*)logits[l]; L.ddelta[l] = (float*)deltas[l]; }
+    else { L.logit[l] = (const float*)logits[l]; L.delta[l] = (const float*)deltas[l]; }
+    L.start[l] = start; L.hw[l] = hw[l]; L.pl[l] = pl[l]; L.pd[l] = pd[l];
+    start += hw[l] * A;
+  }
+  L.start[nlev] = start;
+  return SOD_OK;
+}
+
+extern "C" int sod_rpn_gather_sampled(int nlev, const void* const* logits, const void* const* deltas, const int* hw, const int* logit_pitch,
+                                      const int* delta_pitch, const int* idx, int N, int S, int A, int D, float* row_logits, float* row_deltas,
+                                      void* stream) {
+  RpnLevelPtrs L{};
+  int rc = rpn_levels_fill(L, nlev, logits, deltas, hw, logit_pitch, delta_pitch, A, false);
+  if (rc || !idx || !row_logits || !row_deltas || N <= 0 || S <= 0 || D <= 0) return rc ? rc : SOD_EARG;
+  for (int l = 0; l < nlev; ++l) if (delta_pitch[l] < A * D) return SOD_EARG;
+  SOD_LAUNCH(rpn_sampled_rows_kernel<false>, dim3((N * S + 255) / 256), dim3(256), 0, (hipStream_t)stream, L, idx, N, S, A, D, row_logits, row_deltas);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_rpn_scatter_sampled(int nlev, void* const* dlogits, void* const* ddeltas, const int* hw, const int* logit_pitch,
+                                       const int* delta_pitch, const int* idx, int N, int S, int A, int D, const float* row_dlogits,
+                                       const float* row_ddeltas, void* stream) {
+  RpnLevelPtrs L{};
+  int rc = rpn_levels_fill(L, nlev, (const void* const*)dlogits, (const void* const*)ddeltas, hw, logit_pitch, delta_pitch, A, true);
+  if (rc || !idx || !row_dlogits || !row_ddeltas || N <= 0 || S <= 0 || D <= 0) return rc ? rc : SOD_EARG;
+  for (int l = 0; l < nlev; ++l) if (delta_pitch[l] < A * D) return SOD_EARG;
+  SOD_LAUNCH(rpn_sampled_rows_kernel<true>, dim3((N * S + 255) / 256), dim3(256), 0, (hipStream_t)stream, L, idx, N, S, A, D,
+             const_cast<float*>(row_dlogits), const_cast<float*>(row_ddeltas));
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }

@@ -1113,6 +1113,23 @@ def sample_labels(labels, num_samples, positive_fraction, bg_label, seed=None):
     return out, counts
 
 
+def sample_labels_list(labels, num_samples, positive_fraction, bg_label, seed=None):
+    """sample_labels + the drawn indices of every row as (N, num_samples) int32, -1 padded, sorted descending (a run-to-run stable order;
+    the kernel emits them as it finds them).  For rows far longer than the draw (RPN anchors), where scanning every element a second time
+    to compact the mask would cost more than the draw."""
+    _chk(labels, torch.int8, "labels")
+    N, R = labels.shape
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    out = torch.empty_like(labels)
+    counts = torch.empty((N, 2), dtype=torch.int32, device=labels.device)
+    idx = torch.empty((N, int(num_samples)), dtype=torch.int32, device=labels.device)
+    scratch = torch.empty(N, dtype=torch.int32, device=labels.device)
+    call("sod_sample_labels_list", ptr(labels), N, R, int(num_samples), float(positive_fraction), int(bg_label), ctypes.c_ulonglong(seed), ptr(out),
+         ptr(counts), ptr(idx), ptr(scratch), stream_ptr())
+    return out, counts, torch.sort(idx, dim=1, descending=True).values.contiguous()
+
+
 def compact_samples(mask, slots):
     """Indices of the sampled elements of each row of ``mask`` (N, R) int8 - 1s first, then 0s, index order - as (N, slots) int32 padded
     with -1, and their number (N,) int32."""
@@ -1122,6 +1139,36 @@ def compact_samples(mask, slots):
     num = torch.empty(N, dtype=torch.int32, device=mask.device)
     call("sod_compact_samples", ptr(mask), N, R, int(slots), ptr(idx), ptr(num), stream_ptr())
     return idx, num
+
+
+def rpn_gather_sampled(logits_l, deltas_l, idx, A, D):
+    """Rows of the sampled anchors: per-level padded NHWC head outputs (N, H, W, pitch) fp32 + idx (N, S) int32 (anchor index in the
+    concatenated (level, h, w, a) order, -1 = empty slot) -> (N, S) logits, (N, S, D) deltas."""
+    _chk(idx, torch.int32, "idx")
+    for t in list(logits_l) + list(deltas_l):
+        _chk(t, torch.float32, "head output")
+    N, S = idx.shape
+    lg = torch.empty((N, S), dtype=torch.float32, device=idx.device)
+    dl = torch.empty((N, S, D), dtype=torch.float32, device=idx.device)
+    hw = [t.shape[1] * t.shape[2] for t in logits_l]
+    call("sod_rpn_gather_sampled", len(logits_l), _ptr_arr(logits_l), _ptr_arr(deltas_l), ctypes.cast(_int_arr(hw), ctypes.c_void_p),
+         ctypes.cast(_int_arr([t.shape[3] for t in logits_l]), ctypes.c_void_p), ctypes.cast(_int_arr([t.shape[3] for t in deltas_l]), ctypes.c_void_p),
+         ptr(idx), N, S, A, D, ptr(lg), ptr(dl), stream_ptr())
+    return lg, dl
+
+
+def rpn_scatter_sampled(shapes_l, shapes_d, idx, A, D, row_dlogits, row_ddeltas):
+    """The adjoint of rpn_gather_sampled: zero tensors of the head outputs' shapes with the sampled rows' gradients written in."""
+    _chk(idx, torch.int32, "idx"); _chk(row_dlogits, torch.float32, "row_dlogits"); _chk(row_ddeltas, torch.float32, "row_ddeltas")
+    N, S = idx.shape
+    dev = idx.device
+    gl = [torch.zeros(sh, dtype=torch.float32, device=dev) for sh in shapes_l]
+    gd = [torch.zeros(sh, dtype=torch.float32, device=dev) for sh in shapes_d]
+    hw = [sh[1] * sh[2] for sh in shapes_l]
+    call("sod_rpn_scatter_sampled", len(gl), _ptr_arr(gl), _ptr_arr(gd), ctypes.cast(_int_arr(hw), ctypes.c_void_p),
+         ctypes.cast(_int_arr([sh[3] for sh in shapes_l]), ctypes.c_void_p), ctypes.cast(_int_arr([sh[3] for sh in shapes_d]), ctypes.c_void_p),
+         ptr(idx), N, S, A, D, ptr(row_dlogits), ptr(row_ddeltas), stream_ptr())
+    return gl, gd
 
 
 # ----------------------------------------------------------------------------------------------- RepPoints

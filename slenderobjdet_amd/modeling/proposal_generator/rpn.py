@@ -67,44 +67,64 @@ class StandardRPNHead(nn.Module):
 
 
 class _RpnLossFn(torch.autograd.Function):
-    """RPN.losses over per-level padded head outputs -> [loss_rpn_cls, loss_rpn_loc] (before loss weights)."""
+    """RPN.losses over per-level padded head outputs -> [loss_rpn_cls, loss_rpn_loc] (before loss weights).  detectron2's sums run over
+    the sampled anchors (<= BATCH_SIZE_PER_IMAGE per image; everything else is label -1): the rows of those anchors are gathered from
+    the head outputs (sod_rpn_gather_sampled), the two loss kernels see (N, S) / (N, S, D) tensors, and backward scatters the row
+    gradients into zero tensors of the head outputs' shapes - instead of compacting, labelling and differentiating all ~1.6 M anchors
+    of an image (the dense formulation moved ~3 GB per step at batch 16)."""
 
     @staticmethod
-    def forward(ctx, rpn, gt_labels, gt_deltas, *outs):
+    def forward(ctx, rpn, idx, labels_s, deltas_s, *outs):
         nl = len(outs) // 2
-        logits, deltas = rpn.compact(outs[:nl], outs[nl:])
+        A, D = rpn.head.num_anchors, rpn.head.box_dim
+        outs = [o.contiguous() for o in outs]
+        logits, deltas = HF.rpn_gather_sampled(outs[:nl], outs[nl:], idx, A, D)
         N = logits.shape[0]
         norm = float(rpn.batch_size_per_image * N)
-        s_cls = HF.bce_logits_loss_fwd(logits, gt_labels)
-        s_loc = HF.rpn_loc_loss_fwd(deltas, gt_deltas, gt_labels, rpn.smooth_l1_beta)
+        s_cls = HF.bce_logits_loss_fwd(logits, labels_s)
+        s_loc = HF.rpn_loc_loss_fwd(deltas, deltas_s, labels_s, rpn.smooth_l1_beta)
         ctx.rpn, ctx.nl, ctx.norm = rpn, nl, norm
         ctx.shapes = [tuple(o.shape) for o in outs]
-        ctx.save_for_backward(logits, deltas, gt_labels, gt_deltas)
+        ctx.save_for_backward(logits, deltas, labels_s, deltas_s, idx)
         return torch.cat([s_cls, s_loc]) / norm
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g2):
         rpn, nl = ctx.rpn, ctx.nl
-        logits, deltas, gt_labels, gt_deltas = ctx.saved_tensors
+        logits, deltas, labels_s, deltas_s, idx = ctx.saved_tensors
         g2 = g2.contiguous().float()
-        dl = HF.bce_logits_loss_bwd(logits, gt_labels, g2[0:1], 1.0 / ctx.norm)
-        dd = HF.rpn_loc_loss_bwd(deltas, gt_deltas, gt_labels, rpn.smooth_l1_beta, g2[1:2], 1.0 / ctx.norm)
-        A, D = rpn.head.num_anchors, rpn.head.box_dim
-        N = logits.shape[0]
-        g_log, g_del, off = [], [], 0
-        for l in range(nl):
-            _, H, W, pl = ctx.shapes[l]
-            pd = ctx.shapes[nl + l][3]
-            n = H * W * A
-            a = torch.zeros((N, H, W, pl), dtype=torch.float32, device=logits.device)
-            a[..., :A] = dl[:, off:off + n].view(N, H, W, A)
-            b = torch.zeros((N, H, W, pd), dtype=torch.float32, device=logits.device)
-            b[..., :A * D] = dd[:, off:off + n].reshape(N, H, W, A * D)
-            g_log.append(a)
-            g_del.append(b)
-            off += n
-        return (None, None, None, *g_log, *g_del)
+        dl = HF.bce_logits_loss_bwd(logits, labels_s, g2[0:1], 1.0 / ctx.norm)
+        dd = HF.rpn_loc_loss_bwd(deltas, deltas_s, labels_s, rpn.smooth_l1_beta, g2[1:2], 1.0 / ctx.norm)
+        g_log, g_del = HF.rpn_scatter_sampled(ctx.shapes[:nl], ctx.shapes[nl:], idx, rpn.head.num_anchors, rpn.head.box_dim, dl, dd)
+        return (None, None, None, None, *g_log, *g_del)
+
+
+class _RpnTargets:
+    """What RPN.forward keeps of its targets (``RPN.last_targets``): the sampled labels (N, R) and, on demand, the dense matched boxes /
+    deltas detectron2's formulation carries (tests and the oracle comparison read them; the training step itself only needs the sampled
+    rows).  Iterates as (gt_labels, matched_gt_boxes, gt_deltas)."""
+
+    def __init__(self, rpn, anchors, labels, matches, gt_cat, gt_off):
+        self.rpn, self.anchors, self.labels, self.matches, self.gt_cat, self.gt_off = rpn, anchors, labels, matches, gt_cat, gt_off
+
+    def dense(self):
+        N, R = self.labels.shape
+        D = self.anchors.shape[1]
+        matched = torch.zeros((N, R, D), dtype=torch.float32, device=self.labels.device)
+        for i in range(N):
+            lo, hi = self.gt_off[i], self.gt_off[i + 1]
+            if hi > lo:
+                matched[i] = self.gt_cat[lo:hi][self.matches[i].long()]
+        deltas = torch.stack([self.rpn.box2box_transform.get_deltas(self.anchors, m) for m in matched])
+        return matched, deltas
+
+    def __iter__(self):
+        matched, deltas = self.dense()
+        return iter((self.labels, matched, deltas))
+
+    def __getitem__(self, i):
+        return self.labels if i == 0 else self.dense()[i - 1]
 
 
 @PROPOSAL_GENERATOR_REGISTRY.register()
@@ -147,25 +167,44 @@ class RPN(nn.Module):
 
     @torch.no_grad()
     def label_and_sample_anchors(self, anchors, gt_instances):
-        """Returns gt_labels (N, R) int8 in {-1, 0, 1} and the matched gt boxes (N, R, D)."""
+        """Returns the sampled gt_labels (N, R) int8 in {-1, 0, 1}, the index of every anchor's best gt box (N, R) int32 and the list of
+        the sampled anchors (N, S) int32 (-1 padded)."""
         R = anchors.shape[0]
         N = len(gt_instances)
         dev = anchors.device
         mlabs = torch.empty((N, R), dtype=torch.int8, device=dev)
-        matched = torch.zeros((N, R, self.box_dim), dtype=torch.float32, device=dev)
+        matches = torch.empty((N, R), dtype=torch.int32, device=dev)
+        vals = torch.empty((R,), dtype=torch.float32, device=dev)          # the matched IoUs are not used beyond the labels
         for i, g in enumerate(gt_instances):
             boxes = g.gt_boxes.tensor.float().contiguous()
-            _, matches, mlab = HF.anchor_match(boxes, anchors, self.iou_thresholds, self.iou_labels, True)
-            mlabs[i] = mlab
-            if len(boxes):
-                matched[i] = boxes[matches.long()]
-        # the random subsample of the whole batch in one launch, nothing read back (detectron2: nonzero + randperm per image)
-        labels, _ = HF.sample_labels(mlabs, self.batch_size_per_image, self.positive_fraction, 0)
-        return labels, matched
+            HF.anchor_match(boxes, anchors, self.iou_thresholds, self.iou_labels, True, out=(vals, matches[i], mlabs[i]))
+        # the random subsample of the whole batch in one launch, nothing read back (detectron2: nonzero + randperm per image); the
+        # kernel also lists the drawn anchors (N, S): the losses only ever touch those rows
+        labels, _, idx = HF.sample_labels_list(mlabs, self.batch_size_per_image, self.positive_fraction, 0)
+        return labels, matches, idx
 
     @torch.no_grad()
-    def anchor_deltas_for(self, anchors, matched):
-        return torch.stack([self.box2box_transform.get_deltas(anchors, m) for m in matched])
+    def sampled_targets(self, anchors, gt_instances, labels, matches, idx):
+        """For the sampled anchors idx (N, S) (-1 padded): their labels (N, S) int8 and regression targets (N, S, D)."""
+        S = self.batch_size_per_image
+        safe = idx.clamp(min=0).long()
+        labels_s = torch.where(idx >= 0, torch.gather(labels, 1, safe), torch.full_like(safe, -1, dtype=torch.int8)).contiguous()
+        gts = [g.gt_boxes.tensor.float() for g in gt_instances]
+        counts = [len(g) for g in gts]
+        off = [0]
+        for c in counts:
+            off.append(off[-1] + c)
+        D = anchors.shape[1]
+        if off[-1] == 0:
+            return idx, labels_s, torch.zeros((len(gts), S, D), dtype=torch.float32, device=anchors.device), torch.zeros((0, D), device=anchors.device), off
+        gt_cat = torch.cat(gts).contiguous()
+        base = torch.tensor(off[:-1], dtype=torch.int64, device=anchors.device)[:, None]
+        m_s = torch.gather(matches, 1, safe).long()
+        # images without boxes have no positives: their rows point at box 0 of the batch and are never read (label != 1)
+        tgt = gt_cat[(base + m_s).clamp(max=off[-1] - 1).reshape(-1)]
+        deltas_s = self.box2box_transform.get_deltas(anchors[safe.reshape(-1)].contiguous(), tgt.contiguous()).view(len(gts), S, D)
+        return idx, labels_s, deltas_s, gt_cat, off
+
 
     @torch.no_grad()
     def predict_proposals(self, anchors_l, logits_l, deltas_l, image_sizes):
@@ -218,10 +257,10 @@ class RPN(nn.Module):
         losses = {}
         if self.training:
             anchors = torch.cat(anchors_l).contiguous()
-            gt_labels, matched = self.label_and_sample_anchors(anchors, gt_instances)
-            gt_deltas = self.anchor_deltas_for(anchors, matched)
-            self.last_targets = (gt_labels, matched, gt_deltas)
-            out = _RpnLossFn.apply(self, gt_labels, gt_deltas, *logits_l, *deltas_l)
+            gt_labels, matches, idx = self.label_and_sample_anchors(anchors, gt_instances)
+            idx, labels_s, deltas_s, gt_cat, gt_off = self.sampled_targets(anchors, gt_instances, gt_labels, matches, idx)
+            self.last_targets = _RpnTargets(self, anchors, gt_labels, matches, gt_cat, gt_off)
+            out = _RpnLossFn.apply(self, idx, labels_s, deltas_s, *logits_l, *deltas_l)
             losses = {"loss_rpn_cls": out[0] * self.loss_weight["loss_rpn_cls"], "loss_rpn_loc": out[1] * self.loss_weight["loss_rpn_loc"]}
         proposals = self.predict_proposals(anchors_l, [x.detach() for x in logits_l], [x.detach() for x in deltas_l], images.image_sizes)
         return proposals, losses
@@ -257,18 +296,16 @@ class RPNWNM(RPN):
 
         R, N, dev = anchors.shape[0], len(gt_instances), anchors.device
         mlabs = torch.empty((N, R), dtype=torch.int8, device=dev)
-        matched = torch.zeros((N, R, self.box_dim), dtype=torch.float32, device=dev)
+        matches = torch.empty((N, R), dtype=torch.int32, device=dev)
+        vals = torch.empty((R,), dtype=torch.float32, device=dev)
         for i, g in enumerate(gt_instances):
             boxes = g.gt_boxes.tensor.float().contiguous()
-            _, matches, mlab = HF.anchor_match(boxes, anchors, self.iou_thresholds, self.iou_labels, False)
+            HF.anchor_match(boxes, anchors, self.iou_thresholds, self.iou_labels, False, out=(vals, matches[i], mlabs[i]))
             if len(boxes):      # top-k anchors of every gt (rows of the G x R IoU matrix; G is small)
                 q = pairwise_iou(Boxes(boxes), Boxes(anchors))
-                mlab[q.topk(k=self.matcher_topk, dim=1)[1].reshape(-1)] = 1
-            mlabs[i] = mlab
-            if len(boxes):
-                matched[i] = boxes[matches.long()]
-        labels, _ = HF.sample_labels(mlabs, self.batch_size_per_image, self.positive_fraction, 0)
-        return labels, matched
+                mlabs[i][q.topk(k=self.matcher_topk, dim=1)[1].reshape(-1)] = 1
+        labels, _, idx = HF.sample_labels_list(mlabs, self.batch_size_per_image, self.positive_fraction, 0)
+        return labels, matches, idx
 
 
 def build_proposal_generator(cfg, input_shape):
