@@ -461,6 +461,14 @@ int sod_retina_box_loss_bwd(const float* pred, int pitch, const int* gt_labels, 
 int sod_anchor_match_rotated(const float* gt_boxes, int G, const float* anchors, int A, float thr_lo, float thr_hi,
                              int label_below, int label_between, int label_above, int allow_low_quality,
                              float* matched_vals, int* matches, signed char* labels, unsigned* gt_best_ws, void* stream);
+/* ROIHeads.label_and_sample_proposals' matching + labelling (detectron2 roi_heads.py; reference subclass roi_heads/roi_heads.py:48-53) for
+ * the whole batch in ONE launch: boxes (N, R, box_dim) padded proposal rows (counts[n] valid), the images' ground truth concatenated
+ * (gt_off: N + 1 offsets), Matcher([iou_threshold], [label_below, label_above], allow_low_quality_matches=False).  Out: matches (N, R) =
+ * index of the best box inside its image (first maximum wins), classes (N, R) int8 = its class / num_classes (label 0) / -1 (label -1 and
+ * padding rows).  num_classes <= 126. */
+int sod_roi_label_batched(const float* boxes, const int* counts, int N, int R, int box_dim, const float* gt_boxes, const int* gt_classes,
+                          const int* gt_off, float iou_threshold, int label_below, int label_above, int num_classes, int* matches,
+                          signed char* classes, void* stream);
 int sod_box2box_get_deltas(const float* src, const float* tgt, long long n, int box_dim, const float* weights, float* deltas, void* stream);
 int sod_box2box_apply_deltas(const float* deltas, const float* boxes, long long n, int k, int box_dim, int ld, const float* weights,
                              float scale_clamp, float* out, void* stream);

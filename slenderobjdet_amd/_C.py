@@ -146,6 +146,7 @@ _SIGS = {
     "sod_sample_labels": [_P, _I, _I, _I, _F, _I, ctypes.c_ulonglong, _P, _P, _P],
     "sod_sample_labels_list": [_P, _I, _I, _I, _F, _I, ctypes.c_ulonglong, _P, _P, _P, _P, _P],
     "sod_compact_samples": [_P, _I, _I, _I, _P, _P, _P],
+    "sod_roi_label_batched": [_P, _P, _I, _I, _I, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P],
     "sod_rpn_gather_sampled": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "sod_rpn_scatter_sampled": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "sod_retina_box_loss_bwd_f32": [_P, _I, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],

@@ -1242,6 +1242,55 @@ static int anchor_match_impl(const float* gt_boxes, int G, const float* anchors,
   return SOD_OK;
 }
 
+// ROIHeads.label_and_sample_proposals' matching + labelling for the WHOLE batch in one launch: proposal r of image n (rows >= counts[n] are
+// padding) against that image's boxes gt[gt_off[n] .. gt_off[n + 1]): best IoU with "first maximum wins", Matcher([thr], [l0, l1]) without
+// low-quality matches, class = the matched box's class for label 1, num_classes for label 0, -1 for label -1 and for padding rows.
+template <int D>
+__global__ __launch_bounds__(256) void roi_label_batched_kernel(const float* __restrict__ boxes, const int* __restrict__ counts, int R,
+                                                                const float* __restrict__ gt, const int* __restrict__ gt_classes,
+                                                                const int* __restrict__ gt_off, float thr, int l0, int l1, int num_classes,
+                                                                int* __restrict__ matches, signed char* __restrict__ cls) {
+  __shared__ P2 rot_pts[D == 5 ? 24 * 256 : 1];
+  const int n = blockIdx.y;
+  const int g0 = gt_off[n], G = gt_off[n + 1] - g0, cnt = counts[n];
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+    const long long o = (long long)n * R + r;
+    if (r >= cnt) { matches[o] = 0; cls[o] = -1; continue; }
+    float a[D];
+#pragma unroll
+    for (int e = 0; e < D; ++e) a[e] = boxes[o * D + e];
+    float bv = -1.f; int bi = 0;
+    for (int g = 0; g < G; ++g) {
+      float v;
+      if constexpr (D == 5) v = fmaxf(iou_rotated_lds(gt + (long long)(g0 + g) * D, a, rot_pts + threadIdx.x, 256), 0.f);
+      else v = match_iou<D>(gt + (long long)(g0 + g) * D, a);
+      if (v > bv) { bv = v; bi = g; }
+    }
+    int c = num_classes;                            // no boxes: everything is background (matches stay 0)
+    if (G > 0) {
+      const int lab = (bv < thr) ? l0 : l1;
+      c = (lab == 0) ? num_classes : ((lab == -1) ? -1 : gt_classes[g0 + bi]);
+    }
+    matches[o] = bi;
+    cls[o] = (signed char)c;
+  }
+}
+
+extern "C" int sod_roi_label_batched(const float* boxes, const int* counts, int N, int R, int box_dim, const float* gt_boxes, const int* gt_classes,
+                                     const int* gt_off, float iou_threshold, int label_below, int label_above, int num_classes, int* matches,
+                                     signed char* classes, void* stream) {
+  if (!boxes || !counts || !gt_off || !matches || !classes || N <= 0 || N > 65535 || R <= 0 || (box_dim != 4 && box_dim != 5) || num_classes <= 0 ||
+      num_classes > 126)
+    return SOD_EARG;
+  const dim3 grid((R + 255) / 256, N);
+  if (box_dim == 4) SOD_LAUNCH(roi_label_batched_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, boxes, counts, R, gt_boxes, gt_classes, gt_off,
+                               iou_threshold, label_below, label_above, num_classes, matches, classes);
+  else SOD_LAUNCH(roi_label_batched_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, boxes, counts, R, gt_boxes, gt_classes, gt_off, iou_threshold,
+                  label_below, label_above, num_classes, matches, classes);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
 extern "C" int sod_anchor_match(const float* gt_boxes, int G, const float* anchors, int A, float thr_lo, float thr_hi,
                                 int label_below, int label_between, int label_above, int allow_low_quality,
                                 float* matched_vals, int* matches, signed char* labels, unsigned* gt_best_ws, void* stream) {

@@ -1141,6 +1141,19 @@ def compact_samples(mask, slots):
     return idx, num
 
 
+def roi_label_batched(boxes, counts, gt_boxes, gt_classes, gt_off, iou_threshold, labels2, num_classes):
+    """boxes (N, R, D) padded proposal rows (counts (N,) int32 valid), gt_boxes (G, D) / gt_classes (G,) int32 of all images concatenated,
+    gt_off (N + 1,) int32 -> matches (N, R) int32 (index inside the image), classes (N, R) int8 (class / num_classes / -1)."""
+    _chk(boxes, torch.float32, "boxes"); _chk(counts, torch.int32, "counts"); _chk(gt_boxes, torch.float32, "gt_boxes")
+    _chk(gt_classes, torch.int32, "gt_classes"); _chk(gt_off, torch.int32, "gt_off")
+    N, R, D = boxes.shape
+    matches = torch.empty((N, R), dtype=torch.int32, device=boxes.device)
+    cls = torch.empty((N, R), dtype=torch.int8, device=boxes.device)
+    call("sod_roi_label_batched", ptr(boxes), ptr(counts), N, R, D, ptr(gt_boxes) if gt_boxes.numel() else None, ptr(gt_classes) if gt_classes.numel() else None,
+         ptr(gt_off), float(iou_threshold), int(labels2[0]), int(labels2[1]), int(num_classes), ptr(matches), ptr(cls), stream_ptr())
+    return matches, cls
+
+
 def rpn_gather_sampled(logits_l, deltas_l, idx, A, D):
     """Rows of the sampled anchors: per-level padded NHWC head outputs (N, H, W, pitch) fp32 + idx (N, S) int32 (anchor index in the
     concatenated (level, h, w, a) order, -1 = empty slot) -> (N, S) logits, (N, S, D) deltas."""
