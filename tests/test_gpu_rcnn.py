@@ -441,3 +441,79 @@ def test_rotated_rcnn_r101_step(cuda):
         assert abs(a - b) <= 3e-3 * max(abs(b), 1e-3), (k, a, b)
     ls = [float(_step(model, opt, data)) for _ in range(3)]
     assert all(v == v and abs(v) < 1e6 for v in ls), ls
+
+
+@pytest.mark.parametrize("D", [4, 5])
+def test_batched_roi_labelling_and_sampled_rpn_rows(cuda, D):
+    """sod_roi_label_batched == the per-image anchor matcher + class assignment it replaces (incl. an image without boxes and padding
+    rows); sod_rpn_gather_sampled reads exactly the rows the concatenated (level, h, w, a) order names and sod_rpn_scatter_sampled is its
+    adjoint; sod_sample_labels_list lists exactly the elements its mask marks."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    g = torch.Generator().manual_seed(3)
+
+    def boxes(n):
+        c = torch.rand(n, 2, generator=g) * 200
+        wh = 10 + torch.rand(n, 2, generator=g) * 80
+        if D == 5:
+            return torch.cat((c, wh, torch.rand(n, 1, generator=g) * 180 - 90), 1)
+        return torch.cat((c - wh / 2, c + wh / 2), 1)
+
+    N, R, K = 3, 300, 80
+    counts = [300, 257, 120]
+    gts = [boxes(5), boxes(0), boxes(3)]
+    gtc = [torch.randint(0, K, (len(b),), generator=g) for b in gts]
+    props = torch.zeros(N, R, D)
+    for i in range(N):
+        props[i, :counts[i]] = boxes(counts[i])
+        if len(gts[i]):
+            props[i, :len(gts[i])] = gts[i] + 0.5          # some certain foreground
+    off = [0, 5, 5, 8]
+    m, c = HF.roi_label_batched(props.to(cuda), torch.tensor(counts, dtype=torch.int32, device=cuda), torch.cat(gts).to(cuda).contiguous(),
+                                torch.cat(gtc).to(torch.int32).to(cuda), torch.tensor(off, dtype=torch.int32, device=cuda), 0.5, [0, 1], K)
+    for i in range(N):
+        n = counts[i]
+        assert (c[i, n:] == -1).all()
+        if len(gts[i]) == 0:
+            assert (c[i, :n] == K).all() and (m[i, :n] == 0).all()
+            continue
+        _, mi, lab = HF.anchor_match(gts[i].to(cuda).contiguous(), props[i, :n].to(cuda).contiguous(), [0.5, 0.5], [0, 0, 1], False)
+        want = gtc[i].to(cuda)[mi.long()].clone()
+        want[lab == 0] = K
+        assert torch.equal(m[i, :n], mi) and torch.equal(c[i, :n].long(), want)
+        assert (lab == 1).sum() >= len(gts[i])
+    # sampled RPN rows
+    A, S = 3, 16
+    hw = [(6, 8), (3, 4), (2, 2)]
+    lg = [torch.randn(2, h, w, 8, generator=g).to(cuda) for h, w in hw]
+    dl = [torch.randn(2, h, w, 16 if D == 5 else 16, generator=g).to(cuda) for h, w in hw]
+    Rr = sum(h * w for h, w in hw) * A
+    flat_l = torch.cat([x[..., :A].reshape(2, -1) for x in lg], 1)
+    flat_d = torch.cat([x[..., :A * D].reshape(2, -1, D) for x in dl], 1)
+    idx = torch.stack([torch.randperm(Rr, generator=g)[:S] for _ in range(2)]).to(torch.int32)
+    idx[1, -3:] = -1
+    idx = idx.to(cuda)
+    rl, rd = HF.rpn_gather_sampled(lg, dl, idx, A, D)
+    safe = idx.clamp(min=0).long()
+    assert torch.equal(rl[idx >= 0], torch.gather(flat_l, 1, safe)[idx >= 0])
+    assert torch.equal(rd[idx >= 0], torch.gather(flat_d, 1, safe[:, :, None].expand(-1, -1, D))[idx >= 0])
+    assert (rl[idx < 0] == 0).all() and (rd[idx < 0] == 0).all()
+    gl, gd = HF.rpn_scatter_sampled([tuple(x.shape) for x in lg], [tuple(x.shape) for x in dl], idx, A, D, rl.contiguous(), rd.contiguous())
+    back_l = torch.cat([x[..., :A].reshape(2, -1) for x in gl], 1)
+    back_d = torch.cat([x[..., :A * D].reshape(2, -1, D) for x in gd], 1)
+    want_l = torch.zeros_like(flat_l)
+    want_d = torch.zeros_like(flat_d)
+    for n in range(2):
+        v = idx[n] >= 0
+        want_l[n, safe[n][v]] = flat_l[n, safe[n][v]]
+        want_d[n, safe[n][v]] = flat_d[n, safe[n][v]]
+    assert torch.equal(back_l, want_l) and torch.equal(back_d, want_d)
+    assert all((x[..., A:] == 0).all() for x in gl) and all((x[..., A * D:] == 0).all() for x in gd)
+    # the sampler's list == its mask
+    labels = torch.randint(-1, 2, (4, 5000), generator=g).to(torch.int8).to(cuda)
+    torch.manual_seed(5)
+    mask, cnts, lst = HF.sample_labels_list(labels, 64, 0.5, 0)
+    for n in range(4):
+        got = sorted(int(v) for v in lst[n].tolist() if v >= 0)
+        want = sorted(torch.nonzero(mask[n] >= 0).flatten().tolist())
+        assert got == want and len(got) == int(cnts[n].sum())
