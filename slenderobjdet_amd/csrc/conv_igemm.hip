@@ -359,15 +359,20 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
       int nimg[NP];
       uint32_t mbits[NP];
       bool odd[NP];
+      // (image, pixel-in-image) of this lane's first row by one division, the rows of the following passes (ERPP pixels further each) by carry
+      const uint32_t pfirst = p0 + (wp * FP + h * FH) * 16 + erow;
+      const uint32_t pc0 = pfirst < (uint32_t)gP ? pfirst : 0u;
+      uint32_t n_run = fd_div(pc0, g.div_hw);
+      uint32_t rem_run = pc0 - n_run * g.div_hw.d;
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
-        const int row = k * ERPP + erow;
-        const uint32_t p = p0 + (wp * FP + h * FH) * 16 + row;
+        const uint32_t p = pfirst + (uint32_t)(k * ERPP);
         ok[k] = (p < (uint32_t)gP) && qok;
         drow[k] = 0;
+        const uint32_t n = n_run, rem = rem_run;
+        rem_run += (uint32_t)ERPP;
+        while (rem_run >= g.div_hw.d) { rem_run -= g.div_hw.d; ++n_run; }      // (levels of a few pixels: more than one wrap)
         if (ok[k]) {
-          const uint32_t n = fd_div(p, g.div_hw);
-          const uint32_t rem = p - n * g.div_hw.d;
           nimg[k] = (int)n;
           drow[k] = (size_t)n * g.dst_img_stride + (size_t)rem * Nout;
           if (a.flags & (F_RES | F_RES_UP2)) {

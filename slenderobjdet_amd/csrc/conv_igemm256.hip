@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
       drow[k] = 0;
       const uint32_t n = n_run, rem = rem_run;
       rem_run += (uint32_t)ERPP;
-      if (rem_run >= g.div_hw.d) { rem_run -= g.div_hw.d; ++n_run; }
+      while (rem_run >= g.div_hw.d) { rem_run -= g.div_hw.d; ++n_run; }      // (levels of a few pixels: more than one wrap)
       if (ok[k]) {
         nimg[k] = (int)n;
         drow[k] = (size_t)n * g.dst_img_stride + (size_t)rem * Nout;
