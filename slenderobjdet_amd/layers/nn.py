@@ -385,6 +385,21 @@ class ConvGate:
         self.last.record(torch.cuda.current_stream())
 
 
+class ConvGn:
+    """[Conv (any odd kernel, stride 1) -> GroupNorm] of an existing HipConv2d and HipGroupNorm pair as ONE autograd node (detectron2's
+    ``Conv2d(..., norm=get_norm("GN", C))`` of the FPN under MODEL.FPN.NORM "GN", configs/rep-points/*.yaml): the norm's statistics come out
+    of the conv epilogue, and its backward hands the conv's weight gradient the normalised gradient without another autograd hop.  Not a
+    Module: the two layers stay registered where they are (state-dict names unchanged)."""
+    relu = False
+
+    def __init__(self, conv, gn):
+        self.conv, self.gn, self._last_slot = conv, gn, None
+
+    def __call__(self, x):
+        self.conv.prepare()
+        return _ConvGnReluFn.apply(self.conv.weight, self, None, x)[0]
+
+
 class _ConvGnReluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, unit, prev_slot, *xs):
@@ -393,25 +408,27 @@ class _ConvGnReluFn(torch.autograd.Function):
         gate = ConvGate.current
         if gate is not None:
             gate.before_conv()
-        if (GN_EPILOGUE_STATS and not HF.DETERMINISTIC and not HF.is_f32() and conv.out_channels == 8 * gn.num_groups and conv.bias_eff is not None
-                and conv.kernel_size == 3 and conv.stride == 1 and conv.padding == 1 and conv.dilation == 1):
+        relu = getattr(unit, "relu", True)          # ConvGn (FPN with NORM "GN"): no activation behind the norm
+        if (GN_EPILOGUE_STATS and not HF.DETERMINISTIC and not HF.is_f32() and conv.out_channels == 8 * gn.num_groups
+                and conv.stride == 1 and conv.dilation == 1 and 2 * conv.padding == conv.kernel_size - 1):
             # the norm's statistics are gathered in the conv epilogue (float atomics: not for the deterministic mode)
-            y1s, y2s, stats = HF.conv_gn_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, gw, gb, gn.num_groups, gn.eps, relu=True,
+            y1s, y2s, stats = HF.conv_gn_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, gw, gb, gn.num_groups, gn.eps, relu=relu, pad=conv.padding,
                                                 after_conv=gate.after_conv if gate is not None else None)
         else:
-            y1s = HF.conv2d_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, 1, 1, 1)
+            y1s = HF.conv2d_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, conv.stride, conv.padding, conv.dilation)
             if gate is not None:
                 gate.after_conv()
-            y2s, stats = HF.groupnorm_fwd_ml(y1s, gw, gb, gn.num_groups, gn.eps, relu=True)      # all levels in one launch per pass
-        ctx.unit, ctx.nl = unit, len(xs)
+            y2s, stats = HF.groupnorm_fwd_ml(y1s, gw, gb, gn.num_groups, gn.eps, relu=relu)      # all levels in one launch per pass
+        ctx.unit, ctx.nl, ctx.relu = unit, len(xs), relu
         ctx.save_for_backward(*xs, *y1s, stats)
         ctx.prev_slot = prev_slot
         ctx.slot = unit._last_slot = None
         arena = _arena_of(conv)
         if arena is not None and conv.weight.requires_grad:
             for p in (conv.weight, conv.bias, gn.weight, gn.bias):
-                arena.note_use(p)
-            if conv.out_channels == 8 * gn.num_groups:
+                if p is not None:
+                    arena.note_use(p)
+            if conv.out_channels == 8 * gn.num_groups and relu and conv.kernel_size == 3 and conv.bias is not None:
                 ctx.slot = unit._last_slot = GnBwdSlot(list(y1s), stats, gn, y2s)
         return tuple(y2s)
 
@@ -425,18 +442,21 @@ class _ConvGnReluFn(torch.autograd.Function):
         arena = _arena_of(conv)
         gw, gb = gn.weight.detach(), gn.bias.detach()
         dgw, dgb = arena.grad_view(gn.weight), arena.grad_view(gn.bias)
-        dbias = arena.grad_view(conv.bias)      # the conv bias gradient (sum of dy1 over pixels) falls out of the GN backward pass
+        relu, k = ctx.relu, conv.kernel_size
+        # the conv bias gradient (sum of dy1 over pixels) falls out of the GN backward pass
+        dbias = arena.grad_view(conv.bias) if conv.bias is not None else None
         slot, ctx.slot = ctx.slot, None
         if slot is not None and slot.red is not None:
             # the consumer's data gradient already gathered the group sums and dgamma / dbeta (sod_conv2d_dgrad_ml_gnbwd): apply pass only
             dy1s = HF.groupnorm_bwd_apply_ml([d.contiguous() for d in dy2s], list(y1s), gw, gb, stats, slot.red, gn.num_groups, relu=True, dxsum=dbias)
             slot.red = None
         else:
-            dy1s = HF.groupnorm_bwd_ml([d.contiguous() for d in dy2s], list(y1s), gw, gb, stats, gn.num_groups, dgw, dgb, relu=True, dxsum=dbias)
+            dy1s = HF.groupnorm_bwd_ml([d.contiguous() for d in dy2s], list(y1s), gw, gb, stats, gn.num_groups, dgw, dgb, relu=relu, dxsum=dbias)
         arena.mark_ready(gn.weight)
         arena.mark_ready(gn.bias)
-        arena.mark_ready(conv.bias)
-        HF.conv2d_wgrad_ml(dy1s, list(xs), arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
+        if conv.bias is not None:
+            arena.mark_ready(conv.bias)
+        HF.conv2d_wgrad_ml(dy1s, list(xs), arena.grad_view(conv.weight), k, k, conv.stride, conv.padding, conv.dilation)
         arena.mark_ready(conv.weight)
         dxs = [None] * nl
         if any(ctx.needs_input_grad[3:]):
@@ -447,7 +467,7 @@ class _ConvGnReluFn(torch.autograd.Function):
                 dxs, prev.red = HF.conv2d_dgrad_ml_gnbwd(dy1s, conv.wt_bf16, hw, prev.y1s, prev.stats, pg.weight.detach(), pg.bias.detach(),
                                                          arena.grad_view(pg.weight), arena.grad_view(pg.bias), pg.num_groups, 1, 1, 1)
             else:
-                dxs = HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, hw, 1, 1, 1)
+                dxs = HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, hw, conv.stride, conv.padding, conv.dilation)
         return (None, None, None, *dxs)
 
 
