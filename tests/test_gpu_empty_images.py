@@ -1,0 +1,84 @@
+"""Edge case of every training path: a batch in which ONE image has no ground-truth box at all (and, for the dense detectors, the batch
+in which NO image has one).  The step must run, give finite losses and gradients, and agree with the oracle where the oracle defines the
+case - or fail the way the reference fails (RepPoints)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _strip(data, which):
+    from slenderobjdet_amd.structures import Boxes, Instances, RotatedBoxes
+
+    out = []
+    for i, d in enumerate(data):
+        d = dict(d)
+        if i in which:
+            inst = d["instances"]
+            e = Instances(inst.image_size)
+            bt = type(inst.gt_boxes)
+            e.gt_boxes = bt(inst.gt_boxes.tensor[:0])
+            e.gt_classes = inst.gt_classes[:0]
+            d["instances"] = e
+        out.append(d)
+    return out
+
+
+def _cfg(arch):
+    if arch == "fcos":
+        from bench import make_cfg
+        return make_cfg(18)
+    if arch == "retinanet":
+        from test_gpu_retinanet import _cfg as c
+        return c()
+    if arch == "reppoints":
+        from test_gpu_reppoints import _cfg as c
+        return c()
+    from test_gpu_rcnn import _cfg as c
+    return c(arch == "rrcnn")
+
+
+@pytest.mark.parametrize("arch", ["fcos", "retinanet", "reppoints", "rcnn", "rrcnn"])
+@pytest.mark.parametrize("which", [(1,), (0, 1)], ids=["one_empty", "all_empty"])
+def test_training_step_with_images_without_boxes(cuda, arch, which):
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+
+    cfg = _cfg(arch)
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    if arch in ("rcnn", "rrcnn"):
+        from test_gpu_rcnn import _data
+        data = _data(2, 96, 128, 21, arch == "rrcnn")
+    else:
+        data = synthetic_batch(2, 192, 256, 7, device="cuda")
+    data = _strip(data, which)
+    assert sum(len(d["instances"]) for d in data) == (0 if len(which) == 2 else len(data[0]["instances"]))
+    if arch == "reppoints":     # the reference's point matcher refuses the case (matchers/rep_matcher.py:38-39): same error, same message
+        with pytest.raises(ValueError, match="No gt or bboxes"):
+            model(data)
+        return
+    losses = model(data)
+    total = sum(losses.values())
+    assert all(torch.isfinite(v).all() for v in losses.values()), {k: float(v) for k, v in losses.items()}
+    opt.zero_grad()
+    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    for name, p in model.named_parameters():
+        if p.requires_grad and p.grad is not None:
+            assert torch.isfinite(p.grad).all(), name
+    opt.step()
+    if arch == "fcos":      # the oracle defines the case (fcosv2.py:116-147: normalisers clamped to 1, empty selections sum to 0)
+        from oracle.model import OracleFCOS
+        torch.manual_seed(0)
+        m2 = build_model(cfg)
+        m2.train()
+        ref = OracleFCOS.from_hip_model(m2, emulate_bf16=True).losses([{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data])
+        got = m2(data)
+        for k, v in ref.items():
+            a, b = float(got[k].detach()), float(v)
+            assert abs(a - b) <= 2e-3 * max(abs(b), 1e-3), (k, a, b)
+        if len(which) == 2:
+            assert float(got["reg_loss"].detach()) == 0.0 and float(got["centerness_loss"].detach()) == 0.0
