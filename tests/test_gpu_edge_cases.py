@@ -1,4 +1,4 @@
-"""Edge case of every training path: a batch in which ONE image has no ground-truth box at all (and, for the dense detectors, the batch
+"""Edge cases of the training paths: ragged batches, and a batch in which ONE image has no ground-truth box at all (and, for the dense detectors, the batch
 in which NO image has one).  The step must run, give finite losses and gradients, and agree with the oracle where the oracle defines the
 case - or fail the way the reference fails (RepPoints)."""
 import pytest
@@ -82,3 +82,32 @@ def test_training_step_with_images_without_boxes(cuda, arch, which):
             assert abs(a - b) <= 2e-3 * max(abs(b), 1e-3), (k, a, b)
         if len(which) == 2:
             assert float(got["reg_loss"].detach()) == 0.0 and float(got["centerness_loss"].detach()) == 0.0
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_ragged_batch_matches_oracle(cuda, precision):
+    """Images of DIFFERENT sizes in one batch (ImageList.from_tensors pads to the largest, rounded up to the size divisibility; the
+    targets use the padded grid, fcosv2.py:63-102): FCOS losses against the oracle, 1e-3 for the bf16 product and 2e-5 in the fp32 mode."""
+    from bench import make_cfg
+    from oracle.model import OracleFCOS
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.modeling import build_model
+
+    prev = HF.set_precision(precision)
+    try:
+        cfg = make_cfg(18)
+        torch.manual_seed(0)
+        model = build_model(cfg)
+        model.train()
+        data = [synthetic_batch(1, 192, 256, 3, device="cuda")[0], synthetic_batch(1, 150, 203, 4, device="cuda")[0], synthetic_batch(1, 97, 256, 5, device="cuda")[0]]
+        assert len({tuple(d["image"].shape[-2:]) for d in data}) == 3
+        got = model(data)
+        ref = OracleFCOS.from_hip_model(model, emulate_bf16=precision == "bf16").losses(
+            [{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data])
+        tol = 1e-3 if precision == "bf16" else 2e-5
+        for k, v in ref.items():
+            a, b = float(got[k].detach()), float(v.detach())
+            assert abs(a - b) <= tol * max(abs(b), 1e-3), (k, a, b)
+    finally:
+        HF.set_precision(prev)
