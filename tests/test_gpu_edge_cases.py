@@ -111,3 +111,19 @@ def test_ragged_batch_matches_oracle(cuda, precision):
             assert abs(a - b) <= tol * max(abs(b), 1e-3), (k, a, b)
     finally:
         HF.set_precision(prev)
+
+
+def test_operands_of_2_gib_are_refused_not_wrapped(cuda):
+    """Maximum sizes: the kernels address their operands with 32-bit byte offsets, so an operand of 2 GiB or more must be REFUSED
+    (SOD_ESIZE) by the C ABI before anything is launched - never computed with wrapped offsets.  The shapes are only claimed
+    (``x_shape``), the refusal comes from the size check of sod_conv2d_fwd."""
+    from slenderobjdet_amd._C import SlenderHipError
+    from slenderobjdet_amd.layers import functional as HF
+
+    x = torch.zeros(1, 8, 8, 64, device=cuda, dtype=torch.bfloat16)
+    w = torch.zeros(8, 1, 1, 64, device=cuda, dtype=torch.bfloat16)
+    ok = HF.conv2d_fwd(x, w)                                   # the same call at its real size works
+    assert tuple(ok.shape) == (1, 8, 8, 8)
+    with pytest.raises(SlenderHipError, match="SOD_ESIZE"):
+        HF.conv2d_fwd(x, w, x_shape=(256, 256, 256, 64))      # 2.1 GB of claimed input
+    torch.cuda.synchronize()
