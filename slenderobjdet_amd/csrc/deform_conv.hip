@@ -513,25 +513,52 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, con
         const bool inwin = wy >= 0 && wx >= 0 && wy + 1 < WH && wx + 1 < WW && finite_scale;
         int* w00p = win + ((wy * WW + wx) * PS) + cl * 8;
         float* g00p = a.dx + ((base + (long long)s.yl * a.W + s.xl) * a.C) + cch;
+        // the corner tests are per LANE, not per channel: one branch region per corner around its eight atomics (with the tests inside
+        // the channel loop hipcc emitted 64 exec-mask save / branch pairs per tap - as many cycles as the arithmetic they guard)
+        float dmv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float d = (float)dcv[e];
           const float dm = d * m;
-          if (inwin) {
-            const float ds = dm * S;
-            if (s.ok00) atomicAdd(w00p + e, __float2int_rn(ds * s.w00));
-            if (s.ok01) atomicAdd(w00p + PS + e, __float2int_rn(ds * s.w01));
-            if (s.ok10) atomicAdd(w00p + WW * PS + e, __float2int_rn(ds * s.w10));
-            if (s.ok11) atomicAdd(w00p + WW * PS + PS + e, __float2int_rn(ds * s.w11));
-          } else {
-            if (s.ok00) atomicAdd(g00p + e, dm * s.w00);
-            if (s.ok01) atomicAdd(g00p + a.C + e, dm * s.w01);
-            if (s.ok10) atomicAdd(g00p + (long long)a.W * a.C + e, dm * s.w10);
-            if (s.ok11) atomicAdd(g00p + (long long)a.W * a.C + a.C + e, dm * s.w11);
-          }
+          dmv[e] = dm;
           g_dy += dm * (hx * (v10[e] - v00[e]) + s.lx * (v11[e] - v01[e]));
           g_dx += dm * (hy * (v01[e] - v00[e]) + s.ly * (v11[e] - v10[e]));
           g_m += d * (s.w00 * v00[e] + s.w01 * v01[e] + s.w10 * v10[e] + s.w11 * v11[e]);
+        }
+        if (inwin) {
+          if (s.ok00) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(w00p + e, __float2int_rn(dmv[e] * S * s.w00));
+          }
+          if (s.ok01) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(w00p + PS + e, __float2int_rn(dmv[e] * S * s.w01));
+          }
+          if (s.ok10) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(w00p + WW * PS + e, __float2int_rn(dmv[e] * S * s.w10));
+          }
+          if (s.ok11) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(w00p + WW * PS + PS + e, __float2int_rn(dmv[e] * S * s.w11));
+          }
+        } else {
+          if (s.ok00) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(g00p + e, dmv[e] * s.w00);
+          }
+          if (s.ok01) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(g00p + a.C + e, dmv[e] * s.w01);
+          }
+          if (s.ok10) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(g00p + (long long)a.W * a.C + e, dmv[e] * s.w10);
+          }
+          if (s.ok11) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(g00p + (long long)a.W * a.C + a.C + e, dmv[e] * s.w11);
+          }
         }
         if (a.mask && a.mask_logit) g_m *= m * (1.f - m);
       }
