@@ -7,8 +7,6 @@ FCOSHead / targets / losses are pinned by tests/golden).  Also the ``cpu_baselin
 ``emulate_bf16=True`` rounds weights and every stored activation to bf16 at the same points where the HIP path stores
 bf16, so that end-to-end comparisons isolate kernel errors from the precision the product path computes in.
 """
-import math
-
 import torch
 import torch.nn.functional as F
 

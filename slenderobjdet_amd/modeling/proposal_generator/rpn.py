@@ -8,17 +8,15 @@ smooth-L1(sum, beta 0) both divided by 256 * N; proposals = per-level top-k by l
 NMS 0.7, top post_nms_topk.
 
 MI355X-first: the three head convs are one multi-level launch each (levels share weights); anchor labelling is the fused
-IoU + Matcher kernel (axis-aligned or rotated) that never builds the G x A matrix; both losses run over ALL anchors with the int8
-label as mask (no boolean gathers).
+IoU + Matcher kernel (axis-aligned or rotated) that never builds the G x A matrix; the random subsample is one launch for the batch
+that also lists the drawn anchors, and both losses run over the rows of those <= 256 anchors per image only (gathered from the head
+outputs, gradients scattered back): nothing of the size (N, 1.6 M anchors) is built beyond the int8 labels and the int32 matches.
 """
-import math
-
 import torch
 from torch import nn
 from torch.autograd.function import once_differentiable
 
 from ...layers import functional as HF
-from ...layers.nms import batched_nms, batched_nms_rotated
 from ...layers.nn import ConvML
 from ...structures import Boxes, Instances, RotatedBoxes
 from ...utils.registry import Registry
@@ -31,17 +29,6 @@ RPN_HEAD_REGISTRY = Registry("RPN_HEAD")
 
 def _ceil8(v):
     return (v + 7) // 8 * 8
-
-
-def subsample_labels(labels, num_samples, positive_fraction, bg_label):
-    """detectron2.modeling.sampling.subsample_labels: random positives (not -1, not bg) up to the fraction, negatives fill the rest."""
-    positive = torch.nonzero((labels != -1) & (labels != bg_label), as_tuple=False).squeeze(1)
-    negative = torch.nonzero(labels == bg_label, as_tuple=False).squeeze(1)
-    num_pos = min(positive.numel(), int(num_samples * positive_fraction))
-    num_neg = min(negative.numel(), num_samples - num_pos)
-    perm1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
-    perm2 = torch.randperm(negative.numel(), device=negative.device)[:num_neg]
-    return positive[perm1], negative[perm2]
 
 
 @RPN_HEAD_REGISTRY.register()
@@ -154,14 +141,6 @@ class RPN(nn.Module):
         self.last_targets = None
 
     # ------------------------------------------------------------------ helpers
-    def compact(self, logits_l, deltas_l):
-        """Per-level padded NHWC rows -> (N, sum HWA) logits and (N, sum HWA, D) deltas in d2's (h, w, a) order."""
-        A, D = self.head.num_anchors, self.head.box_dim
-        N = logits_l[0].shape[0]
-        lg = torch.cat([x[..., :A].reshape(N, -1) for x in logits_l], dim=1).contiguous()
-        dl = torch.cat([x[..., :A * D].reshape(N, -1, D) for x in deltas_l], dim=1).contiguous()
-        return lg, dl
-
     def _box_type(self):
         return RotatedBoxes if self.rotated else Boxes
 

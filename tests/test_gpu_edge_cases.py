@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _strip(data, which):
-    from slenderobjdet_amd.structures import Boxes, Instances, RotatedBoxes
+    from slenderobjdet_amd.structures import Instances
 
     out = []
     for i, d in enumerate(data):
