@@ -164,11 +164,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
     }
   };
 
+  // K need not be a multiple of 256 (RetinaNet / AnchorHead class scores: 9 anchors x 80 classes = 720): a lane whose 8 output channels lie
+  // beyond K requests the out-of-range offset (zero fill) - the next channels in memory belong to the following PIXEL.
+  const bool qv[2] = {q0 + schunk * 8 < a.K, q0 + 128 + schunk * 8 < a.K};
   auto stage_a = [&](int u, int kt) {     // dY channels q0 + u*128 + [0,128) of K-tile kt (row state must describe kt)
     char* dst = smem + (kt & 1) * WBUF + u * WUNIT + wave * 1024;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(dst + j * 8192), 16, voy[j] + qadd0 + (uint32_t)(u * 256), 0, 0, 0);
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t off = (qv[u] && voy[j] != SOD_OOB) ? voy[j] + qadd0 + (uint32_t)(u * 256) : SOD_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(dst + j * 8192), 16, off, 0, 0, 0);
+    }
   };
   auto stage_b = [&](int u, int kt) {     // X channels c0 + u*128 + [0,128)
     char* dst = smem + (kt & 1) * WBUF + (2 + u) * WUNIT + wave * 1024;
@@ -273,13 +278,14 @@ __global__ __launch_bounds__(256) void wgrad256_reduce_kernel(const WgradArgs a)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int q = qt * 256 + (i >> 2) * 128 + wr * 64 + (i & 3) * 16 + fg * 4 + e;
+    if (q >= a.K) continue;                 // rows of the last q-tile beyond K (their slab entries are zeros)
     float* dst = a.dw + ((size_t)q * RS + tap) * a.C + c;
     *dst += sum[e] * (a.qscale ? a.qscale[q] : 1.f);
   }
 }
 
 int splits_for(const WgradArgs& a, int cus, int* vps_out) {
-  const int tiles = (a.K / 256) * (a.C / 256) * a.R * a.S;
+  const int tiles = ((a.K + 255) / 256) * (a.C / 256) * a.R * a.S;
   int V = 0;
   for (int l = 0; l < a.nlev; ++l) V += (a.lev[l].P + 63) / 64 * 64;
   const int kt = V / 64;
@@ -295,7 +301,7 @@ int splits_for(const WgradArgs& a, int cus, int* vps_out) {
 }  // namespace
 
 bool wgrad256_supported(const WgradArgs& a) {
-  if ((a.K & 255) || (a.C & 255)) return false;
+  if ((a.K & 7) || a.K < 256 || (a.C & 255)) return false;      // K: any multiple of 8 from 256 up (the last q-tile is masked)
   long long V = 0;
   for (int l = 0; l < a.nlev; ++l) V += (a.lev[l].P + 63) / 64 * 64;
   return V >= 64 && V < (1ll << 30);
@@ -304,13 +310,13 @@ bool wgrad256_supported(const WgradArgs& a) {
 long long wgrad256_workspace_bytes(const WgradArgs& a, int cus) {
   int vps = 0;
   const int nz = splits_for(a, cus, &vps);
-  const long long tiles = (long long)(a.K / 256) * (a.C / 256) * a.R * a.S;
+  const long long tiles = (long long)((a.K + 255) / 256) * (a.C / 256) * a.R * a.S;
   return (long long)nz * tiles * SLAB * (long long)sizeof(float);
 }
 
 int launch_wgrad256(WgradArgs& a, int cus, float* ws, long long ws_bytes, hipStream_t st) {
   if (!wgrad256_supported(a)) return SOD_EARG;
-  a.QT = a.K / 256; a.CT = a.C / 256;
+  a.QT = (a.K + 255) / 256; a.CT = a.C / 256;
   const int tiles = a.QT * a.CT * a.R * a.S;
   int V = 0;
   for (int l = 0; l < a.nlev; ++l) {

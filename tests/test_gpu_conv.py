@@ -179,6 +179,8 @@ WGRAD256_CASES = [
     (1, 10, 66, 256, 256, 3, 1, 2, 2),     # dilation on the incremental path
     (1, 3, 5, 256, 256, 3, 1, 1, 1),       # a single, mostly padded K-tile
     (3, 25, 42, 512, 512, 3, 1, 1, 1),     # res5 conv2 geometry: 36 tiles
+    (2, 13, 21, 256, 720, 3, 1, 1, 1),     # RetinaNet cls_score: K = 9 x 80 = 720, the last q-tile holds 208 of its 256 rows
+    (2, 9, 11, 256, 264, 1, 1, 0, 1),      # 8 rows in the last q-tile
 ]
 
 
@@ -228,7 +230,7 @@ def test_conv_wgrad256_rejects_unsupported(cuda):
     from slenderobjdet_amd import _C
     from slenderobjdet_amd.layers import functional as HF
 
-    dy = torch.zeros((1, 8, 8, 128), dtype=torch.bfloat16, device=cuda)      # K = 128: not a multiple of 256
+    dy = torch.zeros((1, 8, 8, 128), dtype=torch.bfloat16, device=cuda)      # K = 128: below one 256-row tile
     x = torch.zeros((1, 8, 8, 256), dtype=torch.bfloat16, device=cuda)
     dw = torch.zeros((128, 1, 1, 256), dtype=torch.float32, device=cuda)
     with pytest.raises(_C.SlenderHipError):
