@@ -540,6 +540,76 @@ def test_ablation_heads_in_f32_mode_vs_oracle(cuda, f32mode, which):
     print(f"\nf32 mode AblationMetaArch {which}: {checked} head parameter gradients, worst relative distance to the fp32 oracle head {worst:.2e}")
 
 
+@pytest.mark.parametrize("where", ["tower_v1", "tower_v2", "backbone"])
+def test_fcos_with_deformable_convs_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, where):
+    """The DCN configurations of FCOS (configs/fcos/*dcn*.yaml: MODEL.FCOS.USE_DCN_IN_TOWER with DeformConv / ModulatedDeformConv as the
+    last tower conv; MODEL.RESNETS.DEFORM_ON_PER_STAGE = detectron2's DeformBottleneckBlock with FrozenBN folded into the deformable conv)
+    in the validation mode: one step of FCOS R18 / R50 against the fp32 and float64 oracles - losses to 2e-5 (5e-5 with the backbone
+    blocks: offsets of several pixels at random initialisation put samples next to pixel boundaries), every gradient no further from
+    float64 than 1.5x the CPU fp32 oracle is (+ the R18 / R50 floors of the plain FCOS test)."""
+    from bench import make_cfg
+    from oracle.model import OracleFCOS
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+
+    backbone = where == "backbone"
+    cfg = make_cfg(50 if backbone else 18)
+    if backbone:
+        cfg.MODEL.RESNETS.DEFORM_ON_PER_STAGE = [False, True, True, True]
+        cfg.MODEL.RESNETS.DEFORM_MODULATED = True
+    else:
+        cfg.MODEL.FCOS.USE_DCN_IN_TOWER = True
+        cfg.MODEL.FCOS.USE_DCN_V2 = where == "tower_v2"
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    if backbone:            # offsets of a fraction of a pixel: at random initialisation the offset convs see activations of ~1e2
+        from slenderobjdet_amd.modeling.backbone.resnet import DeformBottleneckBlock
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, DeformBottleneckBlock):      # detectron2 zero-initialises the offset conv: give it something to sample with
+                    m.conv2_offset.weight.normal_(0.0, 1e-4)
+                    m.conv2_offset.weight[m.n_off:].zero_()
+        model.arena.bump()
+    opt = build_optimizer(cfg, model)
+    data = synthetic_batch(2, 192, 256, 3, device="cuda")
+    cpu = [{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data]
+    refs = {}
+    for tag in ("f32", "f64"):
+        oracle = OracleFCOS.from_hip_model(model, emulate_bf16=False)
+        if tag == "f64":
+            oracle.double()
+        losses = oracle.losses(cpu)
+        names = list(oracle.trainable().keys())
+        refs[tag] = ({k: float(v.detach()) for k, v in losses.items()},
+                     dict(zip(names, torch.autograd.grad(sum(losses.values()), list(oracle.trainable().values())))))
+    got = model(data)
+    total = sum(got.values())
+    opt.zero_grad()
+    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    ltol = 5e-5 if backbone else 2e-5
+    for k, b in refs["f64"][0].items():
+        a = float(got[k].detach())
+        assert abs(a - b) <= ltol * max(abs(b), 1e-3), (k, a, b)
+    worst, floor = [0.0, 0.0, 0.0], (5e-3 if backbone else 1e-4)
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        gq = p.grad.detach().double().cpu()
+        if gq.dim() == 4:
+            gq = gq.permute(0, 3, 1, 2)
+        r32, r64 = refs["f32"][1][name].double(), refs["f64"][1][name]
+        if gq.shape != r64.shape:          # offset convs: 18 / 27 real rows of the padded 24 / 32
+            assert (gq[r64.shape[0]:] == 0).all(), name
+            gq = gq[: r64.shape[0]]
+        n = max(r64.norm().item(), 1e-30)
+        d_hip, d_cpu, d_pair = (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, (gq - r32).norm().item() / n
+        worst = [max(worst[0], d_hip), max(worst[1], d_cpu), max(worst[2], d_pair)]
+        assert d_hip <= 1.5 * d_cpu + floor, (name, d_hip, d_cpu)
+    print(f"\nf32 mode FCOS DCN {where}: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
+
+
 def test_bf16_only_devices_refuse_in_f32_mode(cuda, f32mode):
     """No silent precision mixing: what exists only on the bf16 product path raises in the validation mode."""
     from slenderobjdet_amd._C import SlenderHipError
