@@ -610,6 +610,58 @@ def test_fcos_with_deformable_convs_in_f32_mode_matches_the_fp32_oracle(cuda, f3
     print(f"\nf32 mode FCOS DCN {where}: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
 
 
+def test_fcos_resnext_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode):
+    """ResNeXt bottlenecks (NUM_GROUPS 32 / WIDTH_PER_GROUP 8 / STRIDE_IN_1X1 false, depth 50; the grouped 3x3 as the block-diagonal
+    embedding of its weight) in the validation mode: losses to 2e-5, gradients (the grouped convs' in the reference's (K, C / 32, 3, 3)
+    shape) no further from float64 than 1.5x the CPU fp32 oracle + the R50 floor."""
+    from bench import make_cfg
+    from oracle.model import OracleFCOS
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.solver import build_optimizer
+
+    cfg = make_cfg(50)
+    cfg.MODEL.RESNETS.NUM_GROUPS, cfg.MODEL.RESNETS.WIDTH_PER_GROUP, cfg.MODEL.RESNETS.STRIDE_IN_1X1 = 32, 8, False
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    data = synthetic_batch(2, 192, 256, 3, device="cuda")
+    cpu = [{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data]
+    refs = {}
+    for tag in ("f32", "f64"):
+        oracle = OracleFCOS.from_hip_model(model, emulate_bf16=False)
+        if tag == "f64":
+            oracle.double()
+        losses = oracle.losses(cpu)
+        names = list(oracle.trainable().keys())
+        refs[tag] = ({k: float(v.detach()) for k, v in losses.items()},
+                     dict(zip(names, torch.autograd.grad(sum(losses.values()), list(oracle.trainable().values())))))
+    got = model(data)
+    total = sum(got.values())
+    opt.zero_grad()
+    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    for k, b in refs["f64"][0].items():
+        a = float(got[k].detach())
+        assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
+    worst, grouped = [0.0, 0.0, 0.0], 0
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        gq = p.grad.detach().double().cpu()
+        if gq.dim() == 4:
+            gq = gq.permute(0, 3, 1, 2)
+        r32, r64 = refs["f32"][1][name].double(), refs["f64"][1][name]
+        assert gq.shape == r64.shape, (name, gq.shape, r64.shape)
+        grouped += int(gq.dim() == 4 and gq.shape[1] * 32 == gq.shape[0] and gq.shape[2] == 3)
+        n = max(r64.norm().item(), 1e-30)
+        d_hip, d_cpu, d_pair = (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, (gq - r32).norm().item() / n
+        worst = [max(worst[0], d_hip), max(worst[1], d_cpu), max(worst[2], d_pair)]
+        assert d_hip <= 1.5 * d_cpu + 5e-3, (name, d_hip, d_cpu)
+    assert grouped >= 10
+    print(f"\nf32 mode FCOS ResNeXt-50 32x8d: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
+
+
 def test_bf16_only_devices_refuse_in_f32_mode(cuda, f32mode):
     """No silent precision mixing: what exists only on the bf16 product path raises in the validation mode."""
     from slenderobjdet_amd._C import SlenderHipError
