@@ -821,6 +821,7 @@ __global__ __launch_bounds__(256) void anchor_match1_kernel(const float* __restr
                                                             float* __restrict__ best_val, int* __restrict__ best_idx,
                                                             unsigned* __restrict__ gt_best_bits) {
   extern __shared__ unsigned lbest[];   // [G]
+  __shared__ P2 rot_pts[D == 5 ? 24 * 256 : 1];
   for (int g = threadIdx.x; g < G; g += 256) lbest[g] = 0u;
   __syncthreads();
   for (int i = blockIdx.x * 256 + threadIdx.x; i < A; i += gridDim.x * 256) {
@@ -829,7 +830,9 @@ __global__ __launch_bounds__(256) void anchor_match1_kernel(const float* __restr
     for (int e = 0; e < D; ++e) a[e] = anchors[(long long)i * D + e];
     float bv = -1.f; int bi = 0;
     for (int g = 0; g < G; ++g) {
-      const float v = match_iou<D>(gts + g * D, a);
+      float v;
+      if constexpr (D == 5) v = fmaxf(iou_rotated_lds(gts + g * D, a, rot_pts + threadIdx.x, 256), 0.f);
+      else v = match_iou<D>(gts + g * D, a);
       if (v > bv) { bv = v; bi = g; }            // first maximum wins (torch.max(dim=0))
       if (v > 0.f) atomicMax(&lbest[g], __float_as_uint(v));  // v >= 0: uint order == float order; lbest starts at 0, so a zero changes nothing
                                                              // (and almost every pair is a zero: 256 threads on one LDS word serialise)

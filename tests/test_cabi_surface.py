@@ -87,7 +87,7 @@ def test_fastdiv_host_model():
             assert got == n // d, (n, d)
 
 
-def test_counted_wait_kernels_do_not_spill(tmp_path):
+def test_no_kernel_spills_or_uses_scratch(tmp_path):
     """The kernels that pace their LDS-DMA pipelines with counted ``s_waitcnt vmcnt(N)`` (bottleneck_fused.hip, conv_igemm256.hip,
     conv_wgrad256.hip, the ring variants in conv_igemm.hip) derive N from the vector-memory instructions they issue themselves;
     scratch (spill) accesses would join that count - two experimental variants that spilled a few registers computed garbage /
@@ -101,7 +101,9 @@ def test_counted_wait_kernels_do_not_spill(tmp_path):
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    files = ["bottleneck_fused", "conv_igemm256", "conv_wgrad256", "conv_igemm"]
+    # ... and no kernel of the WHOLE library may touch scratch memory at all: a dynamically indexed private array (the rotated IoU's point
+    # list until round 3: 400 B per lane) costs a trip to memory per access
+    files = sorted(f[:-4] for f in os.listdir(src) if f.endswith(".hip"))
     procs = []
     for f in files:
         d = tmp_path / f
@@ -116,5 +118,7 @@ def test_counted_wait_kernels_do_not_spill(tmp_path):
         assert asm, os.listdir(d)
         text = open(d / asm[0]).read()
         spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]      # (SGPR spills go to VGPR lanes, not to memory)
+        if not spills and "__global__" not in open(os.path.join(src, f + ".hip")).read():
+            continue                                                                     # a file without kernels (version.hip)
         assert spills and max(spills) == 0, (f, spills)
         assert "scratch_" not in text, f
