@@ -234,7 +234,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
   __builtin_amdgcn_s_barrier();                    // all LDS-DMA (incl. the dummy tail units) landed; all fragment reads done
 
   // ---- epilogue: as conv_igemm.hip - the wave's accumulators go through LDS (fp32, [pixel][q]) so that every lane owns 16
-  // contiguous output bytes of one pixel; residual / mask loads and the stores are 256-512-B runs.
+  // contiguous output bytes of one pixel; residual / mask loads and the stores are 256-512-B runs.  (Storing straight from the
+  // accumulator layout instead - 4 consecutive channels = 8 bytes per lane, no LDS passes, twice the store instructions - measured
+  // SLOWER: 352.5 vs 341.2 us per P3-sized launch, tools/bench_tower_tile.py; the 32-byte runs per pixel cost more in the memory
+  // pipeline than the 64 LDS passes per lane they save.)
   const int Nout = a.Nout;
   constexpr int QW = 128;
   constexpr int EROWB = QW * 4 + 16;
