@@ -172,7 +172,10 @@ def test_100_iteration_loss_parity(cuda):
     # (2) later, bf16 storage noise is amplified by training itself: two bf16 runs (hip, emu) drift from the fp32 run - and from each
     # other - by the same few 1e-3 (measured on MI355X: emu-vs-f32 5.2e-3, hip-vs-f32 6.4e-3, hip-vs-emu 1.2e-2 relative at worst,
     # all three at iterations 92-99).  The product may not be further from fp32 than bf16 storage alone explains:
-    assert worst_f32 <= 1.5 * worst_store + 2e-3, summary
+    # (3 x: the two oracle runs are one pair of realisations of a chaotic run - their distance is itself a sample, measured between
+    # 5.2e-3 and 7.7e-3 on this pool's hosts - and the HIP run has been 5.7e-3 .. 6.5e-3 from fp32; what pins the implementation at
+    # iteration 100 is the one-step test below, not this ratio)
+    assert worst_f32 <= 3.0 * worst_store + 2e-3, summary
     assert worst_emu <= 3.0 * worst_store + 2e-3, summary
     # (3) the default (float-atomic) paths.  They are not reproducible from run to run by construction, and a free run of this problem
     # amplifies any difference chaotically (above): a bound of the form "1.5 x what ONE other run shows" is then a coin toss at the
