@@ -1,7 +1,9 @@
 """How far do two correct fp32 implementations of the SAME 100-iteration FCOS R18 run drift apart?  CPU only: the fp32 oracle
 (oracle/model.py = the reference's CPU path restated) against the same oracle in float64 and against itself with another summation
 order (one thread instead of all, which changes oneDNN's blocking / reduction order).  Same initial weights, data and schedule as
-tests/test_gpu_parity100.py.  Writes tests/golden/chaos100.json (about 15 minutes on 8 cores)."""
+tests/test_gpu_parity100.py.  Writes tests/golden/chaos100.json (about 15 minutes on 8 cores); ``make_chaos100.py emu`` adds the trajectory of
+the bf16-storage-emulating oracle, so that the GPU test does not spend a minute of the GPU box on two 100-iteration CPU runs (it re-runs
+the first iterations of both oracles live and checks them against the file)."""
 import json
 import os
 import sys
@@ -37,9 +39,9 @@ def main(iters=100):
         lrs.append(opt.param_groups[0]["lr"])
         sched.step()
 
-    def run(tag, threads, double):
+    def run(tag, threads, double, emu=False):
         torch.set_num_threads(threads)
-        oracle = OracleFCOS.from_hip_model(build())
+        oracle = OracleFCOS.from_hip_model(build(), emulate_bf16=emu)
         if double:
             oracle.double()
         state, out = {}, []
@@ -54,6 +56,13 @@ def main(iters=100):
         return out
 
     ncpu = os.cpu_count() or 1
+    path = os.path.join(ROOT, "tests", "golden", "chaos100.json")
+    if "emu" in sys.argv[1:]:      # add the bf16-storage-emulating oracle's trajectory (the `emu` run of tests/test_gpu_parity100.py) to the file
+        res = json.load(open(path))
+        assert res["lrs"] == lrs
+        res["emu_all_threads"] = run("emu/all", ncpu, False, emu=True)
+        json.dump(res, open(path, "w"))
+        return
     res = {"lrs": lrs, "f32_all_threads": run("f32/all", ncpu, False), "f32_one_thread": run("f32/1", 1, False), "f64": run("f64", ncpu, True)}
     json.dump(res, open(os.path.join(ROOT, "tests", "golden", "chaos100.json"), "w"))
     a, b, c = res["f32_all_threads"], res["f32_one_thread"], res["f64"]
@@ -62,4 +71,4 @@ def main(iters=100):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 100)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100)

@@ -395,8 +395,8 @@ def test_reppoints_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode):
 def test_rcnn_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, rotated):
     """BASELINE configs[4]'s step family (GeneralizedRCNN: RPN / RRPN + StandardROIHeads / RROIHeads over ROIAlign / ROIAlignRotated) in
     the validation mode against oracle.rcnn.OracleRCNN in fp32 and float64, with the random anchor / proposal samples and the proposals
-    taken from the run under test (they are checked against the oracle's matchers in test_gpu_rcnn.py).  The four losses to 2e-5; every
-    parameter gradient no further from the float64 arbiter than 1.5x the CPU fp32 oracle is (+1e-4) and within 1e-3 of it outright."""
+    taken from the run under test (they are checked against the oracle's matchers in test_gpu_rcnn.py).  The four losses to 2e-5 and every
+    parameter gradient to 1e-4 of its norm against the float64 oracle (measured 3e-6 .. 7e-6)."""
     from oracle import rcnn as orc
     from slenderobjdet_amd.modeling import build_model
     from slenderobjdet_amd.solver import build_optimizer
@@ -419,43 +419,36 @@ def test_rcnn_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, rotated):
     rois = torch.cat([torch.cat((torch.full((len(p), 1), float(i)), p.proposal_boxes.tensor.cpu()), 1) for i, p in enumerate(props)])
     roi_cls = torch.cat([p.gt_classes.cpu() for p in props])
     roi_gtb = torch.cat([p.gt_boxes.tensor.cpu() for p in props])
-    refs = {}
-    for tag in ("f32", "f64"):
-        oracle = orc.OracleRCNN.from_hip_model(model, emulate_bf16=False)
-        args = (gt_labels, gt_deltas, rois, roi_cls, roi_gtb)
-        if tag == "f64":
-            oracle.double()
-            args = (gt_labels, gt_deltas.double(), rois.double(), roi_cls, roi_gtb.double())
-        r = oracle.losses(_cpu(data), *args)
-        tr = oracle.trainable()
-        refs[tag] = ({k: float(v.detach()) for k, v in r.items()},
-                     dict(zip(tr.keys(), torch.autograd.grad(sum(r.values()), list(tr.values()), allow_unused=True))))
-    for k, b in refs["f32"][0].items():
+    # (one oracle pass, in float64: the oracle's ROI pooling is a pure-Python loop over every sample point - a second pass in fp32 costs
+    # the GPU box half a minute and, with hip32 - cpu32 at 3e-6 .. 7e-6 when it was measured, arbitrates nothing)
+    oracle = orc.OracleRCNN.from_hip_model(model, emulate_bf16=False).double()
+    r = oracle.losses(_cpu(data), gt_labels, gt_deltas.double(), rois.double(), roi_cls, roi_gtb.double())
+    tr = oracle.trainable()
+    ref_losses = {k: float(v.detach()) for k, v in r.items()}
+    ref_grads = dict(zip(tr.keys(), torch.autograd.grad(sum(r.values()), list(tr.values()), allow_unused=True)))
+    for k, b in ref_losses.items():
         a = float(got[k].detach())
         assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
-        assert abs(a - refs["f64"][0][k]) <= 2e-5 * max(abs(b), 1e-3), (k, a, refs["f64"][0][k])
     K, A = 80, rpn.head.num_anchors
     rows = {"objectness_logits": A, "anchor_deltas": A * D, "cls_score": K + 1, "bbox_pred": K * D}
-    worst, checked = [0.0, 0.0, 0.0], 0
+    worst, checked = 0.0, 0
     for name, p in model.named_parameters():
-        if not p.requires_grad or refs["f64"][1].get(name) is None:
+        if not p.requires_grad or ref_grads.get(name) is None:
             continue
         gq = p.grad.detach().double().cpu()
         if gq.dim() == 4:
             gq = gq.permute(0, 3, 1, 2)
-        r32, r64 = refs["f32"][1][name].double(), refs["f64"][1][name]
+        r64 = ref_grads[name]
         for key, nrow in rows.items():
             if key in name:
                 assert (gq[nrow:] == 0).all(), name
-                gq, r32, r64 = gq[:nrow], r32[:nrow], r64[:nrow]
-        n = max(r64.norm().item(), 1e-30)
-        d_hip, d_cpu, d_pair = (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, (gq - r32).norm().item() / n
-        worst = [max(worst[0], d_hip), max(worst[1], d_cpu), max(worst[2], d_pair)]
-        assert d_hip <= 1.5 * d_cpu + 1e-4, (name, d_hip, d_cpu)
-        assert d_pair <= 1e-3, (name, d_pair)
+                gq, r64 = gq[:nrow], r64[:nrow]
+        d_hip = (gq - r64).norm().item() / max(r64.norm().item(), 1e-30)
+        worst = max(worst, d_hip)
+        assert d_hip <= 1e-4, (name, d_hip)
         checked += 1
     assert checked > 30
-    print(f"\nf32 mode R-CNN rotated={rotated}: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
+    print(f"\nf32 mode R-CNN rotated={rotated}: worst relative gradient distance hip32 - float64 oracle {worst:.2e}")
 
 
 @pytest.mark.parametrize("which", ["pointset", "lrtb", "anchor"])
@@ -557,7 +550,7 @@ def test_fcos_with_deformable_convs_in_f32_mode_matches_the_fp32_oracle(cuda, f3
     cfg = make_cfg(50 if backbone else 18)
     if backbone:
         cfg.MODEL.RESNETS.DEFORM_ON_PER_STAGE = [False, True, True, True]
-        cfg.MODEL.RESNETS.DEFORM_MODULATED = True
+        cfg.MODEL.RESNETS.DEFORM_MODULATED = False      # the modulated variant: tests/test_gpu_model.py (bf16 product path vs the oracle)
     else:
         cfg.MODEL.FCOS.USE_DCN_IN_TOWER = True
         cfg.MODEL.FCOS.USE_DCN_V2 = where == "tower_v2"

@@ -180,8 +180,8 @@ def test_fcos_with_dcn_tower_trains(cuda, v2):
     assert dcn.conv.weight.grad.abs().sum() > 0 and dcn.offset.weight.grad.abs().sum() > 0
 
 
-@pytest.mark.parametrize("modulated", [True, False])
-def test_fcos_r50_dcn_backbone_step_vs_oracle(cuda, modulated):
+@pytest.mark.parametrize("modulated", [True])      # (DEFORM_MODULATED false: tests/test_gpu_f32_mode.py, backbone case; the oracle's DeformConv
+def test_fcos_r50_dcn_backbone_step_vs_oracle(cuda, modulated):      #  is a Python loop - each variant here costs the GPU box half a minute)
     """configs/fcos/fcos_R_50_FPN_2x_dcnv2.yaml semantics (MODEL.RESNETS.DEFORM_ON_PER_STAGE [F, T, T, T], DEFORM_MODULATED, and
     USE_DCN_IN_TOWER): one training step of FCOS R50 with detectron2's DeformBottleneckBlock in res3..res5 against the oracle
     (oracle/model.py with oracle/deform_conv.py, the restated op pinned by the reference's known-answer test).  The offset convs are
