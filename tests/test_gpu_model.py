@@ -204,7 +204,7 @@ def test_fcos_r50_dcn_backbone_step_vs_oracle(cuda, modulated):      #  is a Pyt
     torch.manual_seed(0)
     model = build_model(cfg)
     model.train()
-    data = synthetic_batch(2, 256, 320, 3, device="cuda")
+    data = synthetic_batch(2, 192, 256, 3, device="cuda")
     # random offset weights, calibrated block by block to offsets of ~0.5 px: without a checkpoint the ResNet activations grow by orders
     # of magnitude from stage to stage, a fixed weight scale gives offsets of tens of pixels in res4 / res5, and sampling that far away
     # turns bf16 rounding of the offset conv's input into O(1) feature differences (measured: 10 % in res4, 36 % in res5) - a property
