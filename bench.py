@@ -158,6 +158,8 @@ def kernel_name(kind, code):
     if kind == "conv_wgrad":
         if code == 256:
             return "sodconv::conv_wgrad256_kernel"
+        if 1000 <= code < 3000:      # conv_wgrad_ring.hip: G*1000 + NSTAGE*100 + EPI*10 + FDB
+            return f"conv_wgrad_ring_kernel<{code // 1000}, {(code // 100) % 10}, {(code // 10) % 10}, {'true' if code % 10 else 'false'}, 0>"
         return f"void conv_wgrad_kernel<{code // 1000}, {code % 1000}>"
     return variant_kernel_name(code, KIND_MODE[kind])
 

@@ -126,6 +126,13 @@ int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, f
  * tiles, Nout % 256 == 0 and R*S*C >= 1024 run on the 256x256x64 8-phase kernel (whole rounds; a short remainder goes to the
  * 128x128 kernel); 0 = 128x128 kernel only; 2 = the 256 kernel for every shape it supports (tests); -1 = re-read the env. */
 int sod_conv_set_tile256(int mode);
+/* Kernel policy of sod_conv2d_wgrad / _wgrad_ml for the shapes the 256x256 kernel does not take (process-wide): -1 (default) = env
+ * SOD_WGRAD_VARIANT or the library's per-shape choice; 0 = conv_wgrad_kernel (two 4-wave workgroups per CU, float atomics);
+ * G*1000 + NSTAGE*100 + EPI*10 + FDB = one variant of conv_wgrad_ring_kernel for every shape (G = 1 | 2 groups of four waves per
+ * workgroup that split the pixel range and combine through LDS, NSTAGE = 3 | 4 ring slots, EPI 0 = atomics / 1 = slabs + reduce,
+ * FDB = fragment reads one K-step ahead): parity tests and A/B measurements.  Same contraction (reference: the weight gradients of
+ * slender_det/modeling/backbone/fpn.py:94-115), another summation order. */
+int sod_conv_set_wgrad_variant(int variant);
 /* Process-wide, like sod_conv_set_tile256: while on, the single-level sod_conv2d_fwd / sod_conv2d_dgrad launches walk their
  * output tiles last to first, so that a kernel reading a tensor its predecessor has just written starts with the part still in the
  * Infinity Cache.  Results are unaffected. */

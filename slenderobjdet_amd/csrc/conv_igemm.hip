@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include <atomic>
+#include <algorithm>
 
 using namespace sodconv;
 
@@ -170,6 +171,9 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
   const int tap_sign = (MODE == MODE_FWD) ? 1 : -1;
 
   auto stage = [&](int t, char* buf) {
+#if defined(SOD_IGEMM_ABL) && (SOD_IGEMM_ABL & 2)      // measurement build: no K-loop loads (tools/bench_1x1.py)
+    return;
+#endif
     if (linear) {
       // both K orders computed with scalar multiply-highs and selected (no branch in the K loop)
       const uint32_t cc = (__umulhi((uint32_t)t, a.div_rs.mul) + (uint32_t)t) >> a.div_rs.shr;
@@ -260,6 +264,10 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
     for (int j = 0; j < FP; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](const char* cur) {
+#if defined(SOD_IGEMM_ABL) && (SOD_IGEMM_ABL & 1)      // measurement build: no fragment reads, no MFMAs
+    acc[0][0][0] += (float)(uintptr_t)cur;
+    return;
+#endif
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8_t af[FQ], bf[FP];
@@ -437,6 +445,9 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
               for (int e = 0; e < EPL; ++e) v[e] = ((mbits[k] >> e) & 1u) ? v[e] : 0.f;
             }
           }
+#if defined(SOD_IGEMM_ABL) && (SOD_IGEMM_ABL & 8)      // measurement build: no output stores (unless a value no input produces shows up)
+          if (v[0] != 12345.678f) continue;
+#endif
           if constexpr (OUT_F32) {
             sod_store16((float*)g.dst + drow[k] + q, f32x4_t{v[0], v[1], v[2], v[3]});
           } else {
@@ -1057,6 +1068,23 @@ bool use_wgrad256(const WgradArgs& a, float* ws, long long ws_bytes) {
   return V / 64 >= nz * min_kt;
 }
 
+int g_wgrad_variant = -1;    // sod_conv_set_wgrad_variant
+
+// Which variant of conv_wgrad_ring.hip a weight gradient takes (0 = conv_wgrad_kernel below).
+int ring_variant_for(const WgradArgs& a, int tiles, int splits, float* ws, long long ws_bytes) {
+  static const int env = getenv("SOD_WGRAD_VARIANT") ? atoi(getenv("SOD_WGRAD_VARIANT")) : -1;
+  const int v = g_wgrad_variant >= 0 ? g_wgrad_variant : env;
+  if (v >= 0) return v;
+  // Measured per shape (tools/bench_wgrad_backbone.py, FCOS R50 at batch 16): the two groups of a workgroup halve the atomic bytes
+  // (16 instead of 32 MB per launch: -9 ... -15 us on the 1x1 shapes of res3 / res4 / res5) but share one barrier per K-step, which costs
+  // 3 - 9 % in long loops; the gain outweighs that up to ~100 K-steps per group.  Explicit split counts (tests) and deterministic mode
+  // keep conv_wgrad_kernel and its slab reduce.
+  if (splits != 0 || a.det || tiles > 128) return 0;
+  const int cus = device_cus();
+  const long long steps = (long long)a.V / std::max(1, 2 * cus / tiles) / 32;
+  return steps <= 100 ? 2300 : 0;
+}
+
 int launch_wgrad(WgradArgs& a, int splits, int flags, hipStream_t st, float* ws = nullptr, long long ws_bytes = 0) {
   a.det = (flags & WGRAD_DETERMINISTIC) ? 1 : 0;
   if (splits < 0 && (!ws || !wgrad256_supported(a) || wgrad256_workspace_bytes(a, device_cus()) > ws_bytes)) return SOD_EARG;
@@ -1076,6 +1104,45 @@ int launch_wgrad(WgradArgs& a, int splits, int flags, hipStream_t st, float* ws 
     Ptot += a.lev[l].P;
   }
   a.V = V;
+  // In-workgroup split over pixels with an LDS combine (conv_wgrad_ring.hip).  g_wgrad_variant: 0 = the kernel below, > 0 forces one
+  // variant of launch_wgrad_ring for every shape, -1 (default) = SOD_WGRAD_VARIANT or the per-shape choice of ring_variant_for().
+  {
+    const int variant = ring_variant_for(a, tiles, splits, ws, ws_bytes);
+    if (variant > 0) {
+      const int cus = device_cus();
+      const int G = (variant % 10000) / 1000;      // + 10000 * ABL in ablation builds (conv_wgrad_ring.hip)
+      int epi = (variant / 10) % 10;
+      long long total = splits > 0 ? splits : (long long)G * std::max(1, (G == 1 ? 2 : 1) * cus / tiles);
+      const long long maxs = (Ptot + 255) / 256;
+      if (total > maxs) total = maxs;
+      if (total < 1) total = 1;
+      int vps = (int)((V + total - 1) / total);
+      vps = (vps + 63) / 64 * 64;
+      const int nsplit = (V + vps - 1) / vps;
+      a.v_per_split = vps;
+      a.nz = (nsplit + G - 1) / G;
+      a.dbg_plain_store = 0;
+      const long long need = (long long)a.nz * tiles * 128 * 128 * (long long)sizeof(float);
+      if (a.det || epi == 1) {
+        if (!ws || need > ws_bytes) {
+          if (a.det) return SOD_EARG;
+          epi = 0;
+        }
+      }
+      a.partial = (a.det || epi == 1) ? ws : nullptr;
+      const int v = variant - ((variant / 10) % 10) * 10 + (a.partial ? 10 : 0);
+      const int pi = prof_begin(st);
+      const int rc = launch_wgrad_ring(a, v, st);
+      if (rc) return rc;
+      if (a.partial) {
+        const int gx = (tiles * 128 * 32 + 255) / 256;
+        SOD_LAUNCH(wgrad_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, a);
+      }
+      prof_end(pi, st, v % 10000, 1.f, 2);          // G*1000 + NSTAGE*100 + EPI*10 + FDB (bench.py: kernel_name)
+      SOD_CHECK_LAUNCH();
+      return SOD_OK;
+    }
+  }
   // Pixels per K-step: 64 (two slots, 64 KB LDS, 175 VGPRs) or 32 (three-slot ring, 48 KB, 131 VGPRs; the default for every shape).  In
   // the training step the wgrad kernels run on the side stream BESIDE the data-gradient kernels, so the LDS footprint counts as well as
   // the stand-alone rate, and the best setting moved every time one of the kernels changed.  Last sweep on the FCOS R50 step (same box;
@@ -1364,6 +1431,12 @@ extern "C" int sod_conv_prof_collect(float* ms, int* variant, float* frac, int* 
 // the single-level forward / data-gradient launches that follow walk their tiles last to first (see F_REVERSE)
 extern "C" int sod_conv_set_reverse(int on) {
   g_conv_reverse = on ? 1 : 0;
+  return SOD_OK;
+}
+
+extern "C" int sod_conv_set_wgrad_variant(int variant) {
+  if (variant < -1) return SOD_EARG;
+  g_wgrad_variant = variant;
   return SOD_OK;
 }
 

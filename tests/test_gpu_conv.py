@@ -170,6 +170,68 @@ def test_conv_wgrad(cuda, case):
     _close(dw, 2 * dw_ref, 2e-4, f"wgrad accumulate {case}")
 
 
+# conv_wgrad_ring.hip: G groups of four waves split one tile's pixel range and combine through LDS.  G*1000 + NSTAGE*100 + EPI*10 + FDB
+RING_VARIANTS = [1300, 1311, 2300, 2301, 2310, 2311, 2400, 2411]
+
+
+@pytest.mark.parametrize("variant", RING_VARIANTS)
+def test_conv_wgrad_ring_variants(cuda, variant):
+    """Every variant of the in-workgroup split-over-pixels kernel against the oracle on every weight-gradient geometry of this file
+    (incremental / division row paths, strides, dilation, partial q / c tiles, ragged last split, explicit split counts), with
+    accumulation semantics, the folded FrozenBN scale, and - for the slab epilogue - bit-identical repeats."""
+    from slenderobjdet_amd import _C
+    from slenderobjdet_amd.layers import functional as HF
+
+    _C.call("sod_conv_set_wgrad_variant", variant)
+    try:
+        for case in WGRAD_CASES + [(2, 50, 84, 128, 256, 1, 1, 0, 1, 0), (1, 40, 66, 128, 128, 3, 1, 1, 1, 5), (2, 7, 9, 136, 72, 3, 1, 1, 1, 3)]:
+            N, H, W, C, K, R, st, pad, dil, splits = case
+            x = _rand((N, H, W, C), 1)
+            w = _rand((K, R, R, C), 2, 0.05)
+            Ho, Wo = HF.conv_out_size(H, W, R, R, st, pad, dil)
+            dy = _rand((N, Ho, Wo, K), 3)
+            _, dw_ref = onn.conv2d_backward(x, w, dy, st, pad, dil)
+            dyd, xd = dy.to(cuda).bfloat16(), x.to(cuda).bfloat16()
+            dw = torch.zeros((K, R, R, C), dtype=torch.float32, device=cuda)
+            HF.conv2d_wgrad(dyd, xd, dw, R, R, st, pad, dil, splits=splits)
+            _close(dw, dw_ref, 2e-4, f"ring {variant} wgrad {case}")
+            first = dw.clone()
+            HF.conv2d_wgrad(dyd, xd, dw, R, R, st, pad, dil, splits=splits)
+            _close(dw, 2 * dw_ref, 2e-4, f"ring {variant} wgrad accumulate {case}")
+            qs = torch.rand(K, generator=torch.Generator().manual_seed(5)) + 0.5
+            dw3 = torch.zeros_like(dw)
+            HF.conv2d_wgrad(dyd, xd, dw3, R, R, st, pad, dil, splits=splits, qscale=qs.to(cuda))
+            _close(dw3, dw_ref * qs.view(-1, 1, 1, 1), 2e-4, f"ring {variant} wgrad qscale {case}")
+            if (variant // 10) % 10 == 1:
+                dw2 = torch.zeros_like(dw)
+                HF.conv2d_wgrad(dyd, xd, dw2, R, R, st, pad, dil, splits=splits)
+                assert torch.equal(dw2, first), f"ring {variant}: slab epilogue must be bit-identical from run to run {case}"
+        # three levels that share the weights: the virtual pixel index crosses levels inside a group's range
+        N, C, K = 2, 128, 128
+        hws = [(20, 68), (10, 34), (5, 17)]
+        xs = [_rand((N, h, w, C), 10 + i) for i, (h, w) in enumerate(hws)]
+        dys = [_rand((N, h, w, K), 20 + i) for i, (h, w) in enumerate(hws)]
+        ref = sum(onn.conv2d_backward(x, torch.zeros((K, 3, 3, C)), dy, 1, 1, 1)[1] for x, dy in zip(xs, dys))
+        dw = torch.zeros((K, 3, 3, C), dtype=torch.float32, device=cuda)
+        HF.conv2d_wgrad_ml([d.to(cuda).bfloat16() for d in dys], [x.to(cuda).bfloat16() for x in xs], dw, 3, 3, 1, 1, 1)
+        _close(dw, ref, 2e-4, f"ring {variant} multi-level")
+        # deterministic mode always takes the slab epilogue, whatever the variant says
+        prev = HF.DETERMINISTIC
+        HF.DETERMINISTIC = True
+        try:
+            outs = []
+            for _ in range(2):
+                dw = torch.zeros((K, 3, 3, C), dtype=torch.float32, device=cuda)
+                HF.conv2d_wgrad_ml([d.to(cuda).bfloat16() for d in dys], [x.to(cuda).bfloat16() for x in xs], dw, 3, 3, 1, 1, 1)
+                outs.append(dw)
+        finally:
+            HF.DETERMINISTIC = prev
+        _close(outs[0], ref, 2e-4, f"ring {variant} deterministic")
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        _C.call("sod_conv_set_wgrad_variant", -1)
+
+
 # the 256x256 8-wave weight-gradient kernel (conv_wgrad256.hip), forced with splits = -1: (N, H, W, C, K, R, stride, pad, dil)
 WGRAD256_CASES = [
     (2, 40, 72, 256, 256, 3, 1, 1, 1),     # incremental row path (Wo >= 64), 9 tiles, column and image wraps
