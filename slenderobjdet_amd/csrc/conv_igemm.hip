@@ -57,7 +57,7 @@ inline void prof_end(int i, hipStream_t st, int variant, float frac, int mode) {
 }
 
 template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK, int NSTAGE, bool GNB = false>
-__global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WQ * WP, (WQ * WP == 4 && BK == 32 && NSTAGE == 2) ? 4 : 2) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int NW = WQ * WP;                  // waves per workgroup (4 or 8)
   constexpr int BQ = WQ * FQ * 16, BP = WP * FP * 16;
   constexpr int ROWB = BK * 2;                 // bytes per LDS row (one pixel / one output channel, BK contraction elements)
@@ -396,7 +396,9 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
             }
             resv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.res + res_row + q);
           }
-          if (a.flags & F_MASK) maskv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.mask + drow[k] + q);
+          if constexpr (MODE == MODE_DGRAD) {      // forward launches never carry a mask: no registers for it there
+            if (a.flags & F_MASK) maskv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.mask + drow[k] + q);
+          }
           if constexpr (MODE == MODE_DGRAD && !OUT_F32) {
             if (a.flags & F_MASKBITS) mbits[k] = ((const uint8_t*)g.mask)[(drow[k] + q) >> 3];
           }
@@ -435,9 +437,11 @@ __global__ __launch_bounds__(64 * WQ * WP, 2) void conv_igemm_kernel(const ConvA
 #pragma unroll
             for (int e = 0; e < EPL; ++e) v[e] = fmaxf(v[e], 0.f);
           }
-          if (a.flags & F_MASK) {
+          if constexpr (MODE == MODE_DGRAD) {
+            if (a.flags & F_MASK) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) v[e] = ((float)maskv[k][e] > 0.f) ? v[e] : 0.f;
+              for (int e = 0; e < EPL; ++e) v[e] = ((float)maskv[k][e] > 0.f) ? v[e] : 0.f;
+            }
           }
           if constexpr (MODE == MODE_DGRAD && !OUT_F32) {
             if (a.flags & F_MASKBITS) {
