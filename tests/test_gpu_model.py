@@ -427,6 +427,93 @@ def test_bench_two_ranks_data_parallel(cuda, tmp_path):
     assert torch.equal(p0, p1), "replicas diverged: gradient all-reduce / broadcast is broken"
 
 
+def test_two_ranks_equal_one_process_on_the_union(cuda, tmp_path):
+    """2 ranks x 2 images == 1 process x the same 4 images (tools/dp_equivalence.py, deterministic mode, fp32 wire, both ranks on
+    cuda:0 over gloo): the mean of the ranks' losses is the one-process loss to 1e-6 relative, and the parameters after ONE step agree
+    to fp32 rounding - what the folded [num_pos, sum centerness] all-reduce (fcos/utils.py:10-19, fcosv2.py:115-118, 132-133) and the
+    gradient SUM x 1 / world (train_net.py:185-195) are there for.  Per-image work is identical in both launches (FrozenBN, GroupNorm);
+    only the fp32 summation order of the weight gradients over the batch differs."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "dp_equivalence.py")
+    env = dict(os.environ, SOD_DETERMINISTIC="1", SOD_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    out = subprocess.run([sys.executable, script, "--out", one], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    from bench import _free_port
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), script, "--out", two], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    ref = torch.load(os.path.join(one, "rank0.pt"))
+    r0, r1 = torch.load(os.path.join(two, "rank0.pt")), torch.load(os.path.join(two, "rank1.pt"))
+    assert ref["world"] == 1 and r0["world"] == 2
+    assert torch.equal(r0["params"], r1["params"]), "replicas diverged"
+    for k, v in ref["loss"].items():
+        mean = 0.5 * (r0["loss"][k] + r1["loss"][k])
+        assert abs(mean - v) <= 1e-6 * max(abs(v), 1e-3), (k, mean, v, r0["loss"][k], r1["loss"][k])
+    assert r0["loss"] != r1["loss"]                       # the ranks really saw different images
+    d = (r0["params"] - ref["params"]).abs().max().item()
+    scale = ref["params"].abs().max().item()
+    assert d <= 2e-6 * scale, (d, scale)
+    # and the step was a real one: the update itself is orders of magnitude above that bound for some parameter
+    torch.manual_seed(1)
+    from bench import make_cfg
+    from slenderobjdet_amd.modeling import build_model
+    init = build_model(make_cfg(18)).arena.params.detach().float().cpu()
+    assert (ref["params"] - init).abs().max().item() > 100 * max(d, 1e-9)
+
+
+def test_fcos_r50_full_size_step(cuda):
+    """BASELINE configs[1] - the configuration bench.py times - at its real depth and resolution (FCOS R50-FPN, 800x1344, L = 22 400
+    locations; batch reduced to 2): targets bit-exact, the three losses within 1e-4 of oracle/losses.py evaluated on the product's own
+    head outputs (fcosv2.py:104-148 restated; Scale + exp of fcosv2.py:372-378 applied on the CPU), and one finite SGD step that
+    changes the loss.  The FCOS twin of test_retinanet_r50_full_size_step."""
+    from bench import train_step
+    from oracle import fcos_targets as ot
+    from oracle import losses as ol
+    from slenderobjdet_amd.data import synthetic_batch
+
+    cfg, model, opt = _build(50)
+    data = synthetic_batch(2, 800, 1333, 77, device="cuda")
+    hw = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    inst = [d["instances"] for d in data]
+    ref_l, ref_r = ot.targets_for_batch(hw, model.fpn_strides, [i.gt_boxes.tensor.cpu() for i in inst], [i.gt_classes.cpu() for i in inst],
+                                        model.center_sampling_radius, 80)
+    labels, reg_t, ctr_t, stats = model.get_ground_truth(hw, inst)
+    assert labels.shape == (2, 22400)
+    assert torch.equal(labels.cpu().long(), ref_l) and torch.equal(reg_t.cpu(), ref_r)
+    with torch.no_grad():
+        imgs = model.preprocess_image(data)
+        feats = model.backbone(imgs.tensor)
+        cls_t, box_t = model.head.run_towers([feats[f] for f in model.in_features])
+        assert [tuple(t.shape[1:3]) for t in cls_t] == hw
+        cls_buf, box_buf, _ = model.head.predict(cls_t, box_t)
+    K = 80
+    assert not model.head.norm_reg_targets               # fcosv2.py:377-380: exp(Scale(bbox_pred)) is the regression output
+    cls_cpu, box_cpu = cls_buf.float().cpu(), box_buf.float().cpu()
+    ctr_cpu = box_cpu[..., 4] if model.head.centerness_on_reg else cls_cpu[..., K]      # fcosv2.py:366-371: which tower carries centerness
+    scales = model.head.scales.detach().float().cpu()
+    pred, off = [], 0
+    for l, (h, w) in enumerate(hw):
+        pred.append(torch.exp(box_cpu[:, off:off + h * w, :4] * scales[l]))
+        off += h * w
+    pred = torch.cat(pred, 1)
+    ref = ol.fcos_losses(ref_l.reshape(-1), ref_r.reshape(-1, 4), cls_cpu[..., :K].reshape(-1, K), pred.reshape(-1, 4), ctr_cpu.reshape(-1),
+                         K, model.focal_loss_alpha, model.focal_loss_gamma, model.iou_loss_type)
+    got = model(data)
+    for k in ref:
+        a, b = float(got[k].detach()), float(ref[k])
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-3), (k, a, b)
+    l0 = float(train_step(model, opt, data).detach())
+    l1 = float(train_step(model, opt, data).detach())
+    assert l0 == l0 and l1 == l1 and abs(l0) < 1e4 and abs(l1) < 1e4 and l1 != l0
+    gn = float(model.arena.grads.float().norm())
+    assert gn == gn and 0 < gn < 1e8
+
+
 def test_bench_rccl_rehearsal_single_rank(cuda):
     """``python bench.py --rccl-rehearsal``: a ONE-rank RCCL ("nccl") process group on the real GPU with every data-parallel
     collective issued anyway - parameter broadcast, the asynchronous normaliser all-reduce waited for in front of the loss node, the
