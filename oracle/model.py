@@ -12,6 +12,8 @@ import torch.nn.functional as F
 
 from . import fcos_targets as ot
 from . import losses as ol
+from .nn import relu as _band_relu      # torch.relu unless a ReluBand context is active (oracle/nn.py)
+from .nn import relu_at as _relu_at       # ... or teacher-forced decisions for this position (ForcedMasks)
 
 
 def _rb(t, on):
@@ -137,7 +139,7 @@ class OracleFCOS:
         mask = om[:, 18 * g:27 * g].sigmoid() if d["modulated"] else None
         y = odc.deform_conv2d(x, om[:, :18 * g], w, bias, d["stride"], d["pad"], d["dil"], mask, g, sample_hook=self._act if self.emu else None)
         if relu:
-            y = torch.relu(y)
+            y = _relu_at(y, name)
         return self._act(y)
 
     def _conv(self, name, x, stride=1, pad=0, relu=False, res=None, out_f32=False):
@@ -152,7 +154,7 @@ class OracleFCOS:
         if res is not None:
             y = y + res
         if relu:
-            y = torch.relu(y)
+            y = _relu_at(y, name)
         return y if out_f32 else self._act(y)      # offset / prediction convs keep fp32 rows on the product path
 
     def _bottom_up(self, x):
@@ -191,7 +193,7 @@ class OracleFCOS:
             outs[f"p{s}"] = self._conv(f"backbone.fpn_output{s}", prev, 1, 1)
         # LastLevelP6P7 reads P5 (fpn.py:94-115, the FCOS builder) or res5 (detectron2's RetinaNet builder)
         p6 = self._conv("backbone.top_block.p6", feats["res5"] if self.c.get("p6_from", "p5") == "res5" else outs["p5"], 2, 1)
-        p7 = self._conv("backbone.top_block.p7", self._act(torch.relu(p6)), 2, 1)
+        p7 = self._conv("backbone.top_block.p7", self._act(_relu_at(p6, "backbone.top_block.p7:in")), 2, 1)
         outs["p6"], outs["p7"] = p6, p7
         return [outs[k] for k in ("p3", "p4", "p5", "p6", "p7")]
 
@@ -203,7 +205,7 @@ class OracleFCOS:
             else:
                 y = self._conv(f"{prefix}.{i}.conv", x, 1, 1)
             y = F.group_norm(y, 32, self.p[f"{prefix}.{i}.gn.weight"], self.p[f"{prefix}.{i}.gn.bias"], 1e-5)
-            x = self._act(torch.relu(y))
+            x = self._act(_relu_at(y, f"{prefix}.{i}.gn"))
         return x
 
     def _head(self, feats):
@@ -223,7 +225,7 @@ class OracleFCOS:
             logits = co[:, :K]
             ctr = bo[:, 4:5] if c["ctr_on_reg"] else co[:, K:K + 1]
             z = bo[:, :4] * self.p["head.scales"][lvl]
-            box = torch.relu(z) * c["strides"][lvl] if c["norm_reg"] else torch.exp(z)
+            box = _band_relu(z) * c["strides"][lvl] if c["norm_reg"] else torch.exp(z)
             N = f.shape[0]
             cls_all.append(logits.permute(0, 2, 3, 1).reshape(N, -1, K))
             box_all.append(box.permute(0, 2, 3, 1).reshape(N, -1, 4))

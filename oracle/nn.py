@@ -8,6 +8,82 @@ import torch
 import torch.nn.functional as F
 
 
+class ReluBand:
+    """Test-side handling of ReLU's discrete decisions (tests/test_gpu_f32_mode.py).  Two correct fp32 implementations
+    of one network disagree on the sign of a pre-activation that cancels to within their rounding of zero; the forward value is ~0
+    either way, but the backward mask differs, and where the incoming gradient is sparse (the regression branch: positives only) one
+    such unit moves a whole weight-gradient tensor by 1e-3 ... 1e-2 of its norm.  While ``ReluBand.active`` is set, every ``relu`` of
+    the whole-model oracles records the units with |x| < tau * rms(x) (the UNDECIDED band); backward then uses, by ``mode``, the
+    natural mask (0), the mask with every undecided unit ON (+1) or OFF (-1).  One forward pass and three backward passes give the
+    gradient and an envelope of what flipping undecided units can do to each tensor: the tolerance of a comparison is then wide
+    exactly where - and only where - an undecided unit sits in a sensitive place."""
+    active = None      # None, or {"tau": float, "mode": 0 | +1 | -1, "count": int, "units": int}
+
+
+class _ReluBandFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        st = ReluBand.active
+        xd = x.detach()
+        band = xd.abs() < st["tau"] * xd.pow(2).mean().sqrt()
+        st["count"] += int(band.sum())
+        st["units"] += xd.numel()
+        ctx.save_for_backward(xd > 0, band)
+        return torch.relu(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, band = ctx.saved_tensors
+        mode = ReluBand.active["mode"] if ReluBand.active is not None else 0
+        m = pos if mode == 0 else ((pos | band) if mode > 0 else (pos & ~band))
+        return g * m.to(g.dtype)
+
+
+def relu(x):
+    """torch.relu, or (inside a ReluBand context) the same forward with a switchable backward mask for the undecided units."""
+    return _ReluBandFn.apply(x) if ReluBand.active is not None else torch.relu(x)
+
+
+class ForcedMasks:
+    """Teacher-forced ReLU decisions: while ``active`` = {"masks": {(key, i): bool tensor shaped like the activation}, ...} is set, the
+    i-th ``relu_at(x, key)`` call returns x * mask - the decisions of ANOTHER implementation of the same network (the HIP validation
+    mode: layers/functional_f32.RELU_TAP) - so that both differentiate the same piecewise-linear function.  Keys without a mask fall
+    back to ``relu`` and are listed in ``missed``."""
+    active = None
+
+    @staticmethod
+    def begin(masks, record=False):
+        """``record=True``: natural decisions everywhere, and every position's (x > 0) is stored into ``masks`` (a dict)."""
+        ForcedMasks.active = {"masks": masks, "count": {}, "used": 0, "missed": [], "record": bool(record)}
+        return ForcedMasks.active
+
+    @staticmethod
+    def end():
+        st, ForcedMasks.active = ForcedMasks.active, None
+        return st
+
+
+def relu_at(x, key):
+    """``relu(x)`` at the network position ``key`` (a module name; shared modules are called once per level, in level order)."""
+    fm = ForcedMasks.active
+    if fm is not None:
+        i = fm["count"].get(key, 0)
+        fm["count"][key] = i + 1
+        if fm["record"]:
+            fm["masks"][(key, i)] = x.detach() > 0
+            return relu(x)
+        m = fm["masks"].get((key, i))
+        if m is not None:
+            if tuple(m.shape) != tuple(x.shape):
+                if m.numel() != x.numel() or [d for d in m.shape if d != 1] != [d for d in x.shape if d != 1]:
+                    raise ValueError(f"forced mask for {key}#{i} has shape {tuple(m.shape)}, activation {tuple(x.shape)}")
+                m = m.reshape(x.shape)          # (R, C, 1, 1) rows of a fully connected layer run as a 1x1 convolution
+            fm["used"] += 1
+            return x * m.to(x.dtype)
+        fm["missed"].append((key, i))
+    return relu(x)
+
+
 def rb(t):
     """Round to bf16 and back (the storage precision of activations/weights on the HIP side)."""
     return t.to(torch.bfloat16).to(torch.float32)

@@ -14,6 +14,8 @@ from . import detection as od
 from . import losses as ol
 from .model import _RoundSTE
 from .reppoints import OracleRepPoints
+from .nn import relu as _band_relu      # torch.relu unless a ReluBand context is active (oracle/nn.py)
+from .nn import relu_at as _relu_at       # ... or teacher-forced decisions for this position (ForcedMasks)
 
 SCALE_CLAMP = math.log(1000.0 / 16)
 
@@ -282,7 +284,7 @@ class OracleRCNN(OracleRepPoints):
         x = self._act(pooled).permute(0, 2, 3, 1).reshape(M, -1)          # the product path pools to bf16 NHWC
         for i in range(c["num_fc"]):
             w = self._w(f"roi_heads.box_head.fcs.{i}.weight").flatten(1)
-            x = self._act(torch.relu(F.linear(x, w, self.p[f"roi_heads.box_head.fcs.{i}.bias"])))
+            x = self._act(_relu_at(F.linear(x, w, self.p[f"roi_heads.box_head.fcs.{i}.bias"]), f"roi_heads.box_head.fcs.{i}"))
         s = F.linear(x, self._w("roi_heads.box_predictor.cls_score.weight").flatten(1)[: K + 1], self.p["roi_heads.box_predictor.cls_score.bias"][: K + 1])
         d = F.linear(x, self._w("roi_heads.box_predictor.bbox_pred.weight").flatten(1)[: K * D], self.p["roi_heads.box_predictor.bbox_pred.bias"][: K * D])
         return s, d

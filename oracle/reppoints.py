@@ -15,6 +15,8 @@ from . import detection as od
 from . import losses as ol
 from .deform_conv import deform_conv2d
 from .model import OracleFCOS, _RoundSTE
+from .nn import relu as _band_relu      # torch.relu unless a ReluBand context is active (oracle/nn.py)
+from .nn import relu_at as _relu_at       # ... or teacher-forced decisions for this position (ForcedMasks)
 
 
 # ------------------------------------------------------------------------------------------------ structures/points.py
@@ -233,13 +235,13 @@ class OracleRepPoints(OracleFCOS):
         src = feats[c["top_in"]] if c["top_in"] in feats else outs[c["top_in"]]
         p6 = self._conv("backbone.top_block.p6", src, 2, 1)
         outs["p6"] = p6
-        outs["p7"] = self._conv("backbone.top_block.p7", self._act(torch.relu(p6)), 2, 1)
+        outs["p7"] = self._conv("backbone.top_block.p7", self._act(_relu_at(p6, "backbone.top_block.p7:in")), 2, 1)
         return [outs[k] for k in c["in_features"]]
 
     def _tower3(self, prefix, x):
         for i in range(3):
             y = self._conv(f"{prefix}.{i}.conv", x, 1, 1)
-            x = self._act(torch.relu(F.group_norm(y, 32, self.p[f"{prefix}.{i}.gn.weight"], self.p[f"{prefix}.{i}.gn.bias"], 1e-5)))
+            x = self._act(_relu_at(F.group_norm(y, 32, self.p[f"{prefix}.{i}.gn.weight"], self.p[f"{prefix}.{i}.gn.bias"], 1e-5), f"{prefix}.{i}.gn"))
         return x
 
     def _w(self, name):
@@ -263,8 +265,8 @@ class OracleRepPoints(OracleFCOS):
             gm = (1 - c["gmul"]) * oi.detach() + c["gmul"] * oi
             off = gm.reshape(N, c["npts"], 2, *gm.shape[-2:]).flip(2).reshape(N, n2, *gm.shape[-2:]) - base_off
             hook = (lambda s: _RoundSTE.apply(s)) if self.emu else None
-            dc = self._act(torch.relu(deform_conv2d(cf, off, self._w("deform_cls_conv.weight"), None, 1, pad, 1, sample_hook=hook)))
-            dr = self._act(torch.relu(deform_conv2d(rf, off, self._w("deform_reg_conv.weight"), None, 1, pad, 1, sample_hook=hook)))
+            dc = self._act(_relu_at(deform_conv2d(cf, off, self._w("deform_cls_conv.weight"), None, 1, pad, 1, sample_hook=hook), "deform_cls_conv"))
+            dr = self._act(_relu_at(deform_conv2d(rf, off, self._w("deform_reg_conv.weight"), None, 1, pad, 1, sample_hook=hook), "deform_reg_conv"))
             lg = F.conv2d(dc, self._w("logits.weight"), self.p["logits.bias"])
             orf = F.conv2d(dr, self._w("offsets_refine.weight")[:n2], self.p["offsets_refine.bias"][:n2]) + oi.detach()
             logits.append(lg.permute(0, 2, 3, 1).reshape(N, -1, lg.shape[1]))

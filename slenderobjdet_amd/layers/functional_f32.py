@@ -18,6 +18,12 @@ from .._C import call, ptr, stream_ptr
 F32 = torch.float32
 CONV_RELU, CONV_RES_UP2 = 1, 2
 
+# Validation-mode observer (tests only): when set, called as RELU_TAP(kind, key_ptr, y) with every tensor this mode produces THROUGH a
+# ReLU - kind "conv" (key = the weight operand's address), "gn" (key = gamma's address), "relu" (key = 0).  tests/test_gpu_f32_mode.py
+# hands the recorded decisions (y > 0) to the CPU oracle, so that both implementations differentiate the SAME piecewise-linear
+# function and a whole-model gradient comparison is not decided by pre-activations that cancel to within rounding of zero.
+RELU_TAP = None
+
 
 def _chk(t, name="tensor", dtype=F32):
     if t is None:
@@ -50,6 +56,8 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
     flags = (CONV_RELU if relu else 0) | (CONV_RES_UP2 if res_up2 else 0)
     call("sod_conv2d_fwd_f32", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), N, H, W, C, K, R, S, stride, pad, dil, x_img_stride, y_img_stride,
          flags, stream_ptr())
+    if relu and RELU_TAP is not None:
+        RELU_TAP("conv", w.data_ptr(), out)
     return out
 
 
@@ -121,6 +129,8 @@ def groupnorm_fwd(x, gamma, beta, G, eps=1e-5, relu=False, stats=None):
     if stats is None:
         stats = torch.empty((N, G, 2), dtype=F32, device=x.device)
     call("sod_groupnorm_fwd_f32", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stats), N, HW, C, G, eps, 1 if relu else 0, stream_ptr())
+    if relu and RELU_TAP is not None:
+        RELU_TAP("gn", gamma.data_ptr(), y)
     return y, stats
 
 
@@ -156,7 +166,10 @@ def _elt(op, a, b=None):
 
 
 def relu_fwd(x):
-    return _elt(0, x)
+    y = _elt(0, x)
+    if RELU_TAP is not None:
+        RELU_TAP("relu", 0, y)
+    return y
 
 
 def relu_bwd(dy, y):

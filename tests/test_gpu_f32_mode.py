@@ -4,6 +4,8 @@ losses AND every parameter gradient - against the plain fp32 oracle (= the refer
 slender_det/modeling/meta_arch/fcos/fcosv2.py:63-148) far inside north_star's 1e-3: with storage rounding out of the picture the layer
 code, the fused epilogue semantics (residual, up-sampled residual, accumulate, masks), the target assignment, the loss kernels and the
 optimizer are what is left to compare.  The 100-iteration statement lives in tests/test_gpu_parity100.py."""
+import contextlib
+
 import pytest
 import torch
 
@@ -165,18 +167,95 @@ def test_elementwise_f32_kernels(cuda, f32mode):
     _close(out, want, 1e-6)
 
 
+@contextlib.contextmanager
+def _forced(masks):
+    """The oracle code inside takes the PRODUCT's ReLU decisions (oracle.nn.ForcedMasks) wherever ``masks`` has the position."""
+    from oracle.nn import ForcedMasks
+
+    st = ForcedMasks.begin(masks)
+    try:
+        yield st
+    finally:
+        ForcedMasks.end()
+
+
+def _tapped_step(model, opt, data):
+    """One forward + backward of the product in the validation mode with its ReLU decisions recorded.  Returns (losses, masks)."""
+    from oracle.conditioning import ProductReluTap
+
+    with ProductReluTap() as tap:
+        got = model(data)
+        total = sum(got.values())
+        opt.zero_grad()
+        model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    masks, unmatched = tap.masks_for(model)
+    assert not unmatched, unmatched[:5]
+    return got, masks
+
+
+def _forced_oracle_grads(make_oracle, losses_of, masks, dtypes=("f32", "f64")):
+    """{tag: (losses, grads)} of the oracle built by ``make_oracle()`` in fp32 and float64, with the PRODUCT's ReLU decisions forced on
+    (oracle.nn.ForcedMasks); also returns the positions the oracle asked for without getting a mask."""
+    refs, missed = {}, []
+    for tag in dtypes:
+        oracle = make_oracle()
+        if tag == "f64":
+            oracle.double()
+        with _forced(masks) as st:
+            losses = losses_of(oracle)
+            tr = oracle.trainable()
+            grads = dict(zip(tr.keys(), torch.autograd.grad(sum(losses.values()), list(tr.values()), allow_unused=True)))
+        missed = st["missed"]
+        refs[tag] = ({k: float(v.detach()) for k, v in losses.items()}, grads)
+    return refs, missed
+
+
+def _assert_gradients_tight(model, refs, what, max_pair=1e-4, share_2e5=0.9, real_rows=None, min_checked=1):
+    """Every parameter gradient of the HIP fp32 run within ``max_pair`` (1e-4) of its norm from the float64 oracle - and from the CPU
+    fp32 oracle where one was run -, ``share_2e5`` of the tensors within 2e-5: bars a localised kernel error of a few 1e-4 cannot pass.
+    They are possible because all runs differentiate the same piecewise-linear function (the product's ReLU decisions; measured
+    worst case 7e-6 on R18 and R50 alike).  ``real_rows``: {substring of a parameter name: real leading rows of a padded tensor}."""
+    rows = []
+    for name, p in model.named_parameters():
+        if not p.requires_grad or refs["f64"][1].get(name) is None:
+            continue
+        gq = p.grad.detach().double().cpu()
+        if gq.dim() == 4:
+            gq = gq.permute(0, 3, 1, 2)
+        r64 = refs["f64"][1][name]
+        r32 = refs["f32"][1][name].double() if "f32" in refs else r64
+        for key, nrow in (real_rows or {}).items():
+            if key in name:
+                assert (gq[nrow:] == 0).all(), name
+                gq, r32, r64 = gq[:nrow], r32[:nrow], r64[:nrow]
+        if gq.shape != r64.shape:          # padded prediction / offset rows beyond the reference's
+            assert gq.shape[1:] == r64.shape[1:] and (gq[r64.shape[0]:] == 0).all(), (name, gq.shape, r64.shape)
+            gq = gq[: r64.shape[0]]
+        n = max(r64.norm().item(), 1e-30)
+        rows.append(((gq - r32).norm().item() / n, (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, name))
+    assert len(rows) >= min_checked, len(rows)
+    worst = max(rows)
+    share = sum(r[0] <= 2e-5 and r[1] <= 2e-5 for r in rows) / len(rows)
+    print(f"\n{what}: {len(rows)} tensors, worst hip32-cpu32 {worst[0]:.2e} ({worst[3]}), worst hip32-f64 {max(r[1] for r in rows):.2e}, "
+          f"worst cpu32-f64 {max(r[2] for r in rows):.2e}, share <= 2e-5: {share:.3f}")
+    for d_pair, d64, _, name in rows:
+        assert d_pair <= max_pair and d64 <= max_pair, (what, name, d_pair, d64)
+    assert share >= share_2e5, (what, share, sorted(rows)[-5:])
+
+
 @pytest.mark.parametrize("depth", [18, 50])
 def test_fcos_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, depth):
-    """One FCOS training step (BASELINE configs[0] shape family) in the validation mode against the plain fp32 oracle (= the reference's
-    CPU path restated): the three losses to 2e-5 relative - 50x inside north_star's 1e-3 - and EVERY parameter gradient.  Two fp32
-    implementations differ by summation order only, which on a random-init ResNet (identity FrozenBN: activations grow 256x in std) is
-    NOT small for the deep weight gradients: the CPU fp32 oracle itself sits up to 1.1e-2 (R50) from the same model evaluated in float64.
-    The float64 oracle therefore arbitrates: the HIP gradient may be no further from it than 1.5x the CPU fp32 oracle is (+1e-4), and
-    for R18, where fp32 noise is small, it must also agree with the CPU fp32 oracle to 1e-3 of the gradient's norm outright (measured
-    9e-5).  R50 gets a floor of 5e-3 instead of 1e-4: there a second family of tensors (fpn_output4, res4.2 / res4.3, the biases behind
-    them) sits at 2-3e-3 from BOTH CPU oracles while the CPU fp32 / float64 pair agrees to 1e-4 on them, and the deep res3 / res4 weights
-    sit at 1e-2 from float64 in the HIP and the CPU fp32 run alike (tools/f32_grad_table.py): single ReLU decisions on pre-activations
-    that cancel to ~1e-7 of their terms fall differently under different summation orders - discrete events, not rounding growth."""
+    """One FCOS training step (BASELINE configs[0] shape family; R50 = the headline's depth) in the validation mode against the plain
+    fp32 oracle (= the reference's CPU path restated) and the same oracle in float64: the three losses to 2e-5 relative - 50x inside
+    north_star's 1e-3 - and EVERY parameter gradient to 1e-4 of its norm, 90 % of them to 2e-5 (measured worst case 7e-6).
+
+    What makes bars of that size possible on a random-init ResNet: two correct fp32 implementations decide the sign of a pre-activation
+    that cancels to within rounding of zero differently, the regression branch's gradient is sparse (positives only), and ONE such
+    unit at P5 moves every backbone weight gradient by 2e-3 ... 1e-2 of its norm (measured: CPU fp32 oracle against float64, R18
+    2.3e-3, R50 1.1e-2; with the decisions of one run forced onto the other 7e-6 and 8e-6).  So the oracle takes the PRODUCT's ReLU
+    decisions (layers/functional_f32.RELU_TAP -> oracle.conditioning.ProductReluTap -> oracle.nn.ForcedMasks): all three runs then
+    differentiate the same piecewise-linear function, and what is left is summation order.  Until round 4 these tests carried caps of
+    5e-3 (R18) and 2e-2 (R50) for those discrete events."""
     from bench import make_cfg
     from oracle.model import OracleFCOS
     from slenderobjdet_amd.data import synthetic_batch
@@ -190,40 +269,14 @@ def test_fcos_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, depth):
     opt = build_optimizer(cfg, model)
     data = synthetic_batch(2, 256 if depth == 18 else 192, 320 if depth == 18 else 256, 3, device="cuda")
     cpu = [{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data]
-    refs = {}
-    for tag in ("f32", "f64"):
-        oracle = OracleFCOS.from_hip_model(model, emulate_bf16=False)
-        if tag == "f64":
-            oracle.double()
-        losses = oracle.losses(cpu)
-        names = list(oracle.trainable().keys())
-        refs[tag] = ({k: float(v.detach()) for k, v in losses.items()},
-                     dict(zip(names, torch.autograd.grad(sum(losses.values()), list(oracle.trainable().values())))))
-    got = model(data)
-    total = sum(got.values())
-    opt.zero_grad()
-    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    got, masks = _tapped_step(model, opt, data)
+    refs, missed = _forced_oracle_grads(lambda: OracleFCOS.from_hip_model(model, emulate_bf16=False), lambda o: o.losses(cpu), masks)
+    assert not missed, missed[:5]          # every ReLU position of the oracle took the product's decisions
     for k, b in refs["f32"][0].items():
         a = float(got[k].detach())
         assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
         assert abs(a - refs["f64"][0][k]) <= 2e-5 * max(abs(b), 1e-3), (k, a, refs["f64"][0][k])
-    worst = [0.0, 0.0, 0.0]
-    for name, p in model.named_parameters():
-        if not p.requires_grad:
-            continue
-        gq = p.grad.detach().double().cpu()
-        if gq.dim() == 4:
-            gq = gq.permute(0, 3, 1, 2)
-        r32, r64 = refs["f32"][1][name].double(), refs["f64"][1][name]
-        n = max(r64.norm().item(), 1e-30)
-        d_hip, d_cpu, d_pair = (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, (gq - r32).norm().item() / n
-        worst = [max(worst[0], d_hip), max(worst[1], d_cpu), max(worst[2], d_pair)]
-        # (R50: the CPU oracle's own distance to float64 is ONE sample of the same discrete events - on another host or thread count it
-        # may come out at 1e-3 where it was 1.1e-2 here; the bound therefore never drops below the level these events have shown, 2e-2)
-        assert d_hip <= (max(1.5 * d_cpu + 1e-4, 5e-3) if depth == 18 else max(1.5 * d_cpu + 5e-3, 2e-2)), (name, d_hip, d_cpu)
-        if depth == 18:
-            assert d_pair <= 5e-3, (name, d_pair)      # measured 9e-5; 5e-3 = one ReLU decision falling differently on another host
-    print(f"\nf32 mode R{depth}: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
+    _assert_gradients_tight(model, refs, f"f32 mode FCOS R{depth}")
 
 
 @pytest.mark.parametrize("box_reg", ["smooth_l1", "giou"])
@@ -245,41 +298,25 @@ def test_retinanet_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, box_r
     opt = build_optimizer(cfg, model)
     data = synthetic_batch(2, 256, 320, 3, device="cuda")
     cpu = [{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data]
-    refs = {}
-    for tag in ("f32", "f64"):
-        oracle = OracleRetinaNet.from_hip_model(model, emulate_bf16=False)
-        if tag == "f64":
-            oracle.double()
-        losses = oracle.losses(cpu)
-        names = list(oracle.trainable().keys())
-        refs[tag] = ({k: float(v.detach()) for k, v in losses.items()},
-                     dict(zip(names, torch.autograd.grad(sum(losses.values()), list(oracle.trainable().values())))))
-        norm = oracle.new_normalizer
-    got = model(data)
-    total = sum(got.values())
-    opt.zero_grad()
-    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
-    assert abs(float(model.loss_normalizer) - norm) < 1e-4
+    norm0 = float(model.loss_normalizer)          # the EMA state BEFORE the step: the oracle is built after the product has moved it
+    got, masks = _tapped_step(model, opt, data)
+    norms = []
+
+    def losses_of(oracle):
+        oracle.c["normalizer"] = norm0
+        out = oracle.losses(cpu)
+        norms.append(oracle.new_normalizer)
+        return out
+
+    refs, missed = _forced_oracle_grads(lambda: OracleRetinaNet.from_hip_model(model, emulate_bf16=False), losses_of, masks)
+    assert not missed, missed[:5]
+    assert abs(float(model.loss_normalizer) - norms[0]) < 1e-4
     for k, b in refs["f32"][0].items():
         a = float(got[k].detach())
         assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
         assert abs(a - refs["f64"][0][k]) <= 2e-5 * max(abs(b), 1e-3), (k, a, refs["f64"][0][k])
-    worst = [0.0, 0.0, 0.0]
-    for name, p in model.named_parameters():
-        if not p.requires_grad:
-            continue
-        gq = p.grad.detach().double().cpu()
-        if gq.dim() == 4:
-            gq = gq.permute(0, 3, 1, 2)
-        r32, r64 = refs["f32"][1][name].double(), refs["f64"][1][name]
-        n = max(r64.norm().item(), 1e-30)
-        d_hip, d_cpu, d_pair = (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, (gq - r32).norm().item() / n
-        worst = [max(worst[0], d_hip), max(worst[1], d_cpu), max(worst[2], d_pair)]
-        # measured 1e-4 .. 1.3e-3 against float64 and <= 1.5e-4 between the two fp32 runs; the caps (5e-3) are what ONE ReLU decision falling
-        # differently in either run costs a tensor behind it (seen at 2.5e-3 on other inputs) - the oracle runs on whatever host the test gets
-        assert d_hip <= max(1.5 * d_cpu + 1e-4, 5e-3), (name, d_hip, d_cpu)
-        assert d_pair <= 5e-3, (name, d_pair)
-    print(f"\nf32 mode RetinaNet {box_reg}: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
+    # the ReLU decisions are the product's in all three runs (see the FCOS test above); the GIoU / smooth-L1 kinks are not forced
+    _assert_gradients_tight(model, refs, f"f32 mode RetinaNet {box_reg}")
 
 
 @pytest.mark.parametrize("v2", [False, True])
@@ -335,8 +372,8 @@ def test_reppoints_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode):
     """BASELINE configs[3]'s step (RepPointsDetector: ResNet + GN-FPN + two DeformConv layers fed by the learned point offsets,
     rpd.py:621-671; R18 stand-in for the depth) in the validation mode against oracle.reppoints.OracleRepPoints in fp32 and float64.
     The point-to-box assignment depends on the PREDICTED init boxes, so the oracle is given the labels of the run under test after they
-    were checked bit-exact against the oracle's own assignment on the same boxes.  Losses to 2e-5; every parameter gradient no further
-    from the float64 arbiter than 1.5x the CPU fp32 oracle is (+1e-4) and within 1e-3 of the CPU fp32 oracle outright."""
+    were checked bit-exact against the oracle's own assignment on the same boxes.  Losses to 2e-5; every parameter gradient within 1e-4
+    of the float64 AND of the CPU fp32 oracle, all three on the product's ReLU decisions (see the FCOS test)."""
     from oracle import reppoints as orp
     from slenderobjdet_amd.data import synthetic_batch
     from slenderobjdet_amd.modeling import build_model
@@ -350,55 +387,41 @@ def test_reppoints_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode):
     opt = build_optimizer(cfg, model)
     data = synthetic_batch(2, 256, 320, 5, device="cuda")
     cpu = [{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data]
-    got = model(data)
-    tg_hip = model.last_targets
-    total = sum(got.values())
-    opt.zero_grad()
-    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    from oracle.conditioning import ProductReluTap
+    with ProductReluTap() as tap:
+        got = model(data)
+        tg_hip = model.last_targets
+        total = sum(got.values())
+        opt.zero_grad()
+        model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    masks, unmatched = tap.masks_for(model)
+    assert not unmatched, unmatched[:5]
     refs = {}
     for tag in ("f32", "f64"):
         oracle = orp.OracleRepPoints.from_hip_model(model, emulate_bf16=False)
         oracle.normalizer = 20.0
-        if tag == "f64":
-            oracle.double()
-            losses = oracle.losses(cpu, targets=tg)
-        else:
-            losses = oracle.losses(cpu)              # the CPU fp32 oracle's own assignment on its own init boxes
-            tg = oracle.last_targets
-            assert torch.equal(tg_hip[0].cpu().float(), tg[0].float()) and torch.equal(tg_hip[2].cpu().long(), tg[2].long()), "labels differ"
-            assert torch.equal(tg_hip[1].cpu(), tg[1]) and torch.equal(tg_hip[3].cpu(), tg[3])
-        tr = oracle.trainable()
-        refs[tag] = ({k: float(v.detach()) for k, v in losses.items()},
-                     dict(zip(tr.keys(), torch.autograd.grad(sum(losses.values()), list(tr.values()), allow_unused=True))))
+        with _forced(masks) as st:       # the product's ReLU decisions in both oracle runs (see the FCOS test)
+            if tag == "f64":
+                oracle.double()
+                losses = oracle.losses(cpu, targets=tg)
+            else:
+                losses = oracle.losses(cpu)              # the CPU fp32 oracle's own assignment on its own init boxes
+                tg = oracle.last_targets
+                assert torch.equal(tg_hip[0].cpu().float(), tg[0].float()) and torch.equal(tg_hip[2].cpu().long(), tg[2].long()), "labels differ"
+                assert torch.equal(tg_hip[1].cpu(), tg[1]) and torch.equal(tg_hip[3].cpu(), tg[3])
+            tr = oracle.trainable()
+            grads = dict(zip(tr.keys(), torch.autograd.grad(sum(losses.values()), list(tr.values()), allow_unused=True)))
+        assert not st["missed"], st["missed"][:5]
+        refs[tag] = ({k: float(v.detach()) for k, v in losses.items()}, grads)
     for k, b in refs["f32"][0].items():
         a = float(got[k].detach())
         assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
         assert abs(a - refs["f64"][0][k]) <= 2e-5 * max(abs(b), 1e-3), (k, a, refs["f64"][0][k])
-    worst, checked = [0.0, 0.0, 0.0], 0
-    for name, p in model.named_parameters():
-        if not p.requires_grad or refs["f64"][1].get(name) is None:
-            continue
-        gq = p.grad.detach().double().cpu()
-        if gq.dim() == 4:
-            gq = gq.permute(0, 3, 1, 2)
-        r32, r64 = refs["f32"][1][name].double(), refs["f64"][1][name]
-        if name.startswith(("offsets_init.1", "offsets_refine")):        # 18 point coordinates padded to 24 rows
-            assert (gq[18:] == 0).all(), name
-            gq, r32, r64 = gq[:18], r32[:18], r64[:18]
-        n = max(r64.norm().item(), 1e-30)
-        d_hip, d_cpu, d_pair = (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, (gq - r32).norm().item() / n
-        worst = [max(worst[0], d_hip), max(worst[1], d_cpu), max(worst[2], d_pair)]
-        # measured 1e-4 .. 1.3e-3 against float64 and <= 1.5e-4 between the two fp32 runs; the caps (5e-3) are what ONE ReLU decision falling
-        # differently in either run costs a tensor behind it (seen at 2.5e-3 on other inputs) - the oracle runs on whatever host the test gets
-        assert d_hip <= max(1.5 * d_cpu + 1e-4, 5e-3), (name, d_hip, d_cpu)
-        assert d_pair <= 5e-3, (name, d_pair)
-        checked += 1
-    assert checked > 40
-    print(f"\nf32 mode RepPoints: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
+    _assert_gradients_tight(model, refs, "f32 mode RepPoints", real_rows={"offsets_init.1": 18, "offsets_refine": 18}, min_checked=41)
 
 
-@pytest.mark.parametrize("rotated", [True])      # (the axis-aligned family shares every kernel but the IoU / ROIAlign variants, which
-def test_rcnn_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, rotated):      #  test_gpu_rcnn.py covers; its oracle pass costs the GPU box 30 s)
+@pytest.mark.parametrize("rotated", [False, True])
+def test_rcnn_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, rotated):
     """BASELINE configs[4]'s step family (GeneralizedRCNN: RPN / RRPN + StandardROIHeads / RROIHeads over ROIAlign / ROIAlignRotated) in
     the validation mode against oracle.rcnn.OracleRCNN in fp32 and float64, with the random anchor / proposal samples and the proposals
     taken from the run under test (they are checked against the oracle's matchers in test_gpu_rcnn.py).  The four losses to 2e-5 and every
@@ -414,10 +437,7 @@ def test_rcnn_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, rotated): 
     model.train()
     opt = build_optimizer(cfg, model)
     data = _data(2, 96, 128, 21, rotated)
-    got = model(data)
-    total = sum(got.values())
-    opt.zero_grad()
-    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    got, masks = _tapped_step(model, opt, data)
     rpn, roi = model.proposal_generator, model.roi_heads
     D = 5 if rotated else 4
     gt_labels, _, gt_deltas = (t.cpu() for t in rpn.last_targets)
@@ -428,33 +448,18 @@ def test_rcnn_step_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, rotated): 
     # (one oracle pass, in float64: the oracle's ROI pooling is a pure-Python loop over every sample point - a second pass in fp32 costs
     # the GPU box half a minute and, with hip32 - cpu32 at 3e-6 .. 7e-6 when it was measured, arbitrates nothing)
     oracle = orc.OracleRCNN.from_hip_model(model, emulate_bf16=False).double()
-    r = oracle.losses(_cpu(data), gt_labels, gt_deltas.double(), rois.double(), roi_cls, roi_gtb.double())
-    tr = oracle.trainable()
+    with _forced(masks) as st:          # the product's ReLU decisions (backbone, RPN conv, the two FC layers); see the FCOS test
+        r = oracle.losses(_cpu(data), gt_labels, gt_deltas.double(), rois.double(), roi_cls, roi_gtb.double())
+        tr = oracle.trainable()
+        ref_grads = dict(zip(tr.keys(), torch.autograd.grad(sum(r.values()), list(tr.values()), allow_unused=True)))
+    assert not st["missed"], st["missed"][:5]
     ref_losses = {k: float(v.detach()) for k, v in r.items()}
-    ref_grads = dict(zip(tr.keys(), torch.autograd.grad(sum(r.values()), list(tr.values()), allow_unused=True)))
     for k, b in ref_losses.items():
         a = float(got[k].detach())
         assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
     K, A = 80, rpn.head.num_anchors
-    rows = {"objectness_logits": A, "anchor_deltas": A * D, "cls_score": K + 1, "bbox_pred": K * D}
-    worst, checked = 0.0, 0
-    for name, p in model.named_parameters():
-        if not p.requires_grad or ref_grads.get(name) is None:
-            continue
-        gq = p.grad.detach().double().cpu()
-        if gq.dim() == 4:
-            gq = gq.permute(0, 3, 1, 2)
-        r64 = ref_grads[name]
-        for key, nrow in rows.items():
-            if key in name:
-                assert (gq[nrow:] == 0).all(), name
-                gq, r64 = gq[:nrow], r64[:nrow]
-        d_hip = (gq - r64).norm().item() / max(r64.norm().item(), 1e-30)
-        worst = max(worst, d_hip)
-        assert d_hip <= 1e-4, (name, d_hip)
-        checked += 1
-    assert checked > 30
-    print(f"\nf32 mode R-CNN rotated={rotated}: worst relative gradient distance hip32 - float64 oracle {worst:.2e}")
+    _assert_gradients_tight(model, {"f64": (ref_losses, ref_grads)}, f"f32 mode R-CNN rotated={rotated}",
+                            real_rows={"objectness_logits": A, "anchor_deltas": A * D, "cls_score": K + 1, "bbox_pred": K * D}, min_checked=31)
 
 
 @pytest.mark.parametrize("which", ["pointset", "lrtb", "anchor"])
@@ -539,24 +544,25 @@ def test_ablation_heads_in_f32_mode_vs_oracle(cuda, f32mode, which):
     print(f"\nf32 mode AblationMetaArch {which}: {checked} head parameter gradients, worst relative distance to the fp32 oracle head {worst:.2e}")
 
 
-@pytest.mark.parametrize("where", ["tower_v1", "tower_v2", "backbone"])
+@pytest.mark.parametrize("where", ["tower_v1", "tower_v2", "backbone", "backbone_v2"])
 def test_fcos_with_deformable_convs_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode, where):
     """The DCN configurations of FCOS (configs/fcos/*dcn*.yaml: MODEL.FCOS.USE_DCN_IN_TOWER with DeformConv / ModulatedDeformConv as the
     last tower conv; MODEL.RESNETS.DEFORM_ON_PER_STAGE = detectron2's DeformBottleneckBlock with FrozenBN folded into the deformable conv)
     in the validation mode: one step of FCOS R18 / R50 against the fp32 and float64 oracles - losses to 2e-5 (5e-5 with the backbone
-    blocks: offsets of several pixels at random initialisation put samples next to pixel boundaries), every gradient no further from
-    float64 than 1.5x the CPU fp32 oracle is (+ the R18 / R50 floors of the plain FCOS test)."""
+    blocks: offsets of several pixels at random initialisation put samples next to pixel boundaries), every gradient within 1e-4 (2e-4
+    with the backbone blocks) of the float64 and the CPU fp32 oracle on the product's ReLU decisions (see the plain FCOS test).
+    ``backbone_v2`` = DEFORM_MODULATED (configs/fcos/fcos_R_50_FPN_2x_dcnv2.yaml), back in this file since round 4."""
     from bench import make_cfg
     from oracle.model import OracleFCOS
     from slenderobjdet_amd.data import synthetic_batch
     from slenderobjdet_amd.modeling import build_model
     from slenderobjdet_amd.solver import build_optimizer
 
-    backbone = where == "backbone"
+    backbone = where.startswith("backbone")
     cfg = make_cfg(50 if backbone else 18)
     if backbone:
         cfg.MODEL.RESNETS.DEFORM_ON_PER_STAGE = [False, True, True, True]
-        cfg.MODEL.RESNETS.DEFORM_MODULATED = False      # the modulated variant: tests/test_gpu_model.py (bf16 product path vs the oracle)
+        cfg.MODEL.RESNETS.DEFORM_MODULATED = where == "backbone_v2"      # configs/fcos/fcos_R_50_FPN_2x_dcnv2.yaml
     else:
         cfg.MODEL.FCOS.USE_DCN_IN_TOWER = True
         cfg.MODEL.FCOS.USE_DCN_V2 = where == "tower_v2"
@@ -574,49 +580,25 @@ def test_fcos_with_deformable_convs_in_f32_mode_matches_the_fp32_oracle(cuda, f3
     opt = build_optimizer(cfg, model)
     data = synthetic_batch(2, 192, 256, 3, device="cuda")
     cpu = [{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data]
-    refs = {}
-    for tag in ("f32", "f64"):
-        oracle = OracleFCOS.from_hip_model(model, emulate_bf16=False)
-        if tag == "f64":
-            oracle.double()
-        losses = oracle.losses(cpu)
-        names = list(oracle.trainable().keys())
-        refs[tag] = ({k: float(v.detach()) for k, v in losses.items()},
-                     dict(zip(names, torch.autograd.grad(sum(losses.values()), list(oracle.trainable().values())))))
-    got = model(data)
-    total = sum(got.values())
-    opt.zero_grad()
-    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    got, masks = _tapped_step(model, opt, data)
+    refs, missed = _forced_oracle_grads(lambda: OracleFCOS.from_hip_model(model, emulate_bf16=False), lambda o: o.losses(cpu), masks)
+    assert not missed, missed[:5]
     ltol = 5e-5 if backbone else 2e-5
     for k, b in refs["f64"][0].items():
         a = float(got[k].detach())
         assert abs(a - b) <= ltol * max(abs(b), 1e-3), (k, a, b)
-    # (R50 at random initialisation: ONE ReLU decision that falls differently under another summation order moves every tensor behind it.
-    # In the run this floor was set on, everything up to res4.3 agrees with float64 to < 5e-3 in both fp32 implementations, and from
-    # res4.4 on - the rest of the backbone and the head - the HIP run sits at 1e-2 and the CPU fp32 run at 3-5e-3: one event each, at
-    # different places.)
-    worst, floor = [0.0, 0.0, 0.0], (2e-2 if backbone else 1e-4)
-    for name, p in model.named_parameters():
-        if not p.requires_grad:
-            continue
-        gq = p.grad.detach().double().cpu()
-        if gq.dim() == 4:
-            gq = gq.permute(0, 3, 1, 2)
-        r32, r64 = refs["f32"][1][name].double(), refs["f64"][1][name]
-        if gq.shape != r64.shape:          # offset convs: 18 / 27 real rows of the padded 24 / 32
-            assert (gq[r64.shape[0]:] == 0).all(), name
-            gq = gq[: r64.shape[0]]
-        n = max(r64.norm().item(), 1e-30)
-        d_hip, d_cpu, d_pair = (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, (gq - r32).norm().item() / n
-        worst = [max(worst[0], d_hip), max(worst[1], d_cpu), max(worst[2], d_pair)]
-        assert d_hip <= max(1.5 * d_cpu + floor, 5e-2 if backbone else 5e-3), (name, d_hip, d_cpu)
-    print(f"\nf32 mode FCOS DCN {where}: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
+    # every ReLU - the DeformConv + FrozenBN + ReLU of DeformBottleneckBlock and GroupNorm + ReLU behind DFConv2d included - takes the
+    # product's decisions in the oracle; what is left between the runs is summation order and the bilinear sampling arithmetic
+    # (unmodulated backbone blocks: the CPU fp32 oracle itself sits 1.4e-4 from float64 there - offsets of several pixels put samples next
+    # to pixel boundaries, where the bilinear weights cancel - and the HIP run at 1.3e-4; the modulated variant: 7e-6 like everything else)
+    v1_backbone = where == "backbone"
+    _assert_gradients_tight(model, refs, f"f32 mode FCOS DCN {where}", max_pair=5e-4 if v1_backbone else 1e-4, share_2e5=0.2 if v1_backbone else 0.9)
 
 
 def test_fcos_resnext_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode):
     """ResNeXt bottlenecks (NUM_GROUPS 32 / WIDTH_PER_GROUP 8 / STRIDE_IN_1X1 false, depth 50; the grouped 3x3 as the block-diagonal
     embedding of its weight) in the validation mode: losses to 2e-5, gradients (the grouped convs' in the reference's (K, C / 32, 3, 3)
-    shape) no further from float64 than 1.5x the CPU fp32 oracle + the R50 floor."""
+    shape) within 1e-4 of the float64 and the CPU fp32 oracle on the product's ReLU decisions (see the plain FCOS test)."""
     from bench import make_cfg
     from oracle.model import OracleFCOS
     from slenderobjdet_amd.data import synthetic_batch
@@ -631,38 +613,15 @@ def test_fcos_resnext_in_f32_mode_matches_the_fp32_oracle(cuda, f32mode):
     opt = build_optimizer(cfg, model)
     data = synthetic_batch(2, 128, 192, 3, device="cuda")
     cpu = [{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data]
-    refs = {}
-    for tag in ("f32", "f64"):
-        oracle = OracleFCOS.from_hip_model(model, emulate_bf16=False)
-        if tag == "f64":
-            oracle.double()
-        losses = oracle.losses(cpu)
-        names = list(oracle.trainable().keys())
-        refs[tag] = ({k: float(v.detach()) for k, v in losses.items()},
-                     dict(zip(names, torch.autograd.grad(sum(losses.values()), list(oracle.trainable().values())))))
-    got = model(data)
-    total = sum(got.values())
-    opt.zero_grad()
-    model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+    got, masks = _tapped_step(model, opt, data)
+    refs, missed = _forced_oracle_grads(lambda: OracleFCOS.from_hip_model(model, emulate_bf16=False), lambda o: o.losses(cpu), masks)
+    assert not missed, missed[:5]
     for k, b in refs["f64"][0].items():
         a = float(got[k].detach())
         assert abs(a - b) <= 2e-5 * max(abs(b), 1e-3), (k, a, b)
-    worst, grouped = [0.0, 0.0, 0.0], 0
-    for name, p in model.named_parameters():
-        if not p.requires_grad:
-            continue
-        gq = p.grad.detach().double().cpu()
-        if gq.dim() == 4:
-            gq = gq.permute(0, 3, 1, 2)
-        r32, r64 = refs["f32"][1][name].double(), refs["f64"][1][name]
-        assert gq.shape == r64.shape, (name, gq.shape, r64.shape)
-        grouped += int(gq.dim() == 4 and gq.shape[1] * 32 == gq.shape[0] and gq.shape[2] == 3)
-        n = max(r64.norm().item(), 1e-30)
-        d_hip, d_cpu, d_pair = (gq - r64).norm().item() / n, (r32 - r64).norm().item() / n, (gq - r32).norm().item() / n
-        worst = [max(worst[0], d_hip), max(worst[1], d_cpu), max(worst[2], d_pair)]
-        assert d_hip <= max(1.5 * d_cpu + 5e-3, 2e-2), (name, d_hip, d_cpu)      # (R50: see the plain FCOS test above)
+    grouped = sum(int(g is not None and g.dim() == 4 and g.shape[1] * 32 == g.shape[0] and g.shape[2] == 3) for g in refs["f64"][1].values())
     assert grouped >= 10
-    print(f"\nf32 mode FCOS ResNeXt-50 32x8d: worst relative gradient distance  hip32-f64 {worst[0]:.2e}  cpu32-f64 {worst[1]:.2e}  hip32-cpu32 {worst[2]:.2e}")
+    _assert_gradients_tight(model, refs, "f32 mode FCOS ResNeXt-50 32x8d")
 
 
 def test_bf16_only_devices_refuse_in_f32_mode(cuda, f32mode):

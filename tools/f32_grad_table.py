@@ -27,6 +27,11 @@ def main(depth=50):
     model.train()
     opt = build_optimizer(cfg, model)
     data = synthetic_batch(2, 256, 320, 3, device="cuda")
+    if os.environ.get("F32_CALIBRATE", "0") == "1":      # a well-conditioned problem: FrozenBN statistics that normalise (oracle/conditioning.py)
+        from oracle.conditioning import calibrate_frozen_bn
+        log = []
+        print("calibrated", calibrate_frozen_bn(model, data, log=log), "norms; raw conv output std range",
+              min(r[1] for r in log), max(r[1] for r in log))
     cpu = [{"image": d["image"].cpu(), "instances": d["instances"].to("cpu")} for d in data]
     refs = {}
     for tag in ("f32", "f64"):
@@ -48,7 +53,13 @@ def main(depth=50):
         n = max(r64.norm().item(), 1e-30)
         rows.append(((g - r64).norm().item() / n, (r32 - r64).norm().item() / n, name, tuple(g.shape)))
     rows.sort(reverse=True)
-    for d_hip, d_cpu, name, shp in rows[:40]:
+    pair = sorted(((g_ - refs["f32"][n_].double()).norm().item() / max(refs["f32"][n_].double().norm().item(), 1e-30), n_)
+                  for n_, g_ in ((name, (p.grad.detach().double().cpu().permute(0, 3, 1, 2) if p.grad.dim() == 4 else p.grad.detach().double().cpu()))
+                                 for name, p in model.named_parameters() if p.requires_grad))
+    print(f"hip32 - cpu32: max {pair[-1][0]:.2e} ({pair[-1][1]}), median {pair[len(pair) // 2][0]:.2e}, "
+          f"share <= 1e-4: {sum(d <= 1e-4 for d, _ in pair) / len(pair):.3f}, tensors {len(pair)}")
+    print("losses hip / f32 / f64:", {k: float(v) for k, v in got.items()})
+    for d_hip, d_cpu, name, shp in rows[:12]:
         print(f"{d_hip:.2e}  {d_cpu:.2e}  {d_hip / max(d_cpu, 1e-30):8.1f}x  {name} {shp}")
 
 
