@@ -299,6 +299,39 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
+def device_fingerprint(index=0):
+    """Which device produced the line: MI355X parts differ by several per cent at equal code (clocks under load, power cap), so a
+    reader comparing two runs needs to know whether they ran on the same one.  Best effort, never fails the benchmark."""
+    fp = {}
+    try:
+        p = torch.cuda.get_device_properties(index)
+        fp["name"] = p.name
+        uuid = str(getattr(p, "uuid", "") or "")
+        if uuid:
+            fp["uuid_tail"] = uuid[-8:]
+        fp["cus"] = p.multi_processor_count
+    except Exception:
+        pass
+    try:
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if cards:
+            base = os.path.dirname(cards[min(index, len(cards) - 1)])
+            levels = [l.strip() for l in open(os.path.join(base, "pp_dpm_sclk")).read().splitlines() if l.strip()]
+            fp["sclk_levels"] = [l.split(":")[1].strip().rstrip("*").strip() for l in levels][-2:]
+            fp["sclk_active"] = next((l.split(":")[1].strip().rstrip("*").strip() for l in levels if l.endswith("*")), None)
+            caps = glob.glob(os.path.join(base, "hwmon", "hwmon*", "power1_cap"))
+            if caps:
+                fp["power_cap_w"] = int(open(caps[0]).read().strip()) // 1000000
+            for f in ("unique_id", "serial_number"):
+                q = os.path.join(base, f)
+                if os.path.exists(q) and "uuid_tail" not in fp:
+                    fp["uuid_tail"] = open(q).read().strip()[-8:]
+    except Exception:
+        pass
+    return fp
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -478,7 +511,15 @@ def main():
     if dump:   # tests: replicas must stay bit-identical
         torch.save(model.arena.params.detach().cpu(), os.path.join(dump, f"params_rank{rank}.pt"))
     loss_val = float(last.detach())
-    assert loss_val == loss_val, "loss is NaN"
+    # A step that silently produced garbage must not print a number: the last step's loss has to be finite and in the band a detector
+    # loss lives in, and the gradient arena it left behind finite and non-zero (every trainable tensor is written by the backward pass).
+    gnorm = float(model.arena.grads.float().norm())
+    if not (loss_val == loss_val and abs(loss_val) < 1e4):
+        print(f"bench.py: final loss {loss_val} is not a sane training loss", file=sys.stderr)
+        sys.exit(3)
+    if not (gnorm == gnorm and 0.0 < gnorm < 1e12):
+        print(f"bench.py: gradient norm {gnorm} after the last step (NaN / zero / overflow)", file=sys.stderr)
+        sys.exit(3)
 
     if rank == 0:
         imgs = args.steps * args.batch_per_gpu * world
@@ -487,8 +528,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.arch], "global_batch": args.batch_per_gpu * world, "parallelism": f"dp{world}",
-                       "final_loss": round(loss_val, 5)},
+                       "final_loss": round(loss_val, 5), "final_grad_norm": round(gnorm, 5), "base_lr": cfg.SOLVER.BASE_LR,
+                       "device": device_fingerprint(dev.index or 0)},
         }
+        ref_lr = {"fcos": 0.01, "retinanet": 0.01, "reppoints": 0.01, "rrcnn": 0.02}[args.arch]
+        if cfg.SOLVER.BASE_LR != ref_lr:        # not the reference configuration's rate: say so in the line (round-3 advisor finding)
+            out["config"]["base_lr_note"] = (f"reference config trains at {ref_lr} from an ImageNet checkpoint; random initialisation diverges there "
+                                             "(DESIGN.md section 4), and for reppoints the diverging offsets leave the DeformConv kernels' LDS windows")
         if world > 1 or rehearsal:
             # what the collective layer saw, so that a reader of this line can check that the run was the N-rank data-parallel job it
             # claims (reference: train_net.py:185-195 -> detectron2 launch -> one process per GPU, NCCL all-reduce of every gradient)

@@ -133,7 +133,8 @@ int sod_conv_set_tile256(int mode);
  * FDB = fragment reads one K-step ahead): parity tests and A/B measurements.  Same contraction (reference: the weight gradients of
  * slender_det/modeling/backbone/fpn.py:94-115), another summation order. */
 int sod_conv_set_wgrad_variant(int variant);
-/* Process-wide, like sod_conv_set_tile256: while on, the single-level sod_conv2d_fwd / sod_conv2d_dgrad launches walk their
+/* Per CALLING THREAD (the forward thread and autograd's worker thread bracket their own launches; a launch issued by another thread
+ * in between is not affected): while on, the single-level sod_conv2d_fwd / sod_conv2d_dgrad launches of this thread walk their
  * output tiles last to first, so that a kernel reading a tensor its predecessor has just written starts with the part still in the
  * Infinity Cache.  Results are unaffected. */
 int sod_conv_set_reverse(int on);
@@ -423,6 +424,10 @@ int sod_deform_im2col(const void* x, const float* offset, const float* mask, voi
 int sod_deform_conv_bwd_fused(const void* dy, const void* wt, const void* x, const float* offset, const float* mask, float* dx_f32,
                               float* doffset, float* dmask, float* wnorm_ws, int N, int H, int W, int C, int K, int KH, int KW, int stride,
                               int pad, int dil, int deformable_groups, int off_ld, int mask_ld, int mask_is_logit, void* stream);
+/* 1 if sod_deform_conv_bwd_fused takes this layer, 0 if it must go through sod_conv2d_dgrad + sod_deform_col2im: the shape rule above AND
+ * the workgroup's LDS window (8x8 output tile + receptive field + slack) within 96 KB - a 3x3, K = 512 layer with stride 2 (res5's first
+ * block under STRIDE_IN_1X1 = False + DEFORM_ON_PER_STAGE) or stride 2 with dilation 2 does not fit.  Host-only, no GPU call. */
+int sod_deform_conv_bwd_fused_supported(int C, int K, int KH, int KW, int stride, int dil, int deformable_groups);
 int sod_deform_col2im(const void* dcols, const void* x, const float* offset, const float* mask,
                       float* dx_f32, float* doffset, float* dmask,
                       int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int deformable_groups,

@@ -294,33 +294,40 @@ def load_into(model, path, strict=False, allow_missing=()):
     """Loads ``path`` (native or reference format) into ``model``.  Returns the report dict; raises if NOTHING of the file matched
     (a silently random-initialised model is the failure this guards against), if the file is a whole-model checkpoint (it holds tensors
     outside ``backbone.``) and leaves a trainable tensor outside the backbone without a value - unless its name starts with one of the
-    ``allow_missing`` prefixes -, or, with ``strict``, on any incompatibility."""
+    ``allow_missing`` prefixes (``"*"`` accepts every such tensor with a warning, detectron2's DetectionCheckpointer behaviour:
+    fine-tuning from a detector trained with another head or NUM_CLASSES; the trainer forwards MODEL.WEIGHTS_ALLOW_MISSING) -, or,
+    with ``strict``, on any incompatibility.  Every check runs BEFORE the model is touched: a refused file leaves it as it was."""
     sd, meta = load_file(path)
     if meta["native"]:
-        res = model.load_state_dict(sd, strict=False)
-        report = {"missing": list(res.missing_keys), "unexpected": list(res.unexpected_keys), "shape_mismatch": []}
-        matched = len(sd) - len(res.unexpected_keys)
+        own = model.state_dict()
+        mism = [(k, tuple(v.shape), tuple(own[k].shape)) for k, v in sd.items() if k in own and hasattr(v, "shape") and tuple(v.shape) != tuple(own[k].shape)]
+        native = {k: v for k, v in sd.items() if k in own and not any(k == m[0] for m in mism)}
+        report = {"missing": [k for k in own if k not in native], "unexpected": [k for k in sd if k not in own], "shape_mismatch": mism}
     else:
         native, report = reference_to_native(sd, model)
-        model.load_state_dict(native, strict=False)
-        matched = len(native)
+    matched = len(native)
     if matched == 0:
         raise RuntimeError(f"checkpoint {path}: no tensor matches this model ({len(sd)} tensors in the file)")
     if any(not k.startswith("backbone.") for k in sd):
         # a detector checkpoint, not an ImageNet backbone file: a head parameter nothing was found for would train from its random
         # initialisation behind a log line (the padded / re-laid-out heads are exactly where a name or shape rule can be missing)
         params = {n for n, _ in model.named_parameters()}
+        accept_all = "*" in tuple(allow_missing)
         lost = [k for k in list(report["missing"]) + [m[0] for m in report["shape_mismatch"]]
                 if k in params and not k.startswith("backbone.") and not any(k.startswith(a) for a in allow_missing)]
-        if lost:
+        if lost and accept_all:
+            logger.warning("checkpoint %s: %d head parameter(s) keep their initialisation (allow_missing '*'): %s%s", path, len(lost),
+                           ", ".join(lost[:12]), " ..." if len(lost) > 12 else "")
+        elif lost:
             raise RuntimeError(f"checkpoint {path}: {len(lost)} head parameter(s) of the model have no counterpart in the file "
-                               f"(pass allow_missing=(prefix, ...) to accept): {lost[:12]}{' ...' if len(lost) > 12 else ''}")
+                               f"(pass allow_missing=(prefix, ...) or MODEL.WEIGHTS_ALLOW_MISSING to accept): {lost[:12]}{' ...' if len(lost) > 12 else ''}")
+    if strict and any(report[k] for k in report):
+        raise RuntimeError(f"checkpoint {path} is incompatible with the model: {report}")
+    model.load_state_dict(native, strict=False)
     for kind in ("shape_mismatch", "missing", "unexpected"):
         if report[kind]:
             logger.warning("checkpoint %s: %d %s key(s): %s%s", path, len(report[kind]), kind.replace("_", " "),
                            ", ".join(str(k) for k in report[kind][:12]), " ..." if len(report[kind]) > 12 else "")
-    if strict and any(report[k] for k in report):
-        raise RuntimeError(f"checkpoint {path} is incompatible with the model: {report}")
     if getattr(model, "arena", None) is not None:
         model.arena.bump()
     return report, meta

@@ -880,7 +880,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   return SOD_OK;
 }
 
-int g_conv_reverse = 0;    // sod_conv_set_reverse
+thread_local int g_conv_reverse = 0;    // sod_conv_set_reverse: per calling thread (the forward thread and autograd's worker each bracket their own launches)
 int g_conv256_mode = -1;   // -1: read SOD_CONV256 (default 1); 0 off; 1 heuristic; 2 every supported shape
 
 template <int MODE, bool OUT_F32, bool GNB = false>

@@ -701,6 +701,21 @@ extern "C" int sod_deform_col2im(const void* dcols, const void* x, const float* 
   return SOD_OK;
 }
 
+// LDS bytes of one dcn_bwd_fused_kernel workgroup: the fixed-point dX window (8x8 output tile + receptive field + slack, 33-float pitch),
+// 32 weight rows of K bf16 (+16 B pad), the 64 x 32 bf16 column-gradient tile.
+static size_t dcn_bwd_fused_lds(int K, int KH, int KW, int stride, int dil) {
+  static const int r_env = getenv("SOD_DCN_FUSED_R") ? atoi(getenv("SOD_DCN_FUSED_R")) : 2;
+  const int WH = 7 * stride + (KH - 1) * dil + 2 + 2 * r_env, WW = 7 * stride + (KW - 1) * dil + 2 + 2 * r_env;
+  return (((size_t)WH * WW * 33 * 4 + 15) & ~(size_t)15) + (size_t)32 * (K * 2 + 16) + (size_t)64 * 32 * 2;
+}
+
+extern "C" int sod_deform_conv_bwd_fused_supported(int C, int K, int KH, int KW, int stride, int dil, int deformable_groups) {
+  if (C <= 0 || K <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || dil <= 0 || deformable_groups <= 0 || C % deformable_groups) return 0;
+  const int cpg = C / deformable_groups;
+  if ((K != 128 && K != 256 && K != 512) || (C & 31) || (cpg & 31) || C / 32 > 65535) return 0;
+  return dcn_bwd_fused_lds(K, KH, KW, stride, dil) <= 96 * 1024 ? 1 : 0;
+}
+
 extern "C" int sod_deform_conv_bwd_fused(const void* dy, const void* wt, const void* x, const float* offset, const float* mask, float* dx_f32,
                                          float* doffset, float* dmask, float* wnorm_ws, int N, int H, int W, int C, int K, int KH, int KW, int stride,
                                          int pad, int dil, int deformable_groups, int off_ld, int mask_ld, int mask_is_logit, void* stream) {
@@ -712,7 +727,7 @@ extern "C" int sod_deform_conv_bwd_fused(const void* dy, const void* wt, const v
   if ((K != 128 && K != 256 && K != 512) || (C & 31) || (cpg & 31) || N > 65535 || C / 32 > 65535) return SOD_EARG;
   static const int r_env = getenv("SOD_DCN_FUSED_R") ? atoi(getenv("SOD_DCN_FUSED_R")) : 2;
   const int WH = 7 * stride + (KH - 1) * dil + 2 + 2 * r_env, WW = 7 * stride + (KW - 1) * dil + 2 + 2 * r_env;
-  const size_t lds = (((size_t)WH * WW * 33 * 4 + 15) & ~(size_t)15) + (size_t)32 * (K * 2 + 16) + (size_t)64 * 32 * 2;
+  const size_t lds = dcn_bwd_fused_lds(K, KH, KW, stride, dil);
   if (lds > 96 * 1024 || (unsigned long long)N * a.Ho * a.Wo * K * 2ull >= 0x80000000ull * 4ull) return SOD_EARG;
   a.x = (const __bf16*)x; a.off = offset; a.mask = mask; a.dx = dx_f32; a.doff = doffset; a.dmask = dmask;
   hipStream_t st = (hipStream_t)stream;

@@ -248,7 +248,8 @@ class _Checkpointer:
                                     "download the file and pass its local path")
         if not os.path.exists(path):
             raise FileNotFoundError(f"MODEL.WEIGHTS = {path!r} does not exist")
-        report, meta = load_into(self.model, path)
+        allow = tuple(getattr(getattr(self.cfg, "MODEL", None), "WEIGHTS_ALLOW_MISSING", ()) or ()) if getattr(self, "cfg", None) is not None else ()
+        report, meta = load_into(self.model, path, allow_missing=allow)
         data = meta["raw"]
         if resume and meta["native"]:
             for k, v in self.checkpointables.items():

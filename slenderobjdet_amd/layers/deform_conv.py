@@ -85,7 +85,7 @@ class _DeformConvFn(torch.autograd.Function):
         aliased = mask is not None and mask.untyped_storage().data_ptr() == offset.untyped_storage().data_ptr()
         if mask is not None:
             dmask = doff.view(-1)[mask.storage_offset() - offset.storage_offset():] if aliased else torch.zeros_like(mask)
-        if BWD_FUSED and HF.deform_bwd_fused_supported(C, K, dg):
+        if BWD_FUSED and HF.deform_bwd_fused_supported(C, K, dg, (k, k), mod.stride, mod.dilation):
             # one pass: the tile's slice of dcols = dY x W^T is computed inside the scatter kernel (no column-gradient tensor)
             dx32 = HF.deform_conv_bwd_fused(dy, mod.wt_bf16, x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, doff, dmask,
                                             off_ld, mask_ld, mask_is_logit)

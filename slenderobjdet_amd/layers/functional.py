@@ -1033,9 +1033,13 @@ def deform_fused_supported(C, K, dg):
     return not is_f32() and C % 128 == 0 and K % 8 == 0 and C % dg == 0 and (dg == 1 or (C // dg) % 128 == 0)
 
 
-def deform_bwd_fused_supported(C, K, dg):
-    """Shapes the fused input / offset / mask gradient (sod_deform_conv_bwd_fused) accepts (bf16 product path only)."""
-    return not is_f32() and K in (128, 256, 512) and C % 32 == 0 and C % dg == 0 and (C // dg) % 32 == 0
+def deform_bwd_fused_supported(C, K, dg, ksize=(3, 3), stride=1, dil=1):
+    """Layers the fused input / offset / mask gradient (sod_deform_conv_bwd_fused) accepts (bf16 product path only): the library's own
+    answer - channel counts AND the LDS window, which depends on kernel size, stride and dilation (a stride-2 K = 512 layer does not fit).
+    ``False`` sends the layer through conv2d_dgrad + deform_col2im."""
+    if is_f32():
+        return False
+    return _C.load().sod_deform_conv_bwd_fused_supported(int(C), int(K), int(ksize[0]), int(ksize[1]), int(stride), int(dil), int(dg)) == 1
 
 
 def deform_conv_bwd_fused(dy, wt, x, offset, mask, ksize, stride, pad, dil, dg, doffset, dmask, off_ld=0, mask_ld=0, mask_is_logit=False):

@@ -153,6 +153,41 @@ def test_deform_conv_fused_backward(cuda, modulated, dg, stride, C, K, hw):
     assert float(dx[1, : max((Ho // 2 - 2) * stride - 3, 0)].abs().max()) == 0 if Ho // 2 > 4 else True
 
 
+@pytest.mark.parametrize("stride,dil", [(2, 1), (2, 2)])
+def test_deform_conv_module_layer_the_fused_backward_declines(cuda, stride, dil):
+    """A 3x3, K = 512 DeformConv with stride 2 (res5's first block under STRIDE_IN_1X1 = False + DEFORM_ON_PER_STAGE; or stride 2 with
+    dilation 2): the fused backward's LDS window does not fit in 96 KB, sod_deform_conv_bwd_fused_supported says so, and the autograd
+    Function takes the 1x1 data gradient + col2im path instead of raising (round-3 advisor finding).  dx / d offset against the oracle."""
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.layers.arena import ParamArena
+    from slenderobjdet_amd.layers.deform_conv import DeformConv
+    from slenderobjdet_amd.layers.nn import attach_arena
+
+    C = K = 512
+    assert not HF.deform_bwd_fused_supported(C, K, 1, (3, 3), stride, dil)
+    assert HF.deform_bwd_fused_supported(C, K, 1, (3, 3), 1, 1)
+    torch.manual_seed(0)
+    m = DeformConv(C, K, 3, stride=stride, padding=dil, dilation=dil).to(cuda)
+    arena = ParamArena(m)
+    attach_arena(m, arena)
+    N, H, W = 1, 12, 14
+    Ho, Wo = HF.conv_out_size(H, W, 3, 3, stride, dil, dil)
+    x = onn.rb(torch.randn(N, C, H, W, generator=_g(0)))
+    off = (torch.rand(N, 18, Ho, Wo, generator=_g(2)) - 0.5) * 3.1 + 0.013
+    dy = onn.rb(torch.randn(N, K, Ho, Wo, generator=_g(4)))
+    xd = _nhwc(x).to(cuda).bfloat16().requires_grad_(True)
+    offd = _nhwc(off).to(cuda).requires_grad_(True)
+    y = m(xd, offd)
+    y.backward(_nhwc(dy).to(cuda).bfloat16())
+    w = onn.rb(m.weight.detach().float().cpu().permute(0, 3, 1, 2))
+    xs, os_ = x.clone().requires_grad_(True), off.clone().requires_grad_(True)
+    ref = odc.deform_conv2d(xs, os_, w, None, stride, dil, dil, None, 1)
+    gx, go = torch.autograd.grad(ref, [xs, os_], dy)
+    assert (y.float().cpu().permute(0, 3, 1, 2) - ref.detach()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
+    for got, want, name in ((xd.grad.float().cpu().permute(0, 3, 1, 2), gx, "dx"), (offd.grad.cpu().permute(0, 3, 1, 2), go, "doffset")):
+        assert (got - want).abs().max().item() <= 3e-2 * want.abs().max().item(), name
+
+
 @pytest.mark.parametrize("v2", [False, True])
 def test_dfconv2d_gradients_vs_oracle(cuda, v2):
     """DFConv2d (slender_det/layers/df_conv.py:67-78) end to end as an autograd module against the CPU oracle: the gradient that reaches

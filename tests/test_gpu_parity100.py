@@ -83,6 +83,19 @@ def _oracle_run(pool, lrs, emu, iters=ITERS):
     return out
 
 
+def _assert_fixture_is_current(chaos):
+    """tests/golden/chaos100.json holds trajectories computed by oracle/model.py: a stale file (the oracle has changed since) would
+    let iterations 7-100 of the comparison drift unnoticed behind the six live ones (round-3 advisor finding)."""
+    import hashlib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stored = chaos.get("sources_sha256") or {}
+    now = {f: hashlib.sha256(open(os.path.join(root, f), "rb").read()).hexdigest() for f in stored}
+    changed = [f for f in stored if stored[f] != now[f]]
+    assert stored and not changed, (f"tests/golden/chaos100.json was generated from other versions of {changed or 'unknown sources'}: run "
+                                    "`python tests/golden/make_chaos100.py stamp` (re-checks the first iterations, re-stamps) or regenerate it")
+
+
 def test_100_iteration_loss_parity(cuda):
     from slenderobjdet_amd.data import synthetic_batch
     from slenderobjdet_amd.layers import functional as HF
@@ -122,6 +135,7 @@ def test_100_iteration_loss_parity(cuda):
     # in practice), the bf16-emulating one to 1e-3 (another summation order flips single bf16 roundings from the first step: 1e-5 at
     # iteration 1, 3e-4 by iteration 3 between this container and the GPU box's host).
     chaos = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chaos100.json")))
+    _assert_fixture_is_current(chaos)
     assert len(chaos["lrs"]) == ITERS and max(abs(a - b) for a, b in zip(chaos["lrs"], lrs)) < 1e-12, "schedule differs from the fixture's"
     emu, f32 = chaos["emu_all_threads"], chaos["f32_all_threads"]
     torch.set_num_threads(min(os.cpu_count() or 1, 32))

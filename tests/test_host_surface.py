@@ -383,9 +383,14 @@ def test_checkpoint_round_trip_retinanet_and_rcnn_heads(tmp_path):
         # a detector file that lacks a head tensor: loud
         broken = {k: v for k, v in ref.items() if k != next(iter(expect))}
         torch.save({"model": broken}, tmp_path / "broken.pth")
+        victim = build(rel, 5)
+        before = {k: v.clone() for k, v in victim.state_dict().items()}
         with pytest.raises(RuntimeError, match="head parameter"):
-            ck.load_into(build(rel, 5), str(tmp_path / "broken.pth"))
+            ck.load_into(victim, str(tmp_path / "broken.pth"))
+        after = victim.state_dict()
+        assert all(torch.equal(before[k], after[k]) for k in before), "a refused checkpoint must leave the model as it was"
         ck.load_into(build(rel, 5), str(tmp_path / "broken.pth"), allow_missing=("head.cls_subnet.", "proposal_generator.head.conv."))
+        ck.load_into(build(rel, 5), str(tmp_path / "broken.pth"), allow_missing=("*",))      # DetectionCheckpointer's warn-and-continue
 
 
 def test_dcnv2_backbone_config_builds_deform_bottleneck_blocks():

@@ -140,3 +140,19 @@ def test_deform_conv_kat_zero_offsets_is_plain_conv():
     for key, off in (("y_dconv_zero", "offsets_2"), ("y_dconv_1", "offsets_1")):
         got = deform_conv2d(torch.tensor(d["input"]), torch.tensor(d[off]), torch.tensor(d["weight"]), stride=1, pad=1)
         np.testing.assert_allclose(got.numpy(), d[key], atol=1e-5)
+
+
+def test_chaos100_fixture_matches_the_oracle_sources():
+    """tests/golden/chaos100.json holds 100-iteration trajectories of oracle/model.py that tests/test_gpu_parity100.py compares the product
+    with (only the first six iterations are re-run live there): the file records the sha256 of the sources it was computed from, and a
+    change of any of them without `python tests/golden/make_chaos100.py stamp` (re-checks the first iterations) or a regeneration fails."""
+    import hashlib
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    chaos = json.load(open(os.path.join(root, "tests", "golden", "chaos100.json")))
+    stored = chaos.get("sources_sha256") or {}
+    assert stored, "fixture without source hashes"
+    changed = [f for f in stored if stored[f] != hashlib.sha256(open(os.path.join(root, f), "rb").read()).hexdigest()]
+    assert not changed, f"chaos100.json is stale for {changed}: python tests/golden/make_chaos100.py stamp"
