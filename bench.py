@@ -373,6 +373,8 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--arch", choices=sorted(ARCH_NAMES), default="fcos", help="fcos = the headline metric (BASELINE.json configs[1])")
+    ap.add_argument("--base-lr", type=float, default=None, help="override SOLVER.BASE_LR (experiments: e.g. RepPoints at the reference's 0.01, where "
+                    "random initialisation diverges and the learned offsets grow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-prof", type=int, default=0, help="print the N most expensive (kernel, shape) groups to stderr")
@@ -422,6 +424,8 @@ def main():
     from slenderobjdet_amd.solver import build_optimizer
 
     cfg = make_cfg(args.depth, args.arch)
+    if args.base_lr is not None:
+        cfg.SOLVER.BASE_LR = args.base_lr
     torch.manual_seed(1 + rank)   # engine/defaults.py:66: SEED + rank
     model = build_model(cfg)
     model.train()

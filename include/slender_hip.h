@@ -424,6 +424,17 @@ int sod_deform_im2col(const void* x, const float* offset, const float* mask, voi
 int sod_deform_conv_bwd_fused(const void* dy, const void* wt, const void* x, const float* offset, const float* mask, float* dx_f32,
                               float* doffset, float* dmask, float* wnorm_ws, int N, int H, int W, int C, int K, int KH, int KW, int stride,
                               int pad, int dil, int deformable_groups, int off_ld, int mask_ld, int mask_is_logit, void* stream);
+/* Diagnostic counter of the tiled DeformConv backward kernels (sod_deform_conv_bwd_fused, sod_deform_col2im): they accumulate dX in an
+ * LDS window around each 8x8 output tile; a sample whose bilinear footprint lies outside the window (offsets larger than the window's
+ * slack, SOD_DCN_FUSED_R = 2 px beyond the receptive field) takes 32 global float atomics instead - a data-dependent performance cliff
+ * (RepPoints' learned offsets, rpd.py:637-647).  While a DEVICE pointer is registered, every such sample lane (one pixel x tap x 8
+ * channels with a non-zero gradient) adds 1 to *device_counter; NULL (default) switches the counting off.  Process-wide. */
+int sod_deform_conv_set_window_counter(unsigned long long* device_counter);
+/* Slack (pixels beyond the tile's receptive field, 0 .. 16) of the LDS window of the sod_deform_conv_bwd_fused launches that follow;
+ * -1 = the default (env SOD_DCN_FUSED_R or 2).  A wider window keeps larger offsets off the global-atomic path and admits fewer
+ * workgroups per CU; sod_deform_conv_bwd_fused_supported answers for the current setting.  layers/deform_conv.py raises it per layer
+ * and level when the counter above shows more than a few per cent of the samples outside.  Process-wide; results do not depend on it. */
+int sod_deform_conv_set_window_slack(int pixels);
 /* 1 if sod_deform_conv_bwd_fused takes this layer, 0 if it must go through sod_conv2d_dgrad + sod_deform_col2im: the shape rule above AND
  * the workgroup's LDS window (8x8 output tile + receptive field + slack) within 96 KB - a 3x3, K = 512 layer with stride 2 (res5's first
  * block under STRIDE_IN_1X1 = False + DEFORM_ON_PER_STAGE) or stride 2 with dilation 2 does not fit.  Host-only, no GPU call. */

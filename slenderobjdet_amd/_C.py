@@ -101,6 +101,8 @@ _SIGS = {
     "sod_deform_col2im": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sod_deform_im2col_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sod_deform_col2im_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "sod_deform_conv_set_window_counter": [_P],
+    "sod_deform_conv_set_window_slack": [_I],
     "sod_deform_conv_bwd_fused_supported": [_I, _I, _I, _I, _I, _I, _I],
     "sod_deform_conv_bwd_fused": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sod_f32_to_bf16": [_P, _P, _L, _P],

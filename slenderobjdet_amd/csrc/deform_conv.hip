@@ -28,6 +28,8 @@ struct DcnArgs {
   int N, H, W, C, Ho, Wo, KH, KW, stride, pad, dil, DG;
   int off_ld, mask_ld;    // row pitch (elements) of offset / mask (and of their gradients)
   int mask_logit;         // mask holds logits: m = sigmoid(mask) here, dmask is the gradient w.r.t. the logit
+  unsigned long long* oow; // optional counter (sod_deform_conv_set_window_counter): sample lanes of the tiled backward kernels whose bilinear
+                           // footprint left the LDS window and took the global float-atomic path
 };
 
 struct Samp {
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_tile_kernel(const DcnArgs a, i
           const int wy = s.yl - wy0, wx = s.xl - wx0;
           const bool inwin0 = wy >= 0 && wx >= 0 && wy + 1 < WH && wx + 1 < WW;
           const bool inwin = inwin0 && finite_scale;
+          if (!inwin0 && a.oow) atomicAdd(a.oow, 1ull);      // (the slow path: 32 global float atomics follow)
           int* w00p = win + ((wy * WW + wx) * PS) + cl * 8;
           float* g00p = a.dx + ((base + (long long)s.yl * a.W + s.xl) * a.C) + cch;
 #pragma unroll
@@ -510,7 +513,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, con
         ld(s.ok00, s.yl, s.xl, v00); ld(s.ok01, s.yl, s.xh, v01); ld(s.ok10, s.yh, s.xl, v10); ld(s.ok11, s.yh, s.xh, v11);
         const float hy = 1.f - s.ly, hx = 1.f - s.lx;
         const int wy = s.yl - wy0, wx = s.xl - wx0;
-        const bool inwin = wy >= 0 && wx >= 0 && wy + 1 < WH && wx + 1 < WW && finite_scale;
+        const bool inwin0 = wy >= 0 && wx >= 0 && wy + 1 < WH && wx + 1 < WW;
+        const bool inwin = inwin0 && finite_scale;
+        if (!inwin0 && a.oow) atomicAdd(a.oow, 1ull);        // (the slow path: 32 global float atomics follow)
         int* w00p = win + ((wy * WW + wx) * PS) + cl * 8;
         float* g00p = a.dx + ((base + (long long)s.yl * a.W + s.xl) * a.C) + cch;
         // the corner tests are per LANE, not per channel: one branch region per corner around its eight atomics (with the tests inside
@@ -594,6 +599,8 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
   }
 }
 
+unsigned long long* g_dcn_oow = nullptr;      // sod_deform_conv_set_window_counter
+
 int dcn_fill(DcnArgs& a, int N, int H, int W, int C, int KH, int KW, int stride, int pad, int dil, int DG, int off_ld, int mask_ld,
              int mask_logit) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || dil <= 0 || pad < 0 || DG <= 0) return SOD_EARG;
@@ -605,6 +612,7 @@ int dcn_fill(DcnArgs& a, int N, int H, int W, int C, int KH, int KW, int stride,
   a.off_ld = off_ld > 0 ? off_ld : 2 * KH * KW * DG;
   a.mask_ld = mask_ld > 0 ? mask_ld : KH * KW * DG;
   a.mask_logit = mask_logit;
+  a.oow = g_dcn_oow;
   if (a.off_ld < 2 * KH * KW * DG || a.mask_ld < KH * KW * DG) return SOD_EARG;
   return SOD_OK;
 }
@@ -701,10 +709,29 @@ extern "C" int sod_deform_col2im(const void* dcols, const void* x, const float* 
   return SOD_OK;
 }
 
+extern "C" int sod_deform_conv_set_window_counter(unsigned long long* device_counter) {
+  g_dcn_oow = device_counter;
+  return SOD_OK;
+}
+
+// Slack of the fused backward's LDS window in pixels beyond the tile's receptive field: -1 = SOD_DCN_FUSED_R or 2.  Larger windows keep
+// larger offsets off the global-atomic path and cost workgroups per CU (29.7 KB at 2, 47.6 KB at 4, 69.8 KB at 6 for a 3x3 layer).
+static int g_dcn_fused_slack = -1;
+static int dcn_fused_slack() {
+  static const int r_env = getenv("SOD_DCN_FUSED_R") ? atoi(getenv("SOD_DCN_FUSED_R")) : 2;
+  return g_dcn_fused_slack >= 0 ? g_dcn_fused_slack : r_env;
+}
+
+extern "C" int sod_deform_conv_set_window_slack(int pixels) {
+  if (pixels < -1 || pixels > 16) return SOD_EARG;
+  g_dcn_fused_slack = pixels;
+  return SOD_OK;
+}
+
 // LDS bytes of one dcn_bwd_fused_kernel workgroup: the fixed-point dX window (8x8 output tile + receptive field + slack, 33-float pitch),
 // 32 weight rows of K bf16 (+16 B pad), the 64 x 32 bf16 column-gradient tile.
 static size_t dcn_bwd_fused_lds(int K, int KH, int KW, int stride, int dil) {
-  static const int r_env = getenv("SOD_DCN_FUSED_R") ? atoi(getenv("SOD_DCN_FUSED_R")) : 2;
+  const int r_env = dcn_fused_slack();
   const int WH = 7 * stride + (KH - 1) * dil + 2 + 2 * r_env, WW = 7 * stride + (KW - 1) * dil + 2 + 2 * r_env;
   return (((size_t)WH * WW * 33 * 4 + 15) & ~(size_t)15) + (size_t)32 * (K * 2 + 16) + (size_t)64 * 32 * 2;
 }
@@ -725,7 +752,7 @@ extern "C" int sod_deform_conv_bwd_fused(const void* dy, const void* wt, const v
   if (rc) return rc;
   const int cpg = C / deformable_groups;
   if ((K != 128 && K != 256 && K != 512) || (C & 31) || (cpg & 31) || N > 65535 || C / 32 > 65535) return SOD_EARG;
-  static const int r_env = getenv("SOD_DCN_FUSED_R") ? atoi(getenv("SOD_DCN_FUSED_R")) : 2;
+  const int r_env = dcn_fused_slack();
   const int WH = 7 * stride + (KH - 1) * dil + 2 + 2 * r_env, WW = 7 * stride + (KW - 1) * dil + 2 + 2 * r_env;
   const size_t lds = dcn_bwd_fused_lds(K, KH, KW, stride, dil);
   if (lds > 96 * 1024 || (unsigned long long)N * a.Ho * a.Wo * K * 2ull >= 0x80000000ull * 4ull) return SOD_EARG;

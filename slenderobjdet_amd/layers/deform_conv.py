@@ -25,6 +25,92 @@ FUSED = os.environ.get("SOD_DCN_FUSED", "1") != "0"
 BWD_FUSED = os.environ.get("SOD_DCN_BWD_FUSED", "1") != "0"
 
 
+# The fused backward keeps dX in an LDS window around each 8x8 output tile; samples outside it take global float atomics, and the time of
+# the P3 level of RepPoints goes 2.5 -> 5.4 -> 18 -> 39 ms as the offsets' spread goes 0.5 -> 2 -> 4 -> 8 px (tools/bench_dcn_bwd_window.py:
+# 0 / 4 / 24 / 57 % of the samples outside a window with 2 px of slack).  Trained RepPoints offsets reach a few pixels per level
+# (rpd.py:637-647: the points of an object of 4-8 strides), so the slack is ADAPTIVE per layer and level: the library counts the samples
+# that left the window (sod_deform_conv_set_window_counter), the count of the previous launch is read back asynchronously, and the slack
+# goes 2 -> 4 -> 6 px while more than 1.5 % (6 % at 4 px) of the samples are outside - a wider window admits fewer workgroups per CU
+# (2.5 / 3.1 / 5.5 ms with nothing outside), so it is only paid where the offsets ask for it: 5.3 -> 3.4 ms at 2 px of spread, 18 -> 6.7 ms
+# at 4 px, 39 -> 22 ms at 8 px; a step that takes back less than 15 % of the outside samples is undone (a diverging run's offsets are beyond
+# any window); every PROBE_EVERY launches a narrower window is tried again.  SOD_DCN_ADAPTIVE_WINDOW=0 switches it off.
+ADAPTIVE_WINDOW = os.environ.get("SOD_DCN_ADAPTIVE_WINDOW", "1") != "0"
+PROBE_EVERY = 200
+
+
+class _WindowPolicy:
+    """Slack of the fused backward's LDS window for ONE (layer, level)."""
+    MAX_SLACK = 6
+
+    def __init__(self, device):
+        self.slack = 2
+        self.counter = torch.zeros(1, dtype=torch.int64, device=device)
+        self.host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.event = None
+        self.pending_slack = 2
+        self.calls = 0
+        self.probing = False
+        self.last_share = 0.0
+        self.widened_from = None      # share at the narrower window while the first count at the widened one is pending
+        self.hold = 0                 # launches left before widening may be tried again
+
+    def poll(self, lanes):
+        """Folds the previous launch's count into the slack, if its read-back has completed (never waits)."""
+        if self.event is None or not self.event.query():
+            return
+        self.event = None
+        share = float(self.host[0]) / max(lanes, 1)
+        self.last_share = share
+        if self.pending_slack != self.slack:        # a count taken at another slack says nothing about this one
+            return
+        if self.widened_from is not None:           # first count at a widened window: did it pay?
+            before, self.widened_from = self.widened_from, None
+            if share > 0.85 * before:                # the offsets are far beyond ANY window (a diverging run): the wide window only costs
+                self.slack -= 2                      # workgroups per CU - back, and no further attempt for a while
+                self.hold = PROBE_EVERY
+                return
+        # break-even shares from tools/bench_dcn_bwd_window.py (P3 level of RepPoints, ms at slack 2 / 4 / 6: 2.5 / 3.1 / 5.5 with nothing
+        # outside, + ~0.65 ms per per cent of the samples outside; a step of the slack takes 3-8x of them back in)
+        if share > (0.015 if self.slack <= 2 else 0.06) and self.slack < self.MAX_SLACK and self.hold == 0:
+            self.widened_from = share
+            self.slack += 2
+            self.probing = False
+        elif self.probing:
+            self.probing = False                     # the narrower window held: keep it
+
+    def before(self, C, K, dg, k, stride, dil):
+        """Slack for this launch (lowered until the library accepts the layer at it); registers the counter.  Returns the slack or None."""
+        self.calls += 1
+        self.hold = max(0, self.hold - 1)
+        if self.slack > 2 and not self.probing and self.calls % PROBE_EVERY == 0:
+            self.slack -= 2
+            self.probing = True
+        r = self.slack
+        while r >= 0:
+            HF.call("sod_deform_conv_set_window_slack", r)
+            if HF.deform_bwd_fused_supported(C, K, dg, (k, k), stride, dil):
+                break
+            r -= 2
+        if r < 0:
+            HF.call("sod_deform_conv_set_window_slack", -1)
+            return None
+        self.slack = min(self.slack, r)             # the layer does not fit at the wider window: stay where it does
+        self.pending_slack = r
+        HF.call("sod_deform_conv_set_window_counter", HF.ptr(self.counter))
+        return r
+
+    def after(self):
+        HF.call("sod_deform_conv_set_window_counter", None)
+        HF.call("sod_deform_conv_set_window_slack", -1)
+        if self.event is None:                       # one read-back in flight at a time
+            self.host.copy_(self.counter, non_blocking=True)
+            self.counter.zero_()
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.counter.zero_()
+
+
 def _ceil8(v):
     return (v + 7) // 8 * 8
 
@@ -85,10 +171,22 @@ class _DeformConvFn(torch.autograd.Function):
         aliased = mask is not None and mask.untyped_storage().data_ptr() == offset.untyped_storage().data_ptr()
         if mask is not None:
             dmask = doff.view(-1)[mask.storage_offset() - offset.storage_offset():] if aliased else torch.zeros_like(mask)
-        if BWD_FUSED and HF.deform_bwd_fused_supported(C, K, dg, (k, k), mod.stride, mod.dilation):
+        pol, slack = None, None
+        if BWD_FUSED and ADAPTIVE_WINDOW and not HF.is_f32():
+            pols = mod.__dict__.setdefault("_window_policies", {})
+            pol = pols.get((N, Ho, Wo))
+            if pol is None:
+                pol = pols[(N, Ho, Wo)] = _WindowPolicy(dy.device)
+            pol.poll(N * Ho * Wo * k * k * (C // 8))
+            slack = pol.before(C, K, dg, k, mod.stride, mod.dilation)
+        if BWD_FUSED and (slack is not None or (pol is None and HF.deform_bwd_fused_supported(C, K, dg, (k, k), mod.stride, mod.dilation))):
             # one pass: the tile's slice of dcols = dY x W^T is computed inside the scatter kernel (no column-gradient tensor)
-            dx32 = HF.deform_conv_bwd_fused(dy, mod.wt_bf16, x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, doff, dmask,
-                                            off_ld, mask_ld, mask_is_logit)
+            try:
+                dx32 = HF.deform_conv_bwd_fused(dy, mod.wt_bf16, x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, doff, dmask,
+                                                off_ld, mask_ld, mask_is_logit)
+            finally:
+                if pol is not None:
+                    pol.after()
         else:
             dcols = HF.conv2d_dgrad(dy, mod.wt_bf16, (Ho, Wo), 1, 0, 1)
             dx32 = HF.deform_col2im(dcols, x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, doff, dmask, off_ld, mask_ld, mask_is_logit)

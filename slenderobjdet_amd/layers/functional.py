@@ -1042,6 +1042,30 @@ def deform_bwd_fused_supported(C, K, dg, ksize=(3, 3), stride=1, dil=1):
     return _C.load().sod_deform_conv_bwd_fused_supported(int(C), int(K), int(ksize[0]), int(ksize[1]), int(stride), int(dil), int(dg)) == 1
 
 
+class DeformWindowCounter:
+    """Counts the sample lanes (pixel x tap x 8 channels with a non-zero gradient) of the tiled DeformConv backward kernels that left
+    their LDS window and took the global-atomic path (sod_deform_conv_set_window_counter): the data-dependent cliff of that design.
+
+        with DeformWindowCounter(device) as c: ...backward...; n = c.read()
+    """
+
+    def __init__(self, device):
+        self.t = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def __enter__(self):
+        call("sod_deform_conv_set_window_counter", ptr(self.t))
+        return self
+
+    def __exit__(self, *exc):
+        call("sod_deform_conv_set_window_counter", None)
+
+    def read(self, reset=True):
+        n = int(self.t.item())
+        if reset:
+            self.t.zero_()
+        return n
+
+
 def deform_conv_bwd_fused(dy, wt, x, offset, mask, ksize, stride, pad, dil, dg, doffset, dmask, off_ld=0, mask_ld=0, mask_is_logit=False):
     """dx fp32 (N,H,W,C) + the (zero-initialised, pitched) doffset / dmask from dy (N,Ho,Wo,K) bf16 and wt = the CRSK weight copy
     ((KH*KW*C, 1, 1, K) bf16), with no column-gradient tensor in between."""

@@ -153,6 +153,75 @@ def test_deform_conv_fused_backward(cuda, modulated, dg, stride, C, K, hw):
     assert float(dx[1, : max((Ho // 2 - 2) * stride - 3, 0)].abs().max()) == 0 if Ho // 2 > 4 else True
 
 
+def test_deform_backward_window_counter(cuda):
+    """The tiled backward kernels keep dX in an LDS window of the 8x8 tile's receptive field + SOD_DCN_FUSED_R (2) px of slack; a sample
+    outside it takes the global-atomic path - a performance cliff on a data-dependent quantity (RepPoints' learned offsets,
+    rpd.py:637-647).  The counter (sod_deform_conv_set_window_counter) must read 0 while every offset stays within the slack, and stay a
+    bounded share at 4x that; the results are the same either way (checked against the two-kernel path by the tests above)."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K = 2, 24, 40, 64, 128
+    x = torch.randn(N, H, W, C, generator=_g(0)).to(cuda).bfloat16()
+    dy = torch.randn(N, H, W, K, generator=_g(1)).to(cuda).bfloat16()
+    w = (torch.randn(K, 1, 1, 9 * C, generator=_g(2)) * 0.05).to(cuda)
+    _, wt = HF.weight_prep(w)
+    lanes = N * H * W * 9 * (C // 8)
+
+    def count(amplitude):
+        off = ((torch.rand(N, H, W, 18, generator=_g(3)) - 0.5) * 2 * amplitude).to(cuda)
+        doff = torch.zeros_like(off)
+        with HF.DeformWindowCounter(cuda) as c:
+            HF.deform_conv_bwd_fused(dy, wt, x, off, None, (3, 3), 1, 1, 1, 1, doff, None)
+            return c.read()
+
+    assert count(1.9) == 0                       # |offset| < R = 2: the bilinear footprint stays inside the window
+    far = count(8.0)
+    assert 0 < far <= 0.8 * lanes, (far, lanes)  # 4 x R: some samples leave, most of those within +-R of the tile's field do not
+    assert count(1.9) == 0                       # the counter pointer is unregistered / re-registered cleanly
+
+
+def test_deform_backward_window_widens_with_the_offsets(cuda):
+    """layers/deform_conv.py::_WindowPolicy: the slack of the fused backward's LDS window follows the share of samples the library
+    counted outside it - 2 px while the offsets are small, 4 / 6 px once more than 2 % of the samples leave (learned RepPoints offsets
+    reach several pixels, rpd.py:637-647) - and the gradients do not depend on it."""
+    from slenderobjdet_amd.layers import deform_conv as dcm
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.layers.arena import ParamArena
+    from slenderobjdet_amd.layers.nn import attach_arena
+
+    assert dcm.ADAPTIVE_WINDOW
+    torch.manual_seed(0)
+    C = K = 128
+    m = dcm.DeformConv(C, K, 3, padding=1).to(cuda)
+    arena = ParamArena(m)
+    attach_arena(m, arena)
+    N, H, W = 2, 24, 40
+    x = torch.randn(N, H, W, C, generator=_g(0)).to(cuda).bfloat16()
+    dy = torch.randn(N, H, W, K, generator=_g(1)).to(cuda).bfloat16()
+
+    def step(off):
+        xd, od = x.clone().requires_grad_(True), off.clone().requires_grad_(True)
+        m(xd, od).backward(dy)
+        torch.cuda.synchronize()                     # lets the policy's read-back complete before the next launch polls it
+        return xd.grad.float(), od.grad
+
+    small = ((torch.rand(N, H, W, 18, generator=_g(3)) - 0.5) * 2.0).to(cuda)
+    large = ((torch.rand(N, H, W, 18, generator=_g(4)) - 0.5) * 12.0).to(cuda)
+    for _ in range(3):
+        step(small)
+    pol = m._window_policies[(N, H, W)]
+    assert pol.slack == 2 and pol.last_share == 0.0
+    first = step(large)
+    shares = [pol.last_share]
+    for _ in range(5):
+        last = step(large)
+        shares.append(pol.last_share)
+    assert pol.slack > 2, (pol.slack, shares)
+    assert shares[-1] < 0.5 * max(shares), shares           # the wider window took most of the samples back
+    for a, b in zip(first, last):                           # same gradients at slack 2 and at the widened window: dx is rounded to bf16
+        assert (a - b).abs().max().item() <= 2 ** -7 * a.abs().max().item()      # once (2^-8), d offset differs by float-atomic order
+
+
 @pytest.mark.parametrize("stride,dil", [(2, 1), (2, 2)])
 def test_deform_conv_module_layer_the_fused_backward_declines(cuda, stride, dil):
     """A 3x3, K = 512 DeformConv with stride 2 (res5's first block under STRIDE_IN_1X1 = False + DEFORM_ON_PER_STAGE; or stride 2 with

@@ -29,9 +29,15 @@ def main():
     dev = torch.device("cuda:0")
     N, H, W = 16, 200, 336
     model = build_model(make_cfg(50))
+    scale = 1.0
+    if "--damp" in sys.argv[1:]:      # the benchmark's RetinaNet / R-CNN conditioning (bench.damp_residual_branches): conv3 gamma 0.25, stem 1/64,
+        from bench import damp_residual_branches      # and activations of the size a damped stem hands on - are small operands slower? (no)
+        damp_residual_branches(model)
+        scale = 1.0 / 64
+        print("damped: last FrozenBN weight of every block 0.25, inputs scaled by 1/64")
     stage = model.backbone.bottom_up.res2
-    x64 = torch.randn(N, H, W, 64, device=dev).to(torch.bfloat16)
-    x256 = torch.randn(N, H, W, 256, device=dev).to(torch.bfloat16).relu()
+    x64 = (torch.randn(N, H, W, 64, device=dev) * scale).to(torch.bfloat16)
+    x256 = (torch.randn(N, H, W, 256, device=dev) * scale).to(torch.bfloat16).relu()
     with torch.no_grad():
         for name, blk, x in (("proj 64->256", stage[0], x64), ("identity 256", stage[1], x256)):
             cin = x.shape[-1]
