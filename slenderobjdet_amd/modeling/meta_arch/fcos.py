@@ -133,7 +133,7 @@ class FCOSHead(nn.Module):
         main = torch.cuda.current_stream(dev)
         s2 = _tower_streams.get(dev.index)
         if s2 is None:
-            s2 = _tower_streams[dev.index] = torch.cuda.Stream(device=dev)
+            s2 = _tower_streams[dev.index] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SOD_TOWER_PRIO", "0")))
             HF.register_compute_stream(dev, s2)
         s2.wait_stream(main)
         for f in feats:
@@ -296,7 +296,7 @@ class FCOSV2(nn.Module):
             bottom.prepare_frozen_prefix()
         side = _prefetch_streams.get(dev.index)
         if side is None:
-            side = _prefetch_streams[dev.index] = torch.cuda.Stream(device=dev)
+            side = _prefetch_streams[dev.index] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SOD_PREFETCH_PRIO", "0")))
         side.wait_stream(main)
         self._prefetched = None
         with torch.cuda.stream(side):
