@@ -373,6 +373,8 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--arch", choices=sorted(ARCH_NAMES), default="fcos", help="fcos = the headline metric (BASELINE.json configs[1])")
+    ap.add_argument("--resnext", action="store_true", help="ResNeXt 32x8d bottlenecks (configs/ablation_studies/*/base_X101.yaml: NUM_GROUPS 32, "
+                    "WIDTH_PER_GROUP 8, STRIDE_IN_1X1 False) instead of ResNet: the grouped-convolution path; not the headline")
     ap.add_argument("--base-lr", type=float, default=None, help="override SOLVER.BASE_LR (experiments: e.g. RepPoints at the reference's 0.01, where "
                     "random initialisation diverges and the learned offsets grow)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -426,6 +428,8 @@ def main():
     cfg = make_cfg(args.depth, args.arch)
     if args.base_lr is not None:
         cfg.SOLVER.BASE_LR = args.base_lr
+    if args.resnext:
+        cfg.MODEL.RESNETS.NUM_GROUPS, cfg.MODEL.RESNETS.WIDTH_PER_GROUP, cfg.MODEL.RESNETS.STRIDE_IN_1X1 = 32, 8, False
     torch.manual_seed(1 + rank)   # engine/defaults.py:66: SEED + rank
     model = build_model(cfg)
     model.train()
@@ -536,7 +540,7 @@ def main():
             "metric": f"training img/sec {ARCH_NAMES[args.arch]} R{args.depth}-FPN 1333x800", "value": round(imgs / dt, 3), "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.arch], "global_batch": args.batch_per_gpu * world, "parallelism": f"dp{world}",
+            "config": {"workload": WORKLOADS[args.arch] + (" [ResNeXt 32x8d backbone]" if args.resnext else ""), "global_batch": args.batch_per_gpu * world, "parallelism": f"dp{world}",
                        "final_loss": round(loss_val, 5), "final_grad_norm": round(gnorm, 5), "base_lr": cfg.SOLVER.BASE_LR,
                        "device": device_fingerprint(dev.index or 0)},
         }

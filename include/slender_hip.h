@@ -30,6 +30,11 @@ extern "C" {
 /* conv flags */
 #define SOD_CONV_RELU 1     /* y = max(y, 0) after bias/residual */
 #define SOD_CONV_RES_UP2 2  /* residual is half resolution and nearest-2x upsampled (FPN top-down path) */
+#define SOD_CONV_CWIN 4     /* grouped convolution in CHANNEL-WINDOW mode (ResNeXt 3x3: detectron2 BottleneckBlock(num_groups), configs/
+                             * ablation_studies/pointset/base_X101.yaml): C == K multiples of 128, groups whose channels divide 128; w is
+                             * [K][R][S][128] - row q holds, per tap, its weights towards the 128 input channels of q's own 128-channel
+                             * tile (block-diagonal inside the window), so a 128-wide output tile contracts over 128 instead of C channels:
+                             * 128 / (C / groups) x the FLOPs of a true grouped kernel instead of groups x for the dense embedding */
 
 /* iou_loss types — slender_det/layers/iou_loss.py:25-32 */
 #define SOD_IOU_LOSS_IOU 0
@@ -68,6 +73,7 @@ int sod_conv2d_dgrad(const void* dy, const void* wt, const void* accum, const vo
  * result is then bit-identical from run to run.  splits > 0 forces the 128x128 kernel with that many pixel splits, splits < 0 the
  * 256x256 kernel (SOD_EARG when the shape or the workspace does not allow it); 0 = the library chooses. */
 #define SOD_WGRAD_DETERMINISTIC 1
+#define SOD_WGRAD_DIAG 2    /* channel-window mode (see SOD_CONV_CWIN): dw is [K][R][S][128] and only the tiles of a q-tile's own channels run */
 long long sod_conv2d_wgrad_workspace_bytes(void);
 int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const float* qscale,
                      int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
@@ -125,6 +131,10 @@ int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, f
 /* Tile policy of sod_conv2d_fwd / _dgrad (process-wide): 1 (default, or env SOD_CONV256) = shapes with >= 1 round of 256x256 output
  * tiles, Nout % 256 == 0 and R*S*C >= 1024 run on the 256x256x64 8-phase kernel (whole rounds; a short remainder goes to the
  * 128x128 kernel); 0 = 128x128 kernel only; 2 = the 256 kernel for every shape it supports (tests); -1 = re-read the env. */
+/* Data gradient of a grouped convolution in channel-window mode (SOD_CONV_CWIN): wt_win [C][R][S][128] - row c holds, per tap, the
+ * weights towards the 128 output channels of c's own tile; relu_mask as for sod_conv2d_dgrad.  C == K multiples of 128. */
+int sod_conv2d_dgrad_cwin(const void* dy, const void* wt_win, const void* relu_mask, void* dx,
+                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, void* stream);
 int sod_conv_set_tile256(int mode);
 /* Kernel policy of sod_conv2d_wgrad / _wgrad_ml for the shapes the 256x256 kernel does not take (process-wide): -1 (default) = env
  * SOD_WGRAD_VARIANT or the library's per-shape choice; 0 = conv_wgrad_kernel (two 4-wave workgroups per CU, float atomics);

@@ -56,6 +56,9 @@ struct ConvArgs {
   float* gnb_dgamma; float* gnb_dbeta;             // F_GNBWD: [Nout] += sum g*xhat, sum g (float atomics)
   int gn_G;            // F_GNSTATS / F_GNBWD: number of groups (Nout / gn_G == 8: the 8 channels a lane stores are one group)
   int tap_inner;       // linear path: K-step order (channel chunk outer, tap inner) - the taps of one chunk re-read the same cache lines
+  int Cpitch;          // channels per pixel of the SOURCE tensor (= Cred except in window mode)
+  int cwin;            // channel WINDOW (grouped convolutions, ResNeXt): the 128 output channels of a q-tile contract over the 128 source
+                       // channels at the same offset only; the weights are [Nout][R*S][128] (block-diagonal inside the window), Cred = 128
 };
 
 // K-step order of the linear staging path: (channel chunk outer, tap inner) makes the R*S taps of one 64-channel chunk re-read the
@@ -213,9 +216,10 @@ struct WgradArgs {
   int V, nz, v_per_split;   // total virtual pixels; v_per_split multiple of 64
   int QT, CT;
   FastDiv div_s;
+  int diag;            // channel window (grouped convolutions): only the tiles with c-tile == q-tile exist, dw is [K][R*S][128]
 };
 
-enum { WGRAD_DETERMINISTIC = 1 };   // sod_conv2d_wgrad flags
+enum { WGRAD_DETERMINISTIC = 1, WGRAD_DIAG = 2 };   // sod_conv2d_wgrad flags
 
 // conv_wgrad256.hip: 256(q) x 256(c) output tile per workgroup of 8 waves, one workgroup per CU, split over pixels with fp32 slabs in
 // the caller's workspace and a fixed-order reduce kernel (no atomics anywhere).

@@ -88,6 +88,8 @@ __global__ __launch_bounds__(64 * WQ * WP, (WQ * WP == 4 && BK == 32 && NSTAGE =
   pt -= g.tile0;
   const int q0 = qt * BQ, p0 = g.pstart + pt * BP;
   const int gP = g.P, gHs = g.Hs, gWs = g.Ws;
+  const uint32_t Cp = (uint32_t)a.Cpitch;               // source channels per pixel (= Cred unless a channel window is on)
+  const uint32_t cw0 = a.cwin ? (uint32_t)q0 : 0u;      // window mode: this q-tile contracts over the source channels at its own offset
 
   auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
   auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.src), 0, g.src_bytes, 0x00020000);
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(64 * WQ * WP, (WQ * WP == 4 && BK == 32 && NSTAGE =
   if (linear) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      rowbase[i] = (xoff[i] + ((uint32_t)xh[i] * (uint32_t)gWs + (uint32_t)xw[i]) * (uint32_t)a.Cred + (uint32_t)schunk * 8u) * 2u;
+      rowbase[i] = (xoff[i] + ((uint32_t)xh[i] * (uint32_t)gWs + (uint32_t)xw[i]) * Cp + cw0 + (uint32_t)schunk * 8u) * 2u;
       // a tap is valid iff its row and its column are: R + S tests and an outer product of the two bit rows instead of R * S tests
       unsigned long long m = 0, colbits = 0;
       for (int s2 = 0; s2 < a.S; ++s2) {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(64 * WQ * WP, (WQ * WP == 4 && BK == 32 && NSTAGE =
       const int c0 = (a.tap_inner ? (int)cc : t - (int)(tap_o * a.div_cpt.d)) * BK;
       const int r = (int)fd_div(tap, a.div_s);
       const int s2 = (int)tap - r * a.S;
-      const uint32_t tapoff = (uint32_t)((tap_sign * (r * a.dil * gWs + s2 * a.dil) * a.Cred + c0) * 2);   // scalar
+      const uint32_t tapoff = (uint32_t)((tap_sign * (r * a.dil * gWs + s2 * a.dil) * (int)Cp + c0) * 2);   // scalar
       const uint32_t woff = (uint32_t)(((int)tap * a.Cred + c0) * 2);
 #pragma unroll
       for (int j = 0; j < (BQ + RPP - 1) / RPP; ++j) {
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(64 * WQ * WP, (WQ * WP == 4 && BK == 32 && NSTAGE =
       int h, w;
       m &= src_coord(xh[i], r, gHs, h);
       m &= src_coord(xw[i], s, gWs, w);
-      const uint32_t off = (xoff[i] + ((uint32_t)h * (uint32_t)gWs + (uint32_t)w) * (uint32_t)a.Cred + (uint32_t)c) * 2u;
+      const uint32_t off = (xoff[i] + ((uint32_t)h * (uint32_t)gWs + (uint32_t)w) * Cp + cw0 + (uint32_t)c) * 2u;
       const uint32_t voff = (off & m) | (SOD_OOB & ~m);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + W_TILE + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
     }
@@ -547,7 +549,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   const int qt = bid % a.QT; bid /= a.QT;
   const int z = bid;
   const int r = tap / a.S, s = tap - r * a.S;
-  const int q0 = qt * 128, c0 = ct * 128;
+  const int q0 = qt * 128, c0 = a.diag ? q0 : ct * 128;      // diag (grouped convolutions): the tile of the q-tile's own channels only
+  const int Cdw = a.diag ? 128 : a.C, cd0 = a.diag ? 0 : c0;  // row length / first column of this tile in dw
   const int vbeg = z * a.v_per_split;
   int vend = vbeg + a.v_per_split; if (vend > a.V) vend = a.V;
   const int nsteps = (vend - vbeg) / KP;
@@ -781,8 +784,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
   }
   const int mode = a.partial ? 0 : (a.dbg_plain_store ? 1 : 2);      // wave-uniform, hoisted out of the element loops
   if (mode == 2 && q0 + 128 <= a.K && c0 + 128 <= a.C) {             // full tile: 64 atomics in straight-line code
-    float* d0 = a.dw + ((size_t)(q0 + wq * 64 + fg * 4) * RS + tap) * a.C + c0 + wc * 64 + fr;
-    const size_t qstride = (size_t)RS * a.C;
+    float* d0 = a.dw + ((size_t)(q0 + wq * 64 + fg * 4) * RS + tap) * Cdw + cd0 + wc * 64 + fr;
+    const size_t qstride = (size_t)RS * Cdw;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -797,14 +800,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     for (int e = 0; e < 4; ++e) {
       const int q = q0 + (wq * 4 + i) * 16 + fg * 4 + e;
       if (q >= a.K) continue;
-      float* drow = a.dw + ((size_t)q * RS + tap) * a.C;
+      float* drow = a.dw + ((size_t)q * RS + tap) * Cdw;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = c0 + (wc * 4 + j) * 16 + fr;
         if (c < a.C) {
-          if (mode == 2) atomicAdd(drow + c, acc[i][j][e]);
+          if (mode == 2) atomicAdd(drow + (c - c0 + cd0), acc[i][j][e]);
           else if (mode == 0) ptile[((wq * 4 + i) * 16 + fg * 4 + e) * 128 + (wc * 4 + j) * 16 + fr] = acc[i][j][e];
-          else drow[c] = acc[i][j][e];
+          else drow[c - c0 + cd0] = acc[i][j][e];
         }
       }
     }
@@ -821,8 +824,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
     int t = (int)(i >> 12);
     const int tap = t % RS; t /= RS;
     const int ct = t % a.CT, qt = t / a.CT;
-    const int q = qt * 128 + row, c = ct * 128 + c4 * 4;
-    if (q >= a.K || c >= a.C) continue;
+    const int q = qt * 128 + row, c = (a.diag ? 0 : ct * 128) + c4 * 4;      // diag: dw rows are the 128 window columns
+    const int Cdw = a.diag ? 128 : a.C;
+    if (q >= a.K || c >= Cdw) continue;
     const float* src = a.partial + ((size_t)(i >> 12) * 128 + row) * 128 + c4 * 4;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     // blockIdx.y = chunk of splits (keeps >= 512 workgroups in flight for 4-tile shapes); chunks meet in dw with one atomic each
@@ -830,16 +834,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
     const int z1 = min(a.nz, z0 + zc);
     for (int z = z0; z < z1; ++z) acc += *reinterpret_cast<const f32x4_t*>(src + (size_t)z * tiles * (128 * 128));
     const float qs = a.qscale ? a.qscale[q] : 1.f;
-    float* dst = a.dw + ((size_t)q * RS + tap) * a.C + c;
+    float* dst = a.dw + ((size_t)q * RS + tap) * Cdw + c;
     if (a.det) {       // gridDim.y == 1: this thread owns the four elements, fixed summation order
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (c + e < a.C) dst[e] += acc[e] * qs;
+        if (c + e < Cdw) dst[e] += acc[e] * qs;
       continue;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (c + e < a.C) atomicAdd(dst + e, acc[e] * qs);
+      if (c + e < Cdw) atomicAdd(dst + e, acc[e] * qs);
   }
 }
 
@@ -886,6 +890,12 @@ int g_conv256_mode = -1;   // -1: read SOD_CONV256 (default 1); 0 off; 1 heurist
 template <int MODE, bool OUT_F32, bool GNB = false>
 int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   const bool generic = (a.Cred & 63) != 0 || a.R * a.S > 64;      // the linear path keeps one validity bit per tap in 64-bit masks
+  if constexpr (!GNB) {
+    if (a.cwin) {         // channel window: the window IS the 128-row q-tile of this variant; Cred = 128 -> never generic
+      if (generic || a.nlev != 1 || (a.Nout & 127)) return SOD_EARG;
+      return launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32>(a, st);
+    }
+  }
   // 256x256 8-phase kernel (conv_igemm256.hip) for the large compute-bound shapes.  SOD_CONV256=0 disables it, =2 forces it for
   // every shape it supports (parity tests).
   static int cus = 0;
@@ -1011,7 +1021,7 @@ int fill_common(ConvArgs& a, int nlev, int N, int Cred, int Nout, int R, int S, 
   if (wb >= 0x80000000ull) return SOD_ESIZE;
   a.nlev = nlev;
   a.w_bytes = (uint32_t)wb;
-  a.N = N; a.Cred = Cred; a.Nout = Nout;
+  a.N = N; a.Cred = Cred; a.Nout = Nout; a.Cpitch = Cred; a.cwin = 0;
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
   a.Kred = R * S * Cred; a.T = (a.Kred + 63) / 64;
   a.div_cpt = make_fastdiv((uint32_t)((Cred & 63) ? Cred / 8 : Cred / 64));
@@ -1024,9 +1034,9 @@ int fill_common(ConvArgs& a, int nlev, int N, int Cred, int Nout, int R, int S, 
 int fill_level(ConvArgs& a, int l, const void* src, void* dst, int Hs, int Ws, int Hp, int Wp, long long src_img_stride,
                long long dst_img_stride, size_t dst_elt) {
   if (!src || !dst || Hs <= 0 || Ws <= 0 || Hp <= 0 || Wp <= 0) return SOD_EARG;
-  if (src_img_stride <= 0) src_img_stride = (long long)Hs * Ws * a.Cred;
+  if (src_img_stride <= 0) src_img_stride = (long long)Hs * Ws * a.Cpitch;
   if (dst_img_stride <= 0) dst_img_stride = (long long)Hp * Wp * a.Nout;
-  if (src_img_stride < (long long)Hs * Ws * a.Cred || dst_img_stride < (long long)Hp * Wp * a.Nout) return SOD_EARG;
+  if (src_img_stride < (long long)Hs * Ws * a.Cpitch || dst_img_stride < (long long)Hp * Wp * a.Nout) return SOD_EARG;
   const unsigned long long sb = (unsigned long long)a.N * src_img_stride * 2ull;
   const unsigned long long db = (unsigned long long)a.N * dst_img_stride * dst_elt;
   if (sb >= 0x80000000ull || db >= 0x200000000ull) return SOD_ESIZE;
@@ -1078,12 +1088,13 @@ int g_wgrad_variant = -1;    // sod_conv_set_wgrad_variant
 int ring_variant_for(const WgradArgs& a, int tiles, int splits, float* ws, long long ws_bytes) {
   static const int env = getenv("SOD_WGRAD_VARIANT") ? atoi(getenv("SOD_WGRAD_VARIANT")) : -1;
   const int v = g_wgrad_variant >= 0 ? g_wgrad_variant : env;
+  if (a.diag) return 0;          // grouped convolutions: conv_wgrad_kernel's diagonal-tile mode only
   if (v >= 0) return v;
   // Measured per shape (tools/bench_wgrad_backbone.py, FCOS R50 at batch 16): the two groups of a workgroup halve the atomic bytes
   // (16 instead of 32 MB per launch: -9 ... -15 us on the 1x1 shapes of res3 / res4 / res5) but share one barrier per K-step, which costs
   // 3 - 9 % in long loops; the gain outweighs that up to ~100 K-steps per group.  Explicit split counts (tests) and deterministic mode
   // keep conv_wgrad_kernel and its slab reduce.
-  if (splits != 0 || a.det || tiles > 128) return 0;
+  if (splits != 0 || a.det || a.diag || tiles > 128) return 0;
   const int cus = device_cus();
   const long long steps = (long long)a.V / std::max(1, 2 * cus / tiles) / 32;
   return steps <= 100 ? 2300 : 0;
@@ -1091,14 +1102,16 @@ int ring_variant_for(const WgradArgs& a, int tiles, int splits, float* ws, long 
 
 int launch_wgrad(WgradArgs& a, int splits, int flags, hipStream_t st, float* ws = nullptr, long long ws_bytes = 0) {
   a.det = (flags & WGRAD_DETERMINISTIC) ? 1 : 0;
+  a.diag = (flags & WGRAD_DIAG) ? 1 : 0;
+  if (a.diag && (a.C != a.K || (a.C & 127) || splits < 0)) return SOD_EARG;
   if (splits < 0 && (!ws || !wgrad256_supported(a) || wgrad256_workspace_bytes(a, device_cus()) > ws_bytes)) return SOD_EARG;
-  if (splits < 0 || (splits == 0 && use_wgrad256(a, ws, ws_bytes))) {
+  if (splits < 0 || (splits == 0 && !a.diag && use_wgrad256(a, ws, ws_bytes))) {
     const int pi = prof_begin(st);
     const int rc = launch_wgrad256(a, device_cus(), ws, ws_bytes, st);
     prof_end(pi, st, 256, 1.f, 2);
     return rc;
   }
-  a.QT = (a.K + 127) / 128; a.CT = (a.C + 127) / 128;
+  a.QT = (a.K + 127) / 128; a.CT = a.diag ? 1 : (a.C + 127) / 128;
   const int tiles = a.QT * a.CT * a.R * a.S;
   int V = 0;
   long long Ptot = 0;
@@ -1239,8 +1252,11 @@ static int conv2d_fwd_impl(const void* x, const void* w, const float* bias, cons
   const int Ho = out_size(H, pad, dil, R, stride), Wo = out_size(W, pad, dil, S, stride);
   if (Ho <= 0 || Wo <= 0) return SOD_EARG;
   ConvArgs a{};
-  int rc = fill_common(a, 1, N, C, K, R, S, stride, pad, dil);
+  const bool cwin = (flags & SOD_CONV_CWIN) != 0;
+  if (cwin && (C != K || (C & 127) || relu_bits)) return SOD_EARG;      // window = the q-tile's own 128 channels; weights [K][R*S][128]
+  int rc = fill_common(a, 1, N, cwin ? 128 : C, K, R, S, stride, pad, dil);
   if (rc) return rc;
+  if (cwin) { a.Cpitch = C; a.cwin = 1; }
   rc = fill_level(a, 0, x, y, H, W, Ho, Wo, x_img_stride, y_img_stride, out_f32 ? 4 : 2);
   if (rc) return rc;
   a.w = w; a.bias = bias;
@@ -1338,6 +1354,25 @@ extern "C" int sod_conv2d_dgrad(const void* dy, const void* wt, const void* accu
   if (accum) { a.flags |= F_RES; a.lev[0].res = accum; a.lev[0].res_img_stride = a.lev[0].dst_img_stride; }
   if (relu_mask) { a.flags |= F_MASK; a.lev[0].mask = relu_mask; }
   if (g_conv_reverse) a.flags |= F_REVERSE;
+  return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
+}
+
+// Data gradient of a grouped convolution in window mode (see SOD_CONV_CWIN): wt_win is [C][R*S][128], row c holds, per tap, the weights
+// towards the 128 output channels of c's own 128-channel tile.  C == K, multiples of 128.
+extern "C" int sod_conv2d_dgrad_cwin(const void* dy, const void* wt_win, const void* relu_mask, void* dx,
+                                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, void* stream) {
+  if (!dy || !wt_win || !dx || C != K || (C & 127)) return SOD_EARG;
+  const int Ho = out_size(H, pad, dil, R, stride), Wo = out_size(W, pad, dil, S, stride);
+  if (Ho <= 0 || Wo <= 0) return SOD_EARG;
+  ConvArgs a{};
+  int rc = fill_common(a, 1, N, 128, C, R, S, stride, pad, dil);
+  if (rc) return rc;
+  a.Cpitch = K; a.cwin = 1;
+  rc = fill_level(a, 0, dy, dx, Ho, Wo, H, W, 0, 0, 2);
+  if (rc) return rc;
+  a.w = wt_win; a.bias = nullptr;
+  a.flags = 0;
+  if (relu_mask) { a.flags |= F_MASK; a.lev[0].mask = relu_mask; }
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 

@@ -215,12 +215,15 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
     _chk(x, torch.bfloat16, "x"); _chk(w, torch.bfloat16, "w"); _chk(bias, torch.float32, "bias"); _chk(res, torch.bfloat16, "res")
     N, H, W, C = x_shape if x_shape is not None else x.shape
     K, R, S, Cw = w.shape
-    if Cw != C:
+    cwin = Cw != C and is_channel_window(C, K, Cw)      # grouped convolution in channel-window mode (layers/nn.py HipGroupedConv2d)
+    if Cw != C and not cwin:
         raise _C.SlenderHipError(f"weight channels {Cw} != input channels {C}")
     Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
     if out is None:
         out = torch.empty((N, Ho, Wo, K), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
-    flags = (CONV_RELU if relu else 0) | (CONV_RES_UP2 if res_up2 else 0)
+    flags = (CONV_RELU if relu else 0) | (CONV_RES_UP2 if res_up2 else 0) | (CONV_CWIN if cwin else 0)
+    if cwin and (relu_bits is not None or res is not None):
+        raise _C.SlenderHipError("conv2d_fwd: the channel-window mode takes neither a residual nor 1-bit ReLU masks")
     e0 = _prof_begin(None, "conv_fwd")
     if relu_bits is not None:       # also records "stored output > 0" as one bit per element (uint8[numel / 8]) for the backward pass
         _chk(relu_bits, torch.uint8, "relu_bits")
@@ -232,8 +235,18 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
         call("sod_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
              x_img_stride, y_img_stride, 0, flags, 1 if out_f32 else 0, stream_ptr())
     # c_real / k_real: un-padded channel counts, so that the profile counts ALGORITHMIC work (stem: 3 of its 8 input channels)
-    _prof_end("conv_fwd", 2.0 * N * Ho * Wo * K * R * S * (c_real or C), e0, (N, H, W, C, K, R, stride))
+    _prof_end("conv_fwd", 2.0 * N * Ho * Wo * K * R * S * (c_real or (Cw if cwin else C)), e0, (N, H, W, C, K, R, stride))
     return out
+
+
+CONV_CWIN = 4               # slender_hip.h SOD_CONV_CWIN
+WGRAD_DIAG = 2              # slender_hip.h SOD_WGRAD_DIAG
+CWIN = 128                  # the window = one 128-channel output tile
+
+
+def is_channel_window(C, K, Cw):
+    """Weights whose contraction width is the 128-channel window instead of the input's C channels: C == K, multiples of 128."""
+    return Cw == CWIN and C == K and C > CWIN and C % CWIN == 0 and not is_f32()
 
 
 def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=None, dy_img_stride=0, dy_shape=None, out=None, relu_bits=None,
@@ -245,6 +258,14 @@ def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=Non
     H, W = x_hw
     if out is None:
         out = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=dy.device)
+    if dy_shape is None and dy.shape[-1] != K and is_channel_window(C, dy.shape[-1], K):      # grouped convolution, channel-window mode
+        if accum is not None or relu_bits is not None or dy_img_stride:
+            raise _C.SlenderHipError("conv2d_dgrad: the channel-window mode takes a ReLU mask tensor only")
+        e0 = _prof_begin(None, "conv_dgrad")
+        call("sod_conv2d_dgrad_cwin", ptr(dy), ptr(wt), ptr(relu_mask), ptr(out), N, H, W, C, C, R, S, stride, pad, dil, stream_ptr())
+        Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
+        _prof_end("conv_dgrad", 2.0 * N * Ho * Wo * C * R * S * K, e0, (N, H, W, C, C, R, stride))
+        return out
     e0 = _prof_begin(None, "conv_dgrad")
     if relu_bits is not None:       # the ReLU mask of dx's tensor as one bit per element (conv2d_fwd(..., relu_bits=...))
         _chk(relu_bits, torch.uint8, "relu_bits")
@@ -291,11 +312,12 @@ def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img
         K = dy.shape[-1]
     side = _wgrad_stream(dw.device, (dy, x), dw.data_ptr())
     ws = wgrad_workspace(dw.device, side)
+    diag = dw.shape[-1] != C and is_channel_window(C, K, dw.shape[-1])      # grouped convolution: dw is (K, R, S, 128), diagonal tiles only
     e0 = _prof_begin(side, "conv_wgrad")
     call("sod_conv2d_wgrad", ptr(dy), ptr(x), ptr(dw), ptr(qscale), N, H, W, C, K, R, S, stride, pad, dil, dy_img_stride, x_img_stride,
-         splits, WGRAD_DETERMINISTIC if DETERMINISTIC else 0, ptr(ws), ws.numel(), stream_ptr(side))
+         splits, (WGRAD_DETERMINISTIC if DETERMINISTIC else 0) | (WGRAD_DIAG if diag else 0), ptr(ws), ws.numel(), stream_ptr(side))
     Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
-    _prof_end("conv_wgrad", 2.0 * N * Ho * Wo * (k_real or K) * R * S * (c_real or C), e0, (N, H, W, C, K, R, stride), side)
+    _prof_end("conv_wgrad", 2.0 * N * Ho * Wo * (k_real or K) * R * S * (c_real or (CWIN if diag else C)), e0, (N, H, W, C, K, R, stride), side)
     return dw
 
 

@@ -195,6 +195,10 @@ class HipConv2d(nn.Module):
         return _ConvFn.apply(x, res, self.weight, self, res_up2)
 
 
+# SOD_GROUPED_WINDOW=0: grouped convolutions as block-diagonal DENSE embeddings on every shape (round 3's form; groups x the FLOPs)
+WINDOWED = _os.environ.get("SOD_GROUPED_WINDOW", "1") != "0"
+
+
 class HipGroupedConv2d(HipConv2d):
     """Conv2d with ``groups`` > 1 (ResNeXt bottlenecks: MODEL.RESNETS.NUM_GROUPS / WIDTH_PER_GROUP, e.g.
     configs/ablation_studies/pointset/base_X101.yaml:9-11).  The master weight has the reference's shape (K, R, S, C / groups); the
@@ -215,6 +219,32 @@ class HipGroupedConv2d(HipConv2d):
     def init_msra(self):               # fan_out of the grouped layer as torch computes it: out_channels * k * k / groups ... of weight (K, C/g, k, k)
         fan_out = self.out_channels * self.kernel_size * self.kernel_size
         nn.init.normal_(self.weight, 0.0, math.sqrt(2.0 / fan_out))
+
+    # ---- channel-window mode (round 4): when C == K are multiples of 128 and a group's channels divide 128, a 128-wide output tile only
+    # needs the 128 input channels at the same offset: compute copies (K, R, S, 128) / (C, R, S, 128), block-diagonal inside each
+    # window, on the implicit-GEMM kernels' window mode (SOD_CONV_CWIN / sod_conv2d_dgrad_cwin / SOD_WGRAD_DIAG).  FLOPs: 128 / (C / g)
+    # times a true grouped kernel's (32x8d: 16x at res2 ... 2x at res5) instead of g = 32 times for the dense embedding.
+    def windowed(self):
+        C, K, g = self.in_channels, self.out_channels, self.groups
+        return (WINDOWED and not HF.is_f32() and C == K and C > HF.CWIN and C % HF.CWIN == 0 and HF.CWIN % (C // g) == 0)
+
+    def window_weight(self, w):
+        """(K, R, S, C/g) -> (K, R, S, 128): row q's weights at the position of its group's channels inside q's 128-channel window."""
+        K, R, S, Cg = w.shape
+        T, gt = K // HF.CWIN, HF.CWIN // Cg          # tiles, groups per tile
+        d = w.new_zeros(T, gt, Cg, R, S, gt, Cg)
+        idx = torch.arange(gt, device=w.device)
+        d[:, idx, :, :, :, idx, :] = w.reshape(T, gt, Cg, R, S, Cg).permute(1, 0, 2, 3, 4, 5)
+        return d.reshape(K, R, S, HF.CWIN)
+
+    def window_blocks(self, win):
+        """(K, R, S, 128) -> (K, R, S, C/g): the inverse selection (the rest of a window are structural zeros / unused gradients)."""
+        K, R, S, _ = win.shape
+        Cg = self.in_channels // self.groups
+        T, gt = K // HF.CWIN, HF.CWIN // Cg
+        idx = torch.arange(gt, device=win.device)
+        v = win.reshape(T, gt, Cg, R, S, gt, Cg)
+        return v[:, idx, :, :, :, idx, :].permute(1, 0, 2, 3, 4, 5).reshape(K, R, S, Cg)
 
     def dense_weight(self, w):
         """(K, R, S, C/g) -> block-diagonal (K, R, S, C)."""
@@ -249,6 +279,17 @@ class HipGroupedConv2d(HipConv2d):
             self.bn_scale = None
             self.bias_eff = self.bias.detach() if self.bias is not None else None
         with torch.no_grad():
+            if self.windowed():
+                win = self.window_weight(self.weight.detach())
+                if self.bn_scale is not None:
+                    win = win * self.bn_scale.view(-1, 1, 1, 1)
+                T = self.out_channels // HF.CWIN
+                # the data gradient's copy: row c holds, per tap, the weights towards the 128 outputs of c's own tile
+                win_t = win.reshape(T, HF.CWIN, self.kernel_size, self.kernel_size, HF.CWIN).permute(0, 4, 2, 3, 1).reshape(win.shape)
+                self.w_bf16 = HF.weight_prep(win.contiguous(), None, True, False, None)[0]
+                self.wt_bf16 = HF.weight_prep(win_t.contiguous(), None, True, False, None)[0]
+                self._prep_key = key
+                return
             dense = self.dense_weight(self.weight.detach())
         self.w_bf16, self.wt_bf16 = HF.weight_prep(dense.contiguous(), self.bn_scale, True, True, None)
         self._prep_key = key
@@ -256,13 +297,14 @@ class HipGroupedConv2d(HipConv2d):
     def wgrad_into(self, arena, g, x):
         """dW of the dense embedding into a scratch tensor on the CURRENT stream, diagonal blocks added to the arena gradient."""
         K, k, C = self.out_channels, self.kernel_size, self.in_channels
-        dense = torch.zeros((K, k, k, C), dtype=torch.float32, device=g.device)
+        win = self.windowed()
+        dense = torch.zeros((K, k, k, HF.CWIN if win else C), dtype=torch.float32, device=g.device)
         prev, HF.WGRAD_SIDE_STREAM = HF.WGRAD_SIDE_STREAM, False
         try:
             HF.conv2d_wgrad(g, x, dense, k, k, self.stride, self.padding, self.dilation, qscale=self.bn_scale)
         finally:
             HF.WGRAD_SIDE_STREAM = prev
-        arena.grad_view(self.weight).add_(self.blocks_of(dense))
+        arena.grad_view(self.weight).add_(self.window_blocks(dense) if win else self.blocks_of(dense))
         arena.mark_ready(self.weight)
 
 

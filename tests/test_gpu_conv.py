@@ -232,6 +232,52 @@ def test_conv_wgrad_ring_variants(cuda, variant):
         _C.call("sod_conv_set_wgrad_variant", -1)
 
 
+@pytest.mark.parametrize("C,groups,stride,hw", [(256, 32, 1, (13, 21)), (512, 32, 2, (14, 18)), (256, 2, 1, (9, 11)), (1024, 32, 1, (7, 9))])
+def test_grouped_conv_channel_window_vs_grouped_oracle(cuda, C, groups, stride, hw):
+    """Grouped 3x3 (ResNeXt: detectron2 BottleneckBlock(num_groups), configs/ablation_studies/pointset/base_X101.yaml) in CHANNEL-WINDOW
+    mode - a 128-wide output tile contracts over the 128 input channels at the same offset (SOD_CONV_CWIN, sod_conv2d_dgrad_cwin,
+    SOD_WGRAD_DIAG) - against F.conv2d(groups=) and its autograd: forward + folded FrozenBN bias + ReLU, data gradient with the ReLU mask
+    of its input, weight gradient in the reference's (K, C / groups, 3, 3) shape, in default and deterministic mode."""
+    import torch.nn.functional as F
+
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.layers.nn import HipGroupedConv2d
+
+    N, (H, W) = 2, hw
+    Cg = C // groups
+    m = HipGroupedConv2d(C, C, 3, stride, 1, 1, groups=groups, bias=False).to(cuda)
+    assert m.windowed()
+    x = _rand((N, H, W, C), 1).relu()                       # an activation: its own ReLU mask is what the data gradient applies
+    w = _rand((C, 3, 3, Cg), 2, 0.05)
+    b = torch.randn(C, generator=torch.Generator().manual_seed(3))
+    win = m.window_weight(w.to(cuda))
+    T = C // 128
+    win_t = win.reshape(T, 128, 3, 3, 128).permute(0, 4, 2, 3, 1).reshape(win.shape)
+    wk = HF.weight_prep(win.contiguous(), None, True, False)[0]
+    wt = HF.weight_prep(win_t.contiguous(), None, True, False)[0]
+    xs, ws = x.permute(0, 3, 1, 2).clone().requires_grad_(True), w.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ref = torch.relu(F.conv2d(xs, ws, b, stride=stride, padding=1, groups=groups))
+    xd = x.to(cuda).bfloat16()
+    y = HF.conv2d_fwd(xd, wk, b.to(cuda), stride=stride, pad=1, relu=True)
+    _close(y.permute(0, 3, 1, 2), ref.detach(), 2 ** -7, "grouped fwd")
+    Ho, Wo = ref.shape[2:]
+    dy = _rand((N, Ho, Wo, C), 4)
+    pre = F.conv2d(xs, ws, b, stride=stride, padding=1, groups=groups)
+    gx, gw = torch.autograd.grad(pre, [xs, ws], dy.permute(0, 3, 1, 2))
+    dyd = dy.to(cuda).bfloat16()
+    dx = HF.conv2d_dgrad(dyd, wt, (H, W), stride, 1, 1, relu_mask=xd)
+    _close(dx.permute(0, 3, 1, 2), gx * (xs.detach() > 0), 2 ** -7, "grouped dgrad + mask")
+    for det in (False, True):
+        prev, HF.DETERMINISTIC = HF.DETERMINISTIC, det
+        try:
+            dw = torch.zeros((C, 3, 3, 128), dtype=torch.float32, device=cuda)
+            HF.conv2d_wgrad(dyd, xd, dw, 3, 3, stride, 1, 1)
+            HF.conv2d_wgrad(dyd, xd, dw, 3, 3, stride, 1, 1)      # accumulation semantics
+        finally:
+            HF.DETERMINISTIC = prev
+        _close(m.window_blocks(dw).permute(0, 3, 1, 2), 2 * gw, 2e-4, f"grouped wgrad det={det}")
+
+
 # the 256x256 8-wave weight-gradient kernel (conv_wgrad256.hip), forced with splits = -1: (N, H, W, C, K, R, stride, pad, dil)
 WGRAD256_CASES = [
     (2, 40, 72, 256, 256, 3, 1, 1, 1),     # incremental row path (Wo >= 64), 9 tiles, column and image wraps
