@@ -155,6 +155,8 @@ def kernel_name(kind, code):
         return "stem_fused_kernel"
     if code == -8:
         return "bottleneck_frozen_kernel"
+    if code == -9:
+        return "bneck_pair_kernel"
     if kind == "conv_wgrad":
         if code == 256:
             return "sodconv::conv_wgrad256_kernel"
@@ -174,6 +176,8 @@ def algo_bytes(kind, desc):
         hw = list(zip(hs, ws))
     else:
         N, H, W, C, K, R, stride = desc[:7]
+        if R == "pair":       # expand + contract pair: narrow in, add operand in, wide out, narrow out, two weight matrices (C = CN, K = CW)
+            return N * H * W * (2 * C + 2 * K) * 2.0 + 2 * C * K * 2.0
         if R == "bneck":      # fused frozen bottleneck block: x in, 256-channel block output out, four weight matrices
             return N * H * W * (C + K) * 2.0 + (C * 64 + 64 * 64 * 9 + 64 * K + (C * K if C != K else 0)) * 2.0
         if R == 7 and C == 3:      # fused stem: uint8 RGB in, pooled 64-channel bf16 out

@@ -249,6 +249,20 @@ int sod_preprocess_batch(int n, const void* const* imgs, int is_uint8, int C, co
  * batch padded to (Hp, Wp) (multiples of 4; images are zero-padded bottom / right as ImageList.from_tensors does). */
 int sod_stem_fused(int n, const void* const* imgs, const int* H, const int* W, const void* w_packed, const float* bias,
                    void* out, int Hp, int Wp, const float* mean3, const float* std3, void* stream);
+/* Two chained 1x1 convolutions of a bottleneck chain in ONE launch (detectron2 BottleneckBlock under fpn.py:94-115): the
+ * EXPANDING one (narrow CN -> wide CW channels, + add operand, + nonlinearity; the wide tensor is stored) and the CONTRACTING one (wide ->
+ * narrow) that consumes it, so that the wide tensor is written once and never read back.  P = N*H*W pixels, NHWC bf16 rows.
+ *   mode 0 (forward):  wide = relu(xin x we^T + bias_e + add), bits_out[e / 8] bit (e % 8) = wide[e] > 0 (optional);
+ *                      narrow = relu(wide x wc^T + bias_c)          = conv3_i + residual + ReLU followed by conv1_{i+1} + ReLU
+ *   mode 1 (backward): wide = bits_in ? xin x we^T + add : 0;  narrow = (mask2 > 0) ? wide x wc^T : 0
+ *                      = the data gradient of conv1_k (+ identity-path gradient, masked with block k-1's output ReLU bits) followed by the
+ *                        data gradient of conv3_{k-1} masked with the ReLU of its input
+ * we [CW][CN], wc [CN][CW] bf16 (KRSC copies for mode 0, CRSK copies for mode 1), biases fp32 or NULL, add [P][CW] or NULL.
+ * CN in {128, 256}, CW a multiple of 128.  Bit-identical to the two launches it replaces (same MFMA instruction and k order). */
+int sod_bottleneck_pair_supported(int CN, int CW);
+int sod_bottleneck_pair(const void* xin, const void* add, const void* we, const float* bias_e, const void* wc, const float* bias_c,
+                        const void* bits_in, const void* mask2, void* wide, void* bits_out, void* narrow,
+                        long long P, int CN, int CW, int mode, void* stream);
 /* A FROZEN bottleneck block of the ResNet body in ONE kernel (detectron2 BottleneckBlock with FrozenBatchNorm2d folded, as
  * build_resnet_backbone builds res2 under MODEL.BACKBONE.FREEZE_AT >= 2; reached from slender_det/modeling/backbone/fpn.py:103):
  *   out = relu(conv3(relu(conv2_3x3(relu(conv1(x))))) + shortcut(x)),  64 bottleneck channels, 256 output channels, stride 1.

@@ -48,6 +48,8 @@ _SIGS = {
     "sod_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
     "sod_upsample2x_bwd": [_P, _P, _I, _I, _I, _I, _P],
     "sod_conv2d_dgrad_cwin": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "sod_bottleneck_pair_supported": [_I, _I],
+    "sod_bottleneck_pair": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "sod_conv_set_tile256": [_I],
     "sod_conv_set_wgrad_variant": [_I],
     "sod_conv_set_reverse": [_I],

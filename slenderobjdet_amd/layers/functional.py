@@ -239,6 +239,43 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
     return out
 
 
+def bottleneck_pair_supported(CN, CW):
+    return not is_f32() and _C.load().sod_bottleneck_pair_supported(int(CN), int(CW)) == 1
+
+
+def bottleneck_pair(xin, add, we, bias_e, wc, bias_c, mode, bits_in=None, mask2=None, want_bits=True):
+    """Expanding 1x1 conv (+ add operand + nonlinearity) and the contracting 1x1 conv that consumes it in one launch
+    (sod_bottleneck_pair).  xin (N,H,W,CN), add (N,H,W,CW) or None, we (CW,1,1,CN), wc (CN,1,1,CW).  Returns (wide, bits or None, narrow)."""
+    _chk(xin, torch.bfloat16, "xin"); _chk(add, torch.bfloat16, "add"); _chk(we, torch.bfloat16, "we"); _chk(wc, torch.bfloat16, "wc")
+    _chk(bias_e, torch.float32, "bias_e"); _chk(bias_c, torch.float32, "bias_c"); _chk(mask2, torch.bfloat16, "mask2")
+    N, H, W, CN = xin.shape
+    CW = we.shape[0]
+    if tuple(we.shape) != (CW, 1, 1, CN) or tuple(wc.shape) != (CN, 1, 1, CW):
+        raise _C.SlenderHipError(f"bottleneck_pair: weights {tuple(we.shape)} / {tuple(wc.shape)} do not chain {CN} -> {CW} -> {CN}")
+    P = N * H * W
+    wide = torch.empty((N, H, W, CW), dtype=torch.bfloat16, device=xin.device)
+    narrow = torch.empty((N, H, W, CN), dtype=torch.bfloat16, device=xin.device)
+    bits = torch.empty(P * CW // 8, dtype=torch.uint8, device=xin.device) if (mode == 0 and want_bits) else None
+    if mode == 1:
+        _chk(bits_in, torch.uint8, "bits_in")
+        if bits_in is None or bits_in.numel() * 8 != P * CW or (mask2 is not None and mask2.numel() != P * CN):
+            raise _C.SlenderHipError("bottleneck_pair: mode 1 needs bits_in of P * CW bits (and mask2 of P * CN elements)")
+    if add is not None and add.numel() != P * CW:
+        raise _C.SlenderHipError("bottleneck_pair: add operand must be (N, H, W, CW)")
+    kind = "conv_fwd" if mode == 0 else "conv_dgrad"
+    prof = PROFILE is not None and (PROFILE_KINDS is None or kind in PROFILE_KINDS)
+    if prof:        # not a library conv dispatch: timed with a torch event pair on the launch stream (bench.py roofline), variant code -9
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    call("sod_bottleneck_pair", ptr(xin), ptr(add), ptr(we), ptr(bias_e), ptr(wc), ptr(bias_c), ptr(bits_in), ptr(mask2), ptr(wide), ptr(bits),
+         ptr(narrow), P, CN, CW, int(mode), stream_ptr())
+    if prof:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((kind, 4.0 * P * CN * CW, e0, e1, (N, H, W, CN, CW, "pair", 1), -9))
+    return wide, bits, narrow
+
+
 CONV_CWIN = 4               # slender_hip.h SOD_CONV_CWIN
 WGRAD_DIAG = 2              # slender_hip.h SOD_WGRAD_DIAG
 CWIN = 128                  # the window = one 128-channel output tile

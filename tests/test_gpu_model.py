@@ -875,6 +875,37 @@ def test_relu_bit_masks_leave_the_step_bit_identical(cuda):
         HF.DETERMINISTIC = prev
 
 
+def test_bottleneck_pair_kernel_leaves_the_step_bit_identical(cuda):
+    """resnet.PAIR_FWD / PAIR_BWD (off by default): conv3 + residual + ReLU of a block and conv1 + ReLU of the next one as ONE launch
+    (csrc/bneck_pair.hip), and the two data gradients of that chain as one launch in backward, for the res3 and res4 chains of R50:
+    losses and every gradient equal bit for bit to the step built from the separate launches (deterministic mode)."""
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.modeling.backbone import resnet
+
+    cfg, model, opt = _build(50, seed=6)
+    data = synthetic_batch(2, 320, 384, 11, device="cuda")
+    prev, HF.DETERMINISTIC = HF.DETERMINISTIC, True
+    keep = (resnet.PAIR_FWD, resnet.PAIR_BWD, resnet.PAIR_MAX_CN)
+    try:
+        def step(fwd, bwd):
+            resnet.PAIR_FWD, resnet.PAIR_BWD, resnet.PAIR_MAX_CN = fwd, bwd, 256
+            opt.zero_grad()
+            out = model(data)
+            total = sum(out.values())
+            model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+            return {k: float(v.detach()) for k, v in out.items()}, model.arena.grads.clone()
+
+        ref_l, ref_g = step(False, False)
+        for fwd, bwd in ((True, False), (False, True), (True, True)):
+            got_l, got_g = step(fwd, bwd)
+            assert got_l == ref_l, (fwd, bwd)
+            assert torch.equal(got_g, ref_g), (fwd, bwd)
+    finally:
+        resnet.PAIR_FWD, resnet.PAIR_BWD, resnet.PAIR_MAX_CN = keep
+        HF.DETERMINISTIC = prev
+
+
 def test_groupnorm_backward_reduction_in_the_consumer_dgrad(cuda):
     """Inside the FCOS towers a unit's data gradient gathers the reduction pass of the PREVIOUS unit's GroupNorm backward (layers/nn.py
     GnBwdSlot).  Same losses bit for bit (forward untouched); gradients agree with the two-pass form to the accuracy float atomics
