@@ -125,6 +125,12 @@ int sod_conv2d_dgrad_ml_gnbwd(int nlev, const void* const* dy, const void* wt, v
 int sod_conv2d_dgrad_ml_mask(int nlev, const void* const* dy, const void* wt, const void* const* relu_mask, void* const* dx,
                              int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                              long long dy_img_stride, void* stream);
+/* sod_conv2d_dgrad_ml + accum[l] (bf16, dx[l]'s shape) added in the epilogue: the second of two consumers of the same tensors (the two
+ * towers of FCOSHead read the same FPN outputs, fcosv2.py:342-361) leaves the SUM of both data gradients - autograd's accumulation pass
+ * (read 2, write 1 per level) is not launched. */
+int sod_conv2d_dgrad_ml_accum(int nlev, const void* const* dy, const void* wt, const void* const* accum, void* const* dx,
+                              int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                              long long dy_img_stride, void* stream);
 int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, float* dw, const float* qscale,
                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                         long long dy_img_stride, int splits, int flags, void* ws, long long ws_bytes, void* stream);

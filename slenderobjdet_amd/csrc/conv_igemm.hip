@@ -1433,6 +1433,27 @@ extern "C" int sod_conv2d_dgrad_ml_mask(int nlev, const void* const* dy, const v
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 
+// sod_conv2d_dgrad_ml whose epilogue adds accum[l] (bf16, dx[l]'s shape) to level l's result: the SECOND of two consumers of the same
+// tensors (the two FCOS towers read the same FPN outputs, fcosv2.py:342-361) leaves the sum of both data gradients in one pass.
+extern "C" int sod_conv2d_dgrad_ml_accum(int nlev, const void* const* dy, const void* wt, const void* const* accum, void* const* dx,
+                                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                         long long dy_img_stride, void* stream) {
+  if (!dy || !wt || !dx || !accum || !H || !W) return SOD_EARG;
+  ConvArgs a{};
+  int rc = fill_common(a, nlev, N, K, C, R, S, stride, pad, dil);
+  if (rc) return rc;
+  for (int l = 0; l < nlev; ++l) {
+    const int Ho = out_size(H[l], pad, dil, R, stride), Wo = out_size(W[l], pad, dil, S, stride);
+    if (Ho <= 0 || Wo <= 0 || !accum[l]) return SOD_EARG;
+    rc = fill_level(a, l, dy[l], dx[l], Ho, Wo, H[l], W[l], dy_img_stride, 0, 2);
+    if (rc) return rc;
+    a.lev[l].res = accum[l];
+    a.lev[l].res_img_stride = a.lev[l].dst_img_stride;
+  }
+  a.w = wt; a.bias = nullptr; a.flags = F_RES;
+  return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
+}
+
 extern "C" int sod_conv_last_variant(void) { return g_last_variant; }
 
 extern "C" int sod_conv_prof_enable(int on) {

@@ -385,6 +385,44 @@ class GnBwdSlot:
         return len(xs) == len(self.out_ptrs) and all((x.data_ptr(), tuple(x.shape)) == k for x, k in zip(xs, self.out_ptrs))
 
 
+class SiblingFold:
+    """Shared by the FIRST units of sibling chains that read the same tensors (the two towers of FCOSHead on the FPN outputs,
+    fcosv2.py:342-361).  autograd would add the two input gradients level by level (read 2, write 1: five launches on the critical path
+    of backward); instead the unit whose backward runs first parks its data gradients here and returns none, and the second adds them
+    in the epilogue of its own data-gradient launch (sod_conv2d_dgrad_ml_accum) and returns the sum.  Only for graphs in which BOTH
+    siblings receive a gradient (the fused FCOS loss node): a parked gradient that nobody collected by the end of the backward pass
+    raises instead of being lost."""
+
+    def __init__(self):
+        self.partial = self.event = self.stream = None
+        self.hooked = False
+
+    def put(self, dxs):
+        self.partial = list(dxs)
+        self.stream = torch.cuda.current_stream(dxs[0].device)
+        self.event = torch.cuda.Event()
+        self.event.record(self.stream)
+        if not self.hooked:
+            torch.autograd.Variable._execution_engine.queue_callback(self._check)
+            self.hooked = True
+
+    def take(self):
+        part, self.partial = self.partial, None
+        cur = torch.cuda.current_stream(part[0].device)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            cur.wait_event(self.event)
+            for t in part:
+                t.record_stream(cur)
+        return part
+
+    def _check(self):
+        self.hooked = False
+        if self.partial is not None:
+            self.partial = None
+            raise RuntimeError("SiblingFold: one tower parked its input gradient and the other never ran in this backward pass "
+                               "(SOD_TOWER_FOLD=0 restores autograd's accumulation)")
+
+
 class ConvGnRelu(nn.Module):
     """[Conv3x3(bias) -> GroupNorm(32) -> ReLU] unit of the FCOS towers (fcosv2.py:300-336), applied to ALL FPN levels at
     once: the levels share the weights, so the convolution forward / dgrad / wgrad are one multi-level launch each."""
@@ -395,9 +433,10 @@ class ConvGnRelu(nn.Module):
         self.gn = HipGroupNorm(num_groups, channels)
         self._last_slot = None
 
-    def forward(self, xs, chained=None):
+    def forward(self, xs, chained=None, fold=None):
         """``chained``: the ConvGnRelu unit whose latest forward produced ``xs`` and that has no other consumer (the previous unit of a
-        tower): this unit's backward then gathers the reduction pass of that unit's GroupNorm backward in its data gradient."""
+        tower): this unit's backward then gathers the reduction pass of that unit's GroupNorm backward in its data gradient.
+        ``fold``: a SiblingFold shared with the other unit that reads the same ``xs``."""
         single = isinstance(xs, torch.Tensor)
         if single:
             xs = [xs]
@@ -405,7 +444,7 @@ class ConvGnRelu(nn.Module):
         prev = None
         if GN_BWD_FUSED and not HF.is_f32() and chained is not None and chained._last_slot is not None and chained._last_slot.matches(xs):
             prev = chained._last_slot
-        out = _ConvGnReluFn.apply(self.conv.weight, self, prev, *xs)
+        out = _ConvGnReluFn.apply(self.conv.weight, self, prev, fold, *xs)
         return out[0] if single else list(out)
 
 
@@ -439,13 +478,14 @@ class ConvGn:
 
     def __call__(self, x):
         self.conv.prepare()
-        return _ConvGnReluFn.apply(self.conv.weight, self, None, x)[0]
+        return _ConvGnReluFn.apply(self.conv.weight, self, None, None, x)[0]
 
 
 class _ConvGnReluFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, weight, unit, prev_slot, *xs):
+    def forward(ctx, weight, unit, prev_slot, fold, *xs):
         conv, gn = unit.conv, unit.gn
+        ctx.fold = fold
         gw, gb = gn.weight.detach(), gn.bias.detach()
         gate = ConvGate.current
         if gate is not None:
@@ -501,16 +541,22 @@ class _ConvGnReluFn(torch.autograd.Function):
         HF.conv2d_wgrad_ml(dy1s, list(xs), arena.grad_view(conv.weight), k, k, conv.stride, conv.padding, conv.dilation)
         arena.mark_ready(conv.weight)
         dxs = [None] * nl
-        if any(ctx.needs_input_grad[3:]):
+        if any(ctx.needs_input_grad[4:]):
             prev, ctx.prev_slot = ctx.prev_slot, None
+            fold, ctx.fold = ctx.fold, None
             hw = [(x.shape[1], x.shape[2]) for x in xs]
-            if prev is not None and not HF.DETERMINISTIC and all(ctx.needs_input_grad[3:]):
+            if prev is not None and not HF.DETERMINISTIC and all(ctx.needs_input_grad[4:]):
                 pg = prev.gn
                 dxs, prev.red = HF.conv2d_dgrad_ml_gnbwd(dy1s, conv.wt_bf16, hw, prev.y1s, prev.stats, pg.weight.detach(), pg.bias.detach(),
                                                          arena.grad_view(pg.weight), arena.grad_view(pg.bias), pg.num_groups, 1, 1, 1)
+            elif fold is not None and all(ctx.needs_input_grad[4:]):
+                if fold.partial is None:      # first of the two siblings: park the gradient, the other returns the sum
+                    fold.put(HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, hw, conv.stride, conv.padding, conv.dilation))
+                else:
+                    dxs = HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, hw, conv.stride, conv.padding, conv.dilation, accums=fold.take())
             else:
                 dxs = HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, hw, conv.stride, conv.padding, conv.dilation)
-        return (None, None, None, *dxs)
+        return (None, None, None, None, *dxs)
 
 
 class _ReluToken:

@@ -48,6 +48,12 @@ TOWER_STREAMS = os.environ.get("SOD_TOWER_STREAMS", "1") != "0"
 # convolution.  Measured SLOWER, 620.1 / 622.3 vs 625.8 / 625.4 img/s in one call: the hardware's own interleaving of the two queues
 # already does better than a forced alternation (which also idles one queue while it waits for the other's event).
 TOWER_GATE = os.environ.get("SOD_TOWER_GATE", "0") != "0"
+# SOD_TOWER_FOLD=1: the second tower's first data-gradient launch adds the first one's in its epilogue (layers/nn.py SiblingFold) instead of
+# autograd adding the two towers' input gradients itself (five elementwise launches).  Off by default - measured twice, neutral to
+# negative: the two launches then run one after the other instead of side by side and the accumulate read costs the 256x256 kernel's
+# exposed epilogue what the add kernels cost (round 3: 622.2 / 623.3 vs 622.2 / 623.5 img/s; round 4: 631.0 / 631.1 vs 632.4 / 633.2
+# with the accumulating tower on the side stream, 625.8 / 624.8 vs 623.8 / 625.2 with it on the main stream).
+TOWER_FOLD = os.environ.get("SOD_TOWER_FOLD", "0") != "0"
 _tower_streams = {}
 _prefetch_streams = {}
 
@@ -110,12 +116,20 @@ class FCOSHead(nn.Module):
         pad_rows = (self.kc_pad - self.kc) + (8 - (5 if self.centerness_on_reg else 4))
         return sum(p.numel() for p in self.parameters()) - pad_rows * (9 * c + 1)
 
-    def run_towers(self, feats):
+    def run_towers(self, feats, fold_input_grads=False):
         """Every tower unit runs over all FPN levels in one multi-level launch (the levels share the weights)."""
         cls_t, box_t = list(feats), list(feats)
+        from ...layers import nn as _nn
+        # the first units of the two towers read the same tensors: the second one to run backward adds the first one's data gradient in
+        # its epilogue (layers/nn.py SiblingFold).  Only under forward()'s fused loss node, which always feeds both towers.
+        fold = None
+        if (fold_input_grads and TOWER_FOLD and torch.is_grad_enabled() and not HF.is_f32() and feats[0].is_cuda
+                and all(f.requires_grad for f in feats) and isinstance(self.cls_tower[0], ConvGnRelu) and isinstance(self.bbox_tower[0], ConvGnRelu)):
+            fold = _nn.SiblingFold()
+
         def run(unit, xs, prev):     # consecutive ConvGnRelu units share the GroupNorm backward reduction (layers/nn.py GnBwdSlot)
             if isinstance(unit, ConvGnRelu):
-                return unit(xs, chained=prev if isinstance(prev, ConvGnRelu) else None)
+                return unit(xs, chained=prev if isinstance(prev, ConvGnRelu) else None, fold=fold if prev is None else None)
             return unit(xs)
 
         if not (TOWER_STREAMS and feats[0].is_cuda):
@@ -139,13 +153,18 @@ class FCOSHead(nn.Module):
         for f in feats:
             f.record_stream(s2)
         pc = pb = None
-        from ...layers import nn as _nn
         _nn.ConvGate.current = _nn.ConvGate() if TOWER_GATE else None
         try:
-            for cu, bu in zip(self.cls_tower, self.bbox_tower):
+            for i, (cu, bu) in enumerate(zip(self.cls_tower, self.bbox_tower)):
+                if i == 0 and fold is not None:
+                    # autograd runs the later-created node first: the box tower (whose stream gets ahead of the main stream in
+                    # backward - the main stream also carries the loss node) parks its gradient, the classification tower on the main
+                    # stream adds it without waiting.  The other way round the main stream waits for a serialised second launch.
+                    cls_t, pc = run(cu, cls_t, pc), cu
                 with torch.cuda.stream(s2):
                     box_t, pb = run(bu, box_t, pb), bu
-                cls_t, pc = run(cu, cls_t, pc), cu
+                if not (i == 0 and fold is not None):
+                    cls_t, pc = run(cu, cls_t, pc), cu
         finally:
             _nn.ConvGate.current = None
         main.wait_stream(s2)
@@ -339,7 +358,7 @@ class FCOSV2(nn.Module):
         features = self.backbone(images.tensor)
         features = [features[f] for f in self.in_features]
         assert [tuple(f.shape[1:3]) for f in features] == level_hw, "feature map sizes differ from the location grid"
-        cls_t, box_t = self.head.run_towers(features)
+        cls_t, box_t = self.head.run_towers(features, fold_input_grads=self.training)
 
         if self.training:
             if stats_work is not None:

@@ -435,6 +435,36 @@ def test_conv_multilevel_matches_per_level(cuda):
     _close(dw2, dw_ref, 2e-4, "ml concat wgrad")
 
 
+@pytest.mark.parametrize("tile", [0, 2])
+def test_conv_multilevel_dgrad_accum(cuda, tile):
+    """sod_conv2d_dgrad_ml_accum: the data gradients of all levels + a second consumer's gradients of the same tensors in one launch
+    (128x128 and 256x256 kernels) == the plain launch's result + accum, rounded once."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, C, K = 2, 256, 256
+    hw = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    w = _rand((K, 3, 3, C), 1, 0.05)
+    dys = [_rand((N, h, ww, K), 20 + i) for i, (h, ww) in enumerate(hw)]
+    accs = [_rand((N, h, ww, C), 40 + i).to(cuda).bfloat16() for i, (h, ww) in enumerate(hw)]
+    _, wt = HF.weight_prep(w.to(cuda), want_krsc=False)
+    dyd = [d.to(cuda).bfloat16() for d in dys]
+    HF.call("sod_conv_set_tile256", tile)
+    try:
+        got = HF.conv2d_dgrad_ml(dyd, wt, hw, 1, 1, 1, accums=accs)
+        plain = HF.conv2d_dgrad_ml(dyd, wt, hw, 1, 1, 1)
+    finally:
+        HF.call("sod_conv_set_tile256", -1)
+    x0 = torch.zeros(1)
+    for g, p0, a, dy, (h, ww) in zip(got, plain, accs, dys, hw):
+        ref, _ = onn.conv2d_backward(torch.zeros(N, h, ww, C), w, dy, 1, 1, 1)
+        _close(g, ref + a.float().cpu(), 2 ** -7, "ml dgrad + accum")
+        # against the two-step form: one bf16 rounding instead of two
+        two = (p0.float() + a.float()).bfloat16().float()
+        assert (g.float() - two).abs().max() <= 2 ** -6 * two.abs().max()
+    with pytest.raises(Exception):
+        HF.conv2d_dgrad_ml(dyd, wt, hw, 1, 1, 1, accums=accs[:-1])
+
+
 # ---- 256x256x64 8-phase kernel (conv_igemm256.hip), forced through sod_conv_set_tile256
 T256_CASES = [
     # (N, H, W, C, K, R, stride, pad, dil)

@@ -958,6 +958,72 @@ def test_groupnorm_backward_reduction_in_the_consumer_dgrad(cuda):
         HN.GN_BWD_FUSED = prev_flag
 
 
+def test_tower_input_gradients_folded_into_the_second_dgrad(cuda):
+    """The two towers of FCOSHead read the same FPN outputs (fcosv2.py:342-361).  The tower whose backward runs second adds the first
+    one's data gradient in the epilogue of its own launch (layers/nn.py SiblingFold) instead of leaving five elementwise additions to
+    autograd: same losses bit for bit (deterministic mode; the forward pass is untouched), gradients equal to the accumulation form up
+    to ONE bf16 rounding of the FPN-output gradient instead of two, the accum launch really runs, and a backward pass that reaches only
+    one tower raises instead of losing the parked gradient."""
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.layers import nn as HN
+    from slenderobjdet_amd.modeling.meta_arch import fcos as FC
+
+    prev_det, keep = HF.DETERMINISTIC, FC.TOWER_FOLD
+    HF.DETERMINISTIC = True
+    cfg, model, opt = _build(50, seed=8)
+    data = synthetic_batch(2, 320, 384, 13, device="cuda")
+    calls = {"accum": 0}
+    orig = HF.conv2d_dgrad_ml
+
+    def counting(*a, **k):
+        calls["accum"] += k.get("accums") is not None
+        return orig(*a, **k)
+
+    def step(on):
+        FC.TOWER_FOLD = on
+        opt.zero_grad()
+        out = model(data)
+        total = sum(out.values())
+        model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+        torch.cuda.synchronize()
+        return {k: float(v.detach()) for k, v in out.items()}, model.arena.grads.clone()
+
+    try:
+        ref_l, ref_g = step(False)
+        HF.conv2d_dgrad_ml = counting
+        got_l, got_g = step(True)
+        again_l, again_g = step(True)
+        assert calls["accum"] == 2, calls
+        assert got_l == ref_l
+        assert torch.equal(got_g, again_g)                                  # still deterministic
+        head = [(n, o, c) for n, o, c in model.arena.names if n.startswith("head.")]
+        for name, off, n in head:                                           # nothing above the FPN outputs changes
+            assert torch.equal(got_g[off:off + n], ref_g[off:off + n]), name
+        worst = 0.0
+        for name, off, n in model.arena.names:
+            a, b = got_g[off:off + n], ref_g[off:off + n]
+            d = (a - b).norm().item() / max(b.norm().item(), 1e-12)
+            worst = max(worst, d)
+            assert d <= 3e-2, (name, d)                                     # one bf16 rounding (2^-9 per element) through the backbone
+        assert 0.0 < worst
+        # a graph that feeds only ONE tower: the parked gradient must not vanish silently
+        FC.TOWER_FOLD = True
+        images = model.preprocess_image(data)
+        feats = model.backbone(images.tensor)
+        ct, bt = model.head.run_towers([feats[f] for f in model.in_features], fold_input_grads=True)
+        opt.zero_grad()
+        model.arena.begin_backward()
+        with pytest.raises(RuntimeError, match="SiblingFold"):
+            sum(t.float().sum() for t in ct).backward()
+        model.arena.finish_backward()
+    finally:
+        HF.conv2d_dgrad_ml = orig
+        FC.TOWER_FOLD = keep
+        HF.DETERMINISTIC = prev_det
+        torch.cuda.synchronize()
+
+
 def test_compact_stride2_input_gradient_is_bit_identical(cuda):
     """A bottleneck stage that opens with stride-2 1x1 convolutions leaves its input gradient in compact (N, H/2, W/2, C) form to the
     producing stage, whose fused launch adds it at the even positions (resnet.COMPACT_S2_GRAD, layers/nn.py DeferSlot.comp) instead of
