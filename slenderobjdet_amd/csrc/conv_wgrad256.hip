@@ -32,13 +32,28 @@ namespace {
 constexpr int WROWB = 256;             // bytes per LDS row: 128 channels of one pixel
 constexpr int WUNIT = 64 * WROWB;      // 16 KB
 constexpr int WBUF = 4 * WUNIT;        // one K-tile: [Ya0][Ya1][Xb0][Xb1]
-constexpr int WLDS_BYTES = 2 * WBUF;   // 128 KB
+constexpr int WRING_BYTES = 2 * WBUF;  // 128 KB
+constexpr int RT_SLOT = 64 * 8;        // row table of one K-tile: 64 pixel rows x {dY byte offset, X byte offset}
+constexpr int RT_SLOTS = 4;
+constexpr int WLDS_BYTES = WRING_BYTES + RT_SLOTS * RT_SLOT;
 constexpr int SLAB = 256 * 256;        // floats per partial tile
+
+// SOD_W256_ABL (measurement builds only, tools/bench_wgrad_shapes.py): 1 = no LDS-DMA, 2 = no fragment reads,
+// 4 = no MFMAs, 8 = no slab stores.  Never defined in the shipped library.
+#ifndef SOD_W256_ABL
+#define SOD_W256_ABL 0
+#endif
+
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 template <int OFF>
 __device__ __forceinline__ s16x4_t tr_read(uint32_t addr) {
   s16x4_t r;
+#if SOD_W256_ABL & 2
+  asm volatile("; no read %0 %1" : "=v"(r) : "v"(addr));
+#else
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+#endif
   return r;
 }
 
@@ -53,23 +68,37 @@ __device__ __forceinline__ void wmma_half(f32x4_t (&acc)[8][4], const bf16x8_t (
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
+#if SOD_W256_ABL & 4
+      asm volatile("; no mfma %0 %1 %2" : "+v"(acc[SA * 4 + i][SB * 2 + j]) : "v"(af[i][KS]), "v"(bf[j][KS]));
+#else
       acc[SA * 4 + i][SB * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][KS], bf[j][KS], acc[SA * 4 + i][SB * 2 + j], 0, 0, 0);
+#endif
 }
 
 // PACK runs after the lgkmcnt(0) + sched_barrier: nothing that touches the raw fragment registers may be scheduled above the wait
 // (the transposing reads are inline asm, invisible to the compiler's own wait insertion).
+#if SOD_W256_ABL & 32
+#define SODW_PRIO(x)
+#else
+#define SODW_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+#if SOD_W256_ABL & 128
+#define SODW_BAR_B
+#else
+#define SODW_BAR_B __builtin_amdgcn_s_barrier()
+#endif
 #define SODW_PHASE(SA, SB, BFR, PACK, STAGE)                              \
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        \
   __builtin_amdgcn_s_barrier();                                           \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      \
   __builtin_amdgcn_sched_barrier(0);                                      \
   PACK;                                                                   \
-  __builtin_amdgcn_s_setprio(1);                                          \
+  SODW_PRIO(1);                                                           \
   wmma_half<SA, SB, 0>(acc, af, BFR);                                     \
   STAGE;                                                                  \
   wmma_half<SA, SB, 1>(acc, af, BFR);                                     \
-  __builtin_amdgcn_s_setprio(0);                                          \
-  __builtin_amdgcn_s_barrier();
+  SODW_PRIO(0);                                                           \
+  SODW_BAR_B;
 
 __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -94,73 +123,60 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
   const int schunk = spos ^ (sswz << 1);                     // logical 16-B chunk (8 channels) this lane fetches
   const uint32_t qadd0 = (uint32_t)(q0 + schunk * 8) * 2u, cadd0 = (uint32_t)(c0 + schunk * 8) * 2u;   // unit 1: + 256 B
 
+  // ---- pixel rows.  The byte offsets of a K-tile's 64 pixel rows (dY row, X row shifted by the tap; out-of-range = zero fill) are the same
+  // for the 16 lanes that stage one row and for all eight waves; tracked per thread they cost ~100 vector instructions per wave and
+  // K-tile - 2 000 of the loop's 4 800 cycles per K-tile, more than the MFMA cluster they ran in can hide (in-kernel stamps,
+  // tools/bench_wgrad256_stamps.py).  ONE wave per K-tile (wave kt & 7, lane = row) now computes them from scratch - two divisions, no
+  // carried state - three K-tiles ahead into a 4-slot LDS table; the staging threads fetch their two rows with one ds_read_b64 each.
   int cur_lv = 0;
 #pragma unroll
   for (int i = 1; i < MAXLEV; ++i)
     if (i < a.nlev && vbeg >= a.lev[i].v0) cur_lv = i;
-  WLevel g = a.lev[cur_lv];
   int next_v0 = (cur_lv + 1 < a.nlev) ? a.lev[cur_lv + 1].v0 : 0x7fffffff;
-  auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.dy), 0, g.dy_bytes, 0x00020000);
-  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, g.x_bytes, 0x00020000);
-
-  // ---- per-thread row state: this thread stages pixel rows L_j = (j*8+wave)*4+srow, j = 0, 1, of every K-tile.
-  // st_* describe the K-tile `st_kt`; voy / vox are the byte offsets the staging uses (out-of-range = zero fill).
-  uint32_t r_oy[2], r_ox[2];
-  int r_ho[2], r_wo[2], r_p[2];
-  uint32_t voy[2], vox[2];
-  bool fast = false;
-  int dh = 0, dw = 0;
-  uint32_t ycorr = 0, xcorr = 0;
-  auto init_rows = [&](int pbase) {      // full computation (two divisions per row)
-    fast = (a.stride == 1) && (g.Wo >= 64) && (g.Ho == g.Hx) && (g.Wo == g.Wx);
-    dh = r * a.dil - a.pad; dw = s * a.dil - a.pad;
-    ycorr = (uint32_t)(g.dy_img_stride - g.Ho * g.Wo * a.K) * 2u;
-    xcorr = (uint32_t)(g.x_img_stride - g.Hx * g.Wx * a.C) * 2u;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int p = pbase + (j * 8 + wave) * 4 + srow;
-      const bool pv = p < g.P;
-      const uint32_t pc = pv ? (uint32_t)p : 0u;
-      const uint32_t n = fd_div(pc, g.div_hw);
-      const uint32_t rem = pc - n * g.div_hw.d;
-      const uint32_t ho = fd_div(rem, g.div_w);
-      const uint32_t wo = rem - ho * g.div_w.d;
-      const int hi = (int)ho * a.stride + dh, wi = (int)wo * a.stride + dw;
-      const bool tv = ((unsigned)hi < (unsigned)g.Hx) & ((unsigned)wi < (unsigned)g.Wx);
-      r_p[j] = p; r_ho[j] = (int)ho; r_wo[j] = (int)wo;
-      r_oy[j] = (n * (uint32_t)g.dy_img_stride + rem * (uint32_t)a.K) * 2u;
-      r_ox[j] = (n * (uint32_t)g.x_img_stride + (uint32_t)(hi * g.Wx + wi) * (uint32_t)a.C) * 2u;
-      voy[j] = pv ? r_oy[j] : SOD_OOB;
-      vox[j] = (pv && tv) ? r_ox[j] : SOD_OOB;
-    }
-  };
-  // Moves the row state to K-tile kt (called with kt = previous + 1).  Dead tiles (kt >= T) stage zeros into slots nobody reads.
-  auto advance = [&](int kt) {
-    if (kt >= T) { voy[0] = voy[1] = vox[0] = vox[1] = SOD_OOB; return; }
+  auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.lev[cur_lv].dy), 0, a.lev[cur_lv].dy_bytes, 0x00020000);
+  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.lev[cur_lv].x), 0, a.lev[cur_lv].x_bytes, 0x00020000);
+  int plv = cur_lv;                      // the producer's level cursor (runs three K-tiles ahead of the staging)
+  int pnext_v0 = next_v0;
+  const int dh = r * a.dil - a.pad, dw = s * a.dil - a.pad;
+  const uint32_t rt0 = (uint32_t)(uintptr_t)SOD_LDS(smem + WRING_BYTES);
+  auto make_rows = [&](int kt) {         // executed by ONE wave: lane = pixel row of K-tile kt
+#if SOD_W256_ABL & 64
+    if (kt > 2) return;
+#endif
+    uint32_t oy = SOD_OOB, ox = SOD_OOB;
     const int v = vbeg + kt * 64;
-    if (v >= next_v0) {                  // wave-uniform: the virtual pixel index crosses into the next level
-      ++cur_lv;
-      g = a.lev[cur_lv];
-      next_v0 = (cur_lv + 1 < a.nlev) ? a.lev[cur_lv + 1].v0 : 0x7fffffff;
-      yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.dy), 0, g.dy_bytes, 0x00020000);
-      xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, g.x_bytes, 0x00020000);
-      init_rows(v - g.v0);
-      return;
+    while (v >= pnext_v0) { ++plv; pnext_v0 = (plv + 1 < a.nlev) ? a.lev[plv + 1].v0 : 0x7fffffff; }      // wave-uniform
+    if (kt < T) {
+      const WLevel& pg = a.lev[plv];
+      const int p = v - pg.v0 + lane;
+      if (p < pg.P) {
+        const uint32_t n = fd_div((uint32_t)p, pg.div_hw);
+        const uint32_t rem = (uint32_t)p - n * pg.div_hw.d;
+        const uint32_t ho = fd_div(rem, pg.div_w);
+        const uint32_t wo = rem - ho * pg.div_w.d;
+        const int hi = (int)ho * a.stride + dh, wi = (int)wo * a.stride + dw;
+        oy = (n * (uint32_t)pg.dy_img_stride + rem * (uint32_t)a.K) * 2u;
+        if (((unsigned)hi < (unsigned)pg.Hx) & ((unsigned)wi < (unsigned)pg.Wx))
+          ox = (n * (uint32_t)pg.x_img_stride + (uint32_t)(hi * pg.Wx + wi) * (uint32_t)a.C) * 2u;
+      }
     }
-    if (!fast) { init_rows(v - g.v0); return; }
-    // incremental path (stride 1, "same" geometry, Wo >= 64): +64 pixels = at most one column wrap and one image wrap
-    const uint32_t ystep = (uint32_t)(128 * a.K), xstep = (uint32_t)(128 * a.C);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      r_p[j] += 64; r_oy[j] += ystep; r_ox[j] += xstep;
-      int wo = r_wo[j] + 64, ho = r_ho[j];
-      if (wo >= g.Wo) { wo -= g.Wo; ho += 1; }
-      if (ho >= g.Ho) { ho -= g.Ho; r_oy[j] += ycorr; r_ox[j] += xcorr; }
-      r_wo[j] = wo; r_ho[j] = ho;
-      const bool pv = r_p[j] < g.P;
-      const bool tv = ((unsigned)(ho + dh) < (unsigned)g.Hx) & ((unsigned)(wo + dw) < (unsigned)g.Wx);
-      voy[j] = pv ? r_oy[j] : SOD_OOB;
-      vox[j] = (pv && tv) ? r_ox[j] : SOD_OOB;
+    asm volatile("ds_write_b64 %0, %1" :: "v"(rt0 + (uint32_t)((kt & (RT_SLOTS - 1)) * RT_SLOT + lane * 8)), "v"(u32x2_t{oy, ox}) : "memory");
+  };
+  // this thread stages pixel rows L_j = (j*8+wave)*4+srow, j = 0, 1, of every K-tile: voy / vox = their table entries
+  uint32_t voy[2], vox[2];
+  u32x2_t rraw[2];
+  const uint32_t rt_mine = rt0 + (uint32_t)((wave * 4 + srow) * 8);
+  auto rows_request = [&](int kt) {      // the caller waits (lgkmcnt) before rows_take
+    const uint32_t ad = rt_mine + (uint32_t)((kt & (RT_SLOTS - 1)) * RT_SLOT);
+    asm volatile("ds_read_b64 %0, %1" : "=v"(rraw[0]) : "v"(ad));
+    asm volatile("ds_read_b64 %0, %1 offset:256" : "=v"(rraw[1]) : "v"(ad));
+  };
+  auto rows_take = [&](int kt) {         // + the staging side's level switch (buffer descriptors), wave-uniform
+    voy[0] = rraw[0][0]; vox[0] = rraw[0][1]; voy[1] = rraw[1][0]; vox[1] = rraw[1][1];
+    if (vbeg + kt * 64 >= next_v0 && kt < T) {
+      while (vbeg + kt * 64 >= next_v0) { ++cur_lv; next_v0 = (cur_lv + 1 < a.nlev) ? a.lev[cur_lv + 1].v0 : 0x7fffffff; }
+      yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.lev[cur_lv].dy), 0, a.lev[cur_lv].dy_bytes, 0x00020000);
+      xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.lev[cur_lv].x), 0, a.lev[cur_lv].x_bytes, 0x00020000);
     }
   };
 
@@ -172,14 +188,23 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const uint32_t off = (qv[u] && voy[j] != SOD_OOB) ? voy[j] + qadd0 + (uint32_t)(u * 256) : SOD_OOB;
+#if SOD_W256_ABL & 1
+      asm volatile("; no dma %0 %1" :: "v"(off), "v"(dst));
+#else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(dst + j * 8192), 16, off, 0, 0, 0);
+#endif
     }
   };
   auto stage_b = [&](int u, int kt) {     // X channels c0 + u*128 + [0,128)
     char* dst = smem + (kt & 1) * WBUF + (2 + u) * WUNIT + wave * 1024;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+#if SOD_W256_ABL & 1
+      asm volatile("; no dma %0 %1" :: "v"(vox[j] + cadd0), "v"(dst));
+#else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(dst + j * 8192), 16, vox[j] + cadd0 + (uint32_t)(u * 256), 0, 0, 0);
+#endif
+    }
   };
 
   // ---- transposed fragment reads: lane 4q+p of a 16-lane group addresses pixel row q, channels 4p..4p+3 of the 16-channel block
@@ -217,15 +242,30 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
 #define SODW_PACK_B(BFR)                                                                       \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) { BFR[j][0] = pack8(br[j][0][0], br[j][0][1]); BFR[j][1] = pack8(br[j][1][0], br[j][1][1]); }
 
-  // ---- prologue: K-tile 0 complete, first two units of K-tile 1
-  init_rows(vbeg - g.v0);
+#if SOD_W256_ABL & 16      // measurement build: wall-clock stamps (100 MHz) around the prologue, the K loop and the epilogue
+  const unsigned long long st0 = __builtin_amdgcn_s_memrealtime(), sc0 = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- prologue: row tables of K-tiles 0..2, K-tile 0 complete, first two units of K-tile 1
+  if (wave < 3) make_rows(wave);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  rows_request(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  rows_take(0);
   stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
-  advance(1);
+  rows_request(1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  rows_take(1);
   stage_a(0, 1); stage_b(0, 1);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();       // wave row 1 runs one barrier behind wave row 0
 
+#if SOD_W256_ABL & 16
+  const unsigned long long st1 = __builtin_amdgcn_s_memrealtime(), sc1 = __builtin_amdgcn_s_memtime();
+#endif
   for (int k = 0; k < T; ++k) {
     const uint32_t cur = lds0 + (uint32_t)((k & 1) * WBUF);
     // phase 0: quadrant (a0, b0)
@@ -235,21 +275,41 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
     // phase 1: quadrant (a0, b1)
     SODW_READ_B(cur, 1)
     SODW_PHASE(0, 1, bf1, SODW_PACK_B(bf1), stage_a(1, k + 1))
-    // phase 2: quadrant (a1, b1); the row state moves on to K-tile k+2 inside the MFMA cluster
+    // phase 2: quadrant (a1, b1); this thread's two rows of K-tile k+2 arrive with the fragments
     SODW_READ_A(cur, 1)
-    SODW_PHASE(1, 1, bf1, SODW_PACK_A, advance(k + 2); stage_a(0, k + 2))
-    // phase 3: quadrant (a1, b0), b0 still in registers
-    SODW_PHASE(1, 0, bf0, , stage_b(0, k + 2))
+    rows_request(k + 2);
+    SODW_PHASE(1, 1, bf1, SODW_PACK_A rows_take(k + 2), stage_a(0, k + 2))
+    // phase 3: quadrant (a1, b0), b0 still in registers; one wave writes the row table of K-tile k+3
+    SODW_PHASE(1, 0, bf0, , stage_b(0, k + 2); if (wave == ((k + 3) & 7)) make_rows(k + 3))
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if SOD_W256_ABL & 16
+  const unsigned long long st2 = __builtin_amdgcn_s_memrealtime(), sc2 = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- epilogue: the partial tile goes to the workspace in FRAGMENT order (16 B per lane, 1 KB per wave instruction)
   float* slab = a.partial + ((size_t)z * (size_t)(a.QT * a.CT * RS) + (size_t)tile) * SLAB + (size_t)wave * (32 * 256) + (size_t)lane * 4;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4_t*>(slab + (i * 4 + j) * 256) = acc[i][j];
+    for (int j = 0; j < 4; ++j) {
+#if SOD_W256_ABL & 8
+      if (acc[i][j][0] == 123.456f) *reinterpret_cast<f32x4_t*>(slab + (i * 4 + j) * 256) = acc[i][j];
+#else
+      *reinterpret_cast<f32x4_t*>(slab + (i * 4 + j) * 256) = acc[i][j];
+#endif
+    }
+#if SOD_W256_ABL & 16
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) {
+    const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
+    float* o = a.partial + ((size_t)z * (size_t)(a.QT * a.CT * RS) + (size_t)tile) * SLAB;
+    o[0] = (float)(st1 - st0); o[1] = (float)(st2 - st1); o[2] = (float)(st3 - st2); o[3] = (float)T;
+    o[64 * 4] = (float)(sc2 - sc1);      // shader cycles of the K loop (lane 0 of the NEXT wave instruction's row: still wave 0's slab part)
+    o[64 * 4 + 1] = (float)(st0 & 0xffffff);
+  }
+#endif
 }
 
 // Sums the nz slabs of every tile in z order and adds the result into dW.  One thread = one float4 of the fragment-ordered slab.
