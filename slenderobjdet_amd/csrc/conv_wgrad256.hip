@@ -32,10 +32,7 @@ namespace {
 constexpr int WROWB = 256;             // bytes per LDS row: 128 channels of one pixel
 constexpr int WUNIT = 64 * WROWB;      // 16 KB
 constexpr int WBUF = 4 * WUNIT;        // one K-tile: [Ya0][Ya1][Xb0][Xb1]
-constexpr int WRING_BYTES = 2 * WBUF;  // 128 KB
-constexpr int RT_SLOT = 64 * 8;        // row table of one K-tile: 64 pixel rows x {dY byte offset, X byte offset}
-constexpr int RT_SLOTS = 4;
-constexpr int WLDS_BYTES = WRING_BYTES + RT_SLOTS * RT_SLOT;
+constexpr int WLDS_BYTES = 2 * WBUF;   // 128 KB
 constexpr int SLAB = 256 * 256;        // floats per partial tile
 
 // SOD_W256_ABL (measurement builds only, tools/bench_wgrad_shapes.py): 1 = no LDS-DMA, 2 = no fragment reads,
@@ -43,8 +40,6 @@ constexpr int SLAB = 256 * 256;        // floats per partial tile
 #ifndef SOD_W256_ABL
 #define SOD_W256_ABL 0
 #endif
-
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
 template <int OFF>
 __device__ __forceinline__ s16x4_t tr_read(uint32_t addr) {
@@ -123,61 +118,53 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
   const int schunk = spos ^ (sswz << 1);                     // logical 16-B chunk (8 channels) this lane fetches
   const uint32_t qadd0 = (uint32_t)(q0 + schunk * 8) * 2u, cadd0 = (uint32_t)(c0 + schunk * 8) * 2u;   // unit 1: + 256 B
 
-  // ---- pixel rows.  The byte offsets of a K-tile's 64 pixel rows (dY row, X row shifted by the tap; out-of-range = zero fill) are the same
-  // for the 16 lanes that stage one row and for all eight waves; tracked per thread they cost ~100 vector instructions per wave and
-  // K-tile - 2 000 of the loop's 4 800 cycles per K-tile, more than the MFMA cluster they ran in can hide (in-kernel stamps,
-  // tools/bench_wgrad256_stamps.py).  ONE wave per K-tile (wave kt & 7, lane = row) now computes them from scratch - two divisions, no
-  // carried state - three K-tiles ahead into a 4-slot LDS table; the staging threads fetch their two rows with one ds_read_b64 each.
+  // ---- pixel rows.  A thread stages pixel rows L_j = (j*8+wave)*4+srow, j = 0, 1, of every K-tile and needs their byte offsets (dY row, X
+  // row shifted by the tap; out-of-range = zero fill).  Tracked incrementally per thread for both rows they cost ~100 vector instructions
+  // per wave and K-tile - 2 000 of the loop's 4 800 cycles per K-tile, more than the MFMA cluster they ran in can hide (in-kernel
+  // stamps, tools/bench_wgrad256_stamps.py).  Now every lane computes ONE row from scratch - two divisions, no carried state: even 16-B
+  // slots row L_0, odd slots row L_1 - and takes the other one from its neighbour lane (DPP quad permute).
   int cur_lv = 0;
 #pragma unroll
   for (int i = 1; i < MAXLEV; ++i)
     if (i < a.nlev && vbeg >= a.lev[i].v0) cur_lv = i;
+  WLevel g = a.lev[cur_lv];
   int next_v0 = (cur_lv + 1 < a.nlev) ? a.lev[cur_lv + 1].v0 : 0x7fffffff;
-  auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.lev[cur_lv].dy), 0, a.lev[cur_lv].dy_bytes, 0x00020000);
-  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.lev[cur_lv].x), 0, a.lev[cur_lv].x_bytes, 0x00020000);
-  int plv = cur_lv;                      // the producer's level cursor (runs three K-tiles ahead of the staging)
-  int pnext_v0 = next_v0;
+  auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.dy), 0, g.dy_bytes, 0x00020000);
+  auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, g.x_bytes, 0x00020000);
   const int dh = r * a.dil - a.pad, dw = s * a.dil - a.pad;
-  const uint32_t rt0 = (uint32_t)(uintptr_t)SOD_LDS(smem + WRING_BYTES);
-  auto make_rows = [&](int kt) {         // executed by ONE wave: lane = pixel row of K-tile kt
+  const bool odd = spos & 1;
+  const int myrow = ((odd ? 8 : 0) + wave) * 4 + srow;
+  uint32_t voy[2], vox[2];
+  auto rows = [&](int kt) {              // row offsets of K-tile kt (+ the level switch, wave-uniform)
 #if SOD_W256_ABL & 64
-    if (kt > 2) return;
+    if (kt > 1) return;
 #endif
     uint32_t oy = SOD_OOB, ox = SOD_OOB;
     const int v = vbeg + kt * 64;
-    while (v >= pnext_v0) { ++plv; pnext_v0 = (plv + 1 < a.nlev) ? a.lev[plv + 1].v0 : 0x7fffffff; }      // wave-uniform
     if (kt < T) {
-      const WLevel& pg = a.lev[plv];
-      const int p = v - pg.v0 + lane;
-      if (p < pg.P) {
-        const uint32_t n = fd_div((uint32_t)p, pg.div_hw);
-        const uint32_t rem = (uint32_t)p - n * pg.div_hw.d;
-        const uint32_t ho = fd_div(rem, pg.div_w);
-        const uint32_t wo = rem - ho * pg.div_w.d;
+      if (v >= next_v0) {
+        while (v >= next_v0) { ++cur_lv; next_v0 = (cur_lv + 1 < a.nlev) ? a.lev[cur_lv + 1].v0 : 0x7fffffff; }
+        g = a.lev[cur_lv];
+        yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.dy), 0, g.dy_bytes, 0x00020000);
+        xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, g.x_bytes, 0x00020000);
+      }
+      const int p = v - g.v0 + myrow;
+      if (p < g.P) {
+        const uint32_t n = fd_div((uint32_t)p, g.div_hw);
+        const uint32_t rem = (uint32_t)p - n * g.div_hw.d;
+        const uint32_t ho = fd_div(rem, g.div_w);
+        const uint32_t wo = rem - ho * g.div_w.d;
         const int hi = (int)ho * a.stride + dh, wi = (int)wo * a.stride + dw;
-        oy = (n * (uint32_t)pg.dy_img_stride + rem * (uint32_t)a.K) * 2u;
-        if (((unsigned)hi < (unsigned)pg.Hx) & ((unsigned)wi < (unsigned)pg.Wx))
-          ox = (n * (uint32_t)pg.x_img_stride + (uint32_t)(hi * pg.Wx + wi) * (uint32_t)a.C) * 2u;
+        oy = (n * (uint32_t)g.dy_img_stride + rem * (uint32_t)a.K) * 2u;
+        if (((unsigned)hi < (unsigned)g.Hx) & ((unsigned)wi < (unsigned)g.Wx))
+          ox = (n * (uint32_t)g.x_img_stride + (uint32_t)(hi * g.Wx + wi) * (uint32_t)a.C) * 2u;
       }
     }
-    asm volatile("ds_write_b64 %0, %1" :: "v"(rt0 + (uint32_t)((kt & (RT_SLOTS - 1)) * RT_SLOT + lane * 8)), "v"(u32x2_t{oy, ox}) : "memory");
-  };
-  // this thread stages pixel rows L_j = (j*8+wave)*4+srow, j = 0, 1, of every K-tile: voy / vox = their table entries
-  uint32_t voy[2], vox[2];
-  u32x2_t rraw[2];
-  const uint32_t rt_mine = rt0 + (uint32_t)((wave * 4 + srow) * 8);
-  auto rows_request = [&](int kt) {      // the caller waits (lgkmcnt) before rows_take
-    const uint32_t ad = rt_mine + (uint32_t)((kt & (RT_SLOTS - 1)) * RT_SLOT);
-    asm volatile("ds_read_b64 %0, %1" : "=v"(rraw[0]) : "v"(ad));
-    asm volatile("ds_read_b64 %0, %1 offset:256" : "=v"(rraw[1]) : "v"(ad));
-  };
-  auto rows_take = [&](int kt) {         // + the staging side's level switch (buffer descriptors), wave-uniform
-    voy[0] = rraw[0][0]; vox[0] = rraw[0][1]; voy[1] = rraw[1][0]; vox[1] = rraw[1][1];
-    if (vbeg + kt * 64 >= next_v0 && kt < T) {
-      while (vbeg + kt * 64 >= next_v0) { ++cur_lv; next_v0 = (cur_lv + 1 < a.nlev) ? a.lev[cur_lv + 1].v0 : 0x7fffffff; }
-      yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.lev[cur_lv].dy), 0, a.lev[cur_lv].dy_bytes, 0x00020000);
-      xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.lev[cur_lv].x), 0, a.lev[cur_lv].x_bytes, 0x00020000);
-    }
+    // neighbour lane's pair: quad_perm [1, 0, 3, 2] = 0xB1
+    const uint32_t ny = (uint32_t)__builtin_amdgcn_mov_dpp((int)oy, 0xB1, 0xF, 0xF, true);
+    const uint32_t nx = (uint32_t)__builtin_amdgcn_mov_dpp((int)ox, 0xB1, 0xF, 0xF, true);
+    voy[0] = odd ? ny : oy; vox[0] = odd ? nx : ox;
+    voy[1] = odd ? oy : ny; vox[1] = odd ? ox : nx;
   };
 
   // K need not be a multiple of 256 (RetinaNet / AnchorHead class scores: 9 anchors x 80 classes = 720): a lane whose 8 output channels lie
@@ -245,19 +232,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
 #if SOD_W256_ABL & 16      // measurement build: wall-clock stamps (100 MHz) around the prologue, the K loop and the epilogue
   const unsigned long long st0 = __builtin_amdgcn_s_memrealtime(), sc0 = __builtin_amdgcn_s_memtime();
 #endif
-  // ---- prologue: row tables of K-tiles 0..2, K-tile 0 complete, first two units of K-tile 1
-  if (wave < 3) make_rows(wave);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  rows_request(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  rows_take(0);
+  // ---- prologue: K-tile 0 complete, first two units of K-tile 1
+  rows(0);
   stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
-  rows_request(1);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  rows_take(1);
+  rows(1);
   stage_a(0, 1); stage_b(0, 1);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -275,12 +253,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
     // phase 1: quadrant (a0, b1)
     SODW_READ_B(cur, 1)
     SODW_PHASE(0, 1, bf1, SODW_PACK_B(bf1), stage_a(1, k + 1))
-    // phase 2: quadrant (a1, b1); this thread's two rows of K-tile k+2 arrive with the fragments
+    // phase 2: quadrant (a1, b1); the rows of K-tile k+2 are computed inside the MFMA cluster
     SODW_READ_A(cur, 1)
-    rows_request(k + 2);
-    SODW_PHASE(1, 1, bf1, SODW_PACK_A rows_take(k + 2), stage_a(0, k + 2))
-    // phase 3: quadrant (a1, b0), b0 still in registers; one wave writes the row table of K-tile k+3
-    SODW_PHASE(1, 0, bf0, , stage_b(0, k + 2); if (wave == ((k + 3) & 7)) make_rows(k + 3))
+    SODW_PHASE(1, 1, bf1, SODW_PACK_A, rows(k + 2); stage_a(0, k + 2))
+    // phase 3: quadrant (a1, b0), b0 still in registers
+    SODW_PHASE(1, 0, bf0, , stage_b(0, k + 2))
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
