@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256 * G, 2) void conv_wgrad_ring_kernel(const Wgrad
   // column wrap and one image wrap - a handful of adds / compares instead of two divisions per row and step.
   uint32_t r_oy[RNI], r_ox[RNI];
   int r_ho[RNI], r_wo[RNI], r_p[RNI];
-  bool fast = false;
+  bool fast = false, linear = false;
   int dh = 0, dw = 0;
   uint32_t ycorr = 0, xcorr = 0;
   auto init_rows = [&](int pbase) {
@@ -101,6 +101,9 @@ __global__ __launch_bounds__(256 * G, 2) void conv_wgrad_ring_kernel(const Wgrad
     dh = r * a.dil - a.pad; dw = s * a.dil - a.pad;
     ycorr = (uint32_t)(g.dy_img_stride - g.Ho * g.Wo * a.K) * 2u;
     xcorr = (uint32_t)(g.x_img_stride - g.Hx * g.Wx * a.C) * 2u;
+    // LINEAR: an un-shifted tap over dense tensors (every 1x1 convolution of the bottleneck blocks) - both byte offsets are affine in
+    // the pixel index, no (row, column) to carry: 6 instead of 22 vector instructions per row and K-step
+    linear = fast && dh == 0 && dw == 0 && ycorr == 0 && xcorr == 0;
     const uint32_t tapshift = (uint32_t)((dh * g.Wx + dw) * a.C * 2);
 #pragma unroll
     for (int i = 0; i < RNI; ++i) {
@@ -131,6 +134,19 @@ __global__ __launch_bounds__(256 * G, 2) void conv_wgrad_ring_kernel(const Wgrad
         xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, g.x_bytes, 0x00020000);
         init_rows(v - g.v0);
       }
+    }
+    if (linear) {
+      const uint32_t ystep = (uint32_t)(2 * RKP * a.K), xstep = (uint32_t)(2 * RKP * a.C);
+#pragma unroll
+      for (int i = 0; i < RNI; ++i) {
+        const bool pv = live && r_p[i] < g.P;
+        const uint32_t vy = (pv && qok) ? r_oy[i] : SOD_OOB;
+        const uint32_t vx = (pv && cok) ? r_ox[i] : SOD_OOB;
+        if constexpr (!(ABL & 16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(buf + (i * 4 + wv) * 1024), 16, vy, 0, 0, 0);
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + RTILE + (i * 4 + wv) * 1024), 16, vx, 0, 0, 0);
+        r_p[i] += RKP; r_oy[i] += ystep; r_ox[i] += xstep;
+      }
+      return;
     }
     if (!live || fast) {
       const uint32_t ystep = (uint32_t)(2 * RKP * a.K), xstep = (uint32_t)(2 * RKP * a.C);
