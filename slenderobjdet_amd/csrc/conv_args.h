@@ -227,6 +227,11 @@ bool wgrad256_supported(const WgradArgs& a);
 long long wgrad256_workspace_bytes(const WgradArgs& a, int cus);
 int launch_wgrad256(WgradArgs& a, int cus, float* ws, long long ws_bytes, hipStream_t st);
 
+// conv_wgrad_fold.hip: few output channels (K <= 80 for 3x3) - the taps folded into the rows of the 128 x 128 tile, X staged once for all
+// taps; stride 1, "same" geometry, float atomics (not for the deterministic mode).
+bool wgrad_fold_supported(const WgradArgs& a);
+int launch_wgrad_fold(WgradArgs& a, int cus, hipStream_t st);
+
 // conv_wgrad_ring.hip: 128 x 128 tile, G groups of 4 waves per workgroup that split the tile's pixel range among themselves and sum
 // their partial tiles through LDS.  variant = G * 1000 + NSTAGE * 100 + EPI * 10 + FDB (EPI 0: float atomics in 256-B runs, 1: [128][128]
 // fp32 slabs in a.partial for wgrad_reduce_kernel; FDB: fragment reads one K-step ahead).  a.nz counts z-BLOCKS of G pixel ranges.

@@ -1111,6 +1111,14 @@ int launch_wgrad(WgradArgs& a, int splits, int flags, hipStream_t st, float* ws 
     prof_end(pi, st, 256, 1.f, 2);
     return rc;
   }
+  // few output channels (prediction convolutions): the taps folded into the tile rows, conv_wgrad_fold.hip.  SOD_WGRAD_FOLD=0 disables.
+  static const int fold = getenv("SOD_WGRAD_FOLD") ? atoi(getenv("SOD_WGRAD_FOLD")) : 1;
+  if (fold && splits == 0 && wgrad_fold_supported(a)) {
+    const int pi = prof_begin(st);
+    const int rc = launch_wgrad_fold(a, device_cus(), st);
+    prof_end(pi, st, 32004, 1.f, 2);
+    return rc;
+  }
   a.QT = (a.K + 127) / 128; a.CT = a.diag ? 1 : (a.C + 127) / 128;
   const int tiles = a.QT * a.CT * a.R * a.S;
   int V = 0;

@@ -465,6 +465,40 @@ def test_conv_multilevel_dgrad_accum(cuda, tile):
         HF.conv2d_dgrad_ml(dyd, wt, hw, 1, 1, 1, accums=accs[:-1])
 
 
+@pytest.mark.parametrize("K", [8, 40, 80])
+def test_conv_wgrad_folded_taps(cuda, K):
+    """conv_wgrad_fold.hip: weight gradient of a 3x3 prediction conv with few output channels (FCOS bbox_pred + centerness: 8 padded,
+    RetinaNet bbox_pred: 40, class scores: 80) with the taps folded into the tile rows == the un-folded kernel (an explicit split count
+    keeps that one) == the oracle; multi-level, dY rows in the concatenated (N, L, K) buffer, a level smaller than one K-step, a level
+    whose pixel count is no multiple of 32."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, C = 2, 256
+    hw = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    xs = [_rand((N, h, ww, C), 10 + i) for i, (h, ww) in enumerate(hw)]
+    dys = [_rand((N, h, ww, K), 20 + i) for i, (h, ww) in enumerate(hw)]
+    xd = [x.to(cuda).bfloat16() for x in xs]
+    L = sum(h * ww for h, ww in hw)
+    offs = [sum(h * ww for h, ww in hw[:i]) for i in range(len(hw))]
+    gbuf = torch.cat([d.reshape(N, -1, K) for d in dys], 1).to(cuda).bfloat16().contiguous()
+    gviews = [gbuf.view(-1)[o * K:] for o in offs]
+    dw_ref = torch.zeros(K, 3, 3, C)
+    for x, dy in zip(xs, dys):
+        dw_ref += onn.conv2d_backward(x, torch.zeros(K, 3, 3, C), dy, 1, 1, 1)[1]
+    dw = torch.zeros((K, 3, 3, C), device=cuda)
+    HF.conv2d_wgrad_ml(gviews, xd, dw, 3, 3, 1, 1, 1, dy_img_stride=L * K, K=K)
+    _close(dw, dw_ref, 2e-4, f"folded wgrad K={K}")
+    plain = torch.zeros_like(dw)
+    HF.conv2d_wgrad_ml(gviews, xd, plain, 3, 3, 1, 1, 1, dy_img_stride=L * K, K=K, splits=3)
+    _close(plain, dw_ref, 2e-4, "un-folded wgrad")
+    assert (dw - plain).abs().max() <= 1e-4 * plain.abs().max()
+    # accumulation into a non-zero gradient, per-output-channel scale
+    qs = torch.rand(K, generator=torch.Generator().manual_seed(5)) + 0.5
+    dw2 = torch.ones((K, 3, 3, C), device=cuda)
+    HF.conv2d_wgrad_ml(gviews, xd, dw2, 3, 3, 1, 1, 1, dy_img_stride=L * K, K=K, qscale=qs.to(cuda))
+    _close(dw2 - 1.0, dw_ref * qs.view(-1, 1, 1, 1), 3e-4, "folded wgrad accumulate + scale")
+
+
 # ---- 256x256x64 8-phase kernel (conv_igemm256.hip), forced through sod_conv_set_tile256
 T256_CASES = [
     # (N, H, W, C, K, R, stride, pad, dil)
