@@ -119,6 +119,9 @@ __global__ __launch_bounds__(256 * G, 2) void conv_wgrad_ring_kernel(const Wgrad
     }
   };
   init_rows(vbeg - g.v0);
+  uint32_t abl_y0[RNI], abl_x0[RNI];
+#pragma unroll
+  for (int i = 0; i < RNI; ++i) { abl_y0[i] = r_oy[i]; abl_x0[i] = r_ox[i]; }
 
   // Requests tile `it` of this group into `buf`.  EVERY call issues RLPS LDS-DMA loads per thread (dead tiles: out-of-range offsets, zero
   // fill into a slot nobody reads) - the counted vmcnt below depends on it.  Called with increasing `it`.
@@ -154,10 +157,15 @@ __global__ __launch_bounds__(256 * G, 2) void conv_wgrad_ring_kernel(const Wgrad
       for (int i = 0; i < RNI; ++i) {
         const bool pv = live && r_p[i] < g.P;
         const bool tv = ((unsigned)(r_ho[i] + dh) < (unsigned)g.Hx) & ((unsigned)(r_wo[i] + dw) < (unsigned)g.Wx);
-        const uint32_t vy = (pv && qok) ? r_oy[i] : SOD_OOB;
-        const uint32_t vx = (pv && tv && cok) ? r_ox[i] : SOD_OOB;
+        uint32_t vy = (pv && qok) ? r_oy[i] : SOD_OOB;
+        uint32_t vx = (pv && tv && cok) ? r_ox[i] : SOD_OOB;
+        if constexpr (ABL & 64) {      // measurement: the row arithmetic runs, the loads keep the rows of the first step (L2-hot)
+          asm volatile("; keep %0 %1" :: "v"(vy), "v"(vx));
+          vy = abl_y0[i]; vx = abl_x0[i];
+        }
         if constexpr (!(ABL & 16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(buf + (i * 4 + wv) * 1024), 16, vy, 0, 0, 0);
         if constexpr (!(ABL & 8)) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + RTILE + (i * 4 + wv) * 1024), 16, vx, 0, 0, 0);
+        if constexpr (ABL & 32) continue;      // measurement: rows never advance (no row arithmetic, L2-hot loads)
         r_p[i] += RKP; r_oy[i] += ystep; r_ox[i] += xstep;
         int wo = r_wo[i] + RKP, ho = r_ho[i];
         if (wo >= g.Wo) { wo -= g.Wo; ho += 1; }
@@ -383,7 +391,7 @@ int launch_wgrad_ring(const WgradArgs& a, int variant, hipStream_t st) {
 #undef SOD_RING_CASE
 #ifdef SOD_RING_ABLATION
 #define SOD_ABL_CASE(ABL) case 2300 + 10000 * (ABL): return launch_one<2, 3, 0, false, (ABL)>(a, tiles, st);
-    SOD_ABL_CASE(1) SOD_ABL_CASE(3) SOD_ABL_CASE(4) SOD_ABL_CASE(5) SOD_ABL_CASE(7) SOD_ABL_CASE(8 + 7) SOD_ABL_CASE(16 + 7) SOD_ABL_CASE(8 + 4) SOD_ABL_CASE(16 + 4) SOD_ABL_CASE(24 + 4)
+    SOD_ABL_CASE(1) SOD_ABL_CASE(3) SOD_ABL_CASE(4) SOD_ABL_CASE(5) SOD_ABL_CASE(7) SOD_ABL_CASE(8 + 7) SOD_ABL_CASE(16 + 7) SOD_ABL_CASE(8 + 4) SOD_ABL_CASE(16 + 4) SOD_ABL_CASE(24 + 4) SOD_ABL_CASE(32) SOD_ABL_CASE(64)
 #undef SOD_ABL_CASE
 #endif
     default: return SOD_EARG;
