@@ -1072,9 +1072,11 @@ bool use_wgrad256(const WgradArgs& a, float* ws, long long ws_bytes) {
   const int cus = device_cus();
   if (wgrad256_workspace_bytes(a, cus) > ws_bytes) return false;
   if (mode == 2) return true;
-  // The kernel masks a partial last q-tile (K = 720 of RetinaNet's class scores), but in the step that shape measured slower on it than on
-  // the 128x128 ring kernel (RetinaNet R50 527.5 / 527.1 vs 533.0 / 531.2 img/s: 27 tiles of which 9 are 19 % empty): multiples of 256 only.
-  if (a.K & 255) return false;
+  // The kernel masks a partial last q-tile (K = 720 of RetinaNet's class scores: 27 tiles of which 9 are 19 % empty).  Until round 4 that
+  // shape measured slower on it than on the 128x128 kernel (RetinaNet R50 527.5 / 527.1 vs 533.0 / 531.2 img/s); with the row arithmetic
+  // out of the K loop it wins (546.6 / 548.5 vs 542.1 / 540.4; the 128x128 launch took 2.6 ms).  SOD_WGRAD256_ANYK=0: multiples of 256 only.
+  static const int anyk = getenv("SOD_WGRAD256_ANYK") ? atoi(getenv("SOD_WGRAD256_ANYK")) : 1;
+  if ((a.K & 255) && !anyk) return false;
   long long V = 0;
   for (int l = 0; l < a.nlev; ++l) V += (a.lev[l].P + 63) / 64 * 64;
   const long long tiles = (long long)((a.K + 255) / 256) * (a.C / 256) * a.R * a.S;
