@@ -1443,6 +1443,29 @@ extern "C" int sod_conv2d_dgrad_ml_mask(int nlev, const void* const* dy, const v
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 
+// sod_conv2d_dgrad_ml for dY rows of `Kpitch` channels contracted as Kp >= Kpitch channels per tap (Kp a multiple of 64): wt_pad is
+// [C][R][S][Kp] with ZERO columns from Kpitch on, so that the Kp - Kpitch values the K loop reads past a pixel's row (the next pixel's
+// first channels, or zero fill at the end of the buffer) do not contribute.  A contraction that is no multiple of 64 channels per tap
+// (RetinaNet's 720 class scores) otherwise takes the per-chunk gather path of the 128x128 kernel; padded to 768 it runs on the linear K
+// loops, i.e. on the 256x256 kernel for the tower-sized output.  stride 1 only.
+extern "C" int sod_conv2d_dgrad_ml_kpitch(int nlev, const void* const* dy, const void* wt_pad, void* const* dx,
+                                          int N, const int* H, const int* W, int C, int Kp, int Kpitch, int R, int S, int pad, int dil,
+                                          long long dy_img_stride, void* stream) {
+  if (!dy || !wt_pad || !dx || !H || !W || Kpitch <= 0 || (Kpitch & 7) || Kp < Kpitch || (Kp & 63)) return SOD_EARG;
+  ConvArgs a{};
+  int rc = fill_common(a, nlev, N, Kp, C, R, S, 1, pad, dil);
+  if (rc) return rc;
+  a.Cpitch = Kpitch;
+  for (int l = 0; l < nlev; ++l) {
+    const int Ho = out_size(H[l], pad, dil, R, 1), Wo = out_size(W[l], pad, dil, S, 1);
+    if (Ho <= 0 || Wo <= 0) return SOD_EARG;
+    rc = fill_level(a, l, dy[l], dx[l], Ho, Wo, H[l], W[l], dy_img_stride, 0, 2);
+    if (rc) return rc;
+  }
+  a.w = wt_pad; a.bias = nullptr; a.flags = 0;
+  return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
+}
+
 // sod_conv2d_dgrad_ml whose epilogue adds accum[l] (bf16, dx[l]'s shape) to level l's result: the SECOND of two consumers of the same
 // tensors (the two FCOS towers read the same FPN outputs, fcosv2.py:342-361) leaves the sum of both data gradients in one pass.
 extern "C" int sod_conv2d_dgrad_ml_accum(int nlev, const void* const* dy, const void* wt, const void* const* accum, void* const* dx,

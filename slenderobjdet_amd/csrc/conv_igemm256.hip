@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
         int xh, xw;
         if (MODE == MODE_FWD) { xh = (int)ph * a.stride - a.pad; xw = (int)pw * a.stride - a.pad; }
         else                  { xh = (int)ph + a.pad;            xw = (int)pw + a.pad; }
-        rb = (n * (uint32_t)g.src_img_stride + ((uint32_t)xh * (uint32_t)gWs + (uint32_t)xw) * (uint32_t)a.Cred + (uint32_t)schunk * 8u) * 2u;
+        rb = (n * (uint32_t)g.src_img_stride + ((uint32_t)xh * (uint32_t)gWs + (uint32_t)xw) * (uint32_t)a.Cpitch + (uint32_t)schunk * 8u) * 2u;
         // tap (r, s) is valid iff its row AND its column lie inside the source: R + S comparisons and an outer product of the two bit
         // rows instead of R * S (this runs once per tile, with nothing else on the CU to hide it)
         uint32_t colbits = 0;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
   // Loop-invariant scalars in registers (no kernarg reloads, i.e. no lgkmcnt waits, inside the K loop); branch-free staging:
   // a dead K-tile (kt >= T) ORs the out-of-range bit into the weight offset and selects tap 31, whose mask bit is never set.
   const uint32_t s_mul = a.div_s.mul, s_shr = a.div_s.shr;
-  const int aS = a.S, row_step = a.dil * gWs * a.Cred * 2 * tap_sign, col_step = a.dil * a.Cred * 2 * tap_sign;
+  const int aS = a.S, row_step = a.dil * gWs * a.Cpitch * 2 * tap_sign, col_step = a.dil * a.Cpitch * 2 * tap_sign;      // Cpitch: source channels per pixel (>= the contraction's own width only in sod_conv2d_dgrad_ml_kpitch)
 
   auto stage_b = [&](int u, int kt) {     // pixel rows of sub-block u (b0 / b1) of K-tile kt
     char* dst = smem + (kt & 1) * BUF + (2 + u) * UNIT + wave * 1024;
@@ -397,7 +397,7 @@ int launch256(const ConvArgs& a0, int max_pt_tiles, hipStream_t st) {
 }  // namespace
 
 bool conv256_supported(const ConvArgs& a, int mode) {
-  if ((a.Cred & 63) || (a.Nout & 7) || a.R * a.S > 31) return false;   // tap-validity masks are 32-bit, bit 31 = "dead tile"
+  if ((a.Cred & 63) || (a.Nout & 7) || a.R * a.S > 31 || a.cwin) return false;   // tap-validity masks are 32-bit, bit 31 = "dead tile"
   if (mode == MODE_DGRAD && a.stride != 1) return false;
   return true;
 }

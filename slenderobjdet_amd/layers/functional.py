@@ -411,10 +411,12 @@ def conv_gn_fwd_ml(xs, w, bias, gamma, beta, G, eps=1e-5, relu=True, pad=1, afte
     return outs, ys, stats
 
 
-def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=None, k_real=None, relu_masks=None, accums=None):
+def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=None, k_real=None, relu_masks=None, accums=None, k_pitch=None):
     """dys: per-level dY tensors (or 1-D views into a concatenated buffer with dy_img_stride); returns per-level dX.  ``relu_masks``:
     the post-ReLU tensors dX is the gradient of - the ReLU backward is then applied in the epilogue (dX = mask > 0 ? dX : 0).
-    ``accums``: per-level bf16 tensors of dX's shapes added in the epilogue (another consumer's gradient of the same tensors)."""
+    ``accums``: per-level bf16 tensors of dX's shapes added in the epilogue (another consumer's gradient of the same tensors).
+    ``k_pitch``: the dY rows hold k_pitch channels and ``wt`` is (C, R, S, Kp) with Kp >= k_pitch a multiple of 64 and ZERO columns from
+    k_pitch on (sod_conv2d_dgrad_ml_kpitch: the linear K loops for contractions that are no multiple of 64 channels per tap)."""
     _chk(wt, torch.bfloat16, "wt")
     C, R, S, K = wt.shape
     if N is None:
@@ -422,7 +424,12 @@ def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=N
     dev = dys[0].device
     outs = [torch.empty((N, h, w, C), dtype=torch.bfloat16, device=dev) for h, w in x_hws]
     e0 = _prof_begin(None, "conv_dgrad")
-    if accums is not None:
+    if k_pitch is not None and k_pitch != K:
+        if relu_masks is not None or accums is not None or stride != 1:
+            raise _C.SlenderHipError("conv2d_dgrad_ml: k_pitch comes without masks / accums, stride 1")
+        call("sod_conv2d_dgrad_ml_kpitch", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]),
+             _int_arr([w for _, w in x_hws]), C, K, int(k_pitch), R, S, pad, dil, dy_img_stride, stream_ptr())
+    elif accums is not None:
         if relu_masks is not None or len(accums) != len(outs):
             raise _C.SlenderHipError("conv2d_dgrad_ml: accums come one per level and without relu_masks")
         for t, o in zip(accums, outs):

@@ -11,6 +11,7 @@ ignored anchors are skipped by label inside the loss kernels (no boolean gathers
 (the reference calls ``.item()`` at :210).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -28,6 +29,9 @@ from .fcos import FCOSV2
 def _ceil8(v):
     return (v + 7) // 8 * 8
 
+
+# SOD_PRED_DGRAD_PAD=0: the data gradient of the class-score conv on the per-chunk gather path (its 720 channels are no multiple of 64)
+PRED_DGRAD_PAD = os.environ.get("SOD_PRED_DGRAD_PAD", "1") != "0"
 
 class RetinaNetHead(nn.Module):
     def __init__(self, cfg, in_channels, num_anchors):
@@ -136,7 +140,13 @@ class _RetinaLossFn(torch.autograd.Function):
             arena.mark_ready(pred.weight)
             HF.bias_grad(dbuf, arena.grad_view(pred.bias), N, P, kk)
             arena.mark_ready(pred.bias)
-            grads.append(HF.conv2d_dgrad_ml(dys, pred.wt_bf16, hw, 1, 1, 1, dy_img_stride=P * kk, N=N))
+            if PRED_DGRAD_PAD and not HF.is_f32() and kk % 64 and kk >= 256:
+                # 720 class scores: contract over a 768-wide zero-padded copy of the transposed weights on the linear K loops (the 256x256
+                # kernel) instead of the per-chunk gather path of the 128x128 kernel (sod_conv2d_dgrad_ml_kpitch)
+                wt_pad = torch.nn.functional.pad(pred.wt_bf16, (0, (kk + 63) // 64 * 64 - kk))
+                grads.append(HF.conv2d_dgrad_ml(dys, wt_pad, hw, 1, 1, 1, dy_img_stride=P * kk, N=N, k_pitch=kk))
+            else:
+                grads.append(HF.conv2d_dgrad_ml(dys, pred.wt_bf16, hw, 1, 1, 1, dy_img_stride=P * kk, N=N))
         return (None, None, None, None, *grads[0], *grads[1])
 
 

@@ -499,6 +499,39 @@ def test_conv_wgrad_folded_taps(cuda, K):
     _close(dw2 - 1.0, dw_ref * qs.view(-1, 1, 1, 1), 3e-4, "folded wgrad accumulate + scale")
 
 
+@pytest.mark.parametrize("tile", [0, 2])
+def test_conv_multilevel_dgrad_padded_contraction(cuda, tile):
+    """sod_conv2d_dgrad_ml_kpitch: dY rows of 72 channels in the concatenated (N, L, 72) buffer (RetinaNet's 720 class scores in small)
+    contracted as 128 channels per tap against zero-padded transposed weights, on the 128x128 and on the 256x256 kernel (source pitch !=
+    contraction width) == the per-chunk gather path of the plain entry point == the oracle; the rows at the very end of the buffer
+    over-read into zero fill."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, C, K = 2, 256, 72
+    hw = [(20, 28), (10, 14), (5, 7), (3, 4), (2, 2)]
+    w = _rand((K, 3, 3, C), 1, 0.05)
+    dys = [_rand((N, h, ww, K), 20 + i) for i, (h, ww) in enumerate(hw)]
+    _, wt = HF.weight_prep(w.to(cuda), want_krsc=False)
+    assert tuple(wt.shape) == (C, 3, 3, K)
+    L = sum(h * ww for h, ww in hw)
+    offs = [sum(h * ww for h, ww in hw[:i]) for i in range(len(hw))]
+    gbuf = torch.cat([d.reshape(N, -1, K) for d in dys], 1).to(cuda).bfloat16().contiguous()
+    gviews = [gbuf.view(-1)[o * K:] for o in offs]
+    plain = HF.conv2d_dgrad_ml(gviews, wt, hw, 1, 1, 1, dy_img_stride=L * K, N=N)
+    wt_pad = torch.nn.functional.pad(wt, (0, 128 - K))
+    HF.call("sod_conv_set_tile256", tile)
+    try:
+        got = HF.conv2d_dgrad_ml(gviews, wt_pad, hw, 1, 1, 1, dy_img_stride=L * K, N=N, k_pitch=K)
+    finally:
+        HF.call("sod_conv_set_tile256", -1)
+    for g, p0, dy, (h, ww) in zip(got, plain, dys, hw):
+        ref, _ = onn.conv2d_backward(torch.zeros(N, h, ww, C), w, dy, 1, 1, 1)
+        _close(g, ref, 2 ** -7, "padded-contraction dgrad")
+        assert (g.float() - p0.float()).abs().max() <= 2 ** -7 * p0.float().abs().max()
+    with pytest.raises(Exception):      # the padded width must be a multiple of 64
+        HF.conv2d_dgrad_ml(gviews, torch.nn.functional.pad(wt, (0, 24)), hw, 1, 1, 1, dy_img_stride=L * K, N=N, k_pitch=K)
+
+
 # ---- 256x256x64 8-phase kernel (conv_igemm256.hip), forced through sod_conv_set_tile256
 T256_CASES = [
     # (N, H, W, C, K, R, stride, pad, dil)
