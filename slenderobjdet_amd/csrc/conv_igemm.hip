@@ -926,7 +926,9 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     }
     static const int min_rounds = getenv("SOD_CONV256_MIN_ROUNDS") ? atoi(getenv("SOD_CONV256_MIN_ROUNDS")) : 1;
     static const int min_k = getenv("SOD_CONV256_MIN_K") ? atoi(getenv("SOD_CONV256_MIN_K")) : 1024;
-    if (a.Nout >= 256 && (a.Nout & 255) == 0 && a.Kred >= min_k && b256 >= (long long)min_rounds * cus) {
+    // output-channel counts that are no multiple of 256 (RetinaNet's 720 class scores: the third q-tile is 19 % empty) from 512 channels up
+    static const int anyn = getenv("SOD_CONV256_ANYN") ? atoi(getenv("SOD_CONV256_ANYN")) : 1;
+    if (a.Nout >= 256 && ((a.Nout & 255) == 0 || (anyn && a.Nout >= 512)) && a.Kred >= min_k && b256 >= (long long)min_rounds * cus) {
       // Measured (16 x FPN levels, 256 -> 256 3x3): 1020-1040 TFLOP/s against 840-930 for the 128x128 kernel.  Shapes with barely more
       // than one round of tiles (res4 conv2: 263 tiles = one round + a 7-tile remainder launch) measured slower stand-alone but win in
       // the training step (545.8-546.3 vs 541.2-542.9 img/s), so one full round is enough (SOD_CONV256_MIN_ROUNDS).

@@ -542,6 +542,7 @@ T256_CASES = [
     (1, 10, 10, 64, 64, 3, 1, 2, 2),      # dilation
     (1, 6, 7, 64, 72, 1, 1, 0, 1),        # a single K-tile (prologue/tail only)
     (1, 12, 10, 128, 256, 5, 1, 2, 1),    # 25 taps
+    (2, 13, 21, 64, 720, 3, 1, 1, 1),     # three q-tiles, the last one 19 % empty (RetinaNet's class scores)
 ]
 
 
