@@ -368,7 +368,17 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const __bf16* __restri
   int p1 = p0 + pix_per_block; if (p1 > HW) p1 = HW;
   if (threadIdx.x < rows_per_iter * c8n) {
     const long long base = (long long)n * img_stride + c8 * 8;
-    for (int p = p0 + prow; p < p1; p += rows_per_iter) {
+    // four independent 16-byte loads in flight per thread (one per trip left the pass at 0.7-1.1 TB/s on the P2 / P3-sized tensors)
+    int p = p0 + prow;
+    for (; p + 3 * rows_per_iter < p1; p += 4 * rows_per_iter) {
+      const bf16x8_t v0 = *reinterpret_cast<const bf16x8_t*>(dy + base + (long long)p * C);
+      const bf16x8_t v1 = *reinterpret_cast<const bf16x8_t*>(dy + base + (long long)(p + rows_per_iter) * C);
+      const bf16x8_t v2 = *reinterpret_cast<const bf16x8_t*>(dy + base + (long long)(p + 2 * rows_per_iter) * C);
+      const bf16x8_t v3 = *reinterpret_cast<const bf16x8_t*>(dy + base + (long long)(p + 3 * rows_per_iter) * C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += ((float)v0[e] + (float)v1[e]) + ((float)v2[e] + (float)v3[e]);
+    }
+    for (; p < p1; p += rows_per_iter) {
       const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(dy + base + (long long)p * C);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
@@ -404,7 +414,16 @@ __global__ __launch_bounds__(256) void channel_sum_ml_kernel(const ChanSumML m, 
   int p1 = p0 + m.ppb[l]; if (p1 > HW) p1 = HW;
   if (threadIdx.x < rows_per_iter * c8n) {
     const __bf16* __restrict__ dy = m.dy[l] + (long long)n * HW * C + c8 * 8;
-    for (int p = p0 + prow; p < p1; p += rows_per_iter) {
+    int p = p0 + prow;
+    for (; p + 3 * rows_per_iter < p1; p += 4 * rows_per_iter) {      // four loads in flight per thread (channel_sum_kernel)
+      const bf16x8_t v0 = *reinterpret_cast<const bf16x8_t*>(dy + (long long)p * C);
+      const bf16x8_t v1 = *reinterpret_cast<const bf16x8_t*>(dy + (long long)(p + rows_per_iter) * C);
+      const bf16x8_t v2 = *reinterpret_cast<const bf16x8_t*>(dy + (long long)(p + 2 * rows_per_iter) * C);
+      const bf16x8_t v3 = *reinterpret_cast<const bf16x8_t*>(dy + (long long)(p + 3 * rows_per_iter) * C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += ((float)v0[e] + (float)v1[e]) + ((float)v2[e] + (float)v3[e]);
+    }
+    for (; p < p1; p += rows_per_iter) {
       const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(dy + (long long)p * C);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
