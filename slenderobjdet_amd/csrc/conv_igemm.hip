@@ -90,6 +90,7 @@ __global__ __launch_bounds__(64 * WQ * WP, (WQ * WP == 4 && BK == 32 && NSTAGE =
   const int gP = g.P, gHs = g.Hs, gWs = g.Ws;
   const uint32_t Cp = (uint32_t)a.Cpitch;               // source channels per pixel (= Cred unless a channel window is on)
   const uint32_t cw0 = a.cwin ? (uint32_t)q0 : 0u;      // window mode: this q-tile contracts over the source channels at its own offset
+  const bool pitched = a.Cpitch < a.Cred;               // wave-uniform: only sod_conv2d_dgrad_ml_kpitch launches
 
   auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.w_bytes, 0x00020000);
   auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.src), 0, g.src_bytes, 0x00020000);
@@ -193,9 +194,12 @@ __global__ __launch_bounds__(64 * WQ * WP, (WQ * WP == 4 && BK == 32 && NSTAGE =
           __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, SOD_LDS(buf + (j * RPP + wave * RPI) * ROWB), 16, voff, 0, 0, 0);
         }
       }
+      // a source pitch BELOW the contraction width (sod_conv2d_dgrad_ml_kpitch): chunks past the pixel's last channel are zero fill, never
+      // the next pixel's data (whatever follows the buffer may hold NaN bit patterns, and NaN x 0 is NaN)
+      const bool cin = !pitched || (c0 + schunk * 8 < (int)Cp);
 #pragma unroll
       for (int i = 0; i < XI; ++i) {
-        const bool ok = (tapmask[i] >> tap) & 1ull;
+        const bool ok = ((tapmask[i] >> tap) & 1ull) && cin;
         const uint32_t voff = ok ? rowbase[i] + tapoff : SOD_OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(buf + W_TILE + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
       }

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
   // and the tap masks for four rows per thread: ~2 us with nothing else on the CU), so their latency runs beside that arithmetic.
   const uint32_t rs_mul = a.div_rs.mul, rs_shr = a.div_rs.shr, rs_d = a.div_rs.d;
   const int aCred = a.Cred;
+  const bool pitched = a.Cpitch < a.Cred;      // wave-uniform
   auto stage_a = [&](int u, int kt) {     // weight rows of sub-block u (a0 / a1) of K-tile kt
     char* dst = smem + (kt & 1) * BUF + u * UNIT + wave * 1024;
     const bool live = kt < T;
@@ -166,9 +167,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
     const int s2 = (int)tap - r * aS;
     const uint32_t tapoff = (uint32_t)(r * row_step + s2 * col_step + c0);
     const uint32_t tbit = live ? tap : 31u;
+    // a source pitch below the contraction width (sod_conv2d_dgrad_ml_kpitch): chunks past the pixel's last channel are zero fill
+    const bool cin = !pitched || ((int)cc * 64 + schunk * 8 < a.Cpitch);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const uint32_t voff = ((tapmask[u][j] >> tbit) & 1u) ? rowbase[u][j] + tapoff : SOD_OOB;
+      const uint32_t voff = (((tapmask[u][j] >> tbit) & 1u) && cin) ? rowbase[u][j] + tapoff : SOD_OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(dst + j * 8192), 16, voff, 0, 0, 0);
     }
   };

@@ -515,7 +515,11 @@ def test_conv_multilevel_dgrad_padded_contraction(cuda, tile):
     assert tuple(wt.shape) == (C, 3, 3, K)
     L = sum(h * ww for h, ww in hw)
     offs = [sum(h * ww for h, ww in hw[:i]) for i in range(len(hw))]
-    gbuf = torch.cat([d.reshape(N, -1, K) for d in dys], 1).to(cuda).bfloat16().contiguous()
+    # the buffer sits inside a larger allocation whose other bytes are NaN: no chunk past a pixel's 72 channels may ever be fetched as
+    # data (the last pixel's would come from behind the buffer, and NaN x 0 is NaN)
+    arena = torch.full((N * L * K + 4096,), float("nan"), device=cuda).bfloat16()
+    gbuf = arena[:N * L * K].view(N, L, K)
+    gbuf.copy_(torch.cat([d.reshape(N, -1, K) for d in dys], 1).to(cuda).bfloat16())
     gviews = [gbuf.view(-1)[o * K:] for o in offs]
     plain = HF.conv2d_dgrad_ml(gviews, wt, hw, 1, 1, 1, dy_img_stride=L * K, N=N)
     wt_pad = torch.nn.functional.pad(wt, (0, 128 - K))
@@ -526,6 +530,7 @@ def test_conv_multilevel_dgrad_padded_contraction(cuda, tile):
         HF.call("sod_conv_set_tile256", -1)
     for g, p0, dy, (h, ww) in zip(got, plain, dys, hw):
         ref, _ = onn.conv2d_backward(torch.zeros(N, h, ww, C), w, dy, 1, 1, 1)
+        assert bool(torch.isfinite(g.float()).all())
         _close(g, ref, 2 ** -7, "padded-contraction dgrad")
         assert (g.float() - p0.float()).abs().max() <= 2 ** -7 * p0.float().abs().max()
     with pytest.raises(Exception):      # the padded width must be a multiple of 64
