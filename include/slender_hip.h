@@ -126,7 +126,7 @@ int sod_conv2d_dgrad_ml_mask(int nlev, const void* const* dy, const void* wt, co
                              int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                              long long dy_img_stride, void* stream);
 /* sod_conv2d_dgrad_ml (stride 1) for dY rows of Kpitch channels contracted as Kp >= Kpitch channels per tap (Kp % 64 == 0): wt_pad is
- * [C][R][S][Kp] with zero columns from Kpitch on.  The 720 class-score channels of RetinaNetHead.cls_score (retina_rotated.py:432-437) run as a
+ * [C][R][S][Kp] with zero columns from Kpitch on; nothing past a pixel's Kpitch channels is ever read (zero fill).  The 720 class-score channels of RetinaNetHead.cls_score (retina_rotated.py:432-437) run as a
  * 768-wide contraction on the linear K loops (256x256 kernel) instead of the per-chunk gather path. */
 int sod_conv2d_dgrad_ml_kpitch(int nlev, const void* const* dy, const void* wt_pad, void* const* dx,
                                int N, const int* H, const int* W, int C, int Kp, int Kpitch, int R, int S, int pad, int dil,

@@ -1450,8 +1450,8 @@ extern "C" int sod_conv2d_dgrad_ml_mask(int nlev, const void* const* dy, const v
 }
 
 // sod_conv2d_dgrad_ml for dY rows of `Kpitch` channels contracted as Kp >= Kpitch channels per tap (Kp a multiple of 64): wt_pad is
-// [C][R][S][Kp] with ZERO columns from Kpitch on, so that the Kp - Kpitch values the K loop reads past a pixel's row (the next pixel's
-// first channels, or zero fill at the end of the buffer) do not contribute.  A contraction that is no multiple of 64 channels per tap
+// [C][R][S][Kp] with zero columns from Kpitch on; the 16-byte chunks of the K loop that lie past a pixel's last channel are requested out
+// of range (zero fill), never read from the next pixel or from behind the buffer.  A contraction that is no multiple of 64 channels per tap
 // (RetinaNet's 720 class scores) otherwise takes the per-chunk gather path of the 128x128 kernel; padded to 768 it runs on the linear K
 // loops, i.e. on the 256x256 kernel for the tower-sized output.  stride 1 only.
 extern "C" int sod_conv2d_dgrad_ml_kpitch(int nlev, const void* const* dy, const void* wt_pad, void* const* dx,
