@@ -133,9 +133,11 @@ int sod_conv2d_dgrad_ml_kpitch(int nlev, const void* const* dy, const void* wt_p
                                long long dy_img_stride, void* stream);
 /* sod_conv2d_dgrad_ml + accum[l] (bf16, dx[l]'s shape) added in the epilogue: the second of two consumers of the same tensors (the two
  * towers of FCOSHead read the same FPN outputs, fcosv2.py:342-361) leaves the SUM of both data gradients - autograd's accumulation pass
- * (read 2, write 1 per level) is not launched. */
-int sod_conv2d_dgrad_ml_accum(int nlev, const void* const* dy, const void* wt, const void* const* accum, void* const* dx,
-                              int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+ * (read 2, write 1 per level) is not launched.  relu_mask (NULL or one post-ReLU tensor per level): the ReLU backward of the tensor the sum
+ * is the gradient of, applied after the addition - StandardRPNHead (d2, the reference's RRPN configs): hidden = relu(conv(x)) feeds the
+ * objectness and the anchor-delta convs. */
+int sod_conv2d_dgrad_ml_accum(int nlev, const void* const* dy, const void* wt, const void* const* accum, const void* const* relu_mask,
+                              void* const* dx, int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                               long long dy_img_stride, void* stream);
 int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, float* dw, const float* qscale,
                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,

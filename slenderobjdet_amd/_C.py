@@ -33,7 +33,7 @@ _SIGS = {
     "sod_conv2d_dgrad_ml": [_I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "sod_conv2d_dgrad_ml_mask": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "sod_conv2d_dgrad_ml_kpitch": [_I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
-    "sod_conv2d_dgrad_ml_accum": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
+    "sod_conv2d_dgrad_ml_accum": [_I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "sod_conv2d_dgrad_ml_gnbwd": [_I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "sod_groupnorm_bwd_apply_ml": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
     "sod_conv2d_wgrad_ml": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P, _L, _P],

@@ -1473,9 +1473,11 @@ extern "C" int sod_conv2d_dgrad_ml_kpitch(int nlev, const void* const* dy, const
 }
 
 // sod_conv2d_dgrad_ml whose epilogue adds accum[l] (bf16, dx[l]'s shape) to level l's result: the SECOND of two consumers of the same
-// tensors (the two FCOS towers read the same FPN outputs, fcosv2.py:342-361) leaves the sum of both data gradients in one pass.
-extern "C" int sod_conv2d_dgrad_ml_accum(int nlev, const void* const* dy, const void* wt, const void* const* accum, void* const* dx,
-                                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
+// tensors (the two FCOS towers read the same FPN outputs, fcosv2.py:342-361; the objectness and anchor-delta convs of the RPN head read the
+// same hidden tensor) leaves the sum of both data gradients in one pass; relu_mask (optional, per level): the post-ReLU tensors the sum is
+// the gradient of - the ReLU backward is applied after the addition (dX = mask > 0 ? dX + accum : 0).
+extern "C" int sod_conv2d_dgrad_ml_accum(int nlev, const void* const* dy, const void* wt, const void* const* accum, const void* const* relu_mask,
+                                         void* const* dx, int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                                          long long dy_img_stride, void* stream) {
   if (!dy || !wt || !dx || !accum || !H || !W) return SOD_EARG;
   ConvArgs a{};
@@ -1488,8 +1490,12 @@ extern "C" int sod_conv2d_dgrad_ml_accum(int nlev, const void* const* dy, const 
     if (rc) return rc;
     a.lev[l].res = accum[l];
     a.lev[l].res_img_stride = a.lev[l].dst_img_stride;
+    if (relu_mask) {
+      if (!relu_mask[l]) return SOD_EARG;
+      a.lev[l].mask = relu_mask[l];
+    }
   }
-  a.w = wt; a.bias = nullptr; a.flags = F_RES;
+  a.w = wt; a.bias = nullptr; a.flags = F_RES | (relu_mask ? F_MASK : 0);
   return dispatch_conv<MODE_DGRAD, false>(a, (hipStream_t)stream);
 }
 

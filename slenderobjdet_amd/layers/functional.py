@@ -414,7 +414,8 @@ def conv_gn_fwd_ml(xs, w, bias, gamma, beta, G, eps=1e-5, relu=True, pad=1, afte
 def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=None, k_real=None, relu_masks=None, accums=None, k_pitch=None):
     """dys: per-level dY tensors (or 1-D views into a concatenated buffer with dy_img_stride); returns per-level dX.  ``relu_masks``:
     the post-ReLU tensors dX is the gradient of - the ReLU backward is then applied in the epilogue (dX = mask > 0 ? dX : 0).
-    ``accums``: per-level bf16 tensors of dX's shapes added in the epilogue (another consumer's gradient of the same tensors).
+    ``accums``: per-level bf16 tensors of dX's shapes added in the epilogue (another consumer's gradient of the same tensors); with
+    ``relu_masks`` as well the mask applies to the sum.
     ``k_pitch``: the dY rows hold k_pitch channels and ``wt`` is (C, R, S, Kp) with Kp >= k_pitch a multiple of 64 and ZERO columns from
     k_pitch on (sod_conv2d_dgrad_ml_kpitch: the linear K loops for contractions that are no multiple of 64 channels per tap)."""
     _chk(wt, torch.bfloat16, "wt")
@@ -430,14 +431,14 @@ def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=N
         call("sod_conv2d_dgrad_ml_kpitch", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]),
              _int_arr([w for _, w in x_hws]), C, K, int(k_pitch), R, S, pad, dil, dy_img_stride, stream_ptr())
     elif accums is not None:
-        if relu_masks is not None or len(accums) != len(outs):
-            raise _C.SlenderHipError("conv2d_dgrad_ml: accums come one per level and without relu_masks")
-        for t, o in zip(accums, outs):
-            _chk(t, torch.bfloat16, "accum")
+        if len(accums) != len(outs) or (relu_masks is not None and len(relu_masks) != len(outs)):
+            raise _C.SlenderHipError("conv2d_dgrad_ml: accums (and relu_masks) come one per level")
+        for t, o in zip(list(accums) + list(relu_masks or ()), list(outs) * 2):
+            _chk(t, torch.bfloat16, "accum / relu_mask")
             if tuple(t.shape) != tuple(o.shape) or not t.is_contiguous():
-                raise _C.SlenderHipError("conv2d_dgrad_ml: accums must be contiguous tensors of the data gradients' shapes")
-        call("sod_conv2d_dgrad_ml_accum", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(accums), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]),
-             _int_arr([w for _, w in x_hws]), C, K, R, S, stride, pad, dil, dy_img_stride, stream_ptr())
+                raise _C.SlenderHipError("conv2d_dgrad_ml: accums / relu_masks must be contiguous tensors of the data gradients' shapes")
+        call("sod_conv2d_dgrad_ml_accum", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(accums), _ptr_arr(relu_masks) if relu_masks is not None else None,
+             _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]), _int_arr([w for _, w in x_hws]), C, K, R, S, stride, pad, dil, dy_img_stride, stream_ptr())
     elif relu_masks is not None:
         for t, o in zip(relu_masks, outs):
             _chk(t, torch.bfloat16, "relu_mask")

@@ -12,12 +12,14 @@ IoU + Matcher kernel (axis-aligned or rotated) that never builds the G x A matri
 that also lists the drawn anchors, and both losses run over the rows of those <= 256 anchors per image only (gathered from the head
 outputs, gradients scattered back): nothing of the size (N, 1.6 M anchors) is built beyond the int8 labels and the int32 matches.
 """
+import os
+
 import torch
 from torch import nn
 from torch.autograd.function import once_differentiable
 
 from ...layers import functional as HF
-from ...layers.nn import ConvML
+from ...layers.nn import ConvML, _arena_of
 from ...structures import Boxes, Instances, RotatedBoxes
 from ...utils.registry import Registry
 from ..anchor_generator import build_anchor_generator
@@ -49,8 +51,93 @@ class StandardRPNHead(nn.Module):
             self.anchor_deltas.conv.weight[num_anchors * box_dim:].zero_()
 
     def forward(self, features):
+        if RPN_HEAD_FUSED and not HF.is_f32() and features[0].is_cuda:
+            for m in (self.conv, self.objectness_logits, self.anchor_deltas):
+                m.conv.prepare()
+            outs = _RpnHeadFn.apply(self.conv.conv.weight, self, *features)
+            nl = len(features)
+            return list(outs[:nl]), list(outs[nl:])
         t = self.conv(features)
         return self.objectness_logits(t), self.anchor_deltas(t)      # per level (N,H,W,obj_pad) / (N,H,W,delta_pad) fp32
+
+
+# SOD_RPN_HEAD_FUSED=0: the three convolutions of the RPN head as three autograd nodes (autograd then adds the two data gradients of the hidden
+# tensor per level and the hidden conv applies its ReLU mask in a pass of its own)
+RPN_HEAD_FUSED = os.environ.get("SOD_RPN_HEAD_FUSED", "1") != "0"
+
+
+class _RpnHeadFn(torch.autograd.Function):
+    """StandardRPNHead as ONE autograd node: hidden = relu(conv3x3(x)); objectness = conv1x1(hidden); deltas = conv1x1(hidden), every conv one
+    multi-level launch (the levels share the weights).  Backward: the anchor-delta conv's data gradient adds the objectness conv's in its
+    epilogue and applies hidden's ReLU mask to the sum (sod_conv2d_dgrad_ml_accum with a mask) - instead of autograd's per-level add
+    (read 2, write 1) and a relu_bwd pass (read 2, write 1) over the 256-channel hidden tensor of every level (P2: 550 MB each)."""
+
+    @staticmethod
+    def forward(ctx, weight, head, *xs):
+        c3, co, cd = head.conv.conv, head.objectness_logits.conv, head.anchor_deltas.conv
+        hid = HF.conv2d_fwd_ml(list(xs), c3.w_bf16, c3.bias_eff, 1, c3.padding, 1, relu=True)
+        obj = HF.conv2d_fwd_ml(hid, co.w_bf16, co.bias_eff, 1, 0, 1, out_f32=True)
+        dlt = HF.conv2d_fwd_ml(hid, cd.w_bf16, cd.bias_eff, 1, 0, 1, out_f32=True)
+        ctx.head, ctx.nl = head, len(xs)
+        ctx.save_for_backward(*xs, *hid)
+        arena = _arena_of(c3)
+        if arena is not None and c3.weight.requires_grad:
+            for m in (c3, co, cd):
+                arena.note_use(m.weight)
+                arena.note_use(m.bias)
+        return (*obj, *dlt)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        head, nl = ctx.head, ctx.nl
+        c3, co, cd = head.conv.conv, head.objectness_logits.conv, head.anchor_deltas.conv
+        saved = ctx.saved_tensors
+        xs, hid = list(saved[:nl]), list(saved[nl:])
+        arena = _arena_of(c3)
+        hw = [(h.shape[1], h.shape[2]) for h in hid]
+
+        def bf16(ts, like):      # a missing gradient (an output nobody differentiated) is a zero tensor
+            out = []
+            for t, ref in zip(ts, like):
+                if t is None:
+                    out.append(None)
+                else:
+                    t = t.contiguous()
+                    out.append(HF.f32_to_bf16(t) if t.dtype == torch.float32 else t)
+            return out
+
+        g_obj, g_dlt = bf16(gs[:nl], hid), bf16(gs[nl:], hid)
+        have_dlt = any(t is not None for t in g_dlt)
+        dh, masked = None, False
+        for conv, g in ((co, g_obj), (cd, g_dlt)):
+            if all(t is None for t in g):
+                arena.mark_ready(conv.weight); arena.mark_ready(conv.bias)
+                continue
+            g = [t if t is not None else torch.zeros((h.shape[0], h.shape[1], h.shape[2], conv.out_channels), dtype=h.dtype, device=h.device)
+                 for t, h in zip(g, hid)]
+            HF.conv2d_wgrad_ml(g, hid, arena.grad_view(conv.weight), 1, 1, 1, 0, 1)
+            arena.mark_ready(conv.weight)
+            HF.bias_grad_ml(g, arena.grad_view(conv.bias))
+            arena.mark_ready(conv.bias)
+            if dh is None and conv is co and have_dlt:
+                dh = HF.conv2d_dgrad_ml(g, conv.wt_bf16, hw, 1, 0, 1)                       # plain: the delta conv's launch carries the mask
+            elif dh is None:
+                dh, masked = HF.conv2d_dgrad_ml(g, conv.wt_bf16, hw, 1, 0, 1, relu_masks=hid), True
+            else:
+                dh, masked = HF.conv2d_dgrad_ml(g, conv.wt_bf16, hw, 1, 0, 1, accums=dh, relu_masks=hid), True
+        if dh is None:
+            arena.mark_ready(c3.weight); arena.mark_ready(c3.bias)
+            return (None, None, *([None] * nl))
+        assert masked
+        HF.conv2d_wgrad_ml(dh, xs, arena.grad_view(c3.weight), 3, 3, 1, c3.padding, 1)
+        arena.mark_ready(c3.weight)
+        HF.bias_grad_ml(dh, arena.grad_view(c3.bias))
+        arena.mark_ready(c3.bias)
+        dxs = [None] * nl
+        if any(ctx.needs_input_grad[2:]):
+            dxs = HF.conv2d_dgrad_ml(dh, c3.wt_bf16, [(x.shape[1], x.shape[2]) for x in xs], 1, c3.padding, 1)
+        return (None, None, *dxs)
 
 
 class _RpnLossFn(torch.autograd.Function):

@@ -195,6 +195,67 @@ def test_device_label_sampling_contract(cuda):
     assert float((freq - 0.25).abs().max()) < 0.08, freq
 
 
+def test_rpn_head_as_one_node_equals_the_three_conv_nodes(cuda):
+    """StandardRPNHead as one autograd node (_RpnHeadFn: the anchor-delta conv's data gradient adds the objectness conv's in its epilogue and
+    applies the hidden tensor's ReLU mask to the sum) against the three ConvML nodes with autograd's add and a relu_bwd pass: same outputs
+    bit for bit, parameter gradients equal up to ONE bf16 rounding of the hidden gradient instead of two (deterministic mode), feature
+    gradients likewise; a graph that differentiates only one of the two outputs still gets the mask."""
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.modeling.proposal_generator import rpn as RPN
+
+    prev_det, keep = HF.DETERMINISTIC, RPN.RPN_HEAD_FUSED
+    HF.DETERMINISTIC = True
+    try:
+        cfg = _cfg(True)
+        torch.manual_seed(0)
+        model = build_model(cfg)
+        model.train()
+        head = model.proposal_generator.head
+        arena = model.arena
+        g = torch.Generator().manual_seed(3)
+        feats0 = [(torch.randn(2, h, w, 256, generator=g) * 0.5).to(cuda).bfloat16() for h, w in ((24, 32), (12, 16), (6, 8), (3, 4), (2, 2))]
+
+        def run(fused, which):
+            RPN.RPN_HEAD_FUSED = fused
+            arena.zero_grad()
+            feats = [f.clone().requires_grad_(True) for f in feats0]
+            obj, dlt = head(feats)
+            w_o = [torch.randn(o.shape, generator=torch.Generator().manual_seed(10 + i)).to(cuda) for i, o in enumerate(obj)]
+            w_d = [torch.randn(o.shape, generator=torch.Generator().manual_seed(20 + i)).to(cuda) for i, o in enumerate(dlt)]
+            total = 0.0
+            if which in ("both", "obj"):
+                total = total + sum((o * w).sum() for o, w in zip(obj, w_o))
+            if which in ("both", "dlt"):
+                total = total + sum((o * w).sum() for o, w in zip(dlt, w_d))
+            arena.begin_backward(); total.backward(); arena.finish_backward()
+            torch.cuda.synchronize()
+            return [o.detach().clone() for o in obj + dlt], arena.grads.clone(), [f.grad.clone() for f in feats]
+
+        for which in ("both", "obj", "dlt"):
+            ref_o, ref_g, ref_f = run(False, which)
+            got_o, got_g, got_f = run(True, which)
+            for a, b in zip(got_o, ref_o):
+                assert torch.equal(a, b)
+            names = [(n, o, c) for n, o, c in arena.names if n.startswith("proposal_generator.head.")]
+            assert len(names) == 6
+            for name, off, n in names:
+                a, b = got_g[off:off + n], ref_g[off:off + n]
+                if "objectness" in name or "anchor_deltas" in name:
+                    assert torch.equal(a, b), (which, name)              # the two 1x1 convs see the same operands either way
+                else:
+                    d = (a - b).norm().item() / max(b.norm().item(), 1e-12)
+                    assert d <= 1e-2, (which, name, d)
+            for a, b in zip(got_f, ref_f):
+                d = (a.float() - b.float()).norm().item() / max(b.float().norm().item(), 1e-12)
+                assert d <= 1e-2, (which, d)
+            if which != "both":                                        # one consumer only: no addition, bit-identical
+                assert torch.equal(got_g, ref_g)
+    finally:
+        RPN.RPN_HEAD_FUSED = keep
+        HF.DETERMINISTIC = prev_det
+
+
 @pytest.mark.parametrize("rotated", [True, False])
 def test_rcnn_training_step_vs_oracle(cuda, rotated):
     from oracle import rcnn as orc
