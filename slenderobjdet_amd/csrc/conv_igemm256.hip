@@ -36,6 +36,8 @@ constexpr int ROWB = 128;              // bytes per LDS row: 64 bf16 contraction
 constexpr int UNIT = 128 * ROWB;       // 16 KB
 constexpr int BUF = 4 * UNIT;          // one K-tile: [Ua0][Ua1][Ub0][Ub1]
 constexpr int LDS_BYTES = 2 * BUF;     // 128 KB
+constexpr int E16_PITCH = 256;         // bytes per pixel row of the bf16 epilogue tile (128 channels, no padding: 8 waves x 64 rows = exactly the ring's 128 KB -
+                                       // a workgroup that claims more than that loses its co-residents on the CU); 8-byte units XOR-swizzled with 2 * (row & 15)
 
 template <int SA, int SB, int KS>
 __device__ __forceinline__ void mma_half(f32x4_t (&acc)[8][4], const bf16x8_t (&af)[4][2], const bf16x8_t (&bf)[2][2]) {
@@ -266,6 +268,62 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
   GnAcc ga{0.f, 0.f, -1};
   GnBwdAcc gb;
   if constexpr (GNB) gnb_init(gb, a.gnb_gamma, a.gnb_beta, q, qok);
+  // ---- bf16 whole-tile path (round 4): without a residual operand, bias and ReLU commute with the layout change, so they are applied in
+  // the ACCUMULATOR layout and the wave's whole 64-pixel x 128-channel tile goes through LDS once as bf16 (16 KB per wave: 32 8-byte writes,
+  // one wait, 16 16-byte reads, one wait) instead of four fp32 passes of 16 pixel rows with a write -> wait -> read -> wait chain each: the
+  // epilogue of a tile is a latency chain on two waves per SIMD, not a bandwidth problem.  Same values bit for bit (one rounding either way).
+  if constexpr (!OUT_F32 && !GNB) {
+    if (!(a.flags & (F_RES | F_RES_UP2))) {
+      char* w16 = smem + wave * (64 * E16_PITCH);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f32x4_t b4 = {0.f, 0.f, 0.f, 0.f};
+        const int qa = q0 + wr * QW + i * 16 + fg * 4;
+        if ((a.flags & F_BIAS) && qa < Nout) b4 = *reinterpret_cast<const f32x4_t*>(a.bias + qa);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          f32x4_t v = acc[i][jj] + b4;
+          if (a.flags & F_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          bf16x4_t o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          // 8-byte unit i*4+fg of row jj*16+fr, swizzled: the 32 lanes of a half wave (16 rows x 2 units) hit 32 distinct units = 64 banks
+          *reinterpret_cast<bf16x4_t*>(w16 + (jj * 16 + fr) * E16_PITCH + (((i * 4 + fg) ^ (2 * fr)) << 3)) = o;
+        }
+      }
+      // (wave-private region: the compiler's lgkmcnt wait between the writes above and the reads below is the only ordering needed)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const uint32_t pfirst = (uint32_t)(p0 + wc * 64 + jj * 16 + erow);
+        const uint32_t pc0 = pfirst < (uint32_t)gP ? pfirst : 0u;
+        uint32_t n_run = fd_div(pc0, g.div_hw);
+        uint32_t rem_run = pc0 - n_run * g.div_hw.d;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const uint32_t p = pfirst + (uint32_t)(k * ERPP);
+          const bool okk = (p < (uint32_t)gP) && qok;
+          const uint32_t n = n_run, rem = rem_run;
+          rem_run += (uint32_t)ERPP;
+          while (rem_run >= g.div_hw.d) { rem_run -= g.div_hw.d; ++n_run; }
+          if (okk) {
+            const size_t drow = (size_t)n * g.dst_img_stride + (size_t)rem * Nout;
+            // (an even XOR keeps the two 8-byte units of a lane's 16 bytes adjacent: one ds_read_b128, the 16 lanes of a row permuted)
+            bf16x8_t o = *reinterpret_cast<const bf16x8_t*>(w16 + (jj * 16 + k * ERPP + erow) * E16_PITCH + (((eq >> 3) ^ (k * ERPP + erow)) << 4));
+            if (a.flags & F_MASK) {
+              const bf16x8_t mv = *reinterpret_cast<const bf16x8_t*>((const __bf16*)g.mask + drow + q);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = ((float)mv[e] > 0.f) ? o[e] : (__bf16)0.f;
+            }
+            sod_store16((__bf16*)g.dst + drow + q, o);
+            if constexpr (MODE == MODE_FWD) { if (a.flags & F_GNSTATS) gn_acc_add(ga, (int)n, o, g.gn_sum, a.gn_G, q >> 3); }
+          }
+        }
+      }
+      if constexpr (MODE == MODE_FWD) {
+        if (a.flags & F_GNSTATS)
+          gn_acc_finish<LPR>(ga, (uint32_t)(p0 + wc * 64), (uint32_t)(p0 + wc * 64 + 63), (uint32_t)gP, g.div_hw, g.gn_sum, a.gn_G, q >> 3, qok, lane);
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int jj = 0; jj < 4; ++jj) {
     // residual / mask operands of the 16 pixel rows are requested before the accumulators go through LDS (one exposed latency)
