@@ -216,6 +216,10 @@ int sod_add_bf16(const void* a, const void* b, void* out, long long n, void* str
 int sod_add_up2_bf16(const void* a, const void* b, void* out, int N, int H, int W, int C, void* stream);
 /* dbias[c] += sum over (n, pixel) of dy — bias gradient of nn.Conv2d(bias=True) */
 int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C, long long img_stride, float* det_ws, long long det_ws_bytes, void* stream);
+/* dbias[c] += s * sum over (n, pixel) of dy, s = scale_num[0] / max(scale_den[0] * den_mul, den_min) read on the device (either pointer may
+ * be NULL = 1): the bias gradient of a conv whose output gradient is stored un-scaled (sod_sigmoid_focal_loss_fwd_grad). */
+int sod_bias_grad_scaled(const void* dy, float* dbias, const float* scale_num, const float* scale_den, float den_mul, float den_min,
+                         int N, int HW, int C, long long img_stride, float* det_ws, long long det_ws_bytes, void* stream);
 /* d2 BasicStem: F.max_pool2d(x, kernel_size=3, stride=2, padding=1) */
 /* sod_bias_grad over several dense (N, hw[l], C) bf16 tensors that share the bias (a conv applied to all FPN levels): one launch,
  * dbias[c] += sum over levels, images and pixels (float atomics). */
@@ -309,6 +313,12 @@ int sod_sigmoid_focal_loss_fwd(const float* logits, const int* labels, const flo
                                long long M, int K, int ld, float alpha, float gamma, float* elem_out,
                                float* sum_out, float* ws, void* stream);
 /* dlogits = dloss/dlogits * scale_num[0] / max(scale_den[0]*den_mul, den_min); rows of pitch ld_out, columns >= K zeroed */
+/* Forward sum and the UN-scaled gradient d(sum)/d(logits) (bf16 rows of ld_out >= K elements, padding columns zero) in one pass over the
+ * logits; class-index labels only (label < 0 = ignored row), K, ld, ld_out multiples of 4.  The training step's backward differs from this
+ * gradient by one scalar (upstream gradient / loss normaliser): the consumers of the gradient apply it - the data gradient through scaled
+ * weights, the weight gradient through its per-output-channel factor, the bias gradient through sod_bias_grad_scaled. */
+int sod_sigmoid_focal_loss_fwd_grad(const float* logits, const int* labels, long long M, int K, int ld, float alpha, float gamma,
+                                    float* sum_out, float* ws, void* dlogits_bf16, int ld_out, void* stream);
 int sod_sigmoid_focal_loss_bwd(const float* logits, const int* labels, const float* dense_targets,
                                long long M, int K, int ld, float alpha, float gamma,
                                const float* scale_num, const float* scale_den, float den_mul, float den_min,

@@ -46,6 +46,7 @@ _SIGS = {
     "sod_add_bf16": [_P, _P, _P, _L, _P],
     "sod_add_up2_bf16": [_P, _P, _P, _I, _I, _I, _I, _P],
     "sod_bias_grad": [_P, _P, _I, _I, _I, _L, _P, _L, _P],
+    "sod_bias_grad_scaled": [_P, _P, _P, _P, _F, _F, _I, _I, _I, _L, _P, _L, _P],
     "sod_bias_grad_ml": [_I, _P, _P, _I, _P, _I, _P],
     "sod_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
     "sod_upsample2x_bwd": [_P, _P, _I, _I, _I, _I, _P],
@@ -70,6 +71,7 @@ _SIGS = {
     "sod_bottleneck_frozen_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "sod_resize_flip_preprocess_batch": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "sod_sigmoid_focal_loss_fwd": [_P, _P, _P, _L, _I, _I, _F, _F, _P, _P, _P, _P],
+    "sod_sigmoid_focal_loss_fwd_grad": [_P, _P, _L, _I, _I, _F, _F, _P, _P, _P, _I, _P],
     "sod_sigmoid_focal_loss_bwd": [_P, _P, _P, _L, _I, _I, _F, _F, _P, _P, _F, _F, _P, _I, _I, _P],
     "sod_iou_loss_fwd": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P],
     "sod_iou_loss_bwd": [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P],

@@ -129,6 +129,45 @@ __global__ __launch_bounds__(256) void focal_fwd_vec4_kernel(const float* __rest
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
+// Forward sum AND the un-scaled gradient in one pass over the logits (round 4): the loss term and its derivative share the sigmoid, the
+// softplus, ce, p_t and the modulating factor, and the backward pass of the training step only differs from this gradient by ONE scalar
+// (upstream gradient / normaliser), which the consumers apply (scaled weights in the data gradient, a per-channel factor in the weight
+// gradient, a scalar in the bias gradient).  The 1 GB fp32 logits of RetinaNet are read once per step instead of twice.
+__global__ __launch_bounds__(256) void focal_fwd_grad_vec4_kernel(const float* __restrict__ x, const int* __restrict__ labels, uint32_t total4,
+                                                                  FastDiv div_k4, int K, int ld, float alpha, float gamma,
+                                                                  float* __restrict__ part, __bf16* __restrict__ dx, int ld_out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
+    const uint32_t m = fd_div(i, div_k4);
+    const int k = (int)(i - m * div_k4.d) * 4;       // column of the (padded) gradient row
+    f32x4_t gv = {0.f, 0.f, 0.f, 0.f};
+    if (k < K) {
+      const int lab = labels[m];
+      if (lab >= 0) {
+        const f32x4_t xv = *reinterpret_cast<const f32x4_t*>(x + (size_t)m * ld + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = (lab == k + e) ? 1.f : 0.f;
+          float p, sp;
+          sigmoid_softplus(xv[e], p, sp);
+          const float ce = fmaxf(xv[e], 0.f) - xv[e] * t + sp;
+          const float pt = p * t + (1.f - p) * (1.f - t);
+          const float om = 1.f - pt;
+          const float mod = (gamma == 2.f) ? om * om : powf(om, gamma);
+          const float at = (alpha >= 0.f) ? alpha * t + (1.f - alpha) * (1.f - t) : 1.f;
+          acc += ce * mod * at;                                                   // focal_term
+          gv[e] = -(2.f * t - 1.f) * mod * (gamma * pt * ce + om) * at;           // focal_grad
+        }
+      }
+    }
+    bf16x4_t o = {(__bf16)gv[0], (__bf16)gv[1], (__bf16)gv[2], (__bf16)gv[3]};
+    *reinterpret_cast<bf16x4_t*>(dx + (size_t)m * ld_out + k) = o;
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void focal_bwd_vec4_kernel(const float* __restrict__ x, const int* __restrict__ labels, uint32_t total4,
                                                              FastDiv div_k4, int K, int ld, float alpha, float gamma,
@@ -481,6 +520,21 @@ extern "C" int sod_sigmoid_focal_loss_fwd(const float* logits, const int* labels
                gamma, elem_out, K, ws);
   else
     SOD_LAUNCH(focal_fwd_kernel, dim3(g), dim3(256), 0, st, logits, labels, dense_targets, M, K, ld, alpha, gamma, elem_out, ws);
+  SOD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, g, 1, sum_out, 0);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
+
+extern "C" int sod_sigmoid_focal_loss_fwd_grad(const float* logits, const int* labels, long long M, int K, int ld, float alpha, float gamma,
+                                               float* sum_out, float* ws, void* dlogits_bf16, int ld_out, void* stream) {
+  if (!logits || !labels || !sum_out || !ws || !dlogits_bf16 || M < 0 || K <= 0 || ld < K || ld_out < K) return SOD_EARG;
+  if ((K & 3) || (ld & 3) || (ld_out & 3) || M * (long long)ld_out >= (1ll << 31) || ((uintptr_t)logits & 15) || ((uintptr_t)dlogits_bf16 & 7))
+    return SOD_EARG;      // the vectorised form only (class-index labels, 4 classes per lane): callers fall back to the two-pass entry points
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t total4 = (uint32_t)(M * ld_out / 4);
+  const int g = grid_for(M * ld_out / 4);
+  SOD_LAUNCH(focal_fwd_grad_vec4_kernel, dim3(g), dim3(256), 0, st, logits, labels, total4, make_fastdiv((uint32_t)(ld_out / 4)), K, ld, alpha, gamma,
+             ws, (__bf16*)dlogits_bf16, ld_out);
   SOD_LAUNCH(finish_sum_kernel, dim3(1), dim3(256), 0, st, ws, g, 1, sum_out, 0);
   SOD_CHECK_LAUNCH();
   return SOD_OK;

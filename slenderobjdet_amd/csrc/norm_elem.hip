@@ -357,7 +357,9 @@ __global__ __launch_bounds__(256) void add_up2_kernel(const __bf16* __restrict__
 
 // bias gradient: db[c] += sum over rows of dy[row][c]; dy rows may be strided per image
 __global__ __launch_bounds__(256) void channel_sum_kernel(const __bf16* __restrict__ dy, float* __restrict__ db,
-                                                          int HW, int C, long long img_stride, int pix_per_block, float* __restrict__ part) {
+                                                          int HW, int C, long long img_stride, int pix_per_block, float* __restrict__ part,
+                                                          const float* __restrict__ scale_num, const float* __restrict__ scale_den,
+                                                          float den_mul, float den_min) {
   extern __shared__ float lsum[];   // [256][8] per-thread partials
   const int n = blockIdx.y;
   const int c8n = C >> 3;
@@ -387,9 +389,12 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const __bf16* __restri
     for (int e = 0; e < 8; ++e) lsum[threadIdx.x * 8 + e] = s[e];      // plain stores, not ds_add_f32 (see gn_stats_body)
   }
   __syncthreads();
+  float sc = scale_num ? scale_num[0] : 1.f;      // sod_bias_grad_scaled: dy is an UN-scaled gradient (sod_sigmoid_focal_loss_fwd_grad)
+  if (scale_den) sc /= fmaxf(scale_den[0] * den_mul, den_min);
   for (int i = threadIdx.x; i < C; i += 256) {
     float t = 0.f;
     for (int r = 0; r < rows_per_iter; ++r) t += lsum[(r * c8n + (i >> 3)) * 8 + (i & 7)];
+    t *= sc;
     if (part) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * C + i] = t;      // deterministic mode: col_accumulate_kernel adds the rows
     else atomicAdd(db + i, t);
   }
@@ -1020,8 +1025,16 @@ extern "C" int sod_add_up2_bf16(const void* a, const void* b, void* out, int N, 
   return SOD_OK;
 }
 
+extern "C" int sod_bias_grad_scaled(const void* dy, float* dbias, const float* scale_num, const float* scale_den, float den_mul, float den_min,
+                                    int N, int HW, int C, long long img_stride, float* det_ws, long long det_ws_bytes, void* stream);
+
 extern "C" int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C, long long img_stride, float* det_ws, long long det_ws_bytes,
                              void* stream) {
+  return sod_bias_grad_scaled(dy, dbias, nullptr, nullptr, 1.f, 1.f, N, HW, C, img_stride, det_ws, det_ws_bytes, stream);
+}
+
+extern "C" int sod_bias_grad_scaled(const void* dy, float* dbias, const float* scale_num, const float* scale_den, float den_mul, float den_min,
+                                    int N, int HW, int C, long long img_stride, float* det_ws, long long det_ws_bytes, void* stream) {
   if (!dy || !dbias || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || C > 2048) return SOD_EARG;
   if (img_stride <= 0) img_stride = (long long)HW * C;
   const int c8n = C / 8;
@@ -1030,7 +1043,7 @@ extern "C" int sod_bias_grad(const void* dy, float* dbias, int N, int HW, int C,
   const int gx = gn_grid(HW, N, ppb);
   if (det_ws && (long long)gx * N * C * (long long)sizeof(float) > det_ws_bytes) return SOD_EARG;
   SOD_LAUNCH(channel_sum_kernel, dim3(gx, N), dim3(256), sizeof(float) * 8 * 256, (hipStream_t)stream, (const __bf16*)dy, dbias, HW, C, img_stride, ppb,
-             det_ws);
+             det_ws, scale_num, scale_den, den_mul, den_min);
   if (det_ws) SOD_LAUNCH(col_accumulate_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, det_ws, gx * N, C, C, dbias);
   SOD_CHECK_LAUNCH();
   return SOD_OK;

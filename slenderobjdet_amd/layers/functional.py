@@ -599,10 +599,16 @@ def add_bf16(a, b):
     return o
 
 
-def bias_grad(dy, dbias, N, HW, C, img_stride=0):
+def bias_grad(dy, dbias, N, HW, C, img_stride=0, scale_num=None, scale_den=None, den_mul=1.0, den_min=1.0):
+    """dbias += [scale_num / max(scale_den * den_mul, den_min), device scalars] * per-channel sum of dy."""
     _chk(dy, torch.bfloat16, "dy"); _chk(dbias, torch.float32, "dbias")
-    side = _wgrad_stream(dbias.device, (dy,), dbias.data_ptr())      # like the weight gradient: only the optimizer / all-reduce consumes it
-    call("sod_bias_grad", ptr(dy), ptr(dbias), N, HW, C, img_stride, *_det_ws(dbias.device, side), stream_ptr(side))
+    _chk(scale_num, torch.float32, "scale_num"); _chk(scale_den, torch.float32, "scale_den")
+    side = _wgrad_stream(dbias.device, (dy, scale_num, scale_den), dbias.data_ptr())      # like the weight gradient: only the optimizer / all-reduce consumes it
+    if scale_num is None and scale_den is None:
+        call("sod_bias_grad", ptr(dy), ptr(dbias), N, HW, C, img_stride, *_det_ws(dbias.device, side), stream_ptr(side))
+    else:
+        call("sod_bias_grad_scaled", ptr(dy), ptr(dbias), ptr(scale_num), ptr(scale_den), float(den_mul), float(den_min), N, HW, C, img_stride,
+             *_det_ws(dbias.device, side), stream_ptr(side))
     return dbias
 
 
@@ -781,6 +787,22 @@ def focal_loss_fwd(logits, labels=None, dense=None, alpha=0.25, gamma=2.0, K=Non
     call("sod_sigmoid_focal_loss_fwd", ptr(logits), ptr(labels), ptr(dense), M, K, ld, alpha, gamma, ptr(elem), ptr(out),
          ptr(reduce_ws(logits.device)), stream_ptr())
     return out, elem
+
+
+def focal_loss_fwd_grad(logits, labels, alpha=0.25, gamma=2.0, K=None, ld_out=None, out=None):
+    """Forward sum and the UN-scaled bf16 gradient (rows of ld_out elements) in one pass over the logits (sod_sigmoid_focal_loss_fwd_grad).
+    Returns (sum (1,), dlogits); raises SlenderHipError for layouts the vectorised kernel does not take."""
+    _chk(logits, torch.float32, "logits"); _chk(labels, torch.int32, "labels")
+    ld = logits.shape[-1]
+    K = ld if K is None else K
+    M = logits.numel() // ld
+    ld_out = K if ld_out is None else ld_out
+    if out is None:
+        out = torch.empty((M, ld_out), dtype=torch.bfloat16, device=logits.device)
+    s = torch.empty(1, dtype=torch.float32, device=logits.device)
+    call("sod_sigmoid_focal_loss_fwd_grad", ptr(logits), ptr(labels), M, K, ld, alpha, gamma, ptr(s), ptr(reduce_ws(logits.device)), ptr(out), ld_out,
+         stream_ptr())
+    return s, out
 
 
 def focal_loss_bwd(logits, labels=None, dense=None, alpha=0.25, gamma=2.0, K=None, scale_num=None, scale_den=None,

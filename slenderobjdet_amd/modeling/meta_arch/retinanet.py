@@ -32,6 +32,8 @@ def _ceil8(v):
 
 # SOD_PRED_DGRAD_PAD=0: the data gradient of the class-score conv on the per-chunk gather path (its 720 channels are no multiple of 64)
 PRED_DGRAD_PAD = os.environ.get("SOD_PRED_DGRAD_PAD", "1") != "0"
+# SOD_FOCAL_FUSED=0: the focal loss as a forward pass (sum) and a backward pass (scaled gradient) over the fp32 logits - 1 GB each at batch 16
+FOCAL_FUSED = os.environ.get("SOD_FOCAL_FUSED", "1") != "0"
 
 class RetinaNetHead(nn.Module):
     def __init__(self, cfg, in_channels, num_anchors):
@@ -102,10 +104,15 @@ class _RetinaLossFn(torch.autograd.Function):
         else:
             sums = HF.retina_box_loss_fwd(box_buf, head.box_pitch, gt_labels, gt_deltas, N, R, A, K, model.smooth_l1_loss_beta,
                                           model.loss_normalizer, model.loss_normalizer_momentum)    # also advances the EMA normaliser
-        focal_sum, _ = HF.focal_loss_fwd(cls_buf.view(N * R, K), gt_labels.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma)
+        dcls_u = None
+        if FOCAL_FUSED and not HF.is_f32() and any(ctx.needs_input_grad[4:]):      # a backward pass follows
+            focal_sum, dcls_u = HF.focal_loss_fwd_grad(cls_buf.view(N * R, K), gt_labels.view(-1), model.focal_loss_alpha, model.focal_loss_gamma)
+        else:
+            focal_sum, _ = HF.focal_loss_fwd(cls_buf.view(N * R, K), gt_labels.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma)
         out = torch.stack([focal_sum[0], sums[0]]) / model.loss_normalizer
         ctx.model, ctx.geo = model, (hw, offs, N, P, A, K, R)
-        ctx.save_for_backward(cls_buf, box_buf, gt_labels, gt_deltas, model.loss_normalizer.clone(), *towers)
+        ctx.fused = dcls_u is not None
+        ctx.save_for_backward(cls_buf if dcls_u is None else dcls_u, box_buf, gt_labels, gt_deltas, model.loss_normalizer.clone(), *towers)
         arena = _arena_of(head)
         if arena is not None:
             for p in (head.cls_score.weight, head.cls_score.bias, head.bbox_pred.weight, head.bbox_pred.bias):
@@ -125,8 +132,14 @@ class _RetinaLossFn(torch.autograd.Function):
         g2 = g2.contiguous().float()
         arena = _arena_of(head)
         dev = cls_buf.device
-        dcls = HF.focal_loss_bwd(cls_buf.view(N * R, K), gt_labels.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma,
-                                 scale_num=g2[0:1], scale_den=norm, den_mul=1.0, den_min=1e-12, out_bf16=not HF.is_f32()).view(N, P, head.kc)
+        if ctx.fused:
+            # the forward pass already wrote the un-scaled class-score gradient (sod_sigmoid_focal_loss_fwd_grad); what is left of the
+            # backward pass is the scalar g / normaliser, applied by the three consumers below
+            dcls, cls_scale = cls_buf.view(N, P, head.kc), (g2[0:1].contiguous(), norm)
+        else:
+            dcls, cls_scale = HF.focal_loss_bwd(cls_buf.view(N * R, K), gt_labels.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma,
+                                                scale_num=g2[0:1], scale_den=norm, den_mul=1.0, den_min=1e-12,
+                                                out_bf16=not HF.is_f32()).view(N, P, head.kc), None
         dbox = torch.zeros((N, P, head.box_pitch), dtype=HF.ACT_DTYPE, device=dev)
         if model.box_reg_loss_type == "giou":
             HF.retina_giou_loss_bwd(box_buf, head.box_pitch, gt_labels, model.anchors_for(hw), gt_deltas, N, R, A, K, model.bbox_reg_weights,
@@ -134,19 +147,27 @@ class _RetinaLossFn(torch.autograd.Function):
         else:
             HF.retina_box_loss_bwd(box_buf, head.box_pitch, gt_labels, gt_deltas, N, R, A, K, model.smooth_l1_loss_beta, g2[1:2], norm, dbox)
         grads = []
-        for pred, dbuf, kk, tower in ((head.cls_score, dcls, head.kc, cls_t), (head.bbox_pred, dbox, head.box_pitch, box_t)):
+        for pred, dbuf, kk, tower, scale in ((head.cls_score, dcls, head.kc, cls_t, cls_scale), (head.bbox_pred, dbox, head.box_pitch, box_t, None)):
             dys = [dbuf.view(-1)[o * kk:] for o in offs]
-            HF.conv2d_wgrad_ml(dys, list(tower), arena.grad_view(pred.weight), 3, 3, 1, 1, 1, dy_img_stride=P * kk, K=kk)
+            wt = pred.wt_bf16
+            if scale is None:
+                HF.conv2d_wgrad_ml(dys, list(tower), arena.grad_view(pred.weight), 3, 3, 1, 1, 1, dy_img_stride=P * kk, K=kk)
+                HF.bias_grad(dbuf, arena.grad_view(pred.bias), N, P, kk)
+            else:
+                qs = (scale[0] / scale[1].clamp_min(1e-12)).expand(kk).contiguous()          # the scalar per output channel, on the device
+                HF.conv2d_wgrad_ml(dys, list(tower), arena.grad_view(pred.weight), 3, 3, 1, 1, 1, dy_img_stride=P * kk, K=kk, qscale=qs)
+                HF.bias_grad(dbuf, arena.grad_view(pred.bias), N, P, kk, scale_num=scale[0], scale_den=scale[1], den_mul=1.0, den_min=1e-12)
+                # the data gradient is linear in the weights: (w * s) rounded to bf16 once, from the fp32 master, as the ordinary copy is
+                _, wt = HF.weight_prep(pred.weight.detach().contiguous(), qs, want_krsc=False)
             arena.mark_ready(pred.weight)
-            HF.bias_grad(dbuf, arena.grad_view(pred.bias), N, P, kk)
             arena.mark_ready(pred.bias)
             if PRED_DGRAD_PAD and not HF.is_f32() and kk % 64 and kk >= 256:
                 # 720 class scores: contract over a 768-wide zero-padded copy of the transposed weights on the linear K loops (the 256x256
                 # kernel) instead of the per-chunk gather path of the 128x128 kernel (sod_conv2d_dgrad_ml_kpitch)
-                wt_pad = torch.nn.functional.pad(pred.wt_bf16, (0, (kk + 63) // 64 * 64 - kk))
+                wt_pad = torch.nn.functional.pad(wt, (0, (kk + 63) // 64 * 64 - kk))
                 grads.append(HF.conv2d_dgrad_ml(dys, wt_pad, hw, 1, 1, 1, dy_img_stride=P * kk, N=N, k_pitch=kk))
             else:
-                grads.append(HF.conv2d_dgrad_ml(dys, pred.wt_bf16, hw, 1, 1, 1, dy_img_stride=P * kk, N=N))
+                grads.append(HF.conv2d_dgrad_ml(dys, wt, hw, 1, 1, 1, dy_img_stride=P * kk, N=N))
         return (None, None, None, None, *grads[0], *grads[1])
 
 

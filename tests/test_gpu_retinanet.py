@@ -339,6 +339,71 @@ def test_retinanet_r50_full_size_step(cuda):
     assert l0 == l0 and abs(l0) < 1e6
 
 
+def test_focal_loss_forward_with_gradient_in_one_pass(cuda):
+    """sod_sigmoid_focal_loss_fwd_grad (the loss sum and the un-scaled gradient from one pass over the logits) against the two-pass entry
+    points at op level, and in the RetinaNet step: same losses bit for bit, every gradient within bf16 rounding of the two-pass step
+    (the scalar g / normaliser moves from the gradient rows into the consumers: scaled weights in the data gradient, a per-channel factor
+    in the weight gradient, a scalar in the bias gradient)."""
+    from bench import make_cfg
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.modeling.meta_arch import retinanet as RN
+    from slenderobjdet_amd.solver import build_optimizer
+
+    g = torch.Generator().manual_seed(5)
+    M, K = 3000, 80
+    logits = (torch.randn(M, K, generator=g) * 3).to(cuda)
+    labels = torch.randint(-1, K + 1, (M,), generator=g, dtype=torch.int32).to(cuda)          # -1 ignored, K background
+    s_ref, _ = HF.focal_loss_fwd(logits, labels, None, 0.25, 2.0)
+    g_ref = HF.focal_loss_bwd(logits, labels, None, 0.25, 2.0, out_bf16=True)
+    s_got, g_got = HF.focal_loss_fwd_grad(logits, labels, 0.25, 2.0)
+    assert abs(float(s_got) - float(s_ref)) <= 1e-6 * abs(float(s_ref))
+    assert torch.equal(g_got, g_ref)                                                          # same arithmetic, scale 1
+    s2, g2 = HF.focal_loss_fwd_grad(logits, labels, 0.25, 2.0, ld_out=K + 8)                   # padded gradient rows: zeros in the pad
+    assert torch.equal(g2[:, :K], g_ref) and float(g2[:, K:].float().abs().max()) == 0.0
+
+    cfg = make_cfg(18, "retinanet")
+    torch.manual_seed(3)
+    model = build_model(cfg)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    data = synthetic_batch(2, 256, 320, 21, device="cuda")
+    prev, HF.DETERMINISTIC = HF.DETERMINISTIC, True
+    keep = RN.FOCAL_FUSED
+    try:
+        norm0 = model.loss_normalizer.clone()
+
+        def step(on):
+            RN.FOCAL_FUSED = on
+            with torch.no_grad():
+                model.loss_normalizer.copy_(norm0)
+            opt.zero_grad()
+            out = model(data)
+            total = sum(out.values())
+            model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+            torch.cuda.synchronize()
+            return {k: float(v.detach()) for k, v in out.items()}, model.arena.grads.clone()
+
+        ref_l, ref_g = step(False)
+        got_l, got_g = step(True)
+        again_l, again_g = step(True)
+        assert got_l == ref_l and torch.equal(got_g, again_g)
+        worst = 0.0
+        for name, off, n in model.arena.names:
+            a, b = got_g[off:off + n], ref_g[off:off + n]
+            if "bbox" in name:
+                assert torch.equal(a, b), name                      # the regression branch does not see the change
+                continue
+            d = (a - b).norm().item() / max(b.norm().item(), 1e-12)
+            worst = max(worst, d)
+            assert d <= 2e-2, (name, d)
+        assert worst > 0.0
+    finally:
+        RN.FOCAL_FUSED = keep
+        HF.DETERMINISTIC = prev
+
+
 def test_relu_chain_in_towers_is_bit_identical(cuda):
     """Consecutive [conv3x3 -> ReLU] units of the RetinaNet towers: the consumer's data gradient applies the producer's ReLU mask in its
     epilogue (layers/nn.py _ReluToken, sod_conv2d_dgrad_ml_mask) instead of one relu_bwd launch per level and unit.  Masking before
