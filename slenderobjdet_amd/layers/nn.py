@@ -385,6 +385,33 @@ class GnBwdSlot:
         return len(xs) == len(self.out_ptrs) and all((x.data_ptr(), tuple(x.shape)) == k for x, k in zip(xs, self.out_ptrs))
 
 
+class GradPark:
+    """Two-stage detectors: the ROI pooler and the RPN head read the same FPN outputs, and the pooler's backward runs first (its node is
+    the younger one).  Instead of handing autograd a dense gradient per level that it then ADDS to the RPN head's (read 2, write 1 over
+    the 256-channel P2 ... P5 tensors), the pooler parks its gradients here and the RPN head's last data-gradient launch adds them in its
+    epilogue (sod_conv2d_dgrad_ml_accum).  ``current`` is set by GeneralizedRCNN.forward for the duration of one training forward pass."""
+    current = None
+
+    def __init__(self):
+        self.consumer_ptrs = set()      # data_ptr of every tensor the RPN head node will produce a gradient for (set in ITS forward)
+        self.parked = {}
+        self.done = False               # the RPN head's backward has run: nobody collects any more
+        self.hooked = False
+
+    def put(self, ptr, g):
+        self.parked[ptr] = g
+        if not self.hooked:
+            torch.autograd.Variable._execution_engine.queue_callback(self._check)
+            self.hooked = True
+
+    def _check(self):
+        self.hooked = False
+        if self.parked:
+            self.parked.clear()
+            raise RuntimeError("GradPark: the ROI pooler parked feature gradients and the RPN head's backward never collected them "
+                               "(SOD_RCNN_GRAD_PARK=0 restores autograd's accumulation)")
+
+
 class SiblingFold:
     """Shared by the FIRST units of sibling chains that read the same tensors (the two towers of FCOSHead on the FPN outputs,
     fcosv2.py:342-361).  autograd would add the two input gradients level by level (read 2, write 1: five launches on the critical path

@@ -2,14 +2,21 @@
 (configs/rotated/faster_R_101.yaml over Base-RRCNN-FPN.yaml) selects; detectron2's source is absent, the contract is the one the
 reference's own subclass relies on (slender_det/modeling/meta_arch/rcnn/pvrcnn.py:17-64): ``forward(batched_inputs)`` returns
 ``{loss_rpn_cls, loss_rpn_loc, loss_cls, loss_box_reg}`` in training and ``[{"instances": Instances}]`` in eval."""
+import os
+
 import torch
 from torch import nn
 
+from ...layers import nn as _nn
 from ..backbone import build_backbone
 from ..proposal_generator import build_proposal_generator
 from ..roi_heads import build_roi_heads
 from .build import META_ARCH_REGISTRY
 from .fcos import FCOSV2
+
+
+# SOD_RCNN_GRAD_PARK=0: autograd adds the ROI pooler's and the RPN head's feature gradients itself (one elementwise pass per level)
+GRAD_PARK = os.environ.get("SOD_RCNN_GRAD_PARK", "1") != "0"
 
 
 @META_ARCH_REGISTRY.register()
@@ -39,8 +46,13 @@ class GeneralizedRCNN(nn.Module):
         images = self.preprocess_image(batched_inputs)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         features = self.backbone(images.tensor)
-        proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
-        _, detector_losses = self.roi_heads(images, features, proposals, gt_instances)
+        # both heads read the FPN outputs: the ROI pooler's feature gradients ride in the RPN head's data-gradient launch (layers/nn.py GradPark)
+        _nn.GradPark.current = _nn.GradPark() if GRAD_PARK and torch.is_grad_enabled() else None
+        try:
+            proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
+            _, detector_losses = self.roi_heads(images, features, proposals, gt_instances)
+        finally:
+            _nn.GradPark.current = None
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)

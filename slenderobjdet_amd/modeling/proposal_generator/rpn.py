@@ -19,6 +19,7 @@ from torch import nn
 from torch.autograd.function import once_differentiable
 
 from ...layers import functional as HF
+from ...layers import nn as _nn
 from ...layers.nn import ConvML, _arena_of
 from ...structures import Boxes, Instances, RotatedBoxes
 from ...utils.registry import Registry
@@ -80,6 +81,11 @@ class _RpnHeadFn(torch.autograd.Function):
         dlt = HF.conv2d_fwd_ml(hid, cd.w_bf16, cd.bias_eff, 1, 0, 1, out_f32=True)
         ctx.head, ctx.nl = head, len(xs)
         ctx.save_for_backward(*xs, *hid)
+        ctx.park = None
+        park = _nn.GradPark.current
+        if park is not None and all(ctx.needs_input_grad[2:]):
+            ctx.park, ctx.ptrs = park, [x.data_ptr() for x in xs]
+            park.consumer_ptrs.update(ctx.ptrs)
         arena = _arena_of(c3)
         if arena is not None and c3.weight.requires_grad:
             for m in (c3, co, cd):
@@ -135,8 +141,17 @@ class _RpnHeadFn(torch.autograd.Function):
         HF.bias_grad_ml(dh, arena.grad_view(c3.bias))
         arena.mark_ready(c3.bias)
         dxs = [None] * nl
+        park = ctx.park
         if any(ctx.needs_input_grad[2:]):
-            dxs = HF.conv2d_dgrad_ml(dh, c3.wt_bf16, [(x.shape[1], x.shape[2]) for x in xs], 1, c3.padding, 1)
+            accums = None
+            if park is not None:
+                park.done = True
+                got = [park.parked.pop(p, None) for p in ctx.ptrs]
+                if any(t is not None for t in got):      # the ROI pooler's gradients of the same tensors (levels it does not read: zeros)
+                    accums = [t if t is not None else torch.zeros_like(x) for t, x in zip(got, xs)]
+            dxs = HF.conv2d_dgrad_ml(dh, c3.wt_bf16, [(x.shape[1], x.shape[2]) for x in xs], 1, c3.padding, 1, accums=accums)
+        elif park is not None:
+            park.done = True
         return (None, None, *dxs)
 
 

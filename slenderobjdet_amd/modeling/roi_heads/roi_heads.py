@@ -22,6 +22,7 @@ from ...layers.nms import batched_nms, batched_nms_rotated
 from ...layers.nn import HipConv2d
 from ...structures import Boxes, Instances, RotatedBoxes
 from ...utils.registry import Registry
+from ...layers import nn as _nn
 from ..box_regression import Box2BoxTransform, Box2BoxTransformRotated
 
 ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
@@ -46,6 +47,7 @@ class _RoiPoolFn(torch.autograd.Function):
                 out[idx] = HF.roi_align_fwd(feats[l], rois[idx].contiguous(), (PH, PW), pooler.scales[l], pooler.sampling_ratio, pooler.rotated)
             start += cnt
         ctx.pooler, ctx.counts, ctx.shapes = pooler, counts, [tuple(f.shape) for f in feats]
+        ctx.park, ctx.ptrs = _nn.GradPark.current, [f.data_ptr() for f in feats]
         ctx.save_for_backward(rois, order)
         return HF.f32_to_bf16(out)
 
@@ -65,6 +67,12 @@ class _RoiPoolFn(torch.autograd.Function):
                                                         pooler.sampling_ratio, pooler.rotated))
                 else:
                     g = torch.zeros(ctx.shapes[l], dtype=HF.ACT_DTYPE, device=dout.device)
+                park = ctx.park
+                if park is not None and not park.done and ctx.ptrs[l] in park.consumer_ptrs:
+                    # the RPN head's data gradient of this level adds it in its epilogue (layers/nn.py GradPark); a level without ROIs parks nothing
+                    if cnt:
+                        park.put(ctx.ptrs[l], g)
+                    g = None
             grads.append(g)
             start += cnt
         return (None, None, None, None, *grads)
