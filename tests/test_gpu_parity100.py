@@ -138,7 +138,7 @@ def test_100_iteration_loss_parity(cuda):
     _assert_fixture_is_current(chaos)
     assert len(chaos["lrs"]) == ITERS and max(abs(a - b) for a, b in zip(chaos["lrs"], lrs)) < 1e-12, "schedule differs from the fixture's"
     emu, f32 = chaos["emu_all_threads"], chaos["f32_all_threads"]
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
     LIVE = 6
     live_emu, live_f32 = _oracle_run(pool, lrs, True, LIVE), _oracle_run(pool, lrs, False, LIVE)
     assert max(abs(a - b) for a, b in zip(live_emu, emu)) <= 1e-3, (live_emu, emu[:LIVE])
@@ -252,7 +252,7 @@ def test_one_step_parity_along_the_100_iteration_trajectory(cuda, precision):
 
     pool = [synthetic_batch(2, 512, 512, 100 + i, device="cuda") for i in range(4)]
     cpu_pool = [_cpu(d) for d in pool]
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
     prev_p, prev_d = HF.set_precision(precision), HF.DETERMINISTIC
     HF.DETERMINISTIC = True
     worst_loss, worst_upd = 0.0, 0.0
@@ -324,7 +324,7 @@ def test_free_100_iterations_on_shared_relu_decisions(cuda):
 
     pool = [synthetic_batch(2, 512, 512, 100 + i, device="cuda") for i in range(4)]
     cpu_pool = [_cpu(d) for d in pool]
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
     prev_p, prev_d = HF.set_precision("fp32"), HF.DETERMINISTIC
     HF.DETERMINISTIC = True
     hip, ora, missed_any = [], [], 0
