@@ -253,6 +253,25 @@ def pmc_traffic(kind, kernel_name_):
         return None
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU quota when there is one (a one-GPU box is a
+    16-CPU share of a 256-CPU host; torch sized by the host's count runs the CPU baseline on an over-subscribed pool)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:      # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())               # cgroup v1
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:      # noqa: BLE001
+            pass
+    return n
+
+
 def cpu_baseline(model, args):
     """Time the CPU oracle (oracle/model.py) on a bounded sample of the same workload, host cores of this box.  SURVEY.md §8(d) asks
     for 3 warm-up + 10 timed iterations: that is the default (``--cpu-warmup`` / ``--cpu-steps``); a 16-image CPU step takes ~20 s, so the
@@ -260,7 +279,7 @@ def cpu_baseline(model, args):
     from oracle.model import OracleFCOS
     from slenderobjdet_amd.data import synthetic_batch
 
-    cores = min(os.cpu_count() or 1, args.cpu_threads)   # more threads than this only adds oneDNN scheduling overhead
+    cores = min(usable_cpus(), args.cpu_threads)   # more threads than this only adds oneDNN scheduling overhead
     torch.set_num_threads(cores)
     n = args.cpu_images
     oracle = OracleFCOS.from_hip_model(model)
