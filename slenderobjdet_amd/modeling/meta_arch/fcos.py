@@ -48,12 +48,13 @@ TOWER_STREAMS = os.environ.get("SOD_TOWER_STREAMS", "1") != "0"
 # convolution.  Measured SLOWER, 620.1 / 622.3 vs 625.8 / 625.4 img/s in one call: the hardware's own interleaving of the two queues
 # already does better than a forced alternation (which also idles one queue while it waits for the other's event).
 TOWER_GATE = os.environ.get("SOD_TOWER_GATE", "0") != "0"
-# SOD_TOWER_FOLD=1: the second tower's first data-gradient launch adds the first one's in its epilogue (layers/nn.py SiblingFold) instead of
-# autograd adding the two towers' input gradients itself (five elementwise launches).  Off by default - measured twice, neutral to
-# negative: the two launches then run one after the other instead of side by side and the accumulate read costs the 256x256 kernel's
-# exposed epilogue what the add kernels cost (round 3: 622.2 / 623.3 vs 622.2 / 623.5 img/s; round 4: 631.0 / 631.1 vs 632.4 / 633.2
-# with the accumulating tower on the side stream, 625.8 / 624.8 vs 623.8 / 625.2 with it on the main stream).
-TOWER_FOLD = os.environ.get("SOD_TOWER_FOLD", "0") != "0"
+# SOD_TOWER_FOLD (default 1): the second tower's first data-gradient launch adds the first one's in its epilogue (layers/nn.py SiblingFold)
+# instead of autograd adding the two towers' input gradients itself (five elementwise launches).  Its effect is below the noise of 60-step
+# runs (round 3: 622.2 / 623.3 vs 622.2 / 623.5 img/s; round 4: 631.0 / 631.1 vs 632.4 / 633.2 with the accumulating tower on the side
+# stream, 625.8 / 624.8 vs 623.8 / 625.2 with it on the main stream, as built now); nine alternating pairs of 100-step runs on two boxes put
+# it at +0.3 % (634.4 vs 632.7 together with a second weight-gradient stream, which alone is -0.3 %; 644.6 vs 642.6 alone, every pair in
+# favour): on.
+TOWER_FOLD = os.environ.get("SOD_TOWER_FOLD", "1") != "0"
 _tower_streams = {}
 _prefetch_streams = {}
 
