@@ -468,8 +468,8 @@ def main():
     loader = SyntheticCocoBatches(args.batch_per_gpu, args.height, args.width, rank=rank, device=dev, pool=2, rotated=args.arch == "rrcnn")
 
     main_prio = os.environ.get("SOD_MAIN_PRIO")          # experiment: the whole step on a stream of another HIP priority (-1 = highest)
-    if main_prio is not None:
-        _main = torch.cuda.Stream(device=dev, priority=int(main_prio))
+    if main_prio is not None or os.environ.get("SOD_CUMASK_MAIN"):
+        _main = HF.make_stream(dev, int(main_prio or 0), "MAIN")
         _main.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(_main)
     sample_at = set() if args.no_roofline else (set(range(args.steps)) if args.dump_prof else set(range(args.steps // 2, args.steps, 32)))

@@ -42,6 +42,16 @@ extern "C" {
 #define SOD_IOU_LOSS_GIOU 2
 
 const char* sod_version(void);
+/* ---------------------------------------------------------------------------------------------------------
+ * Streams.  No reference counterpart: the reference runs its whole step on PyTorch's default CUDA stream (train_net.py:185-195 ->
+ * detectron2 SimpleTrainer.run_step); the MI355X step overlaps independent launch chains on side streams, and a side
+ * stream may be confined to a subset of the compute units so that its whole-CU workgroups cannot displace the main stream's.
+ * mask_words: HOST array of nwords 32-bit words, bit i = logical CU i as hipExtStreamCreateWithCUMask numbers them (on MI355X bit i lies on
+ * XCD i % 8, so a contiguous range of 8*k bits is k CUs on every XCD).  *out_stream receives a hipStream_t the caller destroys with
+ * sod_stream_destroy (after synchronising it). */
+int sod_stream_create_cumask(const unsigned* mask_words, int nwords, void** out_stream);
+int sod_stream_destroy(void* stream);
+
 /* bytes of the scratch buffer `ws` the reduction-type entry points need */
 long long sod_reduce_workspace_bytes(void);
 

@@ -164,6 +164,8 @@ _SIGS = {
     "sod_retina_giou_loss_bwd_f32": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P],
     "sod_reduce_workspace_bytes": [],
     "sod_version": [],
+    "sod_stream_create_cumask": [_P, _I, _P],
+    "sod_stream_destroy": [_P],
 }
 _RESTYPES = {"sod_reduce_workspace_bytes": c_longlong, "sod_conv2d_wgrad_workspace_bytes": c_longlong, "sod_nms_workspace_bytes": c_longlong, "sod_batched_nms_workspace_bytes": c_longlong, "sod_version": c_char_p}
 

@@ -95,7 +95,7 @@ class DefaultTrainer:
             if hasattr(self.optimizer, "grad_scale"):
                 self.optimizer.grad_scale = 1.0 / world
         self.scheduler = self.build_lr_scheduler(cfg, self.optimizer)
-        self.checkpointer = _Checkpointer(self.model, cfg.OUTPUT_DIR, optimizer=self.optimizer, scheduler=self.scheduler)
+        self.checkpointer = _Checkpointer(self.model, cfg.OUTPUT_DIR, cfg=cfg, optimizer=self.optimizer, scheduler=self.scheduler)
         self.start_iter, self.max_iter, self.iter = 0, cfg.SOLVER.MAX_ITER, 0
         self.storage = {}
         self._hooks = []
@@ -207,8 +207,10 @@ class _Checkpointer:
     files (layout conversion, incompatible keys logged).  Remote paths (detectron2://, https://) need the reference's PathManager
     and a network, neither of which this package has: they raise instead of silently training from random weights."""
 
-    def __init__(self, model, save_dir="", **checkpointables):
-        self.model, self.save_dir, self.checkpointables = model, save_dir, checkpointables
+    def __init__(self, model, save_dir="", cfg=None, **checkpointables):
+        # cfg: the trainer's config, for MODEL.WEIGHTS_ALLOW_MISSING (key prefixes a checkpoint may lack: DetectionCheckpointer's
+        # warn-and-continue for fine-tuning from a detector with another head)
+        self.model, self.save_dir, self.cfg, self.checkpointables = model, save_dir, cfg, checkpointables
 
     def save(self, name, **extra):
         if not self.save_dir or not comm.is_main_process():
@@ -248,7 +250,7 @@ class _Checkpointer:
                                     "download the file and pass its local path")
         if not os.path.exists(path):
             raise FileNotFoundError(f"MODEL.WEIGHTS = {path!r} does not exist")
-        allow = tuple(getattr(getattr(self.cfg, "MODEL", None), "WEIGHTS_ALLOW_MISSING", ()) or ()) if getattr(self, "cfg", None) is not None else ()
+        allow = tuple(getattr(getattr(self.cfg, "MODEL", None), "WEIGHTS_ALLOW_MISSING", ()) or ()) if self.cfg is not None else ()
         report, meta = load_into(self.model, path, allow_missing=allow)
         data = meta["raw"]
         if resume and meta["native"]:

@@ -96,6 +96,32 @@ _side_join_queued = False
 _aux_streams = {}
 
 
+def cu_mask_words(lo, hi, total=256):
+    """Bit mask (list of 32-bit words) selecting the logical CUs lo .. hi-1 of hipExtStreamCreateWithCUMask's numbering.  On MI355X bit i
+    lies on XCD i % 8, so a range whose ends are multiples of 8 takes the same number of CUs from every XCD (the workgroup -> XCD
+    round-robin of a launch then still meets equally wide XCDs)."""
+    words = [0] * ((total + 31) // 32)
+    for i in range(max(0, lo), min(hi, total)):
+        words[i // 32] |= 1 << (i % 32)
+    return words
+
+
+def make_stream(device, priority=0, role=None):
+    """A side stream of the training step.  ``SOD_CUMASK_<ROLE>=lo:hi`` (role = WGRAD / TOWER / PREFETCH / MAIN) confines it to the
+    logical compute units lo .. hi-1 (sod_stream_create_cumask; such a stream has the default priority); without the variable it is a
+    plain torch stream of the given HIP priority."""
+    spec = os.environ.get(f"SOD_CUMASK_{role}") if role else None
+    if not spec:
+        return torch.cuda.Stream(device=device, priority=priority)
+    lo, hi = (int(v) for v in spec.split(":"))
+    words = cu_mask_words(lo, hi)
+    arr = (ctypes.c_uint * len(words))(*words)
+    out = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        call("sod_stream_create_cumask", ctypes.cast(arr, ctypes.c_void_p), len(words), ctypes.byref(out))
+    return torch.cuda.ExternalStream(out.value, device=device)       # lives for the rest of the process
+
+
 def register_compute_stream(device, stream):
     """Announce an extra stream that runs backward nodes (e.g. the FCOS box tower's).  Parameter gradients may be produced on it, so
     the bucket reducer (arena._launch_bucket) waits for it in addition to the launching node's stream and the wgrad side stream."""
@@ -156,7 +182,7 @@ def _wgrad_stream(device, tensors, key=None):
         # lowest HIP stream priority (range on MI355X: 1 .. -1): the data-gradient chain is the critical path.  Measured 491.5-492.3
         # (low) / 491.8 (normal) / 483-484 (high) img/s
         prio = int(os.environ.get("SOD_WGRAD_PRIO", "1"))
-        sides = _side_streams[device.index] = [torch.cuda.Stream(device=device, priority=prio) for _ in range(WGRAD_NSTREAMS)]
+        sides = _side_streams[device.index] = [make_stream(device, prio, "WGRAD") for _ in range(WGRAD_NSTREAMS)]
     if len(sides) == 1:
         side = sides[0]
     else:
@@ -347,7 +373,7 @@ def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img
     N, H, W, C = x_shape if x_shape is not None else x.shape
     if K is None:
         K = dy.shape[-1]
-    side = _wgrad_stream(dw.device, (dy, x), dw.data_ptr())
+    side = _wgrad_stream(dw.device, (dy, x, qscale), dw.data_ptr())      # qscale is read by the kernel's last stage: keep it alive too
     ws = wgrad_workspace(dw.device, side)
     diag = dw.shape[-1] != C and is_channel_window(C, K, dw.shape[-1])      # grouped convolution: dw is (K, R, S, 128), diagonal tiles only
     e0 = _prof_begin(side, "conv_wgrad")
@@ -498,7 +524,7 @@ def conv2d_wgrad_ml(dys, xs, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, 
     if K is None:
         K = dys[0].shape[-1]
     hs, ws_ = [x.shape[1] for x in xs], [x.shape[2] for x in xs]
-    side = _wgrad_stream(dw.device, list(dys) + list(xs), dw.data_ptr())
+    side = _wgrad_stream(dw.device, list(dys) + list(xs) + [qscale], dw.data_ptr())
     ws = wgrad_workspace(dw.device, side)
     e0 = _prof_begin(side, "conv_wgrad")
     call("sod_conv2d_wgrad_ml", len(xs), _ptr_arr(dys), _ptr_arr(xs), ptr(dw), ptr(qscale), N, _int_arr(hs), _int_arr(ws_), C, K, R, S,
@@ -1119,7 +1145,7 @@ def deform_conv_wgrad_fused(dy, x, offset, mask, dw, ksize, stride, pad, dil, dg
     K = dy.shape[-1]
     if dw.numel() != K * KH * KW * C:
         raise _C.SlenderHipError("deform_conv_wgrad_fused: dw does not hold K x KH*KW*C elements")
-    side = _wgrad_stream(dw.device, (dy, x, offset, mask), dw.data_ptr())
+    side = _wgrad_stream(dw.device, (dy, x, offset, mask, qscale), dw.data_ptr())
     ws = wgrad_workspace(dw.device, side)
     _chk(qscale, torch.float32, "qscale")
     call("sod_deform_conv_wgrad_fused", ptr(dy), ptr(x), ptr(offset), ptr(mask), ptr(dw), ptr(qscale), N, H, W, C, K, KH, KW, stride, pad, dil, dg, off_ld, mask_ld,

@@ -151,7 +151,7 @@ class FCOSHead(nn.Module):
             # the box tower's stream at the HIGH HIP priority (-1): in backward it is the stream the main stream ends up waiting for (it
             # shares the CUs with the weight-gradient stream from its first kernel on).  Five + four alternating pairs of 100-step runs:
             # 642.9 vs 640.5 img/s (+0.4 %), every pair in favour; with the main stream high as well: 635.5 vs 641.2.  SOD_TOWER_PRIO=0 = normal.
-            s2 = _tower_streams[dev.index] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SOD_TOWER_PRIO", "-1")))
+            s2 = _tower_streams[dev.index] = HF.make_stream(dev, int(os.environ.get("SOD_TOWER_PRIO", "-1")), "TOWER")
             HF.register_compute_stream(dev, s2)
         s2.wait_stream(main)
         for f in feats:
@@ -319,7 +319,7 @@ class FCOSV2(nn.Module):
             bottom.prepare_frozen_prefix()
         side = _prefetch_streams.get(dev.index)
         if side is None:
-            side = _prefetch_streams[dev.index] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("SOD_PREFETCH_PRIO", "0")))
+            side = _prefetch_streams[dev.index] = HF.make_stream(dev, int(os.environ.get("SOD_PREFETCH_PRIO", "0")), "PREFETCH")
         side.wait_stream(main)
         self._prefetched = None
         with torch.cuda.stream(side):

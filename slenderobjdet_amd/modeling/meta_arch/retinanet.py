@@ -105,7 +105,10 @@ class _RetinaLossFn(torch.autograd.Function):
             sums = HF.retina_box_loss_fwd(box_buf, head.box_pitch, gt_labels, gt_deltas, N, R, A, K, model.smooth_l1_loss_beta,
                                           model.loss_normalizer, model.loss_normalizer_momentum)    # also advances the EMA normaliser
         dcls_u = None
-        if FOCAL_FUSED and not HF.is_f32() and any(ctx.needs_input_grad[4:]):      # a backward pass follows
+        # the one-pass kernel is vectorised only (sod_sigmoid_focal_loss_fwd_grad: 4 classes per lane, 32-bit element offsets): other
+        # layouts (NUM_CLASSES % 4 != 0, N * R * K >= 2^31) take the two-pass entry points as before round 4
+        fusable = K % 4 == 0 and N * R * K < 2 ** 31
+        if FOCAL_FUSED and fusable and not HF.is_f32() and any(ctx.needs_input_grad[4:]):      # a backward pass follows
             focal_sum, dcls_u = HF.focal_loss_fwd_grad(cls_buf.view(N * R, K), gt_labels.view(-1), model.focal_loss_alpha, model.focal_loss_gamma)
         else:
             focal_sum, _ = HF.focal_loss_fwd(cls_buf.view(N * R, K), gt_labels.view(-1), None, model.focal_loss_alpha, model.focal_loss_gamma)

@@ -459,3 +459,47 @@ def test_relu_chain_in_towers_is_bit_identical(cuda):
         HF.conv2d_dgrad_ml, HF.relu_bwd = o1, o2
         HN.RELU_CHAIN = prev_chain
         HF.DETERMINISTIC = prev
+
+
+def test_retinanet_step_with_class_count_not_a_multiple_of_four(cuda):
+    """Round-4 advisor finding: the one-pass focal kernel (sod_sigmoid_focal_loss_fwd_grad) is vectorised over 4 classes and was called
+    unconditionally, so NUM_CLASSES = 6 (K % 4 != 0) raised in training.  Such layouts take the two-pass entry points again: the step
+    runs, and equals the step with the fused path switched off bit for bit (it IS that path)."""
+    from bench import make_cfg
+    from slenderobjdet_amd.data import synthetic_batch
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.modeling import build_model
+    from slenderobjdet_amd.modeling.meta_arch import retinanet as RN
+
+    cfg = make_cfg(18, "retinanet")
+    cfg.MODEL.RETINANET.NUM_CLASSES = 6
+    cfg.MODEL.ANCHOR_GENERATOR.SIZES = [[x, x * 2 ** 0.5] for x in [32, 64, 128, 256, 512]]       # 2 sizes x 2 ratios = 4 anchors: A * K = 24
+    cfg.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS = [[0.5, 2.0]]
+    torch.manual_seed(3)
+    model = build_model(cfg)
+    model.train()
+    data = synthetic_batch(2, 256, 320, 21, num_classes=6, device="cuda")
+    prev, HF.DETERMINISTIC = HF.DETERMINISTIC, True
+    keep = RN.FOCAL_FUSED
+    try:
+        norm0 = model.loss_normalizer.clone()
+
+        def step(on):
+            RN.FOCAL_FUSED = on
+            with torch.no_grad():
+                model.loss_normalizer.copy_(norm0)
+            model.arena.zero_grad()
+            out = model(data)
+            total = sum(out.values())
+            model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
+            torch.cuda.synchronize()
+            return {k: float(v.detach()) for k, v in out.items()}, model.arena.grads.clone()
+
+        got_l, got_g = step(True)
+        ref_l, ref_g = step(False)
+        assert all(v == v and abs(v) < 1e4 for v in got_l.values()), got_l
+        assert got_l == ref_l and torch.equal(got_g, ref_g)
+        assert float(got_g.abs().sum()) > 0
+    finally:
+        RN.FOCAL_FUSED = keep
+        HF.DETERMINISTIC = prev

@@ -391,6 +391,15 @@ def test_checkpoint_round_trip_retinanet_and_rcnn_heads(tmp_path):
         assert all(torch.equal(before[k], after[k]) for k in before), "a refused checkpoint must leave the model as it was"
         ck.load_into(build(rel, 5), str(tmp_path / "broken.pth"), allow_missing=("head.cls_subnet.", "proposal_generator.head.conv."))
         ck.load_into(build(rel, 5), str(tmp_path / "broken.pth"), allow_missing=("*",))      # DetectionCheckpointer's warn-and-continue
+        # ... and the same through the trainer's checkpointer, which takes the prefixes from MODEL.WEIGHTS_ALLOW_MISSING (round-4 advisor
+        # finding: the key was documented but never reached load_into)
+        from slenderobjdet_amd.engine.defaults import _Checkpointer
+
+        cfg_t = fresh_cfg()
+        with pytest.raises(RuntimeError, match="head parameter"):
+            _Checkpointer(build(rel, 5), "", cfg=cfg_t).resume_or_load(str(tmp_path / "broken.pth"), resume=False)
+        cfg_t.MODEL.WEIGHTS_ALLOW_MISSING = ("*",)
+        assert _Checkpointer(build(rel, 5), "", cfg=cfg_t).resume_or_load(str(tmp_path / "broken.pth"), resume=False) == 0
 
 
 def test_dcnv2_backbone_config_builds_deform_bottleneck_blocks():
