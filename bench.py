@@ -21,14 +21,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+HBM_ACHIEVABLE_GBPS = 6300.0   # what a streaming kernel sustains on MI355X (MI355X_MICROARCH.md; 8 TB/s is the spec figure)
 TRAIN_FLOP_PER_IMAGE = 1.1913e12   # fwd + dgrad + wgrad, stem+res2 frozen, 800x1344
 
 
 ARCH_NAMES = {"fcos": "FCOS", "retinanet": "RetinaNet", "reppoints": "RepPoints", "rrcnn": "rotated Faster R-CNN"}
 
 
-def make_cfg(depth=50, arch="fcos"):
-    """BASELINE.json configs[1] (fcos, the headline), configs[2] (retinanet) and configs[3] (reppoints) as config objects."""
+def make_cfg(depth=50, arch="fcos", constant_lr=False):
+    """BASELINE.json configs[1] (fcos, the headline), configs[2] (retinanet) and configs[3] (reppoints) as config objects.  ``BASE_LR`` is the
+    reference configuration's; ``constant_lr`` (a run WITHOUT the reference's warm-up schedule, bench.py --constant-lr) lowers it to 0.002
+    for the two architectures that diverge from random initialisation at their full rate."""
     from slenderobjdet_amd.config import fresh_cfg
 
     cfg = fresh_cfg()
@@ -68,18 +71,21 @@ def make_cfg(depth=50, arch="fcos"):
         cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION = 7
         cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE = "ROIAlignRotated"
         cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS = (10.0, 5.0, 5.0, 5.0, 1.0)
-        cfg.SOLVER.BASE_LR = 0.002      # the reference trains at 0.02 from an ImageNet checkpoint; random init diverges there
+        cfg.SOLVER.BASE_LR = 0.02       # configs/rotated/Base-RRCNN-FPN.yaml; without the warm-up schedule random init diverges there
+        if constant_lr:
+            cfg.SOLVER.BASE_LR = 0.002
     if arch == "reppoints":                      # configs/rep-points/rep_points_detector_R_50_FPN_1x.yaml
         cfg.MODEL.META_ARCHITECTURE = "RepPointsDetector"
         cfg.MODEL.RESNETS.OUT_FEATURES = ["res2", "res3", "res4", "res5"]
         cfg.MODEL.FPN.IN_FEATURES = ["res2", "res3", "res4", "res5"]
         cfg.MODEL.FPN.NORM = "GN"
         cfg.MODEL.PROPOSAL_GENERATOR.SAMPLE_MODE = "points"
-        # The reference starts from an ImageNet checkpoint and warms up from 1e-3 x BASE_LR; from random initialisation at the full 0.01
-        # the run diverges within ~40 steps (loss 19 -> 70) and the learned offsets leave the DeformConv kernels' LDS windows: the same
-        # build then measures 431 img/s over steps 5-14, 413 over 7-36 and 340 over 9-48.  0.002 keeps the first 50 steps in the regime
-        # the reference's first thousand iterations are in.
-        cfg.SOLVER.BASE_LR = 0.002
+        # The reference starts from an ImageNet checkpoint and warms up from 1e-3 x BASE_LR (0.01) over 1000 iterations: bench.py steps that
+        # schedule since round 5.  At a CONSTANT 0.01 from random initialisation the run diverges within ~40 steps (loss 19 -> 70) and the
+        # learned offsets leave the DeformConv kernels' LDS windows (431 img/s over steps 5-14, 413 over 7-36, 340 over 9-48): --constant-lr
+        # therefore runs at 0.002.
+        if constant_lr:
+            cfg.SOLVER.BASE_LR = 0.002
     cfg.MODEL.FCOS.CENTER_SAMPLING_RADIUS = 1.5
     cfg.MODEL.FCOS.IOU_LOSS_TYPE = "giou"
     cfg.MODEL.FCOS.CENTERNESS_ON_REG = True
@@ -119,7 +125,7 @@ def damp_residual_branches(model, gamma=0.25):
 PREFETCH = os.environ.get("SOD_PREFETCH", "1") != "0"
 
 
-def train_step(model, optimizer, data, next_data=None):
+def train_step(model, optimizer, data, next_data=None, scheduler=None):
     """One training step.  ``next_data`` (optional) is the batch of the FOLLOWING step: between this step's forward and backward the
     model runs that batch's preprocess + frozen stem/res2 on a side stream (meta-arch ``prefetch``), where the HBM-bound frozen convs
     share the GPU with the MFMA-bound head backward; the next step's forward picks the result up.  Every step still carries exactly one
@@ -133,6 +139,8 @@ def train_step(model, optimizer, data, next_data=None):
     total.backward()
     model.arena.finish_backward()
     optimizer.step()
+    if scheduler is not None:       # the reference steps its WarmupMultiStepLR once per iteration (detectron2 hooks.LRScheduler.after_step)
+        scheduler.step()
     return total
 
 
@@ -200,8 +208,13 @@ def roofline_report(prof, prof_steps, args):
             a[0] += flops; a[1] += sec; a[2] += 1; a[3] += algo_bytes(kind, desc)
 
     def row(v, name=None):
-        fl, sec, cnt = v[:3]
-        r = {"TFLOP/s": round(fl / sec / 1e12, 2), "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4), "ms_per_step": round(sec / prof_steps * 1e3, 3),
+        # frac = share of the dense MFMA peak; hbm_frac = ALGORITHMIC bytes (every conv operand once) / time / the achievable HBM rate;
+        # bound = the roof this group of launches sits closer to (a 1x1 convolution at frac 0.2 and hbm_frac 0.5 is an HBM-bound kernel at
+        # half its roof, not an MFMA kernel at a fifth of it)
+        fl, sec, cnt, nbytes = v[:4]
+        mf, hf = fl / sec / 1e12 / MFMA_PEAK_TFLOPS, nbytes / sec / 1e9 / HBM_ACHIEVABLE_GBPS
+        r = {"TFLOP/s": round(fl / sec / 1e12, 2), "frac": round(mf, 4), "hbm_GBps_algorithmic": round(nbytes / sec / 1e9, 1), "hbm_frac": round(hf, 4),
+             "bound": "mfma" if mf >= hf else "hbm", "ms_per_step": round(sec / prof_steps * 1e3, 3),
              "launches_per_step": round(cnt / prof_steps, 1), "tflop_per_step": round(fl / prof_steps / 1e12, 3)}
         if name:
             r["kernel"] = name
@@ -216,7 +229,7 @@ def roofline_report(prof, prof_steps, args):
            "traffic_source": (tr or {}).get("source"),
            "algorithmic_bytes": round(nbytes / cnt), "algorithmic_bytes_note": "per launch, conv operands read / written once (no fused epilogue operands)",
            "traffic_over_algorithmic": round(tr["hbm_bytes_per_launch"] / (nbytes / cnt), 3) if tr and nbytes else None,
-           "hbm_GBps_algorithmic": round(nbytes / sec / 1e9, 1),
+           "hbm_GBps_algorithmic": round(nbytes / sec / 1e9, 1), "hbm_frac": round(nbytes / sec / 1e9 / HBM_ACHIEVABLE_GBPS, 4),
            "selection": "kernel with the largest share of conv GPU time in the sampled steps", "launches": cnt, "sampled_steps": prof_steps,
            "avg_launch_us": round(sec / cnt * 1e6, 2), "ms_per_step": round(sec / prof_steps * 1e3, 3),
            "flops": "algorithmic, un-padded channels",
@@ -226,7 +239,32 @@ def roofline_report(prof, prof_steps, args):
     if args.arch == "fcos":
         for gname, v in groups.items():
             rep[gname] = row(v)
+    st = pmc_step_traffic()
+    if st:
+        rep["step_hbm"] = st
     return rep
+
+
+def pmc_step_traffic():
+    """HBM bytes of one whole training step from the newest committed PMC summary (every kernel's FETCH_SIZE x 2 + WRITE_SIZE times its
+    launches, divided by the steps of that profiled run): with the step time of THAT run it gives the step-level HBM rate the verdict
+    of round 4 computed by hand (2.5 TB/s = 0.40 of the achievable rate).  None if no summary is committed."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.basename)
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        steps = int(d.get("steps", 7))
+        tot = sum(k["hbm_bytes_per_launch"] * k["launches"] for k in d["kernels"].values()) / steps
+        out = {"bytes_per_step": round(tot), "source": os.path.relpath(files[-1], ROOT), "profiled_steps": steps}
+        if d.get("ms_per_step"):
+            out["hbm_GBps"] = round(tot / (d["ms_per_step"] * 1e-3) / 1e9, 1)
+            out["hbm_frac"] = round(out["hbm_GBps"] / HBM_ACHIEVABLE_GBPS, 4)
+        return out
+    except Exception:
+        return None
 
 
 def pmc_traffic(kind, kernel_name_):
@@ -324,11 +362,13 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
-def device_fingerprint(index=0):
+def device_fingerprint(index=0, clocks_only=False):
     """Which device produced the line: MI355X parts differ by several per cent at equal code (clocks under load, power cap), so a
     reader comparing two runs needs to know whether they ran on the same one.  Best effort, never fails the benchmark."""
     fp = {}
     try:
+        if clocks_only:
+            raise LookupError
         p = torch.cuda.get_device_properties(index)
         fp["name"] = p.name
         uuid = str(getattr(p, "uuid", "") or "")
@@ -402,6 +442,9 @@ def main():
                     "WIDTH_PER_GROUP 8, STRIDE_IN_1X1 False) instead of ResNet: the grouped-convolution path; not the headline")
     ap.add_argument("--base-lr", type=float, default=None, help="override SOLVER.BASE_LR (experiments: e.g. RepPoints at the reference's 0.01, where "
                     "random initialisation diverges and the learned offsets grow)")
+    ap.add_argument("--constant-lr", action="store_true", help="constant SOLVER.BASE_LR from step 0 instead of the reference's WarmupMultiStepLR")
+    ap.add_argument("--bucket-mb", type=float, default=None, help="N > 1: size of the gradient all-reduce buckets (default 32 MB)")
+    ap.add_argument("--wire", choices=["fp32", "bf16"], default=None, help="N > 1: wire format of the gradient buckets (default fp32, SOD_GRAD_BUCKET_DTYPE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-prof", type=int, default=0, help="print the N most expensive (kernel, shape) groups to stderr")
@@ -450,7 +493,7 @@ def main():
     from slenderobjdet_amd.modeling import build_model
     from slenderobjdet_amd.solver import build_optimizer
 
-    cfg = make_cfg(args.depth, args.arch)
+    cfg = make_cfg(args.depth, args.arch, constant_lr=args.constant_lr)
     if args.base_lr is not None:
         cfg.SOLVER.BASE_LR = args.base_lr
     if args.resnext:
@@ -460,11 +503,19 @@ def main():
     model.train()
     if args.arch in ("retinanet", "rrcnn") and args.depth >= 50:
         damp_residual_branches(model)
+    if args.bucket_mb is not None or args.wire is not None:
+        model.arena.configure_buckets(args.bucket_mb if args.bucket_mb is not None else 32.0, args.wire)
     if world > 1 or rehearsal:   # DDP semantics: identical initial parameters on every rank
         dist.broadcast(model.arena.params, src=0)
         model.arena.bump()
     optimizer = build_optimizer(cfg, model)
     optimizer.grad_scale = 1.0 / world
+    # The reference's schedule (configs/fcos/Base-Fcos.yaml:14-18 -> detectron2 WarmupMultiStepLR: linear warm-up from 1e-3 x BASE_LR over
+    # the first 1000 iterations), stepped once per iteration as DefaultTrainer does; --constant-lr = a constant BASE_LR from step 0 (rounds 1-4)
+    scheduler = None
+    if not args.constant_lr:
+        from slenderobjdet_amd.solver import build_lr_scheduler
+        scheduler = build_lr_scheduler(cfg, optimizer)
     loader = SyntheticCocoBatches(args.batch_per_gpu, args.height, args.width, rank=rank, device=dev, pool=2, rotated=args.arch == "rrcnn")
 
     main_prio = os.environ.get("SOD_MAIN_PRIO")          # experiment: the whole step on a stream of another HIP priority (-1 = highest)
@@ -477,7 +528,7 @@ def main():
     cur = next(loader)
     for w in range(args.warmup):
         nxt = next(loader)
-        train_step(model, optimizer, cur, None if (w == args.warmup - 1 and 0 in sample_at) else nxt)
+        train_step(model, optimizer, cur, None if (w == args.warmup - 1 and 0 in sample_at) else nxt, scheduler)
         cur = nxt
     if world > 1 or rehearsal:
         dist.barrier()
@@ -498,8 +549,13 @@ def main():
     side_default = HF.WGRAD_SIDE_STREAM
     from slenderobjdet_amd.modeling.meta_arch import fcos as fcos_mod
     tower_default = fcos_mod.TOWER_STREAMS
+    sclk_mid = None
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if i == (3 * args.steps) // 4 and rank == 0:
+            # the shader clock the device reports WHILE the timed loop keeps it busy (a sysfs read: no GPU call, ~50 us of host time; the
+            # host runs several steps ahead of the device); read after the loop it is the idle clock
+            sclk_mid = device_fingerprint(dev.index or 0, clocks_only=True).get("sclk_active")
         sample = i in sample_at       # one timed step in 32, the first in the middle of the run (all of them with --dump-prof)
         HF.PROFILE = prof_all if sample else None
         if HF.PROFILE_LIB:
@@ -510,10 +566,11 @@ def main():
         # a sampled step computes its own frozen prefix on the main stream (so that its profile holds every conv of a step) and hands
         # none to its successor
         nxt = next(loader)
-        last = train_step(model, optimizer, cur, None if (sample or (i + 1) in sample_at) else nxt)
+        last = train_step(model, optimizer, cur, None if (sample or (i + 1) in sample_at) else nxt, scheduler)
         cur = nxt
     HF.WGRAD_SIDE_STREAM = side_default
     fcos_mod.TOWER_STREAMS = tower_default
+    host_dt = time.perf_counter() - t0          # the host has ENQUEUED the K steps; the device is still working on them
     if world > 1 or rehearsal:
         dist.barrier()
     torch.cuda.synchronize()
@@ -567,8 +624,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.arch] + (" [ResNeXt 32x8d backbone]" if args.resnext else ""), "global_batch": args.batch_per_gpu * world, "parallelism": f"dp{world}",
                        "final_loss": round(loss_val, 5), "final_grad_norm": round(gnorm, 5), "base_lr": cfg.SOLVER.BASE_LR,
+                       "lr_schedule": ("constant" if scheduler is None else
+                                       f"{cfg.SOLVER.LR_SCHEDULER_NAME}: {cfg.SOLVER.WARMUP_METHOD} warm-up from {cfg.SOLVER.WARMUP_FACTOR} x base over "
+                                       f"{cfg.SOLVER.WARMUP_ITERS} iterations, stepped every iteration (lr at the last step {optimizer.param_groups[0]['lr']:.3e})"),
+                       "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
                        "device": device_fingerprint(dev.index or 0)},
         }
+        out["config"]["device"]["sclk_active"] = sclk_mid      # sampled at 3/4 of the timed loop (None if sysfs does not expose it)
         ref_lr = {"fcos": 0.01, "retinanet": 0.01, "reppoints": 0.01, "rrcnn": 0.02}[args.arch]
         if cfg.SOLVER.BASE_LR != ref_lr:        # not the reference configuration's rate: say so in the line (round-3 advisor finding)
             out["config"]["base_lr_note"] = (f"reference config trains at {ref_lr} from an ImageNet checkpoint; random initialisation diverges there "
@@ -584,7 +646,9 @@ def main():
                 "n_buckets": len(ar.buckets), "grad_bytes_per_step": int(ar.total * (4 if ar.bucket_dtype == torch.float32 else 2)),
                 "wire_dtype": str(ar.bucket_dtype).replace("torch.", ""),
                 "exposed_comm_ms_per_step": round(sum(exposed) / len(exposed), 3) if exposed else None,
-                "exposed_comm_note": "rank 0, mean over the timed steps: compute-stream idle time between the end of backward and the end of the last bucket's all-reduce"})
+                "exposed_comm_note": "rank 0, mean over the timed steps: compute-stream idle time between the end of backward and the end of the last bucket's all-reduce",
+                # what RCCL was told (it picks ring / tree and the channel count per call itself; NCCL_DEBUG=INFO prints its choices to stderr)
+                "rccl_env": {k: os.environ[k] for k in sorted(os.environ) if k.startswith(("NCCL_", "RCCL_"))}})
         if rehearsal:
             out["config"]["rccl_rehearsal"] = "one-rank RCCL group, every data-parallel collective issued"
         if args.arch == "fcos" and args.depth == 50:

@@ -120,14 +120,20 @@ class ProductReluTap:
         self.bare = list(bare_relu_keys)
 
     def __enter__(self):
+        # both precisions of the product report through the same observer signature: the fp32 validation mode (functional_f32) and the
+        # bf16 product path (functional; round 5) - whichever runs inside the context is recorded
+        from slenderobjdet_amd.layers import functional as HF
         from slenderobjdet_amd.layers import functional_f32 as F32
 
-        self._mod = F32
-        F32.RELU_TAP = lambda kind, key, y: self.rec.append((kind, int(key), (y.detach() > 0).cpu()))
+        self._mods = (F32, HF)
+        tap = lambda kind, key, y: self.rec.append((kind, int(key), (y.detach() > 0).cpu()))      # noqa: E731
+        for m in self._mods:
+            m.RELU_TAP = tap
         return self
 
     def __exit__(self, *exc):
-        self._mod.RELU_TAP = None
+        for m in self._mods:
+            m.RELU_TAP = None
 
     def masks_for(self, model):
         conv_names, gn_names = {}, {}

@@ -52,9 +52,14 @@ class ForcedMasks:
     active = None
 
     @staticmethod
-    def begin(masks, record=False):
-        """``record=True``: natural decisions everywhere, and every position's (x > 0) is stored into ``masks`` (a dict)."""
-        ForcedMasks.active = {"masks": masks, "count": {}, "used": 0, "missed": [], "record": bool(record)}
+    def begin(masks, record=False, tau=1e-4):
+        """``record=True``: natural decisions everywhere, and every position's (x > 0) is stored into ``masks`` (a dict).
+        ``tau``: a forced decision may differ from the oracle's OWN (x > 0) only on units inside the undecided band |x| < tau * rms(x)
+        of that activation (ReluBand's band) - a pre-activation both implementations hold to rounding of zero.  ``disagree`` counts the
+        units decided differently, ``outside`` those of them OUTSIDE the band (a product pre-activation with the wrong sign, which the
+        forced mask would otherwise hide by producing 0 on both sides); ``outside_at`` lists the positions.  Callers assert outside == 0."""
+        ForcedMasks.active = {"masks": masks, "count": {}, "used": 0, "missed": [], "record": bool(record), "tau": float(tau), "units": 0,
+                              "disagree": 0, "outside": 0, "outside_at": []}
         return ForcedMasks.active
 
     @staticmethod
@@ -79,6 +84,19 @@ def relu_at(x, key):
                     raise ValueError(f"forced mask for {key}#{i} has shape {tuple(m.shape)}, activation {tuple(x.shape)}")
                 m = m.reshape(x.shape)          # (R, C, 1, 1) rows of a fully connected layer run as a 1x1 convolution
             fm["used"] += 1
+            m = m.to(device=x.device, dtype=torch.bool)
+            xd = x.detach()
+            dis = (xd > 0) != m                 # decided differently by the other implementation
+            nd = int(dis.sum())
+            fm["units"] += xd.numel()
+            if nd:
+                fm["disagree"] += nd
+                rms = xd.double().pow(2).mean().sqrt().clamp_min(1e-300)
+                out = dis & (xd.abs().double() >= fm["tau"] * rms)
+                no = int(out.sum())
+                if no:
+                    fm["outside"] += no
+                    fm["outside_at"].append((key, i, no, float((xd.abs().double()[out] / rms).max())))
             return x * m.to(x.dtype)
         fm["missed"].append((key, i))
     return relu(x)

@@ -50,7 +50,21 @@ class ParamArena:
             self.names.append((name, off, n))
         self._plist = [p for _, p in plist]
         self.generation = 0          # bumped whenever params change behind torch's back (fused optimizer step)
-        # ---- gradient buckets for the data-parallel all-reduce ----
+        self._offs = offs
+        self.configure_buckets(bucket_mb, bucket_dtype)
+        self._pending = None
+        self._uses = {}
+        self._counting = True
+        self._comm_stream = None
+        self._handles = []
+
+    def configure_buckets(self, bucket_mb=32.0, bucket_dtype=None):
+        """(Re)build the gradient buckets of the data-parallel all-reduce: contiguous runs of the gradient arena of at least ``bucket_mb``
+        MB each, in backward completion order.  Call between steps only (bench.py --bucket-mb / --wire, so that a scaling curve can be swept
+        without code changes)."""
+        if getattr(self, "_pending", None) is not None:
+            raise RuntimeError("configure_buckets inside a backward pass")
+        offs, total = self._offs, self.total
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self.buckets = []            # (begin, end)
         b0 = 0
@@ -72,11 +86,6 @@ class ParamArena:
         import os as _os
         bd = bucket_dtype if bucket_dtype is not None else _os.environ.get("SOD_GRAD_BUCKET_DTYPE", "fp32")
         self.bucket_dtype = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}[str(bd).replace("torch.", "")]
-        self._pending = None
-        self._uses = {}
-        self._counting = True
-        self._comm_stream = None
-        self._handles = []
 
     # ------------------------------------------------------------------ bf16 compute copies of every trainable conv weight
     def setup_batched_prep(self, model):

@@ -51,6 +51,12 @@ def _precision_dispatch(fn):
         return fn(*args, **kwargs)
     return wrapper
 
+# Observer for tests (None in production): called as RELU_TAP(kind, key_ptr, y) with every tensor the bf16 path produces THROUGH a ReLU whose
+# output is materialised - kind "conv" (key = address of the weight operand), "gn" (key = gamma's address), "relu" (key 0) - exactly as
+# layers/functional_f32.RELU_TAP does for the fp32 validation mode.  tests/test_gpu_parity100.py hands the recorded decisions (y > 0) to the
+# CPU oracle.  The fused frozen kernels (stem + max-pool, res2 bottlenecks) keep their ReLUs inside: no gradient flows through them.
+RELU_TAP = None
+
 # Optional per-launch timing of the convolution kernels (bench.py roofline): a list that receives
 # (kind, algorithmic_flops, start_event, end_event); events are recorded on the stream the kernel is launched on.
 PROFILE = None
@@ -262,6 +268,8 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
              x_img_stride, y_img_stride, 0, flags, 1 if out_f32 else 0, stream_ptr())
     # c_real / k_real: un-padded channel counts, so that the profile counts ALGORITHMIC work (stem: 3 of its 8 input channels)
     _prof_end("conv_fwd", 2.0 * N * Ho * Wo * K * R * S * (c_real or (Cw if cwin else C)), e0, (N, H, W, C, K, R, stride))
+    if relu and RELU_TAP is not None and not x_img_stride and not y_img_stride:
+        RELU_TAP("conv", w.data_ptr(), out)
     return out
 
 
@@ -406,6 +414,9 @@ def conv2d_fwd_ml(xs, w, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=
          stride, pad, dil, y_img_stride, CONV_RELU if relu else 0, 1 if out_f32 else 0, stream_ptr())
     fl = sum(2.0 * N * ho * wo * (k_real or K) * R * S * C for ho, wo in (conv_out_size(h, wd, R, S, stride, pad, dil) for h, wd in zip(hs, ws)))
     _prof_end("conv_fwd", fl, e0, ("ml", N, tuple(hs), C, K, R, stride, tuple(ws)))
+    if relu and RELU_TAP is not None and not y_img_stride:
+        for o in outs:
+            RELU_TAP("conv", w.data_ptr(), o)
     return outs
 
 
@@ -434,6 +445,9 @@ def conv_gn_fwd_ml(xs, w, bias, gamma, beta, G, eps=1e-5, relu=True, pad=1, afte
     hw = [o.shape[1] * o.shape[2] for o in outs]
     call("sod_groupnorm_apply_ml", len(outs), _ptr_arr(outs), ptr(gamma), ptr(beta), _ptr_arr(ys), ptr(stats), N, ctypes.cast(_int_arr(hw), ctypes.c_void_p),
          K, G, eps, 1 if relu else 0, stream_ptr())
+    if relu and RELU_TAP is not None:
+        for y in ys:
+            RELU_TAP("gn", gamma.data_ptr(), y)
     return outs, ys, stats
 
 
@@ -561,6 +575,8 @@ def groupnorm_fwd(x, gamma, beta, G, eps=1e-5, relu=False):
     y = torch.empty_like(x)
     stats = torch.empty((N, G, 2), dtype=torch.float32, device=x.device)
     call("sod_groupnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stats), N, HW, C, G, 0, eps, 1 if relu else 0, *_det_ws(x.device), stream_ptr())
+    if relu and RELU_TAP is not None:
+        RELU_TAP("gn", gamma.data_ptr(), y)
     return y, stats
 
 
@@ -587,6 +603,9 @@ def groupnorm_fwd_ml(xs, gamma, beta, G, eps=1e-5, relu=False):
     stats = torch.empty((len(xs), N, G, 2), dtype=torch.float32, device=xs[0].device)
     call("sod_groupnorm_fwd_ml", len(xs), _ptr_arr(xs), ptr(gamma), ptr(beta), _ptr_arr(ys), ptr(stats), N, ctypes.cast(_int_arr(hw), ctypes.c_void_p),
          C, G, eps, 1 if relu else 0, *_det_ws(xs[0].device), stream_ptr())
+    if relu and RELU_TAP is not None:
+        for y in ys:
+            RELU_TAP("gn", gamma.data_ptr(), y)
     return ys, stats
 
 
@@ -608,6 +627,8 @@ def relu_fwd(x):
     _chk(x, torch.bfloat16, "x")
     y = torch.empty_like(x)
     call("sod_relu_fwd", ptr(x), ptr(y), x.numel(), stream_ptr())
+    if RELU_TAP is not None:
+        RELU_TAP("relu", 0, y)
     return y
 
 

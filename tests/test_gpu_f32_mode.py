@@ -167,6 +167,9 @@ def test_elementwise_f32_kernels(cuda, f32mode):
     _close(out, want, 1e-6)
 
 
+FORCED_STATS = []       # (units decided differently, units) of every forced-mask oracle pass of this session (printed by the last test)
+
+
 @contextlib.contextmanager
 def _forced(masks):
     """The oracle code inside takes the PRODUCT's ReLU decisions (oracle.nn.ForcedMasks) wherever ``masks`` has the position."""
@@ -177,6 +180,10 @@ def _forced(masks):
         yield st
     finally:
         ForcedMasks.end()
+    # shared decisions are a CHECK, not a trust: the product and this oracle run may decide a unit differently only where its
+    # pre-activation is zero to rounding (|x| < 1e-4 rms of the activation); a wrong-sign pre-activation in the product fails here
+    assert st["outside"] == 0, ("ReLU decisions differ outside the undecided band", st["outside_at"][:5])
+    FORCED_STATS.append((st["disagree"], st["units"]))
 
 
 def _tapped_step(model, opt, data):

@@ -30,19 +30,19 @@ pytestmark = pytest.mark.gpu
 ITERS = 100
 
 
-def _cfg():
+def _cfg(depth=18):
     from bench import make_cfg
 
-    cfg = make_cfg(18)
+    cfg = make_cfg(depth)
     cfg.SOLVER.IMS_PER_BATCH = 2
     return cfg
 
 
-def _build(seed):
+def _build(seed, depth=18):
     from slenderobjdet_amd.modeling import build_model
     from slenderobjdet_amd.solver import build_lr_scheduler, build_optimizer
 
-    cfg = _cfg()
+    cfg = _cfg(depth)
     torch.manual_seed(seed)
     model = build_model(cfg)
     model.train()
@@ -304,17 +304,27 @@ def test_one_step_parity_along_the_100_iteration_trajectory(cuda, precision):
     print(f"\none-step parity along the trajectory ({precision}): worst loss delta {worst_loss:.2e} relative, worst update distance {worst_upd:.2e}")
 
 
-def test_free_100_iterations_on_shared_relu_decisions(cuda):
+FROZEN_PREFIX = ("backbone.bottom_up.stem", "backbone.bottom_up.res2")
+
+
+@pytest.mark.parametrize("mode,depth,iters,size", [("fp32", 18, ITERS, 512), ("fp32", 50, 30, 256), ("bf16", 18, ITERS, 512)])
+def test_free_run_on_shared_relu_decisions(cuda, mode, depth, iters, size):
     """north_star's sentence as a statement that CAN hold: "total-loss delta < 1e-3 vs the reference's CPU path after 100 iterations".
     Free-running fp32 implementations of this run end 2e-3 ... 1.3e-2 apart (test above, tests/golden/chaos100.json) - and round 4
     found out why: not rounding growth, but single ReLU decisions on pre-activations that cancel to within rounding of zero, which fall
     differently in every implementation and, through the sparse regression gradient, move whole weight-gradient tensors by 1e-3 ... 1e-2
-    (tests/test_gpu_f32_mode.py).  Here the product (fp32-storage validation mode) and the CPU fp32 oracle BOTH run free for the 100
-    iterations - own parameters, own momentum, same schedule - and the oracle takes, in every iteration, the product's ReLU decisions for
-    that batch (layers/functional_f32.RELU_TAP -> oracle.nn.ForcedMasks).  Both then descend the same piecewise-linear function; what
-    separates them is summation order, amplified by 100 SGD steps with a learning rate that grows 100x.  Asserted: |delta total loss|
-    < 1e-3 absolute at iteration 100 - north_star's number - and < 1e-5 at EVERY iteration (measured: 4.8e-7 at worst, i.e. the two
-    loss trajectories agree to the last bits of an fp32 number for all 100 iterations); the curve is written to gpurun_out/."""
+    (tests/test_gpu_f32_mode.py).  Here the product and the CPU fp32 oracle BOTH run free - own parameters, own momentum, same schedule -
+    and the oracle takes, in every iteration, the product's ReLU decisions for that batch (RELU_TAP of the product's layer code ->
+    oracle.nn.ForcedMasks).  Both then descend the same piecewise-linear function.  The decisions are checked, not trusted: they may
+    differ from the oracle's own only inside the undecided band |x| < tau * rms(x) of an activation (ForcedMasks ``outside``).
+
+    * ``fp32, 18``  the fp32-storage validation mode on BASELINE configs[0], 100 iterations: |delta total loss| < 1e-3 at iteration 100 -
+      north_star's number - and < 1e-5 at EVERY iteration (measured 4.8e-7 at worst); tau 1e-4.
+    * ``fp32, 50``  the same on the R50 family (configs[1] at 256x256, 30 iterations; round-4 verdict).
+    * ``bf16, 18``  the bf16 PRODUCT path (the MFMA kernels bench.py times, default float-atomic reductions) on configs[0], 100 iterations
+      against the plain fp32 oracle on the product's decisions: what is left is bf16 storage rounding, amplified by 100 SGD steps.  The
+      iteration-100 delta is REPORTED (gpurun_out/parity100_shared_relu_bf16_18.json) and held to the bound measured
+      for it; the fused frozen kernels (stem + pool) keep their ReLUs inside, so the oracle decides those itself (no gradient flows there)."""
     from bench import train_step
     from oracle.conditioning import ProductReluTap
     from oracle.model import OracleFCOS
@@ -322,46 +332,64 @@ def test_free_100_iterations_on_shared_relu_decisions(cuda):
     from slenderobjdet_amd.data import synthetic_batch
     from slenderobjdet_amd.layers import functional as HF
 
-    pool = [synthetic_batch(2, 512, 512, 100 + i, device="cuda") for i in range(4)]
+    pool = [synthetic_batch(2, size, size, 100 + i, device="cuda") for i in range(4)]
     cpu_pool = [_cpu(d) for d in pool]
     torch.set_num_threads(min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
-    prev_p, prev_d = HF.set_precision("fp32"), HF.DETERMINISTIC
-    HF.DETERMINISTIC = True
-    hip, ora, missed_any = [], [], 0
+    prev_p, prev_d = HF.set_precision(mode), HF.DETERMINISTIC
+    HF.DETERMINISTIC = mode == "fp32"
+    tau = 1e-4 if mode == "fp32" else 0.25       # bf16: the product's pre-activations carry ~1e-2 rms of storage rounding
+    hip, ora, flipped, units, worst_ratio = [], [], 0, 0, 0.0
     try:
-        cfg, model, opt, sched = _build(7)
+        cfg, model, opt, sched = _build(7, depth)
         oracle, state = OracleFCOS.from_hip_model(model), {}
-        for it in range(ITERS):
+        for it in range(iters):
             lr = opt.param_groups[0]["lr"]
             with ProductReluTap() as tap:
                 hip.append(float(train_step(model, opt, pool[it % len(pool)]).detach()))
             sched.step()
             masks, unmatched = tap.masks_for(model)
             assert not unmatched, (it + 1, unmatched[:3])
-            st = ForcedMasks.begin(masks)
+            st = ForcedMasks.begin(masks, tau=tau)
             try:
                 ref = oracle.losses(cpu_pool[it % len(cpu_pool)])
                 total = sum(ref.values())
                 grads = dict(zip(oracle.trainable().keys(), torch.autograd.grad(total, list(oracle.trainable().values()))))
             finally:
                 ForcedMasks.end()
-            missed_any += len(st["missed"])
+            # every ReLU a gradient flows through took the product's decision (the fp32 mode reports all of them)
+            missed = [k for k in st["missed"] if mode == "fp32" or not str(k[0]).startswith(FROZEN_PREFIX)]
+            assert not missed, (it + 1, missed[:5])
+            # the shared decisions are checked, not trusted: they may differ from the oracle's own only inside the undecided band
+            assert st["outside"] == 0, (it + 1, st["outside_at"][:5])
+            flipped += st["disagree"]
+            units += st["units"]
             oracle.sgd_step(grads, state, lr, cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY, cfg.SOLVER.WEIGHT_DECAY_NORM)
             ora.append(float(total.detach()))
     finally:
         HF.set_precision(prev_p)
         HF.DETERMINISTIC = prev_d
     d = [abs(a - b) for a, b in zip(hip, ora)]
-    print("\nfree run on shared ReLU decisions: |hip32 - cpu32| at iterations 1, 10, 20, ..., 100:",
-          " ".join(f"{d[i]:.1e}" for i in [0] + list(range(9, ITERS, 10))), f" max {max(d):.2e}  loss {hip[0]:.4f} -> {hip[-1]:.4f}")
+    print(f"\nfree run on shared ReLU decisions [{mode}, R{depth}, {iters} iterations]: |product - cpu32| at iterations 1, 10, 20, ...:",
+          " ".join(f"{d[i]:.1e}" for i in [0] + list(range(9, iters, 10))), f" max {max(d):.2e}  last {d[-1]:.2e}  loss {hip[0]:.4f} -> {hip[-1]:.4f}",
+          f" units decided differently (all inside the {tau:g} rms band): {flipped} of {units}")
     try:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-        json.dump({"hip32": hip, "cpu32_on_the_products_relu_decisions": ora, "abs_delta": d}, open(os.path.join(root, "gpurun_out", "parity100_shared_relu.json"), "w"), indent=1)
+        name = "parity100_shared_relu.json" if (mode, depth) == ("fp32", 18) else f"parity100_shared_relu_{mode}_{depth}.json"
+        json.dump({"mode": mode, "depth": depth, "product": hip, "cpu32_on_the_products_relu_decisions": ora, "abs_delta": d,
+                   "units_decided_differently": flipped, "units": units, "tau": tau}, open(os.path.join(root, "gpurun_out", name), "w"), indent=1)
     except OSError:
         pass
-    assert missed_any == 0
     assert all(x == x for x in hip)
-    assert d[-1] < 1e-3, d[-1]                      # north_star's bound ...
-    assert max(d) < 1e-5, max(d)                    # ... and what was measured: 4.8e-7 at worst over the 100 iterations (fp32 ulps of a loss of ~2)
-    assert hip[-1] < hip[0] - 0.3                   # and the run trained (2.84 -> 1.9 in the free runs above)
+    if mode == "fp32":
+        assert d[-1] < 1e-3, d[-1]                      # north_star's bound ...
+        assert max(d) < 1e-5, max(d)                    # ... and what was measured: 4.8e-7 at worst over 100 iterations (fp32 ulps of a loss of ~2)
+    else:
+        assert max(d) < BF16_SHARED_BOUND, (max(d), d[-1])
+    if iters >= 100:
+        assert hip[-1] < hip[0] - 0.3                   # and the run trained (2.84 -> 1.9 in the free runs above)
+
+
+# |bf16 product - fp32 oracle| over the 100 free iterations on shared decisions: measured in round 5; the bound is
+# 3 x that measurement
+BF16_SHARED_BOUND = 3e-2

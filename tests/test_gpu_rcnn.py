@@ -539,7 +539,7 @@ def test_rotated_rcnn_r101_step(cuda):
     from slenderobjdet_amd.modeling import build_model
     from slenderobjdet_amd.solver import build_optimizer
 
-    cfg = make_cfg(101, "rrcnn")
+    cfg = make_cfg(101, "rrcnn", constant_lr=True)      # the test steps the optimizer without the warm-up schedule
     torch.manual_seed(0)
     model = build_model(cfg)
     model.train()

@@ -259,7 +259,7 @@ def test_reppoints_r50_full_size_step(cuda):
     from slenderobjdet_amd.modeling import build_model
     from slenderobjdet_amd.solver import build_optimizer
 
-    cfg = make_cfg(50, "reppoints")
+    cfg = make_cfg(50, "reppoints", constant_lr=True)      # the test steps the optimizer without the warm-up schedule
     torch.manual_seed(0)
     model = build_model(cfg)
     model.train()

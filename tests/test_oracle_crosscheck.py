@@ -123,3 +123,32 @@ def test_oracle_retinanet_whole_step_is_consistent():
                     o64.p[n].sub_(sign * eps * d)
         numeric = (vals[0] - vals[1]) / (2 * eps)
         assert abs(numeric - analytic) <= 1e-3 * max(abs(analytic), 1e-6), (numeric, analytic)
+
+
+def test_forced_masks_report_decisions_outside_the_undecided_band():
+    """oracle.nn.ForcedMasks (the product's ReLU decisions handed to the oracle) must not be able to hide a wrong-sign pre-activation:
+    a forced decision that differs from the oracle's own is counted, and flagged when the unit lies outside |x| < tau * rms(x)."""
+    import torch
+
+    from oracle.nn import ForcedMasks, relu_at
+
+    torch.manual_seed(0)
+    x = torch.randn(2, 8, 5, 5)
+    x[0, 0, 0, 0] = 1e-7          # a unit both implementations hold to rounding of zero
+    own = x > 0
+    st = ForcedMasks.begin({("a", 0): own.clone()})
+    y = relu_at(x, "a")
+    ForcedMasks.end()
+    assert torch.equal(y, torch.relu(x)) and st["disagree"] == 0 and st["outside"] == 0 and st["units"] == x.numel() and not st["missed"]
+    m = own.clone()
+    m[0, 0, 0, 0] = False         # decided the other way inside the band: legitimate
+    st = ForcedMasks.begin({("a", 0): m})
+    relu_at(x, "a")
+    ForcedMasks.end()
+    assert st["disagree"] == 1 and st["outside"] == 0
+    big = (x.abs() > 1.0).nonzero()[0]
+    m[tuple(big)] = ~m[tuple(big)]     # a unit of magnitude ~rms decided the other way: a wrong pre-activation, not rounding
+    st = ForcedMasks.begin({("a", 0): m})
+    relu_at(x, "a")
+    ForcedMasks.end()
+    assert st["disagree"] == 2 and st["outside"] == 1 and st["outside_at"][0][:3] == ("a", 0, 1) and st["outside_at"][0][3] > 1.0

@@ -11,6 +11,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$
 SOD_WGRAD_STREAM=0 SOD_TOWER_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_serial -- $B > gpurun_out/${tag}_serial.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- $B > gpurun_out/${tag}_fetch.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- $B > gpurun_out/${tag}_write.log 2>&1
+# step time of the un-profiled command, for the step-level HBM rate in <tag>_pmc.json
+export SOD_PROFILE_MS_PER_STEP=$(timeout 300 $B 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])")
 python3 tools/summarize_profile.py ${tag} gpurun_out/${tag}_stats gpurun_out/${tag}_fetch gpurun_out/${tag}_write 7
 python3 tools/summarize_profile.py ${tag}_serial gpurun_out/${tag}_serial "" "" 7
 mkdir -p gpurun_out/profiles_${tag} && cp profiles/${tag}* gpurun_out/profiles_${tag}/

@@ -49,7 +49,11 @@ def main(tag, stats_dir, fetch_dir, write_dir, steps):
                 write_b = wr[k][0] / wr[k][1] * 1024.0
                 pmc[k] = {"launches": fe[k][1], "fetch_bytes_per_launch": round(fetch_b), "write_bytes_per_launch": round(write_b),
                           "hbm_bytes_per_launch": round(fetch_b + write_b)}
-        json.dump({"note": "per-launch averages over a bench.py run; FETCH_SIZE x2 correction applied (gfx950)", "kernels": pmc},
+        # ms_per_step: the step time of the kernel-stats run of the same command (span of its kernel trace is not kept; the bench line's
+        # ms_per_step of that run is passed in the environment by tools/profile_step.sh when known)
+        ms = os.environ.get("SOD_PROFILE_MS_PER_STEP")
+        json.dump({"note": "per-launch averages over a bench.py run; FETCH_SIZE x2 correction applied (gfx950)", "steps": steps,
+                   "ms_per_step": float(ms) if ms else None, "kernels": pmc},
                   open(os.path.join(out_dir, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
     print("wrote", tag, len(rows), "kernels;", len(pmc), "with PMC")
 
