@@ -163,8 +163,6 @@ def kernel_name(kind, code):
         return "stem_fused_kernel"
     if code == -8:
         return "bottleneck_frozen_kernel"
-    if code == -9:
-        return "bneck_pair_kernel"
     if kind == "conv_wgrad":
         if code == 256:
             return "sodconv::conv_wgrad256_kernel"
@@ -186,8 +184,6 @@ def algo_bytes(kind, desc):
         hw = list(zip(hs, ws))
     else:
         N, H, W, C, K, R, stride = desc[:7]
-        if R == "pair":       # expand + contract pair: narrow in, add operand in, wide out, narrow out, two weight matrices (C = CN, K = CW)
-            return N * H * W * (2 * C + 2 * K) * 2.0 + 2 * C * K * 2.0
         if R == "bneck":      # fused frozen bottleneck block: x in, 256-channel block output out, four weight matrices
             return N * H * W * (C + K) * 2.0 + (C * 64 + 64 * 64 * 9 + 64 * K + (C * K if C != K else 0)) * 2.0
         if R == 7 and C == 3:      # fused stem: uint8 RGB in, pooled 64-channel bf16 out
@@ -518,9 +514,8 @@ def main():
         scheduler = build_lr_scheduler(cfg, optimizer)
     loader = SyntheticCocoBatches(args.batch_per_gpu, args.height, args.width, rank=rank, device=dev, pool=2, rotated=args.arch == "rrcnn")
 
-    main_prio = os.environ.get("SOD_MAIN_PRIO")          # experiment: the whole step on a stream of another HIP priority (-1 = highest)
-    if main_prio is not None or os.environ.get("SOD_CUMASK_MAIN"):
-        _main = HF.make_stream(dev, int(main_prio or 0), "MAIN")
+    if os.environ.get("SOD_CUMASK_MAIN"):          # experiment: the whole step on a stream confined to a subset of the CUs (layers/functional.make_stream)
+        _main = HF.make_stream(dev, 0, "MAIN")
         _main.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(_main)
     sample_at = set() if args.no_roofline else (set(range(args.steps)) if args.dump_prof else set(range(args.steps // 2, args.steps, 32)))

@@ -119,16 +119,6 @@ int sod_conv2d_fwd_ml_gnsum(int nlev, const void* const* x, const void* w, const
 int sod_conv2d_dgrad_ml(int nlev, const void* const* dy, const void* wt, void* const* dx,
                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
                         long long dy_img_stride, void* stream);
-/* sod_conv2d_dgrad_ml whose output dx IS dL/d(relu(GroupNorm(gn_x))) - the data gradient of the conv that follows a tower unit
- * conv -> GroupNorm(32) -> ReLU (fcosv2.py:300-336) - with the reduction pass of that norm's backward gathered in the epilogue:
- * gn_x[l] = the norm's input (bf16, dx[l]'s shape), gn_mean_rstd = its saved statistics (nlev [N][G][2] blocks); on return
- * gn_red (nlev [N][G][2] blocks, zeroed by this call) holds (sum gm*gamma, sum gm*gamma*xhat) per (image, group) and dgamma / dbeta have
- * been incremented by sum gm*xhat / sum gm per channel (gm = dx masked by gamma*xhat+beta > 0).  C (dx channels) must equal 8 * G.
- * sod_groupnorm_bwd_apply_ml then needs one pass instead of two. */
-int sod_conv2d_dgrad_ml_gnbwd(int nlev, const void* const* dy, const void* wt, void* const* dx,
-                              int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
-                              long long dy_img_stride, const void* const* gn_x, const float* gn_mean_rstd, const float* gamma,
-                              const float* beta, float* gn_red, float* dgamma, float* dbeta, int G, void* stream);
 /* sod_conv2d_dgrad_ml with the ReLU backward of the tensors dx is the gradient of folded into the epilogue: dx[l] = relu_mask[l] > 0 ?
  * (data gradient) : 0, relu_mask[l] = the post-ReLU tensor (bf16, dx[l]'s shape).  Consecutive [conv3x3 -> ReLU] tower units
  * (RetinaNetHead, retina_rotated.py:418-430): the consumer's data gradient applies the producer's mask, one launch per level less. */
@@ -211,12 +201,6 @@ int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void* const* x, 
                          const float* mean_rstd, void* const* dx, float* dgamma, float* dbeta, float* dxsum, float* red_ws,
                          int N, const int* hw, int C, int G, int relu, float* det_ws, long long det_ws_bytes, void* stream);
 
-/* Second half of sod_groupnorm_bwd_ml for reductions that sod_conv2d_dgrad_ml_gnbwd gathered (red = its gn_red; dgamma / dbeta are
- * complete already): dx = rstd * (gm*gamma - (s1 + xhat*s2)/m), dxsum (optional) += per-channel sum of dx. */
-int sod_groupnorm_bwd_apply_ml(int nlev, const void* const* dy, const void* const* x, const float* gamma, const float* beta,
-                               const float* mean_rstd, void* const* dx, float* dxsum, const float* red, int N, const int* hw, int C,
-                               int G, int relu, void* stream);
-
 /* elementwise helpers on bf16 tensors of n elements (n % 8 == 0) */
 int sod_relu_fwd(const void* x, void* y, long long n, void* stream);
 int sod_relu_bwd(const void* dy, const void* y, void* dx, long long n, void* stream);
@@ -277,20 +261,6 @@ int sod_preprocess_batch(int n, const void* const* imgs, int is_uint8, int C, co
  * batch padded to (Hp, Wp) (multiples of 4; images are zero-padded bottom / right as ImageList.from_tensors does). */
 int sod_stem_fused(int n, const void* const* imgs, const int* H, const int* W, const void* w_packed, const float* bias,
                    void* out, int Hp, int Wp, const float* mean3, const float* std3, void* stream);
-/* Two chained 1x1 convolutions of a bottleneck chain in ONE launch (detectron2 BottleneckBlock under fpn.py:94-115): the
- * EXPANDING one (narrow CN -> wide CW channels, + add operand, + nonlinearity; the wide tensor is stored) and the CONTRACTING one (wide ->
- * narrow) that consumes it, so that the wide tensor is written once and never read back.  P = N*H*W pixels, NHWC bf16 rows.
- *   mode 0 (forward):  wide = relu(xin x we^T + bias_e + add), bits_out[e / 8] bit (e % 8) = wide[e] > 0 (optional);
- *                      narrow = relu(wide x wc^T + bias_c)          = conv3_i + residual + ReLU followed by conv1_{i+1} + ReLU
- *   mode 1 (backward): wide = bits_in ? xin x we^T + add : 0;  narrow = (mask2 > 0) ? wide x wc^T : 0
- *                      = the data gradient of conv1_k (+ identity-path gradient, masked with block k-1's output ReLU bits) followed by the
- *                        data gradient of conv3_{k-1} masked with the ReLU of its input
- * we [CW][CN], wc [CN][CW] bf16 (KRSC copies for mode 0, CRSK copies for mode 1), biases fp32 or NULL, add [P][CW] or NULL.
- * CN in {128, 256}, CW a multiple of 128.  Bit-identical to the two launches it replaces (same MFMA instruction and k order). */
-int sod_bottleneck_pair_supported(int CN, int CW);
-int sod_bottleneck_pair(const void* xin, const void* add, const void* we, const float* bias_e, const void* wc, const float* bias_c,
-                        const void* bits_in, const void* mask2, void* wide, void* bits_out, void* narrow,
-                        long long P, int CN, int CW, int mode, void* stream);
 /* A FROZEN bottleneck block of the ResNet body in ONE kernel (detectron2 BottleneckBlock with FrozenBatchNorm2d folded, as
  * build_resnet_backbone builds res2 under MODEL.BACKBONE.FREEZE_AT >= 2; reached from slender_det/modeling/backbone/fpn.py:103):
  *   out = relu(conv3(relu(conv2_3x3(relu(conv1(x))))) + shortcut(x)),  64 bottleneck channels, 256 output channels, stride 1.

@@ -34,8 +34,6 @@ _SIGS = {
     "sod_conv2d_dgrad_ml_mask": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "sod_conv2d_dgrad_ml_kpitch": [_I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "sod_conv2d_dgrad_ml_accum": [_I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P],
-    "sod_conv2d_dgrad_ml_gnbwd": [_I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "sod_groupnorm_bwd_apply_ml": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P],
     "sod_conv2d_wgrad_ml": [_I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _I, _I, _P, _L, _P],
     "sod_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _F, _I, _P, _L, _P],
     "sod_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P, _L, _P],
@@ -51,8 +49,6 @@ _SIGS = {
     "sod_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _P],
     "sod_upsample2x_bwd": [_P, _P, _I, _I, _I, _I, _P],
     "sod_conv2d_dgrad_cwin": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "sod_bottleneck_pair_supported": [_I, _I],
-    "sod_bottleneck_pair": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "sod_conv_set_tile256": [_I],
     "sod_conv_set_wgrad_variant": [_I],
     "sod_conv_set_reverse": [_I],

@@ -68,20 +68,12 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk) {
   return base + (bid >> 3);
 }
 
-// 16-byte global store of a kernel's OUTPUT tensor.  With SOD_WT_STORES the store is write-through (sc1): the line goes to memory now and
-// is dropped from this XCD's L2 instead of staying there dirty until the end-of-kernel release writes it back.  Every kernel boundary on
-// this 8-XCD part flushes the dirty lines of all L2s (the next kernel's workgroups may run on another XCD): MI355X_MICROARCH.md prices a
-// dependent boundary at 1.7-1.9 us plus dirty bytes / 6 TB/s, and the step's kernel trace shows ~6 us between consecutive kernels of one
-// queue (up to 32 MB dirty).  Outputs are never re-read by the kernel that writes them, so nothing is lost inside the kernel.
+// 16-byte global store of a kernel's OUTPUT tensor.  (Round 3 measured write-through "sc1" stores here - the end-of-kernel release then
+// finds no dirty lines in the eight L2s -: 616-619 -> 611-612 img/s, slower, because consumers on the same XCD lose their L2 hits; removed.)
 template <typename V>
 __device__ __forceinline__ void sod_store16(void* p, V v) {
   static_assert(sizeof(V) == 16, "16-byte vectors only");
-#ifdef SOD_WT_STORES
-  const f32x4_t w = __builtin_bit_cast(f32x4_t, v);
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
-#else
   *reinterpret_cast<V*>(p) = v;
-#endif
 }
 
 #define SOD_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -56,7 +56,7 @@ inline void prof_end(int i, hipStream_t st, int variant, float frac, int mode) {
   p.variant[i] = variant; p.frac[i] = frac; p.mode[i] = mode;
 }
 
-template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK, int NSTAGE, bool GNB = false>
+template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK, int NSTAGE>
 __global__ __launch_bounds__(64 * WQ * WP, (WQ * WP == 4 && BK == 32 && NSTAGE == 2) ? 4 : 2) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int NW = WQ * WP;                  // waves per workgroup (4 or 8)
   constexpr int BQ = WQ * FQ * 16, BP = WP * FP * 16;
@@ -360,8 +360,6 @@ __global__ __launch_bounds__(64 * WQ * WP, (WQ * WP == 4 && BK == 32 && NSTAGE =
       }
     }
     GnAcc ga{0.f, 0.f, -1};
-    GnBwdAcc gb;
-    if constexpr (GNB) gnb_init(gb, a.gnb_gamma, a.gnb_beta, q, qok);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       // Residual / mask operands of ALL passes of this half are requested before the accumulators go through LDS: one exposed
@@ -408,7 +406,6 @@ __global__ __launch_bounds__(64 * WQ * WP, (WQ * WP == 4 && BK == 32 && NSTAGE =
           if constexpr (MODE == MODE_DGRAD && !OUT_F32) {
             if (a.flags & F_MASKBITS) mbits[k] = ((const uint8_t*)g.mask)[(drow[k] + q) >> 3];
           }
-          if constexpr (GNB) maskv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.mask + drow[k] + q);      // the norm's input x
         }
       }
 #pragma unroll
@@ -474,7 +471,6 @@ __global__ __launch_bounds__(64 * WQ * WP, (WQ * WP == 4 && BK == 32 && NSTAGE =
               }
             }
             if constexpr (MODE == MODE_FWD) { if (a.flags & F_GNSTATS) gn_acc_add(ga, nimg[k], o, g.gn_sum, a.gn_G, q >> 3); }
-            if constexpr (GNB) gnb_add(gb, nimg[k], maskv[k], o, g.gnb_stats, g.gnb_red, a.gn_G, q >> 3);
           }
         }
       }
@@ -482,14 +478,6 @@ __global__ __launch_bounds__(64 * WQ * WP, (WQ * WP == 4 && BK == 32 && NSTAGE =
     if constexpr (!OUT_F32 && MODE == MODE_FWD) {
       if (a.flags & F_GNSTATS)
         gn_acc_finish<LPR>(ga, p0 + wp * FP * 16, p0 + wp * FP * 16 + FP * 16 - 1, (uint32_t)gP, g.div_hw, g.gn_sum, a.gn_G, q >> 3, qok, lane);
-    }
-    if constexpr (GNB) {
-      gnb_finish_groups<LPR>(gb, p0 + wp * FP * 16, p0 + wp * FP * 16 + FP * 16 - 1, (uint32_t)gP, g.div_hw, g.gnb_red, a.gn_G, q >> 3, qok, lane);
-      gnb_reduce_channels<LPR>(gb);          // this kernel only covers the tail of a launch (< half a round of 256-pixel tiles)
-      if (lane < LPR && qok) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { atomicAdd(a.gnb_dgamma + q + e, gb.dg[e]); atomicAdd(a.gnb_dbeta + q + e, gb.db[e]); }
-      }
     }
     return;
   }
@@ -851,7 +839,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
   }
 }
 
-template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK = 64, int NSTAGE = 2, bool GNB = false>
+template <int MODE, bool GENERIC, int WQ, int WP, int FQ, int FP, bool OUT_F32, int BK = 64, int NSTAGE = 2>
 int launch_conv(const ConvArgs& a0, hipStream_t st) {
   constexpr int BQ = WQ * FQ * 16, BP = WP * FP * 16;
   ConvArgs a = a0;
@@ -879,7 +867,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   size_t lds = a.T == 1 ? (size_t)(BQ + BP) * BK * 2 : lds_full;
   if (lds < epi) lds = epi;
   g_last_variant = BQ * 100000 + BP * 100 + BK + (GENERIC ? 1 : 0);
-  auto kern = conv_igemm_kernel<MODE, GENERIC, WQ, WP, FQ, FP, OUT_F32, BK, NSTAGE, GNB>;
+  auto kern = conv_igemm_kernel<MODE, GENERIC, WQ, WP, FQ, FP, OUT_F32, BK, NSTAGE>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_full > epi ? lds_full : epi));
@@ -896,14 +884,12 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
 thread_local int g_conv_reverse = 0;    // sod_conv_set_reverse: per calling thread (the forward thread and autograd's worker each bracket their own launches)
 int g_conv256_mode = -1;   // -1: read SOD_CONV256 (default 1); 0 off; 1 heuristic; 2 every supported shape
 
-template <int MODE, bool OUT_F32, bool GNB = false>
+template <int MODE, bool OUT_F32>
 int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   const bool generic = (a.Cred & 63) != 0 || a.R * a.S > 64;      // the linear path keeps one validity bit per tap in 64-bit masks
-  if constexpr (!GNB) {
-    if (a.cwin) {         // channel window: the window IS the 128-row q-tile of this variant; Cred = 128 -> never generic
-      if (generic || a.nlev != 1 || (a.Nout & 127)) return SOD_EARG;
-      return launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32>(a, st);
-    }
+  if (a.cwin) {         // channel window: the window IS the 128-row q-tile of this variant; Cred = 128 -> never generic
+    if (generic || a.nlev != 1 || (a.Nout & 127)) return SOD_EARG;
+    return launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32>(a, st);
   }
   // 256x256 8-phase kernel (conv_igemm256.hip) for the large compute-bound shapes.  SOD_CONV256=0 disables it, =2 forces it for
   // every shape it supports (parity tests).
@@ -916,12 +902,10 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   }
   bool any_start = false;
   for (int l = 0; l < a.nlev; ++l) any_start |= a.lev[l].pstart != 0;
-  // Data gradients use the 256 kernel as well (SOD_CONV256_DGRAD=0 keeps them on the 128x128 kernel).  Beside the wgrad side stream
-  // the answer depends on what the wgrad blocks leave free: with 3-4 small wgrad workgroups per CU the 128-KB workgroup rarely found
-  // a CU (490 vs 487.5 img/s in favour of 128x128); with two ring workgroups per CU and the faster wgrad it wins 542.4 vs 536.0.
-  static int c256_dgrad = -1;
-  if (c256_dgrad < 0) { const char* e = getenv("SOD_CONV256_DGRAD"); c256_dgrad = e ? atoi(e) : 1; }
-  if (c256 && !any_start && !(a.flags & (F_WBITS | F_MASKBITS)) && conv256_supported(a, MODE) && (MODE == MODE_FWD || c256_dgrad || c256 == 2)) {
+  // Data gradients use the 256 kernel as well.  Beside the wgrad side stream the answer depends on what the wgrad blocks leave free:
+  // with 3-4 small wgrad workgroups per CU the 128-KB workgroup rarely found a CU (490 vs 487.5 img/s in favour of 128x128); with two
+  // ring workgroups per CU and the faster wgrad it wins 542.4 vs 536.0.
+  if (c256 && !any_start && !(a.flags & (F_WBITS | F_MASKBITS)) && conv256_supported(a, MODE)) {
     const int nq = (a.Nout + 255) / 256;
     long long pt256 = 0;
     for (int l = 0; l < a.nlev; ++l) pt256 += (a.lev[l].P + 255) / 256;
@@ -929,26 +913,27 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     if (c256 == 2) {
       g_last_variant = 256;
       const int pi = prof_begin(st);
-      const int rc = launch_conv256(a, MODE, OUT_F32, 0, st, GNB);
+      const int rc = launch_conv256(a, MODE, OUT_F32, 0, st);
       prof_end(pi, st, 256, 1.f, MODE);
       return rc;
     }
-    static const int min_rounds = getenv("SOD_CONV256_MIN_ROUNDS") ? atoi(getenv("SOD_CONV256_MIN_ROUNDS")) : 1;
-    static const int min_k = getenv("SOD_CONV256_MIN_K") ? atoi(getenv("SOD_CONV256_MIN_K")) : 1024;
-    // output-channel counts that are no multiple of 256 (RetinaNet's 720 class scores: the third q-tile is 19 % empty) from 512 channels up
-    static const int anyn = getenv("SOD_CONV256_ANYN") ? atoi(getenv("SOD_CONV256_ANYN")) : 1;
-    if (a.Nout >= 256 && ((a.Nout & 255) == 0 || (anyn && a.Nout >= 512)) && a.Kred >= min_k && b256 >= (long long)min_rounds * cus) {
+    // (thresholds swept in rounds 2 - 4, DESIGN.md section 4: contraction >= 1024 - 512 / 256 measured 587-588 / 575 vs 593 img/s -, at
+    // least one full round of tiles, output-channel counts that are no multiple of 256 - RetinaNet's 720 class scores: the third q-tile
+    // is 19 % empty - from 512 channels up)
+    constexpr int min_rounds = 1, min_k = 1024;
+    if (a.Nout >= 256 && ((a.Nout & 255) == 0 || a.Nout >= 512) && a.Kred >= min_k && b256 >= (long long)min_rounds * cus) {
       // Measured (16 x FPN levels, 256 -> 256 3x3): 1020-1040 TFLOP/s against 840-930 for the 128x128 kernel.  Shapes with barely more
       // than one round of tiles (res4 conv2: 263 tiles = one round + a 7-tile remainder launch) measured slower stand-alone but win in
-      // the training step (545.8-546.3 vs 541.2-542.9 img/s), so one full round is enough (SOD_CONV256_MIN_ROUNDS).
+      // the training step (545.8-546.3 vs 541.2-542.9 img/s), so one full round is enough.
       // One workgroup per CU: a partial last round of 256x256 tiles wastes up to a whole round.  Whole rounds go to the 256 kernel,
       // a remainder below half a round is computed by the 128x128 kernel (two workgroups per CU, 4x smaller tiles) instead
-      // (P3 output conv, 4.1 rounds: 1035 -> 1075 TFLOP/s).
+      // (P3 output conv, 4.1 rounds: 1035 -> 1075 TFLOP/s).  Round 5 re-measured the threshold on the step - remainders up to 50 / 30 /
+      // 12 / 5 % of a round split off: 633.2 / 631.7 / 634.6 / 631.0 img/s, three alternating 100-step runs each - no difference.
       const long long full = b256 / cus * cus, rem = b256 - full;
       if (rem == 0 || rem * 2 >= (long long)cus || (full / nq) * nq != full) {
         g_last_variant = 256;
         const int pi = prof_begin(st);
-        const int rc = launch_conv256(a, MODE, OUT_F32, 0, st, GNB);
+        const int rc = launch_conv256(a, MODE, OUT_F32, 0, st);
         prof_end(pi, st, 256, 1.f, MODE);
         return rc;
       }
@@ -956,7 +941,7 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
       long long ptot = 0;
       for (int l = 0; l < a.nlev; ++l) ptot += a.lev[l].P;
       const int pi = prof_begin(st);
-      int rc = launch_conv256(a, MODE, OUT_F32, main_pt, st, GNB);
+      int rc = launch_conv256(a, MODE, OUT_F32, main_pt, st);
       prof_end(pi, st, 256, (float)((double)main_pt * 256.0 / (double)ptot), MODE);     // main tiles are full 256-pixel tiles
       if (rc) return rc;
       ConvArgs tail = a;
@@ -966,59 +951,32 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
         else { tail.lev[l].pstart = main_pt * 256; main_pt = 0; }
       }
       ++g_prof_depth;            // the tail launch belongs to this dispatch: no event pair of its own
-      rc = dispatch_conv<MODE, OUT_F32, GNB>(tail, st);
+      rc = dispatch_conv<MODE, OUT_F32>(tail, st);
       --g_prof_depth;
       g_last_variant = 256;      // whole rounds on the 256 kernel (+ a short 128x128 tail launch)
       return rc;
     }
   }
-  if constexpr (GNB) {       // the one 128x128 instantiation that carries the GroupNorm-backward epilogue (256-channel tower tensors)
-    if (generic) return SOD_EARG;
-    return launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32, 64, 2, true>(a, st);
-  }
   if (a.Nout <= 16) {
     return generic ? launch_conv<MODE, true, 1, 4, 1, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 1, 4, 1, 4, OUT_F32>(a, st);
   } else if (a.Nout <= 64) {
-    static int n64_bk = -1;
-    if (n64_bk < 0) { const char* e = getenv("SOD_CONV_N64_BK"); n64_bk = e ? atoi(e) : 32; }   // 4 blocks per CU for the res2-sized convs: +0.3 % on the step
-    if (!generic && n64_bk == 32 && (a.Cred & 31) == 0) return launch_conv<MODE, false, 1, 4, 4, 4, OUT_F32, 32>(a, st);
+    // BK = 32: 4 blocks per CU for the res2-sized convs, +0.3 % on the step
+    if (!generic && (a.Cred & 31) == 0) return launch_conv<MODE, false, 1, 4, 4, 4, OUT_F32, 32>(a, st);
     return generic ? launch_conv<MODE, true, 1, 4, 4, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 1, 4, 4, 4, OUT_F32>(a, st);
   }
   // BK = 32 halves the LDS footprint (4 resident blocks per CU instead of 2): measured better for the latency-/write-bound
   // cases - short contractions - and worse for the large compute-bound shapes (head 3x3: 820 vs 699 TFLOP/s).
-  // SOD_CONV_BK=32|64 forces one variant (experiments).
-  static int force_bk = -1;
-  if (force_bk < 0) { const char* e = getenv("SOD_CONV_BK"); force_bk = e ? atoi(e) : 0; }
   long long blocks = 0;
   for (int l = 0; l < a.nlev; ++l) blocks += (a.lev[l].P - a.lev[l].pstart + 127) / 128;
   blocks *= (a.Nout + 127) / 128;
   // Re-measured per shape after the epilogue fix (serial run, best of the two variants 19.4 vs 19.9 ms of conv per step): grids that fit
   // one round of two blocks per CU want BK = 64 (P5/P6 3x3: 44 vs 54 us); otherwise BK = 32 also wins for Kred <= 512 (the 512-channel
   // 1x1 convs: 276 vs 300 us) and for the 128-channel 3x3 convs.
-  bool use32 = !generic && (a.Cred & 31) == 0 && blocks > 512 &&
-               (a.Kred <= 512 || blocks <= 1024 || (a.Cred <= 128 && a.Kred <= 1152));
-  static int dgrad_bk = -1;
-  if (dgrad_bk < 0) { const char* e = getenv("SOD_DGRAD_BK"); dgrad_bk = e ? atoi(e) : 0; }
-  if (MODE == MODE_DGRAD && dgrad_bk == 32) use32 = !generic && (a.Cred & 31) == 0;
-  if (force_bk == 32) use32 = !generic && (a.Cred & 31) == 0;
-  if (force_bk == 64) use32 = false;
-  // SOD_CONV_RING=3|4|5 (EXPERIMENT): deeper LDS ring for the 32-deep K-steps of the short-K convolutions (bf16 outputs only)
-  static int ring = -1;
-  if (ring < 0) { const char* e = getenv("SOD_CONV_RING"); ring = e ? atoi(e) : 0; }
-  if constexpr (!OUT_F32) {
-    if (use32 && ring >= 3 && a.T >= 3) {
-      if (ring == 3) return launch_conv<MODE, false, 2, 2, 4, 4, false, 32, 3>(a, st);
-      if (ring == 4) return launch_conv<MODE, false, 2, 2, 4, 4, false, 32, 4>(a, st);
-      return launch_conv<MODE, false, 2, 2, 4, 4, false, 32, 5>(a, st);
-    }
-  }
+  const bool use32 = !generic && (a.Cred & 31) == 0 && blocks > 512 &&
+                     (a.Kred <= 512 || blocks <= 1024 || (a.Cred <= 128 && a.Kred <= 1152));
+  // (Measured and removed in round 5: a 3 / 4 / 5-slot LDS ring for the 32-deep K-steps - 113 -> 117 / 114 / 114 us on res3 conv3, -30 %
+  // where it halves the workgroups per CU - and a 128(q) x 256(p) 8-wave tile with a 3-slot ring, 717 vs 813 TFLOP/s on the head shape.)
   if (use32) return launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32, 32>(a, st);
-  // EXPERIMENT (off by default, SOD_CONV_T256=1): 128(q) x 256(p) tile, 8 waves, 3-deep LDS ring with counted vmcnt, one
-  // workgroup per CU.  Measured SLOWER than two independent 4-wave workgroups per CU with a 2-deep ring on the head shape
-  // (717 vs 813 TFLOP/s fwd): the extra prefetch depth does not pay for coupling 8 waves to one barrier.
-  static int t256 = -1;
-  if (t256 < 0) { const char* e = getenv("SOD_CONV_T256"); t256 = e ? atoi(e) : 0; }
-  if (t256 && !generic && blocks > 2048 && a.Kred >= 512) return launch_conv<MODE, false, 2, 4, 4, 4, OUT_F32, 64, 3>(a, st);
   return generic ? launch_conv<MODE, true, 2, 2, 4, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32>(a, st);
 }
 
@@ -1078,16 +1036,15 @@ bool use_wgrad256(const WgradArgs& a, float* ws, long long ws_bytes) {
   // Blocks with few K-tiles are dominated by their 256-KB slab write, and the 48-KB workgroups of the 128x128 kernel share CUs with the
   // data-gradient kernels on the other stream.  Swept on the FCOS R50 step (one box, two rounds): >= 6 K-tiles per block 572.1 / 573.5
   // img/s, >= 40: 575.5 / 576.5, >= 70: 576.7 / 577.4, >= 120: 576.6 / 577.2, >= 250 (head towers off the 256 kernel): 565.6 / 566.1.
-  static const int min_kt = getenv("SOD_WGRAD256_MIN_KT") ? atoi(getenv("SOD_WGRAD256_MIN_KT")) : 64;
+  // (re-swept with the faster kernel in round 4: 64 still best - 635.6 / 634.3 vs 633.2 at 32, 627-628 at 16 / 8)
+  constexpr int min_kt = 64;
   if (!mode || !ws || !wgrad256_supported(a)) return false;
   const int cus = device_cus();
   if (wgrad256_workspace_bytes(a, cus) > ws_bytes) return false;
   if (mode == 2) return true;
   // The kernel masks a partial last q-tile (K = 720 of RetinaNet's class scores: 27 tiles of which 9 are 19 % empty).  Until round 4 that
   // shape measured slower on it than on the 128x128 kernel (RetinaNet R50 527.5 / 527.1 vs 533.0 / 531.2 img/s); with the row arithmetic
-  // out of the K loop it wins (546.6 / 548.5 vs 542.1 / 540.4; the 128x128 launch took 2.6 ms).  SOD_WGRAD256_ANYK=0: multiples of 256 only.
-  static const int anyk = getenv("SOD_WGRAD256_ANYK") ? atoi(getenv("SOD_WGRAD256_ANYK")) : 1;
-  if ((a.K & 255) && !anyk) return false;
+  // out of the K loop it wins (546.6 / 548.5 vs 542.1 / 540.4; the 128x128 launch took 2.6 ms).
   long long V = 0;
   for (int l = 0; l < a.nlev; ++l) V += (a.lev[l].P + 63) / 64 * 64;
   const long long tiles = (long long)((a.K + 255) / 256) * (a.C / 256) * a.R * a.S;
@@ -1099,8 +1056,7 @@ int g_wgrad_variant = -1;    // sod_conv_set_wgrad_variant
 
 // Which variant of conv_wgrad_ring.hip a weight gradient takes (0 = conv_wgrad_kernel below).
 int ring_variant_for(const WgradArgs& a, int tiles, int splits, float* ws, long long ws_bytes) {
-  static const int env = getenv("SOD_WGRAD_VARIANT") ? atoi(getenv("SOD_WGRAD_VARIANT")) : -1;
-  const int v = g_wgrad_variant >= 0 ? g_wgrad_variant : env;
+  const int v = g_wgrad_variant;
   if (a.diag) return 0;          // grouped convolutions: conv_wgrad_kernel's diagonal-tile mode only
   if (v >= 0) return v;
   // Measured per shape (tools/bench_wgrad_backbone.py, FCOS R50 at batch 16): the two groups of a workgroup halve the atomic bytes
@@ -1124,9 +1080,8 @@ int launch_wgrad(WgradArgs& a, int splits, int flags, hipStream_t st, float* ws 
     prof_end(pi, st, 256, 1.f, 2);
     return rc;
   }
-  // few output channels (prediction convolutions): the taps folded into the tile rows, conv_wgrad_fold.hip.  SOD_WGRAD_FOLD=0 disables.
-  static const int fold = getenv("SOD_WGRAD_FOLD") ? atoi(getenv("SOD_WGRAD_FOLD")) : 1;
-  if (fold && splits == 0 && wgrad_fold_supported(a)) {
+  // few output channels (prediction convolutions): the taps folded into the tile rows, conv_wgrad_fold.hip
+  if (splits == 0 && wgrad_fold_supported(a)) {
     const int pi = prof_begin(st);
     const int rc = launch_wgrad_fold(a, device_cus(), st);
     prof_end(pi, st, 32004, 1.f, 2);
@@ -1181,24 +1136,15 @@ int launch_wgrad(WgradArgs& a, int splits, int flags, hipStream_t st, float* ws 
       return SOD_OK;
     }
   }
-  // Pixels per K-step: 64 (two slots, 64 KB LDS, 175 VGPRs) or 32 (three-slot ring, 48 KB, 131 VGPRs; the default for every shape).  In
-  // the training step the wgrad kernels run on the side stream BESIDE the data-gradient kernels, so the LDS footprint counts as well as
-  // the stand-alone rate, and the best setting moved every time one of the kernels changed.  Last sweep on the FCOS R50 step (same box;
-  // 256x256 data gradients): ring everywhere, 3 workgroups per CU for the many-tile shapes and 2 for the rest 550.8-551.5 img/s; 2 / 2
-  // 549.4-550.5; 64-pixel steps for the few-tile shapes 544-547.  SOD_WGRAD_KP=32|64 forces one size, SOD_WGRAD_PC_BIG / _PC_SMALL the counts.
-  static const int kp_env = getenv("SOD_WGRAD_KP") ? atoi(getenv("SOD_WGRAD_KP")) : 0;
-  static const int kp_small = getenv("SOD_WGRAD_KP_SMALL") ? atoi(getenv("SOD_WGRAD_KP_SMALL")) : 32;
-  static const int pc_small = getenv("SOD_WGRAD_PC_SMALL") ? atoi(getenv("SOD_WGRAD_PC_SMALL")) : 2;
-  const int kp = kp_env ? kp_env : (tiles >= 36 ? 32 : kp_small);
+  // 32 pixels per K-step, three-slot LDS ring (48 KB, 131 VGPRs) for every shape.  In the training step the wgrad kernels run on the side
+  // stream BESIDE the data-gradient kernels, so the LDS footprint counts as well as the stand-alone rate.  Last sweeps on the FCOS R50 step
+  // (rounds 1 - 2): ring everywhere, 2 workgroups per CU 581.2 / 581.0 img/s, 3 per CU 576.1 / 575.2, 1: 564; 64-pixel steps with two
+  // slots for the few-tile shapes 544-547 vs 550.8-551.5 (those variants left the tree in round 5).
   if (splits <= 0) {
-    // ONE resident wave of blocks (2 or 4 per CU): measured on the head shape, 504 blocks run at 718 TFLOP/s where 1548 blocks
+    // ONE resident wave of blocks (2 per CU): measured on the head shape, 504 blocks run at 718 TFLOP/s where 1548 blocks
     // (3.02 waves -> a nearly empty 4th round, 3x the atomic traffic) run at 585.  At least 256 pixels per block.
     const int cus = device_cus();
-    static const int per_cu_env = getenv("SOD_WGRAD_PER_CU") ? atoi(getenv("SOD_WGRAD_PER_CU")) : 0;
-    // re-swept with the 256x256 kernel taking the large shapes (round 2, one box): 3 per CU 576.1 / 575.2, 2 per CU 581.2 / 581.0, 1: 564
-    static const int pc_big = getenv("SOD_WGRAD_PC_BIG") ? atoi(getenv("SOD_WGRAD_PC_BIG")) : 2;
-    const int slots = (per_cu_env > 0 ? per_cu_env : (tiles >= 36 ? (kp == 32 ? pc_big : 2) : pc_small)) * cus;
-    splits = slots / tiles;
+    splits = 2 * cus / tiles;
     const int maxs = (int)((Ptot + 255) / 256);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
@@ -1208,31 +1154,18 @@ int launch_wgrad(WgradArgs& a, int splits, int flags, hipStream_t st, float* ws 
   a.v_per_split = vps;
   a.nz = (V + vps - 1) / vps;
   a.div_s = make_fastdiv((uint32_t)a.S);
-  static const int dbg_plain = getenv("SOD_WGRAD_PLAIN") ? atoi(getenv("SOD_WGRAD_PLAIN")) : 0;
-  a.dbg_plain_store = dbg_plain;
-  const size_t lds = 2 * 2 * 64 * 256;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
-  // Two-stage reduction (fp32 partial tiles in the workspace + wgrad_reduce_kernel).  Deterministic mode always takes it and sums in
-  // a fixed order with plain read-modify-writes; otherwise it is an opt-in experiment for shapes where few tiles share many splits
-  // (SOD_WGRAD_TWO_STAGE=1: 447.4 vs 447.5 img/s on the FCOS R50 step) and the blocks meet in dW with fp32 atomics.
-  static const int two_stage = getenv("SOD_WGRAD_TWO_STAGE") ? atoi(getenv("SOD_WGRAD_TWO_STAGE")) : 0;
+  a.dbg_plain_store = 0;
+  // Deterministic mode: fp32 partial tiles in the workspace + wgrad_reduce_kernel, summed in a fixed order with plain read-modify-writes;
+  // otherwise the blocks meet in dW with fp32 atomics (the two-stage form as an option measured 447.4 vs 447.5 img/s, round 1).
   const long long need = (long long)a.nz * tiles * 128 * 128 * (long long)sizeof(float);
   if (a.det) {
     if (!ws || need > ws_bytes) return SOD_EARG;      // deterministic mode never falls back to atomics
     a.partial = ws;
   } else {
-    a.partial = (two_stage && ws && a.nz >= 8 && tiles <= 32 && need <= ws_bytes) ? ws : nullptr;
+    a.partial = nullptr;
   }
-  static const int ring = getenv("SOD_WGRAD_RING") ? atoi(getenv("SOD_WGRAD_RING")) : 1;
   const int pi = prof_begin(st);
-  if (kp == 32 && ring) SOD_LAUNCH((conv_wgrad_kernel<32, 3>), dim3(a.nz * tiles), dim3(256), 3 * 2 * 32 * 256, st, a);
-  else if (kp == 32) SOD_LAUNCH((conv_wgrad_kernel<32, 2>), dim3(a.nz * tiles), dim3(256), lds / 2, st, a);
-  else SOD_LAUNCH((conv_wgrad_kernel<64, 2>), dim3(a.nz * tiles), dim3(256), lds, st, a);
+  SOD_LAUNCH((conv_wgrad_kernel<32, 3>), dim3(a.nz * tiles), dim3(256), 3 * 2 * 32 * 256, st, a);
   if (a.partial) {
     const int gx = (tiles * 128 * 32 + 255) / 256;
     int gy = (1024 + gx - 1) / gx;            // ~1024 workgroups in total
@@ -1240,7 +1173,7 @@ int launch_wgrad(WgradArgs& a, int splits, int flags, hipStream_t st, float* ws 
     if (gy < 1 || a.det) gy = 1;
     SOD_LAUNCH(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, a);
   }
-  prof_end(pi, st, kp == 32 ? (ring ? 32003 : 32002) : 64002, 1.f, 2);
+  prof_end(pi, st, 32003, 1.f, 2);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
@@ -1573,33 +1506,6 @@ extern "C" int sod_conv2d_wgrad(const void* dy, const void* x, float* dw, const 
 // Workspace that lets every shape of one launch take the slab path: one 256x256 fp32 partial tile per CU plus the rounding of the
 // split count, doubled for grids of more than one round (tiles > CUs).
 extern "C" long long sod_conv2d_wgrad_workspace_bytes(void) { return 160ll << 20; }
-
-extern "C" int sod_conv2d_dgrad_ml_gnbwd(int nlev, const void* const* dy, const void* wt, void* const* dx,
-                                         int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,
-                                         long long dy_img_stride, const void* const* gn_x, const float* gn_mean_rstd, const float* gamma,
-                                         const float* beta, float* gn_red, float* dgamma, float* dbeta, int G, void* stream) {
-  if (!dy || !wt || !dx || !H || !W || !gn_x || !gn_mean_rstd || !gamma || !beta || !gn_red || !dgamma || !dbeta) return SOD_EARG;
-  if (G <= 0 || C != 8 * G || (K & 63)) return SOD_EARG;      // a lane's 8 output channels = one group; linear (non-generic) contraction
-  ConvArgs a{};
-  int rc = fill_common(a, nlev, N, K, C, R, S, stride, pad, dil);
-  if (rc) return rc;
-  for (int l = 0; l < nlev; ++l) {
-    const int Ho = out_size(H[l], pad, dil, R, stride), Wo = out_size(W[l], pad, dil, S, stride);
-    if (Ho <= 0 || Wo <= 0 || !gn_x[l]) return SOD_EARG;
-    rc = fill_level(a, l, dy[l], dx[l], Ho, Wo, H[l], W[l], dy_img_stride, 0, 2);
-    if (rc) return rc;
-    a.lev[l].mask = gn_x[l];
-    a.lev[l].gnb_stats = gn_mean_rstd + (size_t)l * N * G * 2;
-    a.lev[l].gnb_red = gn_red + (size_t)l * N * G * 2;
-  }
-  a.w = wt; a.bias = nullptr;
-  a.flags = F_GNBWD;
-  a.gn_G = G; a.gnb_gamma = gamma; a.gnb_beta = beta; a.gnb_dgamma = dgamma; a.gnb_dbeta = dbeta;
-  hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(gn_red, 0, sizeof(float) * 2 * (size_t)N * G * nlev, st);
-  if (e != hipSuccess) return (int)e;
-  return dispatch_conv<MODE_DGRAD, false, true>(a, st);
-}
 
 extern "C" int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, float* dw, const float* qscale,
                                    int N, const int* H, const int* W, int C, int K, int R, int S, int stride, int pad, int dil,

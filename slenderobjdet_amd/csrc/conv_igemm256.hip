@@ -62,7 +62,7 @@ __device__ __forceinline__ void mma_half(f32x4_t (&acc)[8][4], const bf16x8_t (&
   __builtin_amdgcn_s_setprio(0);                                          \
   __builtin_amdgcn_s_barrier();
 
-template <int MODE, bool OUT_F32, bool GNB = false>
+template <int MODE, bool OUT_F32>
 __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -266,13 +266,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
     }
   }
   GnAcc ga{0.f, 0.f, -1};
-  GnBwdAcc gb;
-  if constexpr (GNB) gnb_init(gb, a.gnb_gamma, a.gnb_beta, q, qok);
   // ---- bf16 whole-tile path (round 4): without a residual operand, bias and ReLU commute with the layout change, so they are applied in
   // the ACCUMULATOR layout and the wave's whole 64-pixel x 128-channel tile goes through LDS once as bf16 (16 KB per wave: 32 8-byte writes,
   // one wait, 16 16-byte reads, one wait) instead of four fp32 passes of 16 pixel rows with a write -> wait -> read -> wait chain each: the
   // epilogue of a tile is a latency chain on two waves per SIMD, not a bandwidth problem.  Same values bit for bit (one rounding either way).
-  if constexpr (!OUT_F32 && !GNB) {
+  if constexpr (!OUT_F32) {
     if (!(a.flags & (F_RES | F_RES_UP2))) {
       char* w16 = smem + wave * (64 * E16_PITCH);
 #pragma unroll
@@ -359,7 +357,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
           resv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.res + res_row + q);
         }
         if (a.flags & F_MASK) maskv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.mask + drow[k] + q);
-        if constexpr (GNB) maskv[k] = *reinterpret_cast<const RV*>((const __bf16*)g.mask + drow[k] + q);      // the norm's input x
       }
     }
 #pragma unroll
@@ -399,7 +396,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
           for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
           sod_store16((__bf16*)g.dst + drow[k] + q, o);
           if constexpr (MODE == MODE_FWD) { if (a.flags & F_GNSTATS) gn_acc_add(ga, nimg[k], o, g.gn_sum, a.gn_G, q >> 3); }
-          if constexpr (GNB) gnb_add(gb, nimg[k], maskv[k], o, g.gnb_stats, g.gnb_red, a.gn_G, q >> 3);
         }
       }
     }
@@ -408,28 +404,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
     if (a.flags & F_GNSTATS)
       gn_acc_finish<LPR>(ga, (uint32_t)(p0 + wc * 64), (uint32_t)(p0 + wc * 64 + 63), (uint32_t)gP, g.div_hw, g.gn_sum, a.gn_G, q >> 3, qok, lane);
   }
-  if constexpr (GNB) {
-    gnb_finish_groups<LPR>(gb, (uint32_t)(p0 + wc * 64), (uint32_t)(p0 + wc * 64 + 63), (uint32_t)gP, g.div_hw, g.gnb_red, a.gn_G, q >> 3, qok, lane);
-    // dgamma / dbeta: every workgroup of the launch adds to the same 2 * Nout addresses, so the four waves that own the same channels
-    // are summed through LDS first (beyond the epilogue staging of the 8 waves) and the workgroup issues ONE atomic per address
-    // (per-wave atomics: 4x the operations on 512 hot addresses made the launch 10 % slower than the pass it replaces).
-    gnb_reduce_channels<LPR>(gb);
-    float* rl = reinterpret_cast<float*>(smem + 96 * 1024);
-    if (lane < LPR) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { rl[(wave * 16 + lane) * 16 + e] = gb.dg[e]; rl[(wave * 16 + lane) * 16 + 8 + e] = gb.db[e]; }
-    }
-    __syncthreads();
-    const int t_wr = tid >> 8, t_l = (tid >> 4) & 15, t_v = tid & 15;
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) sum += rl[((t_wr * 4 + c) * 16 + t_l) * 16 + t_v];
-    const int qq = q0 + t_wr * QW + t_l * 8 + (t_v & 7);
-    if (qq < Nout) atomicAdd((t_v < 8 ? a.gnb_dgamma : a.gnb_dbeta) + qq, sum);
-  }
 }
 
-template <int MODE, bool OUT_F32, bool GNB = false>
+template <int MODE, bool OUT_F32>
 int launch256(const ConvArgs& a0, int max_pt_tiles, hipStream_t st) {
   ConvArgs a = a0;
   a.T = a.Kred / 64;
@@ -443,7 +420,7 @@ int launch256(const ConvArgs& a0, int max_pt_tiles, hipStream_t st) {
     tiles += (a.lev[l].P + 255) / 256;
   }
   a.np_tiles = (max_pt_tiles > 0 && max_pt_tiles < tiles) ? max_pt_tiles : tiles;
-  auto kern = conv_igemm256_kernel<MODE, OUT_F32, GNB>;
+  auto kern = conv_igemm256_kernel<MODE, OUT_F32>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -463,9 +440,8 @@ bool conv256_supported(const ConvArgs& a, int mode) {
   return true;
 }
 
-int launch_conv256(const ConvArgs& a, int mode, bool out_f32, int max_pt_tiles, hipStream_t st, bool gnb) {
+int launch_conv256(const ConvArgs& a, int mode, bool out_f32, int max_pt_tiles, hipStream_t st) {
   if (!conv256_supported(a, mode)) return SOD_EARG;
-  if (gnb) return (mode == MODE_DGRAD && !out_f32) ? launch256<MODE_DGRAD, false, true>(a, max_pt_tiles, st) : SOD_EARG;
   if (mode == MODE_FWD) return out_f32 ? launch256<MODE_FWD, true>(a, max_pt_tiles, st) : launch256<MODE_FWD, false>(a, max_pt_tiles, st);
   return out_f32 ? launch256<MODE_DGRAD, true>(a, max_pt_tiles, st) : launch256<MODE_DGRAD, false>(a, max_pt_tiles, st);
 }

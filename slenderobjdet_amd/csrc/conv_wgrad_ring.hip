@@ -15,9 +15,8 @@
 //   * that pass also changes the layout: a wave instruction of the global epilogue covers 256 CONTIGUOUS bytes of one dW row (the shape
 //     MI355X_MICROARCH.md measures at the full atomic rate), or, with a workspace (EPI = 1), the combined tile goes out as a [128][128]
 //     slab with 16-B stores and wgrad_reduce_kernel (conv_igemm.hip) sums the slabs of a tile in fixed order: no atomics;
-//   * FDB: the 16 transposing fragment reads of K-step it+1 are issued before the 16 MFMAs of step it (second fragment register set;
-//     an 8-wave workgroup has 256 registers per lane), so the lgkmcnt(0) -> MFMA chain of a step no longer depends on other
-//     workgroups to hide it.  The memory prefetch distance is unchanged: NSTAGE - 1 tiles in flight either way.
+//   (Round 4 also built fragment double-buffering - the 16 transposing reads of K-step it+1 issued before the MFMAs of step it - and a
+//   four-slot ring; both measured neutral, profiles/r4_wgrad_variants.txt, and left the tree in round 5.)
 // One barrier per K-step for the whole workgroup; groups whose pixel range is shorter (the last split) keep staging dead (zero-fill)
 // tiles so that every thread issues the same number of LDS-DMA loads per step and the counted wait stays valid.
 #include "conv_args.h"
@@ -49,7 +48,7 @@ struct RFrag {
 
 // ABL (measurement builds only, -DSOD_RING_ABLATION): 1 = no MFMAs, 2 = no fragment reads, 4 = no global epilogue, 8 = no X loads,
 // 16 = no dY loads - what the K loop costs without one of its parts (tools/bench_wgrad_backbone.py).
-template <int G, int NSTAGE, int EPI, bool FDB, int ABL = 0>
+template <int G, int NSTAGE, int EPI, int ABL = 0>
 __global__ __launch_bounds__(256 * G, 2) void conv_wgrad_ring_kernel(const WgradArgs a) {
   static_assert(G == 1 || G == 2, "one or two groups of four waves");
   static_assert(NSTAGE == 3 || NSTAGE == 4, "ring of three or four slots");
@@ -248,7 +247,7 @@ __global__ __launch_bounds__(256 * G, 2) void conv_wgrad_ring_kernel(const Wgrad
 #pragma unroll
   for (int d = 0; d < D; ++d) stage(d, ring + d * RSTAGE);
 
-  if constexpr (!FDB) {
+  {
     int slot = 0;
     for (int it = 0; it < nmax; ++it) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * RLPS) : "memory");
@@ -262,31 +261,6 @@ __global__ __launch_bounds__(256 * G, 2) void conv_wgrad_ring_kernel(const Wgrad
       if (it < nsteps) mfma16(f);
       slot = (slot == NSTAGE - 1) ? 0 : slot + 1;
     }
-  } else {
-    // fragments of tile `it` are read during the MFMAs of tile it-1
-    RFrag f0, f1;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * RLPS) : "memory");
-    __builtin_amdgcn_s_barrier();
-    read_frags(f0, 0);
-    stage(D, ring + D * RSTAGE);                                // the one slot that is still empty
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    int slot = 1;                                               // slot of tile it+1
-    auto step = [&](int it, const RFrag& cur, RFrag& nxt) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * RLPS) : "memory");
-      __builtin_amdgcn_s_barrier();    // tile it+1 has landed for every wave; every wave holds tile it in registers
-      read_frags(nxt, slot);
-      int ns = slot + D; if (ns >= NSTAGE) ns -= NSTAGE;
-      stage(it + 1 + D, ring + ns * RSTAGE);                    // the slot of tile it
-      __builtin_amdgcn_sched_barrier(0);
-      if (it < nsteps) mfma16(cur);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      slot = (slot == NSTAGE - 1) ? 0 : slot + 1;
-    };
-    int it = 0;
-    for (; it + 2 <= nmax; it += 2) { step(it, f0, f1); step(it + 1, f1, f0); }
-    if (it < nmax) step(it, f0, f1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // dead tiles still in flight would land in the combine tile
   __builtin_amdgcn_s_barrier();
@@ -361,11 +335,11 @@ __global__ __launch_bounds__(256 * G, 2) void conv_wgrad_ring_kernel(const Wgrad
   }
 }
 
-template <int G, int NSTAGE, int EPI, bool FDB, int ABL = 0>
+template <int G, int NSTAGE, int EPI, int ABL = 0>
 int launch_one(const WgradArgs& a, int tiles, hipStream_t st) {
   constexpr int ring = G * NSTAGE * RSTAGE, comb = G * 64 * TPITCH * 4;
   constexpr int lds = ring > comb ? ring : comb;
-  auto kern = conv_wgrad_ring_kernel<G, NSTAGE, EPI, FDB, ABL>;
+  auto kern = conv_wgrad_ring_kernel<G, NSTAGE, EPI, ABL>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -379,18 +353,16 @@ int launch_one(const WgradArgs& a, int tiles, hipStream_t st) {
 
 }  // namespace
 
-// variant = G * 1000 + NSTAGE * 100 + EPI * 10 + FDB.  a.nz = number of z-BLOCKS (each covers G consecutive pixel ranges of
+// variant = G * 1000 + NSTAGE * 100 + EPI * 10 (2300: atomic epilogue, 2310: slabs).  a.nz = number of z-BLOCKS (each covers G consecutive pixel ranges of
 // a.v_per_split virtual pixels); a.partial must be set for EPI = 1.
 int launch_wgrad_ring(const WgradArgs& a, int variant, hipStream_t st) {
   const int tiles = a.QT * a.CT * a.R * a.S;
   switch (variant) {
-#define SOD_RING_CASE(G, NS, EPI, FDB) case G * 1000 + NS * 100 + EPI * 10 + FDB: return launch_one<G, NS, EPI, (FDB != 0)>(a, tiles, st);
-    SOD_RING_CASE(1, 3, 0, 0) SOD_RING_CASE(1, 3, 1, 0) SOD_RING_CASE(1, 3, 0, 1) SOD_RING_CASE(1, 3, 1, 1)
-    SOD_RING_CASE(2, 3, 0, 0) SOD_RING_CASE(2, 3, 1, 0) SOD_RING_CASE(2, 3, 0, 1) SOD_RING_CASE(2, 3, 1, 1)
-    SOD_RING_CASE(2, 4, 0, 0) SOD_RING_CASE(2, 4, 1, 0) SOD_RING_CASE(2, 4, 0, 1) SOD_RING_CASE(2, 4, 1, 1)
+#define SOD_RING_CASE(G, NS, EPI) case G * 1000 + NS * 100 + EPI * 10: return launch_one<G, NS, EPI>(a, tiles, st);
+    SOD_RING_CASE(2, 3, 0) SOD_RING_CASE(2, 3, 1)
 #undef SOD_RING_CASE
 #ifdef SOD_RING_ABLATION
-#define SOD_ABL_CASE(ABL) case 2300 + 10000 * (ABL): return launch_one<2, 3, 0, false, (ABL)>(a, tiles, st);
+#define SOD_ABL_CASE(ABL) case 2300 + 10000 * (ABL): return launch_one<2, 3, 0, (ABL)>(a, tiles, st);
     SOD_ABL_CASE(1) SOD_ABL_CASE(3) SOD_ABL_CASE(4) SOD_ABL_CASE(5) SOD_ABL_CASE(7) SOD_ABL_CASE(8 + 7) SOD_ABL_CASE(16 + 7) SOD_ABL_CASE(8 + 4) SOD_ABL_CASE(16 + 4) SOD_ABL_CASE(24 + 4) SOD_ABL_CASE(32) SOD_ABL_CASE(64)
 #undef SOD_ABL_CASE
 #endif

@@ -683,18 +683,14 @@ extern "C" int sod_deform_col2im(const void* dcols, const void* x, const float* 
   a.x = (const __bf16*)x; a.off = offset; a.mask = mask; a.dcols = (const __bf16*)dcols; a.dx = dx_f32; a.doff = doffset; a.dmask = dmask;
   hipStream_t st = (hipStream_t)stream;
   {   // tiled LDS-window kernel when the window fits (always for the 3x3 / stride-1 layers of this path)
-    static const int force_plain = getenv("SOD_DCN_PLAIN") ? atoi(getenv("SOD_DCN_PLAIN")) : 0;
-    static const int cc_env = getenv("SOD_DCN_CC") ? atoi(getenv("SOD_DCN_CC")) : 32;
-    static const int r_env = getenv("SOD_DCN_R") ? atoi(getenv("SOD_DCN_R")) : 3;
+    constexpr int r_env = 3, CC = 32;       // 3 px of window slack, 32 channels per workgroup (64: fewer workgroups per CU, measured slower)
     const int cpg = C / deformable_groups;
-    const int CC = (cc_env == 64 && cpg % 64 == 0 && C % 64 == 0) ? 64 : 32;
     const int WH = 7 * stride + (KH - 1) * dil + 2 + 2 * r_env, WW = 7 * stride + (KW - 1) * dil + 2 + 2 * r_env;
     const size_t lds = (size_t)WH * WW * (CC + 1) * sizeof(float);
-    if (!force_plain && cpg % CC == 0 && C % CC == 0 && lds <= 64 * 1024 && N <= 65535 && C / CC <= 65535) {
+    if (cpg % CC == 0 && C % CC == 0 && lds <= 64 * 1024 && N <= 65535 && C / CC <= 65535) {
       const int tiles_x = (a.Wo + 7) / 8, tiles_y = (a.Ho + 7) / 8;
       dim3 grid(tiles_x * tiles_y, C / CC, N);
-      if (CC == 64) SOD_LAUNCH(dcn_col2im_tile_kernel<64>, grid, dim3(256), lds, st, a, tiles_x, WH, WW, r_env);
-      else SOD_LAUNCH(dcn_col2im_tile_kernel<32>, grid, dim3(256), lds, st, a, tiles_x, WH, WW, r_env);
+      SOD_LAUNCH(dcn_col2im_tile_kernel<32>, grid, dim3(256), lds, st, a, tiles_x, WH, WW, r_env);
       SOD_CHECK_LAUNCH();
       return SOD_OK;
     }
@@ -714,12 +710,11 @@ extern "C" int sod_deform_conv_set_window_counter(unsigned long long* device_cou
   return SOD_OK;
 }
 
-// Slack of the fused backward's LDS window in pixels beyond the tile's receptive field: -1 = SOD_DCN_FUSED_R or 2.  Larger windows keep
+// Slack of the fused backward's LDS window in pixels beyond the tile's receptive field: -1 = the default, 2.  Larger windows keep
 // larger offsets off the global-atomic path and cost workgroups per CU (29.7 KB at 2, 47.6 KB at 4, 69.8 KB at 6 for a 3x3 layer).
 static int g_dcn_fused_slack = -1;
 static int dcn_fused_slack() {
-  static const int r_env = getenv("SOD_DCN_FUSED_R") ? atoi(getenv("SOD_DCN_FUSED_R")) : 2;
-  return g_dcn_fused_slack >= 0 ? g_dcn_fused_slack : r_env;
+  return g_dcn_fused_slack >= 0 ? g_dcn_fused_slack : 2;
 }
 
 extern "C" int sod_deform_conv_set_window_slack(int pixels) {

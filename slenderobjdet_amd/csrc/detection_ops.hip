@@ -1187,8 +1187,7 @@ extern "C" int sod_roi_align_bwd(const float* dout, const float* rois, float* dx
   int rc = roi_fill(a, dx, rois, R, N, H, W, C, PH, PW, spatial_scale, sampling_ratio, rotated);   // x unused in bwd
   if (rc || !dout || !dx) return rc ? rc : SOD_EARG;
   if (R == 0) return SOD_OK;
-  static const int plain = getenv("SOD_ROI_PLAIN") ? atoi(getenv("SOD_ROI_PLAIN")) : 0;
-  if (!plain && C % ROI_CC == 0 && C / ROI_CC <= 65535) {
+  if (C % ROI_CC == 0 && C / ROI_CC <= 65535) {
     SOD_LAUNCH(roi_align_bwd_tile_kernel, dim3(R, C / ROI_CC), dim3(256), 0, (hipStream_t)stream, a, dout, dx);
     SOD_CHECK_LAUNCH();
     return SOD_OK;
@@ -1236,8 +1235,7 @@ static int anchor_match_impl(const float* gt_boxes, int G, const float* anchors,
   hipError_t e = hipMemsetAsync(gt_best_ws, 0, sizeof(unsigned) * G, st);
   if (e != hipSuccess) return (int)e;
   const int g = nblk(A, 2048);
-  static const int rot_plain = getenv("SOD_ANCHOR_MATCH_PLAIN") ? atoi(getenv("SOD_ANCHOR_MATCH_PLAIN")) : 0;      // A/B switch
-  if (D == 5 && !rot_plain) SOD_LAUNCH(anchor_match1_rot_kernel, dim3(g), dim3(256), sizeof(unsigned) * G, st, gt_boxes, G, anchors, A, matched_vals, matches, gt_best_ws);
+  if (D == 5) SOD_LAUNCH(anchor_match1_rot_kernel, dim3(g), dim3(256), sizeof(unsigned) * G, st, gt_boxes, G, anchors, A, matched_vals, matches, gt_best_ws);
   else SOD_LAUNCH(anchor_match1_kernel<D>, dim3(g), dim3(256), sizeof(unsigned) * G, st, gt_boxes, G, anchors, A, matched_vals, matches, gt_best_ws);
   SOD_LAUNCH(anchor_match2_kernel<D>, dim3(g), dim3(256), 0, st, gt_boxes, G, anchors, A, matched_vals, gt_best_ws, thr_lo, thr_hi,
              label_below, label_between, label_above, allow_low_quality, labels);

@@ -808,7 +808,7 @@ static int gn_reverse_mask() {
   return v;
 }
 
-static int gn_fill(GnML& m, int nlev, const int* hw, int N, int C, int G, float eps, int relu, const long long* img_strides, int grid_n = 0) {
+static int gn_fill(GnML& m, int nlev, const int* hw, int N, int C, int G, float eps, int relu, const long long* img_strides) {
   if (nlev <= 0 || nlev > GN_MAX_LEVELS || !hw) return SOD_EARG;
   m.nlev = nlev; m.N = N; m.C = C; m.G = G; m.cpg = C / G; m.relu = relu; m.eps = eps;
   int blk = 0;
@@ -819,8 +819,7 @@ static int gn_fill(GnML& m, int nlev, const int* hw, int N, int C, int G, float 
     L.HW = hw[l];
     L.img_stride = (img_strides && img_strides[l] > 0) ? img_strides[l] : (long long)hw[l] * C;
     // ~1024 / N blocks per level for the largest level, proportionally fewer for the small ones (>= 64 pixels per block)
-    // (grid_n: the number of images one launch covers when that is fewer than N - the image-chunked backward)
-    int gx = 1024 / (grid_n > 0 ? grid_n : (N > 0 ? N : 1));
+    int gx = 1024 / (N > 0 ? N : 1);
     if (gx < 1) gx = 1;
     int ppb = (hw[0] + gx - 1) / gx;
     if (ppb < 64) ppb = 64;
@@ -893,32 +892,11 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
                                     float* det_ws, long long det_ws_bytes, void* stream) {
   if (!dy || !x || !gamma || !beta || !mean_rstd || !dx || !dgamma || !dbeta || !red_ws) return SOD_EARG;
   if (!hw || N <= 0 || nlev <= 0 || nlev > GN_MAX_LEVELS) return SOD_EARG;
-  // EXPERIMENT, off by default (SOD_GN_BWD_CHUNK_MB=0): the apply pass re-reads dy and x; over the whole batch they are 367 MB per FCOS
-  // tower unit - more than the 256 MB Infinity Cache - so the two passes can walk over the batch in chunks of images whose dy + x fit the
-  // cache (the statistics are per image: a chunk's reduction is complete when its apply pass starts).  Measured on the FCOS R50 step
-  // (one gpurun call, 60 timed steps each): no chunks 619.6 / 621.9 img/s, 184 MB chunks 617.4 / 620.0, 128 MB 612.3 / 618.4, 96 MB
-  // 609.9 / 617.7 (blocks per image scaled up / kept) - slower every time: the other tower's convolutions and the weight-gradient
-  // stream run beside these kernels and stream ~1 GB through the same cache between a chunk's two passes, and four dependent kernel
-  // pairs expose four grid tails instead of one.  Deterministic mode always keeps one chunk.
-  static const long long chunk_bytes = [] {
-    const char* v = getenv("SOD_GN_BWD_CHUNK_MB");
-    return (long long)(v ? atoi(v) : 0) << 20;
-  }();
-  static const int grid_scale = [] {       // blocks per image grow as the chunk shrinks (1) or stay as for the whole batch (0)
-    const char* v = getenv("SOD_GN_BWD_CHUNK_GRID");
-    return v ? atoi(v) : 1;
-  }();
-  long long per_img = 0;
-  for (int l = 0; l < nlev; ++l) per_img += (long long)hw[l] * C * 2 * 2;
-  int cn = N;
-  if (!det_ws && chunk_bytes > 0 && per_img * N > chunk_bytes) {
-    cn = (int)(chunk_bytes / per_img);
-    if (cn < 1) cn = 1;
-    const int nchunks = (N + cn - 1) / cn;
-    cn = (N + nchunks - 1) / nchunks;          // equal chunks
-  }
+  // (Round 3 measured the two passes in chunks of images whose dy + x fit the 256 MB Infinity Cache: slower in every configuration -
+  // 619.6 / 621.9 img/s without chunks, 617.4 / 620.0 at 184 MB, 612.3 / 618.4 at 128 MB, 609.9 / 617.7 at 96 MB: the other streams move
+  // ~1 GB through the same cache between a chunk's two passes, and four dependent kernel pairs expose four grid tails.  Removed in round 5.)
   GnML m{};
-  const int gx = gn_fill(m, nlev, hw, N, C, G, 0.f, relu, nullptr, (cn < N && grid_scale) ? cn : 0);
+  const int gx = gn_fill(m, nlev, hw, N, C, G, 0.f, relu, nullptr);
   if (gx <= 0) return gx ? gx : SOD_EARG;
   m.gamma = gamma; m.beta = beta; m.dgamma = dgamma; m.dbeta = dbeta; m.dxsum = dxsum;
   for (int l = 0; l < nlev; ++l) {
@@ -944,32 +922,9 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
   }
   hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * N * G * nlev, st);
   if (e != hipSuccess) return (int)e;
-  for (int n0 = 0; n0 < N; n0 += cn) {
-    const int nn = (N - n0 < cn) ? N - n0 : cn;
-    m.n0 = n0;
-    m.rev = (gn_reverse_mask() >> 1) & 1;
-    SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, nn), dim3(256), sizeof(float) * 18 * 256, st, m);
-    m.rev = (gn_reverse_mask() >> 2) & 1;
-    SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, nn), dim3(256), dxsum ? sizeof(float) * 8 * 256 : 0, st, m);
-  }
-  SOD_CHECK_LAUNCH();
-  return SOD_OK;
-}
-
-extern "C" int sod_groupnorm_bwd_apply_ml(int nlev, const void* const* dy, const void* const* x, const float* gamma, const float* beta,
-                                          const float* mean_rstd, void* const* dx, float* dxsum, const float* red, int N, const int* hw, int C,
-                                          int G, int relu, void* stream) {
-  if (!dy || !x || !gamma || !beta || !mean_rstd || !dx || !red) return SOD_EARG;
-  GnML m{};
-  const int gx = gn_fill(m, nlev, hw, N, C, G, 0.f, relu, nullptr);
-  if (gx <= 0) return gx ? gx : SOD_EARG;
-  m.gamma = gamma; m.beta = beta; m.dxsum = dxsum;
-  for (int l = 0; l < nlev; ++l) {
-    if (!x[l] || !dy[l] || !dx[l]) return SOD_EARG;
-    m.lev[l].x = (const __bf16*)x[l]; m.lev[l].dy = (const __bf16*)dy[l]; m.lev[l].dx = (__bf16*)dx[l];
-    m.lev[l].stats = const_cast<float*>(mean_rstd) + (size_t)l * N * G * 2; m.lev[l].red = const_cast<float*>(red) + (size_t)l * N * G * 2;
-  }
-  hipStream_t st = (hipStream_t)stream;
+  m.rev = (gn_reverse_mask() >> 1) & 1;
+  SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 18 * 256, st, m);
+  m.rev = (gn_reverse_mask() >> 2) & 1;
   SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * 8 * 256 : 0, st, m);
   SOD_CHECK_LAUNCH();
   return SOD_OK;

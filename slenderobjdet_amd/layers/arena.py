@@ -187,6 +187,14 @@ class ParamArena:
         """Called in backward after the last kernel that adds to ``p.grad`` for this use has been enqueued."""
         if self._pending is None:
             return
+        if self.device.type == "cuda":
+            from . import functional as HF
+            # behind the launches an open wgrad_batch has collected: the bucket must not reach the reducer before they are issued
+            HF.batch_or_call(lambda: self._mark_ready_now(p))
+        else:
+            self._mark_ready_now(p)
+
+    def _mark_ready_now(self, p):
         bi = self._bucket_of[id(p)]
         self._pending[bi] -= 1
         if self._pending[bi] == 0 and not self._launched[bi]:

@@ -14,7 +14,7 @@ from .nn import HipConv2d, _arena_of
 
 import os
 
-SAVE_COLS = os.environ.get("SOD_DCN_SAVE_COLS", "1") != "0"
+SAVE_COLS = True
 # Fused kernels (csrc/dcn_fused.hip): forward and weight gradient gather the samples into LDS tiles inside the MFMA loop - no
 # (N*Ho*Wo, KH*KW*C) column buffer in HBM.  Measured per 256->256 DCN layer over the 5 RepPoints levels (batch 16): forward
 # 1.51 -> 0.95 ms, weight gradient 0.53 ms (on kept columns) -> 0.79 ms, i.e. 2.04 -> 1.74 ms and 1.65 GB less memory traffic and
@@ -130,7 +130,7 @@ class _DeformConvFn(torch.autograd.Function):
         ctx.mod, ctx.cfg, ctx.fused = mod, (off_ld, mask_ld, mask_is_logit), fused
         # Column-buffer path only: the sampled columns are needed again by the weight gradient.  They are KEPT across the step
         # (2 DCN layers x 5 levels of RepPoints at batch 16: 3.3 GB of the 288 GB) instead of being re-gathered in backward;
-        # SOD_DCN_SAVE_COLS=0 restores the recomputation.
+        # SAVE_COLS = False restores the recomputation.
         keep_cols = SAVE_COLS and mod.weight.requires_grad and cols is not None
         ctx.save_for_backward(x, offset, mask, y if mod.relu else None, cols if keep_cols else None)
         arena = _arena_of(mod)

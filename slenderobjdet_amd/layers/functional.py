@@ -140,10 +140,8 @@ def aux_compute_streams(device):
     return list(_aux_streams.get(device.index, ()))
 
 
-# SOD_WGRAD_STREAMS=n: round-robin over n side streams (independent weight gradients may then overlap each other, which shortens the
-# tail of backward where only weight gradients are left); 1 = a single in-order side stream
-WGRAD_NSTREAMS = max(1, int(os.environ.get("SOD_WGRAD_STREAMS", "1")))
-_side_rr = 0
+# (Two or three round-robin side streams measured neutral to worse in rounds 2 and 4 - 614.7 / 606 vs 613.8 img/s, 640.3 vs 642.0 - and left
+# the tree in round 5: one in-order side stream.)
 
 
 def wgrad_side_streams(device):
@@ -168,13 +166,63 @@ def wgrad_join():
         _wgrad_join()
 
 
-_side_of_key = {}
+# ---- batched hand-over to the side stream.  Every hand-over costs an event RECORD on the producing stream and a WAIT on the side stream;
+# the kernel trace prices each at 6-7 us of queue bubble (the next kernel of that queue starts that much later: 70 hand-overs per FCOS
+# step = 0.45 ms on the main queue and as much on the side queue, profiles/r5_step_occupancy.txt).  Inside ``with wgrad_batch():`` the
+# weight- / bias-gradient launches (and the arena.mark_ready calls that follow them) are collected and issued together when the block ends:
+# ONE record + ONE wait for all of them.  A residual block's three or four weight gradients then cost one hand-over instead of four.
+import threading as _threading
+
+_batch_tls = _threading.local()
+
+
+class wgrad_batch:
+    def __enter__(self):
+        self.outer = getattr(_batch_tls, "items", None)
+        if self.outer is None:
+            _batch_tls.items = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.outer is None:
+            items, _batch_tls.items = _batch_tls.items, None
+            if et is None and items:
+                _batch_tls.flushing, _batch_tls.waited = True, set()
+                try:
+                    for fn in items:
+                        fn()
+                finally:
+                    _batch_tls.flushing, _batch_tls.waited = False, None
+        return False
+
+
+def _batch_defer(fn):
+    """True if ``fn`` was queued into the open batch of this thread (the caller returns without launching)."""
+    items = getattr(_batch_tls, "items", None)
+    if items is None or not WGRAD_BATCH:
+        return False
+    items.append(fn)
+    return True
+
+
+def batch_or_call(fn):
+    """Run ``fn`` now, or behind the launches already collected in the open batch (arena.mark_ready: a bucket must not be handed to the
+    reducer before the launches that fill it have been issued)."""
+    if not _batch_defer(fn):
+        fn()
+
+
+# False: one hand-over per weight-gradient launch (as until round 4).  Batching a whole residual block's weight gradients behind its data
+# gradients measured SLOWER (623 vs 634 img/s, four alternating 100-step pairs, round 5: the side stream is the one that finishes last, and
+# launches that reach it later lengthen the tail of backward by more than the bubbles save), so only launches that were adjacent anyway
+# (weight + bias gradient of one convolution, conv1 + shortcut of a block) share a hand-over.
+WGRAD_BATCH = True
 
 
 def _wgrad_stream(device, tensors, key=None):
     """Returns the stream to launch a wgrad on (None = current stream).  ``key`` identifies the gradient buffer: launches that add to
     the same buffer always use the same stream (the slab / deterministic reductions update it with plain read-modify-writes)."""
-    global _side_join_queued, _side_rr
+    global _side_join_queued
     if not WGRAD_SIDE_STREAM or device.type != "cuda":
         return None
     if not _side_join_queued:
@@ -187,19 +235,18 @@ def _wgrad_stream(device, tensors, key=None):
     if sides is None:
         # lowest HIP stream priority (range on MI355X: 1 .. -1): the data-gradient chain is the critical path.  Measured 491.5-492.3
         # (low) / 491.8 (normal) / 483-484 (high) img/s
-        prio = int(os.environ.get("SOD_WGRAD_PRIO", "1"))
-        sides = _side_streams[device.index] = [make_stream(device, prio, "WGRAD") for _ in range(WGRAD_NSTREAMS)]
-    if len(sides) == 1:
-        side = sides[0]
+        sides = _side_streams[device.index] = [make_stream(device, 1, "WGRAD")]
+    side = sides[0]
+    # one wait per batch flush (the closures of a batch run back to back on this thread: nothing was enqueued on the current stream in
+    # between, so the first launch's wait covers the others) - or one per launch outside a batch
+    cur = torch.cuda.current_stream(device)
+    if getattr(_batch_tls, "flushing", False):
+        tag = (side.cuda_stream, cur.cuda_stream)
+        if tag not in _batch_tls.waited:
+            side.wait_stream(cur)
+            _batch_tls.waited.add(tag)
     else:
-        i = _side_of_key.get(key)
-        if i is None:
-            _side_rr = (_side_rr + 1) % len(sides)
-            i = _side_rr
-            if key is not None:
-                _side_of_key[key] = i
-        side = sides[i]
-    side.wait_stream(torch.cuda.current_stream(device))
+        side.wait_stream(cur)
     # The operands (dY, X) must outlive the side-stream kernel.  They are kept referenced until the join instead of
     # Tensor.record_stream(): with record_stream the allocator cannot reuse a block until a GPU-side event has completed, and since the
     # host runs several steps ahead of the GPU the pool grew from 10 GB to 52 GB; held references are released in main-stream order
@@ -273,43 +320,6 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
     return out
 
 
-def bottleneck_pair_supported(CN, CW):
-    return not is_f32() and _C.load().sod_bottleneck_pair_supported(int(CN), int(CW)) == 1
-
-
-def bottleneck_pair(xin, add, we, bias_e, wc, bias_c, mode, bits_in=None, mask2=None, want_bits=True):
-    """Expanding 1x1 conv (+ add operand + nonlinearity) and the contracting 1x1 conv that consumes it in one launch
-    (sod_bottleneck_pair).  xin (N,H,W,CN), add (N,H,W,CW) or None, we (CW,1,1,CN), wc (CN,1,1,CW).  Returns (wide, bits or None, narrow)."""
-    _chk(xin, torch.bfloat16, "xin"); _chk(add, torch.bfloat16, "add"); _chk(we, torch.bfloat16, "we"); _chk(wc, torch.bfloat16, "wc")
-    _chk(bias_e, torch.float32, "bias_e"); _chk(bias_c, torch.float32, "bias_c"); _chk(mask2, torch.bfloat16, "mask2")
-    N, H, W, CN = xin.shape
-    CW = we.shape[0]
-    if tuple(we.shape) != (CW, 1, 1, CN) or tuple(wc.shape) != (CN, 1, 1, CW):
-        raise _C.SlenderHipError(f"bottleneck_pair: weights {tuple(we.shape)} / {tuple(wc.shape)} do not chain {CN} -> {CW} -> {CN}")
-    P = N * H * W
-    wide = torch.empty((N, H, W, CW), dtype=torch.bfloat16, device=xin.device)
-    narrow = torch.empty((N, H, W, CN), dtype=torch.bfloat16, device=xin.device)
-    bits = torch.empty(P * CW // 8, dtype=torch.uint8, device=xin.device) if (mode == 0 and want_bits) else None
-    if mode == 1:
-        _chk(bits_in, torch.uint8, "bits_in")
-        if bits_in is None or bits_in.numel() * 8 != P * CW or (mask2 is not None and mask2.numel() != P * CN):
-            raise _C.SlenderHipError("bottleneck_pair: mode 1 needs bits_in of P * CW bits (and mask2 of P * CN elements)")
-    if add is not None and add.numel() != P * CW:
-        raise _C.SlenderHipError("bottleneck_pair: add operand must be (N, H, W, CW)")
-    kind = "conv_fwd" if mode == 0 else "conv_dgrad"
-    prof = PROFILE is not None and (PROFILE_KINDS is None or kind in PROFILE_KINDS)
-    if prof:        # not a library conv dispatch: timed with a torch event pair on the launch stream (bench.py roofline), variant code -9
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-    call("sod_bottleneck_pair", ptr(xin), ptr(add), ptr(we), ptr(bias_e), ptr(wc), ptr(bias_c), ptr(bits_in), ptr(mask2), ptr(wide), ptr(bits),
-         ptr(narrow), P, CN, CW, int(mode), stream_ptr())
-    if prof:
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        PROFILE.append((kind, 4.0 * P * CN * CW, e0, e1, (N, H, W, CN, CW, "pair", 1), -9))
-    return wide, bits, narrow
-
-
 CONV_CWIN = 4               # slender_hip.h SOD_CONV_CWIN
 WGRAD_DIAG = 2              # slender_hip.h SOD_WGRAD_DIAG
 CWIN = 128                  # the window = one 128-channel output tile
@@ -378,6 +388,8 @@ def conv2d_wgrad(dy, x, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, x_img
                  k_real=None, c_real=None):
     """Accumulates into dw (K,R,S,C) fp32."""
     _chk(dy, torch.bfloat16, "dy"); _chk(x, torch.bfloat16, "x"); _chk(dw, torch.float32, "dw")
+    if _batch_defer(lambda: conv2d_wgrad(dy, x, dw, R, S, stride, pad, dil, dy_img_stride, x_img_stride, K, x_shape, splits, qscale, k_real, c_real)):
+        return dw
     N, H, W, C = x_shape if x_shape is not None else x.shape
     if K is None:
         K = dy.shape[-1]
@@ -420,7 +432,7 @@ def conv2d_fwd_ml(xs, w, bias=None, stride=1, pad=0, dil=1, relu=False, out_f32=
     return outs
 
 
-def conv_gn_fwd_ml(xs, w, bias, gamma, beta, G, eps=1e-5, relu=True, pad=1, after_conv=None):
+def conv_gn_fwd_ml(xs, w, bias, gamma, beta, G, eps=1e-5, relu=True, pad=1):
     """[conv (stride 1, bias) -> GroupNorm(G) -> ReLU] over several levels that share the weights, with the norm's statistics gathered
     in the conv epilogue (sod_conv2d_fwd_ml_gnsum) instead of a separate pass over the conv output.  Returns (conv outputs, norm
     outputs, stats (nl,N,G,2) = mean / rstd)."""
@@ -439,8 +451,6 @@ def conv_gn_fwd_ml(xs, w, bias, gamma, beta, G, eps=1e-5, relu=True, pad=1, afte
          1, pad, 1, 0, 0, ptr(stats), G, stream_ptr())
     fl = sum(2.0 * N * o.shape[1] * o.shape[2] * K * R * S * C for o in outs)
     _prof_end("conv_fwd", fl, e0, ("ml", N, tuple(hs), C, K, R, 1, tuple(ws)))
-    if after_conv is not None:      # called between the convolution and the normalisation launch (stream events of the caller)
-        after_conv()
     ys = [torch.empty_like(o) for o in outs]
     hw = [o.shape[1] * o.shape[2] for o in outs]
     call("sod_groupnorm_apply_ml", len(outs), _ptr_arr(outs), ptr(gamma), ptr(beta), _ptr_arr(ys), ptr(stats), N, ctypes.cast(_int_arr(hw), ctypes.c_void_p),
@@ -494,46 +504,11 @@ def conv2d_dgrad_ml(dys, wt, x_hws, stride=1, pad=0, dil=1, dy_img_stride=0, N=N
     return outs
 
 
-def conv2d_dgrad_ml_gnbwd(dys, wt, x_hws, gn_xs, gn_stats, gamma, beta, dgamma, dbeta, G, stride=1, pad=0, dil=1, N=None):
-    """conv2d_dgrad_ml whose outputs are the gradients w.r.t. relu(GroupNorm(gn_xs)): the epilogue also gathers the reduction pass of that
-    norm's backward.  Returns (dxs, red) with red (nl, N, G, 2); dgamma / dbeta (fp32, [C]) are incremented in place."""
-    _chk(wt, torch.bfloat16, "wt"); _chk(gn_stats, torch.float32, "gn_stats")
-    for t, nm in ((gamma, "gamma"), (beta, "beta"), (dgamma, "dgamma"), (dbeta, "dbeta")):
-        _chk(t, torch.float32, nm)
-    for t in list(dys) + list(gn_xs):
-        _chk(t, torch.bfloat16, "dy/x")
-    C, R, S, K = wt.shape
-    if N is None:
-        N = dys[0].shape[0]
-    dev = dys[0].device
-    if C != 8 * G or len(gn_xs) != len(dys) or any(tuple(x.shape) != (N, h, w, C) for x, (h, w) in zip(gn_xs, x_hws)):
-        raise _C.SlenderHipError("conv2d_dgrad_ml_gnbwd: the norm's inputs must have the data gradient's shape, 8 channels per group")
-    outs = [torch.empty((N, h, w, C), dtype=torch.bfloat16, device=dev) for h, w in x_hws]
-    red = torch.empty((len(dys), N, G, 2), dtype=torch.float32, device=dev)
-    e0 = _prof_begin(None, "conv_dgrad")
-    call("sod_conv2d_dgrad_ml_gnbwd", len(dys), _ptr_arr(dys), ptr(wt), _ptr_arr(outs), N, _int_arr([h for h, _ in x_hws]), _int_arr([w for _, w in x_hws]),
-         C, K, R, S, stride, pad, dil, 0, _ptr_arr(gn_xs), ptr(gn_stats), ptr(gamma), ptr(beta), ptr(red), ptr(dgamma), ptr(dbeta), G, stream_ptr())
-    fl = sum(2.0 * N * ho * wo * K * R * S * C for ho, wo in (conv_out_size(h, w, R, S, stride, pad, dil) for h, w in x_hws))
-    _prof_end("conv_dgrad", fl, e0, ("ml", N, tuple(h for h, _ in x_hws), C, K, R, stride, tuple(w for _, w in x_hws)))
-    return outs, red
-
-
-def groupnorm_bwd_apply_ml(dys, xs, gamma, beta, stats, red, G, relu=False, dxsum=None):
-    """The apply pass of groupnorm_bwd_ml alone, for reductions gathered by conv2d_dgrad_ml_gnbwd: returns the list of dx."""
-    _chk(stats, torch.float32, "stats"); _chk(red, torch.float32, "red")
-    for t in list(dys) + list(xs):
-        _chk(t, torch.bfloat16, "dy/x")
-    N, C = xs[0].shape[0], xs[0].shape[-1]
-    hw = [x.numel() // (N * C) for x in xs]
-    dxs = [torch.empty_like(x) for x in xs]
-    call("sod_groupnorm_bwd_apply_ml", len(xs), _ptr_arr(dys), _ptr_arr(xs), ptr(gamma), ptr(beta), ptr(stats), _ptr_arr(dxs), ptr(dxsum), ptr(red),
-         N, ctypes.cast(_int_arr(hw), ctypes.c_void_p), C, G, 1 if relu else 0, stream_ptr())
-    return dxs
-
-
 def conv2d_wgrad_ml(dys, xs, dw, R, S, stride=1, pad=0, dil=1, dy_img_stride=0, K=None, splits=0, qscale=None, k_real=None):
     """Accumulates the weight gradient over all levels in one launch."""
     _chk(dw, torch.float32, "dw")
+    if _batch_defer(lambda: conv2d_wgrad_ml(dys, xs, dw, R, S, stride, pad, dil, dy_img_stride, K, splits, qscale, k_real)):
+        return dw
     N, C = xs[0].shape[0], xs[0].shape[3]
     if K is None:
         K = dys[0].shape[-1]
@@ -650,6 +625,8 @@ def bias_grad(dy, dbias, N, HW, C, img_stride=0, scale_num=None, scale_den=None,
     """dbias += [scale_num / max(scale_den * den_mul, den_min), device scalars] * per-channel sum of dy."""
     _chk(dy, torch.bfloat16, "dy"); _chk(dbias, torch.float32, "dbias")
     _chk(scale_num, torch.float32, "scale_num"); _chk(scale_den, torch.float32, "scale_den")
+    if _batch_defer(lambda: bias_grad(dy, dbias, N, HW, C, img_stride, scale_num, scale_den, den_mul, den_min)):
+        return dbias
     side = _wgrad_stream(dbias.device, (dy, scale_num, scale_den), dbias.data_ptr())      # like the weight gradient: only the optimizer / all-reduce consumes it
     if scale_num is None and scale_den is None:
         call("sod_bias_grad", ptr(dy), ptr(dbias), N, HW, C, img_stride, *_det_ws(dbias.device, side), stream_ptr(side))
@@ -666,6 +643,8 @@ def bias_grad_ml(dys, dbias):
     for t in dys:
         _chk(t, torch.bfloat16, "dy")
     N, C = dys[0].shape[0], dys[0].shape[-1]
+    if _batch_defer(lambda: bias_grad_ml(dys, dbias)):
+        return dbias
     if DETERMINISTIC or len(dys) > 6:
         for g in dys:
             bias_grad(g, dbias, N, g.numel() // (N * C), C)
@@ -1581,7 +1560,7 @@ for _name in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad", "conv2d_fwd_ml", "co
               "groupnorm_fwd", "groupnorm_bwd", "groupnorm_fwd_ml", "groupnorm_bwd_ml", "relu_fwd", "relu_bwd", "add_bf16", "f32_to_bf16",
               "add_up2", "upsample2x_bwd", "maxpool3x3s2", "bias_grad", "bias_grad_ml", "preprocess_image", "preprocess_batch"):
     globals()[_name] = _precision_dispatch(globals()[_name])
-for _name in ("conv_gn_fwd_ml", "conv2d_dgrad_ml_gnbwd", "groupnorm_bwd_apply_ml", "stem_fused", "bottleneck_frozen_fwd"):
+for _name in ("conv_gn_fwd_ml", "stem_fused", "bottleneck_frozen_fwd"):
     if _name in globals():
         globals()[_name] = _precision_dispatch(globals()[_name])     # no fp32 variant: raises instead of mixing precisions
 if os.environ.get("SOD_PRECISION", "bf16") != "bf16":

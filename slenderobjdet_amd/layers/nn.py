@@ -59,14 +59,8 @@ import os as _os
 
 # SOD_GN_EPILOGUE_STATS=0: the GroupNorm statistics of the tower units come from their own pass over the conv output
 GN_EPILOGUE_STATS = _os.environ.get("SOD_GN_EPILOGUE_STATS", "1") != "0"
-# SOD_GN_BWD_FUSED=1 (EXPERIMENT, off by default): a tower unit's data gradient gathers the reduction pass of the previous unit's GroupNorm
-# backward in its epilogue (GnBwdSlot).  Correct (tests/test_gpu_conv.py, test_gpu_model.py) but measured SLOWER on the FCOS R50 step:
-# 610.0 / 612.5 vs 618.4 / 616.4 img/s.  The pass it removes (0.79 ms of HBM-bound kernel time per step) already runs beside the other
-# tower's MFMA-bound convolutions, while its ~12 VALU operations per element land in the un-overlapped epilogue of the 256x256 kernel
-# (one workgroup per CU: two waves per SIMD x 128 elements x 12 instructions x 4 cycles = 5.8 us on a 17.5 us tile).
-GN_BWD_FUSED = _os.environ.get("SOD_GN_BWD_FUSED", "0") == "1"
-# SOD_DEFER_LATERAL=0: the FPN lateral convs run their own data gradient and autograd sums it with the next stage's (see DeferSlot)
-DEFER_LATERAL_DGRAD = _os.environ.get("SOD_DEFER_LATERAL", "1") != "0"
+# False: the FPN lateral convs run their own data gradient and autograd sums it with the next stage's (see DeferSlot)
+DEFER_LATERAL_DGRAD = True
 
 
 class HipConv2d(nn.Module):
@@ -296,6 +290,10 @@ class HipGroupedConv2d(HipConv2d):
 
     def wgrad_into(self, arena, g, x):
         """dW of the dense embedding into a scratch tensor on the CURRENT stream, diagonal blocks added to the arena gradient."""
+        # as ONE unit behind whatever an open wgrad_batch has collected (the scratch tensor is consumed right after its launch)
+        HF.batch_or_call(lambda: self._wgrad_into_now(arena, g, x))
+
+    def _wgrad_into_now(self, arena, g, x):
         K, k, C = self.out_channels, self.kernel_size, self.in_channels
         win = self.windowed()
         dense = torch.zeros((K, k, k, HF.CWIN if win else C), dtype=torch.float32, device=g.device)
@@ -339,15 +337,16 @@ class _ConvFn(torch.autograd.Function):
         arena = _arena_of(mod)
         N, H, W, C = x.shape
         if mod.weight.requires_grad:
-            if getattr(mod, "groups", 1) > 1:
-                mod.wgrad_into(arena, g, x)
-            else:
-                dw = arena.grad_view(mod.weight)
-                HF.conv2d_wgrad(g, x, dw, mod.kernel_size, mod.kernel_size, mod.stride, mod.padding, mod.dilation, qscale=mod.bn_scale)
-                arena.mark_ready(mod.weight)
-            if mod.bias is not None:
-                HF.bias_grad(g, arena.grad_view(mod.bias), N, g.shape[1] * g.shape[2], mod.out_channels)
-                arena.mark_ready(mod.bias)
+            with HF.wgrad_batch():      # weight + bias gradient: one hand-over to the side stream
+                if getattr(mod, "groups", 1) > 1:
+                    mod.wgrad_into(arena, g, x)
+                else:
+                    dw = arena.grad_view(mod.weight)
+                    HF.conv2d_wgrad(g, x, dw, mod.kernel_size, mod.kernel_size, mod.stride, mod.padding, mod.dilation, qscale=mod.bn_scale)
+                    arena.mark_ready(mod.weight)
+                if mod.bias is not None:
+                    HF.bias_grad(g, arena.grad_view(mod.bias), N, g.shape[1] * g.shape[2], mod.out_channels)
+                    arena.mark_ready(mod.bias)
         dx = None
         if ctx.needs_input_grad[0]:
             if ctx.slot is not None:      # the producer of x runs this data gradient fused with its own mask / accumulate (DeferSlot)
@@ -369,20 +368,6 @@ class HipGroupNorm(nn.Module):
         self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
         self.weight = nn.Parameter(torch.ones(num_channels))
         self.bias = nn.Parameter(torch.zeros(num_channels))
-
-
-class GnBwdSlot:
-    """What a ConvGnRelu unit publishes for the unit that consumes its output (and is its ONLY consumer): the norm's input, statistics
-    and module.  The consumer's data gradient (sod_conv2d_dgrad_ml_gnbwd) gathers the reduction pass of this unit's GroupNorm backward
-    in its epilogue and leaves the group sums in ``red``; this unit's backward then runs the apply pass alone."""
-
-    def __init__(self, y1s, stats, gn, outs):
-        self.y1s, self.stats, self.gn = y1s, stats, gn
-        self.out_ptrs = [(t.data_ptr(), tuple(t.shape)) for t in outs]
-        self.red = None
-
-    def matches(self, xs):
-        return len(xs) == len(self.out_ptrs) and all((x.data_ptr(), tuple(x.shape)) == k for x, k in zip(xs, self.out_ptrs))
 
 
 class GradPark:
@@ -409,7 +394,7 @@ class GradPark:
         if self.parked:
             self.parked.clear()
             raise RuntimeError("GradPark: the ROI pooler parked feature gradients and the RPN head's backward never collected them "
-                               "(SOD_RCNN_GRAD_PARK=0 restores autograd's accumulation)")
+                               "(meta_arch.rcnn.GRAD_PARK = False restores autograd's accumulation)")
 
 
 class SiblingFold:
@@ -458,87 +443,38 @@ class ConvGnRelu(nn.Module):
         super().__init__()
         self.conv = HipConv2d(channels, channels, 3, 1, 1, bias=True)
         self.gn = HipGroupNorm(num_groups, channels)
-        self._last_slot = None
 
-    def forward(self, xs, chained=None, fold=None):
-        """``chained``: the ConvGnRelu unit whose latest forward produced ``xs`` and that has no other consumer (the previous unit of a
-        tower): this unit's backward then gathers the reduction pass of that unit's GroupNorm backward in its data gradient.
-        ``fold``: a SiblingFold shared with the other unit that reads the same ``xs``."""
+    def forward(self, xs, fold=None):
+        """``fold``: a SiblingFold shared with the other unit that reads the same ``xs``."""
         single = isinstance(xs, torch.Tensor)
         if single:
             xs = [xs]
         self.conv.prepare()
-        prev = None
-        if GN_BWD_FUSED and not HF.is_f32() and chained is not None and chained._last_slot is not None and chained._last_slot.matches(xs):
-            prev = chained._last_slot
-        out = _ConvGnReluFn.apply(self.conv.weight, self, prev, fold, *xs)
+        out = _ConvGnReluFn.apply(self.conv.weight, self, fold, *xs)
         return out[0] if single else list(out)
-
-
-class ConvGate:
-    """EXPERIMENT (SOD_TOWER_GATE=1, modeling/meta_arch/fcos.py): serialises the CONVOLUTION launches of the two head towers across their
-    streams (each conv waits for the previous conv of the other tower), so that a tower's HBM-bound GroupNorm passes always run beside
-    the other tower's MFMA-bound convolution instead of beside its GroupNorm passes."""
-    current = None
-
-    def __init__(self):
-        self.last = None
-
-    def before_conv(self):
-        if self.last is not None:
-            torch.cuda.current_stream().wait_event(self.last)
-
-    def after_conv(self):
-        self.last = torch.cuda.Event()
-        self.last.record(torch.cuda.current_stream())
-
-
-class ConvGn:
-    """[Conv (any odd kernel, stride 1) -> GroupNorm] of an existing HipConv2d and HipGroupNorm pair as ONE autograd node (detectron2's
-    ``Conv2d(..., norm=get_norm("GN", C))`` of the FPN under MODEL.FPN.NORM "GN", configs/rep-points/*.yaml): the norm's statistics come out
-    of the conv epilogue, and its backward hands the conv's weight gradient the normalised gradient without another autograd hop.  Not a
-    Module: the two layers stay registered where they are (state-dict names unchanged)."""
-    relu = False
-
-    def __init__(self, conv, gn):
-        self.conv, self.gn, self._last_slot = conv, gn, None
-
-    def __call__(self, x):
-        self.conv.prepare()
-        return _ConvGnReluFn.apply(self.conv.weight, self, None, None, x)[0]
 
 
 class _ConvGnReluFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, weight, unit, prev_slot, fold, *xs):
+    def forward(ctx, weight, unit, fold, *xs):
         conv, gn = unit.conv, unit.gn
         ctx.fold = fold
         gw, gb = gn.weight.detach(), gn.bias.detach()
-        gate = ConvGate.current
-        if gate is not None:
-            gate.before_conv()
-        relu = getattr(unit, "relu", True)          # ConvGn (FPN with NORM "GN"): no activation behind the norm
+        relu = True
         if (GN_EPILOGUE_STATS and not HF.DETERMINISTIC and not HF.is_f32() and conv.out_channels == 8 * gn.num_groups
                 and conv.stride == 1 and conv.dilation == 1 and 2 * conv.padding == conv.kernel_size - 1):
             # the norm's statistics are gathered in the conv epilogue (float atomics: not for the deterministic mode)
-            y1s, y2s, stats = HF.conv_gn_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, gw, gb, gn.num_groups, gn.eps, relu=relu, pad=conv.padding,
-                                                after_conv=gate.after_conv if gate is not None else None)
+            y1s, y2s, stats = HF.conv_gn_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, gw, gb, gn.num_groups, gn.eps, relu=relu, pad=conv.padding)
         else:
             y1s = HF.conv2d_fwd_ml(list(xs), conv.w_bf16, conv.bias_eff, conv.stride, conv.padding, conv.dilation)
-            if gate is not None:
-                gate.after_conv()
             y2s, stats = HF.groupnorm_fwd_ml(y1s, gw, gb, gn.num_groups, gn.eps, relu=relu)      # all levels in one launch per pass
         ctx.unit, ctx.nl, ctx.relu = unit, len(xs), relu
         ctx.save_for_backward(*xs, *y1s, stats)
-        ctx.prev_slot = prev_slot
-        ctx.slot = unit._last_slot = None
         arena = _arena_of(conv)
         if arena is not None and conv.weight.requires_grad:
             for p in (conv.weight, conv.bias, gn.weight, gn.bias):
                 if p is not None:
                     arena.note_use(p)
-            if conv.out_channels == 8 * gn.num_groups and relu and conv.kernel_size == 3 and conv.bias is not None:
-                ctx.slot = unit._last_slot = GnBwdSlot(list(y1s), stats, gn, y2s)
         return tuple(y2s)
 
     @staticmethod
@@ -554,13 +490,7 @@ class _ConvGnReluFn(torch.autograd.Function):
         relu, k = ctx.relu, conv.kernel_size
         # the conv bias gradient (sum of dy1 over pixels) falls out of the GN backward pass
         dbias = arena.grad_view(conv.bias) if conv.bias is not None else None
-        slot, ctx.slot = ctx.slot, None
-        if slot is not None and slot.red is not None:
-            # the consumer's data gradient already gathered the group sums and dgamma / dbeta (sod_conv2d_dgrad_ml_gnbwd): apply pass only
-            dy1s = HF.groupnorm_bwd_apply_ml([d.contiguous() for d in dy2s], list(y1s), gw, gb, stats, slot.red, gn.num_groups, relu=True, dxsum=dbias)
-            slot.red = None
-        else:
-            dy1s = HF.groupnorm_bwd_ml([d.contiguous() for d in dy2s], list(y1s), gw, gb, stats, gn.num_groups, dgw, dgb, relu=relu, dxsum=dbias)
+        dy1s = HF.groupnorm_bwd_ml([d.contiguous() for d in dy2s], list(y1s), gw, gb, stats, gn.num_groups, dgw, dgb, relu=relu, dxsum=dbias)
         arena.mark_ready(gn.weight)
         arena.mark_ready(gn.bias)
         if conv.bias is not None:
@@ -568,22 +498,17 @@ class _ConvGnReluFn(torch.autograd.Function):
         HF.conv2d_wgrad_ml(dy1s, list(xs), arena.grad_view(conv.weight), k, k, conv.stride, conv.padding, conv.dilation)
         arena.mark_ready(conv.weight)
         dxs = [None] * nl
-        if any(ctx.needs_input_grad[4:]):
-            prev, ctx.prev_slot = ctx.prev_slot, None
+        if any(ctx.needs_input_grad[3:]):
             fold, ctx.fold = ctx.fold, None
             hw = [(x.shape[1], x.shape[2]) for x in xs]
-            if prev is not None and not HF.DETERMINISTIC and all(ctx.needs_input_grad[4:]):
-                pg = prev.gn
-                dxs, prev.red = HF.conv2d_dgrad_ml_gnbwd(dy1s, conv.wt_bf16, hw, prev.y1s, prev.stats, pg.weight.detach(), pg.bias.detach(),
-                                                         arena.grad_view(pg.weight), arena.grad_view(pg.bias), pg.num_groups, 1, 1, 1)
-            elif fold is not None and all(ctx.needs_input_grad[4:]):
+            if fold is not None and all(ctx.needs_input_grad[3:]):
                 if fold.partial is None:      # first of the two siblings: park the gradient, the other returns the sum
                     fold.put(HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, hw, conv.stride, conv.padding, conv.dilation))
                 else:
                     dxs = HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, hw, conv.stride, conv.padding, conv.dilation, accums=fold.take())
             else:
                 dxs = HF.conv2d_dgrad_ml(dy1s, conv.wt_bf16, hw, conv.stride, conv.padding, conv.dilation)
-        return (None, None, None, None, *dxs)
+        return (None, None, None, *dxs)
 
 
 class _ReluToken:
@@ -598,8 +523,8 @@ class _ReluToken:
         return len(xs) == len(self.out_ptrs) and all((x.data_ptr(), tuple(x.shape)) == k for x, k in zip(xs, self.out_ptrs))
 
 
-# SOD_RELU_CHAIN=0: every ConvReluML unit masks its own incoming gradient (one relu_bwd launch per level)
-RELU_CHAIN = _os.environ.get("SOD_RELU_CHAIN", "1") != "0"
+# False: every ConvReluML unit masks its own incoming gradient (one relu_bwd launch per level)
+RELU_CHAIN = True
 
 
 class ConvReluML(nn.Module):
@@ -651,10 +576,11 @@ class _ConvReluMLFn(torch.autograd.Function):
             gs = [dy.contiguous() for dy in dys]
         else:
             gs = [HF.relu_bwd(dy.contiguous(), y) for dy, y in zip(dys, ys)]
-        HF.conv2d_wgrad_ml(gs, list(xs), arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
-        arena.mark_ready(conv.weight)
-        HF.bias_grad_ml(gs, arena.grad_view(conv.bias))
-        arena.mark_ready(conv.bias)
+        with HF.wgrad_batch():
+            HF.conv2d_wgrad_ml(gs, list(xs), arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
+            arena.mark_ready(conv.weight)
+            HF.bias_grad_ml(gs, arena.grad_view(conv.bias))
+            arena.mark_ready(conv.bias)
         dxs = [None] * nl
         if any(ctx.needs_input_grad[3:]):
             hw = [(x.shape[1], x.shape[2]) for x in xs]
@@ -705,10 +631,11 @@ class _ConvMLFn(torch.autograd.Function):
                 dy = HF.f32_to_bf16(dy)
             gs.append(HF.relu_bwd(dy, ys[i]) if unit.relu else dy)
         k = conv.kernel_size
-        HF.conv2d_wgrad_ml(gs, list(xs), arena.grad_view(conv.weight), k, k, 1, conv.padding, 1)
-        arena.mark_ready(conv.weight)
-        HF.bias_grad_ml(gs, arena.grad_view(conv.bias))
-        arena.mark_ready(conv.bias)
+        with HF.wgrad_batch():
+            HF.conv2d_wgrad_ml(gs, list(xs), arena.grad_view(conv.weight), k, k, 1, conv.padding, 1)
+            arena.mark_ready(conv.weight)
+            HF.bias_grad_ml(gs, arena.grad_view(conv.bias))
+            arena.mark_ready(conv.bias)
         dxs = [None] * nl
         if any(ctx.needs_input_grad[2:]):
             dxs = HF.conv2d_dgrad_ml(gs, conv.wt_bf16, [(x.shape[1], x.shape[2]) for x in xs], 1, conv.padding, 1)

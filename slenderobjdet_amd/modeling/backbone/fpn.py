@@ -9,7 +9,7 @@ import math
 import torch
 from torch import nn
 
-from ...layers.nn import ConvGn, HipConv2d, HipGroupNorm, add_up2, group_norm_relu, relu
+from ...layers.nn import HipConv2d, HipGroupNorm, add_up2, group_norm_relu, relu
 from ..shape_spec import ShapeSpec
 from .build import BACKBONE_REGISTRY, Backbone
 from .resnet import build_resnet_backbone
@@ -58,14 +58,6 @@ class LastLevelMaxPool(nn.Module):
         return [_SubsampleFn.apply(x)]
 
 
-import os
-
-# EXPERIMENT (off): the [conv -> GroupNorm] pairs of the FPN under NORM "GN" as one node each with the statistics gathered in the conv
-# epilogue (layers/nn.py ConvGn).  Measured SLOWER on RepPoints R50, 436.5 / 436.3 vs 441.8 / 441.0 img/s in one call: these convolutions
-# (1x1 laterals, one 3x3 per level) are short, and the statistics' atomics in their epilogues cost more than the 0.34 ms pass they save.
-FPN_CONVGN = os.environ.get("SOD_FPN_CONVGN", "0") != "0"
-
-
 class FPN(Backbone):
     def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
         super().__init__()
@@ -96,7 +88,6 @@ class FPN(Backbone):
             output.append(out)
         self.lateral_convs = lateral[::-1]      # top (coarsest) first
         self.output_convs = output[::-1]
-        self._conv_gn = {id(c): ConvGn(c, c.norm) for c in lateral + output} if norm == "GN" else {}
         self.top_block = top_block
         self.in_features = in_features
         self.bottom_up = bottom_up
@@ -124,9 +115,9 @@ class FPN(Backbone):
                 prev = lat(feat, res=prev, res_up2=True)
                 results.insert(0, out(prev))
         else:
-            # [conv -> GroupNorm] pairs run as one node each (layers/nn.py ConvGn): statistics in the conv epilogue instead of a pass of
-            # their own over the conv output
-            cg = self._conv_gn if FPN_CONVGN else {id(c): (lambda t, c=c: group_norm_relu(c(t), c.norm, relu=False)) for c in self.lateral_convs + self.output_convs}
+            # (conv + GroupNorm as one node with epilogue statistics measured slower here - 436.4 vs 441.4 img/s on RepPoints R50, round 3 -
+            # and left the tree in round 5: these short convolutions lose more to the statistics' atomics than the pass costs)
+            cg = {id(c): (lambda t, c=c: group_norm_relu(c(t), c.norm, relu=False)) for c in self.lateral_convs + self.output_convs}
             prev = cg[id(self.lateral_convs[0])](xs[0])
             results.append(cg[id(self.output_convs[0])](prev))
             for feat, lat, out in zip(xs[1:], self.lateral_convs[1:], self.output_convs[1:]):

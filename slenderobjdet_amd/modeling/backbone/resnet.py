@@ -20,11 +20,11 @@ STEM_FUSED = os.environ.get("SOD_STEM_FUSED", "1") != "0"
 # frozen 64 -> 256 bottleneck blocks (res2 under FREEZE_AT >= 2) as one kernel each (csrc/bottleneck_fused.hip)
 BNECK_FUSED = os.environ.get("SOD_BNECK_FUSED", "1") != "0"
 # ReLU masks of the block outputs of a trainable bottleneck stage as 1 bit per element, written by the conv3 epilogue and read by the
-# data gradient that folds the mask in (1/16 of the bytes of re-reading the bf16 block output); SOD_RELU_BITS=0 re-reads the tensor
-RELU_BITS = os.environ.get("SOD_RELU_BITS", "1") != "0"
+# data gradient that folds the mask in (1/16 of the bytes of re-reading the bf16 block output); False re-reads the tensor
+RELU_BITS = True
 # A stage whose first block opens with stride-2 1x1 convolutions hands its input gradient to the producing stage in compact form
-# (layers/nn.py DeferSlot.comp) instead of a zero-stuffed full-resolution tensor; SOD_COMPACT_S2_GRAD=0 scatters it as before
-COMPACT_S2_GRAD = os.environ.get("SOD_COMPACT_S2_GRAD", "1") != "0"
+# (layers/nn.py DeferSlot.comp) instead of a zero-stuffed full-resolution tensor; False scatters it as before
+COMPACT_S2_GRAD = True
 from .build import BACKBONE_REGISTRY, Backbone
 
 
@@ -140,21 +140,13 @@ class _BottleneckStageFn(torch.autograd.Function):
             for m in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut):
                 if m is not None:
                     m.prepare()
-        a_next = None           # conv1 output of the NEXT block, when the pair kernel produced it together with this block's output
         for k, blk in enumerate(blocks):
-            xin = saved[-1] if len(saved) == 1 else saved[-1]
+            xin = saved[-1]
             sc = _conv(blk.shortcut, xin, reverse=True) if blk.shortcut is not None else xin
-            a = a_next if a_next is not None else _conv(blk.conv1, xin, reverse=blk.shortcut is None)
-            a_next = None
+            a = _conv(blk.conv1, xin, reverse=blk.shortcut is None)
             b = _conv(blk.conv2, a)
             c3 = blk.conv3
-            nxt = blocks[k + 1] if k + 1 < len(blocks) else None
-            if (PAIR_FWD and need_bwd and nxt is not None and _pair_ok(c3, nxt.conv1, nxt.shortcut)):
-                # conv3 + residual + ReLU (+ bit mask) and the next block's conv1 + ReLU in ONE launch: the wide tensor is written once and
-                # never read back (csrc/bneck_pair.hip; bit-identical to the two launches)
-                out, bt, a_next = HF.bottleneck_pair(b, sc, c3.w_bf16, c3.bias_eff, nxt.conv1.w_bf16, nxt.conv1.bias_eff, 0)
-                bits.append(bt)
-            elif need_bwd and RELU_BITS and not HF.is_f32() and c3.relu and c3.out_channels % 8 == 0:
+            if need_bwd and RELU_BITS and not HF.is_f32() and c3.relu and c3.out_channels % 8 == 0:
                 N, Hb, Wb, _ = b.shape
                 Ho, Wo = HF.conv_out_size(Hb, Wb, c3.kernel_size, c3.kernel_size, c3.stride, c3.padding, c3.dilation)
                 bt = torch.empty(N * Ho * Wo * c3.out_channels // 8, dtype=torch.uint8, device=b.device)
@@ -219,21 +211,18 @@ class _BottleneckStageFn(torch.autograd.Function):
         else:
             g = HF.relu_bwd(dout.contiguous(), saved[-1])
         dx = None
-        db_ready = None         # conv3's data gradient of the block about to be visited, when the pair kernel of the block behind it made it
         for k in range(len(blocks) - 1, -1, -1):
             blk = blocks[k]
             xin, a, b = saved[3 * k], saved[3 * k + 1], saved[3 * k + 2]
             xin = saved[0] if k == 0 else saved[3 * k]        # block input = previous block's output
             _wgrad(blk.conv3, g, b, arena)
-            if db_ready is not None:
-                db, db_ready = db_ready, None
-            else:
-                db = _dgrad(blk.conv3, g, b, relu_mask=b, reverse=True)
+            db = _dgrad(blk.conv3, g, b, relu_mask=b, reverse=True)
             _wgrad(blk.conv2, db, a, arena)
             da = _dgrad(blk.conv2, db, a, relu_mask=a)
-            _wgrad(blk.conv1, da, xin, arena)
-            if blk.shortcut is not None:
-                _wgrad(blk.shortcut, g, xin, arena)
+            with HF.wgrad_batch():       # adjacent launches: one hand-over to the side stream for both
+                _wgrad(blk.conv1, da, xin, arena)
+                if blk.shortcut is not None:
+                    _wgrad(blk.shortcut, g, xin, arena)
             if k == 0:
                 if ctx.needs_input_grad[0]:
                     if ctx.in_slot is not None:      # compact gradient for the producer's fused launch; autograd sees no gradient here
@@ -246,14 +235,8 @@ class _BottleneckStageFn(torch.autograd.Function):
                     else:
                         dx = _dgrad(blk.conv1, da, xin, accum=g)
             else:   # previous block's output is post-ReLU: fold its mask and the identity-path gradient into the epilogue
-                prev = blocks[k - 1]
                 if blk.shortcut is not None:
                     g = _dgrad(blk.shortcut, g, xin, accum=_dgrad(blk.conv1, da, xin), **mask_of(k - 1))
-                elif bits is not None and PAIR_BWD and _pair_ok(prev.conv3, blk.conv1, None):
-                    # conv1's data gradient + identity gradient under block k-1's ReLU bits, and conv3(k-1)'s data gradient under its
-                    # input's ReLU, in ONE launch (the wide gradient is written once for the weight gradients and never read back)
-                    g, _, db_ready = HF.bottleneck_pair(da, g.contiguous(), blk.conv1.wt_bf16, None, prev.conv3.wt_bf16, None, 1,
-                                                        bits_in=bits[k - 1], mask2=saved[3 * (k - 1) + 2])
                 else:
                     g = _dgrad(blk.conv1, da, xin, accum=g, **mask_of(k - 1))
         return dx, None, None
@@ -261,27 +244,8 @@ class _BottleneckStageFn(torch.autograd.Function):
 
 # The convolutions that read the wide block tensor right after it was written (forward: shortcut / conv1; backward: conv3's data gradient)
 # walk their tiles last to first, i.e. start on the part of the tensor the 256 MB Infinity Cache still holds (sod_conv_set_reverse).
-# Same results; measured 621.8 / 623.1 -> 624.8 / 624.6 img/s (A/B in one gpurun call).  SOD_CONV_REVERSE=0 restores first-to-last.
-CONV_REVERSE = os.environ.get("SOD_CONV_REVERSE", "1") != "0"
-
-
-# The expand + contract pair kernel (csrc/bneck_pair.hip) for chains conv3(i) + residual + ReLU -> conv1(i + 1) inside a stage and their
-# data gradients.  SOD_PAIR_FWD / SOD_PAIR_BWD = 1 switch the forward / backward form on; SOD_PAIR_MAX_CN (default 128): widest
-# bottleneck the pair is used for (stand-alone, tools/bench_pair.py: res3 128 -> 512 -> 128 forward 258 -> 215 us, backward 244 -> 228 us;
-# res4 256 -> 1024 -> 256 is slower than the two launches, 155 -> 165 / 160 -> 190 us - its tiles are 96 pixels wide and stream every
-# weight once per tile).
-PAIR_FWD = os.environ.get("SOD_PAIR_FWD", "0") != "0"       # off by default: neutral on the step (614.7 / 613.8 / 615.1 img/s off, 615.4 /
-PAIR_BWD = os.environ.get("SOD_PAIR_BWD", "0") != "0"       # 613.1 / 616.4 forward pairs, 612.5 / 611.3 / 612.6 both; with res4: 590)
-PAIR_MAX_CN = int(os.environ.get("SOD_PAIR_MAX_CN", "128"))
-
-
-def _pair_ok(c3, c1, shortcut_of_next):
-    """conv3 (1x1, stride 1, ReLU, FrozenBN folded) of one block and conv1 (1x1, stride 1, ReLU) of the NEXT, identity-shortcut block."""
-    if not RELU_BITS or HF.is_f32() or shortcut_of_next is not None:
-        return False
-    ok = all(m.kernel_size == 1 and m.stride == 1 and m.padding == 0 and m.relu and getattr(m, "groups", 1) == 1 for m in (c3, c1))
-    return (ok and c3.in_channels == c1.out_channels and c3.out_channels == c1.in_channels and c1.out_channels <= PAIR_MAX_CN
-            and HF.bottleneck_pair_supported(c1.out_channels, c3.out_channels))
+# Same results; measured 621.8 / 623.1 -> 624.8 / 624.6 img/s (A/B in one gpurun call).  False restores first-to-last.
+CONV_REVERSE = True
 
 
 def _conv(m, x, res=None, reverse=False):

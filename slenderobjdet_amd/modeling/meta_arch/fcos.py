@@ -44,10 +44,6 @@ def _ceil8(v):
 # convs: 573.3-574.6 -> 583.1-584.1 img/s in a 4-round A/B, allocator pool 11.1 -> 14.9 GB and flat over 160 steps.
 # SOD_TOWER_STREAMS=0 keeps both towers on one stream.
 TOWER_STREAMS = os.environ.get("SOD_TOWER_STREAMS", "1") != "0"
-# EXPERIMENT (off): the convolutions of the two towers take turns (layers/nn.py ConvGate) so that a GroupNorm pass always runs beside a
-# convolution.  Measured SLOWER, 620.1 / 622.3 vs 625.8 / 625.4 img/s in one call: the hardware's own interleaving of the two queues
-# already does better than a forced alternation (which also idles one queue while it waits for the other's event).
-TOWER_GATE = os.environ.get("SOD_TOWER_GATE", "0") != "0"
 # SOD_TOWER_FOLD (default 1): the second tower's first data-gradient launch adds the first one's in its epilogue (layers/nn.py SiblingFold)
 # instead of autograd adding the two towers' input gradients itself (five elementwise launches).  Its effect is below the noise of 60-step
 # runs (round 3: 622.2 / 623.3 vs 622.2 / 623.5 img/s; round 4: 631.0 / 631.1 vs 632.4 / 633.2 with the accumulating tower on the side
@@ -128,9 +124,9 @@ class FCOSHead(nn.Module):
                 and all(f.requires_grad for f in feats) and isinstance(self.cls_tower[0], ConvGnRelu) and isinstance(self.bbox_tower[0], ConvGnRelu)):
             fold = _nn.SiblingFold()
 
-        def run(unit, xs, prev):     # consecutive ConvGnRelu units share the GroupNorm backward reduction (layers/nn.py GnBwdSlot)
+        def run(unit, xs, prev):     # the first units of the two towers share the SiblingFold
             if isinstance(unit, ConvGnRelu):
-                return unit(xs, chained=prev if isinstance(prev, ConvGnRelu) else None, fold=fold if prev is None else None)
+                return unit(xs, fold=fold if prev is None else None)
             return unit(xs)
 
         if not (TOWER_STREAMS and feats[0].is_cuda):
@@ -150,27 +146,23 @@ class FCOSHead(nn.Module):
         if s2 is None:
             # the box tower's stream at the HIGH HIP priority (-1): in backward it is the stream the main stream ends up waiting for (it
             # shares the CUs with the weight-gradient stream from its first kernel on).  Five + four alternating pairs of 100-step runs:
-            # 642.9 vs 640.5 img/s (+0.4 %), every pair in favour; with the main stream high as well: 635.5 vs 641.2.  SOD_TOWER_PRIO=0 = normal.
-            s2 = _tower_streams[dev.index] = HF.make_stream(dev, int(os.environ.get("SOD_TOWER_PRIO", "-1")), "TOWER")
+            # 642.9 vs 640.5 img/s (+0.4 %), every pair in favour; with the main stream high as well: 635.5 vs 641.2.
+            s2 = _tower_streams[dev.index] = HF.make_stream(dev, -1, "TOWER")
             HF.register_compute_stream(dev, s2)
         s2.wait_stream(main)
         for f in feats:
             f.record_stream(s2)
         pc = pb = None
-        _nn.ConvGate.current = _nn.ConvGate() if TOWER_GATE else None
-        try:
-            for i, (cu, bu) in enumerate(zip(self.cls_tower, self.bbox_tower)):
-                if i == 0 and fold is not None:
-                    # autograd runs the later-created node first: the box tower (whose stream gets ahead of the main stream in
-                    # backward - the main stream also carries the loss node) parks its gradient, the classification tower on the main
-                    # stream adds it without waiting.  The other way round the main stream waits for a serialised second launch.
-                    cls_t, pc = run(cu, cls_t, pc), cu
-                with torch.cuda.stream(s2):
-                    box_t, pb = run(bu, box_t, pb), bu
-                if not (i == 0 and fold is not None):
-                    cls_t, pc = run(cu, cls_t, pc), cu
-        finally:
-            _nn.ConvGate.current = None
+        for i, (cu, bu) in enumerate(zip(self.cls_tower, self.bbox_tower)):
+            if i == 0 and fold is not None:
+                # autograd runs the later-created node first: the box tower (whose stream gets ahead of the main stream in
+                # backward - the main stream also carries the loss node) parks its gradient, the classification tower on the main
+                # stream adds it without waiting.  The other way round the main stream waits for a serialised second launch.
+                cls_t, pc = run(cu, cls_t, pc), cu
+            with torch.cuda.stream(s2):
+                box_t, pb = run(bu, box_t, pb), bu
+            if not (i == 0 and fold is not None):
+                cls_t, pc = run(cu, cls_t, pc), cu
         main.wait_stream(s2)
         for t in box_t:
             t.record_stream(main)
@@ -257,12 +249,16 @@ class _FcosHeadLossFn(torch.autograd.Function):
             offs.append(off)
             off += h * w
         grads = []
-        for pred, dbuf, kk, tower, kr in ((head.cls_pred, dcls, kcp, cls_t, head.kc), (head.box_pred, dbox, 8, box_t, 5 if head.centerness_on_reg else 4)):
+        preds = ((head.cls_pred, dcls, kcp, cls_t, head.kc), (head.box_pred, dbox, 8, box_t, 5 if head.centerness_on_reg else 4))
+        with HF.wgrad_batch():      # the four weight / bias gradient launches of the two prediction convs: one hand-over to the side stream
+            for pred, dbuf, kk, tower, kr in preds:
+                dys = [dbuf.view(-1)[o * kk:] for o in offs]
+                HF.conv2d_wgrad_ml(dys, list(tower), arena.grad_view(pred.weight), 3, 3, 1, 1, 1, dy_img_stride=L * kk, K=kk, k_real=kr)
+                arena.mark_ready(pred.weight)
+                HF.bias_grad(dbuf, arena.grad_view(pred.bias), N, L, kk)
+                arena.mark_ready(pred.bias)
+        for pred, dbuf, kk, tower, kr in preds:
             dys = [dbuf.view(-1)[o * kk:] for o in offs]
-            HF.conv2d_wgrad_ml(dys, list(tower), arena.grad_view(pred.weight), 3, 3, 1, 1, 1, dy_img_stride=L * kk, K=kk, k_real=kr)
-            arena.mark_ready(pred.weight)
-            HF.bias_grad(dbuf, arena.grad_view(pred.bias), N, L, kk)
-            arena.mark_ready(pred.bias)
             grads.append(HF.conv2d_dgrad_ml(dys, pred.wt_bf16, hw, 1, 1, 1, dy_img_stride=L * kk, N=N, k_real=kr))
         grads_cls, grads_box = grads
         return (None, None, None, None, None, None, None, *grads_cls, *grads_box)
@@ -319,7 +315,7 @@ class FCOSV2(nn.Module):
             bottom.prepare_frozen_prefix()
         side = _prefetch_streams.get(dev.index)
         if side is None:
-            side = _prefetch_streams[dev.index] = HF.make_stream(dev, int(os.environ.get("SOD_PREFETCH_PRIO", "0")), "PREFETCH")
+            side = _prefetch_streams[dev.index] = HF.make_stream(dev, 0, "PREFETCH")
         side.wait_stream(main)
         self._prefetched = None
         with torch.cuda.stream(side):

@@ -15,8 +15,8 @@ from .build import META_ARCH_REGISTRY
 from .fcos import FCOSV2
 
 
-# SOD_RCNN_GRAD_PARK=0: autograd adds the ROI pooler's and the RPN head's feature gradients itself (one elementwise pass per level)
-GRAD_PARK = os.environ.get("SOD_RCNN_GRAD_PARK", "1") != "0"
+# GRAD_PARK = False: autograd adds the ROI pooler's and the RPN head's feature gradients itself (one elementwise pass per level)
+GRAD_PARK = True
 
 
 @META_ARCH_REGISTRY.register()

@@ -30,8 +30,8 @@ def _ceil8(v):
     return (v + 7) // 8 * 8
 
 
-# SOD_PRED_DGRAD_PAD=0: the data gradient of the class-score conv on the per-chunk gather path (its 720 channels are no multiple of 64)
-PRED_DGRAD_PAD = os.environ.get("SOD_PRED_DGRAD_PAD", "1") != "0"
+# PRED_DGRAD_PAD = False: the data gradient of the class-score conv on the per-chunk gather path (its 720 channels are no multiple of 64)
+PRED_DGRAD_PAD = True
 # SOD_FOCAL_FUSED=0: the focal loss as a forward pass (sum) and a backward pass (scaled gradient) over the fp32 logits - 1 GB each at batch 16
 FOCAL_FUSED = os.environ.get("SOD_FOCAL_FUSED", "1") != "0"
 

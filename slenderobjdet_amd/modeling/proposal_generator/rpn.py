@@ -62,9 +62,9 @@ class StandardRPNHead(nn.Module):
         return self.objectness_logits(t), self.anchor_deltas(t)      # per level (N,H,W,obj_pad) / (N,H,W,delta_pad) fp32
 
 
-# SOD_RPN_HEAD_FUSED=0: the three convolutions of the RPN head as three autograd nodes (autograd then adds the two data gradients of the hidden
+# RPN_HEAD_FUSED = False: the three convolutions of the RPN head as three autograd nodes (autograd then adds the two data gradients of the hidden
 # tensor per level and the hidden conv applies its ReLU mask in a pass of its own)
-RPN_HEAD_FUSED = os.environ.get("SOD_RPN_HEAD_FUSED", "1") != "0"
+RPN_HEAD_FUSED = True
 
 
 class _RpnHeadFn(torch.autograd.Function):

@@ -123,38 +123,3 @@ def test_fused_frozen_bottleneck_rejects_bad_operands(cuda):
         HF.bottleneck_frozen_fwd(z(1, 8, 16, 128), z(64, 1, 1, 128), b(64), z(64, 3, 3, 64), b(64), z(256, 1, 1, 64), b(256), z(256, 1, 1, 128))
     with pytest.raises(_C.SlenderHipError):      # CPU tensors: no fallback
         HF.bottleneck_frozen_fwd(z(1, 8, 16, 256).cpu(), z(64, 1, 1, 256), b(64), z(64, 3, 3, 64), b(64), z(256, 1, 1, 64), b(256), None)
-
-
-@pytest.mark.parametrize("CN,CW,N,H,W", [(128, 512, 2, 20, 36), (256, 1024, 2, 13, 21), (128, 512, 1, 7, 9), (256, 1024, 3, 50, 84)])
-def test_bottleneck_pair_is_bit_identical_to_the_two_launches(cuda, CN, CW, N, H, W):
-    """sod_bottleneck_pair (csrc/bneck_pair.hip): the expanding 1x1 convolution with its add operand / nonlinearity and the contracting
-    1x1 convolution behind it in one launch, against the two launches it replaces - same MFMA instruction, same k order, same epilogue
-    arithmetic, so EQUAL bit for bit, wide tensor, ReLU bits and narrow tensor, in the forward form (conv3 + residual + ReLU -> conv1 +
-    ReLU of the next block) and the backward form (conv1's data gradient + identity gradient under the ReLU bits -> conv3's data
-    gradient under its input's ReLU mask).  Tile sizes: ragged last tile, fewer tiles than CUs, several tiles per CU."""
-    from slenderobjdet_amd.layers import functional as HF
-
-    g = torch.Generator().manual_seed(5)
-    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(cuda)
-    xin = r(N, H, W, CN).relu().bfloat16()
-    add = r(N, H, W, CW).bfloat16()
-    w_e, w_c = r(CW, 1, 1, CN, sc=0.05), r(CN, 1, 1, CW, sc=0.03)
-    we, we_t = HF.weight_prep(w_e)          # KRSC (CW,1,1,CN) and CRSK (CN,1,1,CW)
-    wc, wc_t = HF.weight_prep(w_c)          # KRSC (CN,1,1,CW) and CRSK (CW,1,1,CN)
-    be, bc = r(CW), r(CN)
-    assert HF.bottleneck_pair_supported(CN, CW)
-    # ---- forward form
-    bits_ref = torch.empty(N * H * W * CW // 8, dtype=torch.uint8, device=cuda)
-    y_ref = HF.conv2d_fwd(xin, we, be, add, relu=True, relu_bits=bits_ref)
-    h_ref = HF.conv2d_fwd(y_ref, wc, bc, relu=True)
-    y, bits, h = HF.bottleneck_pair(xin, add, we, be, wc, bc, 0)
-    assert torch.equal(y, y_ref) and torch.equal(bits, bits_ref) and torch.equal(h, h_ref)
-    # ---- backward form: da (narrow) -> g (wide) = bits ? da x W1 + g_skip : 0 -> db (narrow) = (b > 0) ? g x W3 : 0
-    da = r(N, H, W, CN).bfloat16()
-    gskip = r(N, H, W, CW).bfloat16()
-    b = r(N, H, W, CN).bfloat16()
-    g_ref = HF.conv2d_dgrad(da, wc_t, (H, W), accum=gskip, relu_bits=bits_ref)          # conv1: weights w_c (CN out, CW in); its CRSK copy is (CW,1,1,CN)
-    db_ref = HF.conv2d_dgrad(g_ref, we_t, (H, W), relu_mask=b)                          # conv3: weights w_e (CW out, CN in); its CRSK copy is (CN,1,1,CW)
-    g2, none_bits, db = HF.bottleneck_pair(da, gskip, wc_t, None, we_t, None, 1, bits_in=bits_ref, mask2=b)
-    assert none_bits is None
-    assert torch.equal(g2, g_ref) and torch.equal(db, db_ref)

@@ -170,8 +170,9 @@ def test_conv_wgrad(cuda, case):
     _close(dw, 2 * dw_ref, 2e-4, f"wgrad accumulate {case}")
 
 
-# conv_wgrad_ring.hip: G groups of four waves split one tile's pixel range and combine through LDS.  G*1000 + NSTAGE*100 + EPI*10 + FDB
-RING_VARIANTS = [1300, 1311, 2300, 2301, 2310, 2311, 2400, 2411]
+# conv_wgrad_ring.hip: G groups of four waves split one tile's pixel range and combine through LDS.  G*1000 + NSTAGE*100 + EPI*10 (atomic /
+# slab epilogue; the fragment-double-buffered, four-slot and one-group variants of round 4 measured neutral and left the tree)
+RING_VARIANTS = [2300, 2310]
 
 
 @pytest.mark.parametrize("variant", RING_VARIANTS)
@@ -709,42 +710,3 @@ def test_relu_bit_masks_match_tensor_masks(cuda):
     b = HF.conv2d_dgrad(d(dy), d(wt), (H, W), accum=d(accum), relu_mask=y)
     assert torch.equal(a, b)
     assert (a != 0).any()
-
-
-def test_dgrad_epilogue_groupnorm_backward_reduction(cuda):
-    """sod_conv2d_dgrad_ml_gnbwd + sod_groupnorm_bwd_apply_ml (the reduction pass of GroupNorm+ReLU's backward gathered in the epilogue
-    of the data gradient that produces the norm's output gradient; 256x256 and 128x128 kernels, levels whose wave ranges straddle
-    images) against conv2d_dgrad_ml -> groupnorm_bwd_ml: the data gradient itself is bit-identical; the norm's input gradient agrees
-    to one bf16 ulp, dgamma / dbeta / the bias gradient to fp32 summation-order accuracy."""
-    from slenderobjdet_amd.layers import functional as HF
-
-    N, C, G = 3, 256, 32
-    hw = [(23, 37), (12, 19), (6, 10), (3, 5)]
-    gen = torch.Generator().manual_seed(50)
-    d = lambda t: t.to(cuda).to(torch.bfloat16).contiguous()
-    f = lambda t: t.to(cuda).contiguous()
-    x1 = [d(_rand((N, h, w, C), 60 + i)) for i, (h, w) in enumerate(hw)]            # the norm's inputs (conv outputs of the previous unit)
-    gamma, beta = f(torch.rand(C, generator=gen) + 0.5), f(torch.randn(C, generator=gen) * 0.3)
-    _, stats = HF.groupnorm_fwd_ml(x1, gamma, beta, G, relu=True)
-    dy = [d(_rand((N, h, w, C), 70 + i)) for i, (h, w) in enumerate(hw)]            # gradient w.r.t. the NEXT conv's output
-    wt = d(_rand((C, 3, 3, C), 80, scale=(9 * C) ** -0.5))
-    for tile256 in (1, 0):
-        HF.call("sod_conv_set_tile256", 2 if tile256 else 0)
-        try:
-            dg_a, db_a = torch.zeros(C, device=cuda), torch.zeros(C, device=cuda)
-            dxs, red = HF.conv2d_dgrad_ml_gnbwd(dy, wt, hw, x1, stats, gamma, beta, dg_a, db_a, G, 1, 1, 1)
-            ref = HF.conv2d_dgrad_ml(dy, wt, hw, 1, 1, 1)
-        finally:
-            HF.call("sod_conv_set_tile256", 1)
-        for a, b in zip(dxs, ref):
-            assert torch.equal(a, b), tile256
-        dsum_a = torch.zeros(C, device=cuda)
-        got = HF.groupnorm_bwd_apply_ml(dxs, x1, gamma, beta, stats, red, G, relu=True, dxsum=dsum_a)
-        dg_b, db_b, dsum_b = torch.zeros(C, device=cuda), torch.zeros(C, device=cuda), torch.zeros(C, device=cuda)
-        want = HF.groupnorm_bwd_ml(ref, x1, gamma, beta, stats, G, dg_b, db_b, relu=True, dxsum=dsum_b)
-        for l, (a, b) in enumerate(zip(got, want)):
-            sc = b.float().abs().max().item()
-            assert (a.float() - b.float()).abs().max().item() <= 2 ** -7 * sc, (tile256, l)
-        for a, b, nm in ((dg_a, dg_b, "dgamma"), (db_a, db_b, "dbeta"), (dsum_a, dsum_b, "dxsum")):
-            tol = 2e-4 * max(b.abs().max().item(), 1e-6) + (2e-2 * b.abs().max().item() if nm == "dxsum" else 0.0)
-            assert (a - b).abs().max().item() <= tol, (nm, tile256, (a - b).abs().max().item(), b.abs().max().item())

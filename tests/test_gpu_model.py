@@ -875,89 +875,6 @@ def test_relu_bit_masks_leave_the_step_bit_identical(cuda):
         HF.DETERMINISTIC = prev
 
 
-def test_bottleneck_pair_kernel_leaves_the_step_bit_identical(cuda):
-    """resnet.PAIR_FWD / PAIR_BWD (off by default): conv3 + residual + ReLU of a block and conv1 + ReLU of the next one as ONE launch
-    (csrc/bneck_pair.hip), and the two data gradients of that chain as one launch in backward, for the res3 and res4 chains of R50:
-    losses and every gradient equal bit for bit to the step built from the separate launches (deterministic mode)."""
-    from slenderobjdet_amd.data import synthetic_batch
-    from slenderobjdet_amd.layers import functional as HF
-    from slenderobjdet_amd.modeling.backbone import resnet
-
-    cfg, model, opt = _build(50, seed=6)
-    data = synthetic_batch(2, 320, 384, 11, device="cuda")
-    prev, HF.DETERMINISTIC = HF.DETERMINISTIC, True
-    keep = (resnet.PAIR_FWD, resnet.PAIR_BWD, resnet.PAIR_MAX_CN)
-    try:
-        def step(fwd, bwd):
-            resnet.PAIR_FWD, resnet.PAIR_BWD, resnet.PAIR_MAX_CN = fwd, bwd, 256
-            opt.zero_grad()
-            out = model(data)
-            total = sum(out.values())
-            model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
-            return {k: float(v.detach()) for k, v in out.items()}, model.arena.grads.clone()
-
-        ref_l, ref_g = step(False, False)
-        for fwd, bwd in ((True, False), (False, True), (True, True)):
-            got_l, got_g = step(fwd, bwd)
-            assert got_l == ref_l, (fwd, bwd)
-            assert torch.equal(got_g, ref_g), (fwd, bwd)
-    finally:
-        resnet.PAIR_FWD, resnet.PAIR_BWD, resnet.PAIR_MAX_CN = keep
-        HF.DETERMINISTIC = prev
-
-
-def test_groupnorm_backward_reduction_in_the_consumer_dgrad(cuda):
-    """Inside the FCOS towers a unit's data gradient gathers the reduction pass of the PREVIOUS unit's GroupNorm backward (layers/nn.py
-    GnBwdSlot).  Same losses bit for bit (forward untouched); gradients agree with the two-pass form to the accuracy float atomics
-    in a different order allow; and the fused path really runs (3 of the 4 units of each tower)."""
-    from slenderobjdet_amd.data import synthetic_batch
-    from slenderobjdet_amd.layers import functional as HF
-    from slenderobjdet_amd.layers import nn as HN
-
-    cfg, model, opt = _build(50, seed=8)
-    data = synthetic_batch(2, 320, 384, 13, device="cuda")
-    calls = {"fused": 0}
-    orig = HF.conv2d_dgrad_ml_gnbwd
-
-    def counting(*a, **k):
-        calls["fused"] += 1
-        return orig(*a, **k)
-
-    prev_flag = HN.GN_BWD_FUSED
-
-    def step(on):
-        HN.GN_BWD_FUSED = on
-        opt.zero_grad()
-        out = model(data)
-        total = sum(out.values())
-        model.arena.begin_backward(); total.backward(); model.arena.finish_backward()
-        return {k: float(v.detach()) for k, v in out.items()}, model.arena.grads.clone()
-
-    try:
-        ref_l, ref_g = step(False)
-        ref2_l, ref2_g = step(False)         # the run-to-run noise of the two-pass form itself (float atomics)
-        HF.conv2d_dgrad_ml_gnbwd = counting
-        got_l, got_g = step(True)
-        assert calls["fused"] == 6, calls
-        # the forward pass is the same code in all steps; its GroupNorm statistics come from float atomics (not bit-reproducible)
-        for k in ref_l:
-            assert abs(got_l[k] - ref_l[k]) <= 2e-4 * abs(ref_l[k]), (k, got_l[k], ref_l[k])
-        # Every gradient may differ from the two-pass form by no more than that form differs from itself between two runs (x4, + 1 %):
-        # a last-bit change in one norm's sums moves bf16 roundings downstream, and sums with cancellation (dgamma) show it at the
-        # per-cent level either way.  A wrong reduction (missing mask, wrong group, lost pixels) is off by tens of per cent.
-        worst = 0.0
-        for name, off, n in model.arena.names:
-            a, b, b2 = got_g[off:off + n], ref_g[off:off + n], ref2_g[off:off + n]
-            nb = max(b.norm().item(), 1e-12)
-            d, noise = (a - b).norm().item() / nb, (b2 - b).norm().item() / nb
-            worst = max(worst, d)
-            assert d <= 4.0 * noise + 1e-2, (name, d, noise)
-        assert worst < 0.3
-    finally:
-        HF.conv2d_dgrad_ml_gnbwd = orig
-        HN.GN_BWD_FUSED = prev_flag
-
-
 def test_tower_input_gradients_folded_into_the_second_dgrad(cuda):
     """The two towers of FCOSHead read the same FPN outputs (fcosv2.py:342-361).  The tower whose backward runs second adds the first
     one's data gradient in the epilogue of its own launch (layers/nn.py SiblingFold) instead of leaving five elementwise additions to
