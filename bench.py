@@ -121,8 +121,10 @@ def damp_residual_branches(model, gamma=0.25):
     return n
 
 
-# SOD_PREFETCH=0: no software pipelining of the frozen backbone prefix (see train_step)
+# SOD_PREFETCH=0: no software pipelining of the frozen backbone prefix (see train_step); "fwd" (rounds 2-4): the next batch's prefix is
+# enqueued between this step's forward and backward; "bwd" (EXPERIMENT): after backward, starting when the main stream has finished its data gradients
 PREFETCH = os.environ.get("SOD_PREFETCH", "1") != "0"
+PREFETCH_AT = os.environ.get("SOD_PREFETCH_AT", "fwd")
 
 
 def train_step(model, optimizer, data, next_data=None, scheduler=None):
@@ -131,12 +133,16 @@ def train_step(model, optimizer, data, next_data=None, scheduler=None):
     share the GPU with the MFMA-bound head backward; the next step's forward picks the result up.  Every step still carries exactly one
     frozen prefix (the next batch's instead of its own)."""
     losses = model(data)
-    if next_data is not None and PREFETCH and hasattr(model, "prefetch"):
+    pre = next_data is not None and PREFETCH and hasattr(model, "prefetch")
+    if pre and PREFETCH_AT == "fwd":
         model.prefetch(next_data)
     total = sum(losses.values())
     optimizer.zero_grad()
     model.arena.begin_backward()
     total.backward()
+    if pre and PREFETCH_AT != "fwd":
+        from slenderobjdet_amd.layers import functional as HF
+        model.prefetch(next_data, after=HF.backward_main_done_event(total.device))
     model.arena.finish_backward()
     optimizer.step()
     if scheduler is not None:       # the reference steps its WarmupMultiStepLR once per iteration (detectron2 hooks.LRScheduler.after_step)

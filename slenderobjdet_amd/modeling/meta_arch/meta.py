@@ -26,11 +26,12 @@ from ...layers.nn import ConvGnRelu, ConvML, ConvReluML, HipConv2d
 
 
 def _run_tower(units, xs):
-    """A tower of [conv -> (GroupNorm) -> ReLU] units: every unit is told which unit produced its input (that unit's ONLY consumer), so
-    that its data gradient can take over the producer's ReLU backward (layers/nn.py _ReluToken / GnBwdSlot)."""
+    """A tower of [conv -> (GroupNorm) -> ReLU] units: a [conv -> ReLU] unit is told which unit produced its input (that unit's ONLY
+    consumer), so that its data gradient can take over the producer's ReLU backward (layers/nn.py _ReluToken)."""
     prev = None
     for u in units:
-        xs, prev = u(xs, chained=prev), u
+        xs = u(xs, chained=prev if isinstance(prev, ConvReluML) else None) if isinstance(u, ConvReluML) else u(xs)
+        prev = u
     return xs
 from ...structures import Boxes, Instances
 from ...utils.registry import Registry
