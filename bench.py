@@ -121,10 +121,11 @@ def damp_residual_branches(model, gamma=0.25):
     return n
 
 
-# SOD_PREFETCH=0: no software pipelining of the frozen backbone prefix (see train_step); "fwd" (rounds 2-4): the next batch's prefix is
-# enqueued between this step's forward and backward; "bwd" (EXPERIMENT): after backward, starting when the main stream has finished its data gradients
+# SOD_PREFETCH=0: no software pipelining of the frozen backbone prefix (see train_step).  The next batch's prefix is enqueued between this
+# step's forward and backward.  (Round 5 also measured it at the END of backward - started when the main stream has finished its data
+# gradients, beside the weight-gradient tail, the optimizer and the next step's prologue: 640.0 vs 642.9 img/s, three alternating 100-step
+# pairs; the weight-gradient tail is the critical path there and the prefix's whole-CU workgroups lengthen it.)
 PREFETCH = os.environ.get("SOD_PREFETCH", "1") != "0"
-PREFETCH_AT = os.environ.get("SOD_PREFETCH_AT", "fwd")
 
 
 def train_step(model, optimizer, data, next_data=None, scheduler=None):
@@ -133,16 +134,12 @@ def train_step(model, optimizer, data, next_data=None, scheduler=None):
     share the GPU with the MFMA-bound head backward; the next step's forward picks the result up.  Every step still carries exactly one
     frozen prefix (the next batch's instead of its own)."""
     losses = model(data)
-    pre = next_data is not None and PREFETCH and hasattr(model, "prefetch")
-    if pre and PREFETCH_AT == "fwd":
+    if next_data is not None and PREFETCH and hasattr(model, "prefetch"):
         model.prefetch(next_data)
     total = sum(losses.values())
     optimizer.zero_grad()
     model.arena.begin_backward()
     total.backward()
-    if pre and PREFETCH_AT != "fwd":
-        from slenderobjdet_amd.layers import functional as HF
-        model.prefetch(next_data, after=HF.backward_main_done_event(total.device))
     model.arena.finish_backward()
     optimizer.step()
     if scheduler is not None:       # the reference steps its WarmupMultiStepLR once per iteration (detectron2 hooks.LRScheduler.after_step)

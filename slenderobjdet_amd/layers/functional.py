@@ -149,25 +149,11 @@ def wgrad_side_streams(device):
     return list(_side_streams.get(device.index, ())) if _side_join_queued else []
 
 
-# The moment the main stream has finished its OWN part of a backward pass (every data gradient), recorded just before it starts waiting for
-# the weight-gradient side stream: from here to the first convolution of the next forward pass the GPU runs the weight-gradient tail, the
-# optimizer and the next step's small prologue kernels - the window FCOSV2.prefetch(after=...) puts the next batch's frozen prefix into.
-_backward_main_done = {}
-
-
-def backward_main_done_event(device):
-    """The event of the most recent backward pass on ``device`` (None before the first)."""
-    return _backward_main_done.get(device.index if device.index is not None else torch.cuda.current_device())
-
-
 def _wgrad_join():
     global _side_join_queued
     _side_join_queued = False
     for idx, sides in _side_streams.items():
         main = torch.cuda.current_stream(idx)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        _backward_main_done[idx] = ev
         for side in sides:
             main.wait_stream(side)
     _side_keep.clear()      # the main stream now waits for every side-stream reader: the operands may go back to its pool

@@ -297,15 +297,12 @@ class FCOSV2(nn.Module):
         return self.pixel_mean.device
 
     # ------------------------------------------------------------------ forward
-    def prefetch(self, batched_inputs, after=None):
+    def prefetch(self, batched_inputs):
         """Software pipelining for training loops: run ``preprocess_image`` and the FROZEN bottom of the backbone (stem + the
         FREEZE_AT stages: no gradient, weights that never change) for the NEXT batch on a side stream.  Called between forward and
         backward of the current batch, the side stream starts when that forward has finished on the GPU, so the HBM-bound frozen
         convolutions run beside the MFMA-bound head backward.  ``forward`` picks the result up when it is handed the same list
-        object; a batch that was not prefetched (or another list) takes the normal path.  Results are identical either way.
-        ``after``: an event the side stream waits for INSTEAD of the current stream's position - called after ``backward()`` with
-        ``functional.backward_main_done_event(device)``, the prefix runs beside the weight-gradient tail of backward, the optimizer and the
-        next step's prologue (the low-occupancy window around the step boundary) instead of beside the loss backward."""
+        object; a batch that was not prefetched (or another list) takes the normal path.  Results are identical either way."""
         bottom = getattr(self.backbone, "bottom_up", self.backbone)
         if not (self.device.type == "cuda" and hasattr(bottom, "forward_frozen_prefix")) or bottom.frozen_prefix_len() < 0:
             return False
@@ -319,10 +316,7 @@ class FCOSV2(nn.Module):
         side = _prefetch_streams.get(dev.index)
         if side is None:
             side = _prefetch_streams[dev.index] = HF.make_stream(dev, 0, "PREFETCH")
-        if after is not None:
-            side.wait_event(after)
-        else:
-            side.wait_stream(main)
+        side.wait_stream(main)
         self._prefetched = None
         with torch.cuda.stream(side):
             images = self.preprocess_image(batched_inputs)

@@ -396,6 +396,7 @@ def test_free_run_on_shared_relu_decisions(cuda, mode, depth, iters, size):
         assert hip[-1] < hip[0] - 0.3                   # and the run trained (2.84 -> 1.9 in the free runs above)
 
 
-# |bf16 product - fp32 oracle| over the 100 free iterations on shared decisions: measured in round 5; the bound is
-# 3 x that measurement
-BF16_SHARED_BOUND = 3e-2
+# |bf16 product - fp32 oracle| over the 100 free iterations on shared decisions, measured in round 5: 1.1e-3 at
+# iteration 100, 1.3e-3 at worst (loss 2.844 -> 1.929) - the bf16 STORAGE floor of this run, at north_star's 1e-3 and not reliably under it
+# (the default reductions are float atomics: the figure moves in the fourth digit from run to run).  Bound = 4 x the measurement.
+BF16_SHARED_BOUND = 5e-3
