@@ -848,7 +848,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
   a.div_rs = make_fastdiv((uint32_t)(a.R * a.S));
   // K order (channel chunk outer, tap inner): consecutive K-steps re-read the same pixel rows shifted by one tap, i.e. lines the CU's vector
   // cache still holds.  Few output channels, where the pixel operand is all the traffic: box_pred fwd 0.223 -> 0.111 ms.  For the other
-  // shapes it is worth 0-3 % (the 128 -> 128 3x3 of res3: 119.1 -> 115.8 us; SOD_CONV_TAP_INNER=1: 629.9 -> 632.5 img/s over three
+  // shapes it is worth 0-3 % (the 128 -> 128 3x3 of res3: 119.1 -> 115.8 us; tap-inner everywhere: 629.9 -> 632.5 img/s over three
   // alternating pairs, inside the noise) and it changes the fp32 summation order of every 3x3 convolution, which the bf16 whole-model tests
   // on random-init models are sensitive to (discrete ReLU / sampling events): not the default.
   a.tap_inner = conv_tap_inner(BQ <= 16 ? 1 : 0);
@@ -1030,7 +1030,7 @@ int device_cus() {
 }
 
 // Which kernel a weight gradient goes to.  SOD_WGRAD256: 0 = never, 1 (default) = shapes with K, C multiples of 256 whose blocks get
-// at least SOD_WGRAD256_MIN_KT (64) K-tiles of work each, 2 = every supported shape (parity tests).
+// at least 64 K-tiles of work each, 2 = every supported shape (parity tests).
 bool use_wgrad256(const WgradArgs& a, float* ws, long long ws_bytes) {
   static const int mode = getenv("SOD_WGRAD256") ? atoi(getenv("SOD_WGRAD256")) : 1;
   // Blocks with few K-tiles are dominated by their 256-KB slab write, and the 48-KB workgroups of the 128x128 kernel share CUs with the
@@ -1098,7 +1098,7 @@ int launch_wgrad(WgradArgs& a, int splits, int flags, hipStream_t st, float* ws 
   }
   a.V = V;
   // In-workgroup split over pixels with an LDS combine (conv_wgrad_ring.hip).  g_wgrad_variant: 0 = the kernel below, > 0 forces one
-  // variant of launch_wgrad_ring for every shape, -1 (default) = SOD_WGRAD_VARIANT or the per-shape choice of ring_variant_for().
+  // variant of launch_wgrad_ring for every shape, -1 (default) = the per-shape choice of ring_variant_for().
   {
     const int variant = ring_variant_for(a, tiles, splits, ws, ws_bytes);
     if (variant > 0) {

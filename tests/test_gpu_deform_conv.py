@@ -154,7 +154,7 @@ def test_deform_conv_fused_backward(cuda, modulated, dg, stride, C, K, hw):
 
 
 def test_deform_backward_window_counter(cuda):
-    """The tiled backward kernels keep dX in an LDS window of the 8x8 tile's receptive field + SOD_DCN_FUSED_R (2) px of slack; a sample
+    """The tiled backward kernels keep dX in an LDS window of the 8x8 tile's receptive field + 2 px of slack (sod_deform_conv_set_window_slack); a sample
     outside it takes the global-atomic path - a performance cliff on a data-dependent quantity (RepPoints' learned offsets,
     rpd.py:637-647).  The counter (sod_deform_conv_set_window_counter) must read 0 while every offset stays within the slack, and stay a
     bounded share at 4x that; the results are the same either way (checked against the two-kernel path by the tests above)."""

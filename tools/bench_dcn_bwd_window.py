@@ -32,8 +32,7 @@ def main():
     w = (torch.randn(K, 1, 1, 9 * C, device=dev) * 0.02)
     _, wt = HF.weight_prep(w)
     lanes = N * H * W * 9 * (C // 8)
-    print(f"P3 level of RepPoints at batch 16: {N}x{H}x{W}, {C} -> {K}, 3x3; {lanes / 1e6:.1f} M sample lanes; window slack SOD_DCN_FUSED_R = "
-          f"{os.environ.get('SOD_DCN_FUSED_R', '2')} px")
+    print(f"P3 level of RepPoints at batch 16: {N}x{H}x{W}, {C} -> {K}, 3x3; {lanes / 1e6:.1f} M sample lanes; window slack = the library default (2 px) unless a row says otherwise")
     for std in (0.5, 1.0, 2.0, 4.0, 8.0, 16.0):
         off = torch.randn(N, H, W, 18, device=dev) * std
         doff = torch.zeros_like(off)
