@@ -150,6 +150,11 @@ int sod_conv2d_wgrad_ml(int nlev, const void* const* dy, const void* const* x, f
 int sod_conv2d_dgrad_cwin(const void* dy, const void* wt_win, const void* relu_mask, void* dx,
                           int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, void* stream);
 int sod_conv_set_tile256(int mode);
+/* Process-wide: 1 (default; -1 = re-read SOD_CONV_PW) sends the EXPANDING 1x1 convolutions of the bottleneck blocks and their data gradients
+ * (C in {128, 256, 512} -> 4 / 8 / 16 x 128 channels, stride 1, one dense level, >= 16384 pixels, 256-CU device; forward epilogues bias /
+ * shortcut / ReLU / bit mask, backward accumulate / bit mask) to the persistent weight-stationary kernel of conv_pw.hip; 0 keeps them on
+ * the tiled kernels.  Bit-identical results either way (d2 BottleneckBlock conv3 / conv1 under slender_det/modeling/backbone/fpn.py:94-115). */
+int sod_conv_set_pw(int on);
 /* Kernel policy of sod_conv2d_wgrad / _wgrad_ml for the shapes the 256x256 kernel does not take (process-wide): -1 (default) = env
  * SOD_WGRAD_VARIANT or the library's per-shape choice; 0 = conv_wgrad_kernel (two 4-wave workgroups per CU, float atomics);
  * G*1000 + NSTAGE*100 + EPI*10 + FDB = one variant of conv_wgrad_ring_kernel for every shape (G = 1 | 2 groups of four waves per

@@ -111,6 +111,10 @@ bool conv256_supported(const ConvArgs& a, int mode);
 // max_pt_tiles > 0 launches only the first max_pt_tiles pixel tiles (the caller covers the rest with the 128x128 kernel).
 int launch_conv256(const ConvArgs& a, int mode, bool out_f32, int max_pt_tiles, hipStream_t st);
 
+// conv_pw.hip: persistent weight-stationary kernel for the expanding 1x1 convolutions of the bottleneck blocks (and their data gradients)
+bool pw_supported(const ConvArgs& a, int mode, bool out_f32, int cus);
+int launch_pw(const ConvArgs& a, int mode, hipStream_t st);
+
 // --------------------------------------------------------------------------------------------
 // wgrad: dW[q][tap][c] += sum_p dY[p][q] * X[p shifted by tap][c]
 // The contraction runs over a VIRTUAL pixel index that concatenates the levels (each padded to a multiple of 64), so

@@ -883,6 +883,8 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
 
 thread_local int g_conv_reverse = 0;    // sod_conv_set_reverse: per calling thread (the forward thread and autograd's worker each bracket their own launches)
 int g_conv256_mode = -1;   // -1: read SOD_CONV256 (default 1); 0 off; 1 heuristic; 2 every supported shape
+int g_conv_pw = -1;        // -1: read SOD_CONV_PW (default 1); 0 off; 1 on (sod_conv_set_pw)
+int device_cus();
 
 template <int MODE, bool OUT_F32>
 int dispatch_conv(const ConvArgs& a, hipStream_t st) {
@@ -890,6 +892,15 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   if (a.cwin) {         // channel window: the window IS the 128-row q-tile of this variant; Cred = 128 -> never generic
     if (generic || a.nlev != 1 || (a.Nout & 127)) return SOD_EARG;
     return launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32>(a, st);
+  }
+  // persistent weight-stationary kernel (conv_pw.hip) for the expanding 1x1 convolutions; SOD_CONV_PW=0 / sod_conv_set_pw(0) disables it
+  if (g_conv_pw < 0) { const char* e = getenv("SOD_CONV_PW"); g_conv_pw = e ? atoi(e) : 1; }
+  if (g_conv_pw && pw_supported(a, MODE, OUT_F32, device_cus())) {
+    g_last_variant = 7001;
+    const int pi = prof_begin(st);
+    const int rc = launch_pw(a, MODE, st);
+    prof_end(pi, st, 7001, 1.f, MODE);
+    return rc;
   }
   // 256x256 8-phase kernel (conv_igemm256.hip) for the large compute-bound shapes.  SOD_CONV256=0 disables it, =2 forces it for
   // every shape it supports (parity tests).
@@ -1480,6 +1491,12 @@ extern "C" int sod_conv_set_reverse(int on) {
 extern "C" int sod_conv_set_wgrad_variant(int variant) {
   if (variant < -1) return SOD_EARG;
   g_wgrad_variant = variant;
+  return SOD_OK;
+}
+
+extern "C" int sod_conv_set_pw(int on) {
+  if (on < -1 || on > 1) return SOD_EARG;
+  g_conv_pw = on;
   return SOD_OK;
 }
 

@@ -710,3 +710,56 @@ def test_relu_bit_masks_match_tensor_masks(cuda):
     b = HF.conv2d_dgrad(d(dy), d(wt), (H, W), accum=d(accum), relu_mask=y)
     assert torch.equal(a, b)
     assert (a != 0).any()
+
+
+@pytest.mark.parametrize("C,K", [(128, 512), (256, 1024), (512, 2048)])
+@pytest.mark.parametrize("shape", [(2, 100, 84), (1, 129, 131)])
+def test_persistent_pointwise_kernel_is_bit_identical_to_the_tiled_kernels(cuda, C, K, shape):
+    """conv_pw.hip (persistent, weight-stationary: the expanding 1x1 convolutions of the bottleneck blocks and their data gradients)
+    against the tiled kernels it replaces - same MFMA instruction, same K order, same epilogue arithmetic, so EQUAL bit for bit: forward
+    with bias + shortcut + ReLU + 1-bit mask, plain forward, the data gradient with accumulate + bit mask, and without the accumulate
+    operand; pixel counts that are no multiple of the 128 / 64 / 32-pixel tiles (ragged last tile, dead prefetches), reversed tile order."""
+    from slenderobjdet_amd import _C
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(cuda)
+    x = r(N, H, W, C).relu().bfloat16()
+    res = r(N, H, W, K).bfloat16()
+    w = r(K, 1, 1, C, sc=C ** -0.5)
+    wk, wt = HF.weight_prep(w)              # KRSC (K,1,1,C) for the forward conv C -> K
+    bias = r(K)
+    # the data gradient of a CONTRACTING conv K -> C (conv1 of a block) expands C -> K channels: transposed weights (K, 1, 1, C) as well
+    w1 = r(C, 1, 1, K, sc=K ** -0.5)
+    _, w1t = HF.weight_prep(w1)             # CRSK copy of (C,1,1,K): shape (K,1,1,C)
+    da = r(N, H, W, C).bfloat16()
+    gskip = r(N, H, W, K).bfloat16()
+
+    def run(on, reverse=False):
+        _C.call("sod_conv_set_pw", on)
+        _C.call("sod_conv_set_reverse", 1 if reverse else 0)
+        try:
+            bits = torch.zeros(N * H * W * K // 8, dtype=torch.uint8, device=cuda)
+            y = HF.conv2d_fwd(x, wk, bias, res, relu=True, relu_bits=bits)
+            v1 = int(_C.load().sod_conv_last_variant())
+            y2 = HF.conv2d_fwd(x, wk, None, None, relu=False)
+            v2 = int(_C.load().sod_conv_last_variant())
+            dx = HF.conv2d_dgrad(da, w1t, (H, W), accum=gskip, relu_bits=bits)
+            v3 = int(_C.load().sod_conv_last_variant())
+            dx2 = HF.conv2d_dgrad(da, w1t, (H, W), relu_bits=bits)
+            dx3 = HF.conv2d_dgrad(da, w1t, (H, W))
+            torch.cuda.synchronize()
+            return (y, bits, y2, dx, dx2, dx3), (v1, v2, v3)
+        finally:
+            _C.call("sod_conv_set_pw", -1)
+            _C.call("sod_conv_set_reverse", 0)
+
+    ref, vref = run(0)
+    assert 7001 not in vref
+    for rev in (False, True):
+        got, vgot = run(1, rev)
+        assert vgot == (7001, 7001, 7001), vgot            # the persistent kernel really ran
+        for name, a, b in zip(("fwd+res+relu", "bits", "fwd plain", "dgrad+accum+bits", "dgrad+bits", "dgrad plain"), got, ref):
+            assert torch.equal(a, b), (name, rev, C, K, shape, (a.float() - b.float()).abs().max().item())
+    assert 0.2 < (ref[0] > 0).float().mean().item() < 0.8 and (ref[3] != 0).any()
