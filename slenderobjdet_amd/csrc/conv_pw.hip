@@ -29,7 +29,18 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 template <int N>
 __device__ __forceinline__ void pw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// CK = C / 32 (4, 8, 16)
+// byte offset of a 16-byte piece (pixel row `row` of pixel tile t, `coff` bytes into the slice's 256-byte channel run) in the (P, Nout)
+// bf16 tensors, or the out-of-range offset for dead tiles / rows.  (A free function: a lambda called from inside the staging lambdas made
+// hipcc drop the kernel's HOST stub without a diagnostic.)
+__device__ __forceinline__ uint32_t pw_row_off(int t, int ntiles, uint32_t pt, uint32_t P, uint32_t Nout, uint32_t q0, uint32_t row, uint32_t coff) {
+  const uint32_t p = (uint32_t)t * pt + row;
+  return (t < ntiles && p < P) ? (p * Nout + q0) * 2u + coff : SOD_OOB;
+}
+
+}  // namespace
+
+// CK = C / 32 (4, 8, 16).  (External linkage on purpose: inside the anonymous namespace hipcc 7.2 dropped this kernel's HOST stub and
+// registration without a diagnostic - the object then referenced an undefined local symbol.)
 template <int MODE, int CK>
 __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const int tiles_per_wg_stride) {
   constexpr int C = CK * 32;
@@ -98,7 +109,8 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
     x_row[k] = row;
     x_coff[k] = ((phys ^ (row & 15u)) << 4);
   }
-  uint32_t r_row[LS], r_coff[LS];        // staging tile: pixel row, byte offset (in the 256-B channel run of the slice) of the logical chunk
+  uint32_t r_row[4], r_coff[4];          // (fixed size 4 >= LS: a dependent-size array captured by the staging lambdas made hipcc 7.2 drop the
+                                         // kernel's HOST stub without a diagnostic)  staging tile: pixel row, byte offset (in the 256-B channel run of the slice) of the logical chunk
 #pragma unroll
   for (int k = 0; k < LS; ++k) {
     const uint32_t o = (uint32_t)((k * 8 + wave) * 1024 + lane * 16);
@@ -122,16 +134,12 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(dst + (k * 8 + wave) * 1024), 16, voff, 0, 0, 0);
     }
   };
-  auto row_off = [&](int t, uint32_t row, uint32_t coff) -> uint32_t {      // byte offset of a 16-byte piece in the (P, Nout) bf16 tensors
-    const uint32_t p = (uint32_t)t * PT + row;
-    return (t < ntiles && p < (uint32_t)P) ? (p * (uint32_t)Nout + (uint32_t)q0) * 2u + coff : SOD_OOB;
-  };
   auto issue_res = [&](int it) {           // shortcut / accumulate tile and (dgrad) the mask bits of iteration it
     const int t = tile_of(it);
     char* dst = smem + P_R + (it & 1) * RT;
 #pragma unroll
     for (int k = 0; k < LS; ++k)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rrsrc, SOD_LDS(dst + (k * 8 + wave) * 1024), 16, row_off(t, r_row[k], r_coff[k]), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rrsrc, SOD_LDS(dst + (k * 8 + wave) * 1024), 16, pw_row_off(t, ntiles, PT, (uint32_t)P, (uint32_t)Nout, (uint32_t)q0, r_row[k], r_coff[k]), 0, 0, 0);
     if constexpr (MODE == MODE_DGRAD) {
       // bits of the tile: 16 bytes per pixel (128 channels), contiguous per pixel at (p * Nout + q0) / 8; one lane per pixel
       const int piece = wave * 64 + lane;                  // pixel index inside the tile for the waves that carry real rows
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
     for (int k = 0; k < LS; ++k) {
       const uint32_t o = (uint32_t)((k * 8 + wave) * 1024 + lane * 16);
       u32x4_t v = *reinterpret_cast<const u32x4_t*>(stg + o);
-      const uint32_t goff = row_off(t, r_row[k], r_coff[k]);
+      const uint32_t goff = pw_row_off(t, ntiles, PT, (uint32_t)P, (uint32_t)Nout, (uint32_t)q0, r_row[k], r_coff[k]);
       if constexpr (MODE == MODE_DGRAD) {
         uint32_t m = has_bits ? (uint32_t)(*reinterpret_cast<const uint8_t*>(bitb + r_row[k] * 16 + (r_coff[k] >> 4))) : 0xffu;
 #pragma unroll
@@ -251,6 +259,8 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
   }
   pw_wait_vm<0>();      // dead prefetches must have landed before the LDS allocation goes back
 }
+
+namespace {
 
 template <int MODE, int CK>
 int launch_pw_one(const ConvArgs& a, hipStream_t st) {
