@@ -39,23 +39,26 @@ __device__ __forceinline__ uint32_t pw_row_off(int t, int ntiles, uint32_t pt, u
 
 }  // namespace
 
-// CK = C / 32 (4, 8, 16).  (External linkage on purpose: inside the anonymous namespace hipcc 7.2 dropped this kernel's HOST stub and
-// registration without a diagnostic - the object then referenced an undefined local symbol.)
-template <int MODE, int CK>
+// CK = C / 32 (4, 8, 16); KS = 128-channel slices of the output per workgroup (its channel range QW = 128 * KS); PT = pixels per tile;
+// NX = slots of the X ring.  (External linkage on purpose, and fixed-size index arrays below: hipcc 7.2 silently dropped this kernel's
+// HOST stub and registration when it sat in the anonymous namespace with a dependent-size array captured by the staging lambdas.)
+template <int MODE, int CK, int KS, int PT, int NX>
 __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const int tiles_per_wg_stride) {
-  constexpr int C = CK * 32;
-  constexpr int PT = 16384 / C;                 // pixels per tile: 128 / 64 / 32
+  constexpr int C = CK * 32, QW = 128 * KS;
   constexpr int XROW = C * 2;                   // bytes per pixel row of the X tile
-  constexpr int XT = PT * XROW;                 // 32 KB
-  constexpr int NX = (C == 128) ? 2 : 3;        // X ring (C = 128: its 32-KB staging tiles leave room for two)
-  constexpr int RT = PT * 256;                  // shortcut / staging tile [PT][128] bf16
-  constexpr int LS = RT / 8192;                 // 16-byte pieces per thread of that tile: 4 / 2 / 1
-  constexpr int BT = PT * 16 < 1024 ? 1024 : PT * 16;   // mask bits of a tile: 16 bytes per pixel (at least one wave instruction's 1 KB)
+  constexpr int XT = PT * XROW;                 // X tile bytes (8 or 32 KB)
+  constexpr int LX = XT / 8192;                 // LDS-DMA loads per thread of an X tile
+  constexpr int RROW = QW * 2;                  // bytes per pixel row of the shortcut / staging tile
+  constexpr int RT = PT * RROW;
+  constexpr int LS = RT / 8192;                 // 16-byte pieces per thread of that tile
+  constexpr int BROW = QW / 8;                  // mask-bit bytes per pixel
+  constexpr int BT = PT * BROW < 1024 ? 1024 : PT * BROW;   // bit tile (at least one wave instruction's 1 KB)
   constexpr int P_R = NX * XT, P_B = P_R + 2 * RT, P_DUMMY = P_B + 2 * BT;
-  constexpr int FQ = 2, FP = PT / 32;           // MFMA tiles per wave: 32 channels x PT/2 pixels
+  constexpr int FQ = 2 * KS, FP = PT / 32;      // MFMA tiles per wave: QW/4 channels x PT/2 pixels
   constexpr int NST = 2 * LS;                   // vector-memory stores per thread and tile: LS x 16 B + LS bit bytes (dead ones included)
-  constexpr int WAITN = (NX == 3 ? 4 : 0) + NST;   // operations that may stay in flight at the top of a tile
-  static_assert(XT == 32768 && BT % 1024 == 0, "tile geometry");
+  constexpr int WAITN = (NX == 3 ? LX : 0) + NST;   // operations that may stay in flight at the top of a tile
+  static_assert(XT % 8192 == 0 && RT % 8192 == 0 && LX <= 4 && LS <= 4 && BT % 1024 == 0 && PT * BROW <= 8192, "tile geometry");
+  static_assert(NX == 2 || NX == 3, "X ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -63,8 +66,8 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
   const int wq = wave >> 1, wp = wave & 1;
   const int fr = lane & 15, fg = lane >> 4;
   const int Nout = a.Nout, P = a.lev[0].P;
-  const int nq = Nout >> 7;
-  // workgroup -> (XCD, slot, channel slice): the nq workgroups of one pixel-tile stream are neighbours on one XCD
+  const int nq = Nout / QW;
+  // workgroup -> (XCD, slot, channel range): the nq workgroups of one pixel-tile stream are neighbours on one XCD
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int qt = local % nq, slot = local / nq;
   const int S = (int)(gridDim.x >> 3) / nq;                 // streams per XCD
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
   const int stride_t = tiles_per_wg_stride;
   const int ntiles = (P + PT - 1) / PT;
   const bool rev = (a.flags & F_REVERSE) != 0;
-  const int q0 = qt * 128;
+  const int q0 = qt * QW;
   const LevelGeo& g = a.lev[0];
 
   auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.src), 0, g.src_bytes, 0x00020000);
@@ -84,10 +87,10 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
   void* bits_ptr = (MODE == MODE_FWD) ? g.bits : const_cast<void*>(g.mask);
   auto brsrc = __builtin_amdgcn_make_buffer_rsrc(has_bits ? bits_ptr : g.dst, 0, has_bits ? (obytes >> 4) : 0u, 0x00020000);
 
-  // ---- weights of this slice -> registers (A operands), once.  a.w is [Nout][C] row-major.
+  // ---- weights of this channel range -> registers (A operands), once.  a.w is [Nout][C] row-major.
   bf16x8_t af[FQ][CK];
   {
-    const __bf16* wbase = (const __bf16*)a.w + (size_t)(q0 + wq * 32 + fr) * C + fg * 8;
+    const __bf16* wbase = (const __bf16*)a.w + (size_t)(q0 + wq * (QW / 4) + fr) * C + fg * 8;
 #pragma unroll
     for (int i = 0; i < FQ; ++i)
 #pragma unroll
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
 #pragma unroll
   for (int i = 0; i < FQ; ++i) {
     bv[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (a.flags & F_BIAS) bv[i] = *reinterpret_cast<const f32x4_t*>(a.bias + q0 + wq * 32 + i * 16 + fg * 4);
+    if (a.flags & F_BIAS) bv[i] = *reinterpret_cast<const f32x4_t*>(a.bias + q0 + wq * (QW / 4) + i * 16 + fg * 4);
   }
 
   // ---- per-thread constants of the LDS-DMA / row-layout mapping: piece k of a thread covers LDS bytes (k * 8 + wave) * 1024 + lane * 16
@@ -109,12 +112,11 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
     x_row[k] = row;
     x_coff[k] = ((phys ^ (row & 15u)) << 4);
   }
-  uint32_t r_row[4], r_coff[4];          // (fixed size 4 >= LS: a dependent-size array captured by the staging lambdas made hipcc 7.2 drop the
-                                         // kernel's HOST stub without a diagnostic)  staging tile: pixel row, byte offset (in the 256-B channel run of the slice) of the logical chunk
+  uint32_t r_row[4], r_coff[4];          // staging tile: pixel row, byte offset (in the QW-channel run of the range) of the logical chunk
 #pragma unroll
-  for (int k = 0; k < LS; ++k) {
+  for (int k = 0; k < 4; ++k) {
     const uint32_t o = (uint32_t)((k * 8 + wave) * 1024 + lane * 16);
-    const uint32_t row = o >> 8, phys = (o >> 4) & 15u;
+    const uint32_t row = o / RROW, phys = (o % RROW) >> 4;
     r_row[k] = row;
     r_coff[k] = ((phys ^ (row & 15u)) << 4);
   }
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
     char* dst = smem + (it % NX) * XT;
     const uint32_t p0 = (uint32_t)t * PT;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < LX; ++k) {
       const uint32_t p = p0 + x_row[k];
       const uint32_t voff = (t < ntiles && p < (uint32_t)P) ? p * (uint32_t)XROW + x_coff[k] : SOD_OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(dst + (k * 8 + wave) * 1024), 16, voff, 0, 0, 0);
@@ -139,14 +141,15 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
     char* dst = smem + P_R + (it & 1) * RT;
 #pragma unroll
     for (int k = 0; k < LS; ++k)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rrsrc, SOD_LDS(dst + (k * 8 + wave) * 1024), 16, pw_row_off(t, ntiles, PT, (uint32_t)P, (uint32_t)Nout, (uint32_t)q0, r_row[k], r_coff[k]), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rrsrc, SOD_LDS(dst + (k * 8 + wave) * 1024), 16,
+                                               pw_row_off(t, ntiles, PT, (uint32_t)P, (uint32_t)Nout, (uint32_t)q0, r_row[k], r_coff[k]), 0, 0, 0);
     if constexpr (MODE == MODE_DGRAD) {
-      // bits of the tile: 16 bytes per pixel (128 channels), contiguous per pixel at (p * Nout + q0) / 8; one lane per pixel
-      const int piece = wave * 64 + lane;                  // pixel index inside the tile for the waves that carry real rows
-      const bool live = piece < PT;
-      const uint32_t p = (uint32_t)t * PT + (uint32_t)piece;
-      const uint32_t voff = (live && t < ntiles && p < (uint32_t)P) ? (p * (uint32_t)Nout + (uint32_t)q0) >> 3 : SOD_OOB;
-      char* bdst = (wave * 64 < PT) ? smem + P_B + (it & 1) * BT + wave * 1024 : smem + P_DUMMY;
+      // bits of the tile: BROW bytes per pixel, contiguous per pixel at (p * Nout + q0) / 8; 16-byte piece `piece` = (pixel, part)
+      const int piece = wave * 64 + lane;
+      const bool live = piece * 16 < PT * BROW;
+      const uint32_t p = (uint32_t)t * PT + (uint32_t)(piece / KS);
+      const uint32_t voff = (live && t < ntiles && p < (uint32_t)P) ? ((p * (uint32_t)Nout + (uint32_t)q0) >> 3) + (uint32_t)(piece % KS) * 16u : SOD_OOB;
+      char* bdst = (wave * 1024 < PT * BROW) ? smem + P_B + (it & 1) * BT + wave * 1024 : smem + P_DUMMY;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, SOD_LDS(bdst), 16, voff, 0, 0, 0);
     }
   };
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
   issue_res(0);
   issue_x(0);
   if constexpr (NX == 3) issue_x(1);
-  pw_wait_vm<(NX == 3 ? 4 : 0)>();
+  pw_wait_vm<(NX == 3 ? LX : 0)>();
 
   const uint32_t t_sw = (uint32_t)(fg ^ fr);            // X fragment swizzle: physical chunk = (kb * 4 + fg) ^ fr = (kb << 2) ^ t_sw
   for (int it = 0; stream0 + it * stride_t < ntiles; ++it) {
@@ -199,8 +202,8 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
       const int r = wp * (PT / 2) + j * 16 + fr;
 #pragma unroll
       for (int i = 0; i < FQ; ++i) {
-        const int chunk = wq * 4 + i * 2 + (fg >> 1);
-        char* p8 = stg + r * 256 + ((chunk ^ fr) << 4) + (fg & 1) * 8;
+        const int chunk = wq * (4 * KS) + i * 2 + (fg >> 1);
+        char* p8 = stg + r * RROW + ((chunk ^ fr) << 4) + (fg & 1) * 8;
         const u32x2_t rv = *reinterpret_cast<const u32x2_t*>(p8);
         float v[4];
 #pragma unroll
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // ---- epilogue 2, row layout: 16 bytes = 8 channels of one pixel per lane; a wave instruction stores four 256-byte runs
+    // ---- epilogue 2, row layout: 16 bytes = 8 channels of one pixel per lane; a wave instruction stores 1 KB of full channel runs
     const char* bitb = smem + P_B + (it & 1) * BT;
 #pragma unroll
     for (int k = 0; k < LS; ++k) {
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
       u32x4_t v = *reinterpret_cast<const u32x4_t*>(stg + o);
       const uint32_t goff = pw_row_off(t, ntiles, PT, (uint32_t)P, (uint32_t)Nout, (uint32_t)q0, r_row[k], r_coff[k]);
       if constexpr (MODE == MODE_DGRAD) {
-        uint32_t m = has_bits ? (uint32_t)(*reinterpret_cast<const uint8_t*>(bitb + r_row[k] * 16 + (r_coff[k] >> 4))) : 0xffu;
+        uint32_t m = has_bits ? (uint32_t)(*reinterpret_cast<const uint8_t*>(bitb + r_row[k] * BROW + (r_coff[k] >> 4))) : 0xffu;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const uint32_t lo = (m >> (2 * e)) & 1u, hi = (m >> (2 * e + 1)) & 1u;
@@ -262,18 +265,18 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
 
 namespace {
 
-template <int MODE, int CK>
+template <int MODE, int CK, int KS, int PT, int NX>
 int launch_pw_one(const ConvArgs& a, hipStream_t st) {
-  constexpr int C = CK * 32, PT = 16384 / C, NX = (C == 128) ? 2 : 3;
-  constexpr int lds = NX * 32768 + 2 * PT * 256 + 2 * (PT * 16 < 1024 ? 1024 : PT * 16) + 1024;
-  auto kern = conv_pw_kernel<MODE, CK>;
+  constexpr int C = CK * 32, QW = 128 * KS;
+  constexpr int lds = NX * PT * C * 2 + 2 * PT * QW * 2 + 2 * (PT * QW / 8 < 1024 ? 1024 : PT * QW / 8) + 1024;
+  auto kern = conv_pw_kernel<MODE, CK, KS, PT, NX>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  const int nq = a.Nout / 128;
+  const int nq = a.Nout / QW;
   const int grid = 256;                         // one workgroup per CU (pw_supported checks the device)
   const int stride = grid / nq;                 // pixel-tile streams
   SOD_LAUNCH(kern, dim3(grid), dim3(512), lds, st, a, stride);
@@ -281,17 +284,21 @@ int launch_pw_one(const ConvArgs& a, hipStream_t st) {
   return SOD_OK;
 }
 
+// channel range of a workgroup per contraction width: the weights of the range must fit the register file (C * QW * 2 B over 512 lanes)
+constexpr int pw_qw(int C) { return C == 128 ? 512 : (C == 256 ? 256 : 128); }
+
 }  // namespace
 
-// Shapes and epilogues the persistent kernel takes: 1x1, stride 1, no padding, one dense level, C in {128, 256, 512}, Nout in {4, 8, 16}
-// x 128 with Nout > C (the EXPANDING convolutions), bf16 output; forward: bias / shortcut / ReLU / bit mask; backward: accumulate /
-// bit mask.  256 CUs (the grid is the chip).
+// Shapes and epilogues the persistent kernel takes: 1x1, stride 1, no padding, one dense level, C in {128, 256, 512}, Nout > C (the
+// EXPANDING convolutions) a multiple of the workgroup's channel range (512 / 256 / 128 channels for C = 128 / 256 / 512) with 1 ... 32
+// ranges, bf16 output; forward: bias / shortcut / ReLU / bit mask; backward: accumulate / bit mask.  256 CUs (the grid is the chip).
 bool pw_supported(const ConvArgs& a, int mode, bool out_f32, int cus) {
   if (out_f32 || cus != 256 || a.nlev != 1 || a.cwin) return false;
   if (a.R != 1 || a.S != 1 || a.stride != 1 || a.pad != 0) return false;
   if (!(a.Cred == 128 || a.Cred == 256 || a.Cred == 512) || a.Cpitch != a.Cred) return false;
-  const int nq = a.Nout / 128;
-  if ((a.Nout & 127) || !(nq == 4 || nq == 8 || nq == 16) || a.Nout <= a.Cred) return false;
+  const int qw = pw_qw(a.Cred);
+  const int nq = a.Nout / qw;
+  if ((a.Nout % qw) || nq < 1 || nq > 32 || (32 % nq) || a.Nout <= a.Cred) return false;
   const LevelGeo& g = a.lev[0];
   if (g.pstart != 0 || g.Hs != g.Hp || g.Ws != g.Wp) return false;
   if (g.src_img_stride != g.Hs * g.Ws * a.Cred || g.dst_img_stride != g.Hp * g.Wp * a.Nout) return false;
@@ -305,13 +312,13 @@ bool pw_supported(const ConvArgs& a, int mode, bool out_f32, int cus) {
 
 int launch_pw(const ConvArgs& a, int mode, hipStream_t st) {
   if (mode == MODE_FWD) {
-    if (a.Cred == 128) return launch_pw_one<MODE_FWD, 4>(a, st);
-    if (a.Cred == 256) return launch_pw_one<MODE_FWD, 8>(a, st);
-    return launch_pw_one<MODE_FWD, 16>(a, st);
+    if (a.Cred == 128) return launch_pw_one<MODE_FWD, 4, 4, 32, 3>(a, st);
+    if (a.Cred == 256) return launch_pw_one<MODE_FWD, 8, 2, 64, 2>(a, st);
+    return launch_pw_one<MODE_FWD, 16, 1, 32, 3>(a, st);
   }
-  if (a.Cred == 128) return launch_pw_one<MODE_DGRAD, 4>(a, st);
-  if (a.Cred == 256) return launch_pw_one<MODE_DGRAD, 8>(a, st);
-  return launch_pw_one<MODE_DGRAD, 16>(a, st);
+  if (a.Cred == 128) return launch_pw_one<MODE_DGRAD, 4, 4, 32, 3>(a, st);
+  if (a.Cred == 256) return launch_pw_one<MODE_DGRAD, 8, 2, 64, 2>(a, st);
+  return launch_pw_one<MODE_DGRAD, 16, 1, 32, 3>(a, st);
 }
 
 }  // namespace sodconv
