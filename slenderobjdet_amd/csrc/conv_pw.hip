@@ -82,9 +82,13 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
   const uint32_t obytes = (uint32_t)P * (uint32_t)Nout * 2u;
   auto orsrc = __builtin_amdgcn_make_buffer_rsrc(g.dst, 0, obytes, 0x00020000);
   const bool has_res = (a.flags & F_RES) != 0;
-  auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(has_res ? g.res : g.dst), 0, has_res ? obytes : 0u, 0x00020000);
+  // backward with a bf16 ReLU MASK TENSOR of dx's shape (conv3's data gradient: dx = b > 0 ? dy W : 0) and no accumulate operand: the mask
+  // tile travels in the shortcut slot and is applied where the shortcut would be added
+  const bool has_mask = (MODE == MODE_DGRAD) && (a.flags & F_MASK) != 0;
+  const void* rsrc_ptr = has_res ? g.res : (has_mask ? g.mask : (const void*)g.dst);
+  auto rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(rsrc_ptr), 0, (has_res || has_mask) ? obytes : 0u, 0x00020000);
   const bool has_bits = (MODE == MODE_FWD) ? (a.flags & F_WBITS) != 0 : (a.flags & F_MASKBITS) != 0;
-  void* bits_ptr = (MODE == MODE_FWD) ? g.bits : const_cast<void*>(g.mask);
+  void* bits_ptr = (MODE == MODE_FWD) ? g.bits : (has_mask ? g.dst : const_cast<void*>(g.mask));
   auto brsrc = __builtin_amdgcn_make_buffer_rsrc(has_bits ? bits_ptr : g.dst, 0, has_bits ? (obytes >> 4) : 0u, 0x00020000);
 
   // ---- weights of this channel range -> registers (A operands), once.  a.w is [Nout][C] row-major.
@@ -220,6 +224,10 @@ __global__ __launch_bounds__(512, 1) void conv_pw_kernel(const ConvArgs a, const
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
+        if (has_mask) {
+          v[0] = (__uint_as_float(rv[0] << 16) > 0.f) ? v[0] : 0.f; v[1] = (__uint_as_float(rv[0] & 0xffff0000u) > 0.f) ? v[1] : 0.f;
+          v[2] = (__uint_as_float(rv[1] << 16) > 0.f) ? v[2] : 0.f; v[3] = (__uint_as_float(rv[1] & 0xffff0000u) > 0.f) ? v[3] : 0.f;
+        }
         bf16x4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
@@ -289,22 +297,25 @@ constexpr int pw_qw(int C) { return C == 128 ? 512 : (C == 256 ? 256 : 128); }
 
 }  // namespace
 
-// Shapes and epilogues the persistent kernel takes: 1x1, stride 1, no padding, one dense level, C in {128, 256, 512}, Nout > C (the
-// EXPANDING convolutions) a multiple of the workgroup's channel range (512 / 256 / 128 channels for C = 128 / 256 / 512) with 1 ... 32
-// ranges, bf16 output; forward: bias / shortcut / ReLU / bit mask; backward: accumulate / bit mask.  256 CUs (the grid is the chip).
+// Shapes and epilogues the persistent kernel takes: 1x1, stride 1, no padding, one dense level, C in {128, 256, 512}, Nout a multiple of
+// the workgroup's channel range (512 / 256 / 128 channels for C = 128 / 256 / 512: 128 KB of weights in registers) with 1 ... 32 ranges:
+// the EXPANDING convolutions of the bottleneck blocks, and the contracting 512 -> 128 ones of res3 (one range: the wide tensor is read
+// exactly once).  bf16 output; forward: bias / shortcut / ReLU / bit mask; backward: accumulate / bit mask, or a bf16 mask tensor without
+// an accumulate operand.  256 CUs (the grid is the chip).
 bool pw_supported(const ConvArgs& a, int mode, bool out_f32, int cus) {
   if (out_f32 || cus != 256 || a.nlev != 1 || a.cwin) return false;
   if (a.R != 1 || a.S != 1 || a.stride != 1 || a.pad != 0) return false;
   if (!(a.Cred == 128 || a.Cred == 256 || a.Cred == 512) || a.Cpitch != a.Cred) return false;
   const int qw = pw_qw(a.Cred);
   const int nq = a.Nout / qw;
-  if ((a.Nout % qw) || nq < 1 || nq > 32 || (32 % nq) || a.Nout <= a.Cred) return false;
+  if ((a.Nout % qw) || nq < 1 || nq > 32 || (32 % nq)) return false;
   const LevelGeo& g = a.lev[0];
   if (g.pstart != 0 || g.Hs != g.Hp || g.Ws != g.Wp) return false;
   if (g.src_img_stride != g.Hs * g.Ws * a.Cred || g.dst_img_stride != g.Hp * g.Wp * a.Nout) return false;
   if ((long long)g.P * a.Nout * 2 >= (1ll << 31)) return false;
-  const int allowed = (mode == MODE_FWD) ? (F_BIAS | F_RELU | F_RES | F_WBITS | F_REVERSE) : (F_RES | F_MASKBITS | F_REVERSE);
+  const int allowed = (mode == MODE_FWD) ? (F_BIAS | F_RELU | F_RES | F_WBITS | F_REVERSE) : (F_RES | F_MASKBITS | F_MASK | F_REVERSE);
   if (a.flags & ~allowed) return false;
+  if ((a.flags & F_MASK) && (a.flags & (F_RES | F_MASKBITS))) return false;      // the mask tensor travels in the shortcut slot
   if ((a.flags & F_RES) && g.res_img_stride != g.dst_img_stride) return false;
   if (g.P < 16384) return false;                // a launch this small does not fill the persistent grid: the tiled kernel is as good
   return true;

@@ -150,10 +150,12 @@ __device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx
   float gm[8], bt[8], dg[8], db[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { gm[e] = a.gamma[c8 * 8 + e]; bt[e] = a.beta[c8 * 8 + e]; dg[e] = 0.f; db[e] = 0.f; }
-  float s1 = 0.f, s2 = 0.f;
   const int p0 = bx * a.pix_per_block;
   int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
   const long long base = (long long)n * a.img_stride + c8 * 8;
+  // Per element only what depends on it: the mask, xhat, dgamma += d * xhat, dbeta += d.  The group sums are linear in those per-channel
+  // sums - s1 = sum_e gamma[e] * dbeta[e], s2 = sum_e gamma[e] * dgamma[e] (a thread's 8 channels are one group, its pixels one image) -
+  // and are formed once per thread after the loop (round 5: 15 -> 9 VALU operations per element of a pass that was not far from VALU-bound).
   for (int p = p0 + prow; p < p1; p += rows_per_iter) {
     const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)p * a.C);
     const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)p * a.C);
@@ -163,9 +165,11 @@ __device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx
       float d = (float)gv[e];
       if (a.relu && !(xh * gm[e] + bt[e] > 0.f)) d = 0.f;
       dg[e] += d * xh; db[e] += d;
-      s1 += d * gm[e]; s2 += d * gm[e] * xh;
     }
   }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1 += db[e] * gm[e]; s2 += dg[e] * gm[e]; }
   // block-level reduction through plain LDS stores (see gn_stats_body), then one global atomic per channel per block
   float* mine = lsum + threadIdx.x * 18;
 #pragma unroll

@@ -712,13 +712,14 @@ def test_relu_bit_masks_match_tensor_masks(cuda):
     assert (a != 0).any()
 
 
-@pytest.mark.parametrize("C,K", [(128, 512), (256, 1024), (512, 2048)])
+@pytest.mark.parametrize("C,K", [(128, 512), (256, 1024), (512, 2048), (512, 128), (256, 256)])
 @pytest.mark.parametrize("shape", [(2, 100, 84), (1, 129, 131)])
 def test_persistent_pointwise_kernel_is_bit_identical_to_the_tiled_kernels(cuda, C, K, shape):
     """conv_pw.hip (persistent, weight-stationary: the expanding 1x1 convolutions of the bottleneck blocks and their data gradients)
     against the tiled kernels it replaces - same MFMA instruction, same K order, same epilogue arithmetic, so EQUAL bit for bit: forward
-    with bias + shortcut + ReLU + 1-bit mask, plain forward, the data gradient with accumulate + bit mask, and without the accumulate
-    operand; pixel counts that are no multiple of the 128 / 64 / 32-pixel tiles (ragged last tile, dead prefetches), reversed tile order."""
+    with bias + shortcut + ReLU + 1-bit mask, plain forward, the data gradient with accumulate + bit mask, without the accumulate
+    operand, and under a bf16 mask TENSOR (conv3's data gradient); expanding shapes and the contracting 512 -> 128 of res3; pixel counts
+    that are no multiple of the 32 / 64-pixel tiles (ragged last tile, dead prefetches), reversed tile order."""
     from slenderobjdet_amd import _C
     from slenderobjdet_amd.layers import functional as HF
 
@@ -749,8 +750,10 @@ def test_persistent_pointwise_kernel_is_bit_identical_to_the_tiled_kernels(cuda,
             v3 = int(_C.load().sod_conv_last_variant())
             dx2 = HF.conv2d_dgrad(da, w1t, (H, W), relu_bits=bits)
             dx3 = HF.conv2d_dgrad(da, w1t, (H, W))
+            dx4 = HF.conv2d_dgrad(da, w1t, (H, W), relu_mask=y)
+            v4 = int(_C.load().sod_conv_last_variant())
             torch.cuda.synchronize()
-            return (y, bits, y2, dx, dx2, dx3), (v1, v2, v3)
+            return (y, bits, y2, dx, dx2, dx3, dx4), (v1, v2, v3, v4)
         finally:
             _C.call("sod_conv_set_pw", -1)
             _C.call("sod_conv_set_reverse", 0)
@@ -759,7 +762,7 @@ def test_persistent_pointwise_kernel_is_bit_identical_to_the_tiled_kernels(cuda,
     assert 7001 not in vref
     for rev in (False, True):
         got, vgot = run(1, rev)
-        assert vgot == (7001, 7001, 7001), vgot            # the persistent kernel really ran
-        for name, a, b in zip(("fwd+res+relu", "bits", "fwd plain", "dgrad+accum+bits", "dgrad+bits", "dgrad plain"), got, ref):
+        assert vgot == (7001, 7001, 7001, 7001), vgot            # the persistent kernel really ran
+        for name, a, b in zip(("fwd+res+relu", "bits", "fwd plain", "dgrad+accum+bits", "dgrad+bits", "dgrad plain", "dgrad+mask tensor"), got, ref):
             assert torch.equal(a, b), (name, rev, C, K, shape, (a.float() - b.float()).abs().max().item())
     assert 0.2 < (ref[0] > 0).float().mean().item() < 0.8 and (ref[3] != 0).any()
