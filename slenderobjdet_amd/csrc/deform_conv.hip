@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, con
   constexpr int NPIECE = KS / 2;          // 16-B pieces of the weight chunk per thread (32 rows x K bf16 / 256 threads)
   extern __shared__ int win[];            // [WH][WW][PS] fixed-point window, then the weight chunk, then the dcols tile
   __shared__ float smax[8];
+  __shared__ unsigned char slow_lane[4][64];   // per wave: the lanes whose sample fell outside the window, compacted (see the scatter)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int c0 = blockIdx.y * CC, n = blockIdx.z;
@@ -487,6 +488,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, con
     // ---- scatter (dcn_col2im_tile_kernel's body, with the column gradients read from the LDS tile)
     const int k = g * taps + tap;
     float g_dy = 0.f, g_dx = 0.f, g_m = 0.f;
+    // a lane whose sample fell outside the window parks what the scatter needs here and the WAVE adds it after the branch (below)
+    bool slow = false;
+    int s_y = 0, s_x = 0, s_ok = 0;
+    float s_m = 0.f, s_w00 = 0.f, s_w01 = 0.f, s_w10 = 0.f, s_w11 = 0.f;
     if (live) {
       const float dyo = a.off[pix * a.off_ld + 2 * k], dxo = a.off[pix * a.off_ld + 2 * k + 1];
       const int ki = tap / a.KW, kj = tap - ki * a.KW;
@@ -517,7 +522,6 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, con
         const bool inwin = inwin0 && finite_scale;
         if (!inwin0 && a.oow) atomicAdd(a.oow, 1ull);        // (the slow path: 32 global float atomics follow)
         int* w00p = win + ((wy * WW + wx) * PS) + cl * 8;
-        float* g00p = a.dx + ((base + (long long)s.yl * a.W + s.xl) * a.C) + cch;
         // the corner tests are per LANE, not per channel: one branch region per corner around its eight atomics (with the tests inside
         // the channel loop hipcc emitted 64 exec-mask save / branch pairs per tap - as many cycles as the arithmetic they guard)
         float dmv[8];
@@ -548,22 +552,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, con
             for (int e = 0; e < 8; ++e) atomicAdd(w00p + WW * PS + PS + e, __float2int_rn(dmv[e] * S * s.w11));
           }
         } else {
-          if (s.ok00) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(g00p + e, dmv[e] * s.w00);
-          }
-          if (s.ok01) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(g00p + a.C + e, dmv[e] * s.w01);
-          }
-          if (s.ok10) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(g00p + (long long)a.W * a.C + e, dmv[e] * s.w10);
-          }
-          if (s.ok11) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(g00p + (long long)a.W * a.C + a.C + e, dmv[e] * s.w11);
-          }
+          slow = true;
+          s_y = s.yl; s_x = s.xl; s_ok = (int)s.ok00 | ((int)s.ok01 << 1) | ((int)s.ok10 << 2) | ((int)s.ok11 << 3);
+          s_m = m; s_w00 = s.w00; s_w01 = s.w01; s_w10 = s.w10; s_w11 = s.w11;
         }
         if (a.mask && a.mask_logit) g_m *= m * (1.f - m);
       }
@@ -576,6 +567,32 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, con
       atomicAdd(a.doff + pix * a.off_ld + 2 * k, g_dy);
       atomicAdd(a.doff + pix * a.off_ld + 2 * k + 1, g_dx);
       if (a.dmask) atomicAdd(a.dmask + pix * a.mask_ld + k, g_m);
+    }
+    // ---- samples outside the window: global float atomics, issued by the WAVE instead of by the lane that owns the sample.  A lane
+    // adding its own 4 corners x 8 channels issues 32 atomic instructions whose 64 lanes touch 64 different 32-B sectors each (16 pixels x
+    // 4 channel groups); here eight parked lanes are served at a time, lane l of the wave adding channel l % 8 of parked lane l / 8: one
+    // instruction per corner whose addresses form eight 32-B runs (two 128-B lines when the four lanes of a pixel are all parked) -
+    // 1/8 of the instructions and 1/8 .. 1/32 of the memory transactions.  The products are formed exactly as the lane would have.
+    const unsigned long long smask = __ballot(slow);
+    if (smask) {                                    // wave-uniform
+      if (slow) slow_lane[wave][__popcll(smask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+      const int nslow = __popcll(smask);
+      for (int j0 = 0; j0 < nslow; j0 += 8) {
+        const int j = j0 + (lane >> 3);
+        const int src = slow_lane[wave][j < nslow ? j : 0];
+        const int yl = __shfl(s_y, src, 64), xl = __shfl(s_x, src, 64), okb = __shfl(s_ok, src, 64);
+        const float mm = __shfl(s_m, src, 64);
+        const float q00 = __shfl(s_w00, src, 64), q01 = __shfl(s_w01, src, 64), q10 = __shfl(s_w10, src, 64), q11 = __shfl(s_w11, src, 64);
+        if (j < nslow) {
+          const int ch = (src & 3) * 8 + (lane & 7);
+          const float dm = (float)dcl[(wave * 16 + (src >> 2)) * CC + ch] * mm;
+          float* gp = a.dx + ((base + (long long)yl * a.W + xl) * a.C) + c0 + ch;
+          if (okb & 1) atomicAdd(gp, dm * q00);
+          if (okb & 2) atomicAdd(gp + a.C, dm * q01);
+          if (okb & 4) atomicAdd(gp + (long long)a.W * a.C, dm * q10);
+          if (okb & 8) atomicAdd(gp + (long long)a.W * a.C + a.C, dm * q11);
+        }
+      }
     }
     if (tap + 1 < taps) w_store();                 // (this wave's own reads of the old rows finished before the barrier above)
     __syncthreads();                               // next tap's weight rows visible; the dcols tile may be overwritten
