@@ -443,6 +443,9 @@ def main():
                     "WIDTH_PER_GROUP 8, STRIDE_IN_1X1 False) instead of ResNet: the grouped-convolution path; not the headline")
     ap.add_argument("--base-lr", type=float, default=None, help="override SOLVER.BASE_LR (experiments: e.g. RepPoints at the reference's 0.01, where "
                     "random initialisation diverges and the learned offsets grow)")
+    ap.add_argument("--reppoints-offset-px", type=float, default=0.0, help="experiment (reppoints): the biases of the initial point "
+                    "prediction drawn from N(0, S px), i.e. DeformConv offsets S pixels (of the level) away from the kernel grid as a trained "
+                    "detector's are - how far the step time depends on the offsets leaving the backward kernel's LDS window")
     ap.add_argument("--constant-lr", action="store_true", help="constant SOLVER.BASE_LR from step 0 instead of the reference's WarmupMultiStepLR")
     ap.add_argument("--bucket-mb", type=float, default=None, help="N > 1: size of the gradient all-reduce buckets (default 32 MB)")
     ap.add_argument("--wire", choices=["fp32", "bf16"], default=None, help="N > 1: wire format of the gradient buckets (default fp32, SOD_GRAD_BUCKET_DTYPE)")
@@ -504,6 +507,12 @@ def main():
     model.train()
     if args.arch in ("retinanet", "rrcnn") and args.depth >= 50:
         damp_residual_branches(model)
+    if args.reppoints_offset_px > 0:
+        assert args.arch == "reppoints", "--reppoints-offset-px needs --arch reppoints"
+        with torch.no_grad():
+            b = model.offsets_init[1].conv.bias
+            b[: 2 * model.num_points].copy_(torch.randn(2 * model.num_points, generator=torch.Generator().manual_seed(5)) * args.reppoints_offset_px)
+        model.arena.bump()
     if args.bucket_mb is not None or args.wire is not None:
         model.arena.configure_buckets(args.bucket_mb if args.bucket_mb is not None else 32.0, args.wire)
     if world > 1 or rehearsal:   # DDP semantics: identical initial parameters on every rank
@@ -624,6 +633,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.arch] + (" [ResNeXt 32x8d backbone]" if args.resnext else ""), "global_batch": args.batch_per_gpu * world, "parallelism": f"dp{world}",
                        "final_loss": round(loss_val, 5), "final_grad_norm": round(gnorm, 5), "base_lr": cfg.SOLVER.BASE_LR,
+                       **({"reppoints_offset_px": args.reppoints_offset_px} if args.reppoints_offset_px > 0 else {}),
                        "lr_schedule": ("constant" if scheduler is None else
                                        f"{cfg.SOLVER.LR_SCHEDULER_NAME}: {cfg.SOLVER.WARMUP_METHOD} warm-up from {cfg.SOLVER.WARMUP_FACTOR} x base over "
                                        f"{cfg.SOLVER.WARMUP_ITERS} iterations, stepped every iteration (lr at the last step {optimizer.param_groups[0]['lr']:.3e})"),

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void dcn_wnorm_kernel(const __bf16* __restrict
 }
 
 template <int KS>      // K = 32 * KS output channels of the convolution = contraction length of the dcols GEMM
-__global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, const __bf16* __restrict__ dy, const __bf16* __restrict__ wt,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 3 : 1))) void dcn_bwd_fused_kernel(const DcnArgs a, const __bf16* __restrict__ dy, const __bf16* __restrict__ wt,
                                                             const float* __restrict__ wnorm, int tiles_x, int WH, int WW, int R) {
   constexpr int CC = 32, PS = CC + 1, L = CC / 8, K = 32 * KS;
   constexpr int WROW = K * 2 + 16;        // bytes per staged weight row (16 B pad: the 16 rows of a fragment read start on different banks)
@@ -489,9 +489,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, con
     const int k = g * taps + tap;
     float g_dy = 0.f, g_dx = 0.f, g_m = 0.f;
     // a lane whose sample fell outside the window parks what the scatter needs here and the WAVE adds it after the branch (below)
-    bool slow = false;
-    int s_y = 0, s_x = 0, s_ok = 0;
-    float s_m = 0.f, s_w00 = 0.f, s_w01 = 0.f, s_w10 = 0.f, s_w11 = 0.f;
+    // (four registers: the kernel sits at 168 VGPRs = three workgroups per CU, and 176 measured 21 % slower on in-window offsets)
+    bool slow = false, outw = false;
+    unsigned s_pk = 0;                 // (xl + 1) << 18 | (yl + 1) << 4 | corner bits; H, W < 16383 is checked by the launcher
+    float s_m = 0.f, s_ly = 0.f, s_lx = 0.f;
     if (live) {
       const float dyo = a.off[pix * a.off_ld + 2 * k], dxo = a.off[pix * a.off_ld + 2 * k + 1];
       const int ki = tap / a.KW, kj = tap - ki * a.KW;
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, con
         const int wy = s.yl - wy0, wx = s.xl - wx0;
         const bool inwin0 = wy >= 0 && wx >= 0 && wy + 1 < WH && wx + 1 < WW;
         const bool inwin = inwin0 && finite_scale;
-        if (!inwin0 && a.oow) atomicAdd(a.oow, 1ull);        // (the slow path: 32 global float atomics follow)
+        outw = !inwin0;
         int* w00p = win + ((wy * WW + wx) * PS) + cl * 8;
         // the corner tests are per LANE, not per channel: one branch region per corner around its eight atomics (with the tests inside
         // the channel loop hipcc emitted 64 exec-mask save / branch pairs per tap - as many cycles as the arithmetic they guard)
@@ -553,8 +554,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, con
           }
         } else {
           slow = true;
-          s_y = s.yl; s_x = s.xl; s_ok = (int)s.ok00 | ((int)s.ok01 << 1) | ((int)s.ok10 << 2) | ((int)s.ok11 << 3);
-          s_m = m; s_w00 = s.w00; s_w01 = s.w01; s_w10 = s.w10; s_w11 = s.w11;
+          s_pk = ((unsigned)(s.xl + 1) << 18) | ((unsigned)(s.yl + 1) << 4) | (unsigned)s.ok00 | ((unsigned)s.ok01 << 1) | ((unsigned)s.ok10 << 2) |
+                 ((unsigned)s.ok11 << 3);
+          s_m = m; s_ly = s.ly; s_lx = s.lx;
         }
         if (a.mask && a.mask_logit) g_m *= m * (1.f - m);
       }
@@ -573,6 +575,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, con
     // 4 channel groups); here eight parked lanes are served at a time, lane l of the wave adding channel l % 8 of parked lane l / 8: one
     // instruction per corner whose addresses form eight 32-B runs (two 128-B lines when the four lanes of a pixel are all parked) -
     // 1/8 of the instructions and 1/8 .. 1/32 of the memory transactions.  The products are formed exactly as the lane would have.
+    if (a.oow) {                                    // one count per wave, not one same-address atomic per lane
+      const unsigned long long om = __ballot(outw);
+      if (om && lane == 0) atomicAdd(a.oow, (unsigned long long)__popcll(om));
+    }
     const unsigned long long smask = __ballot(slow);
     if (smask) {                                    // wave-uniform
       if (slow) slow_lane[wave][__popcll(smask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
@@ -580,9 +586,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_fused_kernel(const DcnArgs a, con
       for (int j0 = 0; j0 < nslow; j0 += 8) {
         const int j = j0 + (lane >> 3);
         const int src = slow_lane[wave][j < nslow ? j : 0];
-        const int yl = __shfl(s_y, src, 64), xl = __shfl(s_x, src, 64), okb = __shfl(s_ok, src, 64);
-        const float mm = __shfl(s_m, src, 64);
-        const float q00 = __shfl(s_w00, src, 64), q01 = __shfl(s_w01, src, 64), q10 = __shfl(s_w10, src, 64), q11 = __shfl(s_w11, src, 64);
+        const unsigned pk = (unsigned)__shfl((int)s_pk, src, 64);
+        const int yl = (int)((pk >> 4) & 0x3fffu) - 1, xl = (int)(pk >> 18) - 1, okb = (int)(pk & 15u);
+        const float mm = __shfl(s_m, src, 64), ly = __shfl(s_ly, src, 64), lx = __shfl(s_lx, src, 64);
+        const float hy = 1.f - ly, hx = 1.f - lx;                                       // the weights as make_samp() forms them
+        const float q00 = hy * hx, q01 = hy * lx, q10 = ly * hx, q11 = ly * lx;
         if (j < nslow) {
           const int ch = (src & 3) * 8 + (lane & 7);
           const float dm = (float)dcl[(wave * 16 + (src >> 2)) * CC + ch] * mm;
@@ -763,7 +771,7 @@ extern "C" int sod_deform_conv_bwd_fused(const void* dy, const void* wt, const v
   int rc = dcn_fill(a, N, H, W, C, KH, KW, stride, pad, dil, deformable_groups, off_ld, mask_ld, mask_is_logit);
   if (rc) return rc;
   const int cpg = C / deformable_groups;
-  if ((K != 128 && K != 256 && K != 512) || (C & 31) || (cpg & 31) || N > 65535 || C / 32 > 65535) return SOD_EARG;
+  if ((K != 128 && K != 256 && K != 512) || (C & 31) || (cpg & 31) || N > 65535 || C / 32 > 65535 || H > 16382 || W > 16382) return SOD_EARG;
   const int r_env = dcn_fused_slack();
   const int WH = 7 * stride + (KH - 1) * dil + 2 + 2 * r_env, WW = 7 * stride + (KW - 1) * dil + 2 + 2 * r_env;
   const size_t lds = dcn_bwd_fused_lds(K, KH, KW, stride, dil);

@@ -25,22 +25,23 @@ FUSED = os.environ.get("SOD_DCN_FUSED", "1") != "0"
 BWD_FUSED = os.environ.get("SOD_DCN_BWD_FUSED", "1") != "0"
 
 
-# The fused backward keeps dX in an LDS window around each 8x8 output tile; samples outside it take global float atomics, and the time of
-# the P3 level of RepPoints goes 2.5 -> 5.4 -> 18 -> 39 ms as the offsets' spread goes 0.5 -> 2 -> 4 -> 8 px (tools/bench_dcn_bwd_window.py:
-# 0 / 4 / 24 / 57 % of the samples outside a window with 2 px of slack).  Trained RepPoints offsets reach a few pixels per level
-# (rpd.py:637-647: the points of an object of 4-8 strides), so the slack is ADAPTIVE per layer and level: the library counts the samples
-# that left the window (sod_deform_conv_set_window_counter), the count of the previous launch is read back asynchronously, and the slack
-# goes 2 -> 4 -> 6 px while more than 1.5 % (6 % at 4 px) of the samples are outside - a wider window admits fewer workgroups per CU
-# (2.5 / 3.1 / 5.5 ms with nothing outside), so it is only paid where the offsets ask for it: 5.3 -> 3.4 ms at 2 px of spread, 18 -> 6.7 ms
-# at 4 px, 39 -> 22 ms at 8 px; a step that takes back less than 15 % of the outside samples is undone (a diverging run's offsets are beyond
-# any window); every PROBE_EVERY launches a narrower window is tried again.  SOD_DCN_ADAPTIVE_WINDOW=0 switches it off.
+# The fused backward keeps dX in an LDS window around each 8x8 output tile; samples outside it are added to HBM with float atomics, eight
+# parked lanes per wave instruction (csrc/deform_conv.hip).  The P3 level of RepPoints takes 2.5 / 3.2 / 4.5 / 7.0 ms at offset spreads of
+# 0.5 / 2 / 4 / 8 px with 2 px of slack (tools/bench_dcn_bwd_window.py, profiles/r5_dcn_bwd_window.txt: 0 / 4 / 24 / 57 % of the samples
+# outside; 2.5 / 5.3 / 18 / 39 ms while every lane added its own 32 scattered atomics, rounds 3-4).  Trained RepPoints offsets reach a few
+# pixels per level (rpd.py:637-647: the points of an object of 4-8 strides), so the slack is ADAPTIVE per layer and level: the library
+# counts the samples that left the window (sod_deform_conv_set_window_counter), the count of the previous launch is read back
+# asynchronously, and the slack goes 2 -> 4 px while more than 10 % of the samples are outside - a wider window admits fewer workgroups
+# per CU (2.5 / 3.1 ms with nothing outside), so it is only paid where the offsets ask for it (4.5 -> 3.9 ms at 4 px, 7.0 -> 6.2 ms at
+# 8 px); a step that takes back less than 15 % of the outside samples is undone (a diverging run's offsets are beyond any window); every
+# PROBE_EVERY launches the narrower window is tried again.  SOD_DCN_ADAPTIVE_WINDOW=0 switches it off.
 ADAPTIVE_WINDOW = os.environ.get("SOD_DCN_ADAPTIVE_WINDOW", "1") != "0"
 PROBE_EVERY = 200
 
 
 class _WindowPolicy:
     """Slack of the fused backward's LDS window for ONE (layer, level)."""
-    MAX_SLACK = 6
+    MAX_SLACK = 4
 
     def __init__(self, device):
         self.slack = 2
@@ -69,9 +70,10 @@ class _WindowPolicy:
                 self.slack -= 2                      # workgroups per CU - back, and no further attempt for a while
                 self.hold = PROBE_EVERY
                 return
-        # break-even shares from tools/bench_dcn_bwd_window.py (P3 level of RepPoints, ms at slack 2 / 4 / 6: 2.5 / 3.1 / 5.5 with nothing
-        # outside, + ~0.65 ms per per cent of the samples outside; a step of the slack takes 3-8x of them back in)
-        if share > (0.015 if self.slack <= 2 else 0.06) and self.slack < self.MAX_SLACK and self.hold == 0:
+        # break-even share from tools/bench_dcn_bwd_window.py (P3 level of RepPoints, profiles/r5_dcn_bwd_window.txt: ms at slack 2 / 4 / 6 =
+        # 2.5 / 3.1 / 5.5 with nothing outside, + ~0.085 ms per per cent of the samples outside since the wave adds them (0.65 before); a
+        # step of the slack takes 3-8x of them back in: slack 4 pays from ~10 % outside, slack 6 never does any more)
+        if share > 0.10 and self.slack < self.MAX_SLACK and self.hold == 0:
             self.widened_from = share
             self.slack += 2
             self.probing = False

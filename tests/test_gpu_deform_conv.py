@@ -188,7 +188,7 @@ def test_deform_backward_window_counter(cuda):
 
 def test_deform_backward_window_widens_with_the_offsets(cuda):
     """layers/deform_conv.py::_WindowPolicy: the slack of the fused backward's LDS window follows the share of samples the library
-    counted outside it - 2 px while the offsets are small, 4 / 6 px once more than 2 % of the samples leave (learned RepPoints offsets
+    counted outside it - 2 px while the offsets are small, 4 px once more than 10 % of the samples leave (learned RepPoints offsets
     reach several pixels, rpd.py:637-647) - and the gradients do not depend on it."""
     from slenderobjdet_amd.layers import deform_conv as dcm
     from slenderobjdet_amd.layers import functional as HF
@@ -212,7 +212,7 @@ def test_deform_backward_window_widens_with_the_offsets(cuda):
         return xd.grad.float(), od.grad
 
     small = ((torch.rand(N, H, W, 18, generator=_g(3)) - 0.5) * 2.0).to(cuda)
-    large = ((torch.rand(N, H, W, 18, generator=_g(4)) - 0.5) * 12.0).to(cuda)
+    large = ((torch.rand(N, H, W, 18, generator=_g(4)) - 0.5) * 8.0).to(cuda)
     for _ in range(3):
         step(small)
     pol = m._window_policies[(N, H, W)]
