@@ -3,7 +3,7 @@
 #   tools/profile_step.sh <tag>     (run from the repo root through gpurun; raw outputs go to gpurun_out/<tag>_*)
 # Passes: kernel stats of the default two-stream run, kernel stats of a single-stream run (true per-kernel durations), and the two PMC
 # passes (FETCH_SIZE / WRITE_SIZE, each alone with --kernel-trace as the pool requires).
-set -u
+set -eu -o pipefail     # a step that fails or times out ends the call: no further GPU step after it
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline"
