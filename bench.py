@@ -150,7 +150,7 @@ def train_step(model, optimizer, data, next_data=None, scheduler=None):
 def variant_kernel_name(code, mode=0):
     """sod_conv_last_variant() code -> the kernel name rocprofv3 prints (slender_hip.h)."""
     if code == 256:
-        return f"void sodconv::conv_igemm256_kernel<{mode}, false, false>"
+        return f"void sodconv::conv_igemm256_kernel<{mode}, false>"
     bq, bp, bk = code // 100000, (code // 100) % 1000, code % 100
     generic, bk = bk & 1, bk & ~1
     wq, wp, fq, fp = {(16, 256): (1, 4, 1, 4), (64, 256): (1, 4, 4, 4), (128, 128): (2, 2, 4, 4), (128, 256): (2, 4, 4, 4)}.get((bq, bp), (0, 0, 0, 0))
@@ -173,8 +173,8 @@ def kernel_name(kind, code):
             return "sodconv::conv_wgrad256_kernel"
         if code == 32004:            # conv_wgrad_fold.hip: taps folded into the tile rows (few output channels)
             return "sodconv::conv_wgrad_fold_kernel"
-        if 1000 <= code < 3000:      # conv_wgrad_ring.hip: G*1000 + NSTAGE*100 + EPI*10 + FDB
-            return f"conv_wgrad_ring_kernel<{code // 1000}, {(code // 100) % 10}, {(code // 10) % 10}, {'true' if code % 10 else 'false'}, 0>"
+        if 1000 <= code < 3000:      # conv_wgrad_ring.hip: G*1000 + NSTAGE*100 + EPI*10 -> conv_wgrad_ring_kernel<G, NSTAGE, EPI, ABL = 0>
+            return f"conv_wgrad_ring_kernel<{code // 1000}, {(code // 100) % 10}, {(code // 10) % 10}, 0>"
         return f"void conv_wgrad_kernel<{code // 1000}, {code % 1000}>"
     return variant_kernel_name(code, KIND_MODE[kind])
 
