@@ -448,6 +448,8 @@ def main():
                     "detector's are - how far the step time depends on the offsets leaving the backward kernel's LDS window")
     ap.add_argument("--constant-lr", action="store_true", help="constant SOLVER.BASE_LR from step 0 instead of the reference's WarmupMultiStepLR")
     ap.add_argument("--bucket-mb", type=float, default=None, help="N > 1: size of the gradient all-reduce buckets (default 32 MB)")
+    ap.add_argument("--bucket-tail-mb", type=float, default=None, help="N > 1: at most this many MB in the LAST bucket (its reduction is exposed; "
+                    "default 6, 0 = off)")
     ap.add_argument("--wire", choices=["fp32", "bf16"], default=None, help="N > 1: wire format of the gradient buckets (default fp32, SOD_GRAD_BUCKET_DTYPE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -455,6 +457,10 @@ def main():
     ap.add_argument("--rccl-rehearsal", action="store_true",
                     help="--gpus 1 only: create a one-rank RCCL process group and issue every data-parallel collective anyway (parameter "
                          "broadcast, normaliser all-reduce, bucketed gradient all-reduce) - exercises the real RCCL path on a one-GPU box")
+    ap.add_argument("--rehearsal-occupancy", default=None, metavar="WGS:GBPS",
+                    help="with --rccl-rehearsal: every bucket's all-reduce is followed on the communication stream by WGS resident workgroups for "
+                         "the time an 8-rank ring takes at GBPS of bus bandwidth (sod_debug_occupy) - what the step loses while RCCL's channel "
+                         "kernels hold CUs; e.g. 32:300")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -513,8 +519,12 @@ def main():
             b = model.offsets_init[1].conv.bias
             b[: 2 * model.num_points].copy_(torch.randn(2 * model.num_points, generator=torch.Generator().manual_seed(5)) * args.reppoints_offset_px)
         model.arena.bump()
-    if args.bucket_mb is not None or args.wire is not None:
-        model.arena.configure_buckets(args.bucket_mb if args.bucket_mb is not None else 32.0, args.wire)
+    if args.bucket_mb is not None or args.wire is not None or args.bucket_tail_mb is not None:
+        model.arena.configure_buckets(args.bucket_mb if args.bucket_mb is not None else 32.0, args.wire, args.bucket_tail_mb)
+    if args.rehearsal_occupancy:
+        assert rehearsal, "--rehearsal-occupancy needs --rccl-rehearsal on one GPU"
+        wgs, gbps = args.rehearsal_occupancy.split(":")
+        model.arena.rehearsal_occupancy = (int(wgs), float(gbps), 8)
     if world > 1 or rehearsal:   # DDP semantics: identical initial parameters on every rank
         dist.broadcast(model.arena.params, src=0)
         model.arena.bump()
@@ -653,7 +663,7 @@ def main():
             exposed = [a.elapsed_time(b) for a, b in pairs]
             out["config"].update({
                 "backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "bucket_mb": round(ar.bucket_elems * 4 / (1 << 20), 1),
-                "n_buckets": len(ar.buckets), "grad_bytes_per_step": int(ar.total * (4 if ar.bucket_dtype == torch.float32 else 2)),
+                "n_buckets": len(ar.buckets), "bucket_mb_each": [round((e - b) * 4 / (1 << 20), 1) for b, e in ar.buckets], "grad_bytes_per_step": int(ar.total * (4 if ar.bucket_dtype == torch.float32 else 2)),
                 "wire_dtype": str(ar.bucket_dtype).replace("torch.", ""),
                 "exposed_comm_ms_per_step": round(sum(exposed) / len(exposed), 3) if exposed else None,
                 "exposed_comm_note": "rank 0, mean over the timed steps: compute-stream idle time between the end of backward and the end of the last bucket's all-reduce",
@@ -661,6 +671,8 @@ def main():
                 "rccl_env": {k: os.environ[k] for k in sorted(os.environ) if k.startswith(("NCCL_", "RCCL_"))}})
         if rehearsal:
             out["config"]["rccl_rehearsal"] = "one-rank RCCL group, every data-parallel collective issued"
+            if args.rehearsal_occupancy:
+                out["config"]["rehearsal_occupancy"] = args.rehearsal_occupancy + " (WGS:GBPS, emulated 8-rank ring occupancy per bucket)"
         if args.arch == "fcos" and args.depth == 50:
             # SURVEY.md 8(d)'s 1.1913 TFLOP per image is an UPPER bound (it counts a data gradient for the first trainable layer);
             # roofline.by_pass sums the FLOPs of the launches actually timed

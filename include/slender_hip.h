@@ -51,6 +51,10 @@ const char* sod_version(void);
  * sod_stream_destroy (after synchronising it). */
 int sod_stream_create_cumask(const unsigned* mask_words, int nwords, void** out_stream);
 int sod_stream_destroy(void* stream);
+/* Rehearsal aid (no reference counterpart): `wgs` (1..256) workgroups of 256 threads stay resident on `stream` for `usec` (1..100000)
+ * microseconds - the CU occupancy of RCCL's channel kernels while a bucket is reduced, emulated on a one-GPU box
+ * (bench.py --rccl-rehearsal --rehearsal-occupancy). */
+int sod_debug_occupy(int wgs, int usec, void* stream);
 
 /* bytes of the scratch buffer `ws` the reduction-type entry points need */
 long long sod_reduce_workspace_bytes(void);

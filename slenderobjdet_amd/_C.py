@@ -163,6 +163,7 @@ _SIGS = {
     "sod_version": [],
     "sod_stream_create_cumask": [_P, _I, _P],
     "sod_stream_destroy": [_P],
+    "sod_debug_occupy": [_I, _I, _P],
 }
 _RESTYPES = {"sod_reduce_workspace_bytes": c_longlong, "sod_conv2d_wgrad_workspace_bytes": c_longlong, "sod_nms_workspace_bytes": c_longlong, "sod_batched_nms_workspace_bytes": c_longlong, "sod_version": c_char_p}
 

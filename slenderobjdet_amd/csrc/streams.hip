@@ -19,3 +19,19 @@ extern "C" int sod_stream_destroy(void* stream) {
   if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
   return SOD_OK;
 }
+
+// Rehearsal aid for the N-GPU path on a one-GPU box (bench.py --rccl-rehearsal --rehearsal-occupancy): `wgs` workgroups of 256 threads that
+// stay resident for `usec` microseconds, as RCCL's channel kernels do while a gradient bucket is on the wire.  A one-rank all-reduce moves
+// no data and occupies nothing, so it cannot show what the whole-CU workgroups of this library (one per CU, all registers of the CU) lose
+// while some CUs hold a foreign wave.  Every wave leaves after the interval (wall_clock64 runs at 100 MHz, independent of the shader clock).
+__global__ __launch_bounds__(256) void occupy_kernel(long long ticks) {
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+extern "C" int sod_debug_occupy(int wgs, int usec, void* stream) {
+  if (wgs <= 0 || wgs > 256 || usec <= 0 || usec > 100000) return SOD_EARG;
+  SOD_LAUNCH(occupy_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (long long)usec * 100ll);
+  SOD_CHECK_LAUNCH();
+  return SOD_OK;
+}
