@@ -448,8 +448,6 @@ def main():
                     "detector's are - how far the step time depends on the offsets leaving the backward kernel's LDS window")
     ap.add_argument("--constant-lr", action="store_true", help="constant SOLVER.BASE_LR from step 0 instead of the reference's WarmupMultiStepLR")
     ap.add_argument("--bucket-mb", type=float, default=None, help="N > 1: size of the gradient all-reduce buckets (default 32 MB)")
-    ap.add_argument("--bucket-tail-mb", type=float, default=None, help="N > 1: at most this many MB in the LAST bucket (its reduction is exposed; "
-                    "default 6, 0 = off)")
     ap.add_argument("--wire", choices=["fp32", "bf16"], default=None, help="N > 1: wire format of the gradient buckets (default fp32, SOD_GRAD_BUCKET_DTYPE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -519,8 +517,8 @@ def main():
             b = model.offsets_init[1].conv.bias
             b[: 2 * model.num_points].copy_(torch.randn(2 * model.num_points, generator=torch.Generator().manual_seed(5)) * args.reppoints_offset_px)
         model.arena.bump()
-    if args.bucket_mb is not None or args.wire is not None or args.bucket_tail_mb is not None:
-        model.arena.configure_buckets(args.bucket_mb if args.bucket_mb is not None else 32.0, args.wire, args.bucket_tail_mb)
+    if args.bucket_mb is not None or args.wire is not None:
+        model.arena.configure_buckets(args.bucket_mb if args.bucket_mb is not None else 32.0, args.wire)
     if args.rehearsal_occupancy:
         assert rehearsal, "--rehearsal-occupancy needs --rccl-rehearsal on one GPU"
         wgs, gbps = args.rehearsal_occupancy.split(":")

@@ -19,7 +19,7 @@ _ALIGN = 64  # elements; keeps every tensor 256-B aligned
 
 
 class ParamArena:
-    def __init__(self, model, bucket_mb=32.0, bucket_dtype=None, tail_mb=None):
+    def __init__(self, model, bucket_mb=32.0, bucket_dtype=None):
         seen, plist = set(), []
         for name, p in model.named_parameters():
             if p.requires_grad and id(p) not in seen:
@@ -51,19 +51,18 @@ class ParamArena:
         self._plist = [p for _, p in plist]
         self.generation = 0          # bumped whenever params change behind torch's back (fused optimizer step)
         self._offs = offs
-        self.configure_buckets(bucket_mb, bucket_dtype, tail_mb)
+        self.configure_buckets(bucket_mb, bucket_dtype)
         self._pending = None
         self._uses = {}
         self._counting = True
         self._comm_stream = None
         self._handles = []
 
-    def configure_buckets(self, bucket_mb=32.0, bucket_dtype=None, tail_mb=None):
+    def configure_buckets(self, bucket_mb=32.0, bucket_dtype=None):
         """(Re)build the gradient buckets of the data-parallel all-reduce: contiguous runs of the gradient arena of at least ``bucket_mb``
         MB each, in backward completion order.  Call between steps only (bench.py --bucket-mb / --wire, so that a scaling curve can be swept
-        without code changes).  ``tail_mb`` (default SOD_BUCKET_TAIL_MB or 6): the LAST bucket - the first trainable layers, whose
-        gradients exist only when backward ends - is all of its reduction time exposed, so at most ``tail_mb`` MB are left for it (the rest
-        of what would have been the last bucket goes out earlier as a bucket of its own); 0 = off."""
+        without code changes).  (A smaller LAST bucket does not shorten the exposed tail - the communication stream is serial and the
+        bucket before it is still on the wire when backward ends: 25.95 vs 25.76 ms per step in the occupancy rehearsal)"""
         if getattr(self, "_pending", None) is not None:
             raise RuntimeError("configure_buckets inside a backward pass")
         offs, total = self._offs, self.total
@@ -76,16 +75,6 @@ class ParamArena:
                 b0 = nxt
         if b0 < total:
             self.buckets.append((b0, total))
-        import os as _os
-        if tail_mb is None:
-            tail_mb = float(_os.environ.get("SOD_BUCKET_TAIL_MB", "6"))
-        self.tail_mb = tail_mb
-        tail_elems = int(tail_mb * (1 << 20) / 4)
-        if tail_elems > 0:
-            b, e = self.buckets[-1]
-            cuts = [o for o in offs if b < o and e - o <= tail_elems]      # parameter boundaries that leave at most tail_mb behind them
-            if cuts and e - b > 2 * tail_elems:
-                self.buckets[-1:] = [(b, cuts[0]), (cuts[0], e)]
         self._bucket_of = {}
         for (name, off, n), p in zip(self.names, self._plist):
             for bi, (b, e) in enumerate(self.buckets):
@@ -95,6 +84,7 @@ class ParamArena:
         # a ring over one 153 GB/s xGMI link pair if nothing overlapped.  bf16 (SOD_GRAD_BUCKET_DTYPE=bf16) sends a
         # rounded copy - half the bytes - and writes the reduced values back as fp32; every rank receives the same reduced values,
         # so replicas stay bit-identical either way (tests/test_ddp_gloo.py).
+        import os as _os
         bd = bucket_dtype if bucket_dtype is not None else _os.environ.get("SOD_GRAD_BUCKET_DTYPE", "fp32")
         self.bucket_dtype = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}[str(bd).replace("torch.", "")]
 

@@ -509,20 +509,3 @@ def test_bench_kernel_names_match_the_committed_profile():
     tr = bench.pmc_traffic("conv_dgrad", bench.kernel_name("conv_dgrad", 256))
     assert tr and tr["hbm_bytes_per_launch"] > 0, tr
 
-
-def test_arena_last_bucket_is_tapered():
-    """layers/arena.py: the bucket that completes last (the first trainable layers) is cut to at most ``tail_mb`` MB - its reduction time is
-    exposed after backward - at a parameter boundary; every gradient element belongs to exactly one bucket either way."""
-    from slenderobjdet_amd.layers.arena import ParamArena
-
-    model = torch.nn.Sequential(*[torch.nn.Linear(256, 256) for _ in range(40)])        # 40 x 0.25 MB
-    arena = ParamArena(model, bucket_mb=2.0, tail_mb=0)
-    plain = list(arena.buckets)
-    arena.configure_buckets(2.0, None, 0.6)
-    tapered = list(arena.buckets)
-    for bk in (plain, tapered):
-        assert bk[0][0] == 0 and bk[-1][1] == arena.total and all(a[1] == b[0] for a, b in zip(bk, bk[1:]))
-    assert len(tapered) == len(plain) + 1 and tapered[:-2] == plain[:-1]
-    assert (tapered[-1][1] - tapered[-1][0]) * 4 <= 0.6 * (1 << 20) < (plain[-1][1] - plain[-1][0]) * 4
-    assert tapered[-1][0] in arena._offs                                                  # cut at a parameter boundary
-    assert set(arena._bucket_of.values()) == set(range(len(tapered)))
