@@ -593,6 +593,18 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, HF.PROFILE = prof_all, None
+    # Host time of ONE step with empty queues (outside the timed region): how long Python + the launch path need to enqueue a step when
+    # nothing blocks them.  host_enqueue_ms_per_step above converges to the device's step time once the launch queues are full, so it cannot
+    # tell whether the host is the limiter; this one can (host-bound if it approaches ms_per_step).
+    host_unblocked = []
+    for _ in range(3):
+        nxt = next(loader)
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        last = train_step(model, optimizer, cur, nxt, scheduler)
+        host_unblocked.append(time.perf_counter() - th)
+        cur = nxt
+    torch.cuda.synchronize()
     if HF.PROFILE_LIB:
         import ctypes
         _C.call("sod_conv_prof_enable", 0)
@@ -646,6 +658,7 @@ def main():
                                        f"{cfg.SOLVER.LR_SCHEDULER_NAME}: {cfg.SOLVER.WARMUP_METHOD} warm-up from {cfg.SOLVER.WARMUP_FACTOR} x base over "
                                        f"{cfg.SOLVER.WARMUP_ITERS} iterations, stepped every iteration (lr at the last step {optimizer.param_groups[0]['lr']:.3e})"),
                        "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
+                       "host_ms_per_step_unblocked": round(min(host_unblocked) * 1e3, 3),
                        "device": device_fingerprint(dev.index or 0)},
         }
         out["config"]["device"]["sclk_active"] = sclk_mid      # sampled at 3/4 of the timed loop (None if sysfs does not expose it)
@@ -657,7 +670,7 @@ def main():
             # what the collective layer saw, so that a reader of this line can check that the run was the N-rank data-parallel job it
             # claims (reference: train_net.py:185-195 -> detectron2 launch -> one process per GPU, NCCL all-reduce of every gradient)
             ar = model.arena
-            pairs = getattr(ar, "comm_probe", None) or []
+            pairs = (getattr(ar, "comm_probe", None) or [])[:args.steps]      # (the three un-timed host-latency steps after the loop excluded)
             exposed = [a.elapsed_time(b) for a, b in pairs]
             out["config"].update({
                 "backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "bucket_mb": round(ar.bucket_elems * 4 / (1 << 20), 1),
