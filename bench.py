@@ -455,6 +455,8 @@ def main():
     ap.add_argument("--rccl-rehearsal", action="store_true",
                     help="--gpus 1 only: create a one-rank RCCL process group and issue every data-parallel collective anyway (parameter "
                          "broadcast, normaliser all-reduce, bucketed gradient all-reduce) - exercises the real RCCL path on a one-GPU box")
+    ap.add_argument("--sync-debug", action="store_true", help="diagnostic: torch.cuda.set_sync_debug_mode('warn') during the timed loop - every "
+                    "call site that makes the host wait for the device prints a warning with its stack (the step must have none)")
     ap.add_argument("--rehearsal-occupancy", default=None, metavar="WGS:GBPS",
                     help="with --rccl-rehearsal: every bucket's all-reduce is followed on the communication stream by WGS resident workgroups for "
                          "the time an 8-rank ring takes at GBPS of bus bandwidth (sod_debug_occupy) - what the step loses while RCCL's channel "
@@ -567,8 +569,24 @@ def main():
     from slenderobjdet_amd.modeling.meta_arch import fcos as fcos_mod
     tower_default = fcos_mod.TOWER_STREAMS
     sclk_mid = None
+    if args.sync_debug:
+        import warnings
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
+    # how far the host runs AHEAD of the device: a device event + a host time stamp at the start of every timed step (a profiler slows the
+    # host down, so only the un-profiled run can say); lead_i = (device time of event i) - (host time of its record call)
+    lead_ev, lead_host = [], []
+    base_ev = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    base_ev.record()
+    torch.cuda.synchronize()
+    base_host = time.perf_counter()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ev_i = torch.cuda.Event(enable_timing=True)
+        lead_host.append(time.perf_counter())
+        ev_i.record()
+        lead_ev.append(ev_i)
         if i == (3 * args.steps) // 4 and rank == 0:
             # the shader clock the device reports WHILE the timed loop keeps it busy (a sysfs read: no GPU call, ~50 us of host time; the
             # host runs several steps ahead of the device); read after the loop it is the idle clock
@@ -588,11 +606,15 @@ def main():
     HF.WGRAD_SIDE_STREAM = side_default
     fcos_mod.TOWER_STREAMS = tower_default
     host_dt = time.perf_counter() - t0          # the host has ENQUEUED the K steps; the device is still working on them
+    if args.sync_debug:
+        torch.cuda.set_sync_debug_mode("default")
     if world > 1 or rehearsal:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, HF.PROFILE = prof_all, None
+    leads = sorted(base_ev.elapsed_time(e) * 1e-3 - (h - base_host) for e, h in zip(lead_ev[2:], lead_host[2:]))
+    host_lead_ms = (round(leads[0] * 1e3, 2), round(leads[len(leads) // 2] * 1e3, 2)) if leads else None
     # Host time of ONE step with empty queues (outside the timed region): how long Python + the launch path need to enqueue a step when
     # nothing blocks them.  host_enqueue_ms_per_step above converges to the device's step time once the launch queues are full, so it cannot
     # tell whether the host is the limiter; this one can (host-bound if it approaches ms_per_step).
@@ -659,6 +681,7 @@ def main():
                                        f"{cfg.SOLVER.WARMUP_ITERS} iterations, stepped every iteration (lr at the last step {optimizer.param_groups[0]['lr']:.3e})"),
                        "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
                        "host_ms_per_step_unblocked": round(min(host_unblocked) * 1e3, 3),
+                       "host_lead_ms_min_median": host_lead_ms,     # device start of a step minus the host's enqueue time of that start
                        "device": device_fingerprint(dev.index or 0)},
         }
         out["config"]["device"]["sclk_active"] = sclk_mid      # sampled at 3/4 of the timed loop (None if sysfs does not expose it)
