@@ -455,6 +455,8 @@ def main():
     ap.add_argument("--rccl-rehearsal", action="store_true",
                     help="--gpus 1 only: create a one-rank RCCL process group and issue every data-parallel collective anyway (parameter "
                          "broadcast, normaliser all-reduce, bucketed gradient all-reduce) - exercises the real RCCL path on a one-GPU box")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this run (default: the runtime's 4 on one GPU, 6 for "
+                    "data-parallel ranks and the rehearsal - utils/comm.py:prepare_rank_env)")
     ap.add_argument("--sync-debug", action="store_true", help="diagnostic: torch.cuda.set_sync_debug_mode('warn') during the timed loop - every "
                     "call site that makes the host wait for the device prints a warning with its stack (the step must have none)")
     ap.add_argument("--rehearsal-occupancy", default=None, metavar="WGS:GBPS",
@@ -471,6 +473,10 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.hw_queues:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
+    from slenderobjdet_amd.utils.comm import prepare_rank_env
+    prepare_rank_env(world, rehearsal=args.rccl_rehearsal)      # nothing has touched the GPU yet: the HIP runtime reads these at start-up
     if world > 1:
         # SOD_BENCH_SHARE_GPU=1 (tests only): every rank uses cuda:0 with the gloo backend, to exercise the data-parallel
         # path on a single-GPU box; the real launch is one rank per GPU over RCCL ("nccl").
@@ -702,7 +708,8 @@ def main():
                 "exposed_comm_ms_per_step": round(sum(exposed) / len(exposed), 3) if exposed else None,
                 "exposed_comm_note": "rank 0, mean over the timed steps: compute-stream idle time between the end of backward and the end of the last bucket's all-reduce",
                 # what RCCL was told (it picks ring / tree and the channel count per call itself; NCCL_DEBUG=INFO prints its choices to stderr)
-                "rccl_env": {k: os.environ[k] for k in sorted(os.environ) if k.startswith(("NCCL_", "RCCL_"))}})
+                "rccl_env": {k: os.environ[k] for k in sorted(os.environ) if k.startswith(("NCCL_", "RCCL_"))},
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")})
         if rehearsal:
             out["config"]["rccl_rehearsal"] = "one-rank RCCL group, every data-parallel collective issued"
             if args.rehearsal_occupancy:

@@ -34,6 +34,8 @@ def _distributed_worker(local_rank, main_func, world_size, num_gpus_per_machine,
     os.environ["WORLD_SIZE"] = str(world_size)      # fcos/utils.py:10-11 reads it
     os.environ["RANK"] = str(global_rank)
     os.environ["LOCAL_RANK"] = str(local_rank)
+    from ..utils.comm import prepare_rank_env
+    prepare_rank_env(world_size)                    # before the first HIP call of this rank (set_device below)
     if use_gpu:
         torch.cuda.set_device(local_rank)
     dist.init_process_group(backend="nccl" if use_gpu else "gloo", init_method=dist_url, world_size=world_size, rank=global_rank)

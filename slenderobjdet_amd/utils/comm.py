@@ -33,6 +33,23 @@ def is_main_process() -> bool:
 # two-ranks-on-one-GPU gloo test cannot.
 FORCE_COLLECTIVES = False
 
+# HIP hardware queues of a data-parallel rank.  The ROCm runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4).  A one-GPU step uses exactly four streams (main, weight gradients, box tower, frozen-prefix look-ahead); a data-parallel
+# rank adds the bucket stream of layers/arena.py and c10d's own RCCL stream, which then SHARE hardware queues with compute streams: the
+# bucket stream's "wait until every compute stream has produced this bucket" barrier sits in the main stream's queue, and the main stream
+# stalls until the weight-gradient stream has drained - at every bucket.  Measured in the one-GPU rehearsal (bench.py --rccl-rehearsal,
+# FCOS R50, ms per step): 4 queues 25.73, 5: 26.75, 6: 24.99 (the plain step: 24.71), 7: 30.1, 8: 30.3, 16: 30.6.
+# Six = one queue per stream; more is pathological on this runtime, so the value is set exactly, before the HIP runtime starts.
+HW_QUEUES_DATA_PARALLEL = 6
+
+
+def prepare_rank_env(world_size, rehearsal=False):
+    """Call BEFORE the first HIP call of the process (``import torch`` and ``torch.cuda.device_count()`` are fine): settings the HIP
+    runtime reads once at start-up.  An explicit GPU_MAX_HW_QUEUES in the environment wins."""
+    if world_size > 1 or rehearsal:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(HW_QUEUES_DATA_PARALLEL))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this platform (RCCL / tensor sharing across ranks)
+
 
 def collectives_active() -> bool:
     return get_world_size() > 1 or (FORCE_COLLECTIVES and is_dist())
