@@ -457,6 +457,8 @@ def main():
                          "broadcast, normaliser all-reduce, bucketed gradient all-reduce) - exercises the real RCCL path on a one-GPU box")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this run (default: the runtime's 4 on one GPU, 6 for "
                     "data-parallel ranks and the rehearsal - utils/comm.py:prepare_rank_env)")
+    ap.add_argument("--no-host-probe", action="store_true", help="skip the three un-timed steps after the loop that measure the host's enqueue time "
+                    "into empty queues (profiling runs: the trace then holds exactly warm-up + timed steps)")
     ap.add_argument("--sync-debug", action="store_true", help="diagnostic: torch.cuda.set_sync_debug_mode('warn') during the timed loop - every "
                     "call site that makes the host wait for the device prints a warning with its stack (the step must have none)")
     ap.add_argument("--rehearsal-occupancy", default=None, metavar="WGS:GBPS",
@@ -625,7 +627,7 @@ def main():
     # nothing blocks them.  host_enqueue_ms_per_step above converges to the device's step time once the launch queues are full, so it cannot
     # tell whether the host is the limiter; this one can (host-bound if it approaches ms_per_step).
     host_unblocked = []
-    for _ in range(3):
+    for _ in range(0 if args.no_host_probe else 3):
         nxt = next(loader)
         torch.cuda.synchronize()
         th = time.perf_counter()
@@ -686,7 +688,7 @@ def main():
                                        f"{cfg.SOLVER.LR_SCHEDULER_NAME}: {cfg.SOLVER.WARMUP_METHOD} warm-up from {cfg.SOLVER.WARMUP_FACTOR} x base over "
                                        f"{cfg.SOLVER.WARMUP_ITERS} iterations, stepped every iteration (lr at the last step {optimizer.param_groups[0]['lr']:.3e})"),
                        "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 3),
-                       "host_ms_per_step_unblocked": round(min(host_unblocked) * 1e3, 3),
+                       "host_ms_per_step_unblocked": round(min(host_unblocked) * 1e3, 3) if host_unblocked else None,
                        "host_lead_ms_min_median": host_lead_ms,     # device start of a step minus the host's enqueue time of that start
                        "device": device_fingerprint(dev.index or 0)},
         }

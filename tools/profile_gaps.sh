@@ -3,6 +3,6 @@
 set -u
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_trace -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline "$@" > gpurun_out/${tag}_trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_trace -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-host-probe "$@" > gpurun_out/${tag}_trace.log 2>&1
 python3 tools/trace_gaps.py gpurun_out/${tag}_trace 4 | tee gpurun_out/${tag}_gaps.txt
 rm -rf gpurun_out/${tag}_trace

@@ -6,7 +6,7 @@
 set -eu -o pipefail     # a step that fails or times out ends the call: no further GPU step after it
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline"
+B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-host-probe"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $B > gpurun_out/${tag}_stats.log 2>&1
 SOD_WGRAD_STREAM=0 SOD_TOWER_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_serial -- $B > gpurun_out/${tag}_serial.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- $B > gpurun_out/${tag}_fetch.log 2>&1
