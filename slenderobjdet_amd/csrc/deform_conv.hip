@@ -360,7 +360,9 @@ __global__ __launch_bounds__(256) void dcn_wnorm_kernel(const __bf16* __restrict
   out[r] = sqrtf(s);
 }
 
-template <int KS>      // K = 32 * KS output channels of the convolution = contraction length of the dcols GEMM
+// KS: K = 32 * KS output channels of the convolution = contraction length of the dcols GEMM.  GM: the mask gradient is wanted (modulated
+// DeformConv); without it - RepPoints' plain DeformConv - a ninth of the scatter's VALU work is not compiled in.
+template <int KS, bool GM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 3 : 1))) void dcn_bwd_fused_kernel(const DcnArgs a, const __bf16* __restrict__ dy, const __bf16* __restrict__ wt,
                                                             const float* __restrict__ wnorm, int tiles_x, int WH, int WW, int R) {
   constexpr int CC = 32, PS = CC + 1, L = CC / 8, K = 32 * KS;
@@ -533,24 +535,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 3
           dmv[e] = dm;
           g_dy += dm * (hx * (v10[e] - v00[e]) + s.lx * (v11[e] - v01[e]));
           g_dx += dm * (hy * (v01[e] - v00[e]) + s.ly * (v11[e] - v10[e]));
-          g_m += d * (s.w00 * v00[e] + s.w01 * v01[e] + s.w10 * v10[e] + s.w11 * v11[e]);
+          if constexpr (GM) g_m += d * (s.w00 * v00[e] + s.w01 * v01[e] + s.w10 * v10[e] + s.w11 * v11[e]);
         }
         if (inwin) {
+          // (dm * S) once per channel instead of once per update: the same product, the same rounding
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dmv[e] *= S;
+          const float q00 = s.w00, q01 = s.w01, q10 = s.w10, q11 = s.w11;
           if (s.ok00) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(w00p + e, __float2int_rn(dmv[e] * S * s.w00));
+            for (int e = 0; e < 8; ++e) atomicAdd(w00p + e, __float2int_rn(dmv[e] * q00));
           }
           if (s.ok01) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(w00p + PS + e, __float2int_rn(dmv[e] * S * s.w01));
+            for (int e = 0; e < 8; ++e) atomicAdd(w00p + PS + e, __float2int_rn(dmv[e] * q01));
           }
           if (s.ok10) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(w00p + WW * PS + e, __float2int_rn(dmv[e] * S * s.w10));
+            for (int e = 0; e < 8; ++e) atomicAdd(w00p + WW * PS + e, __float2int_rn(dmv[e] * q10));
           }
           if (s.ok11) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(w00p + WW * PS + PS + e, __float2int_rn(dmv[e] * S * s.w11));
+            for (int e = 0; e < 8; ++e) atomicAdd(w00p + WW * PS + PS + e, __float2int_rn(dmv[e] * q11));
           }
         } else {
           slow = true;
@@ -784,15 +790,21 @@ extern "C" int sod_deform_conv_bwd_fused(const void* dy, const void* wt, const v
   const dim3 grid(tiles_x * tiles_y, C / 32, N);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipError_t e = hipSuccess;
+    const void* kernels[6] = {(const void*)dcn_bwd_fused_kernel<4, false>, (const void*)dcn_bwd_fused_kernel<8, false>, (const void*)dcn_bwd_fused_kernel<16, false>,
+                              (const void*)dcn_bwd_fused_kernel<4, true>,  (const void*)dcn_bwd_fused_kernel<8, true>,  (const void*)dcn_bwd_fused_kernel<16, true>};
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  if (K == 128) SOD_LAUNCH(dcn_bwd_fused_kernel<4>, grid, dim3(256), lds, st, a, (const __bf16*)dy, (const __bf16*)wt, wnorm_ws, tiles_x, WH, WW, r_env);
-  else if (K == 256) SOD_LAUNCH(dcn_bwd_fused_kernel<8>, grid, dim3(256), lds, st, a, (const __bf16*)dy, (const __bf16*)wt, wnorm_ws, tiles_x, WH, WW, r_env);
-  else SOD_LAUNCH(dcn_bwd_fused_kernel<16>, grid, dim3(256), lds, st, a, (const __bf16*)dy, (const __bf16*)wt, wnorm_ws, tiles_x, WH, WW, r_env);
+#define SOD_DCN_BWD_LAUNCH(KS_, GM_) \
+  SOD_LAUNCH((dcn_bwd_fused_kernel<KS_, GM_>), grid, dim3(256), lds, st, a, (const __bf16*)dy, (const __bf16*)wt, wnorm_ws, tiles_x, WH, WW, r_env)
+  if (a.dmask) {
+    if (K == 128) SOD_DCN_BWD_LAUNCH(4, true); else if (K == 256) SOD_DCN_BWD_LAUNCH(8, true); else SOD_DCN_BWD_LAUNCH(16, true);
+  } else {
+    if (K == 128) SOD_DCN_BWD_LAUNCH(4, false); else if (K == 256) SOD_DCN_BWD_LAUNCH(8, false); else SOD_DCN_BWD_LAUNCH(16, false);
+  }
+#undef SOD_DCN_BWD_LAUNCH
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
