@@ -382,7 +382,27 @@ def device_fingerprint(index=0, clocks_only=False):
         import glob
         cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
         if cards:
-            base = os.path.dirname(cards[min(index, len(cards) - 1)])
+            # the sysfs card of THIS device: a one-GPU box still lists every card of the host, so the card is matched by PCI address
+            # (hipDeviceGetPCIBusId); until round 5 card<index> was read - another GPU's clock
+            base, pci = None, None
+            try:
+                import ctypes
+                # the HIP runtime torch has ALREADY loaded (its exact path from the process map: dlopen returns that handle, never a second copy)
+                loaded = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+                if loaded:
+                    hip = ctypes.CDLL(loaded[0])
+                    buf = ctypes.create_string_buffer(64)
+                    if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+                        pci = buf.value.decode().lower()
+            except Exception:
+                pci = None
+            if pci:
+                for c in cards:
+                    if os.path.basename(os.path.realpath(os.path.dirname(c))).lower() == pci:
+                        base = os.path.dirname(c)
+            fp["sysfs_card"] = os.path.basename(os.path.dirname(base)) if base else "unmatched (card%d read)" % min(index, len(cards) - 1)
+            if base is None:
+                base = os.path.dirname(cards[min(index, len(cards) - 1)])
             levels = [l.strip() for l in open(os.path.join(base, "pp_dpm_sclk")).read().splitlines() if l.strip()]
             fp["sclk_levels"] = [l.split(":")[1].strip().rstrip("*").strip() for l in levels][-2:]
             fp["sclk_active"] = next((l.split(":")[1].strip().rstrip("*").strip() for l in levels if l.endswith("*")), None)
