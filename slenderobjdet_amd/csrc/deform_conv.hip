@@ -362,7 +362,12 @@ __global__ __launch_bounds__(256) void dcn_wnorm_kernel(const __bf16* __restrict
 
 // KS: K = 32 * KS output channels of the convolution = contraction length of the dcols GEMM.  GM: the mask gradient is wanted (modulated
 // DeformConv); without it - RepPoints' plain DeformConv - a ninth of the scatter's VALU work is not compiled in.
-template <int KS, bool GM>
+// STG: the offset gradients of the tile are staged in LDS ([64 px][2 * taps] floats behind the dcols tile) and leave in one coalesced pass
+// after the tap loop instead of two scattered 4-byte atomics per (pixel, tap).  Measured on the P3 level of RepPoints (us per launch at
+// offset spreads 0.5 / 4 / 8 px): 2 px of slack 2474 / 4485 / 6993 direct, 2760 / 3693 / 5596 staged; 4 px of slack 3008 / 3866 / 6218 direct,
+// 2848 / 3608 / 4642 staged - the flush is a serial tail that only the two-workgroup configuration hides, so the launcher stages from 4 px
+// of slack on (where layers/deform_conv.py::_WindowPolicy goes once offsets leave the window).
+template <int KS, bool GM, bool STG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 3 : 1))) void dcn_bwd_fused_kernel(const DcnArgs a, const __bf16* __restrict__ dy, const __bf16* __restrict__ wt,
                                                             const float* __restrict__ wnorm, int tiles_x, int WH, int WW, int R) {
   constexpr int CC = 32, PS = CC + 1, L = CC / 8, K = 32 * KS;
@@ -381,6 +386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 3
   const int win_bytes = (WH * WW * PS * 4 + 15) & ~15;
   char* wl = reinterpret_cast<char*>(win) + win_bytes;
   __bf16* dcl = reinterpret_cast<__bf16*>(wl + 32 * WROW);
+  float* dofl = reinterpret_cast<float*>(dcl + 64 * CC);      // STG only (the launcher sizes the allocation)
   for (int i = tid; i < WH * WW * PS; i += 256) win[i] = 0;
 
   // ---- A fragments: dY rows of this wave's 16 pixels, all K channels (lane: pixel = lane % 16, channels (lane / 16) * 8 .. + 8 of a step)
@@ -571,7 +577,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 3
     for (int o = L >> 1; o > 0; o >>= 1) {
       g_dy += __shfl_xor(g_dy, o, 64); g_dx += __shfl_xor(g_dx, o, 64); g_m += __shfl_xor(g_m, o, 64);
     }
-    if (live && cl == 0) {
+    if constexpr (STG) {
+      if (cl == 0) {
+        dofl[pl * (2 * taps) + 2 * tap] = live ? g_dy : 0.f;
+        dofl[pl * (2 * taps) + 2 * tap + 1] = live ? g_dx : 0.f;
+        if (live && a.dmask) atomicAdd(a.dmask + pix * a.mask_ld + k, g_m);
+      }
+    } else if (live && cl == 0) {
       atomicAdd(a.doff + pix * a.off_ld + 2 * k, g_dy);
       atomicAdd(a.doff + pix * a.off_ld + 2 * k + 1, g_dx);
       if (a.dmask) atomicAdd(a.dmask + pix * a.mask_ld + k, g_m);
@@ -618,6 +630,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 3
       const float v = (float)q * invS;
       const int wx = r % WW, wy = r / WW;
       atomicAdd(a.dx + ((base + (long long)(wy0 + wy) * a.W + (wx0 + wx)) * a.C) + c0 + c, v);
+    }
+  }
+  if constexpr (STG) {      // 2 * taps consecutive floats per pixel, the eight pixels of a tile row one after the other (off_ld apart)
+    for (int i = tid; i < 64 * 2 * taps; i += 256) {
+      const int p = i / (2 * taps), j = i - p * (2 * taps);
+      const int hop = ho0 + (p >> 3), wop = wo0 + (p & 7);
+      const float v = dofl[i];
+      if (hop < a.Ho && wop < a.Wo && v != 0.f) atomicAdd(a.doff + (((long long)n * a.Ho + hop) * a.Wo + wop) * a.off_ld + 2 * g * taps + j, v);
     }
   }
 }
@@ -756,10 +776,10 @@ extern "C" int sod_deform_conv_set_window_slack(int pixels) {
 
 // LDS bytes of one dcn_bwd_fused_kernel workgroup: the fixed-point dX window (8x8 output tile + receptive field + slack, 33-float pitch),
 // 32 weight rows of K bf16 (+16 B pad), the 64 x 32 bf16 column-gradient tile.
-static size_t dcn_bwd_fused_lds(int K, int KH, int KW, int stride, int dil) {
+static size_t dcn_bwd_fused_lds(int K, int KH, int KW, int stride, int dil, bool staged = false) {
   const int r_env = dcn_fused_slack();
   const int WH = 7 * stride + (KH - 1) * dil + 2 + 2 * r_env, WW = 7 * stride + (KW - 1) * dil + 2 + 2 * r_env;
-  return (((size_t)WH * WW * 33 * 4 + 15) & ~(size_t)15) + (size_t)32 * (K * 2 + 16) + (size_t)64 * 32 * 2;
+  return (((size_t)WH * WW * 33 * 4 + 15) & ~(size_t)15) + (size_t)32 * (K * 2 + 16) + (size_t)64 * 32 * 2 + (staged ? (size_t)64 * 2 * KH * KW * sizeof(float) : 0);
 }
 
 extern "C" int sod_deform_conv_bwd_fused_supported(int C, int K, int KH, int KW, int stride, int dil, int deformable_groups) {
@@ -780,7 +800,9 @@ extern "C" int sod_deform_conv_bwd_fused(const void* dy, const void* wt, const v
   if ((K != 128 && K != 256 && K != 512) || (C & 31) || (cpg & 31) || N > 65535 || C / 32 > 65535 || H > 16382 || W > 16382) return SOD_EARG;
   const int r_env = dcn_fused_slack();
   const int WH = 7 * stride + (KH - 1) * dil + 2 + 2 * r_env, WW = 7 * stride + (KW - 1) * dil + 2 + 2 * r_env;
-  const size_t lds = dcn_bwd_fused_lds(K, KH, KW, stride, dil);
+  // offset gradients staged in LDS from 4 px of slack on (see dcn_bwd_fused_kernel), if the larger allocation still fits
+  const bool staged = r_env >= 4 && KH * KW <= 9 && dcn_bwd_fused_lds(K, KH, KW, stride, dil, true) <= 96 * 1024;
+  const size_t lds = dcn_bwd_fused_lds(K, KH, KW, stride, dil, staged);
   if (lds > 96 * 1024 || (unsigned long long)N * a.Ho * a.Wo * K * 2ull >= 0x80000000ull * 4ull) return SOD_EARG;
   a.x = (const __bf16*)x; a.off = offset; a.mask = mask; a.dx = dx_f32; a.doff = doffset; a.dmask = dmask;
   hipStream_t st = (hipStream_t)stream;
@@ -791,19 +813,22 @@ extern "C" int sod_deform_conv_bwd_fused(const void* dy, const void* wt, const v
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipSuccess;
-    const void* kernels[6] = {(const void*)dcn_bwd_fused_kernel<4, false>, (const void*)dcn_bwd_fused_kernel<8, false>, (const void*)dcn_bwd_fused_kernel<16, false>,
-                              (const void*)dcn_bwd_fused_kernel<4, true>,  (const void*)dcn_bwd_fused_kernel<8, true>,  (const void*)dcn_bwd_fused_kernel<16, true>};
-    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    const void* kernels[12] = {
+        (const void*)dcn_bwd_fused_kernel<4, false, false>, (const void*)dcn_bwd_fused_kernel<8, false, false>, (const void*)dcn_bwd_fused_kernel<16, false, false>,
+        (const void*)dcn_bwd_fused_kernel<4, true, false>,  (const void*)dcn_bwd_fused_kernel<8, true, false>,  (const void*)dcn_bwd_fused_kernel<16, true, false>,
+        (const void*)dcn_bwd_fused_kernel<4, false, true>,  (const void*)dcn_bwd_fused_kernel<8, false, true>,  (const void*)dcn_bwd_fused_kernel<16, false, true>,
+        (const void*)dcn_bwd_fused_kernel<4, true, true>,   (const void*)dcn_bwd_fused_kernel<8, true, true>,   (const void*)dcn_bwd_fused_kernel<16, true, true>};
+    for (int i = 0; i < 12 && e == hipSuccess; ++i) e = hipFuncSetAttribute(kernels[i], hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-#define SOD_DCN_BWD_LAUNCH(KS_, GM_) \
-  SOD_LAUNCH((dcn_bwd_fused_kernel<KS_, GM_>), grid, dim3(256), lds, st, a, (const __bf16*)dy, (const __bf16*)wt, wnorm_ws, tiles_x, WH, WW, r_env)
-  if (a.dmask) {
-    if (K == 128) SOD_DCN_BWD_LAUNCH(4, true); else if (K == 256) SOD_DCN_BWD_LAUNCH(8, true); else SOD_DCN_BWD_LAUNCH(16, true);
-  } else {
-    if (K == 128) SOD_DCN_BWD_LAUNCH(4, false); else if (K == 256) SOD_DCN_BWD_LAUNCH(8, false); else SOD_DCN_BWD_LAUNCH(16, false);
-  }
+#define SOD_DCN_BWD_LAUNCH(KS_, GM_, STG_) \
+  SOD_LAUNCH((dcn_bwd_fused_kernel<KS_, GM_, STG_>), grid, dim3(256), lds, st, a, (const __bf16*)dy, (const __bf16*)wt, wnorm_ws, tiles_x, WH, WW, r_env)
+#define SOD_DCN_BWD_PICK(GM_, STG_) \
+  do { if (K == 128) SOD_DCN_BWD_LAUNCH(4, GM_, STG_); else if (K == 256) SOD_DCN_BWD_LAUNCH(8, GM_, STG_); else SOD_DCN_BWD_LAUNCH(16, GM_, STG_); } while (0)
+  if (a.dmask) { if (staged) SOD_DCN_BWD_PICK(true, true); else SOD_DCN_BWD_PICK(true, false); }
+  else         { if (staged) SOD_DCN_BWD_PICK(false, true); else SOD_DCN_BWD_PICK(false, false); }
+#undef SOD_DCN_BWD_PICK
 #undef SOD_DCN_BWD_LAUNCH
   SOD_CHECK_LAUNCH();
   return SOD_OK;

@@ -32,8 +32,8 @@ BWD_FUSED = os.environ.get("SOD_DCN_BWD_FUSED", "1") != "0"
 # pixels per level (rpd.py:637-647: the points of an object of 4-8 strides), so the slack is ADAPTIVE per layer and level: the library
 # counts the samples that left the window (sod_deform_conv_set_window_counter), the count of the previous launch is read back
 # asynchronously, and the slack goes 2 -> 4 px while more than 10 % of the samples are outside - a wider window admits fewer workgroups
-# per CU (2.5 / 3.1 ms with nothing outside), so it is only paid where the offsets ask for it (4.5 -> 3.9 ms at 4 px, 7.0 -> 6.2 ms at
-# 8 px); a step that takes back less than 15 % of the outside samples is undone (a diverging run's offsets are beyond any window); every
+# per CU (2.5 / 2.8 ms with nothing outside), so it is only paid where the offsets ask for it (4.5 -> 3.6 ms at 4 px, 6.9 -> 4.7 ms at
+# 8 px: from 4 px of slack the library also stages the offset gradients in LDS); a step that takes back less than 15 % of the outside samples is undone (a diverging run's offsets are beyond any window); every
 # PROBE_EVERY launches the narrower window is tried again.  SOD_DCN_ADAPTIVE_WINDOW=0 switches it off.
 ADAPTIVE_WINDOW = os.environ.get("SOD_DCN_ADAPTIVE_WINDOW", "1") != "0"
 PROBE_EVERY = 200

@@ -153,6 +153,18 @@ def test_deform_conv_fused_backward(cuda, modulated, dg, stride, C, K, hw, sprea
         scale = want.abs().max().item()
         assert (got.cpu() - want).abs().max().item() <= 2e-2 * scale, name
         assert (got - old).abs().max().item() <= 2e-4 * scale, name          # same bf16 column gradients, another fixed-point scale / order
+    # 4 px of slack: the wider window and the offset gradients staged in LDS + one coalesced pass per tile (STG variants) - same values
+    HF.call("sod_deform_conv_set_window_slack", 4)
+    try:
+        if HF.deform_bwd_fused_supported(C, K, dg, (3, 3), stride, 1):
+            doff4 = torch.zeros_like(offd)
+            dmask4 = torch.zeros_like(maskd) if modulated else None
+            dx4 = HF.deform_conv_bwd_fused(dyd, wt, xd, offd, maskd, (3, 3), stride, 1, 1, dg, doff4, dmask4)
+            for got, old, want, name in ((dx4, dx, grads[0], "dx"), (doff4, doff, grads[1], "doffset")) + (((dmask4, dmask, grads[2], "dmask"),) if modulated else ()):
+                scale = want.abs().max().item()
+                assert (got - old).abs().max().item() <= 2e-4 * scale, (name, "slack 4")
+    finally:
+        HF.call("sod_deform_conv_set_window_slack", -1)
     # rows of image 1 no sample of a pixel with gradient can reach (first such pixel row Ho // 2, tap row -1, offset >= -spread / 2, floor)
     clear = (Ho // 2) * stride - 1 - int(spread / 2 + 1) - 1
     if clear > 0:
