@@ -476,6 +476,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 3
   const bool live = ho < a.Ho && wo < a.Wo;
   const long long pix = ((long long)n * a.Ho + ho) * a.Wo + wo;
   for (int tap = 0; tap < taps; ++tap) {
+    // this tap's offsets (and mask value) are requested BEFORE the matrix-core phase and consumed after its barrier: their latency - the
+    // first of two dependent memory round trips of the scatter (offsets -> corner addresses -> corner loads) - hides behind the MFMAs
+    float dyo = 0.f, dxo = 0.f, mraw = 1.f;
+    if (live) {
+      const int kq = g * taps + tap;
+      dyo = a.off[pix * a.off_ld + 2 * kq]; dxo = a.off[pix * a.off_ld + 2 * kq + 1];
+      if (a.mask) mraw = a.mask[pix * a.mask_ld + kq];
+    }
     // ---- dcols tile of this tap on the matrix cores: 16 px (this wave) x 32 ch
     f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
@@ -502,10 +510,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS <= 8 ? 3
     unsigned s_pk = 0;                 // (xl + 1) << 18 | (yl + 1) << 4 | corner bits; H, W < 16383 is checked by the launcher
     float s_m = 0.f, s_ly = 0.f, s_lx = 0.f;
     if (live) {
-      const float dyo = a.off[pix * a.off_ld + 2 * k], dxo = a.off[pix * a.off_ld + 2 * k + 1];
       const int ki = tap / a.KW, kj = tap - ki * a.KW;
       const Samp s = make_samp((float)(ho * a.stride - a.pad + ki * a.dil) + dyo, (float)(wo * a.stride - a.pad + kj * a.dil) + dxo, a.H, a.W);
-      float m = a.mask ? a.mask[pix * a.mask_ld + k] : 1.f;
+      float m = mraw;
       if (a.mask && a.mask_logit) m = 1.f / (1.f + expf(-m));
       const bf16x8_t dcv = *reinterpret_cast<const bf16x8_t*>(dcl + pl * CC + cl * 8);
       const s16x8_t dbits = __builtin_bit_cast(s16x8_t, dcv);
