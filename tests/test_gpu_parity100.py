@@ -307,7 +307,7 @@ def test_one_step_parity_along_the_100_iteration_trajectory(cuda, precision):
 FROZEN_PREFIX = ("backbone.bottom_up.stem", "backbone.bottom_up.res2")
 
 
-@pytest.mark.parametrize("mode,depth,iters,size", [("fp32", 18, ITERS, 512), ("fp32", 50, 30, 256), ("bf16", 18, ITERS, 512)])
+@pytest.mark.parametrize("mode,depth,iters,size", [("fp32", 18, ITERS, 512), ("fp32", 50, 30, 256), ("bf16", 18, ITERS, 512), ("bf16", 50, 30, 256)])
 def test_free_run_on_shared_relu_decisions(cuda, mode, depth, iters, size):
     """north_star's sentence as a statement that CAN hold: "total-loss delta < 1e-3 vs the reference's CPU path after 100 iterations".
     Free-running fp32 implementations of this run end 2e-3 ... 1.3e-2 apart (test above, tests/golden/chaos100.json) - and round 4
@@ -324,7 +324,9 @@ def test_free_run_on_shared_relu_decisions(cuda, mode, depth, iters, size):
     * ``bf16, 18``  the bf16 PRODUCT path (the MFMA kernels bench.py times, default float-atomic reductions) on configs[0], 100 iterations
       against the plain fp32 oracle on the product's decisions: what is left is bf16 storage rounding, amplified by 100 SGD steps.  The
       iteration-100 delta is REPORTED (gpurun_out/parity100_shared_relu_bf16_18.json) and held to the bound measured
-      for it; the fused frozen kernels (stem + pool) keep their ReLUs inside, so the oracle decides those itself (no gradient flows there)."""
+      for it; the fused frozen kernels (stem + pool) keep their ReLUs inside, so the oracle decides those itself (no gradient flows there).
+    * ``bf16, 50``  the bf16 product path on the R50 family (bottleneck blocks: the persistent 1x1 kernel, 1-bit ReLU masks, the fused
+      frozen res2 blocks), 30 iterations at 256x256, same bound; reported in gpurun_out/parity100_shared_relu_bf16_50.json."""
     from bench import train_step
     from oracle.conditioning import ProductReluTap
     from oracle.model import OracleFCOS
