@@ -986,7 +986,9 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   const bool use32 = !generic && (a.Cred & 31) == 0 && blocks > 512 &&
                      (a.Kred <= 512 || blocks <= 1024 || (a.Cred <= 128 && a.Kred <= 1152));
   // (Measured and removed in round 5: a 3 / 4 / 5-slot LDS ring for the 32-deep K-steps - 113 -> 117 / 114 / 114 us on res3 conv3, -30 %
-  // where it halves the workgroups per CU - and a 128(q) x 256(p) 8-wave tile with a 3-slot ring, 717 vs 813 TFLOP/s on the head shape.)
+  // where it halves the workgroups per CU - and a 128(q) x 256(p) 8-wave tile with a 3-slot ring, 717 vs 813 TFLOP/s on the head shape;
+  // a 4-slot ring of 64-deep steps for the one-workgroup-per-CU grids of the FPN top (P6 / P7, 20 - 70 workgroups): 29.4 vs 28.1 us -
+  // their 0.78 us per K-step is issue time of one wave per SIMD, not load latency.)
   if (use32) return launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32, 32>(a, st);
   return generic ? launch_conv<MODE, true, 2, 2, 4, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 2, 2, 4, 4, OUT_F32>(a, st);
 }
