@@ -549,6 +549,12 @@ def test_bench_rccl_rehearsal_single_rank(cuda):
     for env_extra in ({"SOD_WGRAD_STREAM": "0", "SOD_TOWER_STREAMS": "1"}, {"SOD_WGRAD_STREAM": "0", "SOD_TOWER_STREAMS": "0"}):
         other = run(["--rccl-rehearsal"], dict(env_extra, SOD_GRAD_BUCKET_DTYPE="bf16"))
         assert other["config"]["final_loss"] == reh16["config"]["final_loss"], (env_extra, other["config"], reh16["config"])
+    # one hardware queue per stream for a rank (utils/comm.py::prepare_rank_env) unless the environment says otherwise; the emulated RCCL
+    # occupancy (sod_debug_occupy behind every bucket) changes the timing, never the result
+    assert reh["config"]["hw_queues"] == "6" and "hw_queues" not in plain["config"]
+    occ = run(["--rccl-rehearsal", "--rehearsal-occupancy", "16:300", "--hw-queues", "4"])
+    assert occ["config"]["hw_queues"] == "4" and occ["config"]["rehearsal_occupancy"].startswith("16:300")
+    assert occ["config"]["final_loss"] == plain["config"]["final_loss"], (occ["config"], plain["config"])
 
 
 def test_side_streams_gradients_match_single_stream(cuda):

@@ -509,3 +509,22 @@ def test_bench_kernel_names_match_the_committed_profile():
     tr = bench.pmc_traffic("conv_dgrad", bench.kernel_name("conv_dgrad", 256))
     assert tr and tr["hbm_bytes_per_launch"] > 0, tr
 
+
+
+def test_prepare_rank_env_sets_the_hardware_queue_count_for_data_parallel_ranks_only(monkeypatch):
+    """utils/comm.py::prepare_rank_env: one HIP hardware queue per stream for a data-parallel rank (and the one-GPU rehearsal), the runtime's
+    default on one GPU, and an explicit setting always wins."""
+    from slenderobjdet_amd.utils import comm
+
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    comm.prepare_rank_env(1)
+    assert "GPU_MAX_HW_QUEUES" not in os.environ
+    comm.prepare_rank_env(1, rehearsal=True)
+    assert os.environ["GPU_MAX_HW_QUEUES"] == str(comm.HW_QUEUES_DATA_PARALLEL) == "6"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    comm.prepare_rank_env(8)
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "6"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    comm.prepare_rank_env(8)
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "4"
+    assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
