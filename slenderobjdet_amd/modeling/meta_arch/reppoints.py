@@ -234,6 +234,8 @@ class RepPointsDetector(nn.Module):
 
     # ------------------------------------------------------------------ head
     def run_head(self, features):
+        # (The two towers on two streams, as the FCOS head runs its towers: 448.7 vs 450.2 img/s over three alternating pairs of 60-step
+        # runs in round 5 - no gain here: the DeformConv kernels behind the towers already keep the second stream's share of the chip busy.)
         cls_f, reg_f = list(features), list(features)
         for u in self.cls_conv:
             cls_f = u(cls_f)
