@@ -418,11 +418,12 @@ def device_fingerprint(index=0, clocks_only=False):
     return fp
 
 
-def _free_port():
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
+def launcher_cmd(nproc):
+    """``torch.distributed.run`` for ``nproc`` ranks of this node.  No port is guessed here: the agent's c10d rendezvous binds port 0
+    itself (the kernel picks a free one while the socket stays open) and the ranks reuse that store - binding a probe socket, closing
+    it and handing the number on is a race (EADDRINUSE when anything else takes the port in between)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--rdzv-backend", "c10d",
+            "--rdzv-endpoint", "127.0.0.1:0", "--local-addr", "127.0.0.1"]
 
 
 def spawn_ranks(args, argv):
@@ -437,8 +438,7 @@ def spawn_ranks(args, argv):
     if not share and have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s)", file=sys.stderr)
         sys.exit(2)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    cmd = launcher_cmd(args.gpus) + [os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rc = subprocess.call(cmd, env=env)
@@ -514,10 +514,8 @@ def main():
     else:
         torch.cuda.set_device(0)
         if args.rccl_rehearsal:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(_free_port()))
-            with _StdoutToStderr():
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            with _StdoutToStderr():     # a one-rank group needs no TCP rendezvous: an in-process store
+                dist.init_process_group("nccl", store=dist.HashStore(), rank=0, world_size=1, device_id=torch.device("cuda", 0))
                 dist.barrier()
     dev = torch.device("cuda", torch.cuda.current_device())
     rehearsal = args.rccl_rehearsal and world == 1

@@ -6,24 +6,30 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _find_free_port():
-    import socket
+def _auto_dist_url():
+    """Rendezvous for the ranks of ONE machine without guessing a TCP port: a FileStore in a fresh temporary directory.  (detectron2
+    binds a probe socket to port 0, closes it and passes the number on; whatever takes the port in between makes every rank fail with
+    EADDRINUSE - seen on the GPU box.)"""
+    import tempfile
 
-    sock = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    return port
+    return "file://" + os.path.join(tempfile.mkdtemp(prefix="sod_rdzv_"), "store")
 
 
 def launch(main_func, num_gpus_per_machine, num_machines=1, machine_rank=0, dist_url=None, args=()):
     world_size = num_machines * num_gpus_per_machine
     if world_size > 1:
+        own_dir = None
         if dist_url == "auto" or dist_url is None:
             assert num_machines == 1, "dist_url=auto not supported in multi-machine jobs."
-            dist_url = f"tcp://127.0.0.1:{_find_free_port()}"
-        mp.spawn(_distributed_worker, nprocs=num_gpus_per_machine,
-                 args=(main_func, world_size, num_gpus_per_machine, machine_rank, dist_url, args), daemon=False)
+            dist_url = _auto_dist_url()
+            own_dir = os.path.dirname(dist_url[len("file://"):])
+        try:
+            mp.spawn(_distributed_worker, nprocs=num_gpus_per_machine,
+                     args=(main_func, world_size, num_gpus_per_machine, machine_rank, dist_url, args), daemon=False)
+        finally:
+            if own_dir:
+                import shutil
+                shutil.rmtree(own_dir, ignore_errors=True)
     else:
         main_func(*args)
 

@@ -2,7 +2,6 @@
 backward-side ``mark_ready`` notifications, must leave the SUM of the per-rank gradients on every rank; and the folded
 (num_pos, sum_ctr) normaliser all-reduce must match the reference's two reduce_sum calls (fcos/utils.py:14-19)."""
 import os
-import socket
 
 import pytest
 import torch
@@ -10,17 +9,10 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _worker(rank, world, port, out, bucket_dtype="fp32"):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, store_file, out, bucket_dtype="fp32"):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
+    # a FileStore: no TCP port to guess (bind-to-0-then-close is a race)
+    dist.init_process_group("gloo", init_method="file://" + store_file, rank=rank, world_size=world)
     try:
         from slenderobjdet_amd.layers.arena import ParamArena
         from slenderobjdet_amd.utils import comm
@@ -80,11 +72,10 @@ def _worker(rank, world, port, out, bucket_dtype="fp32"):
 
 
 @pytest.mark.parametrize("bucket_dtype", ["fp32", "bf16"])
-def test_arena_bucketed_allreduce_world2(bucket_dtype):
+def test_arena_bucketed_allreduce_world2(bucket_dtype, tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, bucket_dtype)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, str(tmp_path / "store"), q, bucket_dtype)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

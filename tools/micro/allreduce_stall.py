@@ -11,8 +11,6 @@ import time
 import torch
 import torch.distributed as dist
 
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29533")
 
 
 class UniqueId(ctypes.Structure):
@@ -33,7 +31,7 @@ def direct_comm():
 def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group("nccl", store=dist.HashStore(), rank=0, world_size=1, device_id=dev)
     lib, comm = direct_comm()
     x = torch.ones(16 << 20, device=dev)            # 64 MB: ~30 us per pass
     side_x = torch.ones(16 << 20, device=dev)
