@@ -497,8 +497,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.hw_queues:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
-    from slenderobjdet_amd.utils.comm import prepare_rank_env
-    prepare_rank_env(world, rehearsal=args.rccl_rehearsal)      # nothing has touched the GPU yet: the HIP runtime reads these at start-up
+    from slenderobjdet_amd.utils import comm as _comm_mod
+    _comm_mod.prepare_rank_env(world, rehearsal=args.rccl_rehearsal)      # nothing has touched the GPU yet: the HIP runtime reads these at start-up
     if world > 1:
         # SOD_BENCH_SHARE_GPU=1 (tests only): every rank uses cuda:0 with the gloo backend, to exercise the data-parallel
         # path on a single-GPU box; the real launch is one rank per GPU over RCCL ("nccl").
@@ -729,7 +729,9 @@ def main():
                 "exposed_comm_note": "rank 0, mean over the timed steps: compute-stream idle time between the end of backward and the end of the last bucket's all-reduce",
                 # what RCCL was told (it picks ring / tree and the channel count per call itself; NCCL_DEBUG=INFO prints its choices to stderr)
                 "rccl_env": {k: os.environ[k] for k in sorted(os.environ) if k.startswith(("NCCL_", "RCCL_"))},
-                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")})
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                # set in-process after the HIP runtime had started (e.g. under rocprofv3): requested, not what the runtime used
+                "hw_queues_effective": not _comm_mod.HIP_STARTED_BEFORE_PREPARE})
         if rehearsal:
             out["config"]["rccl_rehearsal"] = "one-rank RCCL group, every data-parallel collective issued"
             if args.rehearsal_occupancy:

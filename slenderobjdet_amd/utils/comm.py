@@ -43,9 +43,30 @@ FORCE_COLLECTIVES = False
 HW_QUEUES_DATA_PARALLEL = 6
 
 
+HIP_STARTED_BEFORE_PREPARE = False
+
+
+def _hip_runtime_started():
+    """True when the HIP runtime of this process has (probably) read its environment already: torch has initialised the device, or a
+    profiler's preloaded tool library is mapped (rocprofv3 initialises HIP before Python starts, so a value set here comes too late and
+    the run uses whatever the SHELL exported - set GPU_MAX_HW_QUEUES in front of ``rocprofv3``, tools/profile_*.sh do)."""
+    import torch
+
+    if torch.cuda.is_initialized():
+        return True
+    try:
+        with open("/proc/self/maps") as f:
+            maps = f.read()
+    except OSError:
+        return False
+    return any(t in maps for t in ("librocprofiler-sdk-tool", "librocprofiler64", "libroctracer64"))
+
+
 def prepare_rank_env(world_size, rehearsal=False):
     """Call BEFORE the first HIP call of the process (``import torch`` and ``torch.cuda.device_count()`` are fine): settings the HIP
     runtime reads once at start-up.  An explicit GPU_MAX_HW_QUEUES in the environment wins."""
+    global HIP_STARTED_BEFORE_PREPARE
+    HIP_STARTED_BEFORE_PREPARE = _hip_runtime_started() and "GPU_MAX_HW_QUEUES" not in os.environ
     if world_size > 1 or rehearsal:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(HW_QUEUES_DATA_PARALLEL))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this platform (RCCL / tensor sharing across ranks)

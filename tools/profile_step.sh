@@ -5,6 +5,9 @@
 # passes (FETCH_SIZE / WRITE_SIZE, each alone with --kernel-trace as the pool requires).
 set -eu -o pipefail     # a step that fails or times out ends the call: no further GPU step after it
 tag=$1
+# a rehearsal / data-parallel profile needs the rank's hardware-queue count exported HERE: rocprofv3's tool library starts the HIP runtime
+# before python does, so bench.py's own in-process setting (utils/comm.py:prepare_rank_env) would come too late
+case " $* " in *" --rccl-rehearsal "*) export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-6};; esac
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-host-probe"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $B > gpurun_out/${tag}_stats.log 2>&1
