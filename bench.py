@@ -363,6 +363,38 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
+def rccl_info(log_pattern):
+    """What RCCL says it built for this rank's communicator (from its INIT / GRAPH log, captured once at start-up): channel counts, how
+    many rings / trees, the transports.  It picks the algorithm (ring / tree) and protocol per CALL from these and the message size;
+    that choice is only visible under NCCL_DEBUG_SUBSYS=TUNING, which prints per collective and is therefore not enabled in a timed
+    run.  Best effort: None when nothing was captured."""
+    import glob
+    import re
+
+    if not log_pattern:
+        return None
+    info = {"version": None, "channels": None, "rings": 0, "trees": 0, "transports": []}
+    try:
+        text = ""
+        for f in glob.glob(os.path.join(os.path.dirname(log_pattern), "*")):
+            with open(f, errors="replace") as fh:
+                text += fh.read()
+        m = re.search(r"(RCCL|NCCL) version ([^\s]+)", text)
+        info["version"] = m.group(2) if m else None
+        m = re.search(r"(\d+) coll channels, (\d+) (?:collnet|nvls) channels.*?(\d+) p2p channels", text)
+        if m:
+            info["channels"] = {"coll": int(m.group(1)), "p2p": int(m.group(3))}
+        info["rings"] = len(set(re.findall(r"Channel (\d+)/\d+\s*:", text)))
+        info["trees"] = len(re.findall(r"Trees \[", text))
+        info["transports"] = sorted(set(re.findall(r"via ([A-Za-z0-9/_]+)", text)))[:8]
+        m = re.search(r"comm 0x[0-9a-f]+ rank \d+ nranks (\d+)", text)
+        info["nranks"] = int(m.group(1)) if m else None
+        info["log_bytes"] = len(text)
+    except Exception as e:      # noqa: BLE001 - reporting only
+        info["error"] = repr(e)[:120]
+    return info
+
+
 def device_fingerprint(index=0, clocks_only=False):
     """Which device produced the line: MI355X parts differ by several per cent at equal code (clocks under load, power cap), so a
     reader comparing two runs needs to know whether they ran on the same one.  Best effort, never fails the benchmark."""
@@ -469,6 +501,9 @@ def main():
     ap.add_argument("--constant-lr", action="store_true", help="constant SOLVER.BASE_LR from step 0 instead of the reference's WarmupMultiStepLR")
     ap.add_argument("--bucket-mb", type=float, default=None, help="N > 1: size of the gradient all-reduce buckets (default 32 MB)")
     ap.add_argument("--wire", choices=["fp32", "bf16"], default=None, help="N > 1: wire format of the gradient buckets (default fp32, SOD_GRAD_BUCKET_DTYPE)")
+    ap.add_argument("--collective", choices=["all_reduce", "rs_ag"], default=None, help="N > 1: shape of the gradient exchange per bucket - one all-reduce "
+                    "(default) or reduce-scatter + all-gather (SURVEY.md 8 e; SOD_GRAD_COLLECTIVE)")
+    ap.add_argument("--no-rccl-info", action="store_true", help="N > 1 / rehearsal: do not capture RCCL's INIT log (channels, rings / trees) into config.rccl_info")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-prof", type=int, default=0, help="print the N most expensive (kernel, shape) groups to stderr")
@@ -499,6 +534,13 @@ def main():
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
     from slenderobjdet_amd.utils import comm as _comm_mod
     _comm_mod.prepare_rank_env(world, rehearsal=args.rccl_rehearsal)      # nothing has touched the GPU yet: the HIP runtime reads these at start-up
+    rccl_log = None
+    if (world > 1 or args.rccl_rehearsal) and not args.no_rccl_info and "NCCL_DEBUG" not in os.environ and os.environ.get("SOD_BENCH_SHARE_GPU") != "1":
+        # RCCL's own account of what it built (channel count, rings / trees, transport): INIT-time lines only, into a file per rank -
+        # nothing is printed per collective call, so the timed loop is unaffected
+        import tempfile
+        rccl_log = os.path.join(tempfile.mkdtemp(prefix="sod_rccl_"), "rccl.%h.%p.log")
+        os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,ENV", NCCL_DEBUG_FILE=rccl_log)
     if world > 1:
         # SOD_BENCH_SHARE_GPU=1 (tests only): every rank uses cuda:0 with the gloo backend, to exercise the data-parallel
         # path on a single-GPU box; the real launch is one rank per GPU over RCCL ("nccl").
@@ -545,8 +587,8 @@ def main():
             b = model.offsets_init[1].conv.bias
             b[: 2 * model.num_points].copy_(torch.randn(2 * model.num_points, generator=torch.Generator().manual_seed(5)) * args.reppoints_offset_px)
         model.arena.bump()
-    if args.bucket_mb is not None or args.wire is not None:
-        model.arena.configure_buckets(args.bucket_mb if args.bucket_mb is not None else 32.0, args.wire)
+    if args.bucket_mb is not None or args.wire is not None or args.collective is not None:
+        model.arena.configure_buckets(args.bucket_mb if args.bucket_mb is not None else 32.0, args.wire, args.collective)
     if args.rehearsal_occupancy:
         assert rehearsal, "--rehearsal-occupancy needs --rccl-rehearsal on one GPU"
         wgs, gbps = args.rehearsal_occupancy.split(":")
@@ -724,7 +766,8 @@ def main():
             out["config"].update({
                 "backend": dist.get_backend(), "ranks_seen": dist.get_world_size(), "bucket_mb": round(ar.bucket_elems * 4 / (1 << 20), 1),
                 "n_buckets": len(ar.buckets), "bucket_mb_each": [round((e - b) * 4 / (1 << 20), 1) for b, e in ar.buckets], "grad_bytes_per_step": int(ar.total * (4 if ar.bucket_dtype == torch.float32 else 2)),
-                "wire_dtype": str(ar.bucket_dtype).replace("torch.", ""),
+                "wire_dtype": str(ar.bucket_dtype).replace("torch.", ""), "collective": ar.collective,
+                "rccl_info": rccl_info(rccl_log),
                 "exposed_comm_ms_per_step": round(sum(exposed) / len(exposed), 3) if exposed else None,
                 "exposed_comm_note": "rank 0, mean over the timed steps: compute-stream idle time between the end of backward and the end of the last bucket's all-reduce",
                 # what RCCL was told (it picks ring / tree and the channel count per call itself; NCCL_DEBUG=INFO prints its choices to stderr)

@@ -19,7 +19,7 @@ _ALIGN = 64  # elements; keeps every tensor 256-B aligned
 
 
 class ParamArena:
-    def __init__(self, model, bucket_mb=32.0, bucket_dtype=None):
+    def __init__(self, model, bucket_mb=32.0, bucket_dtype=None, collective=None):
         seen, plist = set(), []
         for name, p in model.named_parameters():
             if p.requires_grad and id(p) not in seen:
@@ -51,14 +51,14 @@ class ParamArena:
         self._plist = [p for _, p in plist]
         self.generation = 0          # bumped whenever params change behind torch's back (fused optimizer step)
         self._offs = offs
-        self.configure_buckets(bucket_mb, bucket_dtype)
+        self.configure_buckets(bucket_mb, bucket_dtype, collective)
         self._pending = None
         self._uses = {}
         self._counting = True
         self._comm_stream = None
         self._handles = []
 
-    def configure_buckets(self, bucket_mb=32.0, bucket_dtype=None):
+    def configure_buckets(self, bucket_mb=32.0, bucket_dtype=None, collective=None):
         """(Re)build the gradient buckets of the data-parallel all-reduce: contiguous runs of the gradient arena of at least ``bucket_mb``
         MB each, in backward completion order.  Call between steps only (bench.py --bucket-mb / --wire, so that a scaling curve can be swept
         without code changes).  (A smaller LAST bucket does not shorten the exposed tail - the communication stream is serial and the
@@ -87,6 +87,14 @@ class ParamArena:
         import os as _os
         bd = bucket_dtype if bucket_dtype is not None else _os.environ.get("SOD_GRAD_BUCKET_DTYPE", "fp32")
         self.bucket_dtype = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}[str(bd).replace("torch.", "")]
+        # Shape of the exchange (SURVEY.md section 8 e): "all_reduce" = one RCCL all-reduce per bucket (RCCL picks ring / tree itself);
+        # "rs_ag" = reduce-scatter into this rank's 1 / world shard of the bucket followed by an all-gather of the shards back into the
+        # bucket - the same sums on every rank (each element is reduced exactly once, by one rank, and its value distributed), two
+        # collectives RCCL can schedule over all seven xGMI links.  bench.py --collective / SOD_GRAD_COLLECTIVE sweep it on the 8-GPU node.
+        co = collective if collective is not None else getattr(self, "collective", None) or _os.environ.get("SOD_GRAD_COLLECTIVE", "all_reduce")
+        if co not in ("all_reduce", "rs_ag"):
+            raise ValueError(f"gradient collective {co!r}: expected 'all_reduce' or 'rs_ag'")
+        self.collective = co
 
     # ------------------------------------------------------------------ bf16 compute copies of every trainable conv weight
     def setup_batched_prep(self, model):
@@ -224,7 +232,7 @@ class ParamArena:
                 for aux in HF.aux_compute_streams(self.device):   # a bucket may mix parameters whose backward nodes ran on different
                     self._comm_stream.wait_stream(aux)            # streams (the FCOS box tower has its own)
                 wire = view if self.bucket_dtype == torch.float32 else view.to(self.bucket_dtype)
-                h = dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True)
+                h = self._reduce(wire)
                 occ = getattr(self, "rehearsal_occupancy", None)
                 if occ is not None:
                     # one-GPU rehearsal (bench.py --rehearsal-occupancy WGS:GBPS): a one-rank all-reduce occupies nothing; stand in for the
@@ -234,8 +242,22 @@ class ParamArena:
                     HF.call("sod_debug_occupy", int(wgs), min(usec, 100000), HF.stream_ptr(self._comm_stream))
         else:
             wire = view if self.bucket_dtype == torch.float32 else view.to(self.bucket_dtype)
-            h = dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True)
+            h = self._reduce(wire)
         self._handles.append((h, wire, view))
+
+    def _reduce(self, wire):
+        """SUM of ``wire`` over the ranks, in place, asynchronously; returns the handle to wait for."""
+        world = dist.get_world_size()
+        if self.collective == "rs_ag" and wire.numel() % world == 0:
+            n = wire.numel() // world
+            # the shard is reduced INTO its own place in the bucket: rank r's slice of ``wire`` is both an input of the reduce-scatter and
+            # its output (c10d allows the output to alias the rank's own input chunk), so no staging buffer and no copy
+            shard = wire[dist.get_rank() * n:(dist.get_rank() + 1) * n]
+            h = dist.reduce_scatter_tensor(shard, wire, op=dist.ReduceOp.SUM, async_op=True)
+            if dist.get_backend() != "nccl":
+                h.wait()          # gloo runs asynchronous work on a thread pool: nothing orders two of them; RCCL's stream does
+            return dist.all_gather_into_tensor(wire, shard, async_op=True)       # RCCL: same stream, ordered behind the reduce-scatter
+        return dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True)
 
     def finish_backward(self):
         """Launch the buckets that did not complete during backward (parameters unused this step), then wait for

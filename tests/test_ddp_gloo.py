@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _worker(rank, world, store_file, out, bucket_dtype="fp32"):
+def _worker(rank, world, store_file, out, bucket_dtype="fp32", collective="all_reduce"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world))
     # a FileStore: no TCP port to guess (bind-to-0-then-close is a race)
     dist.init_process_group("gloo", init_method="file://" + store_file, rank=rank, world_size=world)
@@ -19,7 +19,8 @@ def _worker(rank, world, store_file, out, bucket_dtype="fp32"):
 
         torch.manual_seed(0)
         model = torch.nn.Sequential(torch.nn.Linear(300, 200), torch.nn.Linear(200, 100), torch.nn.Linear(100, 50), torch.nn.Linear(50, 10))
-        arena = ParamArena(model, bucket_mb=0.01, bucket_dtype=bucket_dtype)   # several buckets
+        arena = ParamArena(model, bucket_mb=0.01, bucket_dtype=bucket_dtype, collective=collective)   # several buckets
+        assert arena.collective == collective
         assert len(arena.buckets) >= 3
         params = [p for p in model.parameters()]
         # forward "uses": last layer used twice (like the head weights shared by FPN levels)
@@ -51,6 +52,8 @@ def _worker(rank, world, store_file, out, bucket_dtype="fp32"):
             else:
                 dist.all_reduce(e)
                 ok = ok and torch.allclose(arena.grad_view(p), e, atol=1e-6)
+                if world == 2:          # a + b is one rounding whichever rank forms it: reduce-scatter + all-gather == all-reduce, bit for bit
+                    ok = ok and torch.equal(arena.grad_view(p), e)
         # replicas must hold bit-identical gradients (same reduced values on every rank), whatever the wire format
         mine = arena.grads.clone()
         other = [torch.zeros_like(mine) for _ in range(world)]
@@ -71,11 +74,13 @@ def _worker(rank, world, store_file, out, bucket_dtype="fp32"):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("collective", ["all_reduce", "rs_ag"])
 @pytest.mark.parametrize("bucket_dtype", ["fp32", "bf16"])
-def test_arena_bucketed_allreduce_world2(bucket_dtype, tmp_path):
+def test_arena_bucketed_allreduce_world2(bucket_dtype, collective, tmp_path):
+    """``collective`` = the shape of the exchange (SURVEY.md section 8 e): one all-reduce per bucket, or reduce-scatter + all-gather."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, str(tmp_path / "store"), q, bucket_dtype)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, str(tmp_path / "store"), q, bucket_dtype, collective)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

@@ -712,6 +712,66 @@ def test_relu_bit_masks_match_tensor_masks(cuda):
     assert (a != 0).any()
 
 
+# conv_pw.hip against the ORACLE directly (round-5 review: the persistent kernel had only been compared with its sibling kernel).  Shapes
+# the dispatcher routes to variant 7001: the expanding 1x1 convolutions of the bottleneck blocks (128 -> 512, 256 -> 1024), the
+# contracting 512 -> 128 of res3, at a ragged pixel count (129 x 131 = 16 899: no multiple of the 32 / 64-pixel tiles).
+PW_CASES = [(1, 129, 131, 128, 512), (1, 129, 131, 256, 1024), (1, 129, 131, 512, 128), (2, 100, 84, 512, 2048)]
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_persistent_pointwise_fwd_vs_oracle(cuda, case):
+    """Forward C -> K through conv_pw.hip (sod_conv_last_variant() == 7001) vs oracle/nn.py: plain, and with bias + shortcut + ReLU."""
+    from slenderobjdet_amd import _C
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K = case
+    x, w = _rand((N, H, W, C), 61).relu(), _rand((K, 1, 1, C), 62, C ** -0.5)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(63))
+    res = _rand((N, H, W, K), 64)
+    d = lambda t: t.to(cuda).bfloat16()
+    y = HF.conv2d_fwd(d(x), d(w), None)
+    assert int(_C.load().sod_conv_last_variant()) == 7001
+    _close(y, onn.conv2d(x, w), 2 ** -7, f"conv_pw fwd plain {case}")
+    bits = torch.zeros(N * H * W * K // 8, dtype=torch.uint8, device=cuda)
+    y = HF.conv2d_fwd(d(x), d(w), b.to(cuda), d(res), relu=True, relu_bits=bits)
+    assert int(_C.load().sod_conv_last_variant()) == 7001
+    ref = onn.conv2d(x, w, b, res=res, relu=True)
+    _close(y, ref, 2 ** -7, f"conv_pw fwd bias+res+relu {case}")
+    # the 1-bit ReLU mask against the oracle's own decision, away from the undecided band (|pre-activation| below one bf16 ulp of the scale)
+    pre = onn.conv2d(x, w, b, res=res)
+    got = ((bits.cpu().reshape(-1, 1) >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(pre.shape).bool()
+    decided = pre.abs() > 2 ** -6 * pre.abs().max()
+    assert torch.equal(got[decided], (pre > 0)[decided])
+    assert 0.2 < got.float().mean().item() < 0.8
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_persistent_pointwise_dgrad_vs_oracle(cuda, case):
+    """Data gradient of a 1x1 conv K' -> C' whose CONTRACTION width is ``C`` and whose output width is ``K`` (conv1 of a bottleneck block
+    for the expanding shapes, conv3 for 512 -> 128) through conv_pw.hip vs oracle/nn.py's autograd: plain, and accumulate + ReLU mask."""
+    from slenderobjdet_amd import _C
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K = case            # dy has C channels, dx has K channels: the forward conv was K -> C with weight (C, 1, 1, K)
+    xin = _rand((N, H, W, K), 71)
+    w = _rand((C, 1, 1, K), 72, K ** -0.5)
+    dy = _rand((N, H, W, C), 73)
+    dx_ref, _ = onn.conv2d_backward(xin, w, dy)
+    _, wt = HF.weight_prep(w.to(cuda), want_krsc=False)
+    d = lambda t: t.to(cuda).bfloat16()
+    dx = HF.conv2d_dgrad(d(dy), wt, (H, W))
+    assert int(_C.load().sod_conv_last_variant()) == 7001
+    _close(dx, dx_ref, 2 ** -7, f"conv_pw dgrad plain {case}")
+    acc, act = _rand((N, H, W, K), 74), _rand((N, H, W, K), 75)
+    bits = ((act.reshape(-1, 8) > 0).to(torch.int32) << torch.arange(8, dtype=torch.int32)).sum(1).to(torch.uint8).to(cuda)
+    dx = HF.conv2d_dgrad(d(dy), wt, (H, W), accum=d(acc), relu_bits=bits)
+    assert int(_C.load().sod_conv_last_variant()) == 7001
+    _close(dx, (dx_ref + acc) * (act > 0), 2 ** -7, f"conv_pw dgrad accum+bits {case}")
+    dx = HF.conv2d_dgrad(d(dy), wt, (H, W), relu_mask=d(act))
+    assert int(_C.load().sod_conv_last_variant()) == 7001
+    _close(dx, dx_ref * (act > 0), 2 ** -7, f"conv_pw dgrad mask tensor {case}")
+
+
 @pytest.mark.parametrize("C,K", [(128, 512), (256, 1024), (512, 2048), (512, 128), (256, 256)])
 @pytest.mark.parametrize("shape", [(2, 100, 84), (1, 129, 131)])
 def test_persistent_pointwise_kernel_is_bit_identical_to_the_tiled_kernels(cuda, C, K, shape):
