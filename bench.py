@@ -224,7 +224,7 @@ def roofline_report(prof, prof_steps, args):
     dom = max(by_k, key=lambda k: by_k[k][1])
     fl, sec, cnt, nbytes = by_k[dom]
     kname = kernel_name(*dom)
-    tr = pmc_traffic(dom[0], kname)
+    tr = pmc_traffic(dom[0], kname, args.arch)
     rep = {"bound": "mfma", "kernel": kname, "achieved": round(fl / sec / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
            "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4), "traffic": (tr or {}).get("hbm_bytes_per_launch"),
            "traffic_source": (tr or {}).get("source"),
@@ -240,19 +240,27 @@ def roofline_report(prof, prof_steps, args):
     if args.arch == "fcos":
         for gname, v in groups.items():
             rep[gname] = row(v)
-    st = pmc_step_traffic()
+    st = pmc_step_traffic(args.arch)
     if st:
         rep["step_hbm"] = st
     return rep
 
 
-def pmc_step_traffic():
+def pmc_files(arch):
+    """The committed PMC summaries of ``arch``, oldest to newest by tag: the headline's are profiles/<tag>_pmc.json (r1b < r2a < ... < r6a), the
+    other architectures' profiles/<tag>_<arch>_pmc.json (tools/profile_arch.sh)."""
+    import glob
+    import re
+
+    pat = re.compile(r"^r\d+[a-z]?_pmc\.json$" if arch == "fcos" else r"^r\d+[a-z]?_%s_pmc\.json$" % re.escape(arch))
+    return sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")) if pat.match(os.path.basename(f))), key=os.path.basename)
+
+
+def pmc_step_traffic(arch="fcos"):
     """HBM bytes of one whole training step from the newest committed PMC summary (every kernel's FETCH_SIZE x 2 + WRITE_SIZE times its
     launches, divided by the steps of that profiled run): with the step time of THAT run it gives the step-level HBM rate the verdict
     of round 4 computed by hand (2.5 TB/s = 0.40 of the achievable rate).  None if no summary is committed."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.basename)
+    files = pmc_files(arch)
     if not files:
         return None
     try:
@@ -268,16 +276,14 @@ def pmc_step_traffic():
         return None
 
 
-def pmc_traffic(kind, kernel_name_):
+def pmc_traffic(kind, kernel_name_, arch="fcos"):
     """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary (profiles/*_pmc.json: separate --pmc
     FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if absent."""
-    import glob
-
     def norm(x):
         return x.replace(";", ",").replace(" ", "").replace("void", "")
 
     # by NAME (tags are ordered: r1b < r2a < ... < r3a): modification times are all equal in a fresh checkout
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.basename)
+    files = pmc_files(arch)
     if not files:
         return None
     try:
@@ -312,29 +318,55 @@ def usable_cpus():
 
 
 def cpu_baseline(model, args):
-    """Time the CPU oracle (oracle/model.py) on a bounded sample of the same workload, host cores of this box.  SURVEY.md §8(d) asks
-    for 3 warm-up + 10 timed iterations: that is the default (``--cpu-warmup`` / ``--cpu-steps``); a 16-image CPU step takes ~20 s, so the
-    sample is bounded to ``--cpu-images`` (2) images per step - about 35 s in all - and says so in `sample`."""
-    from oracle.model import OracleFCOS
+    """Time the CPU oracle (oracle/{model,reppoints,rcnn}.py) on a bounded sample of the same workload, host cores of this box.  SURVEY.md
+    §8(d) asks for 3 warm-up + 10 timed iterations: that is the default (``--cpu-warmup`` / ``--cpu-steps``) whenever it fits; a 16-image
+    CPU step takes ~20 s, so the sample is bounded to ``--cpu-images`` (2) images per step - about 35 s in all for FCOS - and, for the
+    architectures whose oracle has Python-loop operators (DeformConv, rotated ROIAlign), to as many steps as fit ~45 s (at least 1 + 2);
+    `sample` says what was run.  The two-stage oracle takes its sampled anchors / proposals from one forward pass of the product on the
+    same images (subsampling is random; the oracle pins it, tests/test_gpu_rcnn.py): proposal selection + NMS are not in its timed step."""
     from slenderobjdet_amd.data import synthetic_batch
 
     cores = min(usable_cpus(), args.cpu_threads)   # more threads than this only adds oneDNN scheduling overhead
     torch.set_num_threads(cores)
     n = args.cpu_images
-    oracle = OracleFCOS.from_hip_model(model)
-    data = synthetic_batch(n, 800, 1333, 4321, device="cpu")
+    rotated = args.arch == "rrcnn"
+    data = synthetic_batch(n, 800, 1333, 4321, device="cpu", rotated=rotated)
+    extra, note = (), ""
+    if args.arch == "fcos":
+        from oracle.model import OracleFCOS as Oracle
+    elif args.arch == "retinanet":
+        from oracle.model import OracleRetinaNet as Oracle
+    elif args.arch == "reppoints":
+        from oracle.reppoints import OracleRepPoints as Oracle
+    else:
+        from oracle.rcnn import OracleRCNN as Oracle
+        gpu_data = [{"image": d["image"].cuda(), "instances": d["instances"].to("cuda")} for d in data]
+        with torch.no_grad():
+            model(gpu_data)
+        rpn_labels, _m, rpn_deltas = (t.cpu() for t in model.proposal_generator.last_targets)
+        props = model.roi_heads.last_proposals
+        rois = torch.cat([torch.cat((torch.full((len(p), 1), float(i)), p.proposal_boxes.tensor.cpu()), 1) for i, p in enumerate(props)])
+        extra = (rpn_labels, rpn_deltas, rois, torch.cat([p.gt_classes.cpu() for p in props]), torch.cat([p.gt_boxes.tensor.cpu() for p in props]))
+        note = " (sampled anchors / proposals taken from one product forward on the same images: proposal selection + NMS not timed)"
+    oracle = Oracle.from_hip_model(model)
 
     def step():
-        losses = oracle.losses(data)
+        losses = oracle.losses(data, *extra)
         total = sum(losses.values())
-        grads = torch.autograd.grad(total, list(oracle.trainable().values()))
-        oracle.sgd_step(dict(zip(oracle.trainable().keys(), grads)), {}, 0.01)
+        tr = oracle.trainable()
+        grads = torch.autograd.grad(total, list(tr.values()), allow_unused=True)
+        oracle.sgd_step({k: (g if g is not None else torch.zeros_like(v)) for (k, v), g in zip(tr.items(), grads)}, {}, 0.01)
 
     t0 = time.time()
-    for _ in range(args.cpu_warmup):
+    step()
+    first = time.time() - t0
+    warm, steps = args.cpu_warmup, args.cpu_steps
+    if first * (warm + steps) > 60.0:            # bound the leg: ~45 s, never fewer than 1 warm-up + 2 timed steps
+        warm, steps = 1, max(2, min(steps, int(45.0 / first) - 1))
+    for _ in range(warm - 1):
         step()
     t1 = time.time()
-    for _ in range(args.cpu_steps):
+    for _ in range(steps):
         step()
     dt = time.time() - t1
     cpu = ""
@@ -342,9 +374,9 @@ def cpu_baseline(model, args):
         cpu = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except Exception:
         pass
-    return {"value": round(n * args.cpu_steps / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic 1333x800 image(s) per step, {args.cpu_warmup} warm-up + {args.cpu_steps} timed full training steps (fwd+bwd+SGD) of the "
-                      f"fp32 CPU oracle, {dt:.1f} s timed ({time.time() - t0:.1f} s in all); host: {os.cpu_count()} logical CPUs, {cpu}"}
+    return {"value": round(n * steps / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"{n} synthetic 1333x800 image(s) per step, {warm} warm-up + {steps} timed full training steps (fwd+bwd+SGD) of the "
+                      f"fp32 CPU oracle ({Oracle.__name__}){note}, {dt:.1f} s timed ({time.time() - t0:.1f} s in all); host: {os.cpu_count()} logical CPUs, {cpu}"}
 
 
 class _StdoutToStderr:
@@ -794,7 +826,7 @@ def main():
                 a[0] += flops; a[1] += sec_; a[2] += 1
             for (kind, desc), (fl, sec, cnt) in sorted(per.items(), key=lambda kv: -kv[1][1])[:args.dump_prof]:
                 print(f"# {kind:10s} NHWCKRs={desc} calls/step {cnt // prof_steps:3d} ms/step {sec / prof_steps * 1e3:7.3f} TF/s {fl / sec / 1e12:7.1f}", file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline and args.arch == "fcos":
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, args)
         print(json.dumps(out), flush=True)
     if world > 1 or rehearsal:

@@ -21,6 +21,12 @@ def main(tag, stats_dir, fetch_dir, write_dir, steps):
     os.makedirs(out_dir, exist_ok=True)
     rows = list(csv.DictReader(open(glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))[0])))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
+    # The number of steps the TRACE holds, not the number the caller believes it asked for: the optimizer kernel runs exactly once per step
+    # (round 5's three architecture footers divided a 10-step trace by 7).  Falls back to the argument when no optimizer kernel is listed.
+    opt = [int(r["Calls"]) for r in rows if any(t in r["Name"] for t in ("sgd_kernel", "adam_kernel", "adagrad_kernel"))]
+    asked = steps
+    if opt and max(opt) != steps:
+        steps = max(opt)
     with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
         pre = "SOD_WGRAD_STREAM=0 " if tag.endswith("_serial") else ""
         post = " ; one stream, no kernel overlap: true per-kernel durations" if pre else " ; default two-stream run: backward kernels share the GPU"
@@ -30,7 +36,8 @@ def main(tag, stats_dir, fetch_dir, write_dir, steps):
         for r in rows[:40]:
             f.write("%s,%s,%.3f,%.2f,%.2f,%.2f,%s\n" % (short(r["Name"]).replace(",", ";"), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                      float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
-        f.write("# total GPU kernel time %.3f ms over %d steps = %.3f ms/step\n" % (total / 1e6, steps, total / 1e6 / steps))
+        f.write("# total GPU kernel time %.3f ms over %d steps = %.3f ms/step%s\n" % (total / 1e6, steps, total / 1e6 / steps,
+                "" if steps == asked else " (step count taken from the optimizer kernel's %d calls; the caller said %d)" % (steps, asked)))
 
     def load(d):
         agg = collections.defaultdict(lambda: [0.0, 0])
