@@ -171,6 +171,8 @@ def kernel_name(kind, code):
     if kind == "conv_wgrad":
         if code == 256:
             return "sodconv::conv_wgrad256_kernel"
+        if code == 9009:             # conv_wgrad9.hip: the nine taps of a 3x3 convolution in one workgroup
+            return "sodconv::conv_wgrad9_kernel"
         if code == 32004:            # conv_wgrad_fold.hip: taps folded into the tile rows (few output channels)
             return "sodconv::conv_wgrad_fold_kernel"
         if 1000 <= code < 3000:      # conv_wgrad_ring.hip: G*1000 + NSTAGE*100 + EPI*10 -> conv_wgrad_ring_kernel<G, NSTAGE, EPI, ABL = 0>
@@ -198,6 +200,15 @@ def algo_bytes(kind, desc):
     return act + K * R * R * C * (4.0 if kind == "conv_wgrad" else 2.0)
 
 
+def fused_bytes(kind, desc):
+    """algo_bytes + the operands of the epilogue FUSED into the launch, each once: the shortcut a bottleneck's conv3 adds, the gradient of
+    the identity path a data gradient accumulates, the ReLU mask (tensor or 1 bit per element) it applies or writes.  These bytes belong
+    to the operator the launch implements (the reference runs them as separate elementwise kernels: conv -> add -> relu), so THIS is the
+    byte count an HBM-bound launch must be priced against; `hbm_frac` (convolution operands only) is kept beside it for continuity."""
+    extra = desc[7] if desc and desc[0] != "ml" and len(desc) > 7 and not isinstance(desc[5], str) else 0
+    return algo_bytes(kind, desc) + float(extra)
+
+
 def roofline_report(prof, prof_steps, args):
     """`roofline` = the conv kernel with the most GPU time in the sampled steps (duration = hipEvent interval on its launch
     stream, algorithmic FLOPs = 2*N*Ho*Wo*K*R*S*C with UN-padded channel counts); every other kernel in `kernels`;
@@ -205,24 +216,29 @@ def roofline_report(prof, prof_steps, args):
     by_k, groups, kinds = {}, {}, {}
     for kind, flops, sec, desc, variant in prof:
         for tab, key in ((by_k, (kind, variant)), (kinds, kind), (groups, "head_convs" if desc and desc[0] == "ml" else "backbone_convs")):
-            a = tab.setdefault(key, [0.0, 0.0, 0, 0.0])
-            a[0] += flops; a[1] += sec; a[2] += 1; a[3] += algo_bytes(kind, desc)
+            a = tab.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0])
+            a[0] += flops; a[1] += sec; a[2] += 1; a[3] += algo_bytes(kind, desc); a[4] += fused_bytes(kind, desc)
 
     def row(v, name=None):
         # frac = share of the dense MFMA peak; hbm_frac = ALGORITHMIC bytes (every conv operand once) / time / the achievable HBM rate;
         # bound = the roof this group of launches sits closer to (a 1x1 convolution at frac 0.2 and hbm_frac 0.5 is an HBM-bound kernel at
         # half its roof, not an MFMA kernel at a fifth of it)
-        fl, sec, cnt, nbytes = v[:4]
-        mf, hf = fl / sec / 1e12 / MFMA_PEAK_TFLOPS, nbytes / sec / 1e9 / HBM_ACHIEVABLE_GBPS
+        fl, sec, cnt, nbytes, fbytes = v[:5]
+        mf, hf, ff = fl / sec / 1e12 / MFMA_PEAK_TFLOPS, nbytes / sec / 1e9 / HBM_ACHIEVABLE_GBPS, fbytes / sec / 1e9 / HBM_ACHIEVABLE_GBPS
         r = {"TFLOP/s": round(fl / sec / 1e12, 2), "frac": round(mf, 4), "hbm_GBps_algorithmic": round(nbytes / sec / 1e9, 1), "hbm_frac": round(hf, 4),
-             "bound": "mfma" if mf >= hf else "hbm", "ms_per_step": round(sec / prof_steps * 1e3, 3),
-             "launches_per_step": round(cnt / prof_steps, 1), "tflop_per_step": round(fl / prof_steps / 1e12, 3)}
+             "hbm_frac_fused": round(ff, 4),      # incl. the fused epilogue operands (shortcut / accumulate / mask), each once: fused_bytes()
+             "bound": "mfma" if mf >= ff else "hbm", "ms_per_step": round(sec / prof_steps * 1e3, 3),
+             "launches_per_step": round(cnt / prof_steps, 1), "tflop_per_step": round(fl / prof_steps / 1e12, 3),
+             # the floor the bytes set: time of these launches if every fused byte moved once at the achievable HBM rate, and the MFMA
+             # fraction the group would show at that floor - the distance of an HBM-bound group to north_star's 0.5 as a number
+             "byte_floor_ms_per_step": round(fbytes / prof_steps / (HBM_ACHIEVABLE_GBPS * 1e9) * 1e3, 3),
+             "frac_at_byte_floor": round(fl / (fbytes / (HBM_ACHIEVABLE_GBPS * 1e9)) / 1e12 / MFMA_PEAK_TFLOPS, 4) if fbytes else None}
         if name:
             r["kernel"] = name
         return r
 
     dom = max(by_k, key=lambda k: by_k[k][1])
-    fl, sec, cnt, nbytes = by_k[dom]
+    fl, sec, cnt, nbytes = by_k[dom][:4]
     kname = kernel_name(*dom)
     tr = pmc_traffic(dom[0], kname, args.arch)
     rep = {"bound": "mfma", "kernel": kname, "achieved": round(fl / sec / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -826,7 +842,13 @@ def main():
                 a[0] += flops; a[1] += sec_; a[2] += 1
             for (kind, desc), (fl, sec, cnt) in sorted(per.items(), key=lambda kv: -kv[1][1])[:args.dump_prof]:
                 print(f"# {kind:10s} NHWCKRs={desc} calls/step {cnt // prof_steps:3d} ms/step {sec / prof_steps * 1e3:7.3f} TF/s {fl / sec / 1e12:7.1f}", file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.arch == "rrcnn" and os.environ.get("SOD_RRCNN_CPU_BASELINE") != "1":
+            # the oracle's (rotated) ROIAlign is a Python-loop restatement of detectron2's kernel, written for parity at test sizes: at the
+            # benchmark's 2 x 512 map-sized random-init proposals ONE oracle step does not finish within gpurun's 7-minute silence limit
+            out["cpu_baseline"] = {"value": None, "unit": "img/s", "cores": min(usable_cpus(), args.cpu_threads), "kind": "port",
+                                   "sample": "not timed: the CPU oracle's ROIAlignRotated (oracle/detection.py, Python loops over bins and samples) needs "
+                                             "more than 7 minutes per step on 2 x 512 map-sized proposals; SOD_RRCNN_CPU_BASELINE=1 runs it anyway"}
+        elif world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, args)
         print(json.dumps(out), flush=True)
     if world > 1 or rehearsal:

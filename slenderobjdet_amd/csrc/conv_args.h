@@ -154,6 +154,13 @@ bool wgrad256_supported(const WgradArgs& a);
 long long wgrad256_workspace_bytes(const WgradArgs& a, int cus);
 int launch_wgrad256(WgradArgs& a, int cus, float* ws, long long ws_bytes, hipStream_t st);
 
+// conv_wgrad9.hip: 3x3 / stride 1 / pad 1 with the nine taps in ONE workgroup (128 q x 64 c x 9 taps), both operands enumerated in a padded
+// pixel order so that a tap is an LDS row offset; slabs + fixed-order reduce like the 256 kernel.
+bool wgrad9_supported(const WgradArgs& a);
+long long wgrad9_workspace_bytes(const WgradArgs& a, int cus);
+int wgrad9_tiles_per_block(const WgradArgs& a, int cus);
+int launch_wgrad9(const WgradArgs& a, int cus, float* ws, long long ws_bytes, hipStream_t st);
+
 // conv_wgrad_fold.hip: few output channels (K <= 80 for 3x3) - the taps folded into the rows of the 128 x 128 tile, X staged once for all
 // taps; stride 1, "same" geometry, float atomics (not for the deterministic mode).
 bool wgrad_fold_supported(const WgradArgs& a);

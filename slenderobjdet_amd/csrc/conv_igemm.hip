@@ -1065,6 +1065,17 @@ bool use_wgrad256(const WgradArgs& a, float* ws, long long ws_bytes) {
   return V / 64 >= nz * min_kt;
 }
 
+// The nine-tap kernel (conv_wgrad9.hip) for the 3x3 convolutions it supports.  SOD_WGRAD9: 0 = never, 1 (default) = when every block gets
+// at least `min_kt` K-tiles (prologue: ~E + 3 tile loads per level, epilogue: a 288-KB slab), 2 = every supported shape (parity tests).
+bool use_wgrad9(const WgradArgs& a, float* ws, long long ws_bytes) {
+  static const int mode = getenv("SOD_WGRAD9") ? atoi(getenv("SOD_WGRAD9")) : 1;
+  static const int min_kt = getenv("SOD_WGRAD9_MIN_KT") ? atoi(getenv("SOD_WGRAD9_MIN_KT")) : 24;
+  if (!mode || !ws || !wgrad9_supported(a)) return false;
+  const int cus = device_cus();
+  if (wgrad9_workspace_bytes(a, cus) > ws_bytes) return false;
+  return mode == 2 || wgrad9_tiles_per_block(a, cus) >= min_kt;
+}
+
 int g_wgrad_variant = -1;    // sod_conv_set_wgrad_variant
 
 // Which variant of conv_wgrad_ring.hip a weight gradient takes (0 = conv_wgrad_kernel below).
@@ -1086,8 +1097,16 @@ int launch_wgrad(WgradArgs& a, int splits, int flags, hipStream_t st, float* ws 
   a.det = (flags & WGRAD_DETERMINISTIC) ? 1 : 0;
   a.diag = (flags & WGRAD_DIAG) ? 1 : 0;
   if (a.diag && (a.C != a.K || (a.C & 127) || splits < 0)) return SOD_EARG;
-  if (splits < 0 && (!ws || !wgrad256_supported(a) || wgrad256_workspace_bytes(a, device_cus()) > ws_bytes)) return SOD_EARG;
-  if (splits < 0 || (splits == 0 && !a.diag && use_wgrad256(a, ws, ws_bytes))) {
+  // splits == -2 forces the nine-tap kernel, -1 the 256 x 256 kernel (tests, tools); 0 = the dispatcher's choice
+  if (splits == -2 && (!ws || !wgrad9_supported(a) || wgrad9_workspace_bytes(a, device_cus()) > ws_bytes)) return SOD_EARG;
+  if (splits == -2 || (splits == 0 && use_wgrad9(a, ws, ws_bytes))) {
+    const int pi = prof_begin(st);
+    const int rc = launch_wgrad9(a, device_cus(), ws, ws_bytes, st);
+    prof_end(pi, st, 9009, 1.f, 2);
+    return rc;
+  }
+  if (splits == -1 && (!ws || !wgrad256_supported(a) || wgrad256_workspace_bytes(a, device_cus()) > ws_bytes)) return SOD_EARG;
+  if (splits == -1 || (splits == 0 && !a.diag && use_wgrad256(a, ws, ws_bytes))) {
     const int pi = prof_begin(st);
     const int rc = launch_wgrad256(a, device_cus(), ws, ws_bytes, st);
     prof_end(pi, st, 256, 1.f, 2);

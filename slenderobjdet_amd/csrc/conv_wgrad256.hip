@@ -82,8 +82,16 @@ __device__ __forceinline__ void wmma_half(f32x4_t (&acc)[8][4], const bf16x8_t (
 #else
 #define SODW_BAR_B __builtin_amdgcn_s_barrier()
 #endif
+#ifndef SOD_W256_DEEP
+#define SOD_W256_DEEP 0
+#endif
+#if SOD_W256_DEEP
+#define SODW_VMWAIT "s_waitcnt vmcnt(8)"
+#else
+#define SODW_VMWAIT "s_waitcnt vmcnt(6)"
+#endif
 #define SODW_PHASE(SA, SB, BFR, PACK, STAGE)                              \
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        \
+  asm volatile(SODW_VMWAIT ::: "memory");                                 \
   __builtin_amdgcn_s_barrier();                                           \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      \
   __builtin_amdgcn_sched_barrier(0);                                      \
@@ -234,10 +242,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
 #endif
   // ---- prologue: K-tile 0 complete, first two units of K-tile 1
   rows(0);
+#if SOD_W256_DEEP
+  // deeper schedule: every unit is re-issued one phase after its last read (Xb0 / Ya0 are last read in phase 0, Xb1 in 1, Ya1 in 2), i.e.
+  // six to seven phases before its first read instead of five, and four units (64 KB) stay in flight behind every wait instead of three
+  stage_b(0, 0); stage_a(0, 0); stage_b(1, 0); stage_a(1, 0);
+  rows(1);
+  stage_b(0, 1); stage_a(0, 1); stage_b(1, 1);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+#else
   stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
   rows(1);
   stage_a(0, 1); stage_b(0, 1);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();       // wave row 1 runs one barrier behind wave row 0
 
@@ -246,6 +263,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
 #endif
   for (int k = 0; k < T; ++k) {
     const uint32_t cur = lds0 + (uint32_t)((k & 1) * WBUF);
+#if SOD_W256_DEEP
+    SODW_READ_B(cur, 0)
+    SODW_READ_A(cur, 0)
+    SODW_PHASE(0, 0, bf0, SODW_PACK_B(bf0) SODW_PACK_A, stage_a(1, k + 1))
+    SODW_READ_B(cur, 1)
+    SODW_PHASE(0, 1, bf1, SODW_PACK_B(bf1), rows(k + 2); stage_b(0, k + 2))
+    SODW_READ_A(cur, 1)
+    SODW_PHASE(1, 1, bf1, SODW_PACK_A, stage_a(0, k + 2))
+    SODW_PHASE(1, 0, bf0, , stage_b(1, k + 2))
+#else
     // phase 0: quadrant (a0, b0)
     SODW_READ_B(cur, 0)
     SODW_READ_A(cur, 0)
@@ -258,6 +285,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
     SODW_PHASE(1, 1, bf1, SODW_PACK_A, rows(k + 2); stage_a(0, k + 2))
     // phase 3: quadrant (a1, b0), b0 still in registers
     SODW_PHASE(1, 0, bf0, , stage_b(0, k + 2))
+#endif
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

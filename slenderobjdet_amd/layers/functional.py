@@ -76,6 +76,10 @@ def _prof_begin(stream=None, kind=None):
     return e
 
 
+def _nbytes(t):
+    return 0 if t is None else t.numel() * t.element_size()
+
+
 def _prof_end(kind, flops, e0, desc=None, stream=None):
     if e0 is None:
         return
@@ -149,8 +153,33 @@ def wgrad_side_streams(device):
     return list(_side_streams.get(device.index, ())) if _side_join_queued else []
 
 
+# Experiment of round 6 (SOD_HOLD_HEAD_WGRAD=1, off by default): the head towers' weight gradients (MFMA-bound 256x256 kernels) are not
+# launched beside the towers' data gradients (MFMA-bound too) but HELD and released when the FPN backward starts, so that they run beside
+# the HBM-bound backbone kernels instead - re-pairing the backward phases by roof (round-5 review).  Measurement: profiles/r6_pairing.txt.
+HOLD_HEAD_WGRAD = os.environ.get("SOD_HOLD_HEAD_WGRAD", "0") == "1"
+_held = []
+
+
+def hold_or_call(fn):
+    """Tower units: run ``fn`` (weight-gradient launch + mark_ready) now, or park it until release_held()."""
+    if HOLD_HEAD_WGRAD:
+        _held.append(fn)
+    else:
+        fn()
+
+
+def release_held():
+    """First FPN / backbone backward node (and the end-of-backward join, for safety): issue every parked launch, in order."""
+    if _held:
+        items = list(_held)
+        _held.clear()
+        for fn in items:
+            fn()
+
+
 def _wgrad_join():
     global _side_join_queued
+    release_held()
     _side_join_queued = False
     for idx, sides in _side_streams.items():
         main = torch.cuda.current_stream(idx)
@@ -315,7 +344,9 @@ def conv2d_fwd(x, w, bias=None, res=None, stride=1, pad=0, dil=1, relu=False, re
         call("sod_conv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
              x_img_stride, y_img_stride, 0, flags, 1 if out_f32 else 0, stream_ptr())
     # c_real / k_real: un-padded channel counts, so that the profile counts ALGORITHMIC work (stem: 3 of its 8 input channels)
-    _prof_end("conv_fwd", 2.0 * N * Ho * Wo * K * R * S * (c_real or (Cw if cwin else C)), e0, (N, H, W, C, K, R, stride))
+    # 8th entry: bytes of the FUSED epilogue operands this launch also moves (shortcut read, 1-bit mask written) - bench.py hbm_frac_fused
+    _prof_end("conv_fwd", 2.0 * N * Ho * Wo * K * R * S * (c_real or (Cw if cwin else C)), e0,
+              (N, H, W, C, K, R, stride, _nbytes(res) + _nbytes(relu_bits)))
     if relu and RELU_TAP is not None and not x_img_stride and not y_img_stride:
         RELU_TAP("conv", w.data_ptr(), out)
     return out
@@ -363,7 +394,8 @@ def conv2d_dgrad(dy, wt, x_hw, stride=1, pad=0, dil=1, accum=None, relu_mask=Non
         call("sod_conv2d_dgrad", ptr(dy), ptr(wt), ptr(accum), ptr(relu_mask), ptr(out), N, H, W, C, K, R, S, stride, pad, dil,
              dy_img_stride, 0, stream_ptr())
     Ho, Wo = conv_out_size(H, W, R, S, stride, pad, dil)
-    _prof_end("conv_dgrad", 2.0 * N * Ho * Wo * K * R * S * C, e0, (N, H, W, C, K, R, stride))
+    _prof_end("conv_dgrad", 2.0 * N * Ho * Wo * K * R * S * C, e0,
+              (N, H, W, C, K, R, stride, _nbytes(accum) + _nbytes(relu_mask) + _nbytes(relu_bits)))
     return out
 
 

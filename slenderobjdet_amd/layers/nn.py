@@ -336,6 +336,7 @@ class _ConvFn(torch.autograd.Function):
         g = HF.relu_bwd(dy, y) if (mod.relu and not mod.grad_premasked) else dy
         arena = _arena_of(mod)
         N, H, W, C = x.shape
+        HF.release_held()               # weight gradients the head towers parked (SOD_HOLD_HEAD_WGRAD=1; nothing otherwise)
         if mod.weight.requires_grad:
             with HF.wgrad_batch():      # weight + bias gradient: one hand-over to the side stream
                 if getattr(mod, "groups", 1) > 1:
@@ -495,8 +496,10 @@ class _ConvGnReluFn(torch.autograd.Function):
         arena.mark_ready(gn.bias)
         if conv.bias is not None:
             arena.mark_ready(conv.bias)
-        HF.conv2d_wgrad_ml(dy1s, list(xs), arena.grad_view(conv.weight), k, k, conv.stride, conv.padding, conv.dilation)
-        arena.mark_ready(conv.weight)
+        def wgrad():
+            HF.conv2d_wgrad_ml(dy1s, list(xs), arena.grad_view(conv.weight), k, k, conv.stride, conv.padding, conv.dilation)
+            arena.mark_ready(conv.weight)
+        HF.hold_or_call(wgrad)          # (SOD_HOLD_HEAD_WGRAD=1: parked until the FPN backward starts; default: launched here)
         dxs = [None] * nl
         if any(ctx.needs_input_grad[3:]):
             fold, ctx.fold = ctx.fold, None
