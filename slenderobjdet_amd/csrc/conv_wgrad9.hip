@@ -36,7 +36,7 @@ constexpr int G9_XROWB = 128, G9_YROWB = 256;
 constexpr int G9_NXC = 10, G9_RX = 64 * G9_NXC;   // X ring: ten 64-row chunks
 constexpr int G9_XBYTES = (G9_RX + 64) * G9_XROWB;          // + mirror of chunk slot 0: 90 112 B
 constexpr int G9_YTILE = 64 * G9_YROWB;           // 16 KB
-constexpr int G9_LDS = G9_XBYTES + 4 * G9_YTILE;  // 155 648 B
+constexpr int G9_LDS = G9_XBYTES + 4 * G9_YTILE;  // 155 648 B (+ 1 KB offset table behind it)
 constexpr int G9_SLAB = 128 * 64 * 9;             // floats per partial tile
 
 template <int OFF_LO, int OFF_HI>
@@ -165,25 +165,50 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(const W9Args a) {
       stage_x(E + d, xslot); xslot = (xslot + 1 == G9_NXC) ? 0 : xslot + 1;
       stage_y(d);
     }
+    // The loop is bound by instruction ISSUE, not by the matrix pipe alone: an MFMA 16x16x32 leaves the SIMD two vector-issue slots, and
+    // the two waves of a SIMD share them - 288 slots per K-tile for 104 transposed reads and everything else.  So what a K-tile needs besides
+    // its MFMAs and reads is (a) kept small and (b) placed behind the MFMAs of the 18 steps, one tile AHEAD:
+    //   * the nine B addresses of the next tile: steps 0 - 8, five instructions each;
+    //   * the source offsets of the three LDS-DMA requests of the next tile (two divisions per staged row): ONE wave per tile (wave t mod 8)
+    //     works them out for all 64 + 64 rows, a lane per row, and leaves them in a 1-KB table in LDS (steps 9 - 14); after the next
+    //     tile's barrier every lane picks up its three rows' offsets and adds its chunk.
+    const uint32_t hwp_mul = g.div_hwp.mul, hwp_shr = g.div_hwp.shr, wp_mul = g.div_wp.mul, wp_shr = g.div_wp.shr;
+    const uint32_t Npad = (uint32_t)g.Npad, xis = (uint32_t)g.x_img_stride, yis = (uint32_t)g.dy_img_stride, aC = (uint32_t)a.C, aK = (uint32_t)a.K;
+#define G9_PIX1(J, N_, REM, INR) { const uint32_t j_ = (uint32_t)(J); INR = j_ < Npad; N_ = (__umulhi(j_, hwp_mul) + j_) >> hwp_shr; REM = j_ - N_ * (uint32_t)HWp; }
+#define G9_PIX2(REM, HW, OK) { const uint32_t hp_ = (__umulhi(REM, wp_mul) + REM) >> wp_shr; const uint32_t wq_ = REM - hp_ * (uint32_t)Wp; \
+                               HW = (hp_ - 1u) * (uint32_t)W + wq_; OK = OK && hp_ != 0u && wq_ < (uint32_t)W; }
+#define G9_PIX3(TAB, N_, HW, OK, IS, CH) { const uint32_t v_ = OK ? (N_ * (IS) + HW * (CH)) * 2u : SOD_OOB;                                \
+                                           asm volatile("ds_write_b32 %0, %1" :: "v"((uint32_t)(uintptr_t)SOD_LDS(TAB)), "v"(v_) : "memory"); }
+    uint32_t* const tab = reinterpret_cast<uint32_t*>(smem + G9_LDS);      // [2][128]: X rows 0..63, dY rows 0..63 of the group to request
+    uint32_t pn, prem, phw; bool pok;
+    if (wave == 0) {       // the group the first iteration requests: G(D) = X chunk D + E, dY tile D
+      G9_PIX1(j0 + 64 * (G9_D + E) + lane - sh0, pn, prem, pok) G9_PIX2(prem, phw, pok) G9_PIX3(tab + lane, pn, phw, pok, xis, aC)
+      G9_PIX1(j0 + 64 * G9_D + lane, pn, prem, pok) pok = pok && G9_D < T; G9_PIX2(prem, phw, pok) G9_PIX3(tab + 64 + lane, pn, phw, pok, yis, aK)
+    }
+#define G9_BADDR(DST, XB, TAP) { int sbt_ = (XB) + sh[TAP]; if (sbt_ >= G9_RX) sbt_ -= G9_RX; const uint32_t row_ = (uint32_t)sbt_ + (uint32_t)il; \
+                                 DST = ((row_ << 7) | ((row_ << 4) & 0x60u)) ^ bxor; }
+    uint32_t baddr[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) G9_BADDR(baddr[tap], 0, tap)
     int xb = 0;                            // (64 t) mod 640: ring row of the stream index 64 t
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (wave 0's table entries are in LDS before it reaches the barrier)
 
     for (int t = 0; t < T; ++t) {
       // everything K-tile t reads was requested G9_D iterations ago: at most the 3 (D - 1) younger requests may still be in flight
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      stage_x(t + G9_D + E, xslot); xslot = (xslot + 1 == G9_NXC) ? 0 : xslot + 1;
-      stage_y(t + G9_D);
-
-      // ---- fragment addresses of this K-tile
+      const uint32_t* tb = tab + (t & 1) * 128;
+      uint32_t ox, oy0, oy1;
+      asm volatile("ds_read_b32 %0, %1" : "=v"(ox) : "v"((uint32_t)(uintptr_t)SOD_LDS(tb + x_row)));
+      asm volatile("ds_read_b32 %0, %1" : "=v"(oy0) : "v"((uint32_t)(uintptr_t)SOD_LDS(tb + 64 + y_row0)));
+      asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(oy1) : "v"((uint32_t)(uintptr_t)SOD_LDS(tb + 64 + y_row0)));
       const uint32_t ybase = (uint32_t)((t & 3) * G9_YTILE);
-      uint32_t baddr[9];
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        int sbt = xb + sh[tap]; if (sbt >= G9_RX) sbt -= G9_RX;              // scalar
-        const uint32_t row = (uint32_t)sbt + (uint32_t)il;
-        baddr[tap] = ((row << 7) | ((row << 4) & 0x60u)) ^ bxor;
-      }
-      xb += 64; if (xb >= G9_RX) xb -= G9_RX;
+      xb += 64; if (xb >= G9_RX) xb -= G9_RX;          // now the ring row of the NEXT tile's stream index
+      const int jn = j0 + 64 * (t + 1);                // first position of the next tile
+      const bool ylive = t + 1 + G9_D < T;
+      const bool mine = (wave == ((t + 1) & 7));       // this wave fills the table of the next iteration (wave-uniform)
+      uint32_t* const tn = tab + ((t + 1) & 1) * 128 + lane;
+      uint32_t bnext[9];
 
       bf16x8_t af0[4], af1[4], b0, b1, b2;
 #pragma unroll
@@ -191,36 +216,55 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(const W9Args a) {
       b0 = tr_read2<0, 2048>(baddr[0]);
       b1 = tr_read2<0, 2048>(baddr[1]);
 
-#define G9_MMA(AF, B, TAP)                                                                                         \
+      // one step: [request the B fragment of step s + 2] [wait for this step's] [4 MFMAs] [a piece of next tile's bookkeeping]
+#define G9_MMA(AF, B, TAP, WORK)                                                                                   \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
-      acc[i][TAP] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i], B, acc[i][TAP], 0, 0, 0);
-      // 18 steps (tap, K-step); the B fragment of step s + 2 is requested before the MFMAs of step s, the A fragments of the second
-      // K-step at step 4.  lgkmcnt counts ds instructions (two per fragment): the numbers are the requests YOUNGER than the one needed.
+      acc[i][TAP] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i], B, acc[i][TAP], 0, 0, 0);                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                               \
+  WORK                                                                                                             \
+  __builtin_amdgcn_sched_barrier(0);
+      // lgkmcnt counts ds instructions (two per fragment): the numbers are the requests YOUNGER than the one needed.
       __builtin_amdgcn_s_setprio(1);
-      b2 = tr_read2<0, 2048>(baddr[2]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b0, 0)
-      b0 = tr_read2<0, 2048>(baddr[3]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b1, 1)
-      b1 = tr_read2<0, 2048>(baddr[4]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b2, 2)
-      b2 = tr_read2<0, 2048>(baddr[5]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b0, 3)
+      b2 = tr_read2<0, 2048>(baddr[2]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b0, 0, G9_BADDR(bnext[0], xb, 0))
+      {   // X chunk t + D + E and dY tile t + D (the table reads above are older than b0: they have landed)
+        char* xd = smem + (xslot * 64 + wave * 8) * G9_XROWB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(xd), 16, ox + x_cadd, 0, 0, 0);
+        if (xslot == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(xd + G9_RX * G9_XROWB), 16, ox + x_cadd, 0, 0, 0);   // the mirror rows
+        xslot = (xslot + 1 == G9_NXC) ? 0 : xslot + 1;
+        char* yd = smem + G9_XBYTES + ((t + G9_D) & 3) * G9_YTILE + wave * 4 * G9_YROWB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(yd), 16, oy0 + y_qadd, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(yd + 32 * G9_YROWB), 16, oy1 + y_qadd, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      b0 = tr_read2<0, 2048>(baddr[3]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b1, 1, G9_BADDR(bnext[1], xb, 1))
+      b1 = tr_read2<0, 2048>(baddr[4]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b2, 2, G9_BADDR(bnext[2], xb, 2))
+      b2 = tr_read2<0, 2048>(baddr[5]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b0, 3, G9_BADDR(bnext[3], xb, 3))
       b0 = tr_read2<0, 2048>(baddr[6]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) af1[i] = tr_read2<8192, 8192 + 4096>(ybase + aoff[i]);
-                                              G9_WAIT_LGKM(12); G9_MMA(af0, b1, 4)
-      b1 = tr_read2<0, 2048>(baddr[7]);       G9_WAIT_LGKM(12); G9_MMA(af0, b2, 5)
-      b2 = tr_read2<0, 2048>(baddr[8]);       G9_WAIT_LGKM(12); G9_MMA(af0, b0, 6)
-      b0 = tr_read2<4096, 6144>(baddr[0]);    G9_WAIT_LGKM(4);  G9_MMA(af0, b1, 7)
-      b1 = tr_read2<4096, 6144>(baddr[1]);    G9_WAIT_LGKM(4);  G9_MMA(af0, b2, 8)
-      b2 = tr_read2<4096, 6144>(baddr[2]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b0, 0)
-      b0 = tr_read2<4096, 6144>(baddr[3]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b1, 1)
-      b1 = tr_read2<4096, 6144>(baddr[4]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b2, 2)
-      b2 = tr_read2<4096, 6144>(baddr[5]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b0, 3)
-      b0 = tr_read2<4096, 6144>(baddr[6]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b1, 4)
-      b1 = tr_read2<4096, 6144>(baddr[7]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b2, 5)
-      b2 = tr_read2<4096, 6144>(baddr[8]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b0, 6)
-                                              G9_WAIT_LGKM(2);  G9_MMA(af1, b1, 7)
-                                              G9_WAIT_LGKM(0);  G9_MMA(af1, b2, 8)
+                                              G9_WAIT_LGKM(12); G9_MMA(af0, b1, 4, G9_BADDR(bnext[4], xb, 4))
+      b1 = tr_read2<0, 2048>(baddr[7]);       G9_WAIT_LGKM(12); G9_MMA(af0, b2, 5, G9_BADDR(bnext[5], xb, 5))
+      b2 = tr_read2<0, 2048>(baddr[8]);       G9_WAIT_LGKM(12); G9_MMA(af0, b0, 6, G9_BADDR(bnext[6], xb, 6))
+      b0 = tr_read2<4096, 6144>(baddr[0]);    G9_WAIT_LGKM(4);  G9_MMA(af0, b1, 7, G9_BADDR(bnext[7], xb, 7))
+      b1 = tr_read2<4096, 6144>(baddr[1]);    G9_WAIT_LGKM(4);  G9_MMA(af0, b2, 8, G9_BADDR(bnext[8], xb, 8))
+      b2 = tr_read2<4096, 6144>(baddr[2]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b0, 0, if (mine) G9_PIX1(jn + 64 * (G9_D + E) + lane - sh0, pn, prem, pok))
+      b0 = tr_read2<4096, 6144>(baddr[3]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b1, 1, if (mine) G9_PIX2(prem, phw, pok))
+      b1 = tr_read2<4096, 6144>(baddr[4]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b2, 2, if (mine) G9_PIX3(tn, pn, phw, pok, xis, aC))
+      b2 = tr_read2<4096, 6144>(baddr[5]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b0, 3, if (mine) { G9_PIX1(jn + 64 * G9_D + lane, pn, prem, pok) pok = pok && ylive; })
+      b0 = tr_read2<4096, 6144>(baddr[6]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b1, 4, if (mine) G9_PIX2(prem, phw, pok))
+      b1 = tr_read2<4096, 6144>(baddr[7]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b2, 5, if (mine) G9_PIX3(tn + 64, pn, phw, pok, yis, aK))
+      b2 = tr_read2<4096, 6144>(baddr[8]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b0, 6, )
+                                              G9_WAIT_LGKM(2);  G9_MMA(af1, b1, 7, )
+                                              G9_WAIT_LGKM(0);  G9_MMA(af1, b2, 8, )
       __builtin_amdgcn_s_setprio(0);
 #undef G9_MMA
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) baddr[tap] = bnext[tap];
     }
+#undef G9_PIX1
+#undef G9_PIX2
+#undef G9_PIX3
+#undef G9_BADDR
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dead prefetches behind the segment's last K-tile
     __builtin_amdgcn_s_barrier();                          // every wave is done with the rings before the next level refills them
   }
@@ -300,7 +344,7 @@ bool wgrad9_supported(const WgradArgs& a) {
     if (np >= (1ll << 30)) return false;
     tot += np;
   }
-  return tot >= 64 && tot < (1ll << 30);
+  return tot >= 1 && tot < (1ll << 30);
 }
 
 static int w9_splits(const W9Args& w, int cus, int* per_out) {
@@ -343,11 +387,11 @@ int launch_wgrad9(const WgradArgs& a, int cus, float* ws, long long ws_bytes, hi
   w.partial = ws;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G9_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G9_LDS + 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  SOD_LAUNCH(conv_wgrad9_kernel, dim3(w.nz * tiles), dim3(512), G9_LDS, st, w);
+  SOD_LAUNCH(conv_wgrad9_kernel, dim3(w.nz * tiles), dim3(512), G9_LDS + 1024, st, w);
   SOD_LAUNCH(wgrad9_reduce_kernel, dim3(tiles * 72), dim3(256), 0, st, w);
   SOD_CHECK_LAUNCH();
   return SOD_OK;

@@ -335,6 +335,82 @@ def test_conv_wgrad256_multilevel(cuda):
     _close(dw, ref, 2e-4, "wgrad256 multi-level")
 
 
+# the nine-taps-in-one-workgroup weight gradient (conv_wgrad9.hip), forced with splits = -2: (N, H, W, C, K)  [3x3, stride 1, pad 1]
+WGRAD9_CASES = [
+    (2, 40, 72, 256, 256),      # several K-tiles per block, rows longer than a K-tile, two images
+    (2, 13, 21, 256, 256),      # rows shorter than a K-tile: several row / image wraps inside every tile
+    (1, 3, 5, 128, 128),        # one tile, mostly padding: a single q-tile, two c-tiles
+    (3, 25, 42, 512, 512),      # res5 conv2 geometry: 32 tiles, few K-tiles per block
+    (2, 50, 84, 256, 256),      # res4 conv2 / P4 geometry
+    (1, 100, 168, 128, 128),    # res3 conv2 geometry: the widest rows of the step (W = 168: seven X chunks of reach)
+    (2, 7, 190, 64, 128),       # the widest supported row, one c-tile
+    (5, 6, 7, 192, 384),        # C = 3 x 64, K = 3 x 128
+]
+
+
+@pytest.mark.parametrize("case", WGRAD9_CASES)
+def test_conv_wgrad9(cuda, case):
+    """conv_wgrad9.hip vs oracle/nn.py's autograd (F.conv2d backward, fp32): the padded pixel order (zero rows / columns instead of
+    border masks), the X ring and its mirror rows, accumulate semantics, the fixed summation order and the FrozenBN scale."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W, C, K = case
+    x = _rand((N, H, W, C), 1)
+    w = torch.zeros((K, 3, 3, C))
+    dy = _rand((N, H, W, K), 3)
+    _, dw_ref = onn.conv2d_backward(x, w, dy, 1, 1, 1)
+    qs = torch.rand(K, generator=torch.Generator().manual_seed(5)) + 0.5
+    dyd, xd = dy.to(cuda).bfloat16(), x.to(cuda).bfloat16()
+    dw = torch.zeros((K, 3, 3, C), dtype=torch.float32, device=cuda)
+    HF.conv2d_wgrad(dyd, xd, dw, 3, 3, 1, 1, 1, splits=-2)
+    _close(dw, dw_ref, 2e-4, f"wgrad9 {case}")
+    first = dw.clone()
+    HF.conv2d_wgrad(dyd, xd, dw, 3, 3, 1, 1, 1, splits=-2)      # accumulation semantics
+    _close(dw, 2 * dw_ref, 2e-4, f"wgrad9 accumulate {case}")
+    dw2 = torch.zeros_like(dw)
+    HF.conv2d_wgrad(dyd, xd, dw2, 3, 3, 1, 1, 1, splits=-2)     # fixed summation order: bit-identical from run to run
+    assert torch.equal(dw2, first)
+    dw3 = torch.zeros_like(dw)
+    HF.conv2d_wgrad(dyd, xd, dw3, 3, 3, 1, 1, 1, splits=-2, qscale=qs.to(cuda))
+    _close(dw3, dw_ref * qs.view(-1, 1, 1, 1), 2e-4, f"wgrad9 qscale {case}")
+    # every tap separately against the 128 x 128 kernel (an error confined to one tap's shift would hide in the max-norm above)
+    dw4 = torch.zeros_like(dw)
+    HF.conv2d_wgrad(dyd, xd, dw4, 3, 3, 1, 1, 1, splits=1)
+    for r in range(3):
+        for s_ in range(3):
+            _close(first[:, r, s_], dw4[:, r, s_].cpu(), 2e-4, f"wgrad9 tap ({r},{s_}) {case}")
+
+
+def test_conv_wgrad9_multilevel(cuda):
+    """One launch over the five FPN levels of the head towers (scaled down): blocks whose K-tile range crosses a level boundary restart
+    their rings; the levels' row lengths differ (reach of 1 - 3 X chunks)."""
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, C, K = 2, 256, 256
+    hws = [(25, 42), (13, 21), (7, 11), (4, 6), (2, 3)]
+    xs = [_rand((N, h, w, C), 10 + i) for i, (h, w) in enumerate(hws)]
+    dys = [_rand((N, h, w, K), 20 + i) for i, (h, w) in enumerate(hws)]
+    wz = torch.zeros((K, 3, 3, C))
+    ref = sum(onn.conv2d_backward(x, wz, dy, 1, 1, 1)[1] for x, dy in zip(xs, dys))
+    dw = torch.zeros((K, 3, 3, C), dtype=torch.float32, device=cuda)
+    HF.conv2d_wgrad_ml([d.to(cuda).bfloat16() for d in dys], [x.to(cuda).bfloat16() for x in xs], dw, 3, 3, 1, 1, 1, splits=-2)
+    _close(dw, ref, 2e-4, "wgrad9 multi-level")
+
+
+def test_conv_wgrad9_rejects_unsupported(cuda):
+    from slenderobjdet_amd import _C
+    from slenderobjdet_amd.layers import functional as HF
+
+    x = torch.zeros((1, 8, 200, 128), dtype=torch.bfloat16, device=cuda)      # W = 200: beyond the X ring's reach
+    dw = torch.zeros((128, 3, 3, 128), dtype=torch.float32, device=cuda)
+    with pytest.raises(_C.SlenderHipError):
+        HF.conv2d_wgrad(x, x, dw, 3, 3, 1, 1, 1, splits=-2)
+    x = torch.zeros((1, 8, 8, 128), dtype=torch.bfloat16, device=cuda)        # 1x1: not a 3x3
+    dw = torch.zeros((128, 1, 1, 128), dtype=torch.float32, device=cuda)
+    with pytest.raises(_C.SlenderHipError):
+        HF.conv2d_wgrad(x, x, dw, 1, 1, 1, 0, 1, splits=-2)
+
+
 def test_conv_wgrad256_rejects_unsupported(cuda):
     from slenderobjdet_amd import _C
     from slenderobjdet_amd.layers import functional as HF
