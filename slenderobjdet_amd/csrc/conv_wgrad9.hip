@@ -203,12 +203,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(const W9Args a) {
       asm volatile("ds_read_b32 %0, %1" : "=v"(oy0) : "v"((uint32_t)(uintptr_t)SOD_LDS(tb + 64 + y_row0)));
       asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(oy1) : "v"((uint32_t)(uintptr_t)SOD_LDS(tb + 64 + y_row0)));
       const uint32_t ybase = (uint32_t)((t & 3) * G9_YTILE);
+      const int xb_prev = xb;
       xb += 64; if (xb >= G9_RX) xb -= G9_RX;          // now the ring row of the NEXT tile's stream index
       const int jn = j0 + 64 * (t + 1);                // first position of the next tile
       const bool ylive = t + 1 + G9_D < T;
       const bool mine = (wave == ((t + 1) & 7));       // this wave fills the table of the next iteration (wave-uniform)
       uint32_t* const tn = tab + ((t + 1) & 1) * 128 + lane;
-      uint32_t bnext[9];
+      // the next tile's B addresses are this tile's + 64 rows (a multiple of 8 rows: the swizzle bits stay), minus the ring where the
+      // tap's window start wraps - a scalar per tap
+      int binc[9];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        int s0_ = xb_prev + sh[tap]; if (s0_ >= G9_RX) s0_ -= G9_RX;
+        binc[tap] = (s0_ + 64 >= G9_RX) ? (64 - G9_RX) * G9_XROWB : 64 * G9_XROWB;
+      }
 
       bf16x8_t af0[4], af1[4], b0, b1, b2;
 #pragma unroll
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(const W9Args a) {
   __builtin_amdgcn_sched_barrier(0);
       // lgkmcnt counts ds instructions (two per fragment): the numbers are the requests YOUNGER than the one needed.
       __builtin_amdgcn_s_setprio(1);
-      b2 = tr_read2<0, 2048>(baddr[2]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b0, 0, G9_BADDR(bnext[0], xb, 0))
+      b2 = tr_read2<0, 2048>(baddr[2]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b0, 0, if (mine) G9_PIX1(jn + 64 * (G9_D + E) + lane - sh0, pn, prem, pok))
       {   // X chunk t + D + E and dY tile t + D (the table reads above are older than b0: they have landed)
         char* xd = smem + (xslot * 64 + wave * 8) * G9_XROWB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(xd), 16, ox + x_cadd, 0, 0, 0);
@@ -236,30 +244,28 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(const W9Args a) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(yd + 32 * G9_YROWB), 16, oy1 + y_qadd, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      b0 = tr_read2<0, 2048>(baddr[3]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b1, 1, G9_BADDR(bnext[1], xb, 1))
-      b1 = tr_read2<0, 2048>(baddr[4]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b2, 2, G9_BADDR(bnext[2], xb, 2))
-      b2 = tr_read2<0, 2048>(baddr[5]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b0, 3, G9_BADDR(bnext[3], xb, 3))
+      b0 = tr_read2<0, 2048>(baddr[3]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b1, 1, if (mine) G9_PIX2(prem, phw, pok))
+      b1 = tr_read2<0, 2048>(baddr[4]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b2, 2, if (mine) G9_PIX3(tn, pn, phw, pok, xis, aC))
+      b2 = tr_read2<0, 2048>(baddr[5]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b0, 3, if (mine) { G9_PIX1(jn + 64 * G9_D + lane, pn, prem, pok) pok = pok && ylive; })
       b0 = tr_read2<0, 2048>(baddr[6]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) af1[i] = tr_read2<8192, 8192 + 4096>(ybase + aoff[i]);
-                                              G9_WAIT_LGKM(12); G9_MMA(af0, b1, 4, G9_BADDR(bnext[4], xb, 4))
-      b1 = tr_read2<0, 2048>(baddr[7]);       G9_WAIT_LGKM(12); G9_MMA(af0, b2, 5, G9_BADDR(bnext[5], xb, 5))
-      b2 = tr_read2<0, 2048>(baddr[8]);       G9_WAIT_LGKM(12); G9_MMA(af0, b0, 6, G9_BADDR(bnext[6], xb, 6))
-      b0 = tr_read2<4096, 6144>(baddr[0]);    G9_WAIT_LGKM(4);  G9_MMA(af0, b1, 7, G9_BADDR(bnext[7], xb, 7))
-      b1 = tr_read2<4096, 6144>(baddr[1]);    G9_WAIT_LGKM(4);  G9_MMA(af0, b2, 8, G9_BADDR(bnext[8], xb, 8))
-      b2 = tr_read2<4096, 6144>(baddr[2]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b0, 0, if (mine) G9_PIX1(jn + 64 * (G9_D + E) + lane - sh0, pn, prem, pok))
-      b0 = tr_read2<4096, 6144>(baddr[3]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b1, 1, if (mine) G9_PIX2(prem, phw, pok))
-      b1 = tr_read2<4096, 6144>(baddr[4]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b2, 2, if (mine) G9_PIX3(tn, pn, phw, pok, xis, aC))
-      b2 = tr_read2<4096, 6144>(baddr[5]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b0, 3, if (mine) { G9_PIX1(jn + 64 * G9_D + lane, pn, prem, pok) pok = pok && ylive; })
-      b0 = tr_read2<4096, 6144>(baddr[6]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b1, 4, if (mine) G9_PIX2(prem, phw, pok))
-      b1 = tr_read2<4096, 6144>(baddr[7]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b2, 5, if (mine) G9_PIX3(tn + 64, pn, phw, pok, yis, aK))
-      b2 = tr_read2<4096, 6144>(baddr[8]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b0, 6, )
-                                              G9_WAIT_LGKM(2);  G9_MMA(af1, b1, 7, )
-                                              G9_WAIT_LGKM(0);  G9_MMA(af1, b2, 8, )
+                                              G9_WAIT_LGKM(12); G9_MMA(af0, b1, 4, if (mine) G9_PIX2(prem, phw, pok))
+      b1 = tr_read2<0, 2048>(baddr[7]);       G9_WAIT_LGKM(12); G9_MMA(af0, b2, 5, if (mine) G9_PIX3(tn + 64, pn, phw, pok, yis, aK))
+      b2 = tr_read2<0, 2048>(baddr[8]);       G9_WAIT_LGKM(12); G9_MMA(af0, b0, 6, )
+      b0 = tr_read2<4096, 6144>(baddr[0]);    G9_WAIT_LGKM(4);  G9_MMA(af0, b1, 7, )
+      b1 = tr_read2<4096, 6144>(baddr[1]);    G9_WAIT_LGKM(4);  G9_MMA(af0, b2, 8, )
+      b2 = tr_read2<4096, 6144>(baddr[2]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b0, 0, baddr[0] += (uint32_t)binc[0];)
+      b0 = tr_read2<4096, 6144>(baddr[3]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b1, 1, baddr[1] += (uint32_t)binc[1];)
+      b1 = tr_read2<4096, 6144>(baddr[4]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b2, 2, baddr[2] += (uint32_t)binc[2];)
+      b2 = tr_read2<4096, 6144>(baddr[5]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b0, 3, baddr[3] += (uint32_t)binc[3];)
+      b0 = tr_read2<4096, 6144>(baddr[6]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b1, 4, baddr[4] += (uint32_t)binc[4];)
+      b1 = tr_read2<4096, 6144>(baddr[7]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b2, 5, baddr[5] += (uint32_t)binc[5];)
+      b2 = tr_read2<4096, 6144>(baddr[8]);    G9_WAIT_LGKM(4);  G9_MMA(af1, b0, 6, baddr[6] += (uint32_t)binc[6];)
+                                              G9_WAIT_LGKM(2);  G9_MMA(af1, b1, 7, baddr[7] += (uint32_t)binc[7];)
+                                              G9_WAIT_LGKM(0);  G9_MMA(af1, b2, 8, baddr[8] += (uint32_t)binc[8];)
       __builtin_amdgcn_s_setprio(0);
 #undef G9_MMA
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) baddr[tap] = bnext[tap];
     }
 #undef G9_PIX1
 #undef G9_PIX2
