@@ -51,16 +51,11 @@ __device__ __forceinline__ void mma_half(f32x4_t (&acc)[8][4], const bf16x8_t (&
 // One phase after its ds_reads: retire the unit issued four phases ago, meet the other wave row, then 16 MFMAs with this phase's
 // unit (two LDS-DMA pieces) issued inside the cluster, where the MFMA pipe hides their issue cost (measured on the FCOS head:
 // +2 % over issuing them in the load segment; s_setprio around the cluster +5 %).
-#ifndef SOD_C256_DEEP
-#define SOD_C256_DEEP 0
-#endif
-#if SOD_C256_DEEP
-#define SOD256_VMWAIT "s_waitcnt vmcnt(8)"
-#else
-#define SOD256_VMWAIT "s_waitcnt vmcnt(6)"
-#endif
+// (Round 6 measured a deeper schedule - every unit re-requested one phase after its last read, four units in flight behind vmcnt(8) -
+// on the tower shape: forward 352.1 vs 352.8 us, data gradient 355.5 vs 356.8 us per launch, results bit-identical: no gain, not kept.
+// The same change is worth 2.7 % on conv_wgrad256.hip, which stages twice the bytes per MFMA.)
 #define SOD256_PHASE(SA, SB, BFR, STAGE)                                  \
-  asm volatile(SOD256_VMWAIT ::: "memory");                               \
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        \
   __builtin_amdgcn_s_barrier();                                           \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      \
   __builtin_amdgcn_s_setprio(1);                                          \
@@ -222,13 +217,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
 
   // ---- prologue: K-tile 0 complete, first two units of K-tile 1
   stage_b(0, 0); stage_b(1, 0);          // (both weight units of K-tile 0 are on their way since the top of the tile)
-#if SOD_C256_DEEP
-  stage_b(0, 1); stage_a(0, 1); stage_b(1, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // all of K-tile 0 (a1 was requested before b1 here, unlike in the loop)
-#else
   stage_a(0, 1); stage_b(0, 1);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#endif
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();       // wave row 1 runs one barrier behind wave row 0
 
@@ -237,14 +227,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
     // phase 0: quadrant (a0, b0)
     read_b(cur, 0, bf0);
     read_a(cur, 0);
-#if SOD_C256_DEEP
-    SOD256_PHASE(0, 0, bf0, stage_a(1, k + 1))
-    read_b(cur, 1, bf1);
-    SOD256_PHASE(0, 1, bf1, stage_b(0, k + 2))
-    read_a(cur, 1);
-    SOD256_PHASE(1, 1, bf1, stage_a(0, k + 2))
-    SOD256_PHASE(1, 0, bf0, stage_b(1, k + 2))
-#else
     SOD256_PHASE(0, 0, bf0, stage_b(1, k + 1))
     // phase 1: quadrant (a0, b1)
     read_b(cur, 1, bf1);
@@ -254,7 +236,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ConvArgs a)
     SOD256_PHASE(1, 1, bf1, stage_a(0, k + 2))
     // phase 3: quadrant (a1, b0), b0 still in registers
     SOD256_PHASE(1, 0, bf0, stage_b(0, k + 2))
-#endif
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -147,6 +147,7 @@ class ParamArena:
     def zero_grad(self):
         if self.device.type == "cuda":
             from . import functional as HF
+            HF.drop_held()           # (launches parked by a backward pass that died: not into the fresh arena)
             HF.wgrad_join()          # never clear the arena under weight-gradient kernels still running on the side stream
         self.grads.zero_()
 

@@ -153,28 +153,53 @@ def wgrad_side_streams(device):
     return list(_side_streams.get(device.index, ())) if _side_join_queued else []
 
 
-# Experiment of round 6 (SOD_HOLD_HEAD_WGRAD=1, off by default): the head towers' weight gradients (MFMA-bound 256x256 kernels) are not
-# launched beside the towers' data gradients (MFMA-bound too) but HELD and released when the FPN backward starts, so that they run beside
-# the HBM-bound backbone kernels instead - re-pairing the backward phases by roof (round-5 review).  Measurement: profiles/r6_pairing.txt.
-HOLD_HEAD_WGRAD = os.environ.get("SOD_HOLD_HEAD_WGRAD", "0") == "1"
+# Re-pairing the backward phases by roof (round 6; SOD_HOLD_HEAD_WGRAD=0 restores the old order).  The head towers' weight gradients are
+# MFMA-bound, and so are the towers' data gradients they used to run beside (8.5 ms phase on three queues); the FPN / backbone backward
+# that follows is HBM-bound on two saturated queues.  The tower units therefore PARK their weight-gradient launches (and the mark_ready
+# behind them) and the first FPN / backbone backward node releases them, in order, onto the same side stream: they then run beside the
+# HBM-bound kernels.  Same launches, same operands, same results; measured on the FCOS R50 step in alternating 60-step runs:
+# 660.3 -> 665.3, 653.5 -> 661.7, 655.7 -> 660.8 img/s (+0.8 ... +1.2 %), one-rank RCCL rehearsal 646.5 -> 654.2 with the exposed
+# communication unchanged (0.13 ms per step: the head's bucket is launched later, but 7 ms of backward are still ahead of it).  Releasing
+# them onto a side stream of their OWN instead measured 14 % SLOWER (555 - 567 img/s at 4, 5 or 6 hardware queues): three streams of
+# chip-filling kernels take each other's CUs; profiles/r6_pairing.txt.
+HOLD_HEAD_WGRAD = os.environ.get("SOD_HOLD_HEAD_WGRAD", "1") != "0"
 _held = []
 
 
 def hold_or_call(fn):
     """Tower units: run ``fn`` (weight-gradient launch + mark_ready) now, or park it until release_held()."""
-    if HOLD_HEAD_WGRAD:
+    if HOLD_HEAD_WGRAD and _side_join_queued_or_in_backward():
         _held.append(fn)
     else:
         fn()
 
 
+def _side_join_queued_or_in_backward():
+    """Parking is only safe when something will release: inside an autograd backward pass (the end-of-backward callback does, at the
+    latest).  Op-level calls outside a backward pass launch at once."""
+    global _side_join_queued
+    if _side_join_queued:
+        return True
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_wgrad_join)
+    except RuntimeError:
+        return False
+    _side_join_queued = True
+    return True
+
+
 def release_held():
-    """First FPN / backbone backward node (and the end-of-backward join, for safety): issue every parked launch, in order."""
+    """First FPN / backbone backward node (and the end-of-backward join, at the latest): issue every parked launch, in order."""
     if _held:
         items = list(_held)
         _held.clear()
         for fn in items:
             fn()
+
+
+def drop_held():
+    """A backward pass that ended in an exception may leave parked launches behind: never carry them into the next step."""
+    _held.clear()
 
 
 def _wgrad_join():
