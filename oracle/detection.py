@@ -93,6 +93,66 @@ def roi_align(x, rois, output_size, scale, sampling_ratio=0, rotated=False):
     return torch.stack(outs) if outs else torch.zeros(0, x.shape[1], PH, PW)
 
 
+def roi_align_vec(x, rois, output_size, scale, sampling_ratio=0, rotated=False):
+    """roi_align() with the sample points of one ROI evaluated at once (torch ops over a (PH * gh, PW * gw) grid instead of four nested
+    Python loops): the same sample positions, validity rules and bilinear weights (formed in float64 like the loop's Python floats, applied
+    to the features in their own dtype), summed per bin in a different order.  For the CPU BASELINE of bench.py only (the benchmark's
+    map-sized random-init proposals have up to ~1 500 samples per bin: the loop needs minutes per image); the parity tests keep the loop.
+    tests/test_oracle_crosscheck.py pins the two to each other."""
+    PH, PW = output_size
+    N, C, H, W = x.shape
+    flat = x.permute(0, 2, 3, 1).reshape(N, H * W, C)          # rows of C values: a corner gather moves contiguous rows
+    outs = []
+    for roi in rois.tolist():
+        b = int(roi[0])
+        if rotated:
+            cw, ch = roi[1] * scale - 0.5, roi[2] * scale - 0.5
+            rw, rh = roi[3] * scale, roi[4] * scale
+            th = roi[5] * math.pi / 180.0
+            ct, st = math.cos(th), math.sin(th)
+            sh, sw = -rh / 2.0, -rw / 2.0
+        else:
+            sw, sh = roi[1] * scale - 0.5, roi[2] * scale - 0.5
+            rw, rh = roi[3] * scale - 0.5 - sw, roi[4] * scale - 0.5 - sh
+        bh, bw = rh / PH, rw / PW
+        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rh / PH))
+        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rw / PW))
+        if gh <= 0 or gw <= 0:
+            outs.append(torch.zeros(C, PH, PW, dtype=x.dtype))
+            continue
+        ph = torch.arange(PH, dtype=torch.float64).repeat_interleave(gh)
+        iy = torch.arange(gh, dtype=torch.float64).repeat(PH)
+        pw = torch.arange(PW, dtype=torch.float64).repeat_interleave(gw)
+        ix = torch.arange(gw, dtype=torch.float64).repeat(PW)
+        yy = (sh + ph * bh + (iy + 0.5) * bh / gh)[:, None]      # (PH * gh, 1)
+        xx = (sw + pw * bw + (ix + 0.5) * bw / gw)[None, :]      # (1, PW * gw)
+        if rotated:
+            y, xq = yy * ct - xx * st + ch, yy * st + xx * ct + cw
+        else:
+            y, xq = yy.expand(-1, PW * gw), xx.expand(PH * gh, -1)
+        ok = ~((y < -1.0) | (y > H) | (xq < -1.0) | (xq > W))
+        y, xq = y.clamp(min=0.0), xq.clamp(min=0.0)
+        yl, xl = y.floor().long(), xq.floor().long()
+        top, right = yl >= H - 1, xl >= W - 1
+        yl, xl = torch.where(top, torch.full_like(yl, H - 1), yl), torch.where(right, torch.full_like(xl, W - 1), xl)
+        yh, xh = torch.where(top, yl, yl + 1), torch.where(right, xl, xl + 1)
+        y, xq = torch.where(top, yl.double(), y), torch.where(right, xl.double(), xq)
+        ly, lx = y - yl, xq - xl
+        hy, hx = 1.0 - ly, 1.0 - lx
+        okf = ok.double()
+        f = flat[b]
+        acc = None
+        for wgt, yi, xi in ((hy * hx, yl, xl), (hy * lx, yl, xh), (ly * hx, yh, xl), (ly * lx, yh, xh)):
+            v = f.index_select(0, (yi * W + xi).reshape(-1)) * (wgt * okf).reshape(-1, 1).to(x.dtype)
+            acc = v if acc is None else acc + v
+        acc = acc.reshape(PH, gh, PW, gw, C).sum(dim=(1, 3)) / max(gh * gw, 1)
+        outs.append(acc.permute(2, 0, 1))
+    return torch.stack(outs) if outs else torch.zeros(0, C, PH, PW, dtype=x.dtype)
+
+
+ROI_ALIGN_IMPL = "loop"      # "vec": roi_pool() of oracle/rcnn.py takes roi_align_vec (bench.py's cpu_baseline)
+
+
 def pairwise_iou(b1, b2):
     """SURVEY.md C.4."""
     a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])

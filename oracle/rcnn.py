@@ -178,7 +178,8 @@ def roi_pool(feats, rois, scales, out_size=7, sampling_ratio=0):
     for l, (f, s) in enumerate(zip(feats, scales)):
         idx = torch.nonzero(lv == l).squeeze(1)
         if len(idx):
-            out = out.index_put((idx,), od.roi_align(f, rois[idx], (out_size, out_size), s, sampling_ratio, rotated=(D == 5)))
+            ra = od.roi_align_vec if od.ROI_ALIGN_IMPL == "vec" else od.roi_align
+            out = out.index_put((idx,), ra(f, rois[idx], (out_size, out_size), s, sampling_ratio, rotated=(D == 5)))
     return out
 
 

@@ -152,3 +152,23 @@ def test_forced_masks_report_decisions_outside_the_undecided_band():
     relu_at(x, "a")
     ForcedMasks.end()
     assert st["disagree"] == 2 and st["outside"] == 1 and st["outside_at"][0][:3] == ("a", 0, 1) and st["outside_at"][0][3] > 1.0
+
+
+def test_vectorised_roi_align_equals_the_loop_restatement():
+    """oracle/detection.py:roi_align_vec (bench.py's CPU baseline for the two-stage architecture) against roi_align, the Python-loop
+    restatement of detectron2's ROIAlign / ROIAlignRotated the parity tests use: same samples, same weights, forward and gradient."""
+    import torch
+    from oracle import detection as od
+
+    torch.manual_seed(0)
+    x = torch.randn(2, 8, 20, 24, requires_grad=True)
+    cases = {False: torch.tensor([[0, 4., 3., 60., 50.], [1, -10., -5., 30., 90.], [0, 70., 60., 95., 79.], [1, 0., 0., 96., 80.]]),
+             True: torch.tensor([[0, 40., 30., 50., 20., 30.], [1, 10., 10., 90., 70., -75.], [0, 5., 70., 8., 3., 10.], [1, 95., 2., 30., 30., 45.]])}
+    for rotated, rois in cases.items():
+        for sr in (0, 2):
+            a = od.roi_align(x, rois, (7, 7), 0.25, sr, rotated)
+            b = od.roi_align_vec(x, rois, (7, 7), 0.25, sr, rotated)
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (rotated, sr)
+            ga = torch.autograd.grad((a * a).sum(), x)[0]
+            gb = torch.autograd.grad((b * b).sum(), x)[0]
+            assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-5), (rotated, sr)
