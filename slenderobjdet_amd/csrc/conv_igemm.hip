@@ -1050,7 +1050,9 @@ bool use_wgrad256(const WgradArgs& a, float* ws, long long ws_bytes) {
   // data-gradient kernels on the other stream.  Swept on the FCOS R50 step (one box, two rounds): >= 6 K-tiles per block 572.1 / 573.5
   // img/s, >= 40: 575.5 / 576.5, >= 70: 576.7 / 577.4, >= 120: 576.6 / 577.2, >= 250 (head towers off the 256 kernel): 565.6 / 566.1.
   // (re-swept with the faster kernel in round 4: 64 still best - 635.6 / 634.3 vs 633.2 at 32, 627-628 at 16 / 8)
-  constexpr int min_kt = 64;
+  // (round 6, with the nine-tap kernel taking the long 3x3 shapes and the head's weight gradients parked behind the FPN backward: 32 beats 64 -
+  // 663.9 / 662.5 / 664.6 vs 662.1 / 659.8 / 660.3 img/s, 20: 662.8 / 662.0 / 662.4; stand-alone the 256 kernel wins from ~30 K-tiles per block)
+  constexpr int min_kt = 32;
   if (!mode || !ws || !wgrad256_supported(a)) return false;
   const int cus = device_cus();
   if (wgrad256_workspace_bytes(a, cus) > ws_bytes) return false;

@@ -2,7 +2,9 @@
 the 128x128 kernels of conv_igemm.hip (variant 0) and conv_wgrad_ring.hip (sod_conv_set_wgrad_variant codes), interleaved rounds in one
 process, operands cycled through a pool larger than the Infinity Cache.
 
-    python tools/bench_wgrad_backbone.py [variant ...]        # default: 0 2300 2301 2310 2311 2411
+    python tools/bench_wgrad_backbone.py [variant ...]        # default: 0 2300 2310
+Pseudo-variants: -1 = the dispatcher's own choice (what the step runs), 256 = the 256 x 256 kernel forced (splits = -1), 9 = the nine-tap
+kernel forced (splits = -2); unsupported shapes print 0.0.
 Prints one row per shape (us per launch, best of the rounds) and the count-weighted sum per training step."""
 import os
 import sys
@@ -24,6 +26,7 @@ SHAPES = [
     ("ml", 256, 80), ("ml", 256, 8),
 ]
 POOL_BYTES = 600 << 20
+SPLITS = [0]
 
 
 def timeit(fn, iters):
@@ -37,7 +40,7 @@ def timeit(fn, iters):
 
 
 def main():
-    variants = [int(v) for v in sys.argv[1:]] or [0, 2300, 2301, 2310, 2311, 2411]
+    variants = [int(v) for v in sys.argv[1:]] or [0, 2300, 2310]
     total = {v: 0.0 for v in variants}
     flops_total = 0.0
     print("shape".ljust(40) + "".join(f"{v:>10d}" for v in variants) + "   (us per launch; x count per step)")
@@ -51,7 +54,7 @@ def main():
             dys = [[torch.randn(N, h, w, K, device=dev).bfloat16() for h, w in hws] for _ in range(copies)]
             dw = torch.zeros(K, 3, 3, C, device=dev)
             flops = sum(2.0 * N * h * w * K * 9 * C for h, w in hws)
-            fn = lambda i: HF.conv2d_wgrad_ml(dys[i % copies], xs[i % copies], dw, 3, 3, 1, 1, 1)
+            fn = lambda i: HF.conv2d_wgrad_ml(dys[i % copies], xs[i % copies], dw, 3, 3, 1, 1, 1, splits=SPLITS[0])
             name, cnt = f"ml 5 levels C{C} K{K} R3", 1
         else:
             H, W, C, K, R, st, cnt = shp
@@ -62,13 +65,18 @@ def main():
             dy = [torch.randn(N, Ho, Wo, K, device=dev).bfloat16() for _ in range(copies)]
             dw = torch.zeros(K, R, R, C, device=dev)
             flops = 2.0 * N * Ho * Wo * K * R * R * C
-            fn = lambda i: HF.conv2d_wgrad(dy[i % copies], x[i % copies], dw, R, R, st, R // 2, 1)
+            fn = lambda i: HF.conv2d_wgrad(dy[i % copies], x[i % copies], dw, R, R, st, R // 2, 1, splits=SPLITS[0])
             name = f"{H}x{W} C{C} K{K} R{R} s{st}"
         best = {v: 1e9 for v in variants}
         for _ in range(3):
             for v in variants:
-                _C.call("sod_conv_set_wgrad_variant", v)
-                best[v] = min(best[v], timeit(fn, 2 * copies if copies < 8 else copies))
+                _C.call("sod_conv_set_wgrad_variant", v if v not in (-1, 256, 9) else -1)
+                SPLITS[0] = {256: -1, 9: -2}.get(v, 0)
+                try:
+                    best[v] = min(best[v], timeit(fn, 2 * copies if copies < 8 else copies))
+                except _C.SlenderHipError:
+                    best[v] = 0.0
+        SPLITS[0] = 0
         _C.call("sod_conv_set_wgrad_variant", -1)
         for v in variants:
             total[v] += best[v] * cnt
