@@ -39,15 +39,31 @@ constexpr int G9_YTILE = 64 * G9_YROWB;           // 16 KB
 constexpr int G9_LDS = G9_XBYTES + 4 * G9_YTILE;  // 155 648 B (+ 1 KB offset table behind it)
 constexpr int G9_SLAB = 128 * 64 * 9;             // floats per partial tile
 
+// SOD_W9_ABL (measurement builds only, tools/bench_wgrad9_abl.py): 1 = every LDS-DMA request of the loop out of range (zero fill, no memory
+// traffic), 2 = no fragment reads, 4 = no MFMAs, 8 = no barrier in the loop, 16 = no vmcnt wait in the loop (8 / 16: wrong results, timing only),
+// 32 = no s_setprio.  Never defined in the shipped library.
+#ifndef SOD_W9_ABL
+#define SOD_W9_ABL 0
+#endif
+
 template <int OFF_LO, int OFF_HI>
 __device__ __forceinline__ bf16x8_t tr_read2(uint32_t addr) {
   s16x4_t lo, hi;
+#if SOD_W9_ABL & 2
+  asm volatile("; no read %0 %1 %2" : "=&v"(lo), "=&v"(hi) : "v"(addr));
+#else
   asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
                : "=&v"(lo), "=&v"(hi) : "v"(addr), "n"(OFF_LO), "n"(OFF_HI));
+#endif
   s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+#if SOD_W9_ABL & 4
+#define G9_MFMA(ACC, A, B) asm volatile("; no mfma %0 %1 %2" : "+v"(ACC) : "v"(A), "v"(B))
+#else
+#define G9_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, ACC, 0, 0, 0)
+#endif
 #define G9_WAIT_LGKM(N) do { asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 }  // namespace
@@ -195,8 +211,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(const W9Args a) {
 
     for (int t = 0; t < T; ++t) {
       // everything K-tile t reads was requested G9_D iterations ago: at most the 3 (D - 1) younger requests may still be in flight
+#if !(SOD_W9_ABL & 16)
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#endif
+#if !(SOD_W9_ABL & 8)
       __builtin_amdgcn_s_barrier();
+#endif
       const uint32_t* tb = tab + (t & 1) * 128;
       uint32_t ox, oy0, oy1;
       asm volatile("ds_read_b32 %0, %1" : "=v"(ox) : "v"((uint32_t)(uintptr_t)SOD_LDS(tb + x_row)));
@@ -227,15 +247,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(const W9Args a) {
       // one step: [request the B fragment of step s + 2] [wait for this step's] [4 MFMAs] [a piece of next tile's bookkeeping]
 #define G9_MMA(AF, B, TAP, WORK)                                                                                   \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                   \
-      acc[i][TAP] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i], B, acc[i][TAP], 0, 0, 0);                      \
+      G9_MFMA(acc[i][TAP], AF[i], B);                                                                             \
   __builtin_amdgcn_sched_barrier(0);                                                                               \
   WORK                                                                                                             \
   __builtin_amdgcn_sched_barrier(0);
       // lgkmcnt counts ds instructions (two per fragment): the numbers are the requests YOUNGER than the one needed.
+#if !(SOD_W9_ABL & 32)
       __builtin_amdgcn_s_setprio(1);
+#endif
       b2 = tr_read2<0, 2048>(baddr[2]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b0, 0, if (mine) G9_PIX1(jn + 64 * (G9_D + E) + lane - sh0, pn, prem, pok))
       {   // X chunk t + D + E and dY tile t + D (the table reads above are older than b0: they have landed)
         char* xd = smem + (xslot * 64 + wave * 8) * G9_XROWB;
+#if SOD_W9_ABL & 1
+        ox = oy0 = oy1 = SOD_OOB;
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(xd), 16, ox + x_cadd, 0, 0, 0);
         if (xslot == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(xd + G9_RX * G9_XROWB), 16, ox + x_cadd, 0, 0, 0);   // the mirror rows
         xslot = (xslot + 1 == G9_NXC) ? 0 : xslot + 1;
