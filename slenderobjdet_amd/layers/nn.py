@@ -579,11 +579,13 @@ class _ConvReluMLFn(torch.autograd.Function):
             gs = [dy.contiguous() for dy in dys]
         else:
             gs = [HF.relu_bwd(dy.contiguous(), y) for dy, y in zip(dys, ys)]
-        with HF.wgrad_batch():
-            HF.conv2d_wgrad_ml(gs, list(xs), arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
-            arena.mark_ready(conv.weight)
-            HF.bias_grad_ml(gs, arena.grad_view(conv.bias))
-            arena.mark_ready(conv.bias)
+        def wgrad():
+            with HF.wgrad_batch():
+                HF.conv2d_wgrad_ml(gs, list(xs), arena.grad_view(conv.weight), 3, 3, 1, 1, 1)
+                arena.mark_ready(conv.weight)
+                HF.bias_grad_ml(gs, arena.grad_view(conv.bias))
+                arena.mark_ready(conv.bias)
+        HF.hold_or_call(wgrad)          # parked until the FPN backward starts (layers/functional.py: HOLD_HEAD_WGRAD)
         dxs = [None] * nl
         if any(ctx.needs_input_grad[3:]):
             hw = [(x.shape[1], x.shape[2]) for x in xs]
