@@ -383,6 +383,13 @@ def test_free_run_on_shared_relu_decisions(cuda, mode, depth, iters, size):
             # on both sides), so its band is asserted while the runs are still one trajectory (10 iterations) and reported afterwards
             if mode == "fp32" or it < 10:
                 assert st["outside"] == 0, (it + 1, st["outside_at"][:5])
+            # for the WHOLE run (round-5 advisor): a systematic error in a mask path (a wrong-sign pre-activation, a shifted bit) flips a large
+            # share of some layer's units in every iteration, also after the two runs have separated - the share of units decided
+            # differently stays below 1 % per iteration (measured 0.25 - 0.4 %: units whose pre-activation bf16 storage noise can flip), and
+            # what falls outside the undecided band stays a sliver (measured: at most 2 440 of 3.8e7 units in one iteration, late in the run,
+            # all in the last GroupNorm of the classification tower)
+            assert st["disagree"] <= 0.01 * max(st["units"], 1), (it + 1, st["disagree"], st["units"])
+            assert st["outside"] <= 1e-3 * st["units"], (it + 1, st["outside"], st["outside_at"][:5])
             outside_late += st["outside"]
             outside_log += [(it + 1,) + tuple(r) for r in st["outside_at"]]      # (iteration, ReLU position, call = FPN level, units, |x| / rms)
             worst_ratio = max([worst_ratio] + [r[3] for r in st["outside_at"]])
