@@ -166,6 +166,8 @@ def kernel_name(kind, code):
         return "stem_fused_kernel"
     if code == -8:
         return "bottleneck_frozen_kernel"
+    if code == 7003:            # conv_ws3.hip: persistent weight-stationary 3x3 kernel (128 -> 128 channels)
+        return "void sodconv::conv_ws3_kernel<" + ("0" if kind == "conv_fwd" else "1")
     if code == 7001:            # conv_pw.hip: persistent weight-stationary kernel of the expanding 1x1 convolutions
         return "void sodconv::conv_pw_kernel<" + ("0" if kind == "conv_fwd" else "1")
     if kind == "conv_wgrad":

@@ -159,6 +159,11 @@ int sod_conv_set_tile256(int mode);
  * shortcut / ReLU / bit mask, backward accumulate / bit mask) to the persistent weight-stationary kernel of conv_pw.hip; 0 keeps them on
  * the tiled kernels.  Bit-identical results either way (d2 BottleneckBlock conv3 / conv1 under slender_det/modeling/backbone/fpn.py:94-115). */
 int sod_conv_set_pw(int on);
+/* Process-wide policy of the persistent weight-stationary 3x3 kernel (conv_ws3.hip: 3x3 / stride 1 / pad 1, 128 -> 128 channels, one dense level,
+ * 256-CU device; forward bias / ReLU, backward a bf16 ReLU mask tensor) behind sod_conv2d_fwd / sod_conv2d_dgrad: -1 = re-read SOD_CONV_WS3
+ * (default 1), 0 = never, 1 = launches of at least 1 024 tiles of 8 x 14 pixels (conv2 of the res3 bottleneck blocks at batch 16, d2
+ * BottleneckBlock under slender_det/modeling/backbone/fpn.py:94-115), 2 = every supported shape (parity tests). */
+int sod_conv_set_ws3(int mode);
 /* Kernel policy of sod_conv2d_wgrad / _wgrad_ml for the shapes the 256x256 kernel does not take (process-wide): -1 (default) = env
  * SOD_WGRAD_VARIANT or the library's per-shape choice; 0 = conv_wgrad_kernel (two 4-wave workgroups per CU, float atomics);
  * G*1000 + NSTAGE*100 + EPI*10 + FDB = one variant of conv_wgrad_ring_kernel for every shape (G = 1 | 2 groups of four waves per

@@ -51,6 +51,7 @@ _SIGS = {
     "sod_conv2d_dgrad_cwin": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "sod_conv_set_tile256": [_I],
     "sod_conv_set_pw": [_I],
+    "sod_conv_set_ws3": [_I],
     "sod_conv_set_wgrad_variant": [_I],
     "sod_conv_set_reverse": [_I],
     "sod_conv_last_variant": [],

@@ -115,6 +115,11 @@ int launch_conv256(const ConvArgs& a, int mode, bool out_f32, int max_pt_tiles, 
 bool pw_supported(const ConvArgs& a, int mode, bool out_f32, int cus);
 int launch_pw(const ConvArgs& a, int mode, hipStream_t st);
 
+// conv_ws3.hip: persistent weight-stationary kernel for the 3x3 / stride-1 128 -> 128 convolutions (conv2 of the res3 bottleneck blocks and its
+// data gradient): 295 KB of weights in registers, a 10 x 16 halo window per 8 x 14 output tile staged once for the nine taps
+bool ws3_supported(const ConvArgs& a, int mode, bool out_f32, int cus, bool any_size);
+int launch_ws3(const ConvArgs& a, int mode, hipStream_t st);
+
 // --------------------------------------------------------------------------------------------
 // wgrad: dW[q][tap][c] += sum_p dY[p][q] * X[p shifted by tap][c]
 // The contraction runs over a VIRTUAL pixel index that concatenates the levels (each padded to a multiple of 64), so

@@ -884,6 +884,7 @@ int launch_conv(const ConvArgs& a0, hipStream_t st) {
 thread_local int g_conv_reverse = 0;    // sod_conv_set_reverse: per calling thread (the forward thread and autograd's worker each bracket their own launches)
 int g_conv256_mode = -1;   // -1: read SOD_CONV256 (default 1); 0 off; 1 heuristic; 2 every supported shape
 int g_conv_pw = -1;        // -1: read SOD_CONV_PW (default 1); 0 off; 1 on (sod_conv_set_pw)
+int g_conv_ws3 = -1;       // -1: read SOD_CONV_WS3 (default 1); 0 off; 1 large launches; 2 every supported shape (sod_conv_set_ws3)
 int device_cus();
 
 template <int MODE, bool OUT_F32>
@@ -900,6 +901,15 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     const int pi = prof_begin(st);
     const int rc = launch_pw(a, MODE, st);
     prof_end(pi, st, 7001, 1.f, MODE);
+    return rc;
+  }
+  // persistent weight-stationary 3x3 kernel (conv_ws3.hip) for the 128 -> 128 convolutions of res3; SOD_CONV_WS3=0 disables it
+  if (g_conv_ws3 < 0) { const char* e = getenv("SOD_CONV_WS3"); g_conv_ws3 = e ? atoi(e) : 1; }
+  if (g_conv_ws3 && ws3_supported(a, MODE, OUT_F32, device_cus(), g_conv_ws3 == 2)) {
+    g_last_variant = 7003;
+    const int pi = prof_begin(st);
+    const int rc = launch_ws3(a, MODE, st);
+    prof_end(pi, st, 7003, 1.f, MODE);
     return rc;
   }
   // 256x256 8-phase kernel (conv_igemm256.hip) for the large compute-bound shapes.  SOD_CONV256=0 disables it, =2 forces it for
@@ -1514,6 +1524,12 @@ extern "C" int sod_conv_set_reverse(int on) {
 extern "C" int sod_conv_set_wgrad_variant(int variant) {
   if (variant < -1) return SOD_EARG;
   g_wgrad_variant = variant;
+  return SOD_OK;
+}
+
+extern "C" int sod_conv_set_ws3(int mode) {
+  if (mode < -1 || mode > 2) return SOD_EARG;
+  g_conv_ws3 = mode;
   return SOD_OK;
 }
 

@@ -27,7 +27,10 @@ constexpr int W3_BUF = W3_ROWS * 256;                  // 40 960 B
 constexpr int W3_GUARD = 256;                          // a halo column's neighbour reads one row in front of / behind a buffer
 constexpr int W3_LDS = 2 * W3_GUARD + 2 * W3_BUF;      // 82 432 B
 constexpr int W3_STEPS = W3_TH * 9 * 4;                // (pixel row, tap, 32-channel block)
-constexpr int W3_DIST = 3;                             // fragment reads in flight ahead of the MFMAs
+// fragment reads in flight ahead of the MFMAs (one wave per SIMD: nothing else hides the LDS round trip); the data gradient carries its eight
+// mask loads across the epilogue and has the registers for three only (five spill 45 registers)
+template <int MODE> struct W3Dist { static constexpr int v = (MODE == MODE_FWD) ? 5 : 2; };
+constexpr int W3_DMAX = 5;
 
 template <int OFF>
 __device__ __forceinline__ bf16x8_t w3_read(uint32_t addr) {
@@ -39,7 +42,7 @@ __device__ __forceinline__ bf16x8_t w3_read(uint32_t addr) {
 struct W3State {
   f32x4_t acc[2][W3_TH];
   bf16x8_t af[2][9][4];
-  bf16x8_t b[W3_DIST + 1];
+  bf16x8_t b[W3_DMAX + 1];
   uint32_t rb[3][4];           // base address of (column shift, channel block) in the CURRENT buffer
 };
 
@@ -50,20 +53,24 @@ __device__ __forceinline__ void w3_issue(W3State& st) {
     constexpr int j = S / 36, tap = (S % 36) / 4, kb = S % 4;
     constexpr int sg = (MODE == MODE_FWD) ? 1 : -1;
     constexpr int dh = sg * (tap / 3 - 1), dw = sg * (tap % 3 - 1);
-    st.b[S % (W3_DIST + 1)] = w3_read<(j + 1 + dh) * W3_TWC * 256>(st.rb[dw + 1][kb]);
+    st.b[S % (W3Dist<MODE>::v + 1)] = w3_read<(j + 1 + dh) * W3_TWC * 256>(st.rb[dw + 1][kb]);
   }
+}
+
+template <int MODE, int S>
+__device__ __forceinline__ void w3_prime(W3State& st) {          // the first DIST requests
+  if constexpr (S < W3Dist<MODE>::v) { w3_issue<MODE, S>(st); w3_prime<MODE, S + 1>(st); }
 }
 
 template <int MODE, int S>
 __device__ __forceinline__ void w3_steps(W3State& st) {
   if constexpr (S < W3_STEPS) {
     constexpr int j = S / 36, tap = (S % 36) / 4, kb = S % 4;
+    constexpr int W3_DIST = W3Dist<MODE>::v;
     w3_issue<MODE, S + W3_DIST>(st);
     // the fragment of this step is the oldest of at most DIST + 1 requests
-    if constexpr (S + W3_DIST < W3_STEPS) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-    else if constexpr (S + 2 < W3_STEPS) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-    else if constexpr (S + 1 < W3_STEPS) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int younger = (W3_STEPS - 1 - S) < W3_DIST ? (W3_STEPS - 1 - S) : W3_DIST;
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger) : "memory");
     __builtin_amdgcn_sched_barrier(0);
     st.acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.af[0][tap][kb], st.b[S % (W3_DIST + 1)], st.acc[0][j], 0, 0, 0);
     st.acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.af[1][tap][kb], st.b[S % (W3_DIST + 1)], st.acc[1][j], 0, 0, 0);
@@ -74,7 +81,6 @@ __device__ __forceinline__ void w3_steps(W3State& st) {
 
 }  // namespace
 
-static_assert(W3_DIST == 3, "the counted lgkmcnt waits of w3_steps assume three requests ahead");
 
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void conv_ws3_kernel(const ConvArgs a, const int tiles_y, const int tiles_x) {
@@ -107,33 +113,34 @@ __global__ __launch_bounds__(256, 1) void conv_ws3_kernel(const ConvArgs a, cons
   }
 
   // ---- fragment base addresses (buffer 0): pixel column fr + dw of the 16-wide window, channel block kb, swizzled by the column
-  uint32_t rb0[3][4];
 #pragma unroll
   for (int d = 0; d < 3; ++d)
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const int col = fr + d - 1;
-      rb0[d][kb] = (uint32_t)(W3_GUARD + col * 256 + (((kb * 4 + fg) ^ (col & 15)) << 4));
+      st.rb[d][kb] = (uint32_t)(W3_GUARD + col * 256 + (((kb * 4 + fg) ^ (col & 15)) << 4));
     }
 
   // ---- staging: instruction k of a wave = halo row k, columns wave * 4 + fg (a wave instruction covers 4 pixels x 256 B)
   const int s_col = wave * 4 + fg;
   const uint32_t s_chunk = (uint32_t)(((lane & 15) ^ s_col) << 4);             // logical 16-B chunk this lane fetches (source-side swizzle)
   auto stage = [&](int t, int buf) {
-    uint32_t base = SOD_OOB;
+    uint32_t base = 0;
     int h0 = 0;
+    bool cok = false;                      // this lane's column lies inside the image (and the tile exists)
     if (t < ntiles) {
       const int tx = t % tiles_x, r = t / tiles_x;
       const int ty = r % tiles_y, n = r / tiles_y;
       h0 = ty * W3_TH;
       const int wc = tx * W3_TW - 1 + s_col;
-      if ((unsigned)wc < (unsigned)W) base = (uint32_t)(((n * H + h0 - 1) * W + wc) * 256) + s_chunk;      // row h0 - 1 (may lie outside: tested per k)
+      cok = (unsigned)wc < (unsigned)W;
+      base = (uint32_t)(((n * H + h0 - 1) * W + wc) * 256) + s_chunk;      // row h0 - 1 (may lie outside the image: tested per k; arithmetic mod 2^32)
     }
     char* dst = smem + W3_GUARD + buf * W3_BUF + wave * 1024;
 #pragma unroll
     for (int k = 0; k < W3_TH + 2; ++k) {
       const bool rok = (unsigned)(h0 - 1 + k) < (unsigned)H;                    // scalar
-      const uint32_t off = (rok && base != SOD_OOB) ? base + (uint32_t)(k * W * 256) : SOD_OOB;
+      const uint32_t off = (rok && cok) ? base + (uint32_t)(k * W * 256) : SOD_OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(dst + k * 4096), 16, off, 0, 0, 0);
     }
   };
@@ -146,15 +153,18 @@ __global__ __launch_bounds__(256, 1) void conv_ws3_kernel(const ConvArgs a, cons
     if (it == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (it > 0) {                                        // the base addresses follow the buffer (kept in place: no second set of registers)
+      const uint32_t delta = buf ? (uint32_t)W3_BUF : (uint32_t)(-W3_BUF);
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+      for (int d = 0; d < 3; ++d)
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) st.rb[d][kb] = rb0[d][kb] + (uint32_t)(buf * W3_BUF);
+        for (int kb = 0; kb < 4; ++kb) st.rb[d][kb] += delta;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < W3_TH; ++j) st.acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    w3_issue<MODE, 0>(st); w3_issue<MODE, 1>(st); w3_issue<MODE, 2>(st);
+    w3_prime<MODE, 0>(st);
     w3_steps<MODE, 0>(st);
 
     // ---- epilogue 1, accumulator layout -> the consumed halo buffer as a [128 px][128 ch] bf16 tile (8-byte units XOR-swizzled by 2 * column)
@@ -170,29 +180,37 @@ __global__ __launch_bounds__(256, 1) void conv_ws3_kernel(const ConvArgs a, cons
         const int unit = wave * 8 + i * 4 + fg;          // 8-byte unit (4 channels) inside the pixel's 256-byte row
         *reinterpret_cast<bf16x4_t*>(stg + (j * 16 + fr) * 256 + ((unit ^ (2 * fr)) << 3)) = o;
       }
+    // ---- epilogue 2, row layout: 16 bytes = 8 channels of one pixel per lane; a wave instruction stores four pixels' full 256-byte runs.
+    // Thread (c16, col) = (tid & 15, tid >> 4) handles column col of every window row k.  The data gradient's mask values are requested
+    // BEFORE the barrier (the accumulators are dead: their registers carry the eight loads), so their latency runs beside it.
+    const int tx = t % tiles_x, tr = t / tiles_x;
+    const int ty = tr % tiles_y, n = tr / tiles_y;
+    const int c16 = tid & 15, col = tid >> 4;
+    const int wq = tx * W3_TW - 1 + col;
+    const bool cok = col >= 1 && col <= W3_TW && wq < W;
+    const size_t off0 = ((size_t)(n * H + ty * W3_TH) * W + wq) * 128 + c16 * 8;
+    bf16x8_t mv[4];
+    __builtin_amdgcn_sched_barrier(0);       // (the loads below must not be scheduled in front of the staging writes: the accumulators would still be live)
+    const bool masked = MODE == MODE_DGRAD && (a.flags & F_MASK) != 0;
+    if (masked) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (cok && ty * W3_TH + k < H) mv[k] = *reinterpret_cast<const bf16x8_t*>((const __bf16*)g.mask + off0 + (size_t)k * W * 128);
+    }
     __builtin_amdgcn_s_barrier();
-    // ---- epilogue 2, row layout: 16 bytes = 8 channels of one pixel per lane; a wave instruction stores four pixels' full 256-byte runs
-    {
-      const int tx = t % tiles_x, r = t / tiles_x;
-      const int ty = r % tiles_y, n = r / tiles_y;
-      const int c16 = tid & 15;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int row = k * 16 + (tid >> 4);             // pixel of the 8 x 16 window
-        const int j = row >> 4, col = row & 15;
-        const int h = ty * W3_TH + j, w = tx * W3_TW - 1 + col;
-        const bool ok = col >= 1 && col <= W3_TW && h < H && w < W;
-        bf16x8_t o = *reinterpret_cast<const bf16x8_t*>(stg + row * 256 + (((c16 * 2) ^ (2 * col)) << 3));
-        if (ok) {
-          const size_t off = ((size_t)(n * H + h) * W + w) * 128 + c16 * 8;
-          if (MODE == MODE_DGRAD && (a.flags & F_MASK)) {
-            const bf16x8_t mv = *reinterpret_cast<const bf16x8_t*>((const __bf16*)g.mask + off);
+    for (int k = 0; k < 8; ++k) {
+      bf16x8_t o = *reinterpret_cast<const bf16x8_t*>(stg + (k * 16 + col) * 256 + (((c16 * 2) ^ (2 * col)) << 3));
+      if (cok && ty * W3_TH + k < H) {
+        if (masked) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = ((float)mv[e] > 0.f) ? o[e] : (__bf16)0.f;
-          }
-          sod_store16((__bf16*)g.dst + off, o);
+          for (int e = 0; e < 8; ++e) o[e] = ((float)mv[k & 3][e] > 0.f) ? o[e] : (__bf16)0.f;
         }
+        sod_store16((__bf16*)g.dst + off0 + (size_t)k * W * 128, o);
       }
+      // rows 4 .. 7: their mask values take the registers of rows 0 .. 3 as those are consumed
+      if (masked && k < 4 && cok && ty * W3_TH + k + 4 < H)
+        mv[k] = *reinterpret_cast<const bf16x8_t*>((const __bf16*)g.mask + off0 + (size_t)(k + 4) * W * 128);
     }
     __builtin_amdgcn_s_barrier();                       // the staging tile has been read: the buffer may be refilled
     stage(t + 2 * (int)gridDim.x, buf);
@@ -201,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void conv_ws3_kernel(const ConvArgs a, cons
 }
 
 // 3x3, stride 1, pad 1, no dilation, 128 -> 128 channels, one dense level, bf16 output; forward: bias / ReLU; backward: a bf16 mask tensor
-bool ws3_supported(const ConvArgs& a, int mode, bool out_f32, int cus) {
+bool ws3_supported(const ConvArgs& a, int mode, bool out_f32, int cus, bool any_size) {
   if (out_f32 || cus != 256 || a.nlev != 1 || a.cwin) return false;
   if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.dil != 1) return false;
   if (a.Cred != 128 || a.Cpitch != 128 || a.Nout != 128) return false;
@@ -213,7 +231,7 @@ bool ws3_supported(const ConvArgs& a, int mode, bool out_f32, int cus) {
   if (a.flags & ~allowed) return false;
   // the persistent grid wants a few tiles per workgroup
   const long long tiles = (long long)a.N * ((g.Hs + W3_TH - 1) / W3_TH) * ((g.Ws + W3_TW - 1) / W3_TW);
-  return tiles >= 4 * 256;
+  return any_size || tiles >= 4 * 256;
 }
 
 int launch_ws3(const ConvArgs& a, int mode, hipStream_t st) {

@@ -788,6 +788,51 @@ def test_relu_bit_masks_match_tensor_masks(cuda):
     assert (a != 0).any()
 
 
+# conv_ws3.hip (persistent weight-stationary 3x3 kernel, 128 -> 128 channels: conv2 of the res3 bottleneck blocks), forced for every size with
+# sod_conv_set_ws3(2): (N, H, W)
+WS3_CASES = [(2, 100, 168), (1, 8, 14), (3, 13, 21), (2, 37, 50), (1, 9, 15)]
+
+
+@pytest.mark.parametrize("case", WS3_CASES)
+def test_weight_stationary_3x3_vs_oracle(cuda, case):
+    """Forward (bias + ReLU) and data gradient (bf16 ReLU mask tensor of the input) of a 3x3 / stride 1 / pad 1 convolution 128 -> 128 through
+    conv_ws3.hip (sod_conv_last_variant() == 7003) vs oracle/nn.py: the 8 x 14 tiling with its dropped halo columns, partial tiles at the right
+    and bottom edges, the zero padding staged as out-of-range offsets, several tiles per workgroup and the double-buffered window."""
+    from slenderobjdet_amd import _C
+    from slenderobjdet_amd.layers import functional as HF
+
+    N, H, W = case
+    C = K = 128
+    x, w = _rand((N, H, W, C), 81).relu(), _rand((K, 3, 3, C), 82, (9 * C) ** -0.5)
+    b = torch.randn(K, generator=torch.Generator().manual_seed(83))
+    dy, act = _rand((N, H, W, K), 84), _rand((N, H, W, C), 85)
+    d = lambda t: t.to(cuda).bfloat16()
+    _C.call("sod_conv_set_ws3", 2)
+    try:
+        y = HF.conv2d_fwd(d(x), d(w), b.to(cuda), stride=1, pad=1, relu=True)
+        assert int(_C.load().sod_conv_last_variant()) == 7003
+        y2 = HF.conv2d_fwd(d(x), d(w), None, stride=1, pad=1)
+        assert int(_C.load().sod_conv_last_variant()) == 7003
+        _, wt = HF.weight_prep(w.to(cuda), want_krsc=False)
+        dx = HF.conv2d_dgrad(d(dy), wt, (H, W), 1, 1, 1, relu_mask=d(act))
+        assert int(_C.load().sod_conv_last_variant()) == 7003
+        dx2 = HF.conv2d_dgrad(d(dy), wt, (H, W), 1, 1, 1)
+        assert int(_C.load().sod_conv_last_variant()) == 7003
+        torch.cuda.synchronize()
+        # and bit for bit against the tiled kernel (same MFMA instruction; the K order differs: tap outer there, so NOT identical - compared loosely)
+        _C.call("sod_conv_set_ws3", 0)
+        y0 = HF.conv2d_fwd(d(x), d(w), b.to(cuda), stride=1, pad=1, relu=True)
+        assert int(_C.load().sod_conv_last_variant()) != 7003
+    finally:
+        _C.call("sod_conv_set_ws3", -1)
+    _close(y, onn.conv2d(x, w, b, 1, 1, 1, relu=True), 2 ** -7, f"ws3 fwd bias+relu {case}")
+    _close(y2, onn.conv2d(x, w, None, 1, 1, 1), 2 ** -7, f"ws3 fwd plain {case}")
+    dx_ref, _ = onn.conv2d_backward(x, w, dy, 1, 1, 1)
+    _close(dx, dx_ref * (act > 0), 2 ** -7, f"ws3 dgrad + mask {case}")
+    _close(dx2, dx_ref, 2 ** -7, f"ws3 dgrad plain {case}")
+    assert (y.float() - y0.float()).abs().max().item() <= 2 ** -7 * y0.float().abs().max().item()
+
+
 # conv_pw.hip against the ORACLE directly (round-5 review: the persistent kernel had only been compared with its sibling kernel).  Shapes
 # the dispatcher routes to variant 7001: the expanding 1x1 convolutions of the bottleneck blocks (128 -> 512, 256 -> 1024), the
 # contracting 512 -> 128 of res3, at a ragged pixel count (129 x 131 = 16 899: no multiple of the 32 / 64-pixel tiles).
