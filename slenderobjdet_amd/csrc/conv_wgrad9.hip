@@ -114,6 +114,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(const W9Args a) {
   const int y_ps = lane & 15;
   const int y_log = ((((y_ps >> 1) ^ (y_row0 & 7)) << 1) | (y_ps & 1));
   const uint32_t y_qadd = (uint32_t)(q0 + y_log * 8) * 2u;
+  // K need not be a multiple of 128 (RetinaNet's class scores: 9 x 80 = 720): a lane whose 8 output channels lie beyond K requests the
+  // out-of-range offset in every tile (the next bytes in memory belong to the following PIXEL); the reduce kernel skips those rows
+  const bool y_live = q0 + y_log * 8 < a.K;
 
   // ---- fragment read geometry: lane 4q+p of a 16-lane group addresses row q, 8 bytes at p * 8 of the 32-B chunk
   const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(const W9Args a) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         uint32_t n, hw, off = SOD_OOB;
-        if (t < T && pix(j0 + 64 * t + k * 32 + y_row0, n, hw)) off = (n * (uint32_t)g.dy_img_stride + hw * (uint32_t)a.K) * 2u + y_qadd;
+        if (t < T && y_live && pix(j0 + 64 * t + k * 32 + y_row0, n, hw)) off = (n * (uint32_t)g.dy_img_stride + hw * (uint32_t)a.K) * 2u + y_qadd;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(dst + k * 32 * G9_YROWB), 16, off, 0, 0, 0);
       }
     };
@@ -265,8 +268,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad9_kernel(const W9Args a) {
         if (xslot == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, SOD_LDS(xd + G9_RX * G9_XROWB), 16, ox + x_cadd, 0, 0, 0);   // the mirror rows
         xslot = (xslot + 1 == G9_NXC) ? 0 : xslot + 1;
         char* yd = smem + G9_XBYTES + ((t + G9_D) & 3) * G9_YTILE + wave * 4 * G9_YROWB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(yd), 16, oy0 + y_qadd, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(yd + 32 * G9_YROWB), 16, oy1 + y_qadd, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(yd), 16, y_live ? oy0 + y_qadd : SOD_OOB, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, SOD_LDS(yd + 32 * G9_YROWB), 16, y_live ? oy1 + y_qadd : SOD_OOB, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       b0 = tr_read2<0, 2048>(baddr[3]);       G9_WAIT_LGKM(4);  G9_MMA(af0, b1, 1, if (mine) G9_PIX2(prem, phw, pok))
@@ -336,6 +339,7 @@ __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(const W9Args a) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int q = qt * 128 + wr * 64 + i * 16 + fg * 4 + e;
+    if (q >= a.K) continue;                 // rows of the last q-tile beyond K (their slab entries are zeros)
     float* dst = a.dw + ((size_t)q * 9 + tap) * a.C + c;
     *dst += sum[e] * (a.qscale ? a.qscale[q] : 1.f);
   }
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(const W9Args a) {
 
 int w9_fill(const WgradArgs& a, W9Args& w) {
   w.nlev = a.nlev; w.dw = a.dw; w.qscale = a.qscale; w.N = a.N; w.C = a.C; w.K = a.K;
-  w.QT = a.K / 128; w.CT = a.C / 64;
+  w.QT = (a.K + 127) / 128; w.CT = a.C / 64;
   int t0 = 0;
   for (int l = 0; l < a.nlev; ++l) {
     const WLevel& s = a.lev[l];
@@ -362,10 +366,10 @@ int w9_fill(const WgradArgs& a, W9Args& w) {
 
 }  // namespace
 
-// 3x3, stride 1, pad 1, no dilation, same-size output; K a multiple of 128, C of 64; rows short enough for the X ring (W <= 190)
+// 3x3, stride 1, pad 1, no dilation, same-size output; K a multiple of 8 (>= 128), C of 64; rows short enough for the X ring (W <= 190)
 bool wgrad9_supported(const WgradArgs& a) {
   if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.dil != 1 || a.diag) return false;
-  if ((a.K & 127) || (a.C & 63) || a.K < 128 || a.C < 64) return false;
+  if ((a.K & 7) || (a.C & 63) || a.K < 128 || a.C < 64) return false;      // K: any multiple of 8 from 128 up (the last q-tile is masked)
   long long tot = 0;
   for (int l = 0; l < a.nlev; ++l) {
     const WLevel& s = a.lev[l];

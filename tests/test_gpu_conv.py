@@ -345,6 +345,8 @@ WGRAD9_CASES = [
     (1, 100, 168, 128, 128),    # res3 conv2 geometry: the widest rows of the step (W = 168: seven X chunks of reach)
     (2, 7, 190, 64, 128),       # the widest supported row, one c-tile
     (5, 6, 7, 192, 384),        # C = 3 x 64, K = 3 x 128
+    (2, 13, 21, 256, 720),      # RetinaNet cls_score: K = 9 x 80 = 720, the last q-tile holds 80 of its 128 rows
+    (1, 9, 11, 64, 136),        # 8 rows in the last q-tile
 ]
 
 
