@@ -72,8 +72,11 @@ __device__ __forceinline__ void w3_steps(W3State& st) {
     constexpr int younger = (W3_STEPS - 1 - S) < W3_DIST ? (W3_STEPS - 1 - S) : W3_DIST;
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger) : "memory");
     __builtin_amdgcn_sched_barrier(0);
-    st.acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.af[0][tap][kb], st.b[S % (W3_DIST + 1)], st.acc[0][j], 0, 0, 0);
-    st.acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.af[1][tap][kb], st.b[S % (W3_DIST + 1)], st.acc[1][j], 0, 0, 0);
+    // (the first MFMA of a pixel row starts from a constant zero: no accumulator clearing between tiles)
+    constexpr bool first = tap == 0 && kb == 0;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    st.acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.af[0][tap][kb], st.b[S % (W3_DIST + 1)], first ? zero : st.acc[0][j], 0, 0, 0);
+    st.acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.af[1][tap][kb], st.b[S % (W3_DIST + 1)], first ? zero : st.acc[1][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     w3_steps<MODE, S + 1>(st);
   }
@@ -160,10 +163,6 @@ __global__ __launch_bounds__(256, 1) void conv_ws3_kernel(const ConvArgs a, cons
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) st.rb[d][kb] += delta;
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < W3_TH; ++j) st.acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     w3_prime<MODE, 0>(st);
     w3_steps<MODE, 0>(st);
 
