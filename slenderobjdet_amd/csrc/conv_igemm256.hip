@@ -54,13 +54,21 @@ __device__ __forceinline__ void mma_half(f32x4_t (&acc)[8][4], const bf16x8_t (&
 // (Round 6 measured a deeper schedule - every unit re-requested one phase after its last read, four units in flight behind vmcnt(8) -
 // on the tower shape: forward 352.1 vs 352.8 us, data gradient 355.5 vs 356.8 us per launch, results bit-identical: no gain, not kept.
 // The same change is worth 2.7 % on conv_wgrad256.hip, which stages twice the bytes per MFMA.)
+// The scheduling barriers pin the phase's staging arithmetic (tap / channel-chunk division, validity selects: ~25 scalar and vector
+// instructions) BEHIND the first eight MFMAs: hipcc otherwise hoists it between the lgkmcnt wait and the first MFMA, where the matrix pipe
+// waits for it.  Results bit-identical; stand-alone no difference (380 us either way on the tower shape), in the step +0.35 %
+// (664.7 -> 667.0 img/s, three alternating pairs, round 6).
+#define SOD256_SB __builtin_amdgcn_sched_barrier(0);
 #define SOD256_PHASE(SA, SB, BFR, STAGE)                                  \
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                        \
   __builtin_amdgcn_s_barrier();                                           \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      \
+  SOD256_SB                                                               \
   __builtin_amdgcn_s_setprio(1);                                          \
   mma_half<SA, SB, 0>(acc, af, BFR);                                      \
+  SOD256_SB                                                               \
   STAGE;                                                                  \
+  SOD256_SB                                                               \
   mma_half<SA, SB, 1>(acc, af, BFR);                                      \
   __builtin_amdgcn_s_setprio(0);                                          \
   __builtin_amdgcn_s_barrier();
