@@ -156,9 +156,7 @@ __device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx
   // Per element only what depends on it: the mask, xhat, dgamma += d * xhat, dbeta += d.  The group sums are linear in those per-channel
   // sums - s1 = sum_e gamma[e] * dbeta[e], s2 = sum_e gamma[e] * dgamma[e] (a thread's 8 channels are one group, its pixels one image) -
   // and are formed once per thread after the loop (round 5: 15 -> 9 VALU operations per element of a pass that was not far from VALU-bound).
-  for (int p = p0 + prow; p < p1; p += rows_per_iter) {
-    const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)p * a.C);
-    const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)p * a.C);
+  auto accum = [&](const bf16x8_t& xv, const bf16x8_t& gv) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float xh = ((float)xv[e] - mean) * rstd;
@@ -166,6 +164,24 @@ __device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx
       if (a.relu && !(xh * gm[e] + bt[e] > 0.f)) d = 0.f;
       dg[e] += d * xh; db[e] += d;
     }
+  };
+  // Four rows per trip, their eight 16-byte loads requested before the first use (round 6: one row per trip left ~44 KB in flight per CU);
+  // rows are still accumulated in pixel order, so a block's sums are bit for bit those of the one-row loop.
+  int p = p0 + prow;
+  for (; p + 3 * rows_per_iter < p1; p += 4 * rows_per_iter) {
+    bf16x8_t xv[4], gv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xv[u] = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)(p + u * rows_per_iter) * a.C);
+      gv[u] = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)(p + u * rows_per_iter) * a.C);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) accum(xv[u], gv[u]);
+  }
+  for (; p < p1; p += rows_per_iter) {
+    const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)p * a.C);
+    const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)p * a.C);
+    accum(xv, gv);
   }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -220,9 +236,7 @@ __device__ __forceinline__ void gn_bwd_apply_body(const GnArgs& a, const int bx,
   const int p0 = bx * a.pix_per_block;
   int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
   const long long base = (long long)n * a.img_stride + c8 * 8;
-  for (int p = p0 + prow; p < p1; p += rows_per_iter) {
-    const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)p * a.C);
-    const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)p * a.C);
+  auto row = [&](const bf16x8_t& xv, const bf16x8_t& gv, int p) {
     bf16x8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -233,6 +247,21 @@ __device__ __forceinline__ void gn_bwd_apply_body(const GnArgs& a, const int bx,
       sx[e] += (float)o[e];       // the bias gradient is the sum of what the conv's wgrad/dgrad see (the stored bf16 values)
     }
     sod_store16(a.dx + base + (long long)p * a.C, o);
+  };
+  // two rows per trip, four loads in flight per thread (see gn_bwd_reduce_body); same values, same summation order
+  int p = p0 + prow;
+  for (; p + rows_per_iter < p1; p += 2 * rows_per_iter) {
+    const bf16x8_t xv0 = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)p * a.C);
+    const bf16x8_t gv0 = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)p * a.C);
+    const bf16x8_t xv1 = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)(p + rows_per_iter) * a.C);
+    const bf16x8_t gv1 = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)(p + rows_per_iter) * a.C);
+    row(xv0, gv0, p);
+    row(xv1, gv1, p + rows_per_iter);
+  }
+  if (p < p1) {
+    const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)p * a.C);
+    const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)p * a.C);
+    row(xv, gv, p);
   }
   if (a.dxsum) {
 #pragma unroll
@@ -812,7 +841,7 @@ static int gn_reverse_mask() {
   return v;
 }
 
-static int gn_fill(GnML& m, int nlev, const int* hw, int N, int C, int G, float eps, int relu, const long long* img_strides) {
+static int gn_fill(GnML& m, int nlev, const int* hw, int N, int C, int G, float eps, int relu, const long long* img_strides, int tot = 1024) {
   if (nlev <= 0 || nlev > GN_MAX_LEVELS || !hw) return SOD_EARG;
   m.nlev = nlev; m.N = N; m.C = C; m.G = G; m.cpg = C / G; m.relu = relu; m.eps = eps;
   int blk = 0;
@@ -823,7 +852,7 @@ static int gn_fill(GnML& m, int nlev, const int* hw, int N, int C, int G, float 
     L.HW = hw[l];
     L.img_stride = (img_strides && img_strides[l] > 0) ? img_strides[l] : (long long)hw[l] * C;
     // ~1024 / N blocks per level for the largest level, proportionally fewer for the small ones (>= 64 pixels per block)
-    int gx = 1024 / (N > 0 ? N : 1);
+    int gx = tot / (N > 0 ? N : 1);
     if (gx < 1) gx = 1;
     int ppb = (hw[0] + gx - 1) / gx;
     if (ppb < 64) ppb = 64;
@@ -926,8 +955,16 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
   }
   hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(float) * 2 * N * G * nlev, st);
   if (e != hipSuccess) return (int)e;
-  m.rev = (gn_reverse_mask() >> 1) & 1;
-  SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 18 * 256, st, m);
+  // The reduce pass ends every block with 2 C + 2 C / 8 float atomics on the same few lines: half as many blocks of twice the pixels for it
+  // (round 6, five tower levels at batch 16: 4096 / 2048 / 1024 / 512 blocks in all -> 309 / 223 / 216 / 204 us for the two passes).
+  {
+    static const int tot_r = getenv("SOD_GN_RBLOCKS") ? atoi(getenv("SOD_GN_RBLOCKS")) : 512;
+    GnML mr = m;
+    const int gxr = gn_fill(mr, nlev, hw, N, C, G, 0.f, relu, nullptr, tot_r);
+    if (gxr <= 0) return gxr ? gxr : SOD_EARG;
+    mr.rev = (gn_reverse_mask() >> 1) & 1;
+    SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gxr, N), dim3(256), sizeof(float) * 18 * 256, st, mr);
+  }
   m.rev = (gn_reverse_mask() >> 2) & 1;
   SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * 8 * 256 : 0, st, m);
   SOD_CHECK_LAUNCH();
