@@ -978,6 +978,9 @@ int dispatch_conv(const ConvArgs& a, hipStream_t st) {
       return rc;
     }
   }
+  // (Round 6 measured an 80(q) x 256(p) tile - one wave row of 5 x 4 MFMA blocks, BK = 32, three workgroups per CU - for the 80 class scores
+  // instead of 128 x 128 with 37.5 % of the q-tile empty: 195-204 us against 170 us on the P3 level, 664.1 vs 665.4 img/s on the step.  These
+  // convolutions are bound by the pixel operand's way into LDS, not by the matrix pipe; not kept.)
   if (a.Nout <= 16) {
     return generic ? launch_conv<MODE, true, 1, 4, 1, 4, OUT_F32>(a, st) : launch_conv<MODE, false, 1, 4, 1, 4, OUT_F32>(a, st);
   } else if (a.Nout <= 64) {
