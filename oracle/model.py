@@ -5,7 +5,10 @@ ResNet/FPN semantics of SURVEY.md Appendix C.9/C.10 (third-party source absent: 
 FCOSHead / targets / losses are pinned by tests/golden).  Also the ``cpu_baseline`` of bench.py.
 
 ``emulate_bf16=True`` rounds weights and every stored activation to bf16 at the same points where the HIP path stores
-bf16, so that end-to-end comparisons isolate kernel errors from the precision the product path computes in.
+bf16, so that end-to-end comparisons isolate kernel errors from the precision the product path computes in.  A SET of storage points
+instead of ``True`` rounds only those (tests/test_oracle_storage_ablation.py): ``"w"`` the compute copies of the weights, ``"act_bb"`` /
+``"act_head"`` the stored activations of backbone + FPN / of the head towers, ``"grad"`` the stored activation gradients, ``"input"`` the
+normalised image.
 """
 import torch
 import torch.nn.functional as F
@@ -30,6 +33,18 @@ class _RoundSTE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """bf16 rounding of the forward value only (a stored activation, or the bf16 compute copy of an fp32 master weight)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 class _RoundGrad(torch.autograd.Function):
@@ -75,7 +90,7 @@ class OracleFCOS:
         params, buffers, dcn, groups = {}, {}, {}, {}
         for name, m in model.named_modules():
             if isinstance(m, DeformConv):      # DeformConv / ModulatedDeformConv (detectron2): KRSC -> KCRS, optional FrozenBN
-                params[name + ".weight"] = m.weight.detach().float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(m.weight.requires_grad)
+                params[name + ".weight"] = m.weight.detach().float().cpu().permute(0, 3, 1, 2).clone(memory_format=torch.contiguous_format).requires_grad_(m.weight.requires_grad)
                 if m.bias is not None:
                     params[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(m.bias.requires_grad)
                 if m.frozen_bn:
@@ -85,7 +100,7 @@ class OracleFCOS:
             elif isinstance(m, HipConv2d):
                 if getattr(m, "groups", 1) > 1:
                     groups[name] = m.groups
-                w = m.weight.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
+                w = m.weight.detach().float().cpu().permute(0, 3, 1, 2).clone(memory_format=torch.contiguous_format)      # (a copy also for a CPU model's 1x1 weights)
                 params[name + ".weight"] = w.requires_grad_(m.weight.requires_grad)
                 if m.bias is not None:
                     params[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(m.bias.requires_grad)
@@ -120,8 +135,25 @@ class OracleFCOS:
         return self
 
     # ------------------------------------------------------------------ layers
-    def _act(self, x):
-        return _RoundSTE.apply(x) if self.emu else x
+    def _act(self, x, where="bb"):
+        e = self.emu
+        if e is True:
+            return _RoundSTE.apply(x)
+        if not e:
+            return x
+        if ("act_" + where) in e:
+            x = _RoundFwd.apply(x)
+        return _RoundGrad.apply(x) if "grad" in e else x
+
+    def _wt(self, w):
+        e = self.emu
+        if e is True:
+            return _RoundSTE.apply(w)
+        return _RoundFwd.apply(w) if (e and "w" in e) else w
+
+    @staticmethod
+    def _where(name):
+        return "head" if name.startswith("head.") else "bb"
 
     def _dcn(self, name, x, om, relu=False):
         """DeformConv / ModulatedDeformConv ``name`` on x with the offset conv's output ``om`` (first 18*G channels offsets, next 9*G mask
@@ -133,14 +165,15 @@ class OracleFCOS:
         if name + ".scale" in self.b:
             w = w * self.b[name + ".scale"].view(-1, 1, 1, 1)
             bias = self.b[name + ".shift"] + (bias * self.b[name + ".scale"] if bias is not None else 0)
-        if self.emu:
-            w = _RoundSTE.apply(w)
+        w = self._wt(w)
         g = d["dg"]
         mask = om[:, 18 * g:27 * g].sigmoid() if d["modulated"] else None
-        y = odc.deform_conv2d(x, om[:, :18 * g], w, bias, d["stride"], d["pad"], d["dil"], mask, g, sample_hook=self._act if self.emu else None)
+        wh = self._where(name)
+        y = odc.deform_conv2d(x, om[:, :18 * g], w, bias, d["stride"], d["pad"], d["dil"], mask, g,
+                              sample_hook=(lambda t: self._act(t, wh)) if self.emu else None)
         if relu:
             y = _relu_at(y, name)
-        return self._act(y)
+        return self._act(y, wh)
 
     def _conv(self, name, x, stride=1, pad=0, relu=False, res=None, out_f32=False):
         w = self.p[name + ".weight"]
@@ -148,14 +181,13 @@ class OracleFCOS:
         if name + ".scale" in self.b:      # FrozenBN folded the way the product path folds it
             w = w * self.b[name + ".scale"].view(-1, 1, 1, 1)
             bias = self.b[name + ".shift"] + (bias * self.b[name + ".scale"] if bias is not None else 0)
-        if self.emu:
-            w = _RoundSTE.apply(w)
+        w = self._wt(w)
         y = F.conv2d(x, w, bias, stride=stride, padding=pad, groups=self.c.get("groups", {}).get(name, 1))      # ResNeXt 3x3: grouped
         if res is not None:
             y = y + res
         if relu:
             y = _relu_at(y, name)
-        return y if out_f32 else self._act(y)      # offset / prediction convs keep fp32 rows on the product path
+        return y if out_f32 else self._act(y, self._where(name))      # offset / prediction convs keep fp32 rows on the product path
 
     def _bottom_up(self, x):
         c = self.c
@@ -205,7 +237,7 @@ class OracleFCOS:
             else:
                 y = self._conv(f"{prefix}.{i}.conv", x, 1, 1)
             y = F.group_norm(y, 32, self.p[f"{prefix}.{i}.gn.weight"], self.p[f"{prefix}.{i}.gn.bias"], 1e-5)
-            x = self._act(_relu_at(y, f"{prefix}.{i}.gn"))
+            x = self._act(_relu_at(y, f"{prefix}.{i}.gn"), "head")
         return x
 
     def _head(self, feats):
@@ -218,8 +250,7 @@ class OracleFCOS:
             ct, bt = self._tower("head.cls_tower", f), self._tower("head.bbox_tower", f)
             wc, bc = self.p["head.cls_pred.weight"], self.p["head.cls_pred.bias"]
             wb, bb = self.p["head.box_pred.weight"], self.p["head.box_pred.bias"]
-            if self.emu:
-                wc, wb = _RoundSTE.apply(wc), _RoundSTE.apply(wb)
+            wc, wb = self._wt(wc), self._wt(wb)
             co = F.conv2d(ct, wc[:kc], bc[:kc], padding=1)
             bo = F.conv2d(bt, wb[:5 if c["ctr_on_reg"] else 4], bb[:5 if c["ctr_on_reg"] else 4], padding=1)
             logits = co[:, :K]
@@ -242,7 +273,7 @@ class OracleFCOS:
         batch = torch.zeros(len(imgs), 3, mh, mw)
         for i, im in enumerate(imgs):
             batch[i, :, : im.shape[1], : im.shape[2]] = im
-        return _rb(batch, self.emu).to(next(iter(self.p.values())).dtype)
+        return _rb(batch, self.emu is True or (bool(self.emu) and "input" in self.emu)).to(next(iter(self.p.values())).dtype)
 
     def losses(self, batched_inputs, world=1):
         c = self.c

@@ -820,9 +820,13 @@ int gn_check(int N, int HW, int C, int G) {
   return SOD_OK;
 }
 
-int gn_grid(int HW, int N, int& ppb) {
-  // ~2048 blocks in total
-  int gx = 1024 / (N > 0 ? N : 1);
+int gn_grid(int HW, int N, int& ppb, int C = 256) {
+  // Every block ends with C float atomics on the same few lines, and they, not the reads, set the time of the short passes (round 6, 16 x
+  // 100 x 168 x 256: 1024 / 512 / 256 blocks in all -> 42.0 / 30.9 / 25.9 us; five levels in one launch 67.4 / 45.6 / 35.7 us), while a
+  // tensor of half a gigabyte wants 512 blocks to keep enough loads in flight (16 x 200 x 336 x 256: 103.6 / 96.1 / 106.8 us).
+  const long long bytes = (long long)N * HW * C * 2;
+  const int tot = bytes > (256ll << 20) ? 512 : 256;
+  int gx = tot / (N > 0 ? N : 1);
   if (gx < 1) gx = 1;
   ppb = (HW + gx - 1) / gx;
   if (ppb < 64) ppb = 64;
@@ -958,14 +962,13 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
   // The reduce pass ends every block with 2 C + 2 C / 8 float atomics on the same few lines: half as many blocks of twice the pixels for it
   // (round 6, five tower levels at batch 16: 4096 / 2048 / 1024 / 512 blocks in all -> 309 / 223 / 216 / 204 us for the two passes).
   {
-    static const int tot_r = getenv("SOD_GN_RBLOCKS") ? atoi(getenv("SOD_GN_RBLOCKS")) : 512;
     GnML mr = m;
-    const int gxr = gn_fill(mr, nlev, hw, N, C, G, 0.f, relu, nullptr, tot_r);
+    const int gxr = gn_fill(mr, nlev, hw, N, C, G, 0.f, relu, nullptr, 512);
     if (gxr <= 0) return gxr ? gxr : SOD_EARG;
     mr.rev = (gn_reverse_mask() >> 1) & 1;
     SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gxr, N), dim3(256), sizeof(float) * 18 * 256, st, mr);
   }
-  m.rev = (gn_reverse_mask() >> 2) & 1;
+  m.rev = (gn_reverse_mask() >> 2) & 1;      // (the apply pass keeps the 1024-block grid: 512 / 768 blocks measured 205 / 200 us against 191 for the two passes)
   SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * 8 * 256 : 0, st, m);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
@@ -1036,7 +1039,7 @@ extern "C" int sod_bias_grad_scaled(const void* dy, float* dbias, const float* s
   const int c8n = C / 8;
   if (c8n > 256) return SOD_EARG;
   int ppb;
-  const int gx = gn_grid(HW, N, ppb);
+  const int gx = gn_grid(HW, N, ppb, C);
   if (det_ws && (long long)gx * N * C * (long long)sizeof(float) > det_ws_bytes) return SOD_EARG;
   SOD_LAUNCH(channel_sum_kernel, dim3(gx, N), dim3(256), sizeof(float) * 8 * 256, (hipStream_t)stream, (const __bf16*)dy, dbias, HW, C, img_stride, ppb,
              det_ws, scale_num, scale_den, den_mul, den_min);
@@ -1049,13 +1052,20 @@ extern "C" int sod_bias_grad_ml(int nlev, const void* const* dy, float* dbias, i
   if (!dy || !dbias || !hw || nlev <= 0 || nlev > GN_MAX_LEVELS || N <= 0 || C <= 0 || (C & 7) || C > 2048) return SOD_EARG;
   ChanSumML m{};
   m.nlev = nlev; m.C = C;
-  int blk = 0;
+  int blk = 0, hw_max = 0;
   for (int l = 0; l < nlev; ++l) {
     if (!dy[l] || hw[l] <= 0) return SOD_EARG;
-    int ppb;
-    const int gx = gn_grid(hw[l], N, ppb);
-    m.dy[l] = (const __bf16*)dy[l]; m.HW[l] = hw[l]; m.ppb[l] = ppb; m.blk0[l] = blk;
-    blk += gx;
+    // pixels per block from the largest level for all of them: the small levels add a block or two per image, not sixteen
+    if (l == 0 || hw[l] > hw_max) { hw_max = hw[l]; }
+    m.dy[l] = (const __bf16*)dy[l]; m.HW[l] = hw[l]; m.blk0[l] = 0;
+  }
+  int ppb;
+  long long hw_all = 0;
+  for (int l = 0; l < nlev; ++l) hw_all += hw[l];
+  gn_grid(hw_max, N, ppb, (int)((long long)C * hw_all / hw_max));      // (sized by the bytes of all levels)
+  for (int l = 0; l < nlev; ++l) {
+    m.ppb[l] = ppb; m.blk0[l] = blk;
+    blk += (hw[l] + ppb - 1) / ppb;
   }
   SOD_LAUNCH(channel_sum_ml_kernel, dim3(blk, N), dim3(256), sizeof(float) * 8 * 256, (hipStream_t)stream, m, dbias);
   SOD_CHECK_LAUNCH();
