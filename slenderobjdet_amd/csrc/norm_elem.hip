@@ -139,12 +139,29 @@ __device__ __forceinline__ void gn_apply_body(const GnArgs& a, const int bx) {
   }
 }
 
+// The two backward passes stream their operands through wave-private LDS landing buffers (LDS-DMA: `buffer_load ... lds`, 16 bytes per lane,
+// GN_S stages of [x | dy] per wave) instead of through registers: the loads in flight cost no VGPRs, so the kernels stay below 64 registers
+// and ONE of their waves fits on a SIMD beside two waves of the 256 x 256 convolution kernels (2 x 224 of the 512 registers; 24 of the
+// 32 KB of LDS those leave) - the passes of one tower then run BESIDE the other tower's data gradient on the same CUs instead of between
+// its workgroups, and with three stages (6 KB per wave) in flight they stream there at a useful rate.  Every wave issues the same number
+// of vector-memory operations per trip (dead rows use the out-of-range offset: zero fill / dropped stores), so the counted waits hold.
+constexpr int GN_S = 3;
+constexpr int GN_RING = 4 * GN_S * 2048;      // bytes of LDS per block
+
+template <int N>
+__device__ __forceinline__ void gn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+typedef __attribute__((ext_vector_type(4))) unsigned int gn_u32x4_t;
+
 __device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx) {
-  extern __shared__ float lsum[];   // [256][18] per-thread partials: dgamma[8], dbeta[8], s1, s2
+  extern __shared__ __attribute__((aligned(16))) char gsm[];   // landing buffers, then [256][18] per-thread partials: dgamma[8], dbeta[8], s1, s2
+  float* lsum = reinterpret_cast<float*>(gsm);
   const int n = blockIdx.y + a.n0;
   const int c8n = a.C >> 3;
   const int rows_per_iter = 256 / c8n;
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int g = (c8 * 8) / a.cpg;
   const float mean = a.stats[((long long)n * a.G + g) * 2], rstd = a.stats[((long long)n * a.G + g) * 2 + 1];
   float gm[8], bt[8], dg[8], db[8];
@@ -152,37 +169,43 @@ __device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx
   for (int e = 0; e < 8; ++e) { gm[e] = a.gamma[c8 * 8 + e]; bt[e] = a.beta[c8 * 8 + e]; dg[e] = 0.f; db[e] = 0.f; }
   const int p0 = bx * a.pix_per_block;
   int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
-  const long long base = (long long)n * a.img_stride + c8 * 8;
+  const uint32_t img_bytes = (uint32_t)a.HW * (uint32_t)a.C * 2u;
+  auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x + (long long)n * a.img_stride), 0, img_bytes, 0x00020000);
+  auto gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.dy + (long long)n * a.img_stride), 0, img_bytes, 0x00020000);
+  char* ring = gsm + wave * (GN_S * 2048);
+  const uint32_t col = (uint32_t)c8 * 16u, rowb = (uint32_t)a.C * 2u;
+  auto issue = [&](int it, int slot) {
+    const int p = p0 + prow + it * rows_per_iter;
+    const uint32_t off = p < p1 ? (uint32_t)p * rowb + col : SOD_OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, SOD_LDS(ring + slot * 2048), 16, off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, SOD_LDS(ring + slot * 2048 + 1024), 16, off, 0, 0, 0);
+  };
   // Per element only what depends on it: the mask, xhat, dgamma += d * xhat, dbeta += d.  The group sums are linear in those per-channel
   // sums - s1 = sum_e gamma[e] * dbeta[e], s2 = sum_e gamma[e] * dgamma[e] (a thread's 8 channels are one group, its pixels one image) -
   // and are formed once per thread after the loop (round 5: 15 -> 9 VALU operations per element of a pass that was not far from VALU-bound).
-  auto accum = [&](const bf16x8_t& xv, const bf16x8_t& gv) {
+  const int nit = (p1 - p0 + rows_per_iter - 1) / rows_per_iter;      // block-uniform; rows are accumulated in pixel order
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float xh = ((float)xv[e] - mean) * rstd;
-      float d = (float)gv[e];
-      if (a.relu && !(xh * gm[e] + bt[e] > 0.f)) d = 0.f;
-      dg[e] += d * xh; db[e] += d;
+  for (int st = 0; st < GN_S - 1; ++st) issue(st, st);
+  int slot = 0;
+  for (int it = 0; it < nit; ++it) {
+    int nslot = slot + GN_S - 1; if (nslot >= GN_S) nslot -= GN_S;
+    issue(it + GN_S - 1, nslot);                 // (past the end: out-of-range requests, zero fill into a slot nobody reads)
+    gn_wait_vm<2 * (GN_S - 1)>();
+    const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(ring + slot * 2048 + lane * 16);
+    const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(ring + slot * 2048 + 1024 + lane * 16);
+    if (p0 + prow + it * rows_per_iter < p1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = ((float)xv[e] - mean) * rstd;
+        float d = (float)gv[e];
+        if (a.relu && !(xh * gm[e] + bt[e] > 0.f)) d = 0.f;
+        dg[e] += d * xh; db[e] += d;
+      }
     }
-  };
-  // Four rows per trip, their eight 16-byte loads requested before the first use (round 6: one row per trip left ~44 KB in flight per CU);
-  // rows are still accumulated in pixel order, so a block's sums are bit for bit those of the one-row loop.
-  int p = p0 + prow;
-  for (; p + 3 * rows_per_iter < p1; p += 4 * rows_per_iter) {
-    bf16x8_t xv[4], gv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      xv[u] = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)(p + u * rows_per_iter) * a.C);
-      gv[u] = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)(p + u * rows_per_iter) * a.C);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) accum(xv[u], gv[u]);
+    slot = (slot == GN_S - 1) ? 0 : slot + 1;
   }
-  for (; p < p1; p += rows_per_iter) {
-    const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)p * a.C);
-    const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)p * a.C);
-    accum(xv, gv);
-  }
+  gn_wait_vm<0>();
+  __syncthreads();                               // every wave is done with its landing buffers: the space becomes lsum
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1 += db[e] * gm[e]; s2 += dg[e] * gm[e]; }
@@ -222,11 +245,14 @@ __device__ __forceinline__ void gn_bwd_reduce_body(const GnArgs& a, const int bx
 
 
 __device__ __forceinline__ void gn_bwd_apply_body(const GnArgs& a, const int bx, const float inv_m) {
-  extern __shared__ float lsum[];   // [256][8] per-thread sums of dx when a.dxsum
+  extern __shared__ __attribute__((aligned(16))) char gsm[];   // landing buffers, then [256][8] per-thread sums of dx when a.dxsum
+  float* lsum = reinterpret_cast<float*>(gsm);
   const int n = blockIdx.y + a.n0;
   const int c8n = a.C >> 3;
   const int rows_per_iter = 256 / c8n;
   const int c8 = threadIdx.x % c8n, prow = threadIdx.x / c8n;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int g = (c8 * 8) / a.cpg;
   const float mean = a.stats[((long long)n * a.G + g) * 2], rstd = a.stats[((long long)n * a.G + g) * 2 + 1];
   const float m1 = a.red[((long long)n * a.G + g) * 2] * inv_m, m2 = a.red[((long long)n * a.G + g) * 2 + 1] * inv_m;
@@ -235,8 +261,32 @@ __device__ __forceinline__ void gn_bwd_apply_body(const GnArgs& a, const int bx,
   for (int e = 0; e < 8; ++e) { gm[e] = a.gamma[c8 * 8 + e]; bt[e] = a.beta[c8 * 8 + e]; sx[e] = 0.f; }
   const int p0 = bx * a.pix_per_block;
   int p1 = p0 + a.pix_per_block; if (p1 > a.HW) p1 = a.HW;
-  const long long base = (long long)n * a.img_stride + c8 * 8;
-  auto row = [&](const bf16x8_t& xv, const bf16x8_t& gv, int p) {
+  const uint32_t img_bytes = (uint32_t)a.HW * (uint32_t)a.C * 2u;
+  auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x + (long long)n * a.img_stride), 0, img_bytes, 0x00020000);
+  auto gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.dy + (long long)n * a.img_stride), 0, img_bytes, 0x00020000);
+  auto orr = __builtin_amdgcn_make_buffer_rsrc(a.dx + (long long)n * a.img_stride, 0, img_bytes, 0x00020000);
+  char* ring = gsm + wave * (GN_S * 2048);
+  const uint32_t col = (uint32_t)c8 * 16u, rowb = (uint32_t)a.C * 2u;
+  auto issue = [&](int it, int slot) {
+    const int p = p0 + prow + it * rows_per_iter;
+    const uint32_t off = p < p1 ? (uint32_t)p * rowb + col : SOD_OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, SOD_LDS(ring + slot * 2048), 16, off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, SOD_LDS(ring + slot * 2048 + 1024), 16, off, 0, 0, 0);
+  };
+  // trip `it`: requests of trip it + 2, wait for trip it's two loads, compute, ONE store (dropped for rows past the end).  Younger than
+  // trip it's loads at its wait: the loads of trips it + 1 and it + 2 (4) and the stores of trips it - 2 and it - 1 (fewer at the start).
+  const int nit = (p1 - p0 + rows_per_iter - 1) / rows_per_iter;
+#pragma unroll
+  for (int st = 0; st < GN_S - 1; ++st) issue(st, st);
+  int slot = 0;
+  for (int it = 0; it < nit; ++it) {
+    int nslot = slot + GN_S - 1; if (nslot >= GN_S) nslot -= GN_S;
+    issue(it + GN_S - 1, nslot);
+    if (it == 0) gn_wait_vm<2 * (GN_S - 1)>(); else if (it == 1) gn_wait_vm<2 * (GN_S - 1) + 1>(); else gn_wait_vm<3 * (GN_S - 1)>();
+    const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(ring + slot * 2048 + lane * 16);
+    const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(ring + slot * 2048 + 1024 + lane * 16);
+    const int p = p0 + prow + it * rows_per_iter;
+    const bool live = p < p1;
     bf16x8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -244,25 +294,13 @@ __device__ __forceinline__ void gn_bwd_apply_body(const GnArgs& a, const int bx,
       float d = (float)gv[e];
       if (a.relu && !(xh * gm[e] + bt[e] > 0.f)) d = 0.f;
       o[e] = (__bf16)(rstd * (d * gm[e] - m1 - xh * m2));
-      sx[e] += (float)o[e];       // the bias gradient is the sum of what the conv's wgrad/dgrad see (the stored bf16 values)
+      sx[e] += live ? (float)o[e] : 0.f;       // the bias gradient is the sum of what the conv's wgrad/dgrad see (the stored bf16 values)
     }
-    sod_store16(a.dx + base + (long long)p * a.C, o);
-  };
-  // two rows per trip, four loads in flight per thread (see gn_bwd_reduce_body); same values, same summation order
-  int p = p0 + prow;
-  for (; p + rows_per_iter < p1; p += 2 * rows_per_iter) {
-    const bf16x8_t xv0 = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)p * a.C);
-    const bf16x8_t gv0 = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)p * a.C);
-    const bf16x8_t xv1 = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)(p + rows_per_iter) * a.C);
-    const bf16x8_t gv1 = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)(p + rows_per_iter) * a.C);
-    row(xv0, gv0, p);
-    row(xv1, gv1, p + rows_per_iter);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(gn_u32x4_t, o), orr, live ? (uint32_t)p * rowb + col : SOD_OOB, 0, 0);
+    slot = (slot == GN_S - 1) ? 0 : slot + 1;
   }
-  if (p < p1) {
-    const bf16x8_t xv = *reinterpret_cast<const bf16x8_t*>(a.x + base + (long long)p * a.C);
-    const bf16x8_t gv = *reinterpret_cast<const bf16x8_t*>(a.dy + base + (long long)p * a.C);
-    row(xv, gv, p);
-  }
+  gn_wait_vm<0>();
+  __syncthreads();                               // every wave is done with its landing buffers: the space becomes lsum
   if (a.dxsum) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) lsum[threadIdx.x * 8 + e] = sx[e];
@@ -322,12 +360,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnML m) {
   const int l = gn_pick(m, a);
   gn_apply_body(a, gn_bx(m) - m.lev[l].blk0);
 }
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GnML m) {
+__global__ __launch_bounds__(256, 8) void gn_bwd_reduce_kernel(const GnML m) {
   GnArgs a;
   const int l = gn_pick(m, a);
   gn_bwd_reduce_body(a, gn_bx(m) - m.lev[l].blk0);
 }
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GnML m) {
+__global__ __launch_bounds__(256, 8) void gn_bwd_apply_kernel(const GnML m) {
   GnArgs a;
   const int l = gn_pick(m, a);
   gn_bwd_apply_body(a, gn_bx(m) - m.lev[l].blk0, m.lev[l].inv_m);
@@ -948,11 +986,11 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
     m.part_grp = det_ws;
     m.part_gb = det_ws + rows * (C / 8) * 2;
     m.part_dx = dxsum ? m.part_gb + rows * 2 * C : nullptr;
-    SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), sizeof(float) * 18 * 256, st, m);
+    SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gx, N), dim3(256), GN_RING, st, m);
     SOD_LAUNCH(gn_det_group_kernel, dim3((N * G + 255) / 256, nlev), dim3(256), 0, st, m, 0);
     SOD_LAUNCH(col_accumulate_kernel, dim3((C + 63) / 64), dim3(256), 0, st, m.part_gb, (int)rows, C, 2 * C, dgamma);
     SOD_LAUNCH(col_accumulate_kernel, dim3((C + 63) / 64), dim3(256), 0, st, m.part_gb + C, (int)rows, C, 2 * C, dbeta);
-    SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * 8 * 256 : 0, st, m);
+    SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), GN_RING, st, m);
     if (dxsum) SOD_LAUNCH(col_accumulate_kernel, dim3((C + 63) / 64), dim3(256), 0, st, m.part_dx, (int)rows, C, C, dxsum);
     SOD_CHECK_LAUNCH();
     return SOD_OK;
@@ -966,10 +1004,10 @@ extern "C" int sod_groupnorm_bwd_ml(int nlev, const void* const* dy, const void*
     const int gxr = gn_fill(mr, nlev, hw, N, C, G, 0.f, relu, nullptr, 512);
     if (gxr <= 0) return gxr ? gxr : SOD_EARG;
     mr.rev = (gn_reverse_mask() >> 1) & 1;
-    SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gxr, N), dim3(256), sizeof(float) * 18 * 256, st, mr);
+    SOD_LAUNCH(gn_bwd_reduce_kernel, dim3(gxr, N), dim3(256), GN_RING, st, mr);
   }
   m.rev = (gn_reverse_mask() >> 2) & 1;      // (the apply pass keeps the 1024-block grid: 512 / 768 blocks measured 205 / 200 us against 191 for the two passes)
-  SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), dxsum ? sizeof(float) * 8 * 256 : 0, st, m);
+  SOD_LAUNCH(gn_bwd_apply_kernel, dim3(gx, N), dim3(256), GN_RING, st, m);
   SOD_CHECK_LAUNCH();
   return SOD_OK;
 }
