@@ -90,7 +90,7 @@ class OracleFCOS:
         params, buffers, dcn, groups = {}, {}, {}, {}
         for name, m in model.named_modules():
             if isinstance(m, DeformConv):      # DeformConv / ModulatedDeformConv (detectron2): KRSC -> KCRS, optional FrozenBN
-                params[name + ".weight"] = m.weight.detach().float().cpu().permute(0, 3, 1, 2).clone(memory_format=torch.contiguous_format).requires_grad_(m.weight.requires_grad)
+                params[name + ".weight"] = m.weight.detach().float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(m.weight.requires_grad)
                 if m.bias is not None:
                     params[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(m.bias.requires_grad)
                 if m.frozen_bn:
@@ -100,7 +100,7 @@ class OracleFCOS:
             elif isinstance(m, HipConv2d):
                 if getattr(m, "groups", 1) > 1:
                     groups[name] = m.groups
-                w = m.weight.detach().float().cpu().permute(0, 3, 1, 2).clone(memory_format=torch.contiguous_format)      # (a copy also for a CPU model's 1x1 weights)
+                w = m.weight.detach().float().cpu().permute(0, 3, 1, 2).contiguous()      # (NO copy for a CPU model's 1x1 weights: oracles built from one CPU model share them - copy the model first)
                 params[name + ".weight"] = w.requires_grad_(m.weight.requires_grad)
                 if m.bias is not None:
                     params[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(m.bias.requires_grad)

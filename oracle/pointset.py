@@ -167,7 +167,7 @@ class OraclePointSetHead:
         p = {}
         for name, m in head.named_modules():
             if isinstance(m, (HipConv2d, DeformConv)):
-                p[name + ".weight"] = m.weight.detach().float().cpu().permute(0, 3, 1, 2).clone(memory_format=torch.contiguous_format).requires_grad_(True)
+                p[name + ".weight"] = m.weight.detach().float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
                 if m.bias is not None:
                     p[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(True)
             elif isinstance(m, HipGroupNorm):

@@ -228,7 +228,7 @@ class OracleRCNN(OracleRepPoints):
         params, buffers = {}, {}
         for name, m in model.named_modules():
             if isinstance(m, HipConv2d):
-                params[name + ".weight"] = m.weight.detach().float().cpu().permute(0, 3, 1, 2).clone(memory_format=torch.contiguous_format).requires_grad_(m.weight.requires_grad)
+                params[name + ".weight"] = m.weight.detach().float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(m.weight.requires_grad)
                 if m.bias is not None:
                     params[name + ".bias"] = m.bias.detach().float().cpu().clone().requires_grad_(m.bias.requires_grad)
                 if m.frozen_bn:

@@ -36,8 +36,11 @@ def test_which_bf16_storage_point_carries_the_drift():
     torch.manual_seed(7)
     model = build_model(cfg)
     pool = [synthetic_batch(2, 512, 512, 100 + i, device="cpu") for i in range(4)]
-    base, base_state = OracleFCOS.from_hip_model(model), {}
-    runs = {k: (OracleFCOS.from_hip_model(model, emulate_bf16=(v or False)), {}) for k, v in POINTS.items()}
+    import copy
+
+    # (from_hip_model copies nothing for a CPU model's 1x1 weights: every free-running oracle gets its own copy of the model)
+    base, base_state = OracleFCOS.from_hip_model(copy.deepcopy(model)), {}
+    runs = {k: (OracleFCOS.from_hip_model(copy.deepcopy(model), emulate_bf16=(v or False)), {}) for k, v in POINTS.items()}
     wf, wi, lr0 = cfg.SOLVER.WARMUP_FACTOR, cfg.SOLVER.WARMUP_ITERS, cfg.SOLVER.BASE_LR
     delta = {k: [] for k in POINTS}
     losses = []
