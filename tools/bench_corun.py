@@ -75,3 +75,21 @@ tch = timed(chains, 3)
 tc, tg, ts, t2 = timed(conv), timed(gn), timed(both_serial), timed(both_two_streams)
 print(f"4 x dgrad beside 4 x GroupNorm backward: {tch:.1f} us (4 x dgrad alone {4 * tc:.1f}, 4 x GN alone {4 * tg:.1f})", flush=True)
 print(f"tower dgrad {tc:.1f} us | GroupNorm backward {tg:.1f} us | one stream {ts:.1f} us | two streams {t2:.1f} us (hidden: {tc + tg - t2:.1f} us of {tg:.1f})", flush=True)
+
+# where in the window do the GroupNorm passes complete?  (events after every launch of the chains experiment)
+main = torch.cuda.current_stream(dev)
+torch.cuda.synchronize()
+t0 = torch.cuda.Event(enable_timing=True); t0.record()
+s2.wait_stream(main)
+ce, ge = [], []
+for _ in range(4):
+    conv()
+    e = torch.cuda.Event(enable_timing=True); e.record(); ce.append(e)
+with torch.cuda.stream(s2):
+    for _ in range(4):
+        gn()
+        e = torch.cuda.Event(enable_timing=True); e.record(s2); ge.append(e)
+main.wait_stream(s2)
+torch.cuda.synchronize()
+print("dgrad launches end at (us):", " ".join(f"{t0.elapsed_time(e) * 1e3:.0f}" for e in ce), "| GroupNorm backward launches end at:",
+      " ".join(f"{t0.elapsed_time(e) * 1e3:.0f}" for e in ge), flush=True)
