@@ -185,7 +185,10 @@ def test_fcos_regctr_loss(cuda, loss_type, norm_reg):
     _rel(out3, torch.stack([torch.tensor(5.0 / max(npos, 1)), reg_sum / sctr, ctr_sum / max(npos, 1)]), 2e-5, "finalize")
 
 
-@pytest.mark.parametrize("N,HW,C,G,relu", [(2, 77, 256, 32, True), (1, 1000, 256, 32, False), (3, 64, 64, 8, True), (2, 300, 128, 4, True)])
+@pytest.mark.parametrize("N,HW,C,G,relu", [(2, 77, 256, 32, True), (1, 1000, 256, 32, False), (3, 64, 64, 8, True), (2, 300, 128, 4, True),
+                                           # the backward passes' LDS landing buffers at their edges: fewer pixels than one trip covers, one row per
+                                           # wave (512 channels), one row per BLOCK (2048 channels), many blocks per image
+                                           (2, 5, 256, 32, True), (1, 333, 512, 32, True), (2, 40, 2048, 32, False), (2, 9000, 256, 32, True)])
 def test_groupnorm(cuda, N, HW, C, G, relu):
     from slenderobjdet_amd.layers import functional as HF
 
