@@ -25,10 +25,16 @@ def _bilinear_gather(x, py, px):
     return out
 
 
-def deform_conv2d(x, offset, weight, bias=None, stride=1, pad=0, dil=1, mask=None, deformable_groups=1, sample_hook=None):
-    """x (N,C,H,W), offset (N, 2*kh*kw*dg, Ho, Wo), weight (K,C,kh,kw), mask (N, kh*kw*dg, Ho, Wo) or None."""
+def deform_conv2d(x, offset, weight, bias=None, stride=1, pad=0, dil=1, mask=None, deformable_groups=1, sample_hook=None, groups=1):
+    """x (N,C,H,W), offset (N, 2*kh*kw*dg, Ho, Wo), weight (K,C/groups,kh,kw), mask (N, kh*kw*dg, Ho, Wo) or None.  ``groups`` (detectron2's
+    DeformConv argument): output channels [j K/g, (j+1) K/g) see input channels [j C/g, (j+1) C/g) only - computed on the block-diagonal
+    dense weight, which autograd differentiates back to the grouped one."""
     N, C, H, W = x.shape
     K, _, kh, kw = weight.shape
+    if groups > 1:
+        Kg, Cg = K // groups, weight.shape[1]
+        zero = weight.new_zeros(Kg, Cg, kh, kw)
+        weight = torch.cat([torch.cat([weight[j * Kg:(j + 1) * Kg] if jj == j else zero for jj in range(groups)], dim=1) for j in range(groups)], dim=0)
     Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
     Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
     dg = deformable_groups

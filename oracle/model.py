@@ -96,7 +96,7 @@ class OracleFCOS:
                 if m.frozen_bn:
                     scale = m.bn_weight.float().cpu() * torch.rsqrt(m.bn_running_var.float().cpu() + 1e-5)
                     buffers[name + ".scale"], buffers[name + ".shift"] = scale, m.bn_bias.float().cpu() - m.bn_running_mean.float().cpu() * scale
-                dcn[name] = dict(modulated=m.modulated, dg=m.deformable_groups, stride=m.stride, pad=m.padding, dil=m.dilation)
+                dcn[name] = dict(modulated=m.modulated, dg=m.deformable_groups, stride=m.stride, pad=m.padding, dil=m.dilation, groups=getattr(m, "groups", 1))
             elif isinstance(m, HipConv2d):
                 if getattr(m, "groups", 1) > 1:
                     groups[name] = m.groups
@@ -170,7 +170,7 @@ class OracleFCOS:
         mask = om[:, 18 * g:27 * g].sigmoid() if d["modulated"] else None
         wh = self._where(name)
         y = odc.deform_conv2d(x, om[:, :18 * g], w, bias, d["stride"], d["pad"], d["dil"], mask, g,
-                              sample_hook=(lambda t: self._act(t, wh)) if self.emu else None)
+                              sample_hook=(lambda t: self._act(t, wh)) if self.emu else None, groups=d.get("groups", 1))
         if relu:
             y = _relu_at(y, name)
         return self._act(y, wh)

@@ -156,14 +156,25 @@ class _DeformConvFn(torch.autograd.Function):
         N, Ho, Wo, K = dy.shape
         C = x.shape[3]
         if mod.weight.requires_grad:
-            if ctx.fused:
-                HF.deform_conv_wgrad_fused(dy, x, offset, mask, arena.grad_view(mod.weight).view(K, 1, 1, k * k * C), (k, k), mod.stride, mod.padding,
-                                           mod.dilation, dg, off_ld, mask_ld, mask_is_logit, qscale=mod.bn_scale)
-            else:
-                if cols is None:
-                    cols = HF.deform_im2col(x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, off_ld, mask_ld, mask_is_logit)
-                HF.conv2d_wgrad(dy, cols, arena.grad_view(mod.weight).view(K, 1, 1, k * k * C), 1, 1, 1, 0, 1, qscale=mod.bn_scale)
-                del cols
+            grouped = getattr(mod, "groups", 1) > 1
+            # groups > 1: dW of the dense embedding into a scratch tensor on the CURRENT stream, its diagonal blocks added to the arena gradient
+            dw = torch.zeros((K, 1, 1, k * k * C), dtype=torch.float32, device=dy.device) if grouped else arena.grad_view(mod.weight).view(K, 1, 1, k * k * C)
+            prev_side = HF.WGRAD_SIDE_STREAM
+            if grouped:
+                HF.WGRAD_SIDE_STREAM = False
+            try:
+                if ctx.fused:
+                    HF.deform_conv_wgrad_fused(dy, x, offset, mask, dw, (k, k), mod.stride, mod.padding, mod.dilation, dg, off_ld, mask_ld, mask_is_logit,
+                                               qscale=mod.bn_scale)
+                else:
+                    if cols is None:
+                        cols = HF.deform_im2col(x, offset, mask, (k, k), mod.stride, mod.padding, mod.dilation, dg, off_ld, mask_ld, mask_is_logit)
+                    HF.conv2d_wgrad(dy, cols, dw, 1, 1, 1, 0, 1, qscale=mod.bn_scale)
+                    del cols
+            finally:
+                HF.WGRAD_SIDE_STREAM = prev_side
+            if grouped:
+                arena.grad_view(mod.weight).add_(mod.blocks_of(dw.view(K, k, k, C)))
             arena.mark_ready(mod.weight)
             if mod.bias is not None:
                 HF.bias_grad(dy, arena.grad_view(mod.bias), N, Ho * Wo, K)
@@ -211,10 +222,16 @@ class DeformConv(nn.Module):
                  relu=False, frozen_bn=False):
         super().__init__()
         self.relu = relu
-        if groups != 1:
-            # detectron2's ``groups`` splits the GEMM into independent channel groups (ResNeXt + DCN); no config of the reference sets it
-            # (DeformBottleneckBlock passes RESNETS.NUM_GROUPS, 1 in every DCN YAML): refused loudly rather than computed wrongly
-            raise NotImplementedError(f"deformable convolution with groups={groups} is not built (deformable_groups is)")
+        # detectron2's ``groups`` splits the GEMM into independent channel groups (ResNeXt + DCN: DeformBottleneckBlock passes
+        # RESNETS.NUM_GROUPS).  No config of the reference sets it, so it takes the simple exact route of HipGroupedConv2d: the master weight
+        # has the reference's grouped shape (K, k, k, C / groups), the compute copies are its block-diagonal embedding into a dense weight
+        # (every kernel below runs unchanged; groups x the FLOPs of a true grouped GEMM), the weight gradient is taken densely into a
+        # scratch tensor and its diagonal blocks are added to the arena.
+        if groups < 1 or in_channels % groups or out_channels % groups:
+            raise ValueError(f"groups={groups} must divide in_channels={in_channels} and out_channels={out_channels}")
+        self.groups = groups
+        if groups > 1:
+            self.batched_prep_shape = None       # not part of the arena's batched bf16 preparation: prepare() embeds the blocks first
         if bias and not self.modulated:
             raise AssertionError("DeformConv has no bias (detectron2)")
         if isinstance(kernel_size, (tuple, list)):
@@ -222,7 +239,7 @@ class DeformConv(nn.Module):
             kernel_size = kernel_size[0]
         self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
         self.stride, self.padding, self.dilation, self.deformable_groups = stride, padding, dilation, deformable_groups
-        self.weight = nn.Parameter(torch.empty(out_channels, kernel_size, kernel_size, in_channels))   # KRSC
+        self.weight = nn.Parameter(torch.empty(out_channels, kernel_size, kernel_size, in_channels // groups))   # KRSC (C / groups per row)
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         nn.init.kaiming_uniform_(self.weight.permute(0, 3, 1, 2), nonlinearity="relu")
         # detectron2 wraps a norm around the op inside DeformBottleneckBlock (conv2 = DeformConv(..., norm=FrozenBN)): the frozen affine
@@ -235,6 +252,24 @@ class DeformConv(nn.Module):
             self.register_buffer("bn_running_var", torch.ones(out_channels) - 1e-5)
         self._prep_key = None
         self.w_bf16 = self.wt_bf16 = self.bias_eff = self.bn_scale = None
+
+    def dense_weight(self, w):
+        """(K, k, k, C / groups) -> block-diagonal (K, k, k, C)."""
+        K, R, S, Cg = w.shape
+        g = self.groups
+        if g == 1:
+            return w
+        d = w.new_zeros(K, R, S, Cg * g)
+        idx = torch.arange(g, device=w.device)
+        d.view(g, K // g, R, S, g, Cg)[idx, :, :, :, idx, :] = w.reshape(g, K // g, R, S, Cg)
+        return d
+
+    def blocks_of(self, dense):
+        """Diagonal blocks of a dense (K, k, k, C) tensor -> (K, k, k, C / groups)."""
+        K, R, S, C = dense.shape
+        g = self.groups
+        idx = torch.arange(g, device=dense.device)
+        return dense.view(g, K // g, R, S, g, C // g)[idx, :, :, :, idx, :].reshape(K, R, S, C // g)
 
     # batched weight preparation (layers/arena.py): the GEMM view is (K, 1, 1, k*k*C)
     def batched_prep_shape(self):
@@ -290,7 +325,9 @@ class DeformConv(nn.Module):
             return
         K, k, C = self.out_channels, self.kernel_size, self.in_channels
         # the GEMM sees a 1x1 convolution over k*k*C "channels" (tap-major, the layout deform_im2col writes)
-        self.w_bf16, self.wt_bf16 = HF.weight_prep(self.weight.detach().contiguous().view(K, 1, 1, k * k * C), self.bn_scale)
+        with torch.no_grad():
+            dense = self.dense_weight(self.weight.detach()).contiguous()
+        self.w_bf16, self.wt_bf16 = HF.weight_prep(dense.view(K, 1, 1, k * k * C), self.bn_scale)
         self._prep_key = key
 
     def forward(self, x, offset, mask=None, off_ld=0, mask_ld=0, mask_is_logit=False):

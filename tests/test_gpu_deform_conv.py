@@ -411,3 +411,47 @@ def test_deform_conv_f32_mode_vs_oracle(cuda, modulated, dg, stride):
     y = HF.deform_conv_fwd_f32(_nhwc(x).to(cuda), _nhwc(off).to(cuda), _nhwc(mask).to(cuda) if modulated else None,
                                w.permute(0, 2, 3, 1).contiguous().reshape(K, 9 * C).to(cuda), bias.to(cuda), (3, 3), stride, 1, 1, dg)
     assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("modulated,groups,dg,C,K", [(False, 2, 1, 64, 64), (True, 4, 2, 128, 64), (False, 32, 1, 256, 256)])
+def test_deform_conv_with_channel_groups_vs_oracle(cuda, modulated, groups, dg, C, K):
+    """detectron2's ``groups`` argument of DeformConv / ModulatedDeformConv (ResNeXt + DCN; round-5 review, missing #7): the module with the
+    reference's grouped weight shape (K, k, k, C / groups) against oracle/deform_conv.py's grouped form - output, dx, d offset, (d mask) and
+    the weight gradient in its grouped shape; the compute path is the block-diagonal embedding, so the 256-channel case also runs the
+    fused forward / weight-gradient / backward kernels."""
+    from slenderobjdet_amd.layers import functional as HF
+    from slenderobjdet_amd.layers.arena import ParamArena
+    from slenderobjdet_amd.layers.deform_conv import DeformConv, ModulatedDeformConv
+    from slenderobjdet_amd.layers.nn import attach_arena
+
+    torch.manual_seed(0)
+    m = (ModulatedDeformConv if modulated else DeformConv)(C, K, 3, stride=1, padding=1, groups=groups, deformable_groups=dg).to(cuda)
+    assert tuple(m.weight.shape) == (K, 3, 3, C // groups)
+    arena = ParamArena(m)
+    attach_arena(m, arena)
+    N, H, W = 2, 10, 12
+    x = onn.rb(torch.randn(N, C, H, W, generator=_g(0)))
+    off = (torch.rand(N, 18 * dg, H, W, generator=_g(2)) - 0.5) * 3.1 + 0.013
+    mask = torch.rand(N, 9 * dg, H, W, generator=_g(3)) if modulated else None
+    dy = onn.rb(torch.randn(N, K, H, W, generator=_g(4)))
+    xd = _nhwc(x).to(cuda).bfloat16().requires_grad_(True)
+    offd = _nhwc(off).to(cuda).requires_grad_(True)
+    maskd = _nhwc(mask).to(cuda).requires_grad_(True) if modulated else None
+    arena.zero_grad()
+    y = m(xd, offd, maskd)
+    y.backward(_nhwc(dy).to(cuda).bfloat16())
+    HF.wgrad_join()
+    torch.cuda.synchronize()
+    w = onn.rb(m.weight.detach().float().cpu().permute(0, 3, 1, 2)).requires_grad_(True)        # (K, C / groups, 3, 3)
+    xs, os_ = x.clone().requires_grad_(True), off.clone().requires_grad_(True)
+    ms = mask.clone().requires_grad_(True) if modulated else None
+    ref = odc.deform_conv2d(xs, os_, w, None, 1, 1, 1, ms, dg, groups=groups)
+    grads = torch.autograd.grad(ref, [xs, os_, w] + ([ms] if modulated else []), dy)
+    assert (y.float().cpu().permute(0, 3, 1, 2) - ref.detach()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
+    for got, want, name in ((xd.grad.float().cpu().permute(0, 3, 1, 2), grads[0], "dx"), (offd.grad.cpu().permute(0, 3, 1, 2), grads[1], "doffset")):
+        assert (got - want).abs().max().item() <= 3e-2 * want.abs().max().item(), name
+    if modulated:
+        assert (maskd.grad.cpu().permute(0, 3, 1, 2) - grads[3]).abs().max().item() <= 3e-2 * grads[3].abs().max().item()
+    dw = arena.grad_view(m.weight).detach().float().cpu().permute(0, 3, 1, 2)
+    assert tuple(dw.shape) == tuple(grads[2].shape)
+    assert (dw - grads[2]).abs().max().item() <= 2 ** -6 * grads[2].abs().max().item()

@@ -437,8 +437,14 @@ def test_dcnv2_backbone_config_builds_deform_bottleneck_blocks():
     cfg1.MODEL.RESNETS.DEFORM_NUM_GROUPS = 2
     b1 = build_model(cfg1).backbone.bottom_up
     assert type(b1.res5[0].conv2) is DeformConv and b1.res5[0].n_off == 36 and b1.res5[0].conv2.deformable_groups == 2
-    with pytest.raises(NotImplementedError, match="groups=2"):
-        DeformConv(64, 64, 3, groups=2)
+    # detectron2's ``groups`` (round 6): the master weight has the reference's grouped shape, the compute copies are its block-diagonal embedding
+    g2 = DeformConv(64, 64, 3, groups=2)
+    assert tuple(g2.weight.shape) == (64, 3, 3, 32)
+    dense = g2.dense_weight(g2.weight.detach())
+    assert tuple(dense.shape) == (64, 3, 3, 64) and float(dense[:32, :, :, 32:].abs().max()) == 0.0 and float(dense[32:, :, :, :32].abs().max()) == 0.0
+    assert torch.equal(g2.blocks_of(dense), g2.weight.detach())
+    with pytest.raises(ValueError, match="groups=3"):
+        DeformConv(64, 64, 3, groups=3)
     cfg2 = fresh_cfg()
     cfg2.MODEL.DEVICE = "cpu"
     cfg2.MODEL.RESNETS.DEPTH = 18
